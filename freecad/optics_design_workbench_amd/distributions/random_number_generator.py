@@ -1,0 +1,225 @@
+"""Tabulated inverse-CDF random variables (host side of ray generation).
+
+Mirror of the reference's `VectorRandomVariable` / `ScalarRandomVariable`
+interface (distributions/random_number_generator.py:54-769) restricted to what
+the device needs: the *numeric mode* tables.  The reference first tries a
+sympy analytic inverse CDF for 2 s and falls back to numeric mode
+(random_number_generator.py:72-119); every BASELINE source stores
+`RandomNumberGeneratorMode = numeric`.  Here numeric mode is the only mode:
+for the few densities the reference can invert analytically the samples differ
+from its by the table's discretisation error only (resolution 1e5 x 1e2).
+
+Table definition (random_number_generator.py:337-369, 372-464), reproduced
+bit for bit (tests/test_distributions.py against tests/golden/sampler_*.npz):
+  edges_v = linspace(l1, l2, res_v)           res forced odd
+  mid_v   = (edges_v[1:] + edges_v[:-1]) / 2
+  P       = density(mid_theta x mid_phi)      shape (nphi-1, ntheta-1)
+  cdf_theta[row] = [0, cumsum(P[row])] / total        one row per phi mid
+  cdf_phi        = [0, cumsum(P.sum(axis=-1))] / total
+and the draw: phi = interp(u_phi, cdf_phi, edges_phi); row = argmin|mid_phi -
+phi|; theta = interp(u_theta, cdf_theta[row], edges_theta).
+"""
+import numpy as np
+import sympy as sy
+
+
+def _odd(res):
+  res = int(round(float(res)))
+  return res + 1 if res % 2 == 0 else res
+
+
+class SamplerTables:
+  """what is uploaded to the device (odw_source_desc tables)"""
+
+  def __init__(self, first_edges, first_cdf, last_edges, last_cdf):
+    self.t_edges = np.ascontiguousarray(first_edges, dtype=np.float64)
+    self.t_cdf = np.ascontiguousarray(first_cdf, dtype=np.float64)      # (rows, knots)
+    self.phi_edges = np.ascontiguousarray(last_edges, dtype=np.float64)
+    self.phi_cdf = np.ascontiguousarray(last_cdf, dtype=np.float64)
+
+  @property
+  def n_rows(self):
+    return self.t_cdf.shape[0]
+
+  def draw(self, u_last, u_first):
+    """host evaluation of the device sampler (same arithmetic)"""
+    v1 = np.interp(u_last, self.phi_cdf, self.phi_edges)
+    if self.n_rows == 1:
+      return np.interp(u_first, self.t_cdf[0], self.t_edges), v1
+    mids = (self.phi_edges[1:] + self.phi_edges[:-1]) / 2
+    rows = np.abs(mids[None, :] - np.asarray(v1)[:, None]).argmin(axis=1)
+    v0 = np.empty_like(v1)
+    for r in np.unique(rows):
+      sel = rows == r
+      v0[sel] = np.interp(u_first[sel], self.t_cdf[r], self.t_edges)
+    return v0, v1
+
+
+class VectorRandomVariable:
+  '''
+  Vector valued random variable (two variables), numeric mode.
+  '''
+
+  def __init__(self, probabilityDensity, variableDomains={}, numericalResolutions={},
+               variableOrder=None, warnIfDiscretizationStepAbove=5e-2):
+    self._probabilityDensity = probabilityDensity
+    self._variableDomains = dict(variableDomains)
+    self._numericalResolutions = numericalResolutions
+    self._variableOrder = list(variableOrder) if variableOrder else None
+    self._constantsDict = {}
+    self._mode = 'not yet compiled'
+    self._tables = None
+
+  def mode(self):
+    return self._mode
+
+  def _resolution(self, name, nvars):
+    res = self._numericalResolutions
+    if not res:
+      res = 5 + int(1e6**(1 / nvars))
+    if isinstance(res, dict):
+      res = res.get(name)
+    return _odd(res)
+
+  def _prepare(self, **constants):
+    expr = sy.sympify(self._probabilityDensity)
+    used = {}
+    for name, val in constants.items():
+      if name in [str(s) for s in expr.free_symbols]:
+        expr = expr.subs(name, val)
+        used[name] = val
+    names = [str(s) for s in expr.free_symbols]
+    order = [n for n in (self._variableOrder or []) if n in names]
+    order += [n for n in names if n not in order]
+    order += [n for n in self._variableDomains if n not in order]
+    syms = []
+    for name in order:
+      l1, l2 = self._variableDomains.get(name, (-np.inf, np.inf))
+      if not np.isfinite(l1) or not np.isfinite(l2):
+        raise ValueError(f'numerical solution requires finite limits, but found limits '
+                         f'[{l1}, {l2}] for variable {name}')
+      kw = dict(nonnegative=True) if l1 >= 0 else dict(nonpositive=True) if l2 <= 0 else {}
+      s = sy.Symbol(name, real=True, **kw)
+      expr = expr.subs(sy.Symbol(name), s)
+      syms.append(s)
+    for s in expr.free_symbols:
+      if s not in syms:
+        raise ValueError(f'probabilty density expression {expr} has free symbol {s} '
+                         f'which is not in list of variables {syms}')
+    if expr.find(sy.DiracDelta):
+      raise ValueError('cannot use numeric mode for expression containing DiracDelta')
+    return expr, syms, order, used
+
+  def compile(self, **kwargs):
+    expr, syms, order, used = self._prepare(**kwargs)
+    if self._tables is not None and used == self._constantsDict:
+      return
+    if len(order) != 2:
+      raise ValueError(f'expected two variables, found {order}')
+    e0 = np.linspace(*self._variableDomains[order[0]], self._resolution(order[0], 2))
+    e1 = np.linspace(*self._variableDomains[order[1]], self._resolution(order[1], 2))
+    m0, m1 = (e0[1:] + e0[:-1]) / 2, (e1[1:] + e1[:-1]) / 2
+    lam = sy.lambdify(syms, expr, modules=['numpy', 'scipy'])
+    depends_on_last = syms[1] in expr.free_symbols
+
+    def row(v1):
+      p = lam(m0, np.full_like(m0, v1))
+      if not hasattr(p, 'shape') or np.shape(p) != m0.shape:
+        p = m0 * 0 + p
+      if (p < 0).any():
+        raise ValueError(f'found negative probability density, expression: {expr}')
+      return p
+
+    if depends_on_last:
+      cdf0 = np.empty((len(m1), len(e0)))
+      marg = np.empty(len(m1))
+      for i, v in enumerate(m1):
+        p = row(v)
+        marg[i] = p.sum()
+        cdf0[i, 0] = 0.0
+        np.cumsum(p, out=cdf0[i, 1:])
+        cdf0[i] /= cdf0[i, -1]
+    else:
+      p = row(m1[0])
+      marg = np.full(len(m1), p.sum())
+      c = np.concatenate([[0.0], np.cumsum(p)])
+      cdf0 = (c / c[-1])[None, :]
+    cdf1 = np.concatenate([[0.0], np.cumsum(marg)])
+    cdf1 = cdf1 / cdf1[-1]
+    self._tables = SamplerTables(e0, cdf0, e1, cdf1)
+    self._order = order
+    self._constantsDict = used
+    self._mode = 'numeric'
+
+  def tables(self):
+    if self._tables is None:
+      self.compile()
+    return self._tables
+
+  def draw(self, N=None, constants=None):
+    """host draw with numpy's global RNG, consuming uniforms in the
+    reference's order (random_number_generator.py:492-528): u_last, one
+    unused block, u_first, one unused block"""
+    if self._tables is None or (constants is not None and constants != self._constantsDict):
+      self.compile(**(constants or {}))
+    n = 1 if N is None else max(1, int(round(N)))
+    u_last = np.random.random_sample(n)
+    np.random.random_sample(n)
+    u_first = np.random.random_sample(n)
+    np.random.random_sample(n)
+    v0, v1 = self._tables.draw(u_last, u_first)
+    res = {self._order[0]: v0, self._order[1]: v1}
+    names = self._variableOrder or self._order
+    out = np.array([res[k] for k in names])
+    return out if N is not None else out[:, 0]
+
+
+class ScalarRandomVariable:
+  '''
+  Scalar valued random variable; only `findGrid` (fan mode ray placement,
+  random_number_generator.py:685-725 + points_by_density.py:25-38) is needed.
+  '''
+
+  def __init__(self, probabilityDensity, variableDomain, variable=None, numericalResolution=None):
+    self._probabilityDensity = probabilityDensity
+    self._domain = tuple(float(v) for v in variableDomain)
+    self._variable = variable
+    self._resolution = numericalResolution
+    self._expr = None
+
+  def compile(self, **constants):
+    expr = sy.sympify(self._probabilityDensity)
+    for name, val in constants.items():
+      if name in [str(s) for s in expr.free_symbols]:
+        expr = expr.subs(name, val)
+    free = [str(s) for s in expr.free_symbols]
+    var = self._variable or (free[0] if free else 'x')
+    if len(free) > 1 or (free and var not in free):
+      raise ValueError(f'expression "{expr}" seems to have more than one free variable after '
+                       f'substituting constants; did you pass all constants to .compile()?')
+    l1, l2 = self._domain
+    kw = dict(nonnegative=True) if l1 >= 0 else dict(nonpositive=True) if l2 <= 0 else {}
+    self._sym = sy.Symbol(var, real=True, **kw)
+    self._expr = expr.subs(sy.Symbol(var), self._sym)
+
+  def findGrid(self, N, constants=None):
+    if self._expr is None or constants:
+      self.compile(**(constants or {}))
+    l1, l2 = self._domain
+    if not np.isfinite(l1) or not np.isfinite(l2):
+      raise ValueError('variable domains must be finite for grid generation')
+    res = self._resolution if self._resolution else 5 + int(1e6)
+    X = np.linspace(l1, l2, _odd(res))
+    Y = sy.lambdify(self._sym, self._expr, modules=['numpy', 'scipy'])(X)
+    if not hasattr(Y, 'shape'):
+      Y = Y * np.ones(X.shape)
+    # cell-centred cumulative density -> equidistant quantiles
+    nodes = np.empty(len(X) + 1)
+    nodes[0] = X[0] - (X[1] - X[0]) / 2
+    nodes[1:-1] = (X[:-1] + X[1:]) / 2
+    nodes[-1] = X[-1] + (X[-1] - X[-2]) / 2
+    cum = np.concatenate([[0], np.cumsum(Y)])
+    cum = (cum - cum.min()) / (cum.max() - cum.min())
+    quantiles = np.linspace(0, 1, int(round(N)))[1:-1]
+    pts = np.concatenate([[X[0]], np.interp(quantiles, cum, nodes), [X[-1]]])
+    return pts[(pts >= X.min()) & (pts <= X.max())]

@@ -1,0 +1,260 @@
+"""One-time scene bake: document -> flat SoA tables for the device.
+
+This is the build's counterpart of the reference's per-run caches
+(simulation/raytracing_cache.py:43-114) and per-segment document scans
+(freecad_elements/find.py:59-141): everything static is resolved once --
+global placements (freecad_elements/common.py:36-125), the optical property
+table (freecad_elements/optical_group.py:29-96), the tracing sequence
+(freecad_elements/simulation_settings.py:158-196) and the limits of
+Ray.traceRay (freecad_elements/ray.py:46-73, 283-288).
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import geometry
+from .placement import Placement
+
+OPTICAL_TYPES = ['Mirror', 'Lens', 'Grating', 'Absorber', 'Vacuum']
+MAX_GROUPS = 64
+_SOURCE_PROXIES = ('PointSourceProxy',)
+_UNSUPPORTED_SOURCES = ('SurfaceSourceProxy', 'ReplaySourceProxy')
+
+
+# ---------------------------------------------------------------------------
+# find.* equivalents (freecad_elements/find.py)
+# ---------------------------------------------------------------------------
+def lightSources(doc):
+  return [o for o in doc.Objects
+          if o.TypeId == 'App::LinkGroupPython' and o.ProxyClass in _SOURCE_PROXIES + _UNSUPPORTED_SOURCES]
+
+
+def opticalObjects(doc):
+  return [o for o in doc.Objects
+          if o.TypeId == 'App::LinkGroupPython' and o.ProxyClass == 'OpticalGroupProxy']
+
+
+def simulationSettings(doc):
+  return [o for o in doc.Objects
+          if o.TypeId == 'Part::FeaturePython' and o.ProxyClass == 'SimulationSettingsProxy']
+
+
+def activeSimulationSettings(doc):
+  """find.py:116-141: the single Active settings object, else the first one"""
+  allset = simulationSettings(doc)
+  active = [s for s in allset if s._props.get('Active', True)]
+  if len(active) > 1:
+    raise ValueError('only one simulation settings object may have its "Active" property '
+                     'set to true, but the following objects are active: '
+                     + ', '.join(o.Name for o in active))
+  if active:
+    return active[0]
+  return allset[0] if allset else None
+
+
+def globalPlacements(doc, obj, _depth=0):
+  """every global placement `obj` appears under (containers only; App::Link
+  copies of whole groups are resolved by the group bake).  Follows
+  allPlacementsAndPaths (freecad_elements/common.py:36-109)."""
+  if _depth > 100:
+    raise RuntimeError('globalPlacements reached recursion depth 100')
+  own = obj.Placement if obj.hasProperty('Placement') else Placement.identity()
+  parents = doc.parents_of(obj)
+  if not parents:
+    return [own]
+  out = []
+  for p in parents:
+    for pp in globalPlacements(doc, p, _depth + 1):
+      out.append(pp * own)
+  return out
+
+
+def tracingSequence(settings):
+  """SimulationSettingsProxy.getTracingSequence (simulation_settings.py:158-196):
+  non-empty SequentialModeElements_NN lists in ascending order"""
+  if settings is None or not settings._props.get('SequentialMode', False):
+    return []
+  seq = []
+  for i in range(100):
+    lst = settings._props.get(f'SequentialModeElements_{i:02d}')
+    if lst:
+      seq.append(list(lst))
+  return seq
+
+
+# ---------------------------------------------------------------------------
+@dataclass
+class BakedScene:
+  prim_type: np.ndarray
+  prim_group: np.ndarray
+  prim_solid: np.ndarray
+  prim_flags: np.ndarray
+  prim_xform: np.ndarray      # (n,12) global -> local
+  prim_params: np.ndarray     # (n,4)
+  prim_cond_off: np.ndarray
+  cond_prim: np.ndarray
+  cond_inside: np.ndarray
+  group_type: np.ndarray
+  group_ior: np.ndarray
+  group_refl: np.ndarray
+  group_abslen: np.ndarray
+  group_record: np.ndarray
+  group_grating_type: np.ndarray
+  group_grating_lpm: np.ndarray
+  group_grating_dir: np.ndarray
+  group_grating_order: np.ndarray
+  seq_enabled: int
+  seq_mask: np.ndarray
+  ignore_mask: int
+  group_names: list = field(default_factory=list)
+  group_labels: list = field(default_factory=list)
+  prim_sources: list = field(default_factory=list)
+  prim_to_world: list = field(default_factory=list)
+
+  @property
+  def n_prims(self):
+    return int(self.prim_type.shape[0])
+
+  @property
+  def n_groups(self):
+    return int(self.group_type.shape[0])
+
+  @property
+  def n_faces(self):
+    return int(sum(bin(int(f) >> 8).count('1') for f in self.prim_flags))
+
+  def group_index(self, name_or_label):
+    for i, (n, l) in enumerate(zip(self.group_names, self.group_labels)):
+      if name_or_label in (n, l):
+        return i
+    raise KeyError(name_or_label)
+
+
+@dataclass
+class Limits:
+  max_ray_length: float = 1000.0
+  max_intersections: int = 100
+  dist_tol: float = 1e-2
+  power_tol: float = 1e-6
+
+
+def _abslen(v):
+  try:
+    return float(v)
+  except (TypeError, ValueError):
+    return float('inf')
+
+
+def bakeScene(doc, source=None):
+  """flat tables for all optical groups of `doc` as seen by `source`"""
+  groups = opticalObjects(doc)
+  if len(groups) > MAX_GROUPS:
+    raise geometry.UnsupportedGeometry(f'{len(groups)} optical groups (limit {MAX_GROUPS})')
+  prims = []
+  prim_group, prim_solid = [], []
+  solid_id = 0
+  for gi, g in enumerate(groups):
+    for gp in globalPlacements(doc, g):
+      # the group's children are placed relative to the group; gp already
+      # contains the group's own placement
+      for child in g._props.get('ElementList') or []:
+        for tree in geometry.solids_of(child):
+          flat = geometry.flatten(tree, gp)
+          for fp in flat:
+            fp.index = len(prims)
+            prims.append(fp)
+            prim_group.append(gi)
+            prim_solid.append(solid_id)
+          solid_id += 1
+  n = len(prims)
+  cond_off, cond_prim, cond_inside = [0], [], []
+  for fp in prims:
+    for other, inside in fp.conds:
+      cond_prim.append(other.index)
+      cond_inside.append(1 if inside else 0)
+    cond_off.append(len(cond_prim))
+
+  def col(key, default, dtype=np.float64):
+    return np.array([g._props.get(key, default) for g in groups], dtype=dtype)
+
+  types = []
+  for g in groups:
+    t = g._props.get('OpticalType', 'Mirror')
+    types.append(OPTICAL_TYPES.index(t) if isinstance(t, str) else int(t))
+  gt = []
+  for g in groups:
+    t = g._props.get('GratingType', 'Reflection')
+    gt.append(['Reflection', 'Transmission'].index(t) if isinstance(t, str) else int(t))
+  gdir = np.array([np.asarray(g._props.get('GratingLinesOrientation', (0, 0, 1)), dtype=np.float64)
+                   for g in groups], dtype=np.float64).reshape(len(groups), 3)
+
+  settings = activeSimulationSettings(doc)
+  seq = tracingSequence(settings)
+  seq_mask = []
+  for step in seq:
+    m = 0
+    for o in step:
+      if o in groups:
+        m |= 1 << groups.index(o)
+    seq_mask.append(m)
+  ignore = 0
+  if source is not None:
+    for o in source._props.get('IgnoredOpticalElements') or []:
+      if o in groups:
+        ignore |= 1 << groups.index(o)
+
+  return BakedScene(
+      prim_type=np.array([p.kind for p in prims], dtype=np.int32),
+      prim_group=np.array(prim_group, dtype=np.int32),
+      prim_solid=np.array(prim_solid, dtype=np.int32),
+      prim_flags=np.array([(1 if p.flip else 0) | (p.facemask << 8) for p in prims], dtype=np.int32),
+      prim_xform=np.array([p.to_world.inverse().rows12() for p in prims], dtype=np.float64).reshape(n, 12),
+      prim_params=np.array([p.params for p in prims], dtype=np.float64).reshape(n, 4),
+      prim_cond_off=np.array(cond_off, dtype=np.int32),
+      cond_prim=np.array(cond_prim, dtype=np.int32),
+      cond_inside=np.array(cond_inside, dtype=np.int32),
+      group_type=np.array(types, dtype=np.int32),
+      group_ior=col('RefractiveIndex', 2.0),
+      group_refl=col('Reflectivity', 1.0),
+      group_abslen=np.array([_abslen(g._props.get('AbsorptionLength', 'inf')) for g in groups]),
+      group_record=np.array([1 if g._props.get('RecordHits', False) else 0 for g in groups], dtype=np.int32),
+      group_grating_type=np.array(gt, dtype=np.int32),
+      group_grating_lpm=col('GratingLinesPerMillimeter', 1000.0),
+      group_grating_dir=gdir,
+      group_grating_order=col('GratingDiffractionOrder', 1, dtype=np.int32),
+      seq_enabled=1 if (settings is not None and settings._props.get('SequentialMode', False)) else 0,
+      seq_mask=np.array(seq_mask, dtype=np.uint64),
+      ignore_mask=ignore,
+      group_names=[g.Name for g in groups],
+      group_labels=[g._props.get('Label', g.Name) for g in groups],
+      prim_sources=[p.source for p in prims],
+      prim_to_world=[p.to_world for p in prims],
+  )
+
+
+def bakeLimits(doc, source=None, maxRayLength=None, maxIntersections=None, powerTol=1e-6,
+               distTol=None):
+  """Ray.traceRay argument resolution (ray.py:46-73) and _getDistTol
+  (ray.py:283-288)"""
+  settings = activeSimulationSettings(doc)
+  ray_scale = float(source._props.get('MaxRayLengthScale', 1)) if source is not None else 1.0
+  int_scale = float(source._props.get('MaxIntersectionsScale', 1)) if source is not None else 1.0
+  if settings is not None:
+    if maxRayLength is None:
+      maxRayLength = ray_scale * float(settings._props.get('MaxRayLength', 1000))
+    if maxIntersections is None:
+      maxIntersections = int_scale * float(settings._props.get('MaxIntersections', 100))
+  else:
+    if maxRayLength is None:
+      maxRayLength = 1000 * ray_scale
+    if maxIntersections is None:
+      maxIntersections = 100 * int_scale
+  if distTol is None:
+    distTol = 1e-2
+    if settings is not None:
+      distTol = float(settings._props.get('DistanceTolerance', '1e-6'))
+  # `numIntersections >= maxIntersections` with a float limit: the loop runs
+  # ceil(maxIntersections) times
+  return Limits(max_ray_length=float(maxRayLength),
+                max_intersections=int(np.ceil(maxIntersections)),
+                dist_tol=max(float(distTol), 1e-6), power_tol=float(powerTol))

@@ -1,0 +1,225 @@
+"""FCStd-lite: read a FreeCAD document without FreeCAD.
+
+An .FCStd file is a zip; `Document.xml` lists every document object with its
+typed properties.  This module parses exactly the property kinds the hot path
+needs: parametric Part primitives, booleans, App::Link, Draft
+link arrays, App::LinkGroupPython optical groups / light sources and the
+simulation settings object.  BRep payloads (`*.brp`) are never read: the
+geometry is rebuilt from the parametric features, which is what makes the GPU
+box (no FreeCAD) self-sufficient.
+
+It mirrors what the reference reaches through the FreeCAD API
+(`obj.Placement`, `obj.Radius`, `group.ElementList`, `obj.Proxy` class names;
+freecad_elements/find.py:59-141) -- objects expose their properties as
+attributes, and setting an attribute marks the document dirty so the scene is
+re-baked before the next simulation (jupyter_utils/freecad_document.py
+property round trips).
+"""
+import base64
+import json
+import struct
+import xml.etree.ElementTree as ET
+import zipfile
+
+import numpy as np
+
+from .placement import Placement
+
+
+class DocumentObject:
+  """One FreeCAD document object: `Name`, `TypeId`, properties as attributes."""
+
+  def __init__(self, document, name, type_id):
+    object.__setattr__(self, '_doc', document)
+    object.__setattr__(self, 'Name', name)
+    object.__setattr__(self, 'TypeId', type_id)
+    object.__setattr__(self, '_props', {})
+    object.__setattr__(self, '_types', {})
+
+  def __getattr__(self, key):
+    props = object.__getattribute__(self, '_props')
+    if key in props:
+      return props[key]
+    raise AttributeError(f'{self.Name} ({self.TypeId}) has no property {key!r}')
+
+  def __setattr__(self, key, value):
+    self._props[key] = value
+    self._doc._touch()
+
+  def hasProperty(self, key):
+    return key in self._props
+
+  @property
+  def PropertiesList(self):
+    return sorted(self._props)
+
+  @property
+  def ProxyClass(self):
+    p = self._props.get('Proxy')
+    return p.get('class') if isinstance(p, dict) else None
+
+  @property
+  def ProxyModule(self):
+    p = self._props.get('Proxy')
+    return p.get('module') if isinstance(p, dict) else None
+
+  def isDerivedFrom(self, type_id):
+    return self.TypeId == type_id or self.TypeId.startswith(type_id)
+
+  def __repr__(self):
+    return f'<{self.TypeId} {self.Name} ({self._props.get("Label", "")})>'
+
+
+def _parse_enum(prop):
+  integer = prop.find('Integer')
+  idx = int(integer.attrib['value'])
+  custom = prop.find('CustomEnumList')
+  if custom is not None:
+    names = [e.attrib['value'] for e in custom.findall('Enum')]
+    if 0 <= idx < len(names):
+      return names[idx]
+  return idx
+
+
+def _parse_property(prop, zf):
+  ptype = prop.attrib['type'].replace('App::Property', '')
+  child = next(iter(prop), None)
+  if child is None:
+    return None
+  tag = child.tag
+  if ptype == 'Enumeration':
+    return _parse_enum(prop)
+  if tag == 'Float':
+    return float(child.attrib['value'])
+  if tag == 'Integer':
+    return int(child.attrib['value'])
+  if tag == 'Bool':
+    return child.attrib['value'].lower() == 'true'
+  if tag == 'String':
+    return child.attrib['value']
+  if tag == 'PropertyPlacement':
+    a = child.attrib
+    return Placement(base=(float(a['Px']), float(a['Py']), float(a['Pz'])),
+                     quat=(float(a['Q0']), float(a['Q1']), float(a['Q2']), float(a['Q3'])))
+  if tag == 'PropertyVector':
+    a = child.attrib
+    return np.array([float(a['valueX']), float(a['valueY']), float(a['valueZ'])])
+  if tag == 'Link':
+    return child.attrib.get('value') or None
+  if tag == 'LinkList':
+    return [l.attrib['value'] for l in child.findall('Link')]
+  if tag == 'XLink':
+    return child.attrib.get('name') or None
+  if tag == 'LinkSub':
+    return child.attrib.get('value') or None
+  if tag == 'Python':
+    out = dict(module=child.attrib.get('module'), **{'class': child.attrib.get('class')})
+    raw = child.attrib.get('value', '')
+    try:
+      if child.attrib.get('encoded') == 'yes':
+        raw = base64.b64decode(raw).decode()
+      out['state'] = json.loads(raw) if raw else {}
+    except Exception:
+      out['state'] = {}
+    return out
+  if tag == 'PlacementList':
+    fname = child.attrib.get('file')
+    if not fname or zf is None or fname not in zf.namelist():
+      return []
+    data = zf.read(fname)
+    (count,) = struct.unpack_from('<I', data, 0)
+    vals = np.frombuffer(data, dtype='<f8', count=count * 7, offset=4).reshape(count, 7)
+    return [Placement(base=v[:3], quat=v[3:]) for v in vals]
+  if tag == 'BoolList':
+    return [c == '1' for c in child.attrib.get('value', '')]
+  return None
+
+
+class Document:
+  """The parsed document: `doc.Objects`, `doc.getObject(name)`, `doc.<Name>`."""
+
+  def __init__(self, path=None):
+    self.FileName = path
+    self.Objects = []
+    self._by_name = {}
+    self._revision = 0
+    if path is not None:
+      self._load(path)
+
+  # -- loading ------------------------------------------------------------
+  def _load(self, path):
+    with zipfile.ZipFile(path) as zf:
+      root = ET.fromstring(zf.read('Document.xml'))
+      self.ProgramVersion = root.attrib.get('ProgramVersion', '')
+      for o in root.find('Objects').findall('Object'):
+        obj = DocumentObject(self, o.attrib['name'], o.attrib['type'])
+        self.Objects.append(obj)
+        self._by_name[obj.Name] = obj
+      for o in root.find('ObjectData').findall('Object'):
+        obj = self._by_name.get(o.attrib['name'])
+        props = o.find('Properties')
+        if obj is None or props is None:
+          continue
+        for p in props.findall('Property'):
+          try:
+            val = _parse_property(p, zf)
+          except Exception:
+            val = None
+          obj._props[p.attrib['name']] = val
+          obj._types[p.attrib['name']] = p.attrib['type']
+    # resolve link names to objects
+    for obj in self.Objects:
+      for k, v in list(obj._props.items()):
+        t = obj._types.get(k, '')
+        if t in ('App::PropertyLink', 'App::PropertyXLink', 'App::PropertyLinkGlobal'):
+          obj._props[k] = self._by_name.get(v) if isinstance(v, str) else None
+        elif t in ('App::PropertyLinkList', 'App::PropertyLinkListGlobal'):
+          obj._props[k] = [self._by_name[n] for n in (v or []) if n in self._by_name]
+    self._revision = 0
+
+  # -- API ----------------------------------------------------------------
+  def _touch(self):
+    self._revision += 1
+
+  def getObject(self, name):
+    return self._by_name.get(name)
+
+  def getObjectsByLabel(self, label):
+    return [o for o in self.Objects if o._props.get('Label') == label]
+
+  def addObject(self, type_id, name, **props):
+    base, i = name, 0
+    while name in self._by_name:
+      i += 1
+      name = f'{base}{i:03d}'
+    obj = DocumentObject(self, name, type_id)
+    obj._props.update(dict(Label=name, Placement=Placement.identity()))
+    obj._props.update(props)
+    self.Objects.append(obj)
+    self._by_name[name] = obj
+    self._touch()
+    return obj
+
+  def __getattr__(self, key):
+    by_name = self.__dict__.get('_by_name', {})
+    if key in by_name:
+      return by_name[key]
+    for o in self.__dict__.get('Objects', []):
+      if o._props.get('Label') == key:
+        return o
+    raise AttributeError(key)
+
+  def parents_of(self, obj):
+    """objects that hold `obj` as a child (Group / ElementList containers)"""
+    res = []
+    for o in self.Objects:
+      for key in ('Group', 'ElementList'):
+        lst = o._props.get(key)
+        if isinstance(lst, list) and any(c is obj for c in lst):
+          res.append(o)
+          break
+    return res
+
+
+def open_fcstd(path):
+  return Document(path)

@@ -1,0 +1,267 @@
+"""Parametric solids of a FreeCAD document as CSG trees over analytic primitives.
+
+The reference intersects rays with the *analytic* trimmed surfaces FreeCAD's
+`Part` module exposes (`cachedShells/cachedFaces/cachedSurface`,
+simulation/raytracing_cache.py:92-111, used at freecad_elements/ray.py:345-411).
+Without FreeCAD the same faces are rebuilt from the parametric features:
+every face of a boolean result is a face of one operand restricted to the
+inside (Common), outside (Fuse, Cut base) or inside-with-flipped-normal (Cut
+tool) of the other operands.
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from .placement import Placement
+
+BOX, SPHERE, CYLINDER, CONE, TORUS = range(5)
+KIND_NAMES = ['box', 'sphere', 'cylinder', 'cone', 'torus']
+N_FACES = {BOX: 6, SPHERE: 1, CYLINDER: 3, CONE: 3, TORUS: 1}
+
+
+class UnsupportedGeometry(ValueError):
+  """scene feature that needs FreeCAD/OpenCASCADE to evaluate (BRep import,
+  partial revolutions, free-form surfaces)"""
+
+
+@dataclass
+class Node:
+  op: str                       # 'prim' | 'common' | 'cut' | 'fuse'
+  placement: Placement = field(default_factory=Placement.identity)
+  kind: int = -1
+  params: tuple = ()
+  children: list = field(default_factory=list)
+  source: str = ''              # document object name
+
+
+def _close(a, b, tol=1e-9):
+  return abs(float(a) - float(b)) <= tol
+
+
+def _primitive_of(obj):
+  t = obj.TypeId
+  if t == 'Part::Box':
+    return Node('prim', kind=BOX, params=(obj.Length, obj.Width, obj.Height, 0.0), source=obj.Name)
+  if t == 'Part::Sphere':
+    if not (_close(obj.Angle1, -90) and _close(obj.Angle2, 90) and _close(obj.Angle3, 360)):
+      raise UnsupportedGeometry(f'{obj.Name}: partial spheres need FreeCAD')
+    return Node('prim', kind=SPHERE, params=(obj.Radius, 0.0, 0.0, 0.0), source=obj.Name)
+  if t == 'Part::Cylinder':
+    if not _close(obj.Angle, 360):
+      raise UnsupportedGeometry(f'{obj.Name}: cylinder segments need FreeCAD')
+    return Node('prim', kind=CYLINDER, params=(obj.Radius, obj.Height, 0.0, 0.0), source=obj.Name)
+  if t == 'Part::Cone':
+    if not _close(obj.Angle, 360):
+      raise UnsupportedGeometry(f'{obj.Name}: cone segments need FreeCAD')
+    return Node('prim', kind=CONE, params=(obj.Radius1, obj.Radius2, obj.Height, 0.0), source=obj.Name)
+  if t == 'Part::Torus':
+    if not (_close(obj.Angle1, -180) and _close(obj.Angle2, 180) and _close(obj.Angle3, 360)):
+      raise UnsupportedGeometry(f'{obj.Name}: partial tori need FreeCAD')
+    return Node('prim', kind=TORUS, params=(obj.Radius1, obj.Radius2, 0.0, 0.0), source=obj.Name)
+  return None
+
+
+def _moved(nodes, placement):
+  out = []
+  for n in nodes:
+    out.append(Node(n.op, placement * n.placement, n.kind, n.params, n.children, n.source))
+  return out
+
+
+def _is_draft_array(obj):
+  return obj.ProxyClass == 'Array' and (obj.ProxyModule or '').startswith('draftobjects')
+
+
+def solids_of(obj, with_own_placement=True, _depth=0):
+  """-> list of CSG trees (one per shell) of `obj`, in the coordinates of
+  obj's container.  `with_own_placement=False` drops obj.Placement (an
+  App::Link with LinkTransform=false replaces it by its own)."""
+  if _depth > 50:
+    raise UnsupportedGeometry(f'{obj.Name}: link recursion')
+  own = obj.Placement if obj.hasProperty('Placement') and with_own_placement else Placement.identity()
+  t = obj.TypeId
+
+  prim = _primitive_of(obj)
+  if prim is not None:
+    return _moved([prim], own)
+
+  def one(child):
+    s = solids_of(child, _depth=_depth + 1)
+    if len(s) != 1:
+      raise UnsupportedGeometry(f'{obj.Name}: boolean operand {child.Name} is not a single solid')
+    return s[0]
+
+  if t in ('Part::MultiCommon', 'Part::MultiFuse'):
+    kids = [one(c) for c in obj.Shapes]
+    return _moved([Node('common' if t == 'Part::MultiCommon' else 'fuse', children=kids, source=obj.Name)], own)
+  if t in ('Part::Common', 'Part::Fuse', 'Part::Cut'):
+    op = {'Part::Common': 'common', 'Part::Fuse': 'fuse', 'Part::Cut': 'cut'}[t]
+    return _moved([Node(op, children=[one(obj.Base), one(obj.Tool)], source=obj.Name)], own)
+
+  if _is_draft_array(obj) or (t.startswith('App::Link') and not t.startswith('App::LinkGroup')):
+    target = obj.Base if _is_draft_array(obj) else obj.LinkedObject
+    if target is None:
+      return []
+    link_transform = bool(obj._props.get('LinkTransform', False))
+    base = solids_of(target, with_own_placement=link_transform, _depth=_depth + 1)
+    count = int(obj._props.get('ElementCount', 0) or 0)
+    plist = obj._props.get('PlacementList') or []
+    if _is_draft_array(obj):
+      count = int(obj._props.get('Count', len(plist)) or len(plist))
+      if not bool((obj._props.get('Proxy') or {}).get('state', {}).get('use_link', True)):
+        base = solids_of(target, _depth=_depth + 1)
+    if count > 0:
+      if len(plist) < count:
+        raise UnsupportedGeometry(f'{obj.Name}: array without stored PlacementList')
+      out = []
+      for pl in plist[:count]:
+        out.extend(_moved(base, pl))
+      return _moved(out, own)
+    return _moved(base, own)
+
+  if t.startswith('App::LinkGroup') or t in ('App::Part', 'App::DocumentObjectGroup', 'Part::Compound'):
+    key = 'ElementList' if t.startswith('App::LinkGroup') else ('Links' if t == 'Part::Compound' else 'Group')
+    out = []
+    for c in obj._props.get(key) or []:
+      out.extend(solids_of(c, _depth=_depth + 1))
+    return _moved(out, own)
+
+  if t in ('Part::Feature', 'Part::FeaturePython') or t.startswith('PartDesign') or t.startswith('Sketcher'):
+    raise UnsupportedGeometry(
+        f'{obj.Name} ({t}): only a BRep payload is stored; baking it needs FreeCAD '
+        f'(tessellation fallback, SURVEY 8f N4)')
+  return []
+
+
+# ---------------------------------------------------------------------------
+# flattening a CSG tree into primitives with trimming conditions
+# ---------------------------------------------------------------------------
+@dataclass
+class FlatPrim:
+  kind: int
+  params: tuple
+  to_world: Placement
+  flip: bool
+  conds: list            # [(FlatPrim, want_inside)]
+  facemask: int
+  source: str
+  index: int = -1
+
+
+def _leaves(node, acc, out):
+  pl = acc * node.placement
+  if node.op == 'prim':
+    fp = FlatPrim(node.kind, tuple(float(p) for p in node.params), pl, False, [],
+                  (1 << N_FACES[node.kind]) - 1, node.source)
+    node._flat = fp
+    out.append(fp)
+  else:
+    for c in node.children:
+      _leaves(c, pl, out)
+
+
+def _inside_conj(node):
+  if node.op == 'prim':
+    return [(node._flat, True)]
+  if node.op == 'common':
+    return [c for k in node.children for c in _inside_conj(k)]
+  if node.op == 'cut':
+    return _inside_conj(node.children[0]) + _outside_conj(node.children[1])
+  raise UnsupportedGeometry(f'{node.source}: "inside a Fuse" is a disjunction; nested this way it needs FreeCAD')
+
+
+def _outside_conj(node):
+  if node.op == 'prim':
+    return [(node._flat, False)]
+  if node.op == 'fuse':
+    return [c for k in node.children for c in _outside_conj(k)]
+  raise UnsupportedGeometry(f'{node.source}: "outside a {node.op}" is a disjunction; nested this way it needs FreeCAD')
+
+
+def _assign(node, conds, flip):
+  if node.op == 'prim':
+    node._flat.conds = list(conds)
+    node._flat.flip = flip
+    return
+  kids = node.children
+  if node.op == 'common':
+    for i, k in enumerate(kids):
+      extra = [c for j, o in enumerate(kids) if j != i for c in _inside_conj(o)]
+      _assign(k, conds + extra, flip)
+  elif node.op == 'fuse':
+    for i, k in enumerate(kids):
+      extra = [c for j, o in enumerate(kids) if j != i for c in _outside_conj(o)]
+      _assign(k, conds + extra, flip)
+  elif node.op == 'cut':
+    _assign(kids[0], conds + _outside_conj(kids[1]), flip)
+    _assign(kids[1], conds + _inside_conj(kids[0]), not flip)
+
+
+def flatten(tree, acc=None):
+  """CSG tree -> [FlatPrim] (every leaf once; conditions reference leaves)"""
+  out = []
+  _leaves(tree, acc or Placement.identity(), out)
+  _assign(tree, [], False)
+  _prune_faces(out)
+  return out
+
+
+# ---------------------------------------------------------------------------
+# bounding boxes (world AABB) of primitives and of their faces
+# ---------------------------------------------------------------------------
+def local_bounds(kind, params):
+  p = params
+  if kind == BOX:
+    return np.array([0, 0, 0.0]), np.array([p[0], p[1], p[2]])
+  if kind == SPHERE:
+    return np.full(3, -p[0]), np.full(3, p[0])
+  if kind == CYLINDER:
+    return np.array([-p[0], -p[0], 0.0]), np.array([p[0], p[0], p[1]])
+  if kind == CONE:
+    r = max(p[0], p[1])
+    return np.array([-r, -r, 0.0]), np.array([r, r, p[2]])
+  if kind == TORUS:
+    r = p[0] + p[1]
+    return np.array([-r, -r, -p[1]]), np.array([r, r, p[1]])
+  raise ValueError(kind)
+
+
+def face_local_bounds(kind, params, face):
+  lo, hi = local_bounds(kind, params)
+  lo, hi = lo.copy(), hi.copy()
+  if kind == BOX:
+    a = face >> 1
+    v = hi[a] if face & 1 else lo[a]
+    lo[a] = hi[a] = v
+  elif kind in (CYLINDER, CONE) and face in (1, 2):
+    r = params[0] if (face == 1 or kind == CYLINDER) else params[1]
+    z = lo[2] if face == 1 else hi[2]
+    lo = np.array([-r, -r, z]); hi = np.array([r, r, z])
+  return lo, hi
+
+
+def world_aabb(to_world, lo, hi):
+  corners = np.array([[x, y, z] for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])])
+  w = corners @ to_world.m[:3, :3].T + to_world.m[:3, 3]
+  return w.min(axis=0), w.max(axis=0)
+
+
+def _prune_faces(prims, slack=1e-3):
+  """drop faces that can never satisfy a must-be-inside condition (their
+  bounding box misses the other operand's): an optimisation only, the trim
+  test would reject every candidate on them anyway"""
+  for fp in prims:
+    mask = 0
+    for f in range(N_FACES[fp.kind]):
+      flo, fhi = world_aabb(fp.to_world, *face_local_bounds(fp.kind, fp.params, f))
+      keep = True
+      for other, inside in fp.conds:
+        if not inside:
+          continue
+        olo, ohi = world_aabb(other.to_world, *local_bounds(other.kind, other.params))
+        if np.any(flo > ohi + slack) or np.any(fhi < olo - slack):
+          keep = False
+          break
+      if keep:
+        mask |= 1 << f
+    fp.facemask = mask

@@ -1,0 +1,231 @@
+/*
+ * odw_trace.h -- C-ABI of the MI355X-native Monte-Carlo ray-tracing core.
+ *
+ * The reference (zaphB/freecad.optics_design_workbench) has no FFI: its hot
+ * path is the Python method pair
+ *     PointSourceProxy._generateRays(mode='true')   point_source.py:659-679
+ *     Ray.traceRay(store=...)                        ray.py:36-281
+ * driven by GenericSourceProxy.runSimulationIteration (generic_source.py:51)
+ * and observed through SimulationResults.addRayHit (results_store.py:641).
+ * This header is the boundary a binding for that path would bind: plain
+ * pointers and sizes, return codes instead of exceptions.  Each entry point
+ * names the reference interface it replaces.
+ *
+ * All geometry/ray arithmetic is float64 (FreeCAD Vector/Matrix are double).
+ * Units: millimetres, radians, wavelength in nm (as in the reference).
+ */
+#ifndef ODW_TRACE_H
+#define ODW_TRACE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ODW_ABI_VERSION 1
+
+/* ---- return codes ------------------------------------------------------ */
+enum {
+  ODW_OK = 0,
+  ODW_ERR_INVALID = 1,      /* bad argument / inconsistent tables          */
+  ODW_ERR_DEVICE = 2,       /* HIP runtime error (see odw_last_error)      */
+  ODW_ERR_NO_SCENE = 3,     /* trace before scene/source upload            */
+  ODW_ERR_CAPACITY = 4,     /* hit buffer too small for requested fetch    */
+  ODW_ERR_UNSUPPORTED = 5   /* scene feature outside the supported set     */
+};
+
+/* ---- primitive kinds (solid primitives; faces are implicit) ------------ */
+/* local frames follow FreeCAD's Part primitives:                           */
+/*  BOX      [0,L]x[0,W]x[0,H]            params = L, W, H, -               */
+/*  SPHERE   centre 0                     params = R, -, -, -               */
+/*  CYLINDER axis +z, z in [0,H]          params = R, H, -, -               */
+/*  CONE     axis +z, z in [0,H]          params = R1(z=0), R2(z=H), H, -   */
+/*  TORUS    axis +z                      params = R1 (ring), R2 (tube)     */
+enum {
+  ODW_PRIM_BOX = 0,
+  ODW_PRIM_SPHERE = 1,
+  ODW_PRIM_CYLINDER = 2,
+  ODW_PRIM_CONE = 3,
+  ODW_PRIM_TORUS = 4
+};
+
+/* face bit positions inside prim_flags >> ODW_FACEMASK_SHIFT               */
+/*  BOX: 0:-x 1:+x 2:-y 3:+y 4:-z 5:+z ; CYL/CONE: 0:lateral 1:z=0 2:z=H    */
+/*  SPHERE/TORUS: 0                                                         */
+#define ODW_FLAG_FLIP_NORMAL 0x1 /* face normals point INTO the primitive   */
+                                 /* (tool of a Part::Cut)                   */
+#define ODW_FACEMASK_SHIFT 8
+
+/* ---- optical types: OpticalGroupProxy.OpticalType enumeration order ----- */
+/* optical_group.py:32 ['Mirror','Lens','Grating','Absorber','Vacuum']      */
+enum {
+  ODW_OPT_MIRROR = 0,
+  ODW_OPT_LENS = 1,
+  ODW_OPT_GRATING = 2,
+  ODW_OPT_ABSORBER = 3,
+  ODW_OPT_VACUUM = 4
+};
+
+#define ODW_MAX_GROUPS 64
+#define ODW_MAX_SEQUENCE 100 /* simulation_settings.py:165 range(100)       */
+
+/* Flat SoA scene = what raytracing_cache.py memoises per run (Shape, Shells,
+ * Faces, Surface, BoundBox) + the optical group property table
+ * (optical_group.py:29-96) + the sequence lists of
+ * SimulationSettingsProxy.getTracingSequence (simulation_settings.py:158).   */
+typedef struct odw_scene_desc {
+  int32_t n_prims;
+  const int32_t* prim_type;     /* [n_prims] ODW_PRIM_*                       */
+  const int32_t* prim_group;    /* [n_prims] index into group tables          */
+  const int32_t* prim_solid;    /* [n_prims] shell id (informational)         */
+  const int32_t* prim_flags;    /* [n_prims] ODW_FLAG_* | facemask<<8         */
+  const double*  prim_xform;    /* [n_prims*12] global->local, rows (R|t)     */
+  const double*  prim_params;   /* [n_prims*4]                                */
+  const int32_t* prim_cond_off; /* [n_prims+1] CSG trimming conditions        */
+  int32_t n_conds;
+  const int32_t* cond_prim;     /* [n_conds] primitive the point is tested in */
+  const int32_t* cond_inside;   /* [n_conds] 1: must be inside, 0: outside    */
+
+  int32_t n_groups;             /* <= ODW_MAX_GROUPS                          */
+  const int32_t* group_type;    /* [n_groups] ODW_OPT_*                       */
+  const double*  group_ior;     /* [n_groups] RefractiveIndex                 */
+  const double*  group_refl;    /* [n_groups] Reflectivity                    */
+  const double*  group_abslen;  /* [n_groups] AbsorptionLength (inf = none)   */
+  const int32_t* group_record;  /* [n_groups] RecordHits                      */
+  /* grating properties (optical_group.py:82-90); ignored unless GRATING     */
+  const int32_t* group_grating_type;   /* [n_groups] 0 reflection 1 transm.  */
+  const double*  group_grating_lpm;    /* [n_groups] lines per millimetre    */
+  const double*  group_grating_dir;    /* [n_groups*3] GratingLinesOrientation*/
+  const int32_t* group_grating_order;  /* [n_groups]                         */
+
+  int32_t seq_enabled;          /* SimulationSettings.SequentialMode          */
+  int32_t seq_len;              /* <= ODW_MAX_SEQUENCE                        */
+  const uint64_t* seq_mask;     /* [seq_len] bit g set: group g in step       */
+  uint64_t ignore_mask;         /* source.IgnoredOpticalElements              */
+} odw_scene_desc;
+
+/* Point source = PointSourceProxy (point_source.py:32-70) after
+ * VectorRandomVariable.compile() in numeric mode
+ * (random_number_generator.py:337-464): inverse-CDF tables.                  */
+typedef struct odw_source_desc {
+  double xform[12];        /* local->global rows (R|t): gpM of _makeRay       */
+  double focal_length;     /* finite: (theta,phi) mode; +-inf: (r,phi) mode   */
+  double wavelength;       /* nm                                              */
+  double power;            /* initial ray power (1)                           */
+  int32_t n_phi_knots;     /* odd resolution, e.g. 101                        */
+  const double* phi_edges; /* [n_phi_knots]   variableRanges[phi]             */
+  const double* phi_cdf;   /* [n_phi_knots]   cumulative sums / last entry    */
+  int32_t n_t_knots;       /* e.g. 100001                                     */
+  int32_t n_t_rows;        /* n_phi_knots-1, or 1 if density is phi-free      */
+  const double* t_edges;   /* [n_t_knots]     variableRanges[theta or r]      */
+  const double* t_cdf;     /* [n_t_rows*n_t_knots] each row / its last entry  */
+                           /* (random_number_generator.py:441)                */
+} odw_source_desc;
+
+/* Ray.traceRay keyword arguments + settings (ray.py:36-73, 283-288).        */
+typedef struct odw_limits {
+  double max_ray_length;    /* MaxRayLengthScale * settings.MaxRayLength      */
+  int32_t max_intersections;/* MaxIntersectionsScale * MaxIntersections       */
+  double dist_tol;          /* max(DistanceTolerance, 1e-6)                   */
+  double power_tol;         /* 1e-6                                           */
+} odw_limits;
+
+/* Up-front detector binning (cartesian): the reference bins post hoc
+ * (hits.py:176-193 -> histogram.py:24-57); here the plane is fixed before
+ * tracing.  Hit p on a RecordHits group g is binned at
+ *   x = (p-origin).ex, y = (p-origin).ey,
+ *   ix = floor((x-x_lo)*nx/(x_hi-x_lo)), same for y; outside -> overflow
+ * counter.  group < 0: all recording groups.                                 */
+typedef struct odw_detector_desc {
+  int32_t group;
+  double origin[3], ex[3], ey[3];
+  double x_lo, x_hi, y_lo, y_hi;
+  int32_t nx, ny;
+} odw_detector_desc;
+
+/* One recorded hit: the row layout SimulationResults.flush pickles
+ * (results_store.py:405-457): points, directions, powers, isEntering.
+ * 64 bytes.  tag = ray_index | group<<48 | isEntering<<63.                   */
+typedef struct odw_hit {
+  double point[3];
+  double direction[3]; /* incoming direction (pre-interaction), ray.py:132   */
+  double power;        /* after medium absorption, before this surface       */
+  uint64_t tag;
+} odw_hit;
+
+#define ODW_HIT_RAY(tag)      ((tag) & 0xFFFFFFFFFFFFull)
+#define ODW_HIT_GROUP(tag)    (((tag) >> 48) & 0x7FFF)
+#define ODW_HIT_ENTERING(tag) ((tag) >> 63)
+
+/* counters (u64), SimulationResults counters results_store.py:306-310       */
+enum {
+  ODW_CNT_TRACED_RAYS = 0,   /* incrementRayCount, generic_source.py:141     */
+  ODW_CNT_RECORDED_HITS = 1, /* addRayHit on RecordHits groups               */
+  ODW_CNT_SEGMENTS = 2,      /* nearest-hit queries                          */
+  ODW_CNT_ESCAPED = 3,       /* no intersection found, ray.py:105            */
+  ODW_CNT_DIED = 4,          /* power < powerTol, ray.py:280                 */
+  ODW_CNT_CAPPED = 5,        /* numIntersections >= max, ray.py:96           */
+  ODW_CNT_HIST_OVERFLOW = 6, /* recorded hits outside the detector window    */
+  ODW_CNT_HITS_DROPPED = 7,  /* hit list capacity exceeded                   */
+  ODW_CNT_COUNT = 8
+};
+
+/* trace flags */
+#define ODW_TRACE_RECORD_HITS 0x1 /* append odw_hit rows                      */
+#define ODW_TRACE_HISTOGRAM   0x2 /* bin into the detector histogram          */
+
+typedef struct odw_ctx odw_ctx;
+
+/* lifecycle ------------------------------------------------------------- */
+int odw_abi_version(void);
+int odw_create(int device, odw_ctx** out);
+void odw_destroy(odw_ctx* ctx);
+const char* odw_last_error(const odw_ctx* ctx); /* NULL ctx: global message */
+
+/* scene bake upload: replaces raytracing_cache.py:43-114 + find.py:79-104  */
+int odw_upload_scene(odw_ctx* ctx, const odw_scene_desc* scene);
+/* replaces PointSourceProxy._getVrv/_rvArgs result, point_source.py:277-386 */
+int odw_upload_source(odw_ctx* ctx, const odw_source_desc* source);
+int odw_set_limits(odw_ctx* ctx, const odw_limits* limits);
+int odw_set_detector(odw_ctx* ctx, const odw_detector_desc* det);
+/* capacity of the device hit list in rows (0 frees it)                     */
+int odw_reserve_hits(odw_ctx* ctx, uint64_t capacity);
+
+/* replaces one or many runSimulationIteration calls (generic_source.py:51):
+ * rays first_ray .. first_ray+n_rays-1 of the global Philox stream `seed`
+ * are generated (point_source.py:659-679, random_number_generator.py:467),
+ * traced (ray.py:36-281) and recorded.  Asynchronous on the context stream. */
+int odw_trace(odw_ctx* ctx, uint64_t first_ray, uint64_t n_rays, uint64_t seed,
+              uint32_t flags);
+/* trace explicit initial conditions instead of the sampler ("useInitial-
+ * Conditions", generic_source.py:59; fan mode rays): origin/dir [n*3].     */
+int odw_trace_rays(odw_ctx* ctx, uint64_t first_ray, uint64_t n_rays,
+                   const double* origins, const double* directions,
+                   const double* powers, uint32_t flags);
+int odw_sync(odw_ctx* ctx);
+
+/* results --------------------------------------------------------------- */
+int odw_reset_results(odw_ctx* ctx); /* zero counters, hits, histogram      */
+int odw_fetch_counters(odw_ctx* ctx, uint64_t* out, int32_t n);
+int odw_hit_count(odw_ctx* ctx, uint64_t* n);
+/* copies min(n_hits, capacity) rows, sorted by (ray index, bounce order)   */
+int odw_fetch_hits(odw_ctx* ctx, odw_hit* out, uint64_t capacity, uint64_t* n);
+int odw_fetch_histogram(odw_ctx* ctx, uint64_t* out, uint64_t n_bins);
+/* sampler only (diagnostics/tests): theta-or-radius and phi of each ray    */
+int odw_sample(odw_ctx* ctx, uint64_t first_ray, uint64_t n_rays, uint64_t seed,
+               double* theta_out, double* phi_out);
+
+/* device-side handles for collectives (RCCL reduce through torch)          */
+int odw_device_histogram(odw_ctx* ctx, void** dptr, uint64_t* n_bins);
+int odw_device_counters(odw_ctx* ctx, void** dptr, uint64_t* n);
+int odw_stream(odw_ctx* ctx, void** hip_stream);
+
+/* timing of the trace kernel with HIP events on the context stream         */
+int odw_timing_enable(odw_ctx* ctx, int on);
+int odw_timing_read(odw_ctx* ctx, double* total_ms, uint64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ODW_TRACE_H */

@@ -1,0 +1,825 @@
+/*
+ * odw_oracle.c -- CPU restatement of the reference's Monte-Carlo hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product package may import, link
+ * or execute this file; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg do.  Plain C, float64, scalar, one ray at a time, brute
+ * force over every face -- written for clarity, not speed.
+ *
+ * Parity status: the SAMPLER part (interp, row selection, draw order) is
+ * pinned bit-for-bit against numpy.interp and against outputs of the
+ * reference's own random_number_generator.py (tests/golden/sampler_*.npz).
+ * The TRACING part is "parity unpinned" at the per-ray level: the reference
+ * delegates intersections to FreeCAD/OpenCASCADE, which exists neither here
+ * nor on the GPU box, and ships no known-answer vectors for intersections.
+ * It follows the source text of the files cited below and is pinned only by
+ * closed-form physics checks and the reference's statistical acceptance
+ * tests (tests/test_oracle_physics.py).
+ *
+ * Reference files followed (relative to freecad/optics_design_workbench/):
+ *   freecad_elements/ray.py:36-281      traceRay bounce loop / state machine
+ *   freecad_elements/ray.py:290-452     findNearestIntersection
+ *   freecad_elements/ray.py:455-495     getNormal, mirror, snellsLaw
+ *   freecad_elements/ray.py:497-539     lineGrating
+ *   freecad_elements/point_source.py:411-460   _makeRay
+ *   distributions/random_number_generator.py:413-456, 467-560  draw/interp
+ *   freecad_elements/find.py:79-104     relevantOpticalObjects
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off, optional OpenMP).
+ */
+#include "../include/odw_trace.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------ */
+/* Philox4x32-10 (Salmon et al., SC'11), counter-based RNG.            */
+/* The reference seeds MT19937 from pid*time (simulation_loop.py:813), */
+/* i.e. it is non-reproducible; a counter RNG keyed by the global ray  */
+/* index replaces it so that results do not depend on sharding.        */
+/* ------------------------------------------------------------------ */
+void odw_oracle_philox(const uint32_t ctr_in[4], const uint32_t key_in[2],
+                       uint32_t out[4]) {
+  uint32_t c0 = ctr_in[0], c1 = ctr_in[1], c2 = ctr_in[2], c3 = ctr_in[3];
+  uint32_t k0 = key_in[0], k1 = key_in[1];
+  for (int r = 0; r < 10; ++r) {
+    if (r > 0) {
+      k0 += 0x9E3779B9u;
+      k1 += 0xBB67AE85u;
+    }
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+    uint32_t n0 = hi1 ^ c1 ^ k0;
+    uint32_t n1 = lo1;
+    uint32_t n2 = hi0 ^ c3 ^ k1;
+    uint32_t n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* 53-bit uniform in [0,1) from two 32-bit words, the construction numpy's
+ * legacy random_sample uses (a>>5, b>>6).                                  */
+static double u53(uint32_t a, uint32_t b) {
+  return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
+}
+
+/* Uniforms of one ray: counter = (ray_lo, ray_hi, slot, 0), key = seed.
+ * slot 0: words 0,1 -> u_phi ; words 2,3 -> u_theta.
+ * The reference draws u_phi first, then u_theta
+ * (random_number_generator.py:492-498, reversed variable order).           */
+static void ray_uniforms(uint64_t ray, uint64_t seed, double* u_phi, double* u_t) {
+  uint32_t ctr[4] = {(uint32_t)ray, (uint32_t)(ray >> 32), 0u, 0u};
+  uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  uint32_t w[4];
+  odw_oracle_philox(ctr, key, w);
+  *u_phi = u53(w[0], w[1]);
+  *u_t = u53(w[2], w[3]);
+}
+
+/* ------------------------------------------------------------------ */
+/* numpy.interp restated (numpy/_core/src/multiarray/compiled_base.c,  */
+/* arr_interp).  Used by the reference at                              */
+/* random_number_generator.py:445.                                     */
+/* ------------------------------------------------------------------ */
+double odw_oracle_interp(double x, const double* xp, const double* fp, int32_t n) {
+  if (isnan(x)) return x;
+  if (x < xp[0]) return fp[0];
+  if (x > xp[n - 1]) return fp[n - 1];
+  /* j = last index with xp[j] <= x */
+  int32_t lo = 0, hi = n; /* invariant: xp[lo] <= x, (hi==n or xp[hi] > x) */
+  while (hi - lo > 1) {
+    int32_t mid = lo + (hi - lo) / 2;
+    if (x >= xp[mid]) lo = mid; else hi = mid;
+  }
+  int32_t j = lo;
+  if (j == n - 1) return fp[j];
+  if (xp[j] == x) return fp[j];
+  double slope = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);
+  double r = slope * (x - xp[j]) + fp[j];
+  if (isnan(r)) {
+    r = slope * (x - xp[j + 1]) + fp[j + 1];
+    if (isnan(r) && fp[j] == fp[j + 1]) r = fp[j];
+  }
+  return r;
+}
+
+/* VectorRandomVariable.draw for one sample given its two uniforms
+ * (random_number_generator.py:413-456): phi from the marginal table, then
+ * the conditional row nearest to phi (argmin over mid-points, first minimum),
+ * then theta (or r) from that row.                                         */
+static void sample_one(const odw_source_desc* s, double u_phi, double u_t,
+                       double* t_out, double* phi_out) {
+  double phi = odw_oracle_interp(u_phi, s->phi_cdf, s->phi_edges, s->n_phi_knots);
+  int32_t row = 0;
+  if (s->n_t_rows > 1) {
+    double best = INFINITY;
+    for (int32_t i = 0; i < s->n_t_rows; ++i) {
+      double mid = (s->phi_edges[i + 1] + s->phi_edges[i]) / 2;
+      double d = fabs(mid - phi);
+      if (d < best) { best = d; row = i; }
+    }
+  }
+  const double* cdf = s->t_cdf + (size_t)row * (size_t)s->n_t_knots;
+  *t_out = odw_oracle_interp(u_t, cdf, s->t_edges, s->n_t_knots);
+  *phi_out = phi;
+}
+
+int odw_oracle_sample(const odw_source_desc* s, uint64_t first, uint64_t n,
+                      uint64_t seed, double* t_out, double* phi_out) {
+  for (uint64_t i = 0; i < n; ++i) {
+    double up, ut;
+    ray_uniforms(first + i, seed, &up, &ut);
+    sample_one(s, up, ut, &t_out[i], &phi_out[i]);
+  }
+  return ODW_OK;
+}
+
+/* the same with caller-supplied uniforms (pins against the reference's
+ * numpy-seeded draws)                                                      */
+int odw_oracle_sample_uniforms(const odw_source_desc* s, uint64_t n,
+                               const double* u_phi, const double* u_t,
+                               double* t_out, double* phi_out) {
+  for (uint64_t i = 0; i < n; ++i) sample_one(s, u_phi[i], u_t[i], &t_out[i], &phi_out[i]);
+  return ODW_OK;
+}
+
+/* ------------------------------------------------------------------ */
+/* small vector helpers                                                */
+/* ------------------------------------------------------------------ */
+typedef struct { double x, y, z; } v3;
+static v3 V(double x, double y, double z) { v3 r = {x, y, z}; return r; }
+static v3 add(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+static v3 sub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+static v3 mul(v3 a, double s) { return V(a.x * s, a.y * s, a.z * s); }
+static double dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static v3 cross(v3 a, v3 b) {
+  return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+static double len(v3 a) { return sqrt(dot(a, a)); }
+/* point transform with rows (R|t) */
+static v3 xf_point(const double* m, v3 p) {
+  return V(m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3],
+           m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7],
+           m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]);
+}
+/* inverse of a rigid (R|t): p = R^T (q - t) */
+static v3 xf_point_inv(const double* m, v3 q) {
+  v3 d = V(q.x - m[3], q.y - m[7], q.z - m[11]);
+  return V(m[0] * d.x + m[4] * d.y + m[8] * d.z,
+           m[1] * d.x + m[5] * d.y + m[9] * d.z,
+           m[2] * d.x + m[6] * d.y + m[10] * d.z);
+}
+
+/* ------------------------------------------------------------------ */
+/* PointSourceProxy._makeRay (point_source.py:411-460)                 */
+/* ------------------------------------------------------------------ */
+static void make_ray(const odw_source_desc* s, double t_or_r, double phi,
+                     v3* origin, v3* dir) {
+  v3 ldir, lorg;
+  if (isfinite(s->focal_length)) {
+    double theta = t_or_r;
+    /* Rz(phi) * Rx(theta) * (0,0,1) */
+    double st = sin(theta), ct = cos(theta), sp = sin(phi), cp = cos(phi);
+    ldir = V(st * sp, -st * cp, ct);
+    lorg = mul(sub(V(0, 0, 1), ldir), s->focal_length);
+  } else {
+    double r = t_or_r;
+    ldir = V(0, 0, 1);
+    /* r*x^*cos(phi) + r*(x^ x z^)*sin(phi), x^ x z^ = (0,-1,0) */
+    lorg = add(mul(V(1, 0, 0), r * cos(phi)), mul(V(0, -1, 0), r * sin(phi)));
+  }
+  v3 p1 = lorg;
+  v3 p2 = add(lorg, mul(ldir, 1.0 / len(ldir)));
+  p1 = xf_point(s->xform, p1);
+  p2 = xf_point(s->xform, p2);
+  v3 d = sub(p2, p1);
+  *origin = p1;
+  *dir = mul(d, 1.0 / len(d));
+}
+
+/* ------------------------------------------------------------------ */
+/* polynomial root isolation for the torus quartic                     */
+/* ------------------------------------------------------------------ */
+static double poly(const double* c, int deg, double t) {
+  double r = c[deg];
+  for (int i = deg - 1; i >= 0; --i) r = r * t + c[i];
+  return r;
+}
+
+/* root of a function monotone on [a,b] with f(a)*f(b) < 0: bisection safeguarded Newton */
+static double mono_root(const double* c, int deg, double a, double b) {
+  double dc[5];
+  for (int i = 1; i <= deg; ++i) dc[i - 1] = c[i] * i;
+  double fa = poly(c, deg, a);
+  double lo = a, hi = b;
+  if (fa > 0) { lo = b; hi = a; } /* f(lo) < 0 < f(hi) */
+  double x = 0.5 * (a + b);
+  for (int it = 0; it < 200; ++it) {
+    double f = poly(c, deg, x);
+    if (f == 0) return x;
+    if (f < 0) lo = x; else hi = x;
+    double df = poly(dc, deg - 1, x);
+    double xn = (df != 0) ? x - f / df : 0.5 * (lo + hi);
+    double mn = lo < hi ? lo : hi, mx = lo < hi ? hi : lo;
+    if (!(xn > mn && xn < mx)) xn = 0.5 * (lo + hi);
+    if (xn == x || fabs(hi - lo) <= 4e-16 * (fabs(lo) + fabs(hi))) return xn;
+    x = xn;
+  }
+  return x;
+}
+
+/* all sign-change roots of a polynomial of degree <= 4 in [lo,hi], ascending */
+static int poly_roots(const double* c, int deg, double lo, double hi, double* out) {
+  while (deg > 0 && c[deg] == 0) --deg;
+  if (deg <= 0) return 0;
+  if (deg == 1) {
+    double r = -c[0] / c[1];
+    if (r >= lo && r <= hi) { out[0] = r; return 1; }
+    return 0;
+  }
+  double dc[5], crit[4];
+  for (int i = 1; i <= deg; ++i) dc[i - 1] = c[i] * i;
+  int nc = poly_roots(dc, deg - 1, lo, hi, crit);
+  double brk[6];
+  int nb = 0;
+  brk[nb++] = lo;
+  for (int i = 0; i < nc; ++i) brk[nb++] = crit[i];
+  brk[nb++] = hi;
+  int n = 0;
+  for (int i = 0; i + 1 < nb; ++i) {
+    double a = brk[i], b = brk[i + 1];
+    if (!(b > a)) continue;
+    double fa = poly(c, deg, a), fb = poly(c, deg, b);
+    if (fa == 0) {
+      if (n == 0 || out[n - 1] != a) out[n++] = a;
+      continue;
+    }
+    if ((fa < 0 && fb > 0) || (fa > 0 && fb < 0)) out[n++] = mono_root(c, deg, a, b);
+    else if (fb == 0 && i + 2 == nb) out[n++] = b;
+  }
+  return n;
+}
+
+/* ------------------------------------------------------------------ */
+/* primitives: candidate intersections and inside tests                */
+/* ------------------------------------------------------------------ */
+typedef struct {
+  double t;     /* distance along the (unit) ray                     */
+  v3 n_local;   /* outward face normal in the primitive's frame      */
+  int face;
+} cand;
+
+static int quad_roots(double a, double b_half, double c, double* r) {
+  /* a t^2 + 2 b_half t + c = 0 */
+  if (a == 0) {
+    if (b_half == 0) return 0;
+    r[0] = -c / (2 * b_half);
+    return 1;
+  }
+  double disc = b_half * b_half - a * c;
+  if (disc < 0) return 0;
+  double sq = sqrt(disc);
+  double q = -(b_half + (b_half >= 0 ? sq : -sq));
+  double t0 = q / a;
+  double t1 = (q != 0) ? c / q : t0;
+  if (t0 > t1) { double tmp = t0; t0 = t1; t1 = tmp; }
+  r[0] = t0; r[1] = t1;
+  return 2;
+}
+
+/* signed-distance-like value of local point p w.r.t. primitive (negative inside) */
+static double prim_sdist(int type, const double* par, v3 p) {
+  switch (type) {
+    case ODW_PRIM_BOX: {
+      double dx = fmax(-p.x, p.x - par[0]);
+      double dy = fmax(-p.y, p.y - par[1]);
+      double dz = fmax(-p.z, p.z - par[2]);
+      return fmax(dx, fmax(dy, dz));
+    }
+    case ODW_PRIM_SPHERE: return len(p) - par[0];
+    case ODW_PRIM_CYLINDER: {
+      double rho = sqrt(p.x * p.x + p.y * p.y);
+      return fmax(rho - par[0], fmax(-p.z, p.z - par[1]));
+    }
+    case ODW_PRIM_CONE: {
+      double k = (par[1] - par[0]) / par[2];
+      double rho = sqrt(p.x * p.x + p.y * p.y);
+      double lat = (rho - (par[0] + k * p.z)) / sqrt(1 + k * k);
+      return fmax(lat, fmax(-p.z, p.z - par[2]));
+    }
+    case ODW_PRIM_TORUS: {
+      double rho = sqrt(p.x * p.x + p.y * p.y);
+      double a = rho - par[0];
+      return sqrt(a * a + p.z * p.z) - par[1];
+    }
+  }
+  return INFINITY;
+}
+
+/* enumerate every intersection of the unit ray (o,d) (local frame) with the
+ * UNTRIMMED face surfaces of one primitive, then apply the natural face trim
+ * with tolerance tol -- the analogue of line.Curve.intersect(surface) +
+ * vert.distToShape(face) < distTol (ray.py:411-426).                       */
+static int prim_candidates(int type, const double* par, int facemask, v3 o, v3 d,
+                           double tol, cand* out) {
+  int n = 0;
+  const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+  switch (type) {
+    case ODW_PRIM_BOX: {
+      for (int f = 0; f < 6; ++f) {
+        if (!((facemask >> f) & 1)) continue;
+        int a = f >> 1;
+        if (dd[a] == 0) continue;
+        double c = (f & 1) ? par[a] : 0.0;
+        double t = (c - oo[a]) / dd[a];
+        int b1 = (a + 1) % 3, b2 = (a + 2) % 3;
+        double p1 = oo[b1] + t * dd[b1], p2 = oo[b2] + t * dd[b2];
+        if (p1 < -tol || p1 > par[b1] + tol || p2 < -tol || p2 > par[b2] + tol) continue;
+        double nn[3] = {0, 0, 0};
+        nn[a] = (f & 1) ? 1.0 : -1.0;
+        out[n].t = t; out[n].n_local = V(nn[0], nn[1], nn[2]); out[n].face = f; ++n;
+      }
+      break;
+    }
+    case ODW_PRIM_SPHERE: {
+      if (!(facemask & 1)) break;
+      double r[2];
+      int nr = quad_roots(dot(d, d), dot(o, d), dot(o, o) - par[0] * par[0], r);
+      for (int i = 0; i < nr; ++i) {
+        v3 p = add(o, mul(d, r[i]));
+        out[n].t = r[i]; out[n].n_local = mul(p, 1.0 / len(p)); out[n].face = 0; ++n;
+      }
+      break;
+    }
+    case ODW_PRIM_CYLINDER:
+    case ODW_PRIM_CONE: {
+      double R1 = par[0], R2, H, k;
+      if (type == ODW_PRIM_CYLINDER) { R2 = par[0]; H = par[1]; k = 0; }
+      else { R2 = par[1]; H = par[2]; k = (R2 - R1) / H; }
+      if (facemask & 1) {
+        double r[2];
+        double rz = R1 + k * o.z;
+        double a = d.x * d.x + d.y * d.y - k * k * d.z * d.z;
+        double bh = o.x * d.x + o.y * d.y - k * rz * d.z;
+        double c = o.x * o.x + o.y * o.y - rz * rz;
+        int nr = quad_roots(a, bh, c, r);
+        for (int i = 0; i < nr; ++i) {
+          v3 p = add(o, mul(d, r[i]));
+          if (p.z < -tol || p.z > H + tol) continue;
+          double rr = R1 + k * p.z;
+          if (rr < -tol) continue; /* other nappe of the cone */
+          v3 g = V(p.x, p.y, -k * rr);
+          double gl = len(g);
+          if (gl == 0) continue;
+          out[n].t = r[i]; out[n].n_local = mul(g, 1.0 / gl); out[n].face = 0; ++n;
+        }
+      }
+      for (int f = 1; f <= 2; ++f) {
+        if (!((facemask >> f) & 1)) continue;
+        if (d.z == 0) continue;
+        double zc = (f == 1) ? 0.0 : H;
+        double rc = (f == 1) ? R1 : R2;
+        if (rc <= 0) continue;
+        double t = (zc - o.z) / d.z;
+        double px = o.x + t * d.x, py = o.y + t * d.y;
+        if (px * px + py * py > (rc + tol) * (rc + tol)) continue;
+        out[n].t = t; out[n].n_local = V(0, 0, f == 1 ? -1.0 : 1.0); out[n].face = f; ++n;
+      }
+      break;
+    }
+    case ODW_PRIM_TORUS: {
+      if (!(facemask & 1)) break;
+      double R1 = par[0], R2 = par[1];
+      /* re-origin at the closest approach to the torus centre */
+      double dl = dot(d, d);
+      double t0 = -dot(o, d) / dl;
+      v3 q = add(o, mul(d, t0));
+      double A = dl;
+      double C = dot(q, q) + R1 * R1 - R2 * R2;
+      double E = d.x * d.x + d.y * d.y;
+      double F = 2 * (q.x * d.x + q.y * d.y);
+      double G = q.x * q.x + q.y * q.y;
+      double B = 2 * dot(q, d); /* ~0 by construction, kept for exactness */
+      double c[5];
+      c[4] = A * A;
+      c[3] = 2 * A * B;
+      c[2] = B * B + 2 * A * C - 4 * R1 * R1 * E;
+      c[1] = 2 * B * C - 4 * R1 * R1 * F;
+      c[0] = C * C - 4 * R1 * R1 * G;
+      double bound = (R1 + R2) * 1.0000001 + 1e-9;
+      /* all roots lie inside the bounding sphere: |s| <= bound/sqrt(A) */
+      double sb = bound / sqrt(A);
+      double roots[4];
+      int nr = poly_roots(c, 4, -sb, sb, roots);
+      for (int i = 0; i < nr; ++i) {
+        double t = roots[i] + t0;
+        v3 p = add(o, mul(d, t));
+        double rho = sqrt(p.x * p.x + p.y * p.y);
+        if (rho == 0) continue;
+        v3 g = V(p.x - R1 * p.x / rho, p.y - R1 * p.y / rho, p.z);
+        double gl = len(g);
+        if (gl == 0) continue;
+        out[n].t = t; out[n].n_local = mul(g, 1.0 / gl); out[n].face = 0; ++n;
+      }
+      break;
+    }
+  }
+  return n;
+}
+
+/* ------------------------------------------------------------------ */
+/* findNearestIntersection (ray.py:290-452)                            */
+/* ------------------------------------------------------------------ */
+typedef struct {
+  int found;
+  int prim, face, group;
+  double dist;
+  v3 point;    /* global */
+  v3 normal;   /* global outward normal of the solid at the hit (unit) */
+} nearest_hit;
+
+static uint64_t relevant_mask(const odw_scene_desc* sc, int seq_idx) {
+  /* find.py:79-104 */
+  uint64_t all = (sc->n_groups >= 64) ? ~0ull : ((1ull << sc->n_groups) - 1);
+  uint64_t m = all;
+  if (sc->seq_enabled) m = (seq_idx < sc->seq_len) ? sc->seq_mask[seq_idx] : 0ull;
+  return m & ~sc->ignore_mask & all;
+}
+
+static int better(double t, int prim, int face, double bt, int bprim, int bface) {
+  if (t != bt) return t < bt;
+  if (prim != bprim) return prim < bprim;
+  return face < bface;
+}
+
+static nearest_hit nearest(const odw_scene_desc* sc, const odw_limits* lim, v3 start,
+                           v3 dir, int medium, int seq_idx) {
+  const double tol = lim->dist_tol;
+  const double max_len = lim->max_ray_length;
+  uint64_t mask = relevant_mask(sc, seq_idx);
+  v3 dn = mul(dir, 1.0 / len(dir));
+
+  nearest_hit any = {0}, oth = {0};
+  any.dist = INFINITY; oth.dist = INFINITY;
+  any.prim = oth.prim = any.face = oth.face = 0x7fffffff;
+
+  for (int p = 0; p < sc->n_prims; ++p) {
+    int g = sc->prim_group[p];
+    if (!((mask >> g) & 1)) continue;
+    const double* M = sc->prim_xform + 12 * (size_t)p;
+    /* ray in local coordinates: lstart = M*start, ldir = M*(start+dir)-lstart
+     * (ray.py:348-349) */
+    v3 lstart = xf_point(M, start);
+    v3 ldir = sub(xf_point(M, add(start, dn)), lstart);
+    int flags = sc->prim_flags[p];
+    cand cs[8];
+    int nc = prim_candidates(sc->prim_type[p], sc->prim_params + 4 * (size_t)p,
+                             flags >> ODW_FACEMASK_SHIFT, lstart, ldir, tol, cs);
+    for (int i = 0; i < nc; ++i) {
+      double t = cs[i].t;
+      v3 lp = add(lstart, mul(ldir, t));
+      double dist = len(sub(lp, lstart));
+      /* (vec-lstart).Length > distTol ; on the finite line of length
+       * maxRayLength within distTol (ray.py:424-425) */
+      if (!(t > 0) || !(dist > tol) || !(dist < max_len + tol)) continue;
+      /* trimmed face: CSG conditions (boolean results keep only the part of a
+       * face inside/outside the other operands) */
+      v3 gp = xf_point_inv(M, lp);
+      int ok = 1;
+      for (int c = sc->prim_cond_off[p]; c < sc->prim_cond_off[p + 1] && ok; ++c) {
+        int q = sc->cond_prim[c];
+        v3 qp = xf_point(sc->prim_xform + 12 * (size_t)q, gp);
+        double sd = prim_sdist(sc->prim_type[q], sc->prim_params + 4 * (size_t)q, qp);
+        if (sc->cond_inside[c]) { if (sd > tol) ok = 0; }
+        else { if (sd < -tol) ok = 0; }
+      }
+      if (!ok) continue;
+      v3 nl = cs[i].n_local;
+      if (flags & ODW_FLAG_FLIP_NORMAL) nl = mul(nl, -1.0);
+      /* normal to global: gpM*(p+n) - p_global (ray.py:476) */
+      v3 ng = sub(xf_point_inv(M, add(lp, nl)), gp);
+      nearest_hit h;
+      h.found = 1; h.prim = p; h.face = cs[i].face; h.group = g; h.dist = dist;
+      h.point = gp; h.normal = ng;
+      if (better(dist, p, h.face, any.dist, any.prim, any.face)) any = h;
+      if (g != medium && better(dist, p, h.face, oth.dist, oth.prim, oth.face)) oth = h;
+    }
+  }
+  if (!any.found) return any;
+  /* keep hits closer than min+2*distTol, prefer one whose group is not the
+   * current medium (ray.py:438-452) */
+  if (oth.found && oth.dist < any.dist + 2 * tol) return oth;
+  return any;
+}
+
+/* ------------------------------------------------------------------ */
+/* mirror / snellsLaw / lineGrating (ray.py:482-539)                   */
+/* ------------------------------------------------------------------ */
+static v3 mirror(v3 ray, v3 n) {
+  /* -(2*normal*(ray*normal) - ray) */
+  return mul(sub(mul(n, 2 * dot(ray, n)), ray), -1.0);
+}
+
+static v3 snells_law(v3 ray, double n1, double n2, v3 n, int* total_reflection) {
+  v3 c = cross(n, ray);
+  double s = n1 / n2 * n1 / n2;
+  double root = 1 - dot(mul(c, s), c);
+  if (root < 0) { *total_reflection = 1; return mirror(ray, n); }
+  *total_reflection = 0;
+  v3 inner = cross(mul(n, -1.0), ray);
+  return add(mul(cross(n, inner), n1 / n2), mul(n, sqrt(root)));
+}
+
+static v3 line_grating(v3 ray, double n1, double n2, v3 normal, double wavelength_nm,
+                       int order, double lpm, v3 gdir, int transmission) {
+  double wavelength = wavelength_nm / 1000;
+  ray = mul(ray, 1.0 / len(ray));
+  v3 sn = mul(normal, 1.0 / len(normal));
+  v3 g = mul(gdir, 1.0 / len(gdir));
+  v3 P = cross(g, sn); P = mul(P, 1.0 / len(P));
+  v3 D = cross(sn, P); D = mul(D, 1.0 / len(D));
+  double mu = n1 / n2;
+  double d = 1000 / lpm;
+  double T = (order * wavelength) / (n1 * d);
+  double V_ = (mu * dot(ray, sn)) / dot(sn, sn);
+  double W = (mu * mu - 1 + T * T - 2 * mu * T * dot(ray, D)) / dot(sn, sn);
+  double sq = sqrt((2 * V_) * (2 * V_) - 4 * W);
+  double Q0 = (-2 * V_ + sq) / 2, Q1 = (-2 * V_ - sq) / 2;
+  double Q = transmission ? fmin(Q0, Q1) : fmax(Q0, Q1);
+  v3 S = add(sub(mul(ray, mu), mul(D, T)), mul(sn, Q));
+  return mul(S, -1.0);
+}
+
+/* ------------------------------------------------------------------ */
+/* Ray.traceRay (ray.py:36-281)                                        */
+/* ------------------------------------------------------------------ */
+typedef struct {
+  odw_hit* hits; uint64_t cap; uint64_t n;
+  uint64_t* hist;
+  uint64_t cnt[ODW_CNT_COUNT];
+} sink;
+
+static void record_hit(sink* sk, const odw_detector_desc* det, uint32_t flags,
+                       uint64_t ray, int group, v3 p, v3 d, double power, int entering) {
+  sk->cnt[ODW_CNT_RECORDED_HITS]++;
+  if (flags & ODW_TRACE_RECORD_HITS) {
+    if (sk->n < sk->cap) {
+      odw_hit* h = &sk->hits[sk->n];
+      h->point[0] = p.x; h->point[1] = p.y; h->point[2] = p.z;
+      h->direction[0] = d.x; h->direction[1] = d.y; h->direction[2] = d.z;
+      h->power = power;
+      h->tag = (ray & 0xFFFFFFFFFFFFull) | ((uint64_t)group << 48) | ((uint64_t)(entering != 0) << 63);
+      sk->n++;
+    } else {
+      sk->cnt[ODW_CNT_HITS_DROPPED]++;
+    }
+  }
+  if ((flags & ODW_TRACE_HISTOGRAM) && det && sk->hist && (det->group < 0 || det->group == group)) {
+    v3 r = sub(p, V(det->origin[0], det->origin[1], det->origin[2]));
+    double x = dot(r, V(det->ex[0], det->ex[1], det->ex[2]));
+    double y = dot(r, V(det->ey[0], det->ey[1], det->ey[2]));
+    double fx = floor((x - det->x_lo) * (det->nx / (det->x_hi - det->x_lo)));
+    double fy = floor((y - det->y_lo) * (det->ny / (det->y_hi - det->y_lo)));
+    if (fx >= 0 && fx < det->nx && fy >= 0 && fy < det->ny)
+      sk->hist[(size_t)fx * (size_t)det->ny + (size_t)fy]++;
+    else
+      sk->cnt[ODW_CNT_HIST_OVERFLOW]++;
+  }
+}
+
+static void trace_one(const odw_scene_desc* sc, const odw_limits* lim,
+                      const odw_detector_desc* det, double wavelength, uint32_t flags,
+                      uint64_t ray, v3 point, v3 dir, double power, sink* sk) {
+  int seq = 0, nint = 0, medium = -1;
+  for (;;) {
+    if (nint >= lim->max_intersections) { sk->cnt[ODW_CNT_CAPPED]++; break; }
+    nint++;
+    sk->cnt[ODW_CNT_SEGMENTS]++;
+    nearest_hit h = nearest(sc, lim, point, dir, medium, seq);
+    if (!h.found) { sk->cnt[ODW_CNT_ESCAPED]++; break; }
+    v3 prev = point;
+    int prev_medium = medium;
+    point = h.point;
+    /* absorption in the medium just traversed (ray.py:120-125; assignment,
+     * not multiplication, is the reference's behaviour) */
+    if (prev_medium >= 0) {
+      double L = sc->group_abslen[prev_medium];
+      if (L == 0) power = 0;
+      else if (isfinite(L)) power = exp(-len(sub(prev, point)) / L);
+    }
+    /* getNormal (ray.py:455-480) */
+    v3 n = h.normal;
+    v3 dray = sub(point, prev);
+    double cosangle = dot(dray, n) / (len(dray) * len(n));
+    int entering = cosangle < 0;
+    if (entering) n = mul(n, -1.0);
+    int g = h.group;
+    if (sc->group_record[g]) record_hit(sk, det, flags, ray, g, point, dir, power, entering);
+
+    int type = sc->group_type[g];
+    if (type == ODW_OPT_MIRROR) {
+      dir = mirror(dir, n);
+      power *= sc->group_refl[g];
+      seq++;
+    } else if (type == ODW_OPT_LENS) {
+      double n1, n2;
+      if (entering) {
+        n1 = (medium >= 0) ? sc->group_ior[medium] : 1.0;
+        medium = g;
+        n2 = sc->group_ior[g];
+      } else {
+        n1 = (medium >= 0) ? sc->group_ior[medium] : 1.0;
+        n2 = 1.0;
+      }
+      int tir;
+      dir = snells_law(mul(dir, 1.0 / len(dir)), n1, n2, n, &tir);
+      if (!entering && !tir && medium == g) { medium = -1; seq++; }
+    } else if (type == ODW_OPT_GRATING) {
+      v3 gd = V(sc->group_grating_dir[3 * g], sc->group_grating_dir[3 * g + 1],
+                sc->group_grating_dir[3 * g + 2]);
+      if (sc->group_grating_type[g] == 0) { /* reflection */
+        if (entering) {
+          double nn = (medium >= 0) ? sc->group_ior[medium] : 1.0;
+          dir = line_grating(mul(dir, 1.0 / len(dir)), nn, nn, n, wavelength,
+                             sc->group_grating_order[g], sc->group_grating_lpm[g], gd, 0);
+          seq++;
+        }
+      } else { /* transmission */
+        if (entering) {
+          /* the reference raises ValueError if medium is not None; the host
+           * validates scenes for that, here the ray is simply stopped */
+          if (medium >= 0) { sk->cnt[ODW_CNT_DIED]++; break; }
+          medium = g;
+          dir = line_grating(mul(dir, 1.0 / len(dir)), 1.0, sc->group_ior[g], n, wavelength,
+                             sc->group_grating_order[g], sc->group_grating_lpm[g], gd, 1);
+        } else {
+          double n1 = (medium >= 0) ? sc->group_ior[medium] : 1.0;
+          int tir;
+          dir = snells_law(mul(dir, 1.0 / len(dir)), n1, 1.0, n, &tir);
+          if (!tir) { medium = -1; seq++; }
+        }
+      }
+    } else if (type == ODW_OPT_ABSORBER) {
+      power = 0;
+      seq++;
+    } else if (type == ODW_OPT_VACUUM) {
+      seq++;
+    }
+    if (power < lim->power_tol) { sk->cnt[ODW_CNT_DIED]++; break; }
+  }
+  sk->cnt[ODW_CNT_TRACED_RAYS]++;
+}
+
+/* ------------------------------------------------------------------ */
+/* public entry points                                                 */
+/* ------------------------------------------------------------------ */
+#define CHUNK 4096
+
+static int run(const odw_scene_desc* sc, const odw_source_desc* src, const odw_limits* lim,
+               const odw_detector_desc* det, uint64_t first, uint64_t n, uint64_t seed,
+               const double* origins, const double* dirs, const double* powers,
+               uint32_t flags, odw_hit* hits, uint64_t cap, uint64_t* n_hits,
+               uint64_t* hist, uint64_t* counters, int nthreads) {
+  if (!sc || !lim || sc->n_groups > ODW_MAX_GROUPS) return ODW_ERR_INVALID;
+  if (!origins && !src) return ODW_ERR_INVALID;
+  uint64_t nchunks = (n + CHUNK - 1) / CHUNK;
+  size_t nbins = det ? (size_t)det->nx * (size_t)det->ny : 0;
+  /* per-chunk private hit lists keep the output in ray order under OpenMP */
+  odw_hit** chunk_hits = (odw_hit**)calloc(nchunks ? nchunks : 1, sizeof(odw_hit*));
+  uint64_t* chunk_n = (uint64_t*)calloc(nchunks ? nchunks : 1, sizeof(uint64_t));
+  uint64_t total[ODW_CNT_COUNT] = {0};
+  int max_hits_per_ray = lim->max_intersections > 0 ? lim->max_intersections : 1;
+  (void)nthreads;
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#pragma omp parallel
+#endif
+  {
+    uint64_t* lhist = (nbins && hist && (flags & ODW_TRACE_HISTOGRAM)) ? (uint64_t*)calloc(nbins, sizeof(uint64_t)) : NULL;
+    uint64_t lcnt[ODW_CNT_COUNT] = {0};
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+    for (int64_t ci = 0; ci < (int64_t)nchunks; ++ci) {
+      uint64_t b = (uint64_t)ci * CHUNK, e = b + CHUNK < n ? b + CHUNK : n;
+      sink sk;
+      memset(&sk, 0, sizeof sk);
+      sk.hist = lhist;
+      if (flags & ODW_TRACE_RECORD_HITS) {
+        sk.cap = 64; /* grows */
+        sk.hits = (odw_hit*)malloc(sk.cap * sizeof(odw_hit));
+      }
+      for (uint64_t i = b; i < e; ++i) {
+        if ((flags & ODW_TRACE_RECORD_HITS) && sk.cap - sk.n < (uint64_t)max_hits_per_ray) {
+          sk.cap = sk.cap * 2 + (uint64_t)max_hits_per_ray;
+          sk.hits = (odw_hit*)realloc(sk.hits, sk.cap * sizeof(odw_hit));
+        }
+        v3 o, d;
+        double pw;
+        if (origins) {
+          o = V(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]);
+          d = V(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
+          pw = powers ? powers[i] : 1.0;
+        } else {
+          double up, ut, t, phi;
+          ray_uniforms(first + i, seed, &up, &ut);
+          sample_one(src, up, ut, &t, &phi);
+          make_ray(src, t, phi, &o, &d);
+          pw = src->power;
+        }
+        trace_one(sc, lim, det, src ? src->wavelength : 500.0, flags, first + i, o, d, pw, &sk);
+      }
+      chunk_hits[ci] = sk.hits;
+      chunk_n[ci] = sk.n;
+      for (int k = 0; k < ODW_CNT_COUNT; ++k) lcnt[k] += sk.cnt[k];
+    }
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+    {
+      for (int k = 0; k < ODW_CNT_COUNT; ++k) total[k] += lcnt[k];
+      if (lhist) for (size_t i = 0; i < nbins; ++i) hist[i] += lhist[i];
+    }
+    free(lhist);
+  }
+  uint64_t nh = 0, dropped = 0;
+  for (uint64_t ci = 0; ci < nchunks; ++ci) {
+    for (uint64_t k = 0; k < chunk_n[ci]; ++k) {
+      if (hits && nh < cap) hits[nh++] = chunk_hits[ci][k];
+      else dropped++;
+    }
+    free(chunk_hits[ci]);
+  }
+  free(chunk_hits); free(chunk_n);
+  total[ODW_CNT_HITS_DROPPED] += dropped;
+  if (n_hits) *n_hits = nh;
+  if (counters) for (int k = 0; k < ODW_CNT_COUNT; ++k) counters[k] += total[k];
+  return ODW_OK;
+}
+
+int odw_oracle_trace(const odw_scene_desc* sc, const odw_source_desc* src,
+                     const odw_limits* lim, const odw_detector_desc* det,
+                     uint64_t first, uint64_t n, uint64_t seed, uint32_t flags,
+                     odw_hit* hits, uint64_t cap, uint64_t* n_hits, uint64_t* hist,
+                     uint64_t* counters, int nthreads) {
+  return run(sc, src, lim, det, first, n, seed, NULL, NULL, NULL, flags, hits, cap, n_hits,
+             hist, counters, nthreads);
+}
+
+int odw_oracle_trace_rays(const odw_scene_desc* sc, const odw_limits* lim,
+                          const odw_detector_desc* det, double wavelength,
+                          uint64_t first, uint64_t n, const double* origins,
+                          const double* dirs, const double* powers, uint32_t flags,
+                          odw_hit* hits, uint64_t cap, uint64_t* n_hits, uint64_t* hist,
+                          uint64_t* counters, int nthreads) {
+  odw_source_desc s;
+  memset(&s, 0, sizeof s);
+  s.wavelength = wavelength;
+  s.power = 1.0;
+  return run(sc, &s, lim, det, first, n, 0, origins, dirs, powers, flags, hits, cap, n_hits,
+             hist, counters, nthreads);
+}
+
+/* initial conditions only: origin/direction of sampled rays (pins _makeRay) */
+int odw_oracle_make_rays(const odw_source_desc* src, uint64_t first, uint64_t n,
+                         uint64_t seed, double* origins, double* dirs) {
+  for (uint64_t i = 0; i < n; ++i) {
+    double up, ut, t, phi;
+    v3 o, d;
+    ray_uniforms(first + i, seed, &up, &ut);
+    sample_one(src, up, ut, &t, &phi);
+    make_ray(src, t, phi, &o, &d);
+    origins[3 * i] = o.x; origins[3 * i + 1] = o.y; origins[3 * i + 2] = o.z;
+    dirs[3 * i] = d.x; dirs[3 * i + 1] = d.y; dirs[3 * i + 2] = d.z;
+  }
+  return ODW_OK;
+}
+
+/* single nearest-hit query, for unit tests of the geometry */
+int odw_oracle_nearest(const odw_scene_desc* sc, const odw_limits* lim, const double* start,
+                       const double* dir, int medium, int seq_idx, int* prim, int* face,
+                       int* group, double* dist, double* point, double* normal) {
+  nearest_hit h = nearest(sc, lim, V(start[0], start[1], start[2]), V(dir[0], dir[1], dir[2]),
+                          medium, seq_idx);
+  if (!h.found) return 0;
+  *prim = h.prim; *face = h.face; *group = h.group; *dist = h.dist;
+  point[0] = h.point.x; point[1] = h.point.y; point[2] = h.point.z;
+  normal[0] = h.normal.x; normal[1] = h.normal.y; normal[2] = h.normal.z;
+  return 1;
+}
+
+int odw_oracle_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}

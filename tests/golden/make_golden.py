@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Generate golden vectors from the REFERENCE's own Python code.
+
+Run in the authoring container only (needs /root/reference):
+    python tests/golden/make_golden.py
+
+What it does: loads three reference modules *in memory* --
+  distributions/random_number_generator.py   (the Monte-Carlo sampler, A5/A6)
+  distributions/points_by_density.py          (fan-mode grid helper)
+  jupyter_utils/hits.py + histogram.py        (detector binning, A19)
+-- under stub parent packages so that the package __init__ (which needs
+FreeCAD-side dependencies) is bypassed.  random_number_generator.py uses
+three Python-3.11 star-subscripts (lines 438, 650, 651); the text is patched
+in memory before exec because this container runs Python 3.10.  No reference
+source or bytecode is written anywhere; only inputs and outputs (numpy
+arrays) are saved as .npz fixtures next to this script.
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = '/root/reference/freecad/optics_design_workbench'
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _stub(name):
+  m = types.ModuleType(name)
+  m.__path__ = []
+  sys.modules[name] = m
+  return m
+
+
+def load_reference_modules():
+  import matplotlib
+  matplotlib.use('Agg')
+  for n in ('freecad', 'freecad.optics_design_workbench',
+            'freecad.optics_design_workbench.distributions',
+            'freecad.optics_design_workbench.jupyter_utils'):
+    _stub(n)
+  # seaborn is imported by hits.py/histogram.py for plotting only
+  if 'seaborn' not in sys.modules:
+    try:
+      import seaborn  # noqa: F401
+    except ImportError:
+      sys.modules['seaborn'] = types.ModuleType('seaborn')
+
+  def load(modname, relpath, patch=None):
+    full = 'freecad.optics_design_workbench.' + modname
+    path = os.path.join(REF, relpath)
+    if patch is None:
+      spec = importlib.util.spec_from_file_location(full, path)
+      mod = importlib.util.module_from_spec(spec)
+      sys.modules[full] = mod
+      spec.loader.exec_module(mod)
+    else:
+      src = patch(open(path).read())
+      mod = types.ModuleType(full)
+      mod.__package__ = full.rsplit('.', 1)[0]
+      mod.__file__ = path
+      sys.modules[full] = mod
+      exec(compile(src, path, 'exec'), mod.__dict__)
+    parent, _, leaf = full.rpartition('.')
+    setattr(sys.modules[parent], leaf, mod)
+    return mod
+
+  io = load('io', 'io.py')
+  # logging needs the simulation package (FreeCAD side); discretisation
+  # warnings are irrelevant here
+  for fn in ('info', 'verb', 'warn', 'err'):
+    setattr(io, fn, lambda *a, **k: None)
+  pbd = load('distributions.points_by_density', 'distributions/points_by_density.py')
+
+  def patch_rng(s):
+    a = '_gridProbsCol = gridProbs[*index,:]'
+    b = '_gridProbsCol = gridProbs[tuple(index)+(slice(None),)]'
+    assert a in s
+    s = s.replace(a, b)
+    # lines 650/651 (drawPseudo) use the same 3.11 syntax
+    import re
+    s, n = re.subn(r'\[\*([A-Za-z_]+),\s*:\]', r'[tuple(\1)+(slice(None),)]', s)
+    s, n1 = re.subn(r'\[\.\.\.,\s*\*([A-Za-z_]+)\]', r'[(Ellipsis,)+tuple(\1)]', s)
+    s, n2 = re.subn(r'\[\*([A-Za-z_]+)\]', r'[tuple(\1)]', s)
+    return s
+
+  rng = load('distributions.random_number_generator',
+             'distributions/random_number_generator.py', patch=patch_rng)
+  hist = load('jupyter_utils.histogram', 'jupyter_utils/histogram.py')
+  hits = load('jupyter_utils.hits', 'jupyter_utils/hits.py')
+  return io, pbd, rng, hist, hits
+
+
+# (name, density in theta/phi AFTER the *abs(sin(theta)) Jacobian of
+#  point_source.py:299, theta domain, phi domain, theta res, phi res)
+SAMPLER_CASES = [
+  ('c3_sigma1e-2', '(exp(-theta**2/(1e-2)**2))*abs(sin(theta))', (0, np.pi / 4), (0, 2 * np.pi), 1e5, 1e2),
+  ('c5_sigma0p1', '(exp(-theta^2/0.01))*abs(sin(theta))', (0, np.pi / 4), (0, 2 * np.pi), 1e5, 1e2),
+  ('c4_sigma0p2', '(exp(-theta**2/(.2)**2))*abs(sin(theta))', (0, np.pi / 4), (0, 2 * np.pi), 1e5, 1e2),
+  ('phidep', '(exp(-theta**2/0.3**2)*(1.5+cos(2*phi)))*abs(sin(theta))', (0, 1.0), (0, 2 * np.pi), 2001, 41),
+  ('astig', '(exp(-(theta*cos(phi))**2/0.05**2-(theta*sin(phi))**2/0.2**2))*abs(sin(theta))',
+   (0, 0.6), (-np.pi, np.pi), 4001, 61),
+]
+
+
+def make_sampler(rng):
+  N = 4096
+  for name, dens, tdom, pdom, tres, pres in SAMPLER_CASES:
+    vrv = rng.VectorRandomVariable(
+        probabilityDensity=dens, variableOrder=('theta', 'phi'),
+        variableDomains=dict(theta=tdom, phi=pdom),
+        numericalResolutions=dict(theta=tres, phi=pres))
+    vrv.compile(disableAnalytical=True)
+    assert vrv.mode() == 'numeric'
+    out = {}
+    for seed in (1, 2):
+      np.random.seed(seed)
+      th, ph = vrv.draw(N=N)
+      np.random.seed(seed)
+      u_phi = np.random.random_sample(N)
+      _ = np.random.random_sample(N)
+      u_th = np.random.random_sample(N)
+      out[f'theta_seed{seed}'] = np.asarray(th, dtype=np.float64)
+      out[f'phi_seed{seed}'] = np.asarray(ph, dtype=np.float64)
+      out[f'u_phi_seed{seed}'] = u_phi
+      out[f'u_theta_seed{seed}'] = u_th
+    # tables: transform lambdas hold them in closure defaults
+    lam_theta = vrv._transformLambdas[0][0][0]
+    lam_phi = vrv._transformLambdas[1][0][0]
+    kw_t = lam_theta.__kwdefaults__ or {}
+    kw_p = lam_phi.__kwdefaults__ or {}
+    if not kw_t:
+      # defaults are positional-with-default after *params -> keyword-only
+      raise RuntimeError('could not read tables from reference closure')
+    gp_t = np.array(kw_t['gridProbs'], dtype=np.float64)       # (nphi-1, ntheta) normalised rows that were used
+    gp_p = np.array(kw_p['gridProbs'], dtype=np.float64)       # (nphi,)
+    edges_t = np.array(kw_t['variableRanges'][0], dtype=np.float64)
+    edges_p = np.array(kw_t['variableRanges'][1], dtype=np.float64)
+    step = max(1, (gp_t.shape[1] - 1) // 1000)
+    idx = np.unique(np.concatenate([np.arange(0, gp_t.shape[1], step), [gp_t.shape[1] - 1]]))
+    rows = np.unique(np.concatenate([np.arange(0, gp_t.shape[0], max(1, gp_t.shape[0] // 10)), [gp_t.shape[0] - 1]]))
+    # rows of the reference table are normalised lazily, in place, on first
+    # use (random_number_generator.py:441); normalise a copy here for all rows
+    gp_t_n = gp_t / gp_t[:, -1:]
+    out.update(dict(
+        density=np.array(dens), theta_domain=np.array(tdom), phi_domain=np.array(pdom),
+        theta_res=np.array(tres), phi_res=np.array(pres),
+        knot_index=idx, row_index=rows,
+        theta_cdf_knots=gp_t_n[np.ix_(rows, idx)], theta_edges_knots=edges_t[idx],
+        phi_cdf=gp_p / gp_p[-1], phi_edges=edges_p,
+        n_theta_knots=np.array(gp_t.shape[1]), n_rows=np.array(gp_t.shape[0])))
+    np.savez_compressed(os.path.join(OUT, f'sampler_{name}.npz'), **out)
+    print('sampler', name, 'theta knots', gp_t.shape, 'mean theta', float(np.mean(out['theta_seed1'])))
+
+
+def make_fan_grid(rng):
+  # ScalarRandomVariable.findGrid (fan mode, random_number_generator.py:685-725)
+  out = {}
+  cases = [
+    ('stitched_c1', 'exp(-Abs(theta)**2/(1e-2)**2)', (-np.pi / 4, np.pi / 4), 1e5, 20),
+    ('signchange', 'exp(-theta**2/0.1**2)', (-0.3, 0.5), 1e4 + 1, 15),
+    ('gapped', 'exp(-theta**2/0.2**2)', (0.05, 0.4), 1e4 + 1, 10),
+  ]
+  for name, dens, dom, res, N in cases:
+    srv = rng.ScalarRandomVariable(probabilityDensity=dens, variable='theta',
+                                   variableDomain=dom, numericalResolution=res)
+    srv.compile()
+    g = np.asarray(srv.findGrid(N=N), dtype=np.float64)
+    out[name + '_grid'] = g
+    out[name + '_density'] = np.array(dens)
+    out[name + '_domain'] = np.array(dom)
+    out[name + '_res'] = np.array(res)
+    out[name + '_N'] = np.array(N)
+    out[name + '_mode'] = np.array(srv.mode())
+    print('fan grid', name, srv.mode(), g[:3], g[-3:])
+  np.savez_compressed(os.path.join(OUT, 'fan_grid.npz'), **out)
+
+
+def make_hist(hits_mod):
+  rs = np.random.RandomState(7)
+  out = {}
+  # case A: gaussian spot on a plane z=const, rays along +z
+  n = 20000
+  pts = np.stack([rs.normal(0.3, 1.0, n), rs.normal(-0.2, 0.5, n), np.full(n, 20.0)], axis=1)
+  dirs = np.tile(np.array([0.01, -0.02, 1.0]) / np.linalg.norm([0.01, -0.02, 1.0]), (n, 1))
+  # case B: tilted plane, normal (1,1,2)/sqrt6
+  nrm = np.array([1.0, 1.0, 2.0]) / np.sqrt(6)
+  ex = np.cross(nrm, [0, 0, 1.0]); ex /= np.linalg.norm(ex)
+  ey = np.cross(nrm, ex)
+  uv = rs.normal(0, 1, (n, 2)) * np.array([2.0, 0.7])
+  ptsB = np.array([5.0, -3.0, 40.0]) + uv[:, :1] * ex + uv[:, 1:] * ey
+  dirsB = np.tile(nrm, (n, 1)) + rs.normal(0, 0.01, (n, 3))
+  for tag, P, D in (('A', pts, dirs), ('B', ptsB, dirsB)):
+    for kind, kwargs in (('cart30', dict(bins=30)),
+                         ('polar3x50', dict(bins=(3, 50), binCoords='polar')),
+                         ('cartlin', dict(bins=[np.linspace(-2, 2, 41), np.linspace(-1, 1, 21)]))):
+      h = hits_mod.Hits(dict(points=P.copy(), directions=D.copy(),
+                             powers=np.ones(len(P)), isEntering=np.ones(len(P), dtype=int)))
+      H = h.histogram(**kwargs)
+      key = f'{tag}_{kind}'
+      out[key + '_hist'] = np.asarray(H.hist)
+      out[key + '_binX'] = np.asarray(H.binX)
+      out[key + '_binY'] = np.asarray(H.binY)
+      out[key + '_normal'] = np.asarray(H._planeNormal)
+      out[key + '_xvec'] = np.asarray(H._xInPlaneVec)
+      out[key + '_origin'] = np.asarray(H._origin)
+      if kind.startswith('polar'):
+        phi, r, dens = H.byAzimuth()
+        out[key + '_az_phi'] = phi; out[key + '_az_r'] = r; out[key + '_az_dens'] = dens
+        out[key + '_binAreas'] = np.asarray(H.binAreas)
+    out[tag + '_points'] = P
+    out[tag + '_directions'] = D
+  np.savez_compressed(os.path.join(OUT, 'hist_cases.npz'), **out)
+  print('hist cases written;', {k: out[k] for k in out if k.endswith('cart30_normal')})
+
+
+if __name__ == '__main__':
+  io, pbd, rng, hist, hits = load_reference_modules()
+  make_sampler(rng)
+  make_fan_grid(rng)
+  make_hist(hits)
