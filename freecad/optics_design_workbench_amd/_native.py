@@ -1,0 +1,171 @@
+"""ctypes binding of the HIP library (csrc/libodw_trace.so, include/odw_trace.h).
+
+There is no CPU fallback: if the library is missing or no GPU is present the
+calls raise.  `build()` compiles the library in-tree with hipcc for gfx950
+(cross-compiles without a GPU).
+"""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, 'csrc')
+LIB_PATH = os.path.join(CSRC, 'libodw_trace.so')
+_SOURCES = ['odw_capi.hip', 'odw_kernels.hip', 'odw_device.h']
+_HEADER = os.path.normpath(os.path.join(_HERE, '..', '..', 'include', 'odw_trace.h'))
+
+ABI_VERSION = 1
+CNT_NAMES = ['traced_rays', 'recorded_hits', 'segments', 'escaped', 'died', 'capped',
+             'hist_overflow', 'hits_dropped']
+TRACE_RECORD_HITS, TRACE_HISTOGRAM = 1, 2
+ERRORS = {1: 'invalid argument', 2: 'device error', 3: 'no scene', 4: 'capacity', 5: 'unsupported'}
+
+HIT_DTYPE = np.dtype([('point', '<f8', 3), ('direction', '<f8', 3), ('power', '<f8'), ('tag', '<u8')])
+
+# every symbol include/odw_trace.h declares
+SYMBOLS = ['odw_abi_version', 'odw_create', 'odw_destroy', 'odw_last_error', 'odw_upload_scene',
+           'odw_upload_source', 'odw_set_limits', 'odw_set_detector', 'odw_reserve_hits', 'odw_trace',
+           'odw_trace_rays', 'odw_sync', 'odw_reset_results', 'odw_fetch_counters', 'odw_hit_count',
+           'odw_fetch_hits', 'odw_fetch_histogram', 'odw_sample', 'odw_device_histogram',
+           'odw_device_counters', 'odw_stream', 'odw_timing_enable', 'odw_timing_read']
+
+_pd = C.POINTER(C.c_double)
+_pi = C.POINTER(C.c_int32)
+_pu = C.POINTER(C.c_uint64)
+
+
+class SceneDesc(C.Structure):
+  _fields_ = [('n_prims', C.c_int32), ('prim_type', _pi), ('prim_group', _pi), ('prim_solid', _pi),
+              ('prim_flags', _pi), ('prim_xform', _pd), ('prim_params', _pd), ('prim_cond_off', _pi),
+              ('n_conds', C.c_int32), ('cond_prim', _pi), ('cond_inside', _pi),
+              ('n_groups', C.c_int32), ('group_type', _pi), ('group_ior', _pd), ('group_refl', _pd),
+              ('group_abslen', _pd), ('group_record', _pi), ('group_grating_type', _pi),
+              ('group_grating_lpm', _pd), ('group_grating_dir', _pd), ('group_grating_order', _pi),
+              ('seq_enabled', C.c_int32), ('seq_len', C.c_int32), ('seq_mask', _pu),
+              ('ignore_mask', C.c_uint64)]
+
+
+class SourceDesc(C.Structure):
+  _fields_ = [('xform', C.c_double * 12), ('focal_length', C.c_double), ('wavelength', C.c_double),
+              ('power', C.c_double), ('n_phi_knots', C.c_int32), ('phi_edges', _pd), ('phi_cdf', _pd),
+              ('n_t_knots', C.c_int32), ('n_t_rows', C.c_int32), ('t_edges', _pd), ('t_cdf', _pd)]
+
+
+class LimitsDesc(C.Structure):
+  _fields_ = [('max_ray_length', C.c_double), ('max_intersections', C.c_int32),
+              ('dist_tol', C.c_double), ('power_tol', C.c_double)]
+
+
+class DetectorDesc(C.Structure):
+  _fields_ = [('group', C.c_int32), ('origin', C.c_double * 3), ('ex', C.c_double * 3),
+              ('ey', C.c_double * 3), ('x_lo', C.c_double), ('x_hi', C.c_double),
+              ('y_lo', C.c_double), ('y_hi', C.c_double), ('nx', C.c_int32), ('ny', C.c_int32)]
+
+
+class NativeError(RuntimeError):
+  pass
+
+
+def hipcc():
+  for cand in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', shutil.which('hipcc')):
+    if cand and os.path.exists(cand):
+      return cand
+  raise NativeError('hipcc not found; the HIP library cannot be built')
+
+
+def needs_build():
+  if not os.path.exists(LIB_PATH):
+    return True
+  t = os.path.getmtime(LIB_PATH)
+  deps = [os.path.join(CSRC, s) for s in _SOURCES] + [_HEADER]
+  return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=False):
+  """compile csrc/ for gfx950 into csrc/libodw_trace.so"""
+  if not force and not needs_build():
+    return LIB_PATH
+  cmd = [hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
+         '-o', LIB_PATH + '.tmp', os.path.join(CSRC, 'odw_capi.hip')]
+  if verbose:
+    cmd.insert(1, '-Rpass-analysis=kernel-resource-usage')
+  res = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
+  if res.returncode != 0:
+    raise NativeError('hipcc failed:\n' + res.stdout + res.stderr)
+  os.replace(LIB_PATH + '.tmp', LIB_PATH)
+  if verbose:
+    print(res.stderr)
+  return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+  """the loaded library; raises if it is absent (no fallback)"""
+  global _lib
+  if _lib is None:
+    if not os.path.exists(LIB_PATH):
+      raise NativeError(f'{LIB_PATH} is missing: run __graft_entry__.build() '
+                        f'(or freecad.optics_design_workbench_amd._native.build()) first')
+    l = C.CDLL(LIB_PATH)
+    l.odw_last_error.restype = C.c_char_p
+    l.odw_last_error.argtypes = [C.c_void_p]
+    l.odw_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    l.odw_destroy.argtypes = [C.c_void_p]
+    l.odw_destroy.restype = None
+    for name in SYMBOLS:
+      getattr(l, name)
+    if l.odw_abi_version() != ABI_VERSION:
+      raise NativeError('libodw_trace.so ABI version mismatch; rebuild')
+    _lib = l
+  return _lib
+
+
+def check(ctx, rc, what):
+  if rc != 0:
+    msg = lib().odw_last_error(ctx)
+    raise NativeError(f'{what}: {ERRORS.get(rc, rc)}: {msg.decode() if msg else ""}')
+
+
+def _arr(a, dtype):
+  return np.ascontiguousarray(a, dtype=dtype)
+
+
+def scene_desc(sc):
+  keep = dict(
+      prim_type=_arr(sc.prim_type, np.int32), prim_group=_arr(sc.prim_group, np.int32),
+      prim_solid=_arr(sc.prim_solid, np.int32), prim_flags=_arr(sc.prim_flags, np.int32),
+      prim_xform=_arr(sc.prim_xform, np.float64), prim_params=_arr(sc.prim_params, np.float64),
+      prim_cond_off=_arr(sc.prim_cond_off, np.int32), cond_prim=_arr(sc.cond_prim, np.int32),
+      cond_inside=_arr(sc.cond_inside, np.int32), group_type=_arr(sc.group_type, np.int32),
+      group_ior=_arr(sc.group_ior, np.float64), group_refl=_arr(sc.group_refl, np.float64),
+      group_abslen=_arr(sc.group_abslen, np.float64), group_record=_arr(sc.group_record, np.int32),
+      group_grating_type=_arr(sc.group_grating_type, np.int32),
+      group_grating_lpm=_arr(sc.group_grating_lpm, np.float64),
+      group_grating_dir=_arr(sc.group_grating_dir, np.float64),
+      group_grating_order=_arr(sc.group_grating_order, np.int32),
+      seq_mask=_arr(sc.seq_mask, np.uint64))
+  d = SceneDesc()
+  d.n_prims, d.n_conds, d.n_groups = len(keep['prim_type']), len(keep['cond_prim']), len(keep['group_type'])
+  for name, typ in SceneDesc._fields_:
+    if name in keep:
+      setattr(d, name, keep[name].ctypes.data_as(typ))
+  d.seq_enabled, d.seq_len, d.ignore_mask = int(sc.seq_enabled), len(keep['seq_mask']), int(sc.ignore_mask)
+  return d, keep
+
+
+def source_desc(src):
+  t = src.tables
+  keep = dict(phi_edges=_arr(t.phi_edges, np.float64), phi_cdf=_arr(t.phi_cdf, np.float64),
+              t_edges=_arr(t.t_edges, np.float64), t_cdf=_arr(t.t_cdf, np.float64).reshape(-1, len(t.t_edges)))
+  d = SourceDesc()
+  d.xform = (C.c_double * 12)(*np.asarray(src.xform, dtype=np.float64).reshape(12))
+  d.focal_length, d.wavelength, d.power = float(src.focal_length), float(src.wavelength), float(src.power)
+  d.n_phi_knots, d.n_t_knots, d.n_t_rows = len(keep['phi_edges']), len(keep['t_edges']), keep['t_cdf'].shape[0]
+  for name in keep:
+    setattr(d, name, keep[name].ctypes.data_as(_pd))
+  return d, keep

@@ -1,0 +1,679 @@
+// odw_capi.hip -- C-ABI (include/odw_trace.h) over the gfx950 kernels.
+//
+// Host side of the native library: device context, scene/source upload into
+// the HBM layouts of odw_device.h, BVH build for big scenes, inverse-CDF
+// guide tables, launches on a private HIP stream, HIP-event timing, result
+// fetch.  No torch types anywhere: plain pointers and sizes.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "odw_kernels.hip"
+
+using namespace odw;
+
+namespace {
+
+constexpr int kGuide = 1 << 16;
+constexpr int kBvhThreshold = 16;  // brute force (scalar loads) below this many primitives
+constexpr int kBvhLeaf = 2;
+
+std::string g_error;
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+}  // namespace
+
+struct odw_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int n_cu = 256;
+  std::string err;
+
+  // host copies needed for lazy (re)builds
+  std::vector<double> h_prim_f64;
+  std::vector<int32_t> h_prim_i32;
+  bool have_scene = false, have_source = false, have_limits = false;
+  bool bvh_dirty = true;
+
+  DevBuf prim_f64, prim_i32, cond_i32, group_f64, group_i32, group_gdir, seq_mask;
+  DevBuf bvh_box, bvh_link, bvh_prims;
+  DevBuf phi_tab, t_tab, t_guide;
+  DevBuf hits, hit_count, hist, counters;
+  DevBuf ray_o, ray_d, ray_p, samp_t, samp_phi;
+  uint64_t hit_capacity = 0, n_bins = 0;
+
+  TraceParams P;
+  odw_detector_desc det_desc;
+
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
+  double timing_ms = 0;
+  uint64_t timing_launches = 0;
+};
+
+namespace {
+
+int fail(odw_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->err = msg;
+  g_error = msg;
+  return code;
+}
+
+#define HIPCHK(ctx, call)                                                              \
+  do {                                                                                 \
+    hipError_t e_ = (call);                                                            \
+    if (e_ != hipSuccess)                                                              \
+      return fail(ctx, ODW_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+int ensure(odw_ctx* ctx, DevBuf& b, size_t bytes) {
+  if (bytes == 0) bytes = 16;
+  if (b.bytes >= bytes && b.p) return ODW_OK;
+  if (b.p) HIPCHK(ctx, hipFree(b.p));
+  b.p = nullptr;
+  b.bytes = 0;
+  HIPCHK(ctx, hipMalloc(&b.p, bytes));
+  b.bytes = bytes;
+  return ODW_OK;
+}
+
+int upload(odw_ctx* ctx, DevBuf& b, const void* src, size_t bytes) {
+  int rc = ensure(ctx, b, bytes);
+  if (rc) return rc;
+  if (bytes) HIPCHK(ctx, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return ODW_OK;
+}
+
+void release(DevBuf& b) {
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.bytes = 0;
+}
+
+// ---- primitive bounding boxes in global coordinates -----------------------
+void local_bounds(int type, const double* par, double lo[3], double hi[3]) {
+  switch (type) {
+    case ODW_PRIM_BOX:
+      lo[0] = lo[1] = lo[2] = 0; hi[0] = par[0]; hi[1] = par[1]; hi[2] = par[2];
+      break;
+    case ODW_PRIM_SPHERE:
+      for (int i = 0; i < 3; ++i) { lo[i] = -par[0]; hi[i] = par[0]; }
+      break;
+    case ODW_PRIM_CYLINDER:
+      lo[0] = lo[1] = -par[0]; hi[0] = hi[1] = par[0]; lo[2] = 0; hi[2] = par[1];
+      break;
+    case ODW_PRIM_CONE: {
+      const double r = std::max(par[0], par[1]);
+      lo[0] = lo[1] = -r; hi[0] = hi[1] = r; lo[2] = 0; hi[2] = par[2];
+      break;
+    }
+    default: {
+      const double r = par[0] + par[1];
+      lo[0] = lo[1] = -r; hi[0] = hi[1] = r; lo[2] = -par[1]; hi[2] = par[1];
+    }
+  }
+}
+
+struct Box {
+  double lo[3], hi[3];
+  void reset() { for (int i = 0; i < 3; ++i) { lo[i] = INFINITY; hi[i] = -INFINITY; } }
+  void grow(const Box& o) {
+    for (int i = 0; i < 3; ++i) { lo[i] = std::min(lo[i], o.lo[i]); hi[i] = std::max(hi[i], o.hi[i]); }
+  }
+};
+
+Box world_box(const double* pf, int type, double slack) {
+  double lo[3], hi[3];
+  local_bounds(type, pf + 12, lo, hi);
+  Box b;
+  b.reset();
+  for (int c = 0; c < 8; ++c) {
+    const double l[3] = {(c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2]};
+    // global = R^T (local - t)
+    const double d[3] = {l[0] - pf[3], l[1] - pf[7], l[2] - pf[11]};
+    const double g[3] = {pf[0] * d[0] + pf[4] * d[1] + pf[8] * d[2],
+                         pf[1] * d[0] + pf[5] * d[1] + pf[9] * d[2],
+                         pf[2] * d[0] + pf[6] * d[1] + pf[10] * d[2]};
+    for (int i = 0; i < 3; ++i) { b.lo[i] = std::min(b.lo[i], g[i]); b.hi[i] = std::max(b.hi[i], g[i]); }
+  }
+  for (int i = 0; i < 3; ++i) {
+    const double s = slack + 1e-9 * (std::fabs(b.lo[i]) + std::fabs(b.hi[i]));
+    b.lo[i] -= s;
+    b.hi[i] += s;
+  }
+  return b;
+}
+
+struct BvhBuilder {
+  const std::vector<Box>& boxes;
+  std::vector<int> order;
+  std::vector<double> node_box;
+  std::vector<int32_t> node_link;
+  int max_depth = 0;
+
+  explicit BvhBuilder(const std::vector<Box>& b) : boxes(b) {
+    order.resize(b.size());
+    for (size_t i = 0; i < b.size(); ++i) order[i] = (int)i;
+  }
+
+  int build(int first, int count, int depth) {
+    max_depth = std::max(max_depth, depth);
+    const int id = (int)(node_link.size() / 4);
+    node_box.resize(node_box.size() + 6);
+    node_link.resize(node_link.size() + 4);
+    Box bb, cb;
+    bb.reset();
+    cb.reset();
+    for (int i = first; i < first + count; ++i) {
+      const Box& b = boxes[order[i]];
+      bb.grow(b);
+      for (int a = 0; a < 3; ++a) {
+        const double c = 0.5 * (b.lo[a] + b.hi[a]);
+        cb.lo[a] = std::min(cb.lo[a], c);
+        cb.hi[a] = std::max(cb.hi[a], c);
+      }
+    }
+    for (int a = 0; a < 3; ++a) { node_box[6 * id + a] = bb.lo[a]; node_box[6 * id + 3 + a] = bb.hi[a]; }
+    int axis = 0;
+    for (int a = 1; a < 3; ++a)
+      if (cb.hi[a] - cb.lo[a] > cb.hi[axis] - cb.lo[axis]) axis = a;
+    if (count <= kBvhLeaf || !(cb.hi[axis] > cb.lo[axis])) {
+      node_link[4 * id] = ~first;
+      node_link[4 * id + 1] = count;
+      node_link[4 * id + 2] = 0;
+      node_link[4 * id + 3] = 0;
+      return id;
+    }
+    const int mid = first + count / 2;
+    std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + first + count,
+                     [&](int x, int y) {
+                       const double cx = boxes[x].lo[axis] + boxes[x].hi[axis];
+                       const double cy = boxes[y].lo[axis] + boxes[y].hi[axis];
+                       return cx < cy || (cx == cy && x < y);
+                     });
+    const int l = build(first, mid - first, depth + 1);
+    const int r = build(mid, first + count - mid, depth + 1);
+    node_link[4 * id] = l;
+    node_link[4 * id + 1] = r;
+    node_link[4 * id + 2] = axis;
+    node_link[4 * id + 3] = 0;
+    return id;
+  }
+};
+
+int build_bvh(odw_ctx* ctx) {
+  const int n = ctx->P.scene.n_prims;
+  ctx->P.scene.n_nodes = 0;
+  ctx->bvh_dirty = false;
+  if (n <= kBvhThreshold) return ODW_OK;
+  // boxes contain every point the tolerance rules may accept
+  const double slack = 2.0 * (ctx->have_limits ? ctx->P.lim.dist_tol : 1e-2);
+  std::vector<Box> boxes(n);
+  for (int p = 0; p < n; ++p)
+    boxes[p] = world_box(ctx->h_prim_f64.data() + 16 * (size_t)p, ctx->h_prim_i32[4 * p], slack);
+  BvhBuilder b(boxes);
+  b.build(0, n, 0);
+  if (b.max_depth + 1 > ODW_BVH_STACK) return fail(ctx, ODW_ERR_UNSUPPORTED, "BVH deeper than the LDS stack");
+  int rc;
+  if ((rc = upload(ctx, ctx->bvh_box, b.node_box.data(), b.node_box.size() * sizeof(double)))) return rc;
+  if ((rc = upload(ctx, ctx->bvh_link, b.node_link.data(), b.node_link.size() * sizeof(int32_t)))) return rc;
+  if ((rc = upload(ctx, ctx->bvh_prims, b.order.data(), b.order.size() * sizeof(int)))) return rc;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host vectors die with this scope
+  ctx->P.scene.bvh_box = (const double*)ctx->bvh_box.p;
+  ctx->P.scene.bvh_link = (const int32_t*)ctx->bvh_link.p;
+  ctx->P.scene.bvh_prims = (const int32_t*)ctx->bvh_prims.p;
+  ctx->P.scene.n_nodes = (int)(b.node_link.size() / 4);
+  return ODW_OK;
+}
+
+int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32_t flags,
+                 bool explicit_rays) {
+  if (!ctx->have_scene || !ctx->have_limits) return fail(ctx, ODW_ERR_NO_SCENE, "scene/limits not uploaded");
+  if (!explicit_rays && !ctx->have_source) return fail(ctx, ODW_ERR_NO_SCENE, "source not uploaded");
+  if (n == 0) return ODW_OK;
+  if (ctx->bvh_dirty) {
+    int rc = build_bvh(ctx);
+    if (rc) return rc;
+  }
+  if ((flags & ODW_TRACE_RECORD_HITS) && ctx->hit_capacity == 0)
+    return fail(ctx, ODW_ERR_CAPACITY, "ODW_TRACE_RECORD_HITS without odw_reserve_hits");
+  if ((flags & ODW_TRACE_HISTOGRAM) && !ctx->P.det.enabled) flags &= ~ODW_TRACE_HISTOGRAM;
+  TraceParams& P = ctx->P;
+  P.first_ray = first;
+  P.n_rays = n;
+  P.seed = seed;
+  P.flags = flags;
+  P.ray_origins = explicit_rays ? (const double*)ctx->ray_o.p : nullptr;
+  P.ray_dirs = explicit_rays ? (const double*)ctx->ray_d.p : nullptr;
+  P.ray_powers = (explicit_rays && ctx->ray_p.p) ? (const double*)ctx->ray_p.p : nullptr;
+  P.out.hits = (odw_hit*)ctx->hits.p;
+  P.out.hit_capacity = ctx->hit_capacity;
+  P.out.hit_count = (unsigned long long*)ctx->hit_count.p;
+  P.out.hist = (unsigned long long*)ctx->hist.p;
+  P.out.counters = (unsigned long long*)ctx->counters.p;
+
+  const uint64_t want = (n + 255) / 256;
+  const uint64_t cap = (uint64_t)ctx->n_cu * 8;  // >> 256 workgroups, grid-stride over the rest
+  const unsigned grid = (unsigned)std::min<uint64_t>(want, cap);
+  const size_t lds = P.scene.n_nodes ? (size_t)ODW_BVH_STACK * 256 * sizeof(int) : 0;
+
+  std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+  if (ctx->timing) {
+    if (!ctx->free_events.empty()) {
+      ev = ctx->free_events.back();
+      ctx->free_events.pop_back();
+    } else {
+      HIPCHK(ctx, hipEventCreate(&ev.first));
+      HIPCHK(ctx, hipEventCreate(&ev.second));
+    }
+    HIPCHK(ctx, hipEventRecord(ev.first, ctx->stream));
+  }
+  hipLaunchKernelGGL(odw_trace_kernel, dim3(grid), dim3(256), lds, ctx->stream, P);
+  HIPCHK(ctx, hipGetLastError());
+  if (ctx->timing) {
+    HIPCHK(ctx, hipEventRecord(ev.second, ctx->stream));
+    ctx->events.push_back(ev);
+  }
+  return ODW_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int odw_abi_version(void) { return ODW_ABI_VERSION; }
+
+const char* odw_last_error(const odw_ctx* ctx) { return ctx ? ctx->err.c_str() : g_error.c_str(); }
+
+int odw_create(int device, odw_ctx** out) {
+  if (!out) return fail(nullptr, ODW_ERR_INVALID, "odw_create: null out");
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0)
+    return fail(nullptr, ODW_ERR_DEVICE, std::string("no HIP device: ") + hipGetErrorString(e));
+  if (device < 0 || device >= count) return fail(nullptr, ODW_ERR_INVALID, "odw_create: bad device index");
+  odw_ctx* ctx = new (std::nothrow) odw_ctx();
+  if (!ctx) return fail(nullptr, ODW_ERR_DEVICE, "out of host memory");
+  ctx->device = device;
+  std::memset(&ctx->P, 0, sizeof ctx->P);
+  std::memset(&ctx->det_desc, 0, sizeof ctx->det_desc);
+  if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess) {
+    fail(nullptr, ODW_ERR_DEVICE, std::string("odw_create: ") + hipGetErrorString(e));
+    delete ctx;
+    return ODW_ERR_DEVICE;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
+  int rc = ensure(ctx, ctx->counters, ODW_CNT_COUNT * sizeof(uint64_t));
+  if (!rc) rc = ensure(ctx, ctx->hit_count, sizeof(uint64_t));
+  if (!rc) rc = ensure(ctx, ctx->hist, 16);
+  if (rc) { g_error = ctx->err; odw_destroy(ctx); return rc; }
+  (void)hipMemsetAsync(ctx->counters.p, 0, ctx->counters.bytes, ctx->stream);
+  (void)hipMemsetAsync(ctx->hit_count.p, 0, ctx->hit_count.bytes, ctx->stream);
+  *out = ctx;
+  return ODW_OK;
+}
+
+void odw_destroy(odw_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  for (auto& ev : ctx->free_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  DevBuf* all[] = {&ctx->prim_f64, &ctx->prim_i32, &ctx->cond_i32, &ctx->group_f64, &ctx->group_i32,
+                   &ctx->group_gdir, &ctx->seq_mask, &ctx->bvh_box, &ctx->bvh_link, &ctx->bvh_prims,
+                   &ctx->phi_tab, &ctx->t_tab, &ctx->t_guide, &ctx->hits, &ctx->hit_count, &ctx->hist,
+                   &ctx->counters, &ctx->ray_o, &ctx->ray_d, &ctx->ray_p, &ctx->samp_t, &ctx->samp_phi};
+  for (DevBuf* b : all) release(*b);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int odw_upload_scene(odw_ctx* ctx, const odw_scene_desc* s) {
+  if (!ctx || !s) return fail(ctx, ODW_ERR_INVALID, "odw_upload_scene: null argument");
+  if (s->n_prims < 0 || s->n_groups < 0 || s->n_groups > ODW_MAX_GROUPS || s->seq_len < 0 ||
+      s->seq_len > ODW_MAX_SEQUENCE || s->n_conds < 0 || s->n_conds >= (1 << 24))
+    return fail(ctx, ODW_ERR_INVALID, "odw_upload_scene: counts out of range");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const int n = s->n_prims;
+  ctx->h_prim_f64.assign((size_t)n * 16, 0.0);
+  ctx->h_prim_i32.assign((size_t)n * 4, 0);
+  for (int p = 0; p < n; ++p) {
+    const int type = s->prim_type[p], group = s->prim_group[p];
+    if (type < ODW_PRIM_BOX || type > ODW_PRIM_TORUS) return fail(ctx, ODW_ERR_UNSUPPORTED, "unknown primitive type");
+    if (group < 0 || group >= s->n_groups) return fail(ctx, ODW_ERR_INVALID, "primitive group out of range");
+    const int off = s->prim_cond_off[p], cnt = s->prim_cond_off[p + 1] - off;
+    if (off < 0 || cnt < 0 || cnt > 255 || off + cnt > s->n_conds)
+      return fail(ctx, ODW_ERR_INVALID, "bad condition offsets");
+    std::memcpy(&ctx->h_prim_f64[16 * (size_t)p], s->prim_xform + 12 * (size_t)p, 12 * sizeof(double));
+    std::memcpy(&ctx->h_prim_f64[16 * (size_t)p + 12], s->prim_params + 4 * (size_t)p, 4 * sizeof(double));
+    ctx->h_prim_i32[4 * p] = type;
+    ctx->h_prim_i32[4 * p + 1] = group;
+    ctx->h_prim_i32[4 * p + 2] = s->prim_flags[p];
+    ctx->h_prim_i32[4 * p + 3] = off | (cnt << 24);
+  }
+  std::vector<int32_t> cond((size_t)std::max(1, s->n_conds), 0);
+  for (int c = 0; c < s->n_conds; ++c) {
+    if (s->cond_prim[c] < 0 || s->cond_prim[c] >= n) return fail(ctx, ODW_ERR_INVALID, "condition primitive out of range");
+    cond[c] = s->cond_prim[c] | (s->cond_inside[c] ? (int32_t)0x80000000 : 0);
+  }
+  std::vector<double> gf(ODW_MAX_GROUPS * 4, 0.0), gd(ODW_MAX_GROUPS * 3, 0.0);
+  std::vector<int32_t> gi(ODW_MAX_GROUPS * 4, 0);
+  for (int g = 0; g < s->n_groups; ++g) {
+    if (s->group_type[g] < ODW_OPT_MIRROR || s->group_type[g] > ODW_OPT_VACUUM)
+      return fail(ctx, ODW_ERR_INVALID, "unknown optical type");
+    gf[4 * g] = s->group_ior[g];
+    gf[4 * g + 1] = s->group_refl[g];
+    gf[4 * g + 2] = s->group_abslen[g];
+    gf[4 * g + 3] = s->group_grating_lpm ? s->group_grating_lpm[g] : 1000.0;
+    gi[4 * g] = s->group_type[g];
+    gi[4 * g + 1] = s->group_record[g] ? 1 : 0;
+    gi[4 * g + 2] = s->group_grating_type ? s->group_grating_type[g] : 0;
+    gi[4 * g + 3] = s->group_grating_order ? s->group_grating_order[g] : 1;
+    for (int k = 0; k < 3; ++k) gd[3 * g + k] = s->group_grating_dir ? s->group_grating_dir[3 * g + k] : (k == 2);
+  }
+  std::vector<uint64_t> seq((size_t)std::max(1, s->seq_len), 0);
+  for (int i = 0; i < s->seq_len; ++i) seq[i] = s->seq_mask[i];
+  int rc;
+  if ((rc = upload(ctx, ctx->prim_f64, ctx->h_prim_f64.data(), ctx->h_prim_f64.size() * sizeof(double)))) return rc;
+  if ((rc = upload(ctx, ctx->prim_i32, ctx->h_prim_i32.data(), ctx->h_prim_i32.size() * sizeof(int32_t)))) return rc;
+  if ((rc = upload(ctx, ctx->cond_i32, cond.data(), cond.size() * sizeof(int32_t)))) return rc;
+  if ((rc = upload(ctx, ctx->group_f64, gf.data(), gf.size() * sizeof(double)))) return rc;
+  if ((rc = upload(ctx, ctx->group_i32, gi.data(), gi.size() * sizeof(int32_t)))) return rc;
+  if ((rc = upload(ctx, ctx->group_gdir, gd.data(), gd.size() * sizeof(double)))) return rc;
+  if ((rc = upload(ctx, ctx->seq_mask, seq.data(), seq.size() * sizeof(uint64_t)))) return rc;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  DeviceScene& d = ctx->P.scene;
+  d.prim_f64 = (const double*)ctx->prim_f64.p;
+  d.prim_i32 = (const int32_t*)ctx->prim_i32.p;
+  d.cond_i32 = (const int32_t*)ctx->cond_i32.p;
+  d.group_f64 = (const double*)ctx->group_f64.p;
+  d.group_i32 = (const int32_t*)ctx->group_i32.p;
+  d.group_gdir = (const double*)ctx->group_gdir.p;
+  d.seq_mask = (const uint64_t*)ctx->seq_mask.p;
+  d.n_prims = n;
+  d.n_groups = s->n_groups;
+  d.n_nodes = 0;
+  d.seq_enabled = s->seq_enabled ? 1 : 0;
+  d.seq_len = s->seq_len;
+  d.all_mask = (s->n_groups >= 64) ? ~0ull : ((1ull << s->n_groups) - 1ull);
+  d.ignore_mask = s->ignore_mask;
+  ctx->have_scene = true;
+  ctx->bvh_dirty = true;
+  return ODW_OK;
+}
+
+int odw_upload_source(odw_ctx* ctx, const odw_source_desc* s) {
+  if (!ctx || !s) return fail(ctx, ODW_ERR_INVALID, "odw_upload_source: null argument");
+  if (s->n_phi_knots < 2 || s->n_t_knots < 2 || s->n_t_rows < 1 ||
+      (s->n_t_rows != 1 && s->n_t_rows != s->n_phi_knots - 1))
+    return fail(ctx, ODW_ERR_INVALID, "odw_upload_source: table shape");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const int np = s->n_phi_knots, nt = s->n_t_knots, rows = s->n_t_rows;
+  if (s->phi_cdf[0] != 0.0 || s->phi_cdf[np - 1] != 1.0)
+    return fail(ctx, ODW_ERR_INVALID, "phi cdf must run from 0 to 1");
+  std::vector<double> ptab((size_t)np * 2), ttab((size_t)rows * nt * 2);
+  for (int i = 0; i < np; ++i) { ptab[2 * i] = s->phi_cdf[i]; ptab[2 * i + 1] = s->phi_edges[i]; }
+  std::vector<int32_t> guide((size_t)rows * (kGuide + 1));
+  for (int r = 0; r < rows; ++r) {
+    const double* cdf = s->t_cdf + (size_t)r * nt;
+    if (cdf[0] != 0.0 || cdf[nt - 1] != 1.0) return fail(ctx, ODW_ERR_INVALID, "theta cdf rows must run from 0 to 1");
+    double* dst = ttab.data() + (size_t)r * nt * 2;
+    for (int i = 0; i < nt; ++i) {
+      if (i && cdf[i] < cdf[i - 1]) return fail(ctx, ODW_ERR_INVALID, "cdf not monotone");
+      dst[2 * i] = cdf[i];
+      dst[2 * i + 1] = s->t_edges[i];
+    }
+    // guide[k] = last knot with cdf <= k/G: brackets the search for any u in
+    // [k/G, (k+1)/G) without changing which knot is found
+    int32_t* g = guide.data() + (size_t)r * (kGuide + 1);
+    int j = 0;
+    for (int k = 0; k <= kGuide; ++k) {
+      const double x = (double)k / (double)kGuide;
+      while (j + 1 < nt && cdf[j + 1] <= x) ++j;
+      g[k] = j;
+    }
+  }
+  int rc;
+  if ((rc = upload(ctx, ctx->phi_tab, ptab.data(), ptab.size() * sizeof(double)))) return rc;
+  if ((rc = upload(ctx, ctx->t_tab, ttab.data(), ttab.size() * sizeof(double)))) return rc;
+  if ((rc = upload(ctx, ctx->t_guide, guide.data(), guide.size() * sizeof(int32_t)))) return rc;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  DeviceSource& d = ctx->P.source;
+  std::memcpy(d.m, s->xform, sizeof d.m);
+  d.focal_length = s->focal_length;
+  d.finite_focal = std::isfinite(s->focal_length) ? 1 : 0;
+  d.wavelength = s->wavelength;
+  d.power = s->power;
+  d.phi_tab = (const double*)ctx->phi_tab.p;
+  d.t_tab = (const double*)ctx->t_tab.p;
+  d.t_guide = (const int32_t*)ctx->t_guide.p;
+  d.n_phi_knots = np;
+  d.n_t_knots = nt;
+  d.n_t_rows = rows;
+  d.n_guide = kGuide;
+  ctx->have_source = true;
+  return ODW_OK;
+}
+
+int odw_set_limits(odw_ctx* ctx, const odw_limits* l) {
+  if (!ctx || !l) return fail(ctx, ODW_ERR_INVALID, "odw_set_limits: null argument");
+  if (!(l->dist_tol > 0) || l->max_intersections < 0 || !(l->max_ray_length > 0))
+    return fail(ctx, ODW_ERR_INVALID, "odw_set_limits: values out of range");
+  if (!ctx->have_limits || ctx->P.lim.dist_tol != l->dist_tol) ctx->bvh_dirty = true;
+  ctx->P.lim.max_ray_length = l->max_ray_length;
+  ctx->P.lim.max_intersections = l->max_intersections;
+  ctx->P.lim.dist_tol = l->dist_tol;
+  ctx->P.lim.power_tol = l->power_tol;
+  ctx->have_limits = true;
+  return ODW_OK;
+}
+
+int odw_set_detector(odw_ctx* ctx, const odw_detector_desc* det) {
+  if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_set_detector: null ctx");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  DeviceDetector& d = ctx->P.det;
+  if (!det) { d.enabled = 0; ctx->n_bins = 0; return ODW_OK; }
+  if (det->nx <= 0 || det->ny <= 0 || !(det->x_hi > det->x_lo) || !(det->y_hi > det->y_lo))
+    return fail(ctx, ODW_ERR_INVALID, "odw_set_detector: bad window");
+  ctx->det_desc = *det;
+  for (int k = 0; k < 3; ++k) { d.origin[k] = det->origin[k]; d.ex[k] = det->ex[k]; d.ey[k] = det->ey[k]; }
+  d.x_lo = det->x_lo;
+  d.y_lo = det->y_lo;
+  d.x_scale = det->nx / (det->x_hi - det->x_lo);
+  d.y_scale = det->ny / (det->y_hi - det->y_lo);
+  d.nx = det->nx;
+  d.ny = det->ny;
+  d.group = det->group;
+  d.enabled = 1;
+  ctx->n_bins = (uint64_t)det->nx * (uint64_t)det->ny;
+  int rc = ensure(ctx, ctx->hist, ctx->n_bins * sizeof(uint64_t));
+  if (rc) return rc;
+  HIPCHK(ctx, hipMemsetAsync(ctx->hist.p, 0, ctx->n_bins * sizeof(uint64_t), ctx->stream));
+  return ODW_OK;
+}
+
+int odw_reserve_hits(odw_ctx* ctx, uint64_t capacity) {
+  if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_reserve_hits: null ctx");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (capacity == 0) { release(ctx->hits); ctx->hit_capacity = 0; return ODW_OK; }
+  if (capacity > ctx->hit_capacity) {
+    release(ctx->hits);
+    ctx->hit_capacity = 0;
+    int rc = ensure(ctx, ctx->hits, capacity * sizeof(odw_hit));
+    if (rc) return rc;
+    ctx->hit_capacity = capacity;
+  }
+  return ODW_OK;
+}
+
+int odw_trace(odw_ctx* ctx, uint64_t first_ray, uint64_t n_rays, uint64_t seed, uint32_t flags) {
+  if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_trace: null ctx");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  return launch_trace(ctx, first_ray, n_rays, seed, flags, false);
+}
+
+int odw_trace_rays(odw_ctx* ctx, uint64_t first_ray, uint64_t n_rays, const double* origins,
+                   const double* directions, const double* powers, uint32_t flags) {
+  if (!ctx || !origins || !directions) return fail(ctx, ODW_ERR_INVALID, "odw_trace_rays: null argument");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (n_rays == 0) return ODW_OK;
+  // the previous launch may still read the staging buffers
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  int rc;
+  if ((rc = upload(ctx, ctx->ray_o, origins, n_rays * 3 * sizeof(double)))) return rc;
+  if ((rc = upload(ctx, ctx->ray_d, directions, n_rays * 3 * sizeof(double)))) return rc;
+  if (powers) {
+    if ((rc = upload(ctx, ctx->ray_p, powers, n_rays * sizeof(double)))) return rc;
+  } else {
+    release(ctx->ray_p);
+  }
+  rc = launch_trace(ctx, first_ray, n_rays, 0, flags, true);
+  if (rc) return rc;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // caller's arrays may go away
+  return ODW_OK;
+}
+
+int odw_sync(odw_ctx* ctx) {
+  if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_sync: null ctx");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return ODW_OK;
+}
+
+int odw_reset_results(odw_ctx* ctx) {
+  if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_reset_results: null ctx");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, ODW_CNT_COUNT * sizeof(uint64_t), ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->hit_count.p, 0, sizeof(uint64_t), ctx->stream));
+  if (ctx->n_bins) HIPCHK(ctx, hipMemsetAsync(ctx->hist.p, 0, ctx->n_bins * sizeof(uint64_t), ctx->stream));
+  return ODW_OK;
+}
+
+int odw_fetch_counters(odw_ctx* ctx, uint64_t* out, int32_t n) {
+  if (!ctx || !out || n < 0) return fail(ctx, ODW_ERR_INVALID, "odw_fetch_counters: bad argument");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  uint64_t tmp[ODW_CNT_COUNT];
+  HIPCHK(ctx, hipMemcpyAsync(tmp, ctx->counters.p, sizeof tmp, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < n && i < ODW_CNT_COUNT; ++i) out[i] = tmp[i];
+  return ODW_OK;
+}
+
+int odw_hit_count(odw_ctx* ctx, uint64_t* n) {
+  if (!ctx || !n) return fail(ctx, ODW_ERR_INVALID, "odw_hit_count: bad argument");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  uint64_t v = 0;
+  HIPCHK(ctx, hipMemcpyAsync(&v, ctx->hit_count.p, sizeof v, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  *n = std::min<uint64_t>(v, ctx->hit_capacity);
+  return ODW_OK;
+}
+
+int odw_fetch_hits(odw_ctx* ctx, odw_hit* out, uint64_t capacity, uint64_t* n) {
+  if (!ctx || !n) return fail(ctx, ODW_ERR_INVALID, "odw_fetch_hits: bad argument");
+  uint64_t have = 0;
+  int rc = odw_hit_count(ctx, &have);
+  if (rc) return rc;
+  *n = have;
+  if (!out || capacity == 0) return ODW_OK;
+  if (have > capacity) return fail(ctx, ODW_ERR_CAPACITY, "odw_fetch_hits: output buffer too small");
+  if (have) {
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->hits.p, have * sizeof(odw_hit), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // append order is scheduling dependent; a ray's own rows are appended in
+    // bounce order, so a stable sort by ray index gives (ray, bounce) order
+    std::stable_sort(out, out + have, [](const odw_hit& a, const odw_hit& b) {
+      return ODW_HIT_RAY(a.tag) < ODW_HIT_RAY(b.tag);
+    });
+  }
+  return ODW_OK;
+}
+
+int odw_fetch_histogram(odw_ctx* ctx, uint64_t* out, uint64_t n_bins) {
+  if (!ctx || !out) return fail(ctx, ODW_ERR_INVALID, "odw_fetch_histogram: bad argument");
+  if (n_bins != ctx->n_bins || n_bins == 0) return fail(ctx, ODW_ERR_INVALID, "odw_fetch_histogram: bin count mismatch");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipMemcpyAsync(out, ctx->hist.p, n_bins * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return ODW_OK;
+}
+
+int odw_sample(odw_ctx* ctx, uint64_t first_ray, uint64_t n_rays, uint64_t seed, double* theta_out,
+               double* phi_out) {
+  if (!ctx || !theta_out || !phi_out) return fail(ctx, ODW_ERR_INVALID, "odw_sample: bad argument");
+  if (!ctx->have_source) return fail(ctx, ODW_ERR_NO_SCENE, "source not uploaded");
+  if (n_rays == 0) return ODW_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = ensure(ctx, ctx->samp_t, n_rays * sizeof(double)))) return rc;
+  if ((rc = ensure(ctx, ctx->samp_phi, n_rays * sizeof(double)))) return rc;
+  const unsigned grid = (unsigned)std::min<uint64_t>((n_rays + 255) / 256, (uint64_t)ctx->n_cu * 8);
+  hipLaunchKernelGGL(odw_sample_kernel, dim3(grid), dim3(256), 0, ctx->stream, ctx->P.source, first_ray,
+                     n_rays, seed, (double*)ctx->samp_t.p, (double*)ctx->samp_phi.p);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpyAsync(theta_out, ctx->samp_t.p, n_rays * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(phi_out, ctx->samp_phi.p, n_rays * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return ODW_OK;
+}
+
+int odw_device_histogram(odw_ctx* ctx, void** dptr, uint64_t* n_bins) {
+  if (!ctx || !dptr || !n_bins) return fail(ctx, ODW_ERR_INVALID, "odw_device_histogram: bad argument");
+  *dptr = ctx->n_bins ? ctx->hist.p : nullptr;
+  *n_bins = ctx->n_bins;
+  return ODW_OK;
+}
+
+int odw_device_counters(odw_ctx* ctx, void** dptr, uint64_t* n) {
+  if (!ctx || !dptr || !n) return fail(ctx, ODW_ERR_INVALID, "odw_device_counters: bad argument");
+  *dptr = ctx->counters.p;
+  *n = ODW_CNT_COUNT;
+  return ODW_OK;
+}
+
+int odw_stream(odw_ctx* ctx, void** hip_stream) {
+  if (!ctx || !hip_stream) return fail(ctx, ODW_ERR_INVALID, "odw_stream: bad argument");
+  *hip_stream = (void*)ctx->stream;
+  return ODW_OK;
+}
+
+int odw_timing_enable(odw_ctx* ctx, int on) {
+  if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_timing_enable: null ctx");
+  ctx->timing = on != 0;
+  return ODW_OK;
+}
+
+int odw_timing_read(odw_ctx* ctx, double* total_ms, uint64_t* launches) {
+  if (!ctx || !total_ms || !launches) return fail(ctx, ODW_ERR_INVALID, "odw_timing_read: bad argument");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  for (auto& ev : ctx->events) {
+    float ms = 0;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, ev.first, ev.second));
+    ctx->timing_ms += ms;
+    ctx->timing_launches += 1;
+    ctx->free_events.push_back(ev);
+  }
+  ctx->events.clear();
+  *total_ms = ctx->timing_ms;
+  *launches = ctx->timing_launches;
+  ctx->timing_ms = 0;
+  ctx->timing_launches = 0;
+  return ODW_OK;
+}
+
+}  // extern "C"

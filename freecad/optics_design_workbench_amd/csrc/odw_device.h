@@ -1,0 +1,93 @@
+// odw_device.h -- device-side tables and math of the gfx950 ray-tracing core.
+//
+// Layout in HBM (all read-only during a launch, L2/scalar-cache resident):
+//   prim_f64 : n_prims x 16 f64   rows 0..11 global->local (R|t), 12..15 params
+//   prim_i32 : n_prims x 4  i32   type, group, flags|facemask<<8, cond_off|cnt<<24
+//   cond_i32 : n_conds      i32   prim | inside<<31
+//   group_f64: 64 x 4 f64         ior, reflectivity, absorption length, grating lpm
+//   group_i32: 64 x 4 i32         optical type, record, grating type, grating order
+//   cdf tables: interleaved (cdf, edge) f64 pairs per knot, one 16-B load each
+// Everything a wave needs per primitive is addressed with wave-uniform
+// indices, so hipcc emits scalar (s_load) loads: the scene costs SGPRs, not
+// VGPRs, and no LDS staging is needed for the small benchmark scenes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../../include/odw_trace.h"
+
+namespace odw {
+
+struct d3 {
+  double x, y, z;
+};
+__device__ __forceinline__ d3 mk(double x, double y, double z) { return d3{x, y, z}; }
+__device__ __forceinline__ d3 operator+(d3 a, d3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ d3 operator-(d3 a, d3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ d3 operator*(d3 a, double s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ double dot(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ d3 cross(d3 a, d3 b) {
+  return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ double comp(d3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+
+struct DeviceScene {
+  const double* prim_f64;
+  const int32_t* prim_i32;
+  const int32_t* cond_i32;
+  const double* group_f64;      // [64*4]
+  const int32_t* group_i32;     // [64*4]
+  const double* group_gdir;     // [64*3]
+  const uint64_t* seq_mask;     // [seq_len]
+  // BVH (big scenes only): per node 6 f64 (lo xyz, hi xyz) + 4 i32
+  const double* bvh_box;        // [n_nodes*6]
+  const int32_t* bvh_link;      // [n_nodes*4] left, right, split axis, - | leaves: ~first, count
+  const int32_t* bvh_prims;     // leaf primitive order
+  int32_t n_prims, n_groups, n_nodes;
+  int32_t seq_enabled, seq_len;
+  uint64_t ignore_mask, all_mask;
+};
+
+struct DeviceSource {
+  double m[12];                 // local -> global
+  double focal_length, wavelength, power;
+  const double* phi_tab;        // [n_phi_knots*2] (cdf, edge)
+  const double* t_tab;          // [rows*n_t_knots*2]
+  const int32_t* t_guide;       // [rows*(GUIDE+1)] bracket guide for the inverse CDF
+  int32_t n_phi_knots, n_t_knots, n_t_rows, n_guide;
+  int32_t finite_focal;
+};
+
+struct DeviceLimits {
+  double max_ray_length, dist_tol, power_tol;
+  int32_t max_intersections;
+};
+
+struct DeviceDetector {
+  double origin[3], ex[3], ey[3];
+  double x_lo, y_lo, x_scale, y_scale;  // scale = n/(hi-lo)
+  int32_t nx, ny, group, enabled;
+};
+
+struct DeviceOutputs {
+  odw_hit* hits;
+  uint64_t hit_capacity;
+  unsigned long long* hit_count;       // device counter
+  unsigned long long* hist;            // nx*ny
+  unsigned long long* counters;        // ODW_CNT_COUNT
+};
+
+struct TraceParams {
+  DeviceScene scene;
+  DeviceSource source;
+  DeviceLimits lim;
+  DeviceDetector det;
+  DeviceOutputs out;
+  const double* ray_origins;    // explicit initial conditions (or null)
+  const double* ray_dirs;
+  const double* ray_powers;
+  uint64_t first_ray, n_rays, seed;
+  uint32_t flags;
+};
+
+}  // namespace odw

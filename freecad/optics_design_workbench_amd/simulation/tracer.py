@@ -1,0 +1,202 @@
+"""Device tracer: the accelerated region of runSimulationIteration.
+
+In the reference `GenericSourceProxy.runSimulationIteration`
+(freecad_elements/generic_source.py:51-146) generates RaysPerIteration rays and
+walks `ray.traceRay(store=store)` for each; here one `Tracer.trace(first, n,
+seed)` call does that for n rays on the GPU through the C-ABI and leaves hit
+rows, counters and the detector histogram in HBM until they are fetched.
+"""
+import ctypes as C
+
+import numpy as np
+
+from .. import _native
+from .._native import CNT_NAMES, HIT_DTYPE, TRACE_HISTOGRAM, TRACE_RECORD_HITS
+
+
+class _CudaArrayView:
+  """zero-copy view of a device buffer for torch.as_tensor (RCCL reductions)"""
+
+  def __init__(self, ptr, n, typestr, owner):
+    self.__cuda_array_interface__ = dict(shape=(int(n),), typestr=typestr, data=(int(ptr), False),
+                                         version=2, strides=None)
+    self._owner = owner
+
+
+class Tracer:
+
+  def __init__(self, device=0):
+    self._lib = _native.lib()
+    self._ctx = C.c_void_p()
+    self.device = int(device)
+    _native.check(None, self._lib.odw_create(self.device, C.byref(self._ctx)), 'odw_create')
+    self._det = None
+    self._keep = {}
+
+  # -- lifecycle ------------------------------------------------------------
+  def close(self):
+    if self._ctx:
+      self._lib.odw_destroy(self._ctx)
+      self._ctx = C.c_void_p()
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:
+      pass
+
+  def __enter__(self):
+    return self
+
+  def __exit__(self, *a):
+    self.close()
+
+  def _chk(self, rc, what):
+    _native.check(self._ctx, rc, what)
+
+  # -- uploads --------------------------------------------------------------
+  def setScene(self, scene):
+    d, keep = _native.scene_desc(scene)
+    self._chk(self._lib.odw_upload_scene(self._ctx, C.byref(d)), 'odw_upload_scene')
+    self.scene = scene
+
+  def setSource(self, source):
+    d, keep = _native.source_desc(source)
+    self._chk(self._lib.odw_upload_source(self._ctx, C.byref(d)), 'odw_upload_source')
+    self.source = source
+
+  def setLimits(self, lim):
+    d = _native.LimitsDesc(float(lim.max_ray_length), int(lim.max_intersections),
+                           float(lim.dist_tol), float(lim.power_tol))
+    self._chk(self._lib.odw_set_limits(self._ctx, C.byref(d)), 'odw_set_limits')
+    self.limits = lim
+
+  def setDetector(self, det):
+    """det: dict(group, origin, ex, ey, x_lo, x_hi, y_lo, y_hi, nx, ny) or None"""
+    if det is None:
+      self._chk(self._lib.odw_set_detector(self._ctx, None), 'odw_set_detector')
+      self._det = None
+      return
+    d = _native.DetectorDesc()
+    d.group = int(det.get('group', -1))
+    d.origin = (C.c_double * 3)(*det['origin'])
+    d.ex = (C.c_double * 3)(*det['ex'])
+    d.ey = (C.c_double * 3)(*det['ey'])
+    d.x_lo, d.x_hi, d.y_lo, d.y_hi = (float(det[k]) for k in ('x_lo', 'x_hi', 'y_lo', 'y_hi'))
+    d.nx, d.ny = int(det['nx']), int(det['ny'])
+    self._chk(self._lib.odw_set_detector(self._ctx, C.byref(d)), 'odw_set_detector')
+    self._det = dict(det)
+
+  def reserveHits(self, capacity):
+    self._chk(self._lib.odw_reserve_hits(self._ctx, C.c_uint64(int(capacity))), 'odw_reserve_hits')
+
+  # -- tracing --------------------------------------------------------------
+  @staticmethod
+  def _flags(record_hits, histogram):
+    return (TRACE_RECORD_HITS if record_hits else 0) | (TRACE_HISTOGRAM if histogram else 0)
+
+  def trace(self, first, n, seed, record_hits=True, histogram=True):
+    """asynchronous: rays first..first+n-1 of Philox stream `seed`"""
+    self._chk(self._lib.odw_trace(self._ctx, C.c_uint64(int(first)), C.c_uint64(int(n)),
+                                  C.c_uint64(int(seed)), C.c_uint32(self._flags(record_hits, histogram))),
+              'odw_trace')
+
+  def traceRays(self, origins, directions, powers=None, first=0, record_hits=True, histogram=True):
+    o = np.ascontiguousarray(origins, dtype=np.float64).reshape(-1, 3)
+    d = np.ascontiguousarray(directions, dtype=np.float64).reshape(-1, 3)
+    if o.shape != d.shape:
+      raise ValueError('origins and directions differ in shape')
+    p = np.ascontiguousarray(powers, dtype=np.float64) if powers is not None else None
+    pd = C.POINTER(C.c_double)
+    self._chk(self._lib.odw_trace_rays(
+        self._ctx, C.c_uint64(int(first)), C.c_uint64(len(o)), o.ctypes.data_as(pd), d.ctypes.data_as(pd),
+        p.ctypes.data_as(pd) if p is not None else None,
+        C.c_uint32(self._flags(record_hits, histogram))), 'odw_trace_rays')
+
+  def sync(self):
+    self._chk(self._lib.odw_sync(self._ctx), 'odw_sync')
+
+  def reset(self):
+    self._chk(self._lib.odw_reset_results(self._ctx), 'odw_reset_results')
+
+  # -- results --------------------------------------------------------------
+  def counters(self):
+    out = np.zeros(len(CNT_NAMES), dtype=np.uint64)
+    self._chk(self._lib.odw_fetch_counters(self._ctx, out.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                           C.c_int32(len(out))), 'odw_fetch_counters')
+    return {k: int(v) for k, v in zip(CNT_NAMES, out)}
+
+  def hitCount(self):
+    n = C.c_uint64(0)
+    self._chk(self._lib.odw_hit_count(self._ctx, C.byref(n)), 'odw_hit_count')
+    return int(n.value)
+
+  def hits(self):
+    """recorded hit rows sorted by (ray index, bounce order)"""
+    n = self.hitCount()
+    out = np.zeros(n, dtype=HIT_DTYPE)
+    got = C.c_uint64(0)
+    self._chk(self._lib.odw_fetch_hits(self._ctx, out.ctypes.data_as(C.c_void_p), C.c_uint64(n),
+                                       C.byref(got)), 'odw_fetch_hits')
+    return out[:int(got.value)]
+
+  def histogram(self):
+    if self._det is None:
+      raise ValueError('no detector set')
+    nb = self._det['nx'] * self._det['ny']
+    out = np.zeros(nb, dtype=np.uint64)
+    self._chk(self._lib.odw_fetch_histogram(self._ctx, out.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                            C.c_uint64(nb)), 'odw_fetch_histogram')
+    return out.reshape(self._det['nx'], self._det['ny'])
+
+  def sample(self, first, n, seed):
+    t = np.empty(int(n))
+    phi = np.empty(int(n))
+    pd = C.POINTER(C.c_double)
+    self._chk(self._lib.odw_sample(self._ctx, C.c_uint64(int(first)), C.c_uint64(int(n)),
+                                   C.c_uint64(int(seed)), t.ctypes.data_as(pd), phi.ctypes.data_as(pd)),
+              'odw_sample')
+    return t, phi
+
+  # -- device views for collectives ------------------------------------------
+  def histogramView(self):
+    p, n = C.c_void_p(), C.c_uint64(0)
+    self._chk(self._lib.odw_device_histogram(self._ctx, C.byref(p), C.byref(n)), 'odw_device_histogram')
+    return _CudaArrayView(p.value, n.value, '<i8', self)
+
+  def countersView(self):
+    p, n = C.c_void_p(), C.c_uint64(0)
+    self._chk(self._lib.odw_device_counters(self._ctx, C.byref(p), C.byref(n)), 'odw_device_counters')
+    return _CudaArrayView(p.value, n.value, '<i8', self)
+
+  def stream(self):
+    p = C.c_void_p()
+    self._chk(self._lib.odw_stream(self._ctx, C.byref(p)), 'odw_stream')
+    return p.value
+
+  # -- timing -----------------------------------------------------------------
+  def timingEnable(self, on=True):
+    self._chk(self._lib.odw_timing_enable(self._ctx, C.c_int(1 if on else 0)), 'odw_timing_enable')
+
+  def timingRead(self):
+    ms, n = C.c_double(0), C.c_uint64(0)
+    self._chk(self._lib.odw_timing_read(self._ctx, C.byref(ms), C.byref(n)), 'odw_timing_read')
+    return float(ms.value), int(n.value)
+
+
+def hitsToDict(hits, scene, sourceName='', group=None):
+  """rows -> the reference's pickled hit dictionary
+  (results_store.py:405-457): one dict per (source, object)."""
+  tags = hits['tag']
+  grp = ((tags >> np.uint64(48)) & np.uint64(0x7FFF)).astype(np.int64)
+  out = {}
+  for g in np.unique(grp) if group is None else [group]:
+    sel = grp == g
+    out[scene.group_names[g]] = dict(
+        source=sourceName, obj=scene.group_names[g],
+        points=np.ascontiguousarray(hits['point'][sel]),
+        directions=np.ascontiguousarray(hits['direction'][sel]),
+        powers=np.ascontiguousarray(hits['power'][sel]),
+        isEntering=(tags[sel] >> np.uint64(63)).astype(np.int64),
+        rayIndex=(tags[sel] & np.uint64(0xFFFFFFFFFFFF)).astype(np.int64))
+  return out

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Scene fixtures: the document descriptions of the reference's benchmark /
+example / test FCStd files, reduced to what the FCStd-lite loader reads.
+
+Run in the authoring container only (needs /root/reference):
+    python tests/golden/make_scenes.py
+
+An FCStd file is a zip of data files.  Only `Document.xml` (object list and
+property values) and the binary `PlacementList*` members (Draft link-array
+placements) are kept; BRep payloads, GUI state and thumbnails are dropped.
+The fixtures are data (scene descriptions), not code.
+"""
+import os
+import zipfile
+
+REF = '/root/reference'
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'scenes')
+
+SCENES = {
+  'minimal': 'benchmark/minimal.FCStd',
+  'lensesAndMirrors': 'benchmark/lensesAndMirrors.FCStd',
+  'lensesAndMirrorsSequential': 'benchmark/lensesAndMirrorsSequential.FCStd',
+  'hugeArray': 'benchmark/hugeArray.FCStd',
+  'GettingStarted': 'examples/1-getting-started/GettingStarted.FCStd',
+  'source-and-absorber': 'test/70-point-source-slow/source-and-absorber.FCStd',
+  'gaussian': 'test/50-old-tests/gaussian.FCStd',
+  'lens-overlap': 'test/50-old-tests/lens-overlap.FCStd',
+}
+
+if __name__ == '__main__':
+  os.makedirs(OUT, exist_ok=True)
+  for name, rel in SCENES.items():
+    src = os.path.join(REF, rel)
+    if not os.path.exists(src):
+      print('missing', src)
+      continue
+    dst = os.path.join(OUT, name + '.FCStd')
+    with zipfile.ZipFile(src) as zin, zipfile.ZipFile(dst, 'w', zipfile.ZIP_DEFLATED) as zout:
+      for info in zin.infolist():
+        if info.filename == 'Document.xml' or info.filename.startswith('PlacementList'):
+          zout.writestr(info.filename, zin.read(info.filename))
+    print(name, os.path.getsize(src), '->', os.path.getsize(dst))
