@@ -28,7 +28,7 @@ HIT_DTYPE = np.dtype([('point', '<f8', 3), ('direction', '<f8', 3), ('power', '<
 # every symbol include/odw_trace.h declares
 SYMBOLS = ['odw_abi_version', 'odw_create', 'odw_destroy', 'odw_last_error', 'odw_upload_scene',
            'odw_upload_source', 'odw_set_limits', 'odw_set_detector', 'odw_reserve_hits', 'odw_trace',
-           'odw_trace_rays', 'odw_sync', 'odw_reset_results', 'odw_fetch_counters', 'odw_hit_count',
+           'odw_trace_rays', 'odw_sync', 'odw_reset_results', 'odw_reset_hits', 'odw_fetch_counters', 'odw_hit_count',
            'odw_fetch_hits', 'odw_fetch_histogram', 'odw_sample', 'odw_device_histogram',
            'odw_device_counters', 'odw_stream', 'odw_timing_enable', 'odw_timing_read']
 

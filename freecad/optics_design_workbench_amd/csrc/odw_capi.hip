@@ -563,6 +563,13 @@ int odw_reset_results(odw_ctx* ctx) {
   return ODW_OK;
 }
 
+int odw_reset_hits(odw_ctx* ctx) {
+  if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_reset_hits: null ctx");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipMemsetAsync(ctx->hit_count.p, 0, sizeof(uint64_t), ctx->stream));
+  return ODW_OK;
+}
+
 int odw_fetch_counters(odw_ctx* ctx, uint64_t* out, int32_t n) {
   if (!ctx || !out || n < 0) return fail(ctx, ODW_ERR_INVALID, "odw_fetch_counters: bad argument");
   HIPCHK(ctx, hipSetDevice(ctx->device));

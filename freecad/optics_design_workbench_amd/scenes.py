@@ -36,11 +36,13 @@ def bakeProject(doc, source=None, **traceKwargs):
                       limits=_bake.bakeLimits(doc, source, **traceKwargs), sourceObject=source)
 
 
-def planeDetector(scene, group, nx=1024, ny=1024, window=None, prim=None, face=None):
+def planeDetector(scene, group, nx=1024, ny=1024, window=None, prim=None, face=None, toward=None):
   """detector window on a planar face of a recording group: by default the
   box face of `group` with the largest area (the reference picks the plane
   post hoc from the point cloud, hits.py:96-174; a device histogram needs it
-  up front).  -> dict for Tracer.setDetector"""
+  up front).  Among equally large faces the one whose outward normal points
+  most towards the point `toward` (e.g. the source position) wins.
+  -> dict for Tracer.setDetector"""
   gi = scene.group_index(group) if isinstance(group, str) else int(group)
   best = None
   for p in range(scene.n_prims):
@@ -55,11 +57,21 @@ def planeDetector(scene, group, nx=1024, ny=1024, window=None, prim=None, face=N
       a = f >> 1
       b1, b2 = (a + 1) % 3, (a + 2) % 3
       area = size[b1] * size[b2]
-      if best is None or area > best[0]:
-        best = (area, p, f)
+      score = 0.0
+      if toward is not None:
+        tw = scene.prim_to_world[p]
+        c = np.array(size) / 2
+        nrm = np.zeros(3)
+        nrm[a] = 1.0 if f & 1 else -1.0
+        c_face = c.copy()
+        c_face[a] = size[a] if f & 1 else 0.0
+        v = np.asarray(toward, dtype=np.float64) - (tw * c_face)
+        score = float((tw.m[:3, :3] @ nrm) @ (v / (np.linalg.norm(v) + 1e-300)))
+      if best is None or (area, score) > (best[0], best[3]):
+        best = (area, p, f, score)
   if best is None:
     raise ValueError(f'group {group} has no planar box face')
-  _, p, f = best
+  _, p, f, _ = best
   a = f >> 1
   b1, b2 = (a + 1) % 3, (a + 2) % 3
   size = scene.prim_params[p][:3]

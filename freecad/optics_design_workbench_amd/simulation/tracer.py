@@ -119,6 +119,11 @@ class Tracer:
   def reset(self):
     self._chk(self._lib.odw_reset_results(self._ctx), 'odw_reset_results')
 
+  def resetHits(self):
+    """recycle the hit list (the reference's periodic flush,
+    results_store.py:455-457); counters and histogram keep accumulating"""
+    self._chk(self._lib.odw_reset_hits(self._ctx), 'odw_reset_hits')
+
   # -- results --------------------------------------------------------------
   def counters(self):
     out = np.zeros(len(CNT_NAMES), dtype=np.uint64)
@@ -198,5 +203,5 @@ def hitsToDict(hits, scene, sourceName='', group=None):
         directions=np.ascontiguousarray(hits['direction'][sel]),
         powers=np.ascontiguousarray(hits['power'][sel]),
         isEntering=(tags[sel] >> np.uint64(63)).astype(np.int64),
-        rayIndex=(tags[sel] & np.uint64(0xFFFFFFFFFFFF)).astype(np.int64))
+        globalRayIndex=(tags[sel] & np.uint64(0xFFFFFFFFFFFF)).astype(np.int64))
   return out

@@ -207,6 +207,7 @@ int odw_sync(odw_ctx* ctx);
 
 /* results --------------------------------------------------------------- */
 int odw_reset_results(odw_ctx* ctx); /* zero counters, hits, histogram      */
+int odw_reset_hits(odw_ctx* ctx);    /* recycle the hit list only (flush)   */
 int odw_fetch_counters(odw_ctx* ctx, uint64_t* out, int32_t n);
 int odw_hit_count(odw_ctx* ctx, uint64_t* n);
 /* copies min(n_hits, capacity) rows, sorted by (ray index, bounce order)   */

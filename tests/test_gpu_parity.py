@@ -61,7 +61,7 @@ def test_scene_parity(tracer, oracle, scene, group, n):
   proj = project(scene)
   det = None
   if group is not None:
-    det = scenes.planeDetector(proj.scene, group, nx=128, ny=128)
+    det = scenes.planeDetector(proj.scene, group, nx=128, ny=128, toward=proj.source.xform[[3, 7, 11]])
   gpu = run_gpu(tracer, proj, 0, n, SEED, det)
   ref = oracle.trace(proj.scene, proj.source, proj.limits, 0, n, SEED, det=det, nthreads=0)
   assert ref['counters']['traced_rays'] == n
