@@ -51,6 +51,7 @@ __device__ __forceinline__ void ray_uniforms(uint64_t ray, uint64_t seed, double
 // evaluates slope*(u - cdf[j]) + edge[j] WITHOUT fma contraction, i.e. the
 // exact arithmetic of numpy's arr_interp.
 __device__ __forceinline__ double inv_cdf(const double* __restrict__ tab, int lo, int hi, double u) {
+#pragma clang fp contract(off)
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
     if (u >= tab[2 * mid]) lo = mid; else hi = mid;
@@ -58,12 +59,14 @@ __device__ __forceinline__ double inv_cdf(const double* __restrict__ tab, int lo
   const double2 a = *reinterpret_cast<const double2*>(tab + 2 * lo);
   const double2 b = *reinterpret_cast<const double2*>(tab + 2 * lo + 2);
   if (a.x == u) return a.y;
-  const double slope = __ddiv_rn(__dsub_rn(b.y, a.y), __dsub_rn(b.x, a.x));
-  return __dadd_rn(__dmul_rn(slope, __dsub_rn(u, a.x)), a.y);
+  const double slope = (b.y - a.y) / (b.x - a.x);
+  const double prod = slope * (u - a.x);
+  return prod + a.y;
 }
 
 __device__ __forceinline__ void sample_source(const DeviceSource& s, double u_phi, double u_t,
                                               double& t_out, double& phi_out) {
+#pragma clang fp contract(off)
   const double phi = inv_cdf(s.phi_tab, 0, s.n_phi_knots - 1, u_phi);
   int row = 0;
   if (s.n_t_rows > 1) {
@@ -74,8 +77,8 @@ __device__ __forceinline__ void sample_source(const DeviceSource& s, double u_ph
     r = max(0, min(s.n_t_rows - 1, r));
     double best = INFINITY;
     for (int i = max(0, r - 1); i <= min(s.n_t_rows - 1, r + 1); ++i) {
-      const double mid = __ddiv_rn(__dadd_rn(s.phi_tab[2 * (i + 1) + 1], s.phi_tab[2 * i + 1]), 2.0);
-      const double d = fabs(__dsub_rn(mid, phi));
+      const double mid = (s.phi_tab[2 * (i + 1) + 1] + s.phi_tab[2 * i + 1]) / 2.0;
+      const double d = fabs(mid - phi);
       if (d < best) { best = d; row = i; }
     }
   }
@@ -549,8 +552,8 @@ __device__ __forceinline__ void record_hit(const TraceParams& P, uint64_t ray, i
     const d3 r = p - mk(P.det.origin[0], P.det.origin[1], P.det.origin[2]);
     const double x = dot(r, mk(P.det.ex[0], P.det.ex[1], P.det.ex[2]));
     const double y = dot(r, mk(P.det.ey[0], P.det.ey[1], P.det.ey[2]));
-    const double fx = floor(__dmul_rn(__dsub_rn(x, P.det.x_lo), P.det.x_scale));
-    const double fy = floor(__dmul_rn(__dsub_rn(y, P.det.y_lo), P.det.y_scale));
+    const double fx = floor((x - P.det.x_lo) * P.det.x_scale);
+    const double fy = floor((y - P.det.y_lo) * P.det.y_scale);
     if (fx >= 0 && fx < (double)P.det.nx && fy >= 0 && fy < (double)P.det.ny)
       atomicAdd(P.out.hist + ((size_t)fx * (size_t)P.det.ny + (size_t)fy), 1ull);
     else

