@@ -1,0 +1,77 @@
+"""N>1 path on CPU: two ranks (gloo) shard the global ray index range, trace
+their shards (the CPU oracle stands in for the device here), sum histogram
+and counters with the product's reduce helper; rank 0 must hold exactly the
+single-process result (integer sums: independent of the rank count)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+
+from conftest import ROOT, project
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], 'tests'))
+import numpy as np, torch, torch.distributed as dist
+from conftest import project
+from oracle import capi
+from freecad.optics_design_workbench_amd import scenes
+from freecad.optics_design_workbench_amd.simulation import parallel
+dist.init_process_group('gloo')
+rank, world = dist.get_rank(), dist.get_world_size()
+pr = project('lensesAndMirrors')
+det = scenes.planeDetector(pr.scene, 'OpticalAbsorberGroup', nx=64, ny=64, toward=pr.source.xform[[3, 7, 11]])
+first, n = parallel.shardRange(1000, 30001, rank, world)
+r = capi.trace(pr.scene, pr.source, pr.limits, first, n, 77, det=det)
+hist = torch.from_numpy(r['hist'].astype(np.int64).ravel().copy())
+cnt = torch.tensor([r['counters'][k] for k in capi.CNT_NAMES], dtype=torch.int64)
+parallel.reduceTensors(dist, [cnt, hist], dst=0)
+if rank == 0:
+  np.savez(sys.argv[2], hist=hist.numpy(), cnt=cnt.numpy())
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_shard_range_partitions_exactly():
+  from freecad.optics_design_workbench_amd.simulation import parallel
+  for n in (0, 1, 7, 1000, 10**9 + 3):
+    for world in (1, 2, 3, 8):
+      parts = [parallel.shardRange(5, n, r, world) for r in range(world)]
+      assert sum(p[1] for p in parts) == n
+      pos = 5
+      for f, c in parts:
+        assert f == pos
+        pos += c
+      assert max(p[1] for p in parts) - min(p[1] for p in parts) <= 1
+  # weak-scaling step addressing never overlaps between ranks/steps
+  seen = set()
+  for s in range(3):
+    for r in range(4):
+      f = parallel.shardFirst(s, r, 4, 100)
+      assert f not in seen
+      seen.add(f)
+  assert parallel.shardFirst(0, 0, 4, 100, warm=True) >= parallel.WARM_BASE
+
+
+def test_two_rank_reduce_matches_single(tmp_path, oracle):
+  from freecad.optics_design_workbench_amd import scenes
+  script = tmp_path / 'worker.py'
+  script.write_text(WORKER)
+  out = tmp_path / 'rank0.npz'
+  with socket.socket() as s:
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+  env = dict(os.environ, OMP_NUM_THREADS='2')
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+         '--master-addr', '127.0.0.1', '--master-port', str(port), str(script), ROOT, str(out)]
+  res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+  assert res.returncode == 0, res.stdout + res.stderr
+  got = np.load(out)
+  pr = project('lensesAndMirrors')
+  det = scenes.planeDetector(pr.scene, 'OpticalAbsorberGroup', nx=64, ny=64, toward=pr.source.xform[[3, 7, 11]])
+  ref = oracle.trace(pr.scene, pr.source, pr.limits, 1000, 30001, 77, det=det)
+  assert np.array_equal(got['hist'].reshape(64, 64), ref['hist'].astype(np.int64))
+  assert [int(v) for v in got['cnt']] == [ref['counters'][k] for k in oracle.CNT_NAMES]
