@@ -150,6 +150,13 @@ def bakeScene(doc, source=None):
   groups = opticalObjects(doc)
   if len(groups) > MAX_GROUPS:
     raise geometry.UnsupportedGeometry(f'{len(groups)} optical groups (limit {MAX_GROUPS})')
+  for g in groups:
+    for key in ('ReflectedProbabilityDensity', 'RefractedProbabilityDensity',
+                'RayModificationProbabilityDensity'):
+      if str(g._props.get(key, '') or '').strip():
+        raise NotImplementedError(
+            f'{g.Name}.{key} is set: stochastic surface corrections '
+            f'(optical_group.py:279-323) are not on the accelerated path yet (SURVEY 8f N3)')
   prims = []
   prim_group, prim_solid = [], []
   solid_id = 0
