@@ -45,7 +45,7 @@ struct odw_ctx {
   bool have_scene = false, have_source = false, have_limits = false;
   bool bvh_dirty = true;
 
-  DevBuf prim_f64, prim_i32, cond_i32, group_f64, group_i32, group_gdir, seq_mask;
+  DevBuf prim_f64, prim_box, prim_i32, cond_i32, group_f64, group_i32, group_gdir, seq_mask;
   DevBuf bvh_box, bvh_link, bvh_prims;
   DevBuf phi_tab, t_tab, t_guide;
   DevBuf hits, hit_count, hist, counters;
@@ -216,12 +216,21 @@ int build_bvh(odw_ctx* ctx) {
   const int n = ctx->P.scene.n_prims;
   ctx->P.scene.n_nodes = 0;
   ctx->bvh_dirty = false;
-  if (n <= kBvhThreshold) return ODW_OK;
   // boxes contain every point the tolerance rules may accept
   const double slack = 2.0 * (ctx->have_limits ? ctx->P.lim.dist_tol : 1e-2);
   std::vector<Box> boxes(n);
-  for (int p = 0; p < n; ++p)
+  std::vector<double> flat((size_t)std::max(1, n) * 6, 0.0);
+  for (int p = 0; p < n; ++p) {
     boxes[p] = world_box(ctx->h_prim_f64.data() + 16 * (size_t)p, ctx->h_prim_i32[4 * p], slack);
+    for (int a = 0; a < 3; ++a) { flat[6 * (size_t)p + a] = boxes[p].lo[a]; flat[6 * (size_t)p + 3 + a] = boxes[p].hi[a]; }
+  }
+  {
+    int rc = upload(ctx, ctx->prim_box, flat.data(), flat.size() * sizeof(double));
+    if (rc) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->P.scene.prim_box = (const double*)ctx->prim_box.p;
+  }
+  if (n <= kBvhThreshold) return ODW_OK;
   BvhBuilder b(boxes);
   b.build(0, n, 0);
   if (b.max_depth + 1 > ODW_BVH_STACK) return fail(ctx, ODW_ERR_UNSUPPORTED, "BVH deeper than the LDS stack");
@@ -279,7 +288,10 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
     }
     HIPCHK(ctx, hipEventRecord(ev.first, ctx->stream));
   }
-  hipLaunchKernelGGL(odw_trace_kernel, dim3(grid), dim3(256), lds, ctx->stream, P);
+  if (P.scene.n_nodes)
+    hipLaunchKernelGGL(odw_trace_kernel<true>, dim3(grid), dim3(256), lds, ctx->stream, P);
+  else
+    hipLaunchKernelGGL(odw_trace_kernel<false>, dim3(grid), dim3(256), 0, ctx->stream, P);
   HIPCHK(ctx, hipGetLastError());
   if (ctx->timing) {
     HIPCHK(ctx, hipEventRecord(ev.second, ctx->stream));
@@ -332,7 +344,7 @@ void odw_destroy(odw_ctx* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   for (auto& ev : ctx->free_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
-  DevBuf* all[] = {&ctx->prim_f64, &ctx->prim_i32, &ctx->cond_i32, &ctx->group_f64, &ctx->group_i32,
+  DevBuf* all[] = {&ctx->prim_f64, &ctx->prim_box, &ctx->prim_i32, &ctx->cond_i32, &ctx->group_f64, &ctx->group_i32,
                    &ctx->group_gdir, &ctx->seq_mask, &ctx->bvh_box, &ctx->bvh_link, &ctx->bvh_prims,
                    &ctx->phi_tab, &ctx->t_tab, &ctx->t_guide, &ctx->hits, &ctx->hit_count, &ctx->hist,
                    &ctx->counters, &ctx->ray_o, &ctx->ray_d, &ctx->ray_p, &ctx->samp_t, &ctx->samp_phi};

@@ -19,6 +19,47 @@
 
 namespace odw {
 
+// Scene tables are immutable during a launch.  Reading them through the
+// constant address space lets hipcc use scalar loads (s_load_*) whenever the
+// index is wave-uniform -- which it is in the flat primitive loop -- so the
+// scene occupies SGPRs / the scalar cache instead of 16 VGPR pairs per
+// primitive.  (Plain global pointers inside a by-value struct are not
+// provably unclobbered, and hipcc falls back to per-lane global_load.)
+#define ODW_CONST __attribute__((address_space(4)))
+typedef const double ODW_CONST* cf64;
+typedef const int32_t ODW_CONST* ci32;
+typedef const uint64_t ODW_CONST* cu64;
+template <class T>
+__device__ __forceinline__ const T ODW_CONST* as_const(const T* p) {
+  return (const T ODW_CONST*)(uintptr_t)p;
+}
+
+// ---- cheap float64 reciprocal / square root ------------------------------
+// v_rcp_f64 / v_rsq_f64 deliver ~26 bits; two Newton steps give ~1 ulp without
+// the v_div_scale/v_div_fmas/v_div_fixup tail of an IEEE division (used where
+// the result feeds tolerance tests with 1e-6 slack, never in the sampler).
+__device__ __forceinline__ double frcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ double fsqrt(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  g = fma(fma(-g, g, x), h, g);
+  return x > 0 ? g : 0.0;
+}
+__device__ __forceinline__ double frsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  return y;
+}
+
 // ---------------------------------------------------------------- Philox
 __device__ __forceinline__ void philox4x32_10(uint32_t& c0, uint32_t& c1, uint32_t& c2,
                                               uint32_t& c3, uint32_t k0, uint32_t k1) {
@@ -91,16 +132,19 @@ __device__ __forceinline__ void sample_source(const DeviceSource& s, double u_ph
   phi_out = phi;
 }
 
-__device__ __forceinline__ d3 xf_point(const double* __restrict__ m, d3 p) {
+template <class P>
+__device__ __forceinline__ d3 xf_point(P m, d3 p) {
   return mk(m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3],
             m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7],
             m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]);
 }
-__device__ __forceinline__ d3 xf_vec(const double* __restrict__ m, d3 v) {
+template <class P>
+__device__ __forceinline__ d3 xf_vec(P m, d3 v) {
   return mk(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z,
             m[8] * v.x + m[9] * v.y + m[10] * v.z);
 }
-__device__ __forceinline__ d3 xf_vec_t(const double* __restrict__ m, d3 v) {  // R^T v
+template <class P>
+__device__ __forceinline__ d3 xf_vec_t(P m, d3 v) {  // R^T v
   return mk(m[0] * v.x + m[4] * v.y + m[8] * v.z, m[1] * v.x + m[5] * v.y + m[9] * v.z,
             m[2] * v.x + m[6] * v.y + m[10] * v.z);
 }
@@ -129,7 +173,7 @@ __device__ __forceinline__ void make_ray(const DeviceSource& s, double t_or_r, d
 }
 
 // ----------------------------------------------------------- primitives
-__device__ __forceinline__ double prim_sdist(int type, const double* __restrict__ par, d3 p) {
+__device__ __forceinline__ double prim_sdist(int type, cf64 par, d3 p) {
   switch (type) {
     case ODW_PRIM_BOX: {
       const double dx = fmax(-p.x, p.x - par[0]);
@@ -137,21 +181,21 @@ __device__ __forceinline__ double prim_sdist(int type, const double* __restrict_
       const double dz = fmax(-p.z, p.z - par[2]);
       return fmax(dx, fmax(dy, dz));
     }
-    case ODW_PRIM_SPHERE: return sqrt(dot(p, p)) - par[0];
+    case ODW_PRIM_SPHERE: return fsqrt(dot(p, p)) - par[0];
     case ODW_PRIM_CYLINDER: {
-      const double rho = sqrt(p.x * p.x + p.y * p.y);
+      const double rho = fsqrt(p.x * p.x + p.y * p.y);
       return fmax(rho - par[0], fmax(-p.z, p.z - par[1]));
     }
     case ODW_PRIM_CONE: {
       const double k = (par[1] - par[0]) / par[2];
-      const double rho = sqrt(p.x * p.x + p.y * p.y);
-      const double lat = (rho - (par[0] + k * p.z)) / sqrt(1 + k * k);
+      const double rho = fsqrt(p.x * p.x + p.y * p.y);
+      const double lat = (rho - (par[0] + k * p.z)) * frsqrt(1 + k * k);
       return fmax(lat, fmax(-p.z, p.z - par[2]));
     }
     default: {  // torus
-      const double rho = sqrt(p.x * p.x + p.y * p.y);
+      const double rho = fsqrt(p.x * p.x + p.y * p.y);
       const double a = rho - par[0];
-      return sqrt(a * a + p.z * p.z) - par[1];
+      return fsqrt(a * a + p.z * p.z) - par[1];
     }
   }
 }
@@ -160,28 +204,43 @@ __device__ __forceinline__ double prim_sdist(int type, const double* __restrict_
 __device__ __forceinline__ int quad_roots(double a, double bh, double c, double& t0, double& t1) {
   if (a == 0) {
     if (bh == 0) return 0;
-    t0 = t1 = -c / (2 * bh);
+    t0 = t1 = -c * frcp(2 * bh);
     return 1;
   }
   const double disc = bh * bh - a * c;
   if (!(disc >= 0)) return 0;
-  const double sq = sqrt(disc);
+  const double sq = fsqrt(disc);
   const double q = -(bh + (bh >= 0 ? sq : -sq));
-  double r0 = q / a;
-  double r1 = (q != 0) ? c / q : r0;
+  double r0 = q * frcp(a);
+  double r1 = (q != 0) ? c * frcp(q) : r0;
+  if (r0 > r1) { const double tmp = r0; r0 = r1; r1 = tmp; }
+  t0 = r0; t1 = r1;
+  return 2;
+}
+// the same for a == 1 (unit direction in a rigid frame)
+__device__ __forceinline__ int quad_roots_unit(double bh, double c, double& t0, double& t1) {
+  const double disc = bh * bh - c;
+  if (!(disc >= 0)) return 0;
+  const double sq = fsqrt(disc);
+  const double q = -(bh + (bh >= 0 ? sq : -sq));
+  double r0 = q;
+  double r1 = (q != 0) ? c * frcp(q) : r0;
   if (r0 > r1) { const double tmp = r0; r0 = r1; r1 = tmp; }
   t0 = r0; t1 = r1;
   return 2;
 }
 
 // ---- torus quartic: roots by derivative isolation + safeguarded Newton ----
+// Rare (only when a ray really enters the torus' bounding slab outside the
+// hole), kept out of line so its private arrays do not cost the hot loop
+// registers or scratch traffic.
 __device__ __forceinline__ double poly_eval(const double* c, int deg, double t) {
   double r = c[deg];
   for (int i = deg - 1; i >= 0; --i) r = r * t + c[i];
   return r;
 }
 
-__device__ double mono_root(const double* c, int deg, double a, double b) {
+__device__ __noinline__ double mono_root(const double* c, int deg, double a, double b) {
   double dc[4];
   for (int i = 1; i <= deg; ++i) dc[i - 1] = c[i] * i;
   const double fa = poly_eval(c, deg, a);
@@ -203,7 +262,7 @@ __device__ double mono_root(const double* c, int deg, double a, double b) {
 }
 
 // sign-change roots of c (degree deg) on the pieces between breakpoints
-__device__ int roots_between(const double* c, int deg, const double* brk, int nb, double* out) {
+__device__ __noinline__ int roots_between(const double* c, int deg, const double* brk, int nb, double* out) {
   int n = 0;
   for (int i = 0; i + 1 < nb; ++i) {
     const double a = brk[i], b = brk[i + 1];
@@ -219,7 +278,16 @@ __device__ int roots_between(const double* c, int deg, const double* brk, int nb
   return n;
 }
 
-__device__ int quartic_roots(const double* c4, double lo, double hi, double* out) {
+// smallest-first roots of the torus quartic on [lo, hi]; the coefficients are
+// rebuilt here from the 8 scalars the caller has in registers
+__device__ __noinline__ int torus_roots(double A, double B, double C, double E, double F, double G,
+                                        double R1, double lo, double hi, double* out) {
+  double c4[5];
+  c4[4] = A * A;
+  c4[3] = 2 * A * B;
+  c4[2] = B * B + 2 * A * C - 4 * R1 * R1 * E;
+  c4[1] = 2 * B * C - 4 * R1 * R1 * F;
+  c4[0] = C * C - 4 * R1 * R1 * G;
   // q'' (quadratic) -> q' (cubic) -> q (quartic)
   double c3[4] = {c4[1], 2 * c4[2], 3 * c4[3], 4 * c4[4]};
   double c2[3] = {c3[1], 2 * c3[2], 3 * c3[3]};
@@ -260,9 +328,14 @@ struct Query {
   Best any, oth;
 };
 
+struct SceneView {    // constant-address-space views of the scene tables
+  cf64 prim_f64, prim_box;
+  ci32 prim_i32, cond_i32;
+};
+
 // trimming by the other operands of a boolean (cond list), then bookkeeping
 // of the two running minima (nearest of all / nearest not in current medium)
-__device__ __forceinline__ void consider(const DeviceScene& sc, Query& q, double t, int p, int face,
+__device__ __forceinline__ void consider(const SceneView& sv, Query& q, double t, int p, int face,
                                          int group, int cond_off, int cond_cnt) {
   if (!(t > q.tol && t < q.tmax)) return;
   const bool cand_any = better(t, p, face, q.any);
@@ -271,10 +344,10 @@ __device__ __forceinline__ void consider(const DeviceScene& sc, Query& q, double
   if (cond_cnt) {
     const d3 gp = q.start + q.dn * t;
     for (int c = cond_off; c < cond_off + cond_cnt; ++c) {
-      const int cw = sc.cond_i32[c];
+      const int cw = sv.cond_i32[c];
       const int qp = cw & 0x7fffffff;
-      const double* pf = sc.prim_f64 + (size_t)qp * 16;
-      const double sd = prim_sdist(sc.prim_i32[4 * qp], pf + 12, xf_point(pf, gp));
+      cf64 pf = sv.prim_f64 + (size_t)qp * 16;
+      const double sd = prim_sdist(sv.prim_i32[4 * qp], pf + 12, xf_point(pf, gp));
       if (cw < 0) { if (sd > q.tol) return; }     // must be inside
       else { if (sd < -q.tol) return; }           // must be outside
     }
@@ -285,13 +358,13 @@ __device__ __forceinline__ void consider(const DeviceScene& sc, Query& q, double
 
 // every face of primitive p against the ray: untrimmed analytic surface,
 // natural face bounds with tolerance (ray.py:411-426)
-__device__ __forceinline__ void intersect_prim(const DeviceScene& sc, Query& q, int p) {
-  const double* __restrict__ pf = sc.prim_f64 + (size_t)p * 16;
-  const int32_t* __restrict__ pi = sc.prim_i32 + 4 * p;
+__device__ __forceinline__ void intersect_prim(const SceneView& sv, Query& q, int p) {
+  cf64 pf = sv.prim_f64 + (size_t)p * 16;
+  ci32 pi = sv.prim_i32 + 4 * p;
   const int type = pi[0], group = pi[1], flags = pi[2];
   const int cond_off = pi[3] & 0xffffff, cond_cnt = (pi[3] >> 24) & 0xff;
   const int fmask = flags >> ODW_FACEMASK_SHIFT;
-  const double* __restrict__ par = pf + 12;
+  cf64 par = pf + 12;
   const double tol = q.tol;
   const d3 o = xf_point(pf, q.start);
   const d3 d = xf_vec(pf, q.dn);
@@ -302,7 +375,7 @@ __device__ __forceinline__ void intersect_prim(const DeviceScene& sc, Query& q, 
       if (!((fmask >> (2 * a)) & 3)) continue;
       const int b1 = (a + 1) % 3, b2 = (a + 2) % 3;
       const double oa = comp(o, a), da = comp(d, a);
-      const double inv = 1.0 / da;
+      const double inv = frcp(da);
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         if (!((fmask >> (2 * a + s)) & 1)) continue;
@@ -310,21 +383,23 @@ __device__ __forceinline__ void intersect_prim(const DeviceScene& sc, Query& q, 
         const double p1 = comp(o, b1) + t * comp(d, b1);
         const double p2 = comp(o, b2) + t * comp(d, b2);
         if (p1 >= -tol && p1 <= par[b1] + tol && p2 >= -tol && p2 <= par[b2] + tol)
-          consider(sc, q, t, p, 2 * a + s, group, cond_off, cond_cnt);
+          consider(sv, q, t, p, 2 * a + s, group, cond_off, cond_cnt);
       }
     }
   } else if (type == ODW_PRIM_SPHERE) {
     if (fmask & 1) {
       double t0, t1;
-      const int nr = quad_roots(dot(d, d), dot(o, d), dot(o, o) - par[0] * par[0], t0, t1);
-      if (nr >= 1) consider(sc, q, t0, p, 0, group, cond_off, cond_cnt);
-      if (nr == 2) consider(sc, q, t1, p, 0, group, cond_off, cond_cnt);
+      const int nr = quad_roots_unit(dot(o, d), dot(o, o) - par[0] * par[0], t0, t1);
+      if (nr == 2) {
+        consider(sv, q, t0, p, 0, group, cond_off, cond_cnt);
+        consider(sv, q, t1, p, 0, group, cond_off, cond_cnt);
+      }
     }
   } else if (type == ODW_PRIM_CYLINDER || type == ODW_PRIM_CONE) {
     const double R1 = par[0];
     const double R2 = (type == ODW_PRIM_CYLINDER) ? par[0] : par[1];
     const double H = (type == ODW_PRIM_CYLINDER) ? par[1] : par[2];
-    const double k = (R2 - R1) / H;
+    const double k = (type == ODW_PRIM_CYLINDER) ? 0.0 : (R2 - R1) / H;
     if (fmask & 1) {
       const double rz = R1 + k * o.z;
       double t0, t1;
@@ -335,34 +410,36 @@ __device__ __forceinline__ void intersect_prim(const DeviceScene& sc, Query& q, 
         const double t = i ? t1 : t0;
         const double z = o.z + t * d.z;
         if (z >= -tol && z <= H + tol && (R1 + k * z) >= -tol)
-          consider(sc, q, t, p, 0, group, cond_off, cond_cnt);
+          consider(sv, q, t, p, 0, group, cond_off, cond_cnt);
       }
     }
-    const double invz = 1.0 / d.z;
+    if (fmask & 6) {
+      const double invz = frcp(d.z);
 #pragma unroll
-    for (int f = 1; f <= 2; ++f) {
-      if (!((fmask >> f) & 1)) continue;
-      const double rc = (f == 1) ? R1 : R2;
-      if (!(rc > 0)) continue;
-      const double t = (((f == 1) ? 0.0 : H) - o.z) * invz;
-      const double px = o.x + t * d.x, py = o.y + t * d.y;
-      if (px * px + py * py <= (rc + tol) * (rc + tol))
-        consider(sc, q, t, p, f, group, cond_off, cond_cnt);
+      for (int f = 1; f <= 2; ++f) {
+        if (!((fmask >> f) & 1)) continue;
+        const double rc = (f == 1) ? R1 : R2;
+        if (!(rc > 0)) continue;
+        const double t = (((f == 1) ? 0.0 : H) - o.z) * invz;
+        const double px = o.x + t * d.x, py = o.y + t * d.y;
+        if (px * px + py * py <= (rc + tol) * (rc + tol))
+          consider(sv, q, t, p, f, group, cond_off, cond_cnt);
+      }
     }
   } else {  // torus
     if (!(fmask & 1)) return;
     const double R1 = par[0], R2 = par[1];
-    const double dl = dot(d, d);
-    const double t0 = -dot(o, d) / dl;
-    const d3 c = o + d * t0;  // closest approach to the centre
+    const double t0 = -dot(o, d);          // |d| = 1
+    const d3 c = o + d * t0;               // closest approach to the centre
     const double bound = (R1 + R2) * 1.0000001 + 1e-9;
     const double h2 = bound * bound - dot(c, c);
-    if (!(h2 > 0)) return;  // misses the bounding sphere
-    double s_lo = -sqrt(h2 / dl), s_hi = -s_lo;
+    if (!(h2 > 0)) return;                 // misses the bounding sphere
+    double s_lo = -fsqrt(h2), s_hi = -s_lo;
     // slab |z| <= R2 (+slack): the torus lies inside it
     const double zs = R2 * 1.0000001 + 1e-9;
     if (d.z != 0) {
-      double a = (-zs - c.z) / d.z, b = (zs - c.z) / d.z;
+      const double iz = frcp(d.z);
+      double a = (-zs - c.z) * iz, b = (zs - c.z) * iz;
       if (a > b) { const double tmp = a; a = b; b = tmp; }
       s_lo = fmax(s_lo, a);
       s_hi = fmin(s_hi, b);
@@ -378,47 +455,40 @@ __device__ __forceinline__ void intersect_prim(const DeviceScene& sc, Query& q, 
       const double rin = (R1 - R2) * 0.9999999 - 1e-9;
       if (rin > 0 && xa * xa + ya * ya < rin * rin && xb * xb + yb * yb < rin * rin) return;
     }
-    const double A = dl, B = 2 * dot(c, d);
-    const double C = dot(c, c) + R1 * R1 - R2 * R2;
-    const double E = d.x * d.x + d.y * d.y, F = 2 * (c.x * d.x + c.y * d.y);
-    const double G = c.x * c.x + c.y * c.y;
-    double cf[5];
-    cf[4] = A * A;
-    cf[3] = 2 * A * B;
-    cf[2] = B * B + 2 * A * C - 4 * R1 * R1 * E;
-    cf[1] = 2 * B * C - 4 * R1 * R1 * F;
-    cf[0] = C * C - 4 * R1 * R1 * G;
     double roots[4];
-    const int nr = quartic_roots(cf, s_lo, s_hi, roots);
-    for (int i = 0; i < nr; ++i) consider(sc, q, roots[i] + t0, p, 0, group, cond_off, cond_cnt);
+    const int nr = torus_roots(dot(d, d), 2 * dot(c, d), dot(c, c) + R1 * R1 - R2 * R2,
+                               d.x * d.x + d.y * d.y, 2 * (c.x * d.x + c.y * d.y),
+                               c.x * c.x + c.y * c.y, R1, s_lo, s_hi, roots);
+    for (int i = 0; i < nr; ++i) consider(sv, q, roots[i] + t0, p, 0, group, cond_off, cond_cnt);
   }
 }
 
 // outward normal of face `face` of primitive p at local point lp
-__device__ __forceinline__ d3 face_normal(int type, const double* __restrict__ par, int face, d3 lp) {
+__device__ __forceinline__ d3 face_normal(int type, cf64 par, int face, d3 lp) {
   if (type == ODW_PRIM_BOX) {
     const double s = (face & 1) ? 1.0 : -1.0;
     const int a = face >> 1;
     return mk(a == 0 ? s : 0.0, a == 1 ? s : 0.0, a == 2 ? s : 0.0);
   }
-  if (type == ODW_PRIM_SPHERE) return lp * (1.0 / sqrt(dot(lp, lp)));
+  if (type == ODW_PRIM_SPHERE) return lp * frsqrt(dot(lp, lp));
   if (type == ODW_PRIM_CYLINDER || type == ODW_PRIM_CONE) {
     if (face == 1) return mk(0, 0, -1);
     if (face == 2) return mk(0, 0, 1);
     double k = 0;
     if (type == ODW_PRIM_CONE) k = (par[1] - par[0]) / par[2];
     const d3 g = mk(lp.x, lp.y, -k * (par[0] + k * lp.z));
-    return g * (1.0 / sqrt(dot(g, g)));
+    return g * frsqrt(dot(g, g));
   }
-  const double rho = sqrt(lp.x * lp.x + lp.y * lp.y);
-  const double f = 1.0 - par[0] / rho;
+  const double f = 1.0 - par[0] * frsqrt(lp.x * lp.x + lp.y * lp.y);
   const d3 g = mk(lp.x * f, lp.y * f, lp.z);
-  return g * (1.0 / sqrt(dot(g, g)));
+  return g * frsqrt(dot(g, g));
 }
 
-// BVH over primitive bounding boxes for big scenes (host-built, odw_capi.hip)
+// slab test against a global AABB (already enlarged by the tolerance slack).
+// A NaN from 0*inf drops out of fmin/fmax, i.e. that axis does not cull.
 #define ODW_BVH_STACK 32
-__device__ __forceinline__ bool ray_box(const double* __restrict__ bx, d3 o, d3 inv, double tmax) {
+template <class P>
+__device__ __forceinline__ bool ray_box(P bx, d3 o, d3 inv, double tmax) {
   double t0 = (bx[0] - o.x) * inv.x, t1 = (bx[3] - o.x) * inv.x;
   double lo = fmin(t0, t1), hi = fmax(t0, t1);
   t0 = (bx[1] - o.y) * inv.y; t1 = (bx[4] - o.y) * inv.y;
@@ -429,46 +499,57 @@ __device__ __forceinline__ bool ray_box(const double* __restrict__ bx, d3 o, d3 
 }
 
 // findNearestIntersection (ray.py:290-452).  Returns prim (<0: none).
-__device__ __forceinline__ int nearest(const DeviceScene& sc, const DeviceLimits& lim, d3 start,
-                                       d3 dn, int medium, uint64_t mask, double& t_hit, int& face,
+// BVH=false: flat loop, wave-uniform primitive index (scalar loads), each
+//            primitive culled by its bounding box first -- the analogue of the
+//            reference's shell/face BoundBox culls (ray.py:353-398);
+// BVH=true : stack traversal, node stack in LDS (one column per thread).
+template <bool BVH>
+__device__ __forceinline__ int nearest(const DeviceScene& sc, const SceneView& sv,
+                                       const DeviceLimits& lim, d3 start, d3 dn, int medium,
+                                       uint64_t mask, double& t_hit, int& face,
                                        int* __restrict__ stack) {
   Query q;
   q.start = start; q.dn = dn; q.tol = lim.dist_tol; q.tmax = lim.max_ray_length + lim.dist_tol;
   q.medium = medium;
   q.any.t = INFINITY; q.any.prim = 0x7fffffff; q.any.face = 0x7fffffff;
   q.oth = q.any;
-  if (sc.n_nodes == 0) {
+  const d3 inv = mk(frcp(dn.x), frcp(dn.y), frcp(dn.z));
+  if (!BVH) {
     for (int p = 0; p < sc.n_prims; ++p) {
-      const int g = sc.prim_i32[4 * p + 1];
+      const int g = sv.prim_i32[4 * p + 1];
       if (!((mask >> g) & 1)) continue;
-      intersect_prim(sc, q, p);
-    }
-  } else {
-    const d3 inv = mk(1.0 / dn.x, 1.0 / dn.y, 1.0 / dn.z);
-    int sp = 0;
-    int node = 0;
-    for (;;) {
       // candidates farther than the nearest hit + 2*distTol can never be
       // selected (ray.py:432,440): shrink the search like the reference does
       const double cut = fmin(q.tmax, q.any.t + 2.0 * q.tol);
-      bool descend = ray_box(sc.bvh_box + (size_t)node * 6, start, inv, cut);
+      if (!ray_box(sv.prim_box + 6 * p, start, inv, cut)) continue;
+      intersect_prim(sv, q, p);
+    }
+  } else {
+    cf64 bvh_box = as_const(sc.bvh_box);
+    ci32 bvh_link = as_const(sc.bvh_link);
+    ci32 bvh_prims = as_const(sc.bvh_prims);
+    int sp = 0;
+    int node = 0;
+    for (;;) {
+      const double cut = fmin(q.tmax, q.any.t + 2.0 * q.tol);
+      bool descend = ray_box(bvh_box + (size_t)node * 6, start, inv, cut);
       if (descend) {
-        const int4 lk = *reinterpret_cast<const int4*>(sc.bvh_link + 4 * node);
-        if (lk.x < 0) {  // leaf: ~first, count
-          const int first = ~lk.x;
-          for (int i = 0; i < lk.y; ++i) {
-            const int p = sc.bvh_prims[first + i];
-            const int g = sc.prim_i32[4 * p + 1];
-            if ((mask >> g) & 1) intersect_prim(sc, q, p);
+        const int lk_x = bvh_link[4 * node], lk_y = bvh_link[4 * node + 1], lk_z = bvh_link[4 * node + 2];
+        if (lk_x < 0) {  // leaf: ~first, count
+          const int first = ~lk_x;
+          for (int i = 0; i < lk_y; ++i) {
+            const int p = bvh_prims[first + i];
+            const int g = sv.prim_i32[4 * p + 1];
+            if ((mask >> g) & 1) intersect_prim(sv, q, p);
           }
           descend = false;
         } else {
           // near child first: the left child holds the smaller centroids
           // along the split axis
-          const bool fwd = comp(dn, lk.z) >= 0;
-          stack[sp * 256] = fwd ? lk.y : lk.x;  // LDS stack, one column per thread
+          const bool fwd = comp(dn, lk_z) >= 0;
+          stack[sp * 256] = fwd ? lk_y : lk_x;  // LDS stack, one column per thread
           ++sp;
-          node = fwd ? lk.x : lk.y;
+          node = fwd ? lk_x : lk_y;
         }
       }
       if (!descend) {
@@ -492,17 +573,17 @@ __device__ __forceinline__ d3 mirror(d3 r, d3 n) { return r - n * (2.0 * dot(r, 
 
 __device__ __forceinline__ d3 snells_law(d3 r, double n1, double n2, d3 n, bool& tir) {
   const d3 c = cross(n, r);
-  const double mu = n1 / n2;
+  const double mu = n1 * frcp(n2);
   const double root = 1.0 - mu * mu * dot(c, c);
   if (root < 0) { tir = true; return mirror(r, n); }
   tir = false;
   // n x ((-n) x r) = r (n.n) - n (n.r)
   const d3 perp = cross(n, cross(n * -1.0, r));
-  return perp * mu + n * sqrt(root);
+  return perp * mu + n * fsqrt(root);
 }
 
-__device__ d3 line_grating(d3 ray, double n1, double n2, d3 normal, double wavelength_nm, int order,
-                           double lpm, d3 gdir, bool transmission) {
+__device__ __noinline__ d3 line_grating(d3 ray, double n1, double n2, d3 normal, double wavelength_nm,
+                                        int order, double lpm, d3 gdir, bool transmission) {
   const double wl = wavelength_nm / 1000;
   ray = ray * (1.0 / sqrt(dot(ray, ray)));
   const d3 sn = normal * (1.0 / sqrt(dot(normal, normal)));
@@ -549,6 +630,7 @@ __device__ __forceinline__ void record_hit(const TraceParams& P, uint64_t ray, i
     }
   }
   if ((P.flags & ODW_TRACE_HISTOGRAM) && P.det.enabled && (P.det.group < 0 || P.det.group == group)) {
+#pragma clang fp contract(off)
     const d3 r = p - mk(P.det.origin[0], P.det.origin[1], P.det.origin[2]);
     const double x = dot(r, mk(P.det.ex[0], P.det.ex[1], P.det.ex[2]));
     const double y = dot(r, mk(P.det.ey[0], P.det.ey[1], P.det.ey[2]));
@@ -568,10 +650,23 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 }
 
 // ------------------------------------------------------------ the kernel
-__global__ __launch_bounds__(256) void odw_trace_kernel(const TraceParams P) {
-  extern __shared__ int bvh_stack[];  // ODW_BVH_STACK x 256 ints when the scene has a BVH
+#ifndef ODW_WAVES_PER_SIMD
+#define ODW_WAVES_PER_SIMD 2
+#endif
+template <bool BVH>
+__global__ __launch_bounds__(256, ODW_WAVES_PER_SIMD) void odw_trace_kernel(const TraceParams P) {
+  extern __shared__ int bvh_stack[];  // ODW_BVH_STACK x 256 ints (BVH variant only)
   const DeviceScene& sc = P.scene;
   const DeviceLimits& lim = P.lim;
+  SceneView sv;
+  sv.prim_f64 = as_const(sc.prim_f64);
+  sv.prim_box = as_const(sc.prim_box);
+  sv.prim_i32 = as_const(sc.prim_i32);
+  sv.cond_i32 = as_const(sc.cond_i32);
+  cf64 group_f64 = as_const(sc.group_f64);
+  ci32 group_i32 = as_const(sc.group_i32);
+  cf64 group_gdir = as_const(sc.group_gdir);
+  cu64 seq_mask = as_const(sc.seq_mask);
   uint32_t c_rays = 0, c_hits = 0, c_seg = 0, c_esc = 0, c_died = 0, c_cap = 0, c_over = 0, c_drop = 0;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P.n_rays; i += stride) {
@@ -581,6 +676,7 @@ __global__ __launch_bounds__(256) void odw_trace_kernel(const TraceParams P) {
     if (P.ray_origins) {
       point = mk(P.ray_origins[3 * i], P.ray_origins[3 * i + 1], P.ray_origins[3 * i + 2]);
       dir = mk(P.ray_dirs[3 * i], P.ray_dirs[3 * i + 1], P.ray_dirs[3 * i + 2]);
+      dir = dir * (1.0 / sqrt(dot(dir, dir)));
       power = P.ray_powers ? P.ray_powers[i] : 1.0;
     } else {
       double up, ut, t, phi;
@@ -589,26 +685,28 @@ __global__ __launch_bounds__(256) void odw_trace_kernel(const TraceParams P) {
       make_ray(P.source, t, phi, point, dir);
       power = P.source.power;
     }
+    // `dir` stays a unit vector: mirror() preserves length, snells_law() and
+    // line_grating() return unit vectors for unit input; the reference
+    // renormalises every segment (ray.py:377), a no-op up to rounding
     int seq = 0, nint = 0, medium = -1;
     for (;;) {
       if (nint >= lim.max_intersections) { ++c_cap; break; }
       ++nint;
       ++c_seg;
       uint64_t mask = sc.all_mask;
-      if (sc.seq_enabled) mask = (seq < sc.seq_len) ? sc.seq_mask[seq] : 0ull;
+      if (sc.seq_enabled) mask = (seq < sc.seq_len) ? seq_mask[seq] : 0ull;
       mask &= ~sc.ignore_mask;
-      const d3 dn = dir * (1.0 / sqrt(dot(dir, dir)));
       double t_hit;
       int face;
-      const int prim = nearest(sc, lim, point, dn, medium, mask, t_hit, face, bvh_stack + threadIdx.x);
+      const int prim = nearest<BVH>(sc, sv, lim, point, dir, medium, mask, t_hit, face,
+                                    bvh_stack + threadIdx.x);
       if (prim < 0) { ++c_esc; break; }
-      const double* __restrict__ pf = sc.prim_f64 + (size_t)prim * 16;
-      const int32_t* __restrict__ pi = sc.prim_i32 + 4 * prim;
-      const d3 prev = point;
-      point = point + dn * t_hit;
+      cf64 pf = sv.prim_f64 + (size_t)prim * 16;
+      ci32 pi = sv.prim_i32 + 4 * prim;
+      point = point + dir * t_hit;
       // absorption along the traversed medium (ray.py:120-125, assignment)
       if (medium >= 0) {
-        const double L = sc.group_f64[4 * medium + 2];
+        const double L = group_f64[4 * medium + 2];
         if (L == 0) power = 0;
         else if (L < INFINITY) power = exp(-t_hit / L);
       }
@@ -616,24 +714,24 @@ __global__ __launch_bounds__(256) void odw_trace_kernel(const TraceParams P) {
       d3 n = face_normal(pi[0], pf + 12, face, xf_point(pf, point));
       if (pi[2] & ODW_FLAG_FLIP_NORMAL) n = n * -1.0;
       n = xf_vec_t(pf, n);
-      const bool entering = dot(point - prev, n) < 0;
+      const bool entering = dot(dir, n) < 0;
       if (entering) n = n * -1.0;
       const int g = pi[1];
-      const int gtype = sc.group_i32[4 * g];
-      if (sc.group_i32[4 * g + 1]) {
+      const int gtype = group_i32[4 * g];
+      if (group_i32[4 * g + 1]) {
         ++c_hits;
         record_hit(P, ray, g, point, dir, power, entering, c_over, c_drop);
       }
       if (gtype == ODW_OPT_MIRROR) {
         dir = mirror(dir, n);
-        power *= sc.group_f64[4 * g + 1];
+        power *= group_f64[4 * g + 1];
         ++seq;
       } else if (gtype == ODW_OPT_LENS) {
-        const double n1 = (medium >= 0) ? sc.group_f64[4 * medium] : 1.0;
+        const double n1 = (medium >= 0) ? group_f64[4 * medium] : 1.0;
         double n2 = 1.0;
-        if (entering) { medium = g; n2 = sc.group_f64[4 * g]; }
+        if (entering) { medium = g; n2 = group_f64[4 * g]; }
         bool tir;
-        dir = snells_law(dn, n1, n2, n, tir);
+        dir = snells_law(dir, n1, n2, n, tir);
         if (!entering && !tir && medium == g) { medium = -1; ++seq; }
       } else if (gtype == ODW_OPT_ABSORBER) {
         power = 0;
@@ -641,23 +739,23 @@ __global__ __launch_bounds__(256) void odw_trace_kernel(const TraceParams P) {
       } else if (gtype == ODW_OPT_VACUUM) {
         ++seq;
       } else {  // grating (ray.py:216-268)
-        const d3 gd = mk(sc.group_gdir[3 * g], sc.group_gdir[3 * g + 1], sc.group_gdir[3 * g + 2]);
-        const double lpm = sc.group_f64[4 * g + 3];
-        const int order = sc.group_i32[4 * g + 3];
-        if (sc.group_i32[4 * g + 2] == 0) {
+        const d3 gd = mk(group_gdir[3 * g], group_gdir[3 * g + 1], group_gdir[3 * g + 2]);
+        const double lpm = group_f64[4 * g + 3];
+        const int order = group_i32[4 * g + 3];
+        if (group_i32[4 * g + 2] == 0) {
           if (entering) {
-            const double nn = (medium >= 0) ? sc.group_f64[4 * medium] : 1.0;
-            dir = line_grating(dn, nn, nn, n, P.source.wavelength, order, lpm, gd, false);
+            const double nn = (medium >= 0) ? group_f64[4 * medium] : 1.0;
+            dir = line_grating(dir, nn, nn, n, P.source.wavelength, order, lpm, gd, false);
             ++seq;
           }
         } else if (entering) {
           if (medium >= 0) { ++c_died; break; }
           medium = g;
-          dir = line_grating(dn, 1.0, sc.group_f64[4 * g], n, P.source.wavelength, order, lpm, gd, true);
+          dir = line_grating(dir, 1.0, group_f64[4 * g], n, P.source.wavelength, order, lpm, gd, true);
         } else {
-          const double n1 = (medium >= 0) ? sc.group_f64[4 * medium] : 1.0;
+          const double n1 = (medium >= 0) ? group_f64[4 * medium] : 1.0;
           bool tir;
-          dir = snells_law(dn, n1, 1.0, n, tir);
+          dir = snells_law(dir, n1, 1.0, n, tir);
           if (!tir) { medium = -1; ++seq; }
         }
       }
