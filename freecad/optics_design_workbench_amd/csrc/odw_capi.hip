@@ -47,7 +47,9 @@ struct odw_ctx {
 
   DevBuf prim_f64, prim_box, prim_i32, cond_i32, group_f64, group_i32, group_gdir, seq_mask;
   DevBuf bvh_box, bvh_link, bvh_prims;
-  DevBuf phi_tab, t_tab, t_guide;
+  DevBuf phi_tab, t_tab, t_guide, d_source, d_det;
+  DeviceSource h_source;
+  DeviceDetector h_det;
   DevBuf hits, hit_count, hist, counters;
   DevBuf ray_o, ray_d, ray_p, samp_t, samp_phi;
   uint64_t hit_capacity = 0, n_bins = 0;
@@ -257,7 +259,7 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
   }
   if ((flags & ODW_TRACE_RECORD_HITS) && ctx->hit_capacity == 0)
     return fail(ctx, ODW_ERR_CAPACITY, "ODW_TRACE_RECORD_HITS without odw_reserve_hits");
-  if ((flags & ODW_TRACE_HISTOGRAM) && !ctx->P.det.enabled) flags &= ~ODW_TRACE_HISTOGRAM;
+  if ((flags & ODW_TRACE_HISTOGRAM) && !ctx->P.det_enabled) flags &= ~ODW_TRACE_HISTOGRAM;
   TraceParams& P = ctx->P;
   P.first_ray = first;
   P.n_rays = n;
@@ -321,6 +323,8 @@ int odw_create(int device, odw_ctx** out) {
   ctx->device = device;
   std::memset(&ctx->P, 0, sizeof ctx->P);
   std::memset(&ctx->det_desc, 0, sizeof ctx->det_desc);
+  std::memset(&ctx->h_source, 0, sizeof ctx->h_source);
+  std::memset(&ctx->h_det, 0, sizeof ctx->h_det);
   if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess) {
     fail(nullptr, ODW_ERR_DEVICE, std::string("odw_create: ") + hipGetErrorString(e));
     delete ctx;
@@ -346,7 +350,7 @@ void odw_destroy(odw_ctx* ctx) {
   for (auto& ev : ctx->free_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   DevBuf* all[] = {&ctx->prim_f64, &ctx->prim_box, &ctx->prim_i32, &ctx->cond_i32, &ctx->group_f64, &ctx->group_i32,
                    &ctx->group_gdir, &ctx->seq_mask, &ctx->bvh_box, &ctx->bvh_link, &ctx->bvh_prims,
-                   &ctx->phi_tab, &ctx->t_tab, &ctx->t_guide, &ctx->hits, &ctx->hit_count, &ctx->hist,
+                   &ctx->phi_tab, &ctx->t_tab, &ctx->t_guide, &ctx->d_source, &ctx->d_det, &ctx->hits, &ctx->hit_count, &ctx->hist,
                    &ctx->counters, &ctx->ray_o, &ctx->ray_d, &ctx->ray_p, &ctx->samp_t, &ctx->samp_phi};
   for (DevBuf* b : all) release(*b);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -463,7 +467,7 @@ int odw_upload_source(odw_ctx* ctx, const odw_source_desc* s) {
   if ((rc = upload(ctx, ctx->t_tab, ttab.data(), ttab.size() * sizeof(double)))) return rc;
   if ((rc = upload(ctx, ctx->t_guide, guide.data(), guide.size() * sizeof(int32_t)))) return rc;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  DeviceSource& d = ctx->P.source;
+  DeviceSource& d = ctx->h_source;
   std::memcpy(d.m, s->xform, sizeof d.m);
   d.focal_length = s->focal_length;
   d.finite_focal = std::isfinite(s->focal_length) ? 1 : 0;
@@ -476,6 +480,9 @@ int odw_upload_source(odw_ctx* ctx, const odw_source_desc* s) {
   d.n_t_knots = nt;
   d.n_t_rows = rows;
   d.n_guide = kGuide;
+  if ((rc = upload(ctx, ctx->d_source, &ctx->h_source, sizeof(DeviceSource)))) return rc;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->P.source = (const DeviceSource*)ctx->d_source.p;
   ctx->have_source = true;
   return ODW_OK;
 }
@@ -496,8 +503,8 @@ int odw_set_limits(odw_ctx* ctx, const odw_limits* l) {
 int odw_set_detector(odw_ctx* ctx, const odw_detector_desc* det) {
   if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_set_detector: null ctx");
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  DeviceDetector& d = ctx->P.det;
-  if (!det) { d.enabled = 0; ctx->n_bins = 0; return ODW_OK; }
+  DeviceDetector& d = ctx->h_det;
+  if (!det) { d.enabled = 0; ctx->P.det_enabled = 0; ctx->n_bins = 0; return ODW_OK; }
   if (det->nx <= 0 || det->ny <= 0 || !(det->x_hi > det->x_lo) || !(det->y_hi > det->y_lo))
     return fail(ctx, ODW_ERR_INVALID, "odw_set_detector: bad window");
   ctx->det_desc = *det;
@@ -508,11 +515,17 @@ int odw_set_detector(odw_ctx* ctx, const odw_detector_desc* det) {
   d.y_scale = det->ny / (det->y_hi - det->y_lo);
   d.nx = det->nx;
   d.ny = det->ny;
+  d.nx_f = (double)det->nx;
+  d.ny_f = (double)det->ny;
   d.group = det->group;
   d.enabled = 1;
   ctx->n_bins = (uint64_t)det->nx * (uint64_t)det->ny;
   int rc = ensure(ctx, ctx->hist, ctx->n_bins * sizeof(uint64_t));
   if (rc) return rc;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // a running launch may still read the old block
+  if ((rc = upload(ctx, ctx->d_det, &ctx->h_det, sizeof(DeviceDetector)))) return rc;
+  ctx->P.det = (const DeviceDetector*)ctx->d_det.p;
+  ctx->P.det_enabled = 1;
   HIPCHK(ctx, hipMemsetAsync(ctx->hist.p, 0, ctx->n_bins * sizeof(uint64_t), ctx->stream));
   return ODW_OK;
 }

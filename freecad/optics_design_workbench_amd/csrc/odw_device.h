@@ -68,6 +68,7 @@ struct DeviceLimits {
 struct DeviceDetector {
   double origin[3], ex[3], ey[3];
   double x_lo, y_lo, x_scale, y_scale;  // scale = n/(hi-lo)
+  double nx_f, ny_f;
   int32_t nx, ny, group, enabled;
 };
 
@@ -79,11 +80,16 @@ struct DeviceOutputs {
   unsigned long long* counters;        // ODW_CNT_COUNT
 };
 
+// Kernel argument.  The source and detector blocks live in device memory and
+// are read where they are used (once per ray) through an opaque pointer:
+// passed by value, hipcc hoists every field (and values derived from them)
+// out of the ray loop and keeps ~40 VGPRs occupied for the whole kernel.
 struct TraceParams {
   DeviceScene scene;
-  DeviceSource source;
   DeviceLimits lim;
-  DeviceDetector det;
+  const DeviceSource* source;
+  const DeviceDetector* det;
+  int32_t det_enabled;
   DeviceOutputs out;
   const double* ray_origins;    // explicit initial conditions (or null)
   const double* ray_dirs;

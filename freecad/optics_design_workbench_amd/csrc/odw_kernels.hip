@@ -33,6 +33,15 @@ template <class T>
 __device__ __forceinline__ const T ODW_CONST* as_const(const T* p) {
   return (const T ODW_CONST*)(uintptr_t)p;
 }
+// a uniform pointer the optimiser cannot see through: loads behind it stay
+// where they are written instead of being hoisted out of the ray loop
+template <class T>
+__device__ __forceinline__ const T* opaque(const T* p) {
+  asm volatile("" : "+s"(p));
+  return p;
+}
+typedef const DeviceSource ODW_CONST* csource;
+typedef const DeviceDetector ODW_CONST* cdetector;
 
 // ---- cheap float64 reciprocal / square root ------------------------------
 // v_rcp_f64 / v_rsq_f64 deliver ~26 bits; two Newton steps give ~1 ulp without
@@ -105,9 +114,12 @@ __device__ __forceinline__ double inv_cdf(const double* __restrict__ tab, int lo
   return prod + a.y;
 }
 
-__device__ __forceinline__ void sample_source(const DeviceSource& s, double u_phi, double u_t,
+__device__ __forceinline__ void sample_source(csource sp_, double u_phi, double u_t,
                                               double& t_out, double& phi_out) {
 #pragma clang fp contract(off)
+  struct { const double* phi_tab; const double* t_tab; const int32_t* t_guide; int n_phi_knots, n_t_knots, n_t_rows, n_guide; } s;
+  s.phi_tab = sp_->phi_tab; s.t_tab = sp_->t_tab; s.t_guide = sp_->t_guide;
+  s.n_phi_knots = sp_->n_phi_knots; s.n_t_knots = sp_->n_t_knots; s.n_t_rows = sp_->n_t_rows; s.n_guide = sp_->n_guide;
   const double phi = inv_cdf(s.phi_tab, 0, s.n_phi_knots - 1, u_phi);
   int row = 0;
   if (s.n_t_rows > 1) {
@@ -149,24 +161,45 @@ __device__ __forceinline__ d3 xf_vec_t(P m, d3 v) {  // R^T v
             m[2] * v.x + m[6] * v.y + m[10] * v.z);
 }
 
+// sin and cos for |x| <~ 64 (source angles are domain-limited): one Cody-Waite
+// reduction step by pi/2 with fma, fdlibm kernel polynomials; <= 1 ulp of 1.0
+// absolute error (checked against libm on 4e6 points).  Replaces ocml's
+// sincos(double), whose large-argument path costs ~20 extra VGPRs.
+__device__ __forceinline__ void sincos_bounded(double x, double& s, double& c) {
+  const double k = rint(x * 0.63661977236758134308);
+  double r = fma(-k, 1.5707963267948966, x);
+  r = fma(-k, 6.123233995736766e-17, r);
+  const double z = r * r;
+  const double ps = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 +
+                    z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+  const double sn = r + (z * r) * (-1.66666666666666324348e-01 + z * ps);
+  const double pc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                    z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+  const double cs = 1.0 - (0.5 * z - z * pc);
+  const int q = (int)k & 3;
+  const double a = (q & 1) ? cs : sn, b = (q & 1) ? sn : cs;
+  s = (q & 2) ? -a : a;
+  c = ((q + 1) & 2) ? -b : b;
+}
+
 // PointSourceProxy._makeRay (point_source.py:411-460)
-__device__ __forceinline__ void make_ray(const DeviceSource& s, double t_or_r, double phi,
+__device__ __forceinline__ void make_ray(csource s, double t_or_r, double phi,
                                          d3& origin, d3& dir) {
   d3 ldir, lorg;
   double sp, cp;
-  sincos(phi, &sp, &cp);
-  if (s.finite_focal) {
+  sincos_bounded(phi, sp, cp);
+  if (s->finite_focal) {
     double st, ct;
-    sincos(t_or_r, &st, &ct);
+    sincos_bounded(t_or_r, st, ct);
     ldir = mk(st * sp, -st * cp, ct);
-    lorg = (mk(0, 0, 1) - ldir) * s.focal_length;
+    lorg = (mk(0, 0, 1) - ldir) * s->focal_length;
   } else {
     ldir = mk(0, 0, 1);
     lorg = mk(t_or_r * cp, -t_or_r * sp, 0.0);
   }
   const d3 ln = ldir * (1.0 / sqrt(dot(ldir, ldir)));
-  const d3 p1 = xf_point(s.m, lorg);
-  const d3 p2 = xf_point(s.m, lorg + ln);
+  const d3 p1 = xf_point(s->m, lorg);
+  const d3 p2 = xf_point(s->m, lorg + ln);
   const d3 d = p2 - p1;
   origin = p1;
   dir = d * (1.0 / sqrt(dot(d, d)));
@@ -230,86 +263,6 @@ __device__ __forceinline__ int quad_roots_unit(double bh, double c, double& t0, 
   return 2;
 }
 
-// ---- torus quartic: roots by derivative isolation + safeguarded Newton ----
-// Rare (only when a ray really enters the torus' bounding slab outside the
-// hole), kept out of line so its private arrays do not cost the hot loop
-// registers or scratch traffic.
-__device__ __forceinline__ double poly_eval(const double* c, int deg, double t) {
-  double r = c[deg];
-  for (int i = deg - 1; i >= 0; --i) r = r * t + c[i];
-  return r;
-}
-
-__device__ __noinline__ double mono_root(const double* c, int deg, double a, double b) {
-  double dc[4];
-  for (int i = 1; i <= deg; ++i) dc[i - 1] = c[i] * i;
-  const double fa = poly_eval(c, deg, a);
-  double lo = a, hi = b;
-  if (fa > 0) { lo = b; hi = a; }
-  double x = 0.5 * (a + b);
-  for (int it = 0; it < 200; ++it) {
-    const double f = poly_eval(c, deg, x);
-    if (f == 0) return x;
-    if (f < 0) lo = x; else hi = x;
-    const double df = poly_eval(dc, deg - 1, x);
-    double xn = (df != 0) ? x - f / df : 0.5 * (lo + hi);
-    const double mn = fmin(lo, hi), mx = fmax(lo, hi);
-    if (!(xn > mn && xn < mx)) xn = 0.5 * (lo + hi);
-    if (xn == x || fabs(hi - lo) <= 4e-16 * (fabs(lo) + fabs(hi))) return xn;
-    x = xn;
-  }
-  return x;
-}
-
-// sign-change roots of c (degree deg) on the pieces between breakpoints
-__device__ __noinline__ int roots_between(const double* c, int deg, const double* brk, int nb, double* out) {
-  int n = 0;
-  for (int i = 0; i + 1 < nb; ++i) {
-    const double a = brk[i], b = brk[i + 1];
-    if (!(b > a)) continue;
-    const double fa = poly_eval(c, deg, a), fb = poly_eval(c, deg, b);
-    if (fa == 0) {
-      if (n == 0 || out[n - 1] != a) out[n++] = a;
-      continue;
-    }
-    if ((fa < 0 && fb > 0) || (fa > 0 && fb < 0)) out[n++] = mono_root(c, deg, a, b);
-    else if (fb == 0 && i + 2 == nb) out[n++] = b;
-  }
-  return n;
-}
-
-// smallest-first roots of the torus quartic on [lo, hi]; the coefficients are
-// rebuilt here from the 8 scalars the caller has in registers
-__device__ __noinline__ int torus_roots(double A, double B, double C, double E, double F, double G,
-                                        double R1, double lo, double hi, double* out) {
-  double c4[5];
-  c4[4] = A * A;
-  c4[3] = 2 * A * B;
-  c4[2] = B * B + 2 * A * C - 4 * R1 * R1 * E;
-  c4[1] = 2 * B * C - 4 * R1 * R1 * F;
-  c4[0] = C * C - 4 * R1 * R1 * G;
-  // q'' (quadratic) -> q' (cubic) -> q (quartic)
-  double c3[4] = {c4[1], 2 * c4[2], 3 * c4[3], 4 * c4[4]};
-  double c2[3] = {c3[1], 2 * c3[2], 3 * c3[3]};
-  double brk[6];
-  int nb = 0;
-  brk[nb++] = lo;
-  {
-    double r0, r1;
-    const int nr = quad_roots(c2[2], 0.5 * c2[1], c2[0], r0, r1);
-    if (nr >= 1 && r0 > lo && r0 < hi) brk[nb++] = r0;
-    if (nr == 2 && r1 > lo && r1 < hi && r1 != r0) brk[nb++] = r1;
-  }
-  brk[nb++] = hi;
-  double crit[4];
-  const int nc = roots_between(c3, 3, brk, nb, crit);
-  nb = 0;
-  brk[nb++] = lo;
-  for (int i = 0; i < nc; ++i) brk[nb++] = crit[i];
-  brk[nb++] = hi;
-  return roots_between(c4, 4, brk, nb, out);
-}
-
 // ------------------------------------------------------------------------
 struct Best {
   double t;
@@ -333,8 +286,10 @@ struct SceneView {    // constant-address-space views of the scene tables
   ci32 prim_i32, cond_i32;
 };
 
-// trimming by the other operands of a boolean (cond list), then bookkeeping
-// of the two running minima (nearest of all / nearest not in current medium)
+// One candidate intersection of primitive p: range test, then -- only if it
+// would replace a running minimum -- the trim by the other operands of a
+// boolean (cond list), then bookkeeping of the two running minima (nearest of
+// all / nearest whose group is not the current medium).
 __device__ __forceinline__ void consider(const SceneView& sv, Query& q, double t, int p, int face,
                                          int group, int cond_off, int cond_cnt) {
   if (!(t > q.tol && t < q.tmax)) return;
@@ -356,8 +311,33 @@ __device__ __forceinline__ void consider(const SceneView& sv, Query& q, double t
   if (cand_oth) { q.oth.t = t; q.oth.prim = p; q.oth.face = face; }
 }
 
+// up to four candidate (t, face) pairs of one primitive, kept in registers
+struct Cands {
+  double t0, t1, t2, t3;
+  int f0, f1, f2, f3;
+};
+__device__ __forceinline__ void cand_push(Cands& c, int& n, double t, int f) {
+  // n is compile-time after unrolling at every call site
+  if (n == 0) { c.t0 = t; c.f0 = f; }
+  else if (n == 1) { c.t1 = t; c.f1 = f; }
+  else if (n == 2) { c.t2 = t; c.f2 = f; }
+  else { c.t3 = t; c.f3 = f; }
+  ++n;
+}
+// keep the two smallest (t, face) of a stream (box: entry and exit face)
+__device__ __forceinline__ void cand_min2(Cands& c, double t, int f) {
+  const bool lt0 = t < c.t0 || (t == c.t0 && f < c.f0);
+  const bool lt1 = t < c.t1 || (t == c.t1 && f < c.f1);
+  c.t1 = lt0 ? c.t0 : (lt1 ? t : c.t1);
+  c.f1 = lt0 ? c.f0 : (lt1 ? f : c.f1);
+  c.t0 = lt0 ? t : c.t0;
+  c.f0 = lt0 ? f : c.f0;
+}
+
 // every face of primitive p against the ray: untrimmed analytic surface,
-// natural face bounds with tolerance (ray.py:411-426)
+// natural face bounds with tolerance (ray.py:411-426).  The candidates are
+// collected first and judged by ONE copy of consider() (code size: the hot
+// loop must stay inside the instruction cache).
 __device__ __forceinline__ void intersect_prim(const SceneView& sv, Query& q, int p) {
   cf64 pf = sv.prim_f64 + (size_t)p * 16;
   ci32 pi = sv.prim_i32 + 4 * p;
@@ -368,31 +348,54 @@ __device__ __forceinline__ void intersect_prim(const SceneView& sv, Query& q, in
   const double tol = q.tol;
   const d3 o = xf_point(pf, q.start);
   const d3 d = xf_vec(pf, q.dn);
+  Cands c;
+  c.t0 = c.t1 = c.t2 = c.t3 = INFINITY;
+  c.f0 = c.f1 = c.f2 = c.f3 = 0;
 
   if (type == ODW_PRIM_BOX) {
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      if (!((fmask >> (2 * a)) & 3)) continue;
-      const int b1 = (a + 1) % 3, b2 = (a + 2) % 3;
-      const double oa = comp(o, a), da = comp(d, a);
-      const double inv = frcp(da);
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        if (!((fmask >> (2 * a + s)) & 1)) continue;
-        const double t = ((s ? par[a] : 0.0) - oa) * inv;
-        const double p1 = comp(o, b1) + t * comp(d, b1);
-        const double p2 = comp(o, b2) + t * comp(d, b2);
-        if (p1 >= -tol && p1 <= par[b1] + tol && p2 >= -tol && p2 <= par[b2] + tol)
-          consider(sv, q, t, p, 2 * a + s, group, cond_off, cond_cnt);
-      }
+    // Slab form of the six plane tests.  Per axis the ray meets the low/high
+    // plane at tn <= tf; a face hit is valid when the other two coordinates lie
+    // inside the face rectangle (+- tol).  All faces of a primitive share its
+    // group, so without trimming conditions only the nearest valid hit can be
+    // selected: the three entry faces are tried first, the three exit faces
+    // only if no entry face qualifies (ray starts inside / on the box) or the
+    // box is trimmed (a nearer candidate may then be rejected by its trim).
+    const double ix = frcp(d.x), iy = frcp(d.y), iz = frcp(d.z);
+    const double ax = -o.x * ix, ay = -o.y * iy, az = -o.z * iz;            // plane at 0
+    const double bx = fma(par[0], ix, ax), by = fma(par[1], iy, ay), bz = fma(par[2], iz, az);
+    const bool px = d.x > 0, py = d.y > 0, pz = d.z > 0;
+    double bt = INFINITY;
+    int bf = 0;
+#define ODW_BOX_FACE(T, FACE, P1, D1, S1, P2, D2, S2)                                         \
+    {                                                                                         \
+      const double t_ = (T);                                                                  \
+      const double u_ = fma(t_, D1, P1), v_ = fma(t_, D2, P2);                                \
+      const bool ok_ = ((fmask >> (FACE)) & 1) && t_ > tol && u_ >= -tol && u_ <= (S1) + tol && \
+                       v_ >= -tol && v_ <= (S2) + tol;                                        \
+      if (ok_ && (t_ < bt || (t_ == bt && (FACE) < bf))) { bt = t_; bf = (FACE); }            \
     }
+    // entry faces: low face when moving in +axis direction
+    ODW_BOX_FACE(px ? ax : bx, px ? 0 : 1, o.y, d.y, par[1], o.z, d.z, par[2]);
+    ODW_BOX_FACE(py ? ay : by, py ? 2 : 3, o.z, d.z, par[2], o.x, d.x, par[0]);
+    ODW_BOX_FACE(pz ? az : bz, pz ? 4 : 5, o.x, d.x, par[0], o.y, d.y, par[1]);
+    c.t0 = bt;
+    c.f0 = bf;
+    if (cond_cnt || !(bt < INFINITY)) {
+      bt = INFINITY;
+      bf = 0;
+      ODW_BOX_FACE(px ? bx : ax, px ? 1 : 0, o.y, d.y, par[1], o.z, d.z, par[2]);
+      ODW_BOX_FACE(py ? by : ay, py ? 3 : 2, o.z, d.z, par[2], o.x, d.x, par[0]);
+      ODW_BOX_FACE(pz ? bz : az, pz ? 5 : 4, o.x, d.x, par[0], o.y, d.y, par[1]);
+      c.t1 = bt;
+      c.f1 = bf;
+    }
+#undef ODW_BOX_FACE
   } else if (type == ODW_PRIM_SPHERE) {
     if (fmask & 1) {
       double t0, t1;
-      const int nr = quad_roots_unit(dot(o, d), dot(o, o) - par[0] * par[0], t0, t1);
-      if (nr == 2) {
-        consider(sv, q, t0, p, 0, group, cond_off, cond_cnt);
-        consider(sv, q, t1, p, 0, group, cond_off, cond_cnt);
+      if (quad_roots_unit(dot(o, d), dot(o, o) - par[0] * par[0], t0, t1) == 2) {
+        c.t0 = t0;
+        c.t1 = t1;
       }
     }
   } else if (type == ODW_PRIM_CYLINDER || type == ODW_PRIM_CONE) {
@@ -402,64 +405,117 @@ __device__ __forceinline__ void intersect_prim(const SceneView& sv, Query& q, in
     const double k = (type == ODW_PRIM_CYLINDER) ? 0.0 : (R2 - R1) / H;
     if (fmask & 1) {
       const double rz = R1 + k * o.z;
-      double t0, t1;
+      double t0 = INFINITY, t1 = INFINITY;
       const int nr = quad_roots(d.x * d.x + d.y * d.y - k * k * d.z * d.z,
                                 o.x * d.x + o.y * d.y - k * rz * d.z,
                                 o.x * o.x + o.y * o.y - rz * rz, t0, t1);
-      for (int i = 0; i < nr; ++i) {
-        const double t = i ? t1 : t0;
-        const double z = o.z + t * d.z;
-        if (z >= -tol && z <= H + tol && (R1 + k * z) >= -tol)
-          consider(sv, q, t, p, 0, group, cond_off, cond_cnt);
-      }
+      const double z0 = o.z + t0 * d.z, z1 = o.z + t1 * d.z;
+      if (nr >= 1 && z0 >= -tol && z0 <= H + tol && (R1 + k * z0) >= -tol) c.t0 = t0;
+      if (nr == 2 && z1 >= -tol && z1 <= H + tol && (R1 + k * z1) >= -tol) c.t1 = t1;
     }
     if (fmask & 6) {
       const double invz = frcp(d.z);
-#pragma unroll
-      for (int f = 1; f <= 2; ++f) {
-        if (!((fmask >> f) & 1)) continue;
-        const double rc = (f == 1) ? R1 : R2;
-        if (!(rc > 0)) continue;
-        const double t = (((f == 1) ? 0.0 : H) - o.z) * invz;
-        const double px = o.x + t * d.x, py = o.y + t * d.y;
-        if (px * px + py * py <= (rc + tol) * (rc + tol))
-          consider(sv, q, t, p, f, group, cond_off, cond_cnt);
-      }
+      const double ta = (0.0 - o.z) * invz, tb = (H - o.z) * invz;
+      const double xa = o.x + ta * d.x, ya = o.y + ta * d.y;
+      const double xb = o.x + tb * d.x, yb = o.y + tb * d.y;
+      if ((fmask & 2) && R1 > 0 && xa * xa + ya * ya <= (R1 + tol) * (R1 + tol)) { c.t2 = ta; c.f2 = 1; }
+      if ((fmask & 4) && R2 > 0 && xb * xb + yb * yb <= (R2 + tol) * (R2 + tol)) { c.t3 = tb; c.f3 = 2; }
     }
   } else {  // torus
     if (!(fmask & 1)) return;
     const double R1 = par[0], R2 = par[1];
     const double t0 = -dot(o, d);          // |d| = 1
-    const d3 c = o + d * t0;               // closest approach to the centre
+    const d3 cc = o + d * t0;              // closest approach to the centre
     const double bound = (R1 + R2) * 1.0000001 + 1e-9;
-    const double h2 = bound * bound - dot(c, c);
+    const double h2 = bound * bound - dot(cc, cc);
     if (!(h2 > 0)) return;                 // misses the bounding sphere
     double s_lo = -fsqrt(h2), s_hi = -s_lo;
     // slab |z| <= R2 (+slack): the torus lies inside it
     const double zs = R2 * 1.0000001 + 1e-9;
     if (d.z != 0) {
       const double iz = frcp(d.z);
-      double a = (-zs - c.z) * iz, b = (zs - c.z) * iz;
+      double a = (-zs - cc.z) * iz, b = (zs - cc.z) * iz;
       if (a > b) { const double tmp = a; a = b; b = tmp; }
       s_lo = fmax(s_lo, a);
       s_hi = fmin(s_hi, b);
-    } else if (fabs(c.z) > zs) {
+    } else if (fabs(cc.z) > zs) {
       return;
     }
     if (!(s_hi > s_lo)) return;
     // through the hole: rho^2 is convex in s, its maximum over the clipped
     // segment is at an end point
     {
-      const double xa = c.x + s_lo * d.x, ya = c.y + s_lo * d.y;
-      const double xb = c.x + s_hi * d.x, yb = c.y + s_hi * d.y;
+      const double xa = cc.x + s_lo * d.x, ya = cc.y + s_lo * d.y;
+      const double xb = cc.x + s_hi * d.x, yb = cc.y + s_hi * d.y;
       const double rin = (R1 - R2) * 0.9999999 - 1e-9;
       if (rin > 0 && xa * xa + ya * ya < rin * rin && xb * xb + yb * yb < rin * rin) return;
     }
-    double roots[4];
-    const int nr = torus_roots(dot(d, d), 2 * dot(c, d), dot(c, c) + R1 * R1 - R2 * R2,
-                               d.x * d.x + d.y * d.y, 2 * (c.x * d.x + c.y * d.y),
-                               c.x * c.x + c.y * c.y, R1, s_lo, s_hi, roots);
-    for (int i = 0; i < nr; ++i) consider(sv, q, roots[i] + t0, p, 0, group, cond_off, cond_cnt);
+    // Crossings of the tube surface by marching the exact distance function
+    // f(s) = |(rho - R1, z)| - R2 (|df/ds| <= 1, so a step of |f| cannot
+    // jump over the surface), each sign change polished by bracketed Newton.
+    // No coefficient arrays, no calls: the state is a dozen registers.
+    const double s_begin = fmax(s_lo, 0.5 * tol - t0);   // roots with t <= tol/2 are rejected anyway
+    const double step_min = 1e-7 * R2;
+    double sc = s_begin, fc;
+    {
+      const double px = cc.x + sc * d.x, py = cc.y + sc * d.y, pz = cc.z + sc * d.z;
+      const double a = fsqrt(px * px + py * py) - R1;
+      fc = fsqrt(a * a + pz * pz) - R2;
+    }
+    int nfound = 0;
+    for (int it = 0; it < 4096 && sc < s_hi && nfound < 4; ++it) {
+      const double sn = fmin(sc + fmax(fabs(fc), step_min), s_hi);
+      double fn;
+      {
+        const double px = cc.x + sn * d.x, py = cc.y + sn * d.y, pz = cc.z + sn * d.z;
+        const double a = fsqrt(px * px + py * py) - R1;
+        fn = fsqrt(a * a + pz * pz) - R2;
+      }
+      if ((fc > 0) != (fn > 0)) {
+        double lo = sc, hi = sn, x = sn;
+        const bool lo_pos = fc > 0;
+        for (int j = 0; j < 48; ++j) {
+          const double px = cc.x + x * d.x, py = cc.y + x * d.y, pz = cc.z + x * d.z;
+          const double rho = fsqrt(px * px + py * py);
+          const double a = rho - R1;
+          const double rr = fsqrt(a * a + pz * pz);
+          const double f = rr - R2;
+          if ((f > 0) == lo_pos) lo = x; else hi = x;
+          // df/ds = grad f . d,  grad f = ((a/rr) (px,py)/rho, pz/rr)
+          const double ir = frcp(rr * rho);
+          const double df = (a * (px * d.x + py * d.y)) * ir + pz * d.z * frcp(rr);
+          double xn = x - f * frcp(df);
+          if (!(xn > lo && xn < hi)) xn = 0.5 * (lo + hi);
+          const bool done = fabs(xn - x) <= 2e-16 * fabs(x) || f == 0;
+          x = xn;
+          if (done) break;
+        }
+        const double tr = x + t0;
+        if (nfound == 0) c.t0 = tr; else if (nfound == 1) c.t1 = tr; else if (nfound == 2) c.t2 = tr; else c.t3 = tr;
+        ++nfound;
+      }
+      sc = sn;
+      fc = fn;
+    }
+  }
+  if (cond_cnt == 0) {
+    // untrimmed: only the nearest admissible candidate can win
+    double bt = INFINITY;
+    int bf = 0;
+#define ODW_PICK(T, F) if ((T) > tol && ((T) < bt || ((T) == bt && (F) < bf))) { bt = (T); bf = (F); }
+    ODW_PICK(c.t0, c.f0)
+    ODW_PICK(c.t1, c.f1)
+    ODW_PICK(c.t2, c.f2)
+    ODW_PICK(c.t3, c.f3)
+#undef ODW_PICK
+    consider(sv, q, bt, p, bf, group, 0, 0);
+  } else {
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) {
+      const double t = k == 0 ? c.t0 : (k == 1 ? c.t1 : (k == 2 ? c.t2 : c.t3));
+      const int f = k == 0 ? c.f0 : (k == 1 ? c.f1 : (k == 2 ? c.f2 : c.f3));
+      consider(sv, q, t, p, f, group, cond_off, cond_cnt);
+    }
   }
 }
 
@@ -488,12 +544,13 @@ __device__ __forceinline__ d3 face_normal(int type, cf64 par, int face, d3 lp) {
 // A NaN from 0*inf drops out of fmin/fmax, i.e. that axis does not cull.
 #define ODW_BVH_STACK 32
 template <class P>
-__device__ __forceinline__ bool ray_box(P bx, d3 o, d3 inv, double tmax) {
-  double t0 = (bx[0] - o.x) * inv.x, t1 = (bx[3] - o.x) * inv.x;
+__device__ __forceinline__ bool ray_box(P bx, d3 oi, d3 inv, double tmax) {
+  // oi = origin * inv (component-wise): one fma per plane
+  double t0 = fma(bx[0], inv.x, -oi.x), t1 = fma(bx[3], inv.x, -oi.x);
   double lo = fmin(t0, t1), hi = fmax(t0, t1);
-  t0 = (bx[1] - o.y) * inv.y; t1 = (bx[4] - o.y) * inv.y;
+  t0 = fma(bx[1], inv.y, -oi.y); t1 = fma(bx[4], inv.y, -oi.y);
   lo = fmax(lo, fmin(t0, t1)); hi = fmin(hi, fmax(t0, t1));
-  t0 = (bx[2] - o.z) * inv.z; t1 = (bx[5] - o.z) * inv.z;
+  t0 = fma(bx[2], inv.z, -oi.z); t1 = fma(bx[5], inv.z, -oi.z);
   lo = fmax(lo, fmin(t0, t1)); hi = fmin(hi, fmax(t0, t1));
   return hi >= fmax(lo, 0.0) && lo < tmax;
 }
@@ -514,6 +571,7 @@ __device__ __forceinline__ int nearest(const DeviceScene& sc, const SceneView& s
   q.any.t = INFINITY; q.any.prim = 0x7fffffff; q.any.face = 0x7fffffff;
   q.oth = q.any;
   const d3 inv = mk(frcp(dn.x), frcp(dn.y), frcp(dn.z));
+  const d3 oi = mk(start.x * inv.x, start.y * inv.y, start.z * inv.z);
   if (!BVH) {
     for (int p = 0; p < sc.n_prims; ++p) {
       const int g = sv.prim_i32[4 * p + 1];
@@ -521,7 +579,7 @@ __device__ __forceinline__ int nearest(const DeviceScene& sc, const SceneView& s
       // candidates farther than the nearest hit + 2*distTol can never be
       // selected (ray.py:432,440): shrink the search like the reference does
       const double cut = fmin(q.tmax, q.any.t + 2.0 * q.tol);
-      if (!ray_box(sv.prim_box + 6 * p, start, inv, cut)) continue;
+      if (!ray_box(sv.prim_box + 6 * p, oi, inv, cut)) continue;
       intersect_prim(sv, q, p);
     }
   } else {
@@ -532,7 +590,7 @@ __device__ __forceinline__ int nearest(const DeviceScene& sc, const SceneView& s
     int node = 0;
     for (;;) {
       const double cut = fmin(q.tmax, q.any.t + 2.0 * q.tol);
-      bool descend = ray_box(bvh_box + (size_t)node * 6, start, inv, cut);
+      bool descend = ray_box(bvh_box + (size_t)node * 6, oi, inv, cut);
       if (descend) {
         const int lk_x = bvh_link[4 * node], lk_y = bvh_link[4 * node + 1], lk_z = bvh_link[4 * node + 2];
         if (lk_x < 0) {  // leaf: ~first, count
@@ -562,10 +620,12 @@ __device__ __forceinline__ int nearest(const DeviceScene& sc, const SceneView& s
   if (q.any.prim == 0x7fffffff) return -1;
   // hits within 2*distTol of the nearest: prefer one whose group differs
   // from the current medium (ray.py:438-452)
-  const Best& sel = (q.oth.prim != 0x7fffffff && q.oth.t < q.any.t + 2.0 * q.tol) ? q.oth : q.any;
-  t_hit = sel.t;
-  face = sel.face;
-  return sel.prim;
+  // (selected member by member: a reference picked with ?: would pin both
+  // records in scratch memory)
+  const bool use_oth = q.oth.prim != 0x7fffffff && q.oth.t < q.any.t + 2.0 * q.tol;
+  t_hit = use_oth ? q.oth.t : q.any.t;
+  face = use_oth ? q.oth.face : q.any.face;
+  return use_oth ? q.oth.prim : q.any.prim;
 }
 
 // ------------------------------------------ mirror / Snell / grating
@@ -582,7 +642,7 @@ __device__ __forceinline__ d3 snells_law(d3 r, double n1, double n2, d3 n, bool&
   return perp * mu + n * fsqrt(root);
 }
 
-__device__ __noinline__ d3 line_grating(d3 ray, double n1, double n2, d3 normal, double wavelength_nm,
+__device__ __forceinline__ d3 line_grating(d3 ray, double n1, double n2, d3 normal, double wavelength_nm,
                                         int order, double lpm, d3 gdir, bool transmission) {
   const double wl = wavelength_nm / 1000;
   ray = ray * (1.0 / sqrt(dot(ray, ray)));
@@ -607,8 +667,7 @@ __device__ __noinline__ d3 line_grating(d3 ray, double n1, double n2, d3 normal,
 // Active lanes append one 64-B row each: one atomic per wave reserves the
 // block, lanes take consecutive slots by popcount prefix of the ballot.
 __device__ __forceinline__ void record_hit(const TraceParams& P, uint64_t ray, int group, d3 p, d3 d,
-                                           double power, bool entering, uint32_t& n_over,
-                                           uint32_t& n_drop) {
+                                           double power, bool entering, uint32_t* cnt) {
   if (P.flags & ODW_TRACE_RECORD_HITS) {
     const uint64_t active = __ballot(1);
     const int lane = __lane_id();
@@ -626,20 +685,23 @@ __device__ __forceinline__ void record_hit(const TraceParams& P, uint64_t ray, i
       row[2] = make_double2(d.y, d.z);
       row[3] = make_double2(power, __longlong_as_double((long long)tag));
     } else {
-      ++n_drop;
+      cnt[ODW_CNT_HITS_DROPPED * 256] += 1u;
     }
   }
-  if ((P.flags & ODW_TRACE_HISTOGRAM) && P.det.enabled && (P.det.group < 0 || P.det.group == group)) {
+  if ((P.flags & ODW_TRACE_HISTOGRAM) && P.det_enabled) {
 #pragma clang fp contract(off)
-    const d3 r = p - mk(P.det.origin[0], P.det.origin[1], P.det.origin[2]);
-    const double x = dot(r, mk(P.det.ex[0], P.det.ex[1], P.det.ex[2]));
-    const double y = dot(r, mk(P.det.ey[0], P.det.ey[1], P.det.ey[2]));
-    const double fx = floor((x - P.det.x_lo) * P.det.x_scale);
-    const double fy = floor((y - P.det.y_lo) * P.det.y_scale);
-    if (fx >= 0 && fx < (double)P.det.nx && fy >= 0 && fy < (double)P.det.ny)
-      atomicAdd(P.out.hist + ((size_t)fx * (size_t)P.det.ny + (size_t)fy), 1ull);
-    else
-      ++n_over;
+    cdetector det = as_const(opaque(P.det));
+    if (det->group < 0 || det->group == group) {
+      const d3 r = p - mk(det->origin[0], det->origin[1], det->origin[2]);
+      const double x = dot(r, mk(det->ex[0], det->ex[1], det->ex[2]));
+      const double y = dot(r, mk(det->ey[0], det->ey[1], det->ey[2]));
+      const double fx = floor((x - det->x_lo) * det->x_scale);
+      const double fy = floor((y - det->y_lo) * det->y_scale);
+      if (fx >= 0 && fx < det->nx_f && fy >= 0 && fy < det->ny_f)
+        atomicAdd(P.out.hist + ((size_t)fx * (size_t)det->ny + (size_t)fy), 1ull);
+      else
+        cnt[ODW_CNT_HIST_OVERFLOW * 256] += 1u;
+    }
   }
 }
 
@@ -651,11 +713,17 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 
 // ------------------------------------------------------------ the kernel
 #ifndef ODW_WAVES_PER_SIMD
-#define ODW_WAVES_PER_SIMD 2
+#define ODW_WAVES_PER_SIMD 4
 #endif
 template <bool BVH>
 __global__ __launch_bounds__(256, ODW_WAVES_PER_SIMD) void odw_trace_kernel(const TraceParams P) {
   extern __shared__ int bvh_stack[];  // ODW_BVH_STACK x 256 ints (BVH variant only)
+  // per-thread event counters live in LDS (one column per thread, ds_add_u32
+  // at the event): eight fewer VGPRs across the whole ray loop
+  __shared__ uint32_t cnt_lds[ODW_CNT_COUNT * 256];
+#pragma unroll
+  for (int k = 0; k < ODW_CNT_COUNT; ++k) cnt_lds[k * 256 + threadIdx.x] = 0;
+#define ODW_COUNT(k) (cnt_lds[(k) * 256 + threadIdx.x] += 1u)
   const DeviceScene& sc = P.scene;
   const DeviceLimits& lim = P.lim;
   SceneView sv;
@@ -667,10 +735,8 @@ __global__ __launch_bounds__(256, ODW_WAVES_PER_SIMD) void odw_trace_kernel(cons
   ci32 group_i32 = as_const(sc.group_i32);
   cf64 group_gdir = as_const(sc.group_gdir);
   cu64 seq_mask = as_const(sc.seq_mask);
-  uint32_t c_rays = 0, c_hits = 0, c_seg = 0, c_esc = 0, c_died = 0, c_cap = 0, c_over = 0, c_drop = 0;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P.n_rays; i += stride) {
-    const uint64_t ray = P.first_ray + i;
     d3 point, dir;
     double power;
     if (P.ray_origins) {
@@ -680,19 +746,19 @@ __global__ __launch_bounds__(256, ODW_WAVES_PER_SIMD) void odw_trace_kernel(cons
       power = P.ray_powers ? P.ray_powers[i] : 1.0;
     } else {
       double up, ut, t, phi;
-      ray_uniforms(ray, P.seed, up, ut);
-      sample_source(P.source, up, ut, t, phi);
-      make_ray(P.source, t, phi, point, dir);
-      power = P.source.power;
+      csource src = as_const(opaque(P.source));
+      ray_uniforms(P.first_ray + i, P.seed, up, ut);
+      sample_source(src, up, ut, t, phi);
+      make_ray(src, t, phi, point, dir);
+      power = src->power;
     }
     // `dir` stays a unit vector: mirror() preserves length, snells_law() and
     // line_grating() return unit vectors for unit input; the reference
     // renormalises every segment (ray.py:377), a no-op up to rounding
     int seq = 0, nint = 0, medium = -1;
     for (;;) {
-      if (nint >= lim.max_intersections) { ++c_cap; break; }
+      if (nint >= lim.max_intersections) { ODW_COUNT(ODW_CNT_CAPPED); break; }
       ++nint;
-      ++c_seg;
       uint64_t mask = sc.all_mask;
       if (sc.seq_enabled) mask = (seq < sc.seq_len) ? seq_mask[seq] : 0ull;
       mask &= ~sc.ignore_mask;
@@ -700,7 +766,7 @@ __global__ __launch_bounds__(256, ODW_WAVES_PER_SIMD) void odw_trace_kernel(cons
       int face;
       const int prim = nearest<BVH>(sc, sv, lim, point, dir, medium, mask, t_hit, face,
                                     bvh_stack + threadIdx.x);
-      if (prim < 0) { ++c_esc; break; }
+      if (prim < 0) { ODW_COUNT(ODW_CNT_ESCAPED); break; }
       cf64 pf = sv.prim_f64 + (size_t)prim * 16;
       ci32 pi = sv.prim_i32 + 4 * prim;
       point = point + dir * t_hit;
@@ -719,8 +785,8 @@ __global__ __launch_bounds__(256, ODW_WAVES_PER_SIMD) void odw_trace_kernel(cons
       const int g = pi[1];
       const int gtype = group_i32[4 * g];
       if (group_i32[4 * g + 1]) {
-        ++c_hits;
-        record_hit(P, ray, g, point, dir, power, entering, c_over, c_drop);
+        ODW_COUNT(ODW_CNT_RECORDED_HITS);
+        record_hit(P, P.first_ray + i, g, point, dir, power, entering, cnt_lds + threadIdx.x);
       }
       if (gtype == ODW_OPT_MIRROR) {
         dir = mirror(dir, n);
@@ -745,13 +811,13 @@ __global__ __launch_bounds__(256, ODW_WAVES_PER_SIMD) void odw_trace_kernel(cons
         if (group_i32[4 * g + 2] == 0) {
           if (entering) {
             const double nn = (medium >= 0) ? group_f64[4 * medium] : 1.0;
-            dir = line_grating(dir, nn, nn, n, P.source.wavelength, order, lpm, gd, false);
+            dir = line_grating(dir, nn, nn, n, as_const(opaque(P.source))->wavelength, order, lpm, gd, false);
             ++seq;
           }
         } else if (entering) {
-          if (medium >= 0) { ++c_died; break; }
+          if (medium >= 0) { ODW_COUNT(ODW_CNT_DIED); break; }
           medium = g;
-          dir = line_grating(dir, 1.0, group_f64[4 * g], n, P.source.wavelength, order, lpm, gd, true);
+          dir = line_grating(dir, 1.0, group_f64[4 * g], n, as_const(opaque(P.source))->wavelength, order, lpm, gd, true);
         } else {
           const double n1 = (medium >= 0) ? group_f64[4 * medium] : 1.0;
           bool tir;
@@ -759,21 +825,21 @@ __global__ __launch_bounds__(256, ODW_WAVES_PER_SIMD) void odw_trace_kernel(cons
           if (!tir) { medium = -1; ++seq; }
         }
       }
-      if (power < lim.power_tol) { ++c_died; break; }
+      if (power < lim.power_tol) { ODW_COUNT(ODW_CNT_DIED); break; }
     }
-    ++c_rays;
+    cnt_lds[ODW_CNT_SEGMENTS * 256 + threadIdx.x] += (uint32_t)nint;
+    ODW_COUNT(ODW_CNT_TRACED_RAYS);
   }
   // counters: wave reduction, one atomic per wave and counter
-  uint32_t v[ODW_CNT_COUNT] = {c_rays, c_hits, c_seg, c_esc, c_died, c_cap, c_over, c_drop};
 #pragma unroll
   for (int k = 0; k < ODW_CNT_COUNT; ++k) {
-    const uint32_t s = wave_sum(v[k]);
+    const uint32_t s = wave_sum(cnt_lds[k * 256 + threadIdx.x]);
     if (__lane_id() == 0 && s) atomicAdd(P.out.counters + k, (unsigned long long)s);
   }
 }
 
 // sampler only: theta-or-radius and phi per ray (diagnostics / parity tests)
-__global__ __launch_bounds__(256) void odw_sample_kernel(const DeviceSource s, uint64_t first,
+__global__ __launch_bounds__(256) void odw_sample_kernel(const DeviceSource* sp, uint64_t first,
                                                          uint64_t n, uint64_t seed,
                                                          double* __restrict__ t_out,
                                                          double* __restrict__ phi_out) {
@@ -781,7 +847,7 @@ __global__ __launch_bounds__(256) void odw_sample_kernel(const DeviceSource s, u
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     double up, ut, t, phi;
     ray_uniforms(first + i, seed, up, ut);
-    sample_source(s, up, ut, t, phi);
+    sample_source(as_const(sp), up, ut, t, phi);
     t_out[i] = t;
     phi_out[i] = phi;
   }
