@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -275,7 +276,9 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
   P.out.counters = (unsigned long long*)ctx->counters.p;
 
   const uint64_t want = (n + 255) / 256;
-  const uint64_t cap = (uint64_t)ctx->n_cu * 8;  // >> 256 workgroups, grid-stride over the rest
+  // >> 256 workgroups, grid-stride over the rest (ODW_GRID_MULT: blocks per CU, tuning knob)
+  static const int grid_mult = [] { const char* e = getenv("ODW_GRID_MULT"); int v = e ? atoi(e) : 0; return v > 0 ? v : 64; }();
+  const uint64_t cap = (uint64_t)ctx->n_cu * grid_mult;
   const unsigned grid = (unsigned)std::min<uint64_t>(want, cap);
   const size_t lds = P.scene.n_nodes ? (size_t)ODW_BVH_STACK * 256 * sizeof(int) : 0;
 
