@@ -128,6 +128,18 @@ def main():
     bytes_per_ray = kbar * 2 * RAY_STATE_BYTES + hbar * HIT_BYTES
     avg_kernel_s = kernel_ms / 1e3 / max(1, launches)
     achieved = bytes_per_ray * n_per / avg_kernel_s / 1e9
+    # HBM traffic of one launch from the committed rocprofv3 PMC passes of this
+    # same command (FETCH_SIZE / WRITE_SIZE, separate --pmc runs, gfx950
+    # correction applied; see profiles/traffic.json).  PMC cannot be collected
+    # from inside the process, so the figure is only attached when the
+    # workload matches the profiled one.
+    traffic = traffic_src = None
+    tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+    if os.path.exists(tpath):
+      tj = json.load(open(tpath))
+      if tj.get('rays_per_launch') == n_per and record_hits:
+        traffic = tj['hbm_bytes_per_launch'] / avg_kernel_s / 1e9
+        traffic_src = tj.get('source')
     out = {
         'metric': 'Monte-Carlo rays/sec (whole node), lensesAndMirrors.FCStd',
         'value': total_rays / dt, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps,
@@ -140,7 +152,7 @@ def main():
                    'record_hit_rows': record_hits, 'histogram': '1024x1024 u64',
                    'parallelism': f'ray-index sharding x{world}, one RCCL reduce'},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
                      'kernel': 'odw_trace_kernel', 'avg_kernel_ms': avg_kernel_s * 1e3,
                      'algorithmic_bytes_per_ray': bytes_per_ray},
     }
