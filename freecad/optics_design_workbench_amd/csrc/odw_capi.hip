@@ -325,6 +325,7 @@ int odw_create(int device, odw_ctx** out) {
   if (!ctx) return fail(nullptr, ODW_ERR_DEVICE, "out of host memory");
   ctx->device = device;
   std::memset(&ctx->P, 0, sizeof ctx->P);
+  ctx->P.wavelength = 500.0;
   std::memset(&ctx->det_desc, 0, sizeof ctx->det_desc);
   std::memset(&ctx->h_source, 0, sizeof ctx->h_source);
   std::memset(&ctx->h_det, 0, sizeof ctx->h_det);
@@ -486,6 +487,7 @@ int odw_upload_source(odw_ctx* ctx, const odw_source_desc* s) {
   if ((rc = upload(ctx, ctx->d_source, &ctx->h_source, sizeof(DeviceSource)))) return rc;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->P.source = (const DeviceSource*)ctx->d_source.p;
+  ctx->P.wavelength = s->wavelength;
   ctx->have_source = true;
   return ODW_OK;
 }

@@ -90,6 +90,7 @@ struct TraceParams {
   const DeviceSource* source;
   const DeviceDetector* det;
   int32_t det_enabled;
+  double wavelength;            // nm; of the uploaded source, 500 if none (explicit rays)
   DeviceOutputs out;
   const double* ray_origins;    // explicit initial conditions (or null)
   const double* ray_dirs;

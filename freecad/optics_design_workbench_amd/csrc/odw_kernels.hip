@@ -480,13 +480,16 @@ __device__ __forceinline__ void intersect_prim(const SceneView& sv, Query& q, in
           const double a = rho - R1;
           const double rr = fsqrt(a * a + pz * pz);
           const double f = rr - R2;
+          if (f == 0) break;
           if ((f > 0) == lo_pos) lo = x; else hi = x;
           // df/ds = grad f . d,  grad f = ((a/rr) (px,py)/rho, pz/rr)
           const double ir = frcp(rr * rho);
           const double df = (a * (px * d.x + py * d.y)) * ir + pz * d.z * frcp(rr);
           double xn = x - f * frcp(df);
-          if (!(xn > lo && xn < hi)) xn = 0.5 * (lo + hi);
-          const bool done = fabs(xn - x) <= 2e-16 * fabs(x) || f == 0;
+          if (!(xn >= lo && xn <= hi)) xn = 0.5 * (lo + hi);
+          // converged when Newton stops moving (it then sits on a bracket end:
+          // the bracket test above must be inclusive) or the bracket is empty
+          const bool done = xn == x || (hi - lo) <= 4e-16 * (fabs(lo) + fabs(hi));
           x = xn;
           if (done) break;
         }
@@ -811,13 +814,13 @@ __global__ __launch_bounds__(256, ODW_WAVES_PER_SIMD) void odw_trace_kernel(cons
         if (group_i32[4 * g + 2] == 0) {
           if (entering) {
             const double nn = (medium >= 0) ? group_f64[4 * medium] : 1.0;
-            dir = line_grating(dir, nn, nn, n, as_const(opaque(P.source))->wavelength, order, lpm, gd, false);
+            dir = line_grating(dir, nn, nn, n, P.wavelength, order, lpm, gd, false);
             ++seq;
           }
         } else if (entering) {
           if (medium >= 0) { ODW_COUNT(ODW_CNT_DIED); break; }
           medium = g;
-          dir = line_grating(dir, 1.0, group_f64[4 * g], n, as_const(opaque(P.source))->wavelength, order, lpm, gd, true);
+          dir = line_grating(dir, 1.0, group_f64[4 * g], n, P.wavelength, order, lpm, gd, true);
         } else {
           const double n1 = (medium >= 0) ? group_f64[4 * medium] : 1.0;
           bool tir;

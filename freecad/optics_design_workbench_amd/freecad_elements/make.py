@@ -67,8 +67,8 @@ def makeCommon(doc, shapes, name='Common', **pl):
   return doc.addObject('Part::MultiCommon', name, Shapes=list(shapes), Placement=_placement(**pl))
 
 
-def makeCut(doc, base, tool, name='Cut', **pl):
-  return doc.addObject('Part::Cut', name, Base=base, Tool=tool, Placement=_placement(**pl))
+def makeCut(doc, baseObject, toolObject, name='Cut', **pl):
+  return doc.addObject('Part::Cut', name, Base=baseObject, Tool=toolObject, Placement=_placement(**pl))
 
 
 def makeFuse(doc, shapes, name='Fusion', **pl):
