@@ -51,7 +51,7 @@ struct odw_ctx {
   DevBuf phi_tab, t_tab, t_guide, d_source, d_det;
   DeviceSource h_source;
   DeviceDetector h_det;
-  DevBuf hits, hit_count, hist, counters;
+  DevBuf hits, hit_count, hist, counters, chunk_counter;
   DevBuf ray_o, ray_d, ray_p, samp_t, samp_phi;
   uint64_t hit_capacity = 0, n_bins = 0;
 
@@ -274,12 +274,16 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
   P.out.hit_count = (unsigned long long*)ctx->hit_count.p;
   P.out.hist = (unsigned long long*)ctx->hist.p;
   P.out.counters = (unsigned long long*)ctx->counters.p;
+  P.out.chunk_counter = (unsigned long long*)ctx->chunk_counter.p;
 
-  const uint64_t want = (n + 255) / 256;
-  // >> 256 workgroups, grid-stride over the rest (ODW_GRID_MULT: blocks per CU, tuning knob)
-  static const int grid_mult = [] { const char* e = getenv("ODW_GRID_MULT"); int v = e ? atoi(e) : 0; return v > 0 ? v : 64; }();
+  // persistent waves: one grid that fills the chip (4 blocks of 256 threads
+  // per CU at 4 waves/SIMD, x2 so that a CU never waits for a block launch);
+  // chunks of ODW_CHUNK rays are handed out dynamically inside the kernel
+  static const int grid_mult = [] { const char* e = getenv("ODW_GRID_MULT"); int v = e ? atoi(e) : 0; return v > 0 ? v : 8; }();
+  const uint64_t n_chunks = (n + ODW_CHUNK - 1) / ODW_CHUNK;
   const uint64_t cap = (uint64_t)ctx->n_cu * grid_mult;
-  const unsigned grid = (unsigned)std::min<uint64_t>(want, cap);
+  const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_chunks + 3) / 4, cap));
+  HIPCHK(ctx, hipMemsetAsync(ctx->chunk_counter.p, 0, sizeof(uint64_t), ctx->stream));
   const size_t lds = P.scene.n_nodes ? (size_t)ODW_BVH_STACK * 256 * sizeof(int) : 0;
 
   std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
@@ -338,6 +342,7 @@ int odw_create(int device, odw_ctx** out) {
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
   int rc = ensure(ctx, ctx->counters, ODW_CNT_COUNT * sizeof(uint64_t));
   if (!rc) rc = ensure(ctx, ctx->hit_count, sizeof(uint64_t));
+  if (!rc) rc = ensure(ctx, ctx->chunk_counter, sizeof(uint64_t));
   if (!rc) rc = ensure(ctx, ctx->hist, 16);
   if (rc) { g_error = ctx->err; odw_destroy(ctx); return rc; }
   (void)hipMemsetAsync(ctx->counters.p, 0, ctx->counters.bytes, ctx->stream);
@@ -354,7 +359,7 @@ void odw_destroy(odw_ctx* ctx) {
   for (auto& ev : ctx->free_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   DevBuf* all[] = {&ctx->prim_f64, &ctx->prim_box, &ctx->prim_i32, &ctx->cond_i32, &ctx->group_f64, &ctx->group_i32,
                    &ctx->group_gdir, &ctx->seq_mask, &ctx->bvh_box, &ctx->bvh_link, &ctx->bvh_prims,
-                   &ctx->phi_tab, &ctx->t_tab, &ctx->t_guide, &ctx->d_source, &ctx->d_det, &ctx->hits, &ctx->hit_count, &ctx->hist,
+                   &ctx->phi_tab, &ctx->t_tab, &ctx->t_guide, &ctx->d_source, &ctx->d_det, &ctx->hits, &ctx->hit_count, &ctx->chunk_counter, &ctx->hist,
                    &ctx->counters, &ctx->ray_o, &ctx->ray_d, &ctx->ray_p, &ctx->samp_t, &ctx->samp_phi};
   for (DevBuf* b : all) release(*b);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

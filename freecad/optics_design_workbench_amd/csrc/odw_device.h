@@ -78,6 +78,7 @@ struct DeviceOutputs {
   unsigned long long* hit_count;       // device counter
   unsigned long long* hist;            // nx*ny
   unsigned long long* counters;        // ODW_CNT_COUNT
+  unsigned long long* chunk_counter;   // next unassigned chunk of this launch (zeroed per launch)
 };
 
 // Kernel argument.  The source and detector blocks live in device memory and

@@ -589,34 +589,43 @@ __device__ __forceinline__ int nearest(const DeviceScene& sc, const SceneView& s
     cf64 bvh_box = as_const(sc.bvh_box);
     ci32 bvh_link = as_const(sc.bvh_link);
     ci32 bvh_prims = as_const(sc.bvh_prims);
+    // "while-while" traversal: every lane first walks inner nodes (cheap,
+    // same code for all lanes) until it stands on a leaf or is done; only then
+    // are the leaf primitives intersected (expensive), so that part runs with
+    // as many lanes as possible instead of one lane at a time.
     int sp = 0;
     int node = 0;
     for (;;) {
-      const double cut = fmin(q.tmax, q.any.t + 2.0 * q.tol);
-      bool descend = ray_box(bvh_box + (size_t)node * 6, oi, inv, cut);
-      if (descend) {
-        const int lk_x = bvh_link[4 * node], lk_y = bvh_link[4 * node + 1], lk_z = bvh_link[4 * node + 2];
-        if (lk_x < 0) {  // leaf: ~first, count
-          const int first = ~lk_x;
-          for (int i = 0; i < lk_y; ++i) {
-            const int p = bvh_prims[first + i];
-            const int g = sv.prim_i32[4 * p + 1];
-            if ((mask >> g) & 1) intersect_prim(sv, q, p);
+      int leaf_first = 0, leaf_count = 0;
+      while (node >= 0) {
+        const double cut = fmin(q.tmax, q.any.t + 2.0 * q.tol);
+        int nxt = -1;
+        if (ray_box(bvh_box + (size_t)node * 6, oi, inv, cut)) {
+          const int lk_x = bvh_link[4 * node], lk_y = bvh_link[4 * node + 1];
+          if (lk_x < 0) {            // leaf: ~first, count
+            leaf_first = ~lk_x;
+            leaf_count = lk_y;
+          } else {
+            // near child first: the left child holds the smaller centroids
+            // along the split axis
+            const bool fwd = comp(dn, bvh_link[4 * node + 2]) >= 0;
+            stack[sp * 256] = fwd ? lk_y : lk_x;  // LDS stack, one column per thread
+            ++sp;
+            nxt = fwd ? lk_x : lk_y;
           }
-          descend = false;
-        } else {
-          // near child first: the left child holds the smaller centroids
-          // along the split axis
-          const bool fwd = comp(dn, lk_z) >= 0;
-          stack[sp * 256] = fwd ? lk_y : lk_x;  // LDS stack, one column per thread
-          ++sp;
-          node = fwd ? lk_x : lk_y;
         }
+        if (nxt < 0 && sp > 0) {
+          --sp;
+          nxt = stack[sp * 256];
+        }
+        node = nxt;
+        if (leaf_count) break;
       }
-      if (!descend) {
-        if (sp == 0) break;
-        --sp;
-        node = stack[sp * 256];
+      if (!leaf_count) break;        // stack exhausted
+      for (int i = 0; i < leaf_count; ++i) {
+        const int p = bvh_prims[leaf_first + i];
+        const int g = sv.prim_i32[4 * p + 1];
+        if ((mask >> g) & 1) intersect_prim(sv, q, p);
       }
     }
   }
@@ -715,6 +724,12 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 }
 
 // ------------------------------------------------------------ the kernel
+#ifndef ODW_CHUNK
+#define ODW_CHUNK 2048ull      // rays per hand-out unit (32 per lane)
+#endif
+#ifndef ODW_REFILL_MIN
+#define ODW_REFILL_MIN 16      // idle lanes that trigger a refill of a partly busy wave
+#endif
 #ifndef ODW_WAVES_PER_SIMD
 #define ODW_WAVES_PER_SIMD 4
 #endif
@@ -738,29 +753,69 @@ __global__ __launch_bounds__(256, ODW_WAVES_PER_SIMD) void odw_trace_kernel(cons
   ci32 group_i32 = as_const(sc.group_i32);
   cf64 group_gdir = as_const(sc.group_gdir);
   cu64 seq_mask = as_const(sc.seq_mask);
-  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P.n_rays; i += stride) {
-    d3 point, dir;
-    double power;
-    if (P.ray_origins) {
-      point = mk(P.ray_origins[3 * i], P.ray_origins[3 * i + 1], P.ray_origins[3 * i + 2]);
-      dir = mk(P.ray_dirs[3 * i], P.ray_dirs[3 * i + 1], P.ray_dirs[3 * i + 2]);
-      dir = dir * (1.0 / sqrt(dot(dir, dir)));
-      power = P.ray_powers ? P.ray_powers[i] : 1.0;
-    } else {
-      double up, ut, t, phi;
-      csource src = as_const(opaque(P.source));
-      ray_uniforms(P.first_ray + i, P.seed, up, ut);
-      sample_source(src, up, ut, t, phi);
-      make_ray(src, t, phi, point, dir);
-      power = src->power;
+  // Persistent waves with ray regeneration.  Rays are handed out in chunks of
+  // ODW_CHUNK consecutive indices, taken from a launch-wide atomic counter.  A
+  // lane whose ray has terminated takes the next index of its wave's chunk
+  // (ballot + popcount prefix, no atomics) instead of idling until the slowest
+  // ray of the wave is done -- in scenes like hugeArray path lengths range
+  // from 1 to 100 segments, and a wave would otherwise run at the pace of its
+  // longest path.  One loop iteration = one segment of every live lane.
+  const uint32_t lane = __lane_id();
+  uint64_t next = 0, chunk_end = 0;                        // wave-uniform
+  bool alive = false;
+  uint64_t i = 0;
+  d3 point = mk(0, 0, 0), dir = mk(0, 0, 1);
+  double power = 0;
+  int seq = 0, nint = 0, medium = -1;
+  for (;;) {
+    const uint64_t idle = __ballot(!alive);
+    // refill when the wave is empty or enough lanes are idle to make the
+    // (divergent) generation code worth running
+    if (idle && (idle == ~0ull || __popcll(idle) >= ODW_REFILL_MIN)) {
+      if (next >= chunk_end) {
+        // next chunk of the launch: one atomic per wave and chunk (dynamic
+        // hand-out keeps every CU busy until the very end of the launch)
+        unsigned long long c = 0;
+        if (lane == (uint32_t)(__ffsll((unsigned long long)__ballot(1)) - 1)) c = atomicAdd(P.out.chunk_counter, 1ull);
+        const uint64_t chunk = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(c >> 32)) << 32) |
+                               __builtin_amdgcn_readfirstlane((uint32_t)c);
+        next = chunk * ODW_CHUNK;
+        if (next > P.n_rays) next = P.n_rays;
+        chunk_end = next + ODW_CHUNK < P.n_rays ? next + ODW_CHUNK : P.n_rays;
+      }
+      const uint64_t avail = next < chunk_end ? chunk_end - next : 0;
+      const uint32_t rank = __popcll(idle & ((1ull << lane) - 1ull));
+      const uint32_t want = __popcll(idle);
+      const uint32_t take = want < avail ? want : (uint32_t)avail;
+      if (!alive && rank < take) {
+        i = next + rank;
+        if (P.ray_origins) {
+          point = mk(P.ray_origins[3 * i], P.ray_origins[3 * i + 1], P.ray_origins[3 * i + 2]);
+          dir = mk(P.ray_dirs[3 * i], P.ray_dirs[3 * i + 1], P.ray_dirs[3 * i + 2]);
+          dir = dir * (1.0 / sqrt(dot(dir, dir)));
+          power = P.ray_powers ? P.ray_powers[i] : 1.0;
+        } else {
+          double up, ut, t, phi;
+          csource src = as_const(opaque(P.source));
+          ray_uniforms(P.first_ray + i, P.seed, up, ut);
+          sample_source(src, up, ut, t, phi);
+          make_ray(src, t, phi, point, dir);
+          power = src->power;
+        }
+        // `dir` stays a unit vector: mirror() preserves length, snells_law() and
+        // line_grating() return unit vectors for unit input; the reference
+        // renormalises every segment (ray.py:377), a no-op up to rounding
+        seq = 0; nint = 0; medium = -1;
+        alive = true;
+      }
+      next += take;
+      if (take == 0 && idle == ~0ull) break;               // nothing live, nothing left
     }
-    // `dir` stays a unit vector: mirror() preserves length, snells_law() and
-    // line_grating() return unit vectors for unit input; the reference
-    // renormalises every segment (ray.py:377), a no-op up to rounding
-    int seq = 0, nint = 0, medium = -1;
-    for (;;) {
-      if (nint >= lim.max_intersections) { ODW_COUNT(ODW_CNT_CAPPED); break; }
+    if (alive) {
+      if (nint >= lim.max_intersections) {
+        ODW_COUNT(ODW_CNT_CAPPED);
+        alive = false;
+      } else {
       ++nint;
       uint64_t mask = sc.all_mask;
       if (sc.seq_enabled) mask = (seq < sc.seq_len) ? seq_mask[seq] : 0ull;
@@ -769,7 +824,10 @@ __global__ __launch_bounds__(256, ODW_WAVES_PER_SIMD) void odw_trace_kernel(cons
       int face;
       const int prim = nearest<BVH>(sc, sv, lim, point, dir, medium, mask, t_hit, face,
                                     bvh_stack + threadIdx.x);
-      if (prim < 0) { ODW_COUNT(ODW_CNT_ESCAPED); break; }
+      if (prim < 0) {
+        ODW_COUNT(ODW_CNT_ESCAPED);
+        alive = false;
+      } else {
       cf64 pf = sv.prim_f64 + (size_t)prim * 16;
       ci32 pi = sv.prim_i32 + 4 * prim;
       point = point + dir * t_hit;
@@ -818,7 +876,7 @@ __global__ __launch_bounds__(256, ODW_WAVES_PER_SIMD) void odw_trace_kernel(cons
             ++seq;
           }
         } else if (entering) {
-          if (medium >= 0) { ODW_COUNT(ODW_CNT_DIED); break; }
+          if (medium >= 0) { ODW_COUNT(ODW_CNT_DIED); alive = false; }
           medium = g;
           dir = line_grating(dir, 1.0, group_f64[4 * g], n, P.wavelength, order, lpm, gd, true);
         } else {
@@ -828,10 +886,14 @@ __global__ __launch_bounds__(256, ODW_WAVES_PER_SIMD) void odw_trace_kernel(cons
           if (!tir) { medium = -1; ++seq; }
         }
       }
-      if (power < lim.power_tol) { ODW_COUNT(ODW_CNT_DIED); break; }
+      if (alive && power < lim.power_tol) { ODW_COUNT(ODW_CNT_DIED); alive = false; }
+      }
+      }
+      if (!alive) {
+        cnt_lds[ODW_CNT_SEGMENTS * 256 + threadIdx.x] += (uint32_t)nint;
+        ODW_COUNT(ODW_CNT_TRACED_RAYS);
+      }
     }
-    cnt_lds[ODW_CNT_SEGMENTS * 256 + threadIdx.x] += (uint32_t)nint;
-    ODW_COUNT(ODW_CNT_TRACED_RAYS);
   }
   // counters: wave reduction, one atomic per wave and counter
 #pragma unroll

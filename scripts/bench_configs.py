@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Throughput of every BASELINE config scene on ONE GPU (diagnostic companion
+of bench.py, which measures the headline config only).
+
+  python scripts/bench_configs.py [--quick]
+Prints one JSON line per config: rays/s, segments per ray, hits per ray.
+C5 is the radius sweep of examples/1-getting-started/optimize-spotsize.ipynb
+(cell 9): 64 sphere radii, 1e7 rays each, FWHM-style spot size per radius.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+
+from freecad.optics_design_workbench_amd import scenes
+from freecad.optics_design_workbench_amd.scene import open_fcstd
+from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
+
+SC = os.path.join(ROOT, 'tests', 'golden', 'scenes')
+SEED = 0x0D15EA5E
+
+
+def run(tr, proj, n, batch, det=None, hits=True):
+  tr.setScene(proj.scene)
+  tr.setSource(proj.source)
+  tr.setLimits(proj.limits)
+  tr.setDetector(det)
+  if hits:
+    tr.reserveHits(batch * 2)
+  tr.reset()
+  tr.trace(1 << 40, min(batch, n), SEED, record_hits=hits)   # warm-up
+  tr.sync()
+  tr.reset()
+  t0 = time.perf_counter()
+  done = 0
+  while done < n:
+    m = min(batch, n - done)
+    if hits:
+      tr.resetHits()
+    tr.trace(done, m, SEED, record_hits=hits)
+    done += m
+  tr.sync()
+  dt = time.perf_counter() - t0
+  c = tr.counters()
+  return dict(rays=n, seconds=dt, rays_per_s=n / dt, segments_per_ray=c['segments'] / n,
+              hits_per_ray=c['recorded_hits'] / n, capped=c['capped'])
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--quick', action='store_true')
+  args = ap.parse_args()
+  q = 0.1 if args.quick else 1.0
+  tr = Tracer(0)
+  out = []
+  for name, scene, n, batch in (('C2 minimal true-mode', 'minimal', int(1e7 * q), int(1e7 * q)),
+                                ('C3 lensesAndMirrors', 'lensesAndMirrors', int(1e8 * q), int(1e8 * q)),
+                                ('C3s lensesAndMirrorsSequential', 'lensesAndMirrorsSequential', int(1e8 * q), int(1e8 * q)),
+                                ('C4 hugeArray (1 GPU share of 1e9/8)', 'hugeArray', int(1.25e8 * q), int(2.5e7 * q))):
+    proj = scenes.bakeProject(os.path.join(SC, scene + '.FCStd'))
+    det = scenes.planeDetector(proj.scene, 'OpticalAbsorberGroup', nx=1024, ny=1024,
+                               toward=proj.source.xform[[3, 7, 11]]) if scene != 'hugeArray' else None
+    r = run(tr, proj, n, batch, det)
+    r['config'] = name
+    print(json.dumps(r), flush=True)
+    out.append(r)
+  # C5: radius sweep, one re-bake per radius (host) + 1e7 rays each
+  doc = open_fcstd(os.path.join(SC, 'GettingStarted.FCStd'))
+  radii = np.linspace(9, 11, 64 if not args.quick else 8)
+  n5 = int(1e7 * q)
+  t0 = time.perf_counter()
+  spots = []
+  for rad in radii:
+    doc.Sphere.Radius = float(rad)
+    proj = scenes.bakeProject(doc)
+    det = scenes.planeDetector(proj.scene, 'OpticalAbsorberGroup', nx=1024, ny=1024, window=2.0,
+                               toward=proj.source.xform[[3, 7, 11]])
+    # window centred on the chief ray's landing point (one explicit ray)
+    tr.setScene(proj.scene)
+    tr.setSource(proj.source)
+    tr.setLimits(proj.limits)
+    tr.setDetector(None)
+    tr.reserveHits(16)
+    tr.reset()
+    m = proj.source.xform.reshape(3, 4)
+    tr.traceRays([m[:, 3]], [m[:, 2]])
+    tr.sync()
+    chief = tr.hits()
+    if len(chief):
+      det['origin'] = chief['point'][-1].tolist()
+    tr.setDetector(det)
+    tr.reset()
+    tr.trace(0, n5, SEED, record_hits=False)
+    tr.sync()
+    h = tr.histogram().astype(float)
+    xs = (np.arange(1024) + 0.5) / 1024 * 4.0 - 2.0
+    w = h.sum()
+    mx, my = (h.sum(1) * xs).sum() / w, (h.sum(0) * xs).sum() / w
+    spots.append(float(np.sqrt((h.sum(1) * (xs - mx)**2).sum() / w + (h.sum(0) * (xs - my)**2).sum() / w)))
+  dt = time.perf_counter() - t0
+  r = dict(config='C5 GettingStarted radius sweep', radii=len(radii), rays=n5 * len(radii), seconds=dt,
+           rays_per_s=n5 * len(radii) / dt, best_radius=float(radii[int(np.argmin(spots))]),
+           rms_spot_min=min(spots), note='per radius: host re-bake, chief-ray probe, 1e7 rays into the device histogram, 8 MiB histogram fetch')
+  print(json.dumps(r), flush=True)
+  tr.close()
+
+
+if __name__ == '__main__':
+  main()
