@@ -62,7 +62,7 @@ def main():
 
   import torch
   dist = None
-  if world > 1:
+  if world > 1 or 'RANK' in os.environ:   # launched by torch.distributed.run (also with one rank)
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
     dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))

@@ -144,3 +144,109 @@ def makeRay(baked, thetaOrRadius, phi):
   p2 = m[:, :3] @ (lorg + ldir / np.linalg.norm(ldir)) + m[:, 3]
   d = p2 - p1
   return p1, d / np.linalg.norm(d)
+
+
+def _fanMode(l1, l2):
+  if (l1 > 0 and l2 > 0) or (l1 < 0 and l2 < 0):
+    return 'gapped'
+  if l1 == 0 or l2 == 0:
+    return 'stitched'
+  if l1 < 0 and l2 > 0:
+    return 'theta-sign-change'
+  raise ValueError(f'{l1=}, {l2=}')
+
+
+def generateFanAngles(obj, maxFanCount=np.inf, maxRaysPerFan=np.inf):
+  """fan-mode ray placement of PointSourceProxy._generateRays
+  (point_source.py:474-656): -> list of (thetaOrRadius, phi, metadata) in the
+  reference's emission order.  One fan covers both the phi and phi+pi side of
+  the optical axis; depending on the theta (radius) domain the two sides are
+  placed independently ('gapped'), from one symmetric density ('stitched') or
+  through the sign of theta ('theta-sign-change')."""
+  p = obj._props
+  finite = np.isfinite(float(p.get('FocalLength', 1)))
+  var = 'theta' if finite else 'r'
+  l1, l2 = parsedDomain(p.get('ThetaDomain', '0, pi/4')) if finite else parsedDomain(p.get('RadiusDomain', '0, 10'))
+  phiL1, phiL2 = parsedDomain(p.get('PhiDomain', '0, 2*pi'))
+  raysPerFan = min(int(p.get('RaysPerFan', 20)), maxRaysPerFan)
+  totalFanCount = int(min(int(p.get('Fans', 2)), maxFanCount))
+  fanMode = _fanMode(l1, l2)
+  if fanMode == 'gapped':
+    raysPerFan = max(4, int(np.ceil(raysPerFan / 2) * 2))
+  density = p.get('PowerDensity', 'exp(-theta^2/0.01)')
+  span = float(p.get('FanModePowerSpan', 0.9))
+  phi0 = float(sy.sympify(p.get('FanPhi0', '0')).evalf())
+  out = []
+
+  def in_domain(cands):
+    return [c for c in cands if phiL1 - 1e-9 <= c <= phiL2 + 1e-9]
+
+  def srv(dens, domain):
+    return distributions.ScalarRandomVariable(**rvArgs(obj, dens, variableDomain=domain, scalarRandomVar=True))
+
+  for fanIndex, _phi in enumerate(phi0 + np.linspace(0, np.pi, totalFanCount + 1)[:-1]):
+    cands = in_domain(np.arange(_phi - 30 * np.pi, _phi + 31 * np.pi, np.pi))
+    if not cands:
+      continue
+    phiA = cands[int(np.argmin(np.abs(_phi - np.array(cands))))]
+    cands = in_domain(np.arange(phiA + np.pi - 30 * np.pi, phiA + np.pi + 31 * np.pi, 2 * np.pi))
+    phiB = cands[int(np.argmin(np.abs(phiA + np.pi - np.array(cands))))] if cands else np.nan
+    piecewise = f'Piecewise( ( ({phiA}), ({var})>0 ), ( ({phiB}),  True     ) )'
+
+    # restrict the fan to the central FanModePowerSpan of the emitted power;
+    # like in the reference the narrowed limits carry over to the next fans
+    if 0 < span < 1:
+      power = sy.lambdify(var, sy.sympify(density).subs('theta', 'abs(theta)').subs('phi', piecewise))
+      limit = max(abs(l1), abs(l2))
+      grid = np.linspace(-limit, limit, int(1e5))
+      cum = np.cumsum(power(grid) * np.ones_like(grid))
+      cum = cum / cum.max()
+      a = grid[int(np.argmin(np.abs(cum - (1 - span) / 2)))]
+      b = grid[int(np.argmin(np.abs(cum - (1 - (1 - span) / 2))))]
+      maxL = max(abs(a), abs(b))
+      if abs(l1) > maxL:
+        l1 = np.sign(l1) * maxL
+      if abs(l2) > maxL:
+        l2 = np.sign(l2) * maxL
+
+    side2 = []
+    if fanMode == 'gapped':
+      rv = srv(density, (l1, l2))
+      side1 = rv.findGrid(N=raysPerFan // 2, constants=dict(phi=phiA))
+      side2 = rv.findGrid(N=raysPerFan // 2, constants=dict(phi=phiB))
+    elif fanMode == 'stitched':
+      limit = max(abs(l1), abs(l2))
+      expr = sy.sympify(density).subs('theta', 'abs(theta)').subs('r', 'abs(r)')
+      if np.isfinite(phiB):
+        rv = srv(str(expr.subs('phi', piecewise)), (-limit, limit))
+      else:
+        rv = srv(str(expr), (0, limit))
+      side1 = rv.findGrid(N=raysPerFan, constants=dict(phi=phiA))
+    else:
+      side1 = srv(density, (l1, l2)).findGrid(N=raysPerFan, constants=dict(phi=phiA))
+
+    if len(side2) > 0:
+      side1, side2 = sorted(side1, key=abs), sorted(side2, key=abs)
+      idx1 = list(1 + np.arange(len(side1)))
+      idx2 = list(-(1 + np.arange(len(side2))))
+    else:
+      side1 = np.array(sorted(side1))
+      idx1 = list(np.arange(len(side1)) - int(np.argmin(np.abs(side1))))
+      idx2 = []
+    packed = list(zip(idx1, side1, [phiA] * len(side1))) + list(zip(idx2, side2, [phiB] * len(side2)))
+    for rayIndex, value, phi in sorted(packed, key=lambda e: abs(e[0]) - .1):
+      out.append((float(value), float(phi),
+                  dict(fanIndex=int(fanIndex), rayIndex=int(rayIndex), totalFanCount=int(totalFanCount),
+                       totalRaysInFan=len(packed))))
+  return out
+
+
+def generateFanRays(obj, baked, **kwargs):
+  """-> list of (origin, direction, metadata): explicit initial conditions for
+  Tracer.traceRays (the reference's useInitialConditions path)"""
+  rays = []
+  for value, phi, meta in generateFanAngles(obj, **kwargs):
+    o, d = makeRay(baked, value, phi)
+    meta = dict(meta, initPhi=phi, initTheta=value if np.isfinite(baked.focal_length) else np.nan)
+    rays.append((o, d, meta))
+  return rays

@@ -1,0 +1,141 @@
+"""runSimulation: the continuous Monte-Carlo run on the GPU tracer.
+
+Counterpart of `simulation.runSimulation(action)` main loop A
+(simulation/processes/simulation_loop.py:291-632): for every light source an
+iteration generates RaysPerIteration*RaysPerIterationScale rays and traces
+them (generic_source.py:51-146); the loop ends when totalIterations >
+EndAfterIterations, totalTracedRays > EndAfterRays or totalRecordedHits >
+EndAfterHits (results_store.py:486-512).  Here many iterations are fused into
+one device launch; the end criteria are evaluated between launches, so the
+overshoot is at most one launch (the reference overshoots too: its criteria
+are evaluated asynchronously from worker progress files).
+
+Worker processes, flag files and the FreeCAD child process of the reference
+are replaced by the device; `devices` > 1 shards the ray index range over
+several GPUs of this process' node through `parallel`.
+"""
+import numpy as np
+
+from ..freecad_elements import point_source
+from ..scene import bake as _bake
+from . import results_store
+from .tracer import Tracer
+
+DEFAULT_SEED = 0x0D15EA5E
+_MODES = ('true', 'singletrue', 'fans', 'singlefans')
+
+
+def _limit(settings, key, default):
+  v = settings._props.get(key, default) if settings is not None else default
+  try:
+    return float(v)
+  except (TypeError, ValueError):
+    return np.inf
+
+
+def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPath=None, store=None,
+                  raysPerLaunch=1 << 22, endIf=None, tracer=None, **traceKwargs):
+  """trace `doc` until its simulation settings' end criteria are met.
+
+  action       'true' (continuous Monte-Carlo) | 'singletrue' (one iteration)
+               | 'fans' / 'singlefans' (ray fans, explicit initial conditions)
+  resultsPath  `<doc>.OpticsDesign` folder to write the run folder into
+               (None: keep results in memory only)
+  endIf        optional callback(store) -> bool, checked between launches
+               (FreecadDocument.runSimulation's endIf)
+  traceKwargs  maxRayLength, maxIntersections, powerTol, distTol (ray.py:36-38)
+  -> SimulationResults
+  """
+  if action not in _MODES:
+    raise ValueError(f'unexpected simulation mode {action!r}')
+  settings = _bake.activeSimulationSettings(doc)
+  continuous = action == 'true'
+  if store is None:
+    store = results_store.SimulationResults(
+        action, resultsPath=resultsPath,
+        endAfterIterations=_limit(settings, 'EndAfterIterations', np.inf) if continuous else 0,
+        endAfterRays=_limit(settings, 'EndAfterRays', np.inf) if continuous else np.inf,
+        endAfterHits=_limit(settings, 'EndAfterHits', np.inf) if continuous else np.inf)
+  if continuous and not (np.isfinite(store.endAfterIterations) or np.isfinite(store.endAfterRays)
+                         or np.isfinite(store.endAfterHits)) and endIf is None:
+    raise ValueError('continuous simulation without any end criterion (EndAfterIterations / '
+                     'EndAfterRays / EndAfterHits are all inf and no endIf callback)')
+  sources = _bake.lightSources(doc)
+  if not sources:
+    raise ValueError('document has no light source')
+  rpi = float(settings._props.get('RaysPerIteration', 100)) if settings is not None else 100.0
+  own = tracer is None
+  tr = tracer or Tracer(device)
+  try:
+    baked = []
+    for src in sources:
+      scene = _bake.bakeScene(doc, src)
+      baked.append((src, scene, point_source.bakeSource(doc, src), _bake.bakeLimits(doc, src, **traceKwargs)))
+    first = {src.Name: 0 for src in sources}
+    while True:
+      for src, scene, bsrc, lim in baked:
+        per_iter = max(1, int(round(rpi * bsrc.rays_per_iteration_scale)))
+        tr.setScene(scene)
+        tr.setLimits(lim)
+        tr.setDetector(None)
+        if action in ('fans', 'singlefans'):
+          rays = point_source.generateFanRays(src, bsrc)
+          o = np.array([r[0] for r in rays])
+          d = np.array([r[1] for r in rays])
+          tr.reserveHits(max(16, len(rays) * (lim.max_intersections + 1)))
+          tr.reset()
+          tr.traceRays(o, d)
+          tr.sync()
+          n, iters = len(rays), 1
+          meta = [r[2] for r in rays]
+        else:
+          tr.setSource(bsrc)
+          iters = 1 if not continuous else _iterations_for_launch(store, per_iter, raysPerLaunch)
+          n = iters * per_iter
+          tr.reserveHits(max(16, min(n * (lim.max_intersections + 1), 4 * n + 1024)))
+          tr.reset()
+          tr.trace(first[src.Name], n, seed)
+          tr.sync()
+          meta = None
+        first[src.Name] += n
+        cnt = tr.counters()
+        if cnt['hits_dropped']:
+          raise RuntimeError(f'{cnt["hits_dropped"]} hit rows did not fit the device buffer')
+        _store_hits(store, tr.hits(), scene, src, meta)
+        store.incrementRayCount(n)
+        store.incrementIterationCount(iters)
+      store.flush()
+      if not continuous or store.reachedEnd() or (endIf is not None and endIf(store)):
+        break
+  finally:
+    if own:
+      tr.close()
+  return store
+
+
+def _iterations_for_launch(store, per_iter, raysPerLaunch):
+  """iterations to fuse into the next launch: up to the nearest end criterion
+  (+1 iteration, the criteria are strict '>'), at most raysPerLaunch rays"""
+  cap = max(1, int(raysPerLaunch // per_iter))
+  need = cap
+  if np.isfinite(store.endAfterRays):
+    need = min(need, int((store.endAfterRays - store.totalTracedRays) // per_iter) + 1)
+  if np.isfinite(store.endAfterIterations):
+    need = min(need, int(store.endAfterIterations - store.totalIterations) + 1)
+  return max(1, need)
+
+
+def _store_hits(store, rows, scene, src, meta):
+  tags = rows['tag']
+  grp = ((tags >> np.uint64(48)) & np.uint64(0x7FFF)).astype(np.int64)
+  ray = (tags & np.uint64(0xFFFFFFFFFFFF)).astype(np.int64)
+  for g in np.unique(grp):
+    sel = grp == g
+    extra = {}
+    if meta is not None:
+      # fan metadata of the ray each hit belongs to (ray.py:57-65 StoreHit* keys)
+      for key in ('fanIndex', 'rayIndex', 'totalFanCount', 'totalRaysInFan'):
+        extra[key] = np.array([meta[i][key] for i in ray[sel]])
+    store.addRayHits(src.Name, src._props.get('Label', src.Name), scene.group_names[g],
+                     scene.group_labels[g], rows['point'][sel], rows['direction'][sel],
+                     rows['power'][sel], (tags[sel] >> np.uint64(63)).astype(np.int64), **extra)

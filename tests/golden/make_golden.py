@@ -16,6 +16,7 @@ source or bytecode is written anywhere; only inputs and outputs (numpy
 arrays) are saved as .npz fixtures next to this script.
 """
 import importlib.util
+import json
 import os
 import sys
 import types
@@ -215,8 +216,83 @@ def make_hist(hits_mod):
   print('hist cases written;', {k: out[k] for k in out if k.endswith('cart30_normal')})
 
 
+FAN_CASES = {
+  # benchmark/minimal.FCStd's source (BASELINE configs[0]: ray-fan mode)
+  'c1_minimal': dict(PowerDensity='exp(-theta**2/(1e-2)**2)', FocalLength='0', ThetaDomain='0, pi/4',
+                     PhiDomain='0, 2*pi', RadiusDomain='0, 10', Fans=2, RaysPerFan=20, FanPhi0='0',
+                     FanModePowerSpan=0.9),
+  'gapped': dict(PowerDensity='exp(-theta**2/0.2**2)*(2+cos(phi))', FocalLength='5', ThetaDomain='0.05, 0.3',
+                 PhiDomain='0, 2*pi', RadiusDomain='0, 10', Fans=3, RaysPerFan=9, FanPhi0='0.3',
+                 FanModePowerSpan=0.8),
+  'signchange': dict(PowerDensity='exp(-theta**2/0.1**2)', FocalLength='-20', ThetaDomain='-0.2, 0.3',
+                     PhiDomain='-pi, pi', RadiusDomain='0, 10', Fans=2, RaysPerFan=11, FanPhi0='pi/8',
+                     FanModePowerSpan=1.0),
+  'parallel': dict(PowerDensity='10-abs(r)', FocalLength='inf', ThetaDomain='0, pi/4',
+                   PhiDomain='0, 2*pi', RadiusDomain='0, 8', Fans=4, RaysPerFan=7, FanPhi0='0',
+                   FanModePowerSpan=0.9),
+  'halfphi': dict(PowerDensity='exp(-theta**2/0.05**2)', FocalLength='0', ThetaDomain='0, 0.4',
+                  PhiDomain='0, pi/2', RadiusDomain='0, 10', Fans=2, RaysPerFan=8, FanPhi0='0.1',
+                  FanModePowerSpan=0.9),
+}
+
+
+def make_fan_rays(io, rng, pbd):
+  """PointSourceProxy._generateRays(mode='fans') of the reference with a
+  property-bag object instead of a FreeCAD document object; `_makeRay` (which
+  needs FreeCAD vectors) is replaced by a recorder, so the golden vectors are
+  the (theta|r, phi, fan metadata) sequences the reference would place."""
+  base = 'freecad.optics_design_workbench'
+  dist = sys.modules[base + '.distributions']
+  for k in ('VectorRandomVariable', 'ScalarRandomVariable', 'SampledVectorRandomVariable'):
+    setattr(dist, k, getattr(rng, k))
+  sim = _stub(base + '.simulation')
+  sys.modules[base].simulation = sim
+  fe = _stub(base + '.freecad_elements')
+  sys.modules[base].freecad_elements = fe
+
+  def load(full, relpath):
+    spec = importlib.util.spec_from_file_location(full, os.path.join(REF, relpath))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[full] = mod
+    spec.loader.exec_module(mod)
+    parent, _, leaf = full.rpartition('.')
+    setattr(sys.modules[parent], leaf, mod)
+    return mod
+
+  load(base + '.simulation.raytracing_cache', 'simulation/raytracing_cache.py')
+  for name in ('find', 'ray'):
+    m = types.ModuleType(base + '.freecad_elements.' + name)
+    sys.modules[m.__name__] = m
+    setattr(fe, name, m)
+  load(base + '.freecad_elements.common', 'freecad_elements/common.py')
+  load(base + '.freecad_elements.generic_source', 'freecad_elements/generic_source.py')
+  ps = load(base + '.freecad_elements.point_source', 'freecad_elements/point_source.py')
+  ps.keepGuiResponsiveAndRaiseIfSimulationDone = lambda **kw: None
+
+  class Bag:
+    def addProperty(self, *a):
+      pass
+
+  out = {}
+  for name, props in FAN_CASES.items():
+    obj = Bag()
+    for k, v in props.items():
+      setattr(obj, k, v)
+    proxy = ps.PointSourceProxy.__new__(ps.PointSourceProxy)
+    rec = []
+    proxy._makeRay = lambda obj, thetaOrRadius, phi, power=1, metadata={}, rec=rec: rec.append(
+        (float(thetaOrRadius), float(phi), metadata['fanIndex'], metadata['rayIndex'],
+         metadata['totalFanCount'], metadata['totalRaysInFan']))
+    list(proxy._generateRays(obj, mode='fans'))
+    out[name] = np.array(rec, dtype=np.float64)
+    out[name + '_props'] = np.array(json.dumps(props))
+    print('fan rays', name, len(rec), rec[:2])
+  np.savez_compressed(os.path.join(OUT, 'fan_rays.npz'), **out)
+
+
 if __name__ == '__main__':
   io, pbd, rng, hist, hits = load_reference_modules()
   make_sampler(rng)
   make_fan_grid(rng)
   make_hist(hits)
+  make_fan_rays(io, rng, pbd)
