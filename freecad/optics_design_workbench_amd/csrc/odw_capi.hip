@@ -46,7 +46,7 @@ struct odw_ctx {
   bool have_scene = false, have_source = false, have_limits = false;
   bool bvh_dirty = true;
 
-  DevBuf prim_f64, prim_box, prim_i32, cond_i32, group_f64, group_i32, group_gdir, seq_mask;
+  DevBuf prim_f64, prim_hdr, prim_i32, cond_i32, group_f64, group_i32, group_gdir, seq_mask;
   DevBuf bvh_box, bvh_link, bvh_prims;
   DevBuf phi_tab, t_tab, t_guide, d_source, d_det;
   DeviceSource h_source;
@@ -222,16 +222,18 @@ int build_bvh(odw_ctx* ctx) {
   // boxes contain every point the tolerance rules may accept
   const double slack = 2.0 * (ctx->have_limits ? ctx->P.lim.dist_tol : 1e-2);
   std::vector<Box> boxes(n);
-  std::vector<double> flat((size_t)std::max(1, n) * 6, 0.0);
+  std::vector<double> flat((size_t)std::max(1, n) * 8, 0.0);   // 64-byte headers
   for (int p = 0; p < n; ++p) {
     boxes[p] = world_box(ctx->h_prim_f64.data() + 16 * (size_t)p, ctx->h_prim_i32[4 * p], slack);
-    for (int a = 0; a < 3; ++a) { flat[6 * (size_t)p + a] = boxes[p].lo[a]; flat[6 * (size_t)p + 3 + a] = boxes[p].hi[a]; }
+    double* h = flat.data() + 8 * (size_t)p;
+    for (int a = 0; a < 3; ++a) { h[a] = boxes[p].lo[a]; h[3 + a] = boxes[p].hi[a]; }
+    std::memcpy(h + 6, &ctx->h_prim_i32[4 * (size_t)p], 4 * sizeof(int32_t));
   }
   {
-    int rc = upload(ctx, ctx->prim_box, flat.data(), flat.size() * sizeof(double));
+    int rc = upload(ctx, ctx->prim_hdr, flat.data(), flat.size() * sizeof(double));
     if (rc) return rc;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->P.scene.prim_box = (const double*)ctx->prim_box.p;
+    ctx->P.scene.prim_hdr = (const double*)ctx->prim_hdr.p;
   }
   if (n <= kBvhThreshold) return ODW_OK;
   BvhBuilder b(boxes);
@@ -357,7 +359,7 @@ void odw_destroy(odw_ctx* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   for (auto& ev : ctx->free_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
-  DevBuf* all[] = {&ctx->prim_f64, &ctx->prim_box, &ctx->prim_i32, &ctx->cond_i32, &ctx->group_f64, &ctx->group_i32,
+  DevBuf* all[] = {&ctx->prim_f64, &ctx->prim_hdr, &ctx->prim_i32, &ctx->cond_i32, &ctx->group_f64, &ctx->group_i32,
                    &ctx->group_gdir, &ctx->seq_mask, &ctx->bvh_box, &ctx->bvh_link, &ctx->bvh_prims,
                    &ctx->phi_tab, &ctx->t_tab, &ctx->t_guide, &ctx->d_source, &ctx->d_det, &ctx->hits, &ctx->hit_count, &ctx->chunk_counter, &ctx->hist,
                    &ctx->counters, &ctx->ray_o, &ctx->ray_d, &ctx->ray_p, &ctx->samp_t, &ctx->samp_phi};

@@ -2,7 +2,7 @@
 //
 // Layout in HBM (all read-only during a launch, L2/scalar-cache resident):
 //   prim_f64 : n_prims x 16 f64   rows 0..11 global->local (R|t), 12..15 params
-//   prim_box : n_prims x 6  f64   global bounding box (culling)
+//   prim_hdr : n_prims x 64 B     global bounding box (6 f64) + type, group, flags, conds (4 i32)
 //   prim_i32 : n_prims x 4  i32   type, group, flags|facemask<<8, cond_off|cnt<<24
 //   cond_i32 : n_conds      i32   prim | inside<<31
 //   group_f64: 64 x 4 f64         ior, reflectivity, absorption length, grating lpm
@@ -34,7 +34,8 @@ __device__ __forceinline__ double comp(d3 a, int i) { return i == 0 ? a.x : (i =
 
 struct DeviceScene {
   const double* prim_f64;
-  const double* prim_box;       // [n_prims*6] global AABB (lo xyz, hi xyz), tolerance slack included
+  const double* prim_hdr;       // [n_prims*8] 64-B header: global AABB lo xyz, hi xyz (tolerance slack
+                                //   included) | i32 type, group, flags, cond_off|cnt<<24  -- one s_load_dwordx16
   const int32_t* prim_i32;
   const int32_t* cond_i32;
   const double* group_f64;      // [64*4]

@@ -282,7 +282,7 @@ struct Query {
 };
 
 struct SceneView {    // constant-address-space views of the scene tables
-  cf64 prim_f64, prim_box;
+  cf64 prim_f64, prim_hdr;
   ci32 prim_i32, cond_i32;
 };
 
@@ -338,11 +338,10 @@ __device__ __forceinline__ void cand_min2(Cands& c, double t, int f) {
 // natural face bounds with tolerance (ray.py:411-426).  The candidates are
 // collected first and judged by ONE copy of consider() (code size: the hot
 // loop must stay inside the instruction cache).
-__device__ __forceinline__ void intersect_prim(const SceneView& sv, Query& q, int p) {
+__device__ __forceinline__ void intersect_prim(const SceneView& sv, Query& q, int p, int type, int group,
+                                               int flags, int cond_word) {
   cf64 pf = sv.prim_f64 + (size_t)p * 16;
-  ci32 pi = sv.prim_i32 + 4 * p;
-  const int type = pi[0], group = pi[1], flags = pi[2];
-  const int cond_off = pi[3] & 0xffffff, cond_cnt = (pi[3] >> 24) & 0xff;
+  const int cond_off = cond_word & 0xffffff, cond_cnt = (cond_word >> 24) & 0xff;
   const int fmask = flags >> ODW_FACEMASK_SHIFT;
   cf64 par = pf + 12;
   const double tol = q.tol;
@@ -576,14 +575,24 @@ __device__ __forceinline__ int nearest(const DeviceScene& sc, const SceneView& s
   const d3 inv = mk(frcp(dn.x), frcp(dn.y), frcp(dn.z));
   const d3 oi = mk(start.x * inv.x, start.y * inv.y, start.z * inv.z);
   if (!BVH) {
+    // without sequential mode the set of relevant groups is the same for
+    // every ray: the test is scalar and skips a primitive for the whole wave
+    const bool per_lane_mask = sc.seq_enabled != 0;
+    const uint64_t umask = sc.all_mask & ~sc.ignore_mask;
     for (int p = 0; p < sc.n_prims; ++p) {
-      const int g = sv.prim_i32[4 * p + 1];
-      if (!((mask >> g) & 1)) continue;
+      cf64 hdr = sv.prim_hdr + 8 * p;                 // one 64-byte scalar load
+      ci32 hi = (ci32)(hdr + 6);
+      const int type = hi[0], g = hi[1], flags = hi[2], cond_word = hi[3];
+      if (per_lane_mask) {
+        if (!((mask >> g) & 1)) continue;
+      } else {
+        if (!((umask >> g) & 1)) continue;
+      }
       // candidates farther than the nearest hit + 2*distTol can never be
       // selected (ray.py:432,440): shrink the search like the reference does
       const double cut = fmin(q.tmax, q.any.t + 2.0 * q.tol);
-      if (!ray_box(sv.prim_box + 6 * p, oi, inv, cut)) continue;
-      intersect_prim(sv, q, p);
+      if (!ray_box(hdr, oi, inv, cut)) continue;
+      intersect_prim(sv, q, p, type, g, flags, cond_word);
     }
   } else {
     cf64 bvh_box = as_const(sc.bvh_box);
@@ -624,8 +633,9 @@ __device__ __forceinline__ int nearest(const DeviceScene& sc, const SceneView& s
       if (!leaf_count) break;        // stack exhausted
       for (int i = 0; i < leaf_count; ++i) {
         const int p = bvh_prims[leaf_first + i];
-        const int g = sv.prim_i32[4 * p + 1];
-        if ((mask >> g) & 1) intersect_prim(sv, q, p);
+        ci32 pi = sv.prim_i32 + 4 * p;
+        const int g = pi[1];
+        if ((mask >> g) & 1) intersect_prim(sv, q, p, pi[0], g, pi[2], pi[3]);
       }
     }
   }
@@ -723,6 +733,18 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
   return v;
 }
 
+struct RayInit { d3 point, dir; double power; };
+__device__ __noinline__ RayInit generate_ray(const DeviceSource* sp, uint64_t ray, uint64_t seed) {
+  RayInit r;
+  double up, ut, t, phi;
+  csource src = as_const(sp);
+  ray_uniforms(ray, seed, up, ut);
+  sample_source(src, up, ut, t, phi);
+  make_ray(src, t, phi, r.point, r.dir);
+  r.power = src->power;
+  return r;
+}
+
 // ------------------------------------------------------------ the kernel
 #ifndef ODW_CHUNK
 #define ODW_CHUNK 2048ull      // rays per hand-out unit (32 per lane)
@@ -746,7 +768,7 @@ __global__ __launch_bounds__(256, ODW_WAVES_PER_SIMD) void odw_trace_kernel(cons
   const DeviceLimits& lim = P.lim;
   SceneView sv;
   sv.prim_f64 = as_const(sc.prim_f64);
-  sv.prim_box = as_const(sc.prim_box);
+  sv.prim_hdr = as_const(sc.prim_hdr);
   sv.prim_i32 = as_const(sc.prim_i32);
   sv.cond_i32 = as_const(sc.cond_i32);
   cf64 group_f64 = as_const(sc.group_f64);
@@ -795,12 +817,8 @@ __global__ __launch_bounds__(256, ODW_WAVES_PER_SIMD) void odw_trace_kernel(cons
           dir = dir * (1.0 / sqrt(dot(dir, dir)));
           power = P.ray_powers ? P.ray_powers[i] : 1.0;
         } else {
-          double up, ut, t, phi;
-          csource src = as_const(opaque(P.source));
-          ray_uniforms(P.first_ray + i, P.seed, up, ut);
-          sample_source(src, up, ut, t, phi);
-          make_ray(src, t, phi, point, dir);
-          power = src->power;
+          const RayInit r = generate_ray(P.source, P.first_ray + i, P.seed);
+          point = r.point; dir = r.dir; power = r.power;
         }
         // `dir` stays a unit vector: mirror() preserves length, snells_law() and
         // line_grating() return unit vectors for unit input; the reference
