@@ -5,6 +5,7 @@
 // guide tables, launches on a private HIP stream, HIP-event timing, result
 // fetch.  No torch types anywhere: plain pointers and sizes.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -53,6 +54,7 @@ struct odw_ctx {
   DeviceDetector h_det;
   DevBuf hits, hit_count, hist, counters, chunk_counter;
   DevBuf ray_o, ray_d, ray_p, samp_t, samp_phi;
+  DevBuf sort_keys[2], sort_vals[2], sort_tmp, sorted_rows;
   uint64_t hit_capacity = 0, n_bins = 0;
 
   TraceParams P;
@@ -251,6 +253,28 @@ int build_bvh(odw_ctx* ctx) {
   return ODW_OK;
 }
 
+// ---- device-side ordering of the hit list (odw_fetch_hits) -----------------
+__global__ void hit_keys_kernel(const odw_hit* __restrict__ hits, uint64_t n, uint64_t* __restrict__ keys,
+                                uint32_t* __restrict__ vals) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    keys[i] = ODW_HIT_RAY(hits[i].tag);
+    vals[i] = (uint32_t)i;
+  }
+}
+
+// four lanes move one 64-byte row (16 B each): coalesced reads of the index
+// list, 64-B gathers, fully coalesced writes
+__global__ void hit_gather_kernel(const odw_hit* __restrict__ hits, const uint32_t* __restrict__ order,
+                                  uint64_t n, odw_hit* __restrict__ out) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t row = t >> 2;
+  if (row < n) {
+    const double2* src = reinterpret_cast<const double2*>(hits + order[row]);
+    reinterpret_cast<double2*>(out + row)[t & 3] = src[t & 3];
+  }
+}
+
 int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32_t flags,
                  bool explicit_rays) {
   if (!ctx->have_scene || !ctx->have_limits) return fail(ctx, ODW_ERR_NO_SCENE, "scene/limits not uploaded");
@@ -362,7 +386,9 @@ void odw_destroy(odw_ctx* ctx) {
   DevBuf* all[] = {&ctx->prim_f64, &ctx->prim_hdr, &ctx->prim_i32, &ctx->cond_i32, &ctx->group_f64, &ctx->group_i32,
                    &ctx->group_gdir, &ctx->seq_mask, &ctx->bvh_box, &ctx->bvh_link, &ctx->bvh_prims,
                    &ctx->phi_tab, &ctx->t_tab, &ctx->t_guide, &ctx->d_source, &ctx->d_det, &ctx->hits, &ctx->hit_count, &ctx->chunk_counter, &ctx->hist,
-                   &ctx->counters, &ctx->ray_o, &ctx->ray_d, &ctx->ray_p, &ctx->samp_t, &ctx->samp_phi};
+                   &ctx->counters, &ctx->ray_o, &ctx->ray_d, &ctx->ray_p, &ctx->samp_t, &ctx->samp_phi,
+                   &ctx->sort_keys[0], &ctx->sort_keys[1], &ctx->sort_vals[0], &ctx->sort_vals[1],
+                   &ctx->sort_tmp, &ctx->sorted_rows};
   for (DevBuf* b : all) release(*b);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -636,13 +662,37 @@ int odw_fetch_hits(odw_ctx* ctx, odw_hit* out, uint64_t capacity, uint64_t* n) {
   if (!out || capacity == 0) return ODW_OK;
   if (have > capacity) return fail(ctx, ODW_ERR_CAPACITY, "odw_fetch_hits: output buffer too small");
   if (have) {
-    HIPCHK(ctx, hipMemcpyAsync(out, ctx->hits.p, have * sizeof(odw_hit), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     // append order is scheduling dependent; a ray's own rows are appended in
-    // bounce order, so a stable sort by ray index gives (ray, bounce) order
-    std::stable_sort(out, out + have, [](const odw_hit& a, const odw_hit& b) {
-      return ODW_HIT_RAY(a.tag) < ODW_HIT_RAY(b.tag);
-    });
+    // bounce order, so a STABLE sort by ray index gives (ray, bounce) order.
+    // Done on the device: LSD radix sort of (ray index -> row number) pairs
+    // (hipCUB, stable), then a gather of the 64-byte rows, then one D2H copy.
+    if (have > 0x7FFFFFFFull) return fail(ctx, ODW_ERR_CAPACITY, "odw_fetch_hits: more than 2^31 rows per fetch");
+    int rc;
+    for (int k = 0; k < 2; ++k) {
+      if ((rc = ensure(ctx, ctx->sort_keys[k], have * sizeof(uint64_t)))) return rc;
+      if ((rc = ensure(ctx, ctx->sort_vals[k], have * sizeof(uint32_t)))) return rc;
+    }
+    if ((rc = ensure(ctx, ctx->sorted_rows, have * sizeof(odw_hit)))) return rc;
+    uint64_t* k_in = (uint64_t*)ctx->sort_keys[0].p;
+    uint64_t* k_out = (uint64_t*)ctx->sort_keys[1].p;
+    uint32_t* v_in = (uint32_t*)ctx->sort_vals[0].p;
+    uint32_t* v_out = (uint32_t*)ctx->sort_vals[1].p;
+    const unsigned blocks = (unsigned)((have + 255) / 256);
+    hipLaunchKernelGGL(hit_keys_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const odw_hit*)ctx->hits.p,
+                       have, k_in, v_in);
+    HIPCHK(ctx, hipGetLastError());
+    size_t tmp_bytes = 0;
+    HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k_in, k_out, v_in, v_out, (int)have, 0, 48,
+                                                   ctx->stream));
+    if ((rc = ensure(ctx, ctx->sort_tmp, tmp_bytes))) return rc;
+    HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(ctx->sort_tmp.p, tmp_bytes, k_in, k_out, v_in, v_out, (int)have,
+                                                   0, 48, ctx->stream));
+    const unsigned gblocks = (unsigned)((have * 4 + 255) / 256);
+    hipLaunchKernelGGL(hit_gather_kernel, dim3(gblocks), dim3(256), 0, ctx->stream, (const odw_hit*)ctx->hits.p,
+                       v_out, have, (odw_hit*)ctx->sorted_rows.p);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->sorted_rows.p, have * sizeof(odw_hit), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   }
   return ODW_OK;
 }
