@@ -119,7 +119,8 @@ def bakeSource(doc, obj):
   if obj.ProxyClass != 'PointSourceProxy':
     raise NotImplementedError(f'{obj.Name}: {obj.ProxyClass} is outside the accelerated path '
                               f'(SURVEY 8f N4)')
-  gp = _bake.globalPlacements(doc, obj)[0]
+  # _getCoordinateTransformMatricesWithoutLinks (common.py:279-280)
+  gp = _bake.globalPlacements(doc, obj, ignoreLinks=True)[0]
   return BakedSource(xform=gp.rows12(), focal_length=float(obj.FocalLength),
                      wavelength=float(obj._props.get('Wavelength', 500)), power=1.0,
                      tables=getVrv(obj).tables(), name=obj.Name,

@@ -3,4 +3,5 @@ from .placement import Placement
 from .fcstd import Document, DocumentObject, open_fcstd
 from .geometry import UnsupportedGeometry
 from .bake import (BakedScene, Limits, bakeScene, bakeLimits, lightSources, opticalObjects,
-                   simulationSettings, activeSimulationSettings, globalPlacements, tracingSequence)
+                   simulationSettings, activeSimulationSettings, globalPlacements, allPlacementsAndPaths,
+                   tracingSequence)

@@ -52,21 +52,48 @@ def activeSimulationSettings(doc):
   return allset[0] if allset else None
 
 
-def globalPlacements(doc, obj, _depth=0):
-  """every global placement `obj` appears under (containers only; App::Link
-  copies of whole groups are resolved by the group bake).  Follows
-  allPlacementsAndPaths (freecad_elements/common.py:36-109)."""
+def _is_link(o):
+  return o.TypeId.startswith('App::Link') and not o.TypeId.startswith('App::LinkGroup')
+
+
+def allPlacementsAndPaths(doc, obj, ignoreLinks=False, _depth=0):
+  """every representation of `obj` in the global model: [(Placement, path)]
+  with path = tuple of object names from the top level down to obj.
+  Follows allPlacementsAndPaths (freecad_elements/common.py:36-109):
+  containers (App::Part / LinkGroup / DocumentObjectGroup) compose their
+  placement with the child's; an App::Link pointing at obj contributes the
+  link's own placements, replacing obj.Placement unless LinkTransform is set.
+  DocumentObjectGroups have no placement and are transparent: an object listed
+  in a group and in the Part around that group is one instance (paths are
+  compared without groups)."""
   if _depth > 100:
-    raise RuntimeError('globalPlacements reached recursion depth 100')
+    raise RuntimeError('allPlacementsAndPaths reached recursion depth 100')
   own = obj.Placement if obj.hasProperty('Placement') else Placement.identity()
-  parents = doc.parents_of(obj)
-  if not parents:
-    return [own]
   out = []
-  for p in parents:
-    for pp in globalPlacements(doc, p, _depth + 1):
-      out.append(pp * own)
-  return out
+  containers = doc.parents_of(obj)
+  links = [] if ignoreLinks else [o for o in doc.Objects
+                                  if _is_link(o) and o._props.get('LinkedObject') is obj]
+  if not containers:
+    out.append((own, (obj.Name,)))
+  for c in containers:
+    transparent = c.TypeId == 'App::DocumentObjectGroup'
+    for pl, path in allPlacementsAndPaths(doc, c, ignoreLinks, _depth + 1):
+      out.append((pl * own, (path[:-1] if transparent else path) + (obj.Name,)))
+  for l in links:
+    keep_own = own if bool(l._props.get('LinkTransform', False)) else Placement.identity()
+    for pl, path in allPlacementsAndPaths(doc, l, ignoreLinks, _depth + 1):
+      out.append((pl * keep_own, path + (obj.Name,)))
+  seen, uniq = set(), []
+  for pl, path in out:
+    if path not in seen:
+      seen.add(path)
+      uniq.append((pl, path))
+  return sorted(uniq, key=lambda e: '.'.join(e[1])) if _depth == 0 else uniq
+
+
+def globalPlacements(doc, obj, ignoreLinks=False):
+  """global placements of `obj` (one per representation)"""
+  return [pl for pl, _ in allPlacementsAndPaths(doc, obj, ignoreLinks)]
 
 
 def tracingSequence(settings):

@@ -135,6 +135,44 @@ def _parse_property(prop, zf):
   return None
 
 
+# property tables of the workbench proxies (optical_group.py:29-96,
+# point_source.py:32-70 + generic_source.py:23-37, simulation_settings.py:20-77)
+_PROXY_PROPERTIES = {
+  ('freecad.optics_design_workbench.freecad_elements.optical_group', 'OpticalGroupProxy'): (
+      'OpticalType RefractiveIndex ReflectedProbabilityDensity RefractedProbabilityDensity PowerThetaDomain '
+      'PowerPhiDomain RayModificationProbabilityDensity ModifyThetaDomain ModifyPhiDomain Reflectivity '
+      'AbsorptionLength GratingType GratingLinesPerMillimeter GratingLinesOrientation GratingDiffractionOrder '
+      'RecordHits').split(),
+  ('freecad.optics_design_workbench.freecad_elements.point_source', 'PointSourceProxy'): (
+      'PowerDensity Wavelength FocalLength Divergence ThetaDomain PhiDomain RadiusDomain RandomNumberGeneratorMode '
+      'ThetaResolutionNumericMode RadiusResolutionNumericMode PhiResolutionNumericMode Fans FanPhi0 RaysPerFan '
+      'FanModePowerSpan RecordRays IgnoredOpticalElements RaysPerIterationScale MaxIntersectionsScale '
+      'MaxRayLengthScale').split(),
+  ('freecad.optics_design_workbench.freecad_elements.simulation_settings', 'SimulationSettingsProxy'): (
+      'Active EnableStoreSingleShotData EndAfterIterations EndAfterRays EndAfterHits RaysPerIteration '
+      'MaxIntersections DistanceTolerance MaxRayLength ShowRaysInContinuousMode WorkerProcessCount SequentialMode '
+      'SequentialModeElements_00 StoreHitInitPoint StoreHitInitDirection StoreHitInitPower StoreHitInitWavelength '
+      'StoreHitInitPhi StoreHitInitTheta StoreHitRayIndex StoreHitFanIndex StoreHitTotalFanCount '
+      'StoreHitTotalRaysInFan').split(),
+}
+
+
+def repairProxies(doc):
+  """documents saved without proxy information (`Proxy` = null) still carry
+  the workbench properties; like the reference's repairAllProxies
+  (freecad_elements/common.py:181-242) an object named Optical* whose
+  properties match a proxy's table well enough (more than 5 present, fewer
+  than 3 missing) gets that proxy back"""
+  for obj in doc.Objects:
+    if not obj.Name.startswith('Optical') or obj.ProxyClass:
+      continue
+    for (module, cls), names in _PROXY_PROPERTIES.items():
+      present = sum(1 for n in names if n in obj._props)
+      if present > 5 and present > len(names) - 3:
+        obj._props['Proxy'] = {'module': module, 'class': cls, 'state': {}, 'repaired': True}
+        break
+
+
 class Document:
   """The parsed document: `doc.Objects`, `doc.getObject(name)`, `doc.<Name>`."""
 
@@ -175,6 +213,7 @@ class Document:
           obj._props[k] = self._by_name.get(v) if isinstance(v, str) else None
         elif t in ('App::PropertyLinkList', 'App::PropertyLinkListGlobal'):
           obj._props[k] = [self._by_name[n] for n in (v or []) if n in self._by_name]
+    repairProxies(self)
     self._revision = 0
 
   # -- API ----------------------------------------------------------------

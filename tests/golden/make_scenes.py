@@ -25,6 +25,8 @@ SCENES = {
   'source-and-absorber': 'test/70-point-source-slow/source-and-absorber.FCStd',
   'gaussian': 'test/50-old-tests/gaussian.FCStd',
   'lens-overlap': 'test/50-old-tests/lens-overlap.FCStd',
+  'global-placement-main': 'test/22-global-placement/main.FCStd',
+  'nested-structure': 'test/22-global-placement/nested-structure.FCStd',
 }
 
 if __name__ == '__main__':

@@ -1,0 +1,70 @@
+"""Global placement resolution (A1) against the reference's only exact pin:
+test/22-global-placement/z-freecad-placements.py:40-70 lists the eight 4x4
+matrices `allPlacementsAndPaths` must produce for the cube 'ShiftedCube',
+which is reached through nested App::Parts, a DocumentObjectGroup, a LinkGroup
+and App::Links with and without LinkTransform (scene: main.FCStd)."""
+import os
+
+import numpy as np
+
+from conftest import SCENES
+
+# expected translations (all rotations are identity), in the reference's order
+EXPECTED = [(0, 0, -100), (3, 3, -100), (3, 0, -100), (3, -27, -100), (3, -27, -100),
+            (3, 3, -97), (0, 0, -100), (0, -30, -100)]
+
+
+def _doc():
+  from freecad.optics_design_workbench_amd.scene import open_fcstd
+  return open_fcstd(os.path.join(SCENES, 'global-placement-main.FCStd'))
+
+
+def test_shifted_cube_placements():
+  from freecad.optics_design_workbench_amd.scene import allPlacementsAndPaths
+  doc = _doc()
+  cube = doc.getObjectsByLabel('ShiftedCube')[0]
+  got = allPlacementsAndPaths(doc, cube)
+  assert len(got) == 8
+  for pl, _ in got:
+    assert np.allclose(pl.Rotation, np.eye(3))
+  bases = sorted(tuple(np.round(pl.Base, 9) + 0.0) for pl, _ in got)
+  assert bases == sorted(tuple(float(v) for v in e) for e in EXPECTED)
+  # ignoring links leaves only the container path
+  only = allPlacementsAndPaths(doc, cube, ignoreLinks=True)
+  assert len(only) == 1 and np.allclose(only[0][0].Base, [3, 3, -97])
+  # paths are reported top-down and sorted lexically like the reference does
+  paths = ['.'.join(p) for _, p in got]
+  assert paths == sorted(paths) and all(p.endswith('Box003') for p in paths)
+
+
+def test_proxy_repair_and_nested_bake():
+  """main.FCStd was saved with Proxy = null; the reference re-attaches proxies
+  from the property signature (common.py:181-242).  Groups nested in rotated
+  Parts bake to the composed placements."""
+  from freecad.optics_design_workbench_amd import scenes
+  from freecad.optics_design_workbench_amd.scene import bake
+  doc = _doc()
+  assert [s.Name for s in bake.lightSources(doc)] == ['OpticalPointSource']
+  assert [g._props['OpticalType'] for g in bake.opticalObjects(doc)] == ['Mirror', 'Lens', 'Mirror', 'Absorber']
+  assert len(bake.simulationSettings(doc)) == 1
+  pr = scenes.bakeProject(doc)
+  # source: Part004 (z-3) > Part003 (z-12) > Part (x+5) > source (z+4)
+  assert np.allclose(pr.source.xform.reshape(3, 4)[:, 3], [5, 0, -11])
+  sc = pr.scene
+  assert sc.n_prims == 4
+  # lens sphere: Part002 o Part005 (z+9) o group (5,0,10) o sphere
+  p2, p5, lg = doc.Part002.Placement, doc.Part005.Placement, doc.OpticalLensGroup.Placement
+  assert np.allclose(sc.prim_to_world[1].Base, (p2 * p5 * lg).Base)
+  # mirror cube: Part002 o mirror group o Part001 o Box
+  exp = doc.Part002.Placement * doc.OpticalMirrorGroup.Placement * doc.Part001.Placement * doc.Box.Placement
+  assert np.allclose(sc.prim_to_world[0].m, exp.m)
+
+
+def test_nested_body_is_rejected_loudly():
+  """nested-structure.FCStd contains a PartDesign::Body (sketch based, BRep
+  only): it cannot be rebuilt without OpenCASCADE and must not be guessed"""
+  import pytest
+  from freecad.optics_design_workbench_amd import scenes
+  from freecad.optics_design_workbench_amd.scene import UnsupportedGeometry
+  with pytest.raises(UnsupportedGeometry):
+    scenes.bakeProject(os.path.join(SCENES, 'nested-structure.FCStd'))
