@@ -1,0 +1,167 @@
+"""`FreecadDocument`: the notebook-facing document handle.
+
+In the reference this class drives a `FreeCAD -c` child process over pipes
+(jupyter_utils/freecad_document.py:454-1288) and `runSimulation` waits for the
+run folder that process writes (:640-770).  Here the document is parsed
+in-process (FCStd-lite) and the simulation runs on the GPU tracer; the
+surface a notebook touches is kept:
+
+    with FreecadDocument('GettingStarted.FCStd') as f:
+      f.Sphere.Radius = 10.5                      # property write
+      print(f.OpticalPointSource.PowerDensity.get())
+      raw = f.runSimulation('true')               # -> RawFolder
+      hits = raw.loadHits('*')                    # -> Hits
+      hits.histogram(bins=30)
+
+Objects resolve by label first, then by internal name, as in the reference
+(`getObjectsByLabel(...)[0]`, freecad_document.py:197-200).
+"""
+import os
+import shutil
+import tempfile
+
+from ..scene.fcstd import Document
+from ..simulation import results_store, simulation_loop
+
+
+class FreecadProperty:
+  '''
+  One property of a document object; `get()`/`set()` like the reference's
+  FreecadProperty (freecad_document.py:176-413).  Comparisons, float() and
+  str() act on the value.
+  '''
+
+  def __init__(self, obj, name):
+    self.__dict__['_obj'] = obj
+    self.__dict__['_name'] = name
+
+  def get(self):
+    return self._obj._props[self._name]
+
+  def set(self, value):
+    setattr(self._obj, self._name, value)
+
+  def getStr(self):
+    return str(self.get())
+
+  def __repr__(self):
+    return f'<FreecadProperty {self._obj.Name}.{self._name}, value: {self.getStr()}>'
+
+  def __float__(self):
+    return float(self.get())
+
+  def __eq__(self, other):
+    return self.get() == (other.get() if isinstance(other, FreecadProperty) else other)
+
+  def __getattr__(self, key):            # e.g. Placement.Base
+    return getattr(self.get(), key)
+
+
+class FreecadObject:
+  '''
+  A document object; attribute reads give FreecadProperty handles, attribute
+  writes set the property (and mark the scene for re-baking).
+  '''
+
+  def __init__(self, obj):
+    self.__dict__['_obj'] = obj
+
+  def __getattr__(self, key):
+    if key not in self._obj._props:
+      raise AttributeError(f'{self._obj.Name} has no property {key!r}')
+    return FreecadProperty(self._obj, key)
+
+  def __setattr__(self, key, value):
+    setattr(self._obj, key, value.get() if isinstance(value, FreecadProperty) else value)
+
+  def __dir__(self):
+    return self._obj.PropertiesList
+
+  def __repr__(self):
+    return f'<FreecadObject {self._obj.Name} ({self._obj._props.get("Label", "")})>'
+
+
+class FreecadDocument:
+  '''
+  Handle on one FCStd project.  workInTempCopy=True (the reference's option of
+  the same name) leaves the original project folder untouched: results go to a
+  temporary `.OpticsDesign` folder that is removed on close.
+  '''
+
+  def __init__(self, path, workInTempCopy=False, device=0, seed=simulation_loop.DEFAULT_SEED):
+    self._origPath = os.path.abspath(path)
+    self._tmp = None
+    if workInTempCopy:
+      self._tmp = tempfile.mkdtemp(prefix='odw-')
+      work = os.path.join(self._tmp, os.path.basename(path))
+      shutil.copy(self._origPath, work)
+      self._path = work
+    else:
+      self._path = self._origPath
+    self.__dict__['_doc'] = Document(self._path)
+    self._resultsPath = results_store.resultsFolderPath(self._path)
+    self._device = device
+    self._seed = seed
+    self._runs = 0
+
+  # -- context manager / lifecycle -------------------------------------------
+  def __enter__(self):
+    return self
+
+  def __exit__(self, *a):
+    self.close()
+
+  def close(self):
+    if self._tmp and os.path.isdir(self._tmp):
+      shutil.rmtree(self._tmp, ignore_errors=True)
+    self._tmp = None
+
+  # -- objects -----------------------------------------------------------------
+  def getObject(self, nameOrLabel):
+    doc = self.__dict__['_doc']
+    by_label = doc.getObjectsByLabel(nameOrLabel)
+    obj = by_label[0] if by_label else doc.getObject(nameOrLabel)
+    if obj is None:
+      raise AttributeError(f'document has no object labelled or named {nameOrLabel!r}')
+    return FreecadObject(obj)
+
+  def __getattr__(self, key):
+    if key.startswith('_'):
+      raise AttributeError(key)
+    return self.getObject(key)
+
+  def objects(self):
+    return [FreecadObject(o) for o in self.__dict__['_doc'].Objects]
+
+  def document(self):
+    return self.__dict__['_doc']
+
+  # -- simulation ----------------------------------------------------------------
+  def runSimulation(self, action='true', endIf=None, **kwargs):
+    """run and return the RawFolder of the new run
+    (freecad_document.py:640-770); endIf(rawFolder) -> bool ends a continuous
+    run early"""
+    allowed = 'true singletrue fans singlefans'.split()
+    if action not in allowed:
+      raise ValueError(f'illegal action {action}, expected one of {", ".join(allowed)} '
+                       f'(pseudo-random modes are not on the accelerated path)')
+    store_box = {}
+
+    def _end_if(store):
+      store.flush()
+      return bool(endIf(results_store.RawFolder(store.runFolderPath())))
+
+    # every run draws from a fresh part of the Philox stream
+    seed = self._seed + self._runs
+    self._runs += 1
+    store = simulation_loop.runSimulation(self.__dict__['_doc'], action, seed=seed, device=self._device,
+                                          resultsPath=self._resultsPath,
+                                          endIf=_end_if if endIf is not None else None, **kwargs)
+    store_box['store'] = store
+    return results_store.RawFolder(store.runFolderPath())
+
+  def rawFolders(self):
+    return results_store.rawFolders(self._resultsPath)
+
+  def latestRawFolder(self):
+    return results_store.latestRawFolder(self._resultsPath)

@@ -97,3 +97,45 @@ def test_run_simulation_end_criteria_on_device(native_lib, tmp_path):
   store = runSimulation(doc, 'fans')
   h = store.hits().hits
   assert store.totalTracedRays == 40 and {'fanIndex', 'rayIndex', 'totalRaysInFan'} <= set(h)
+
+
+def test_freecad_document_property_api(tmp_path):
+  """property round trips of test/20-freecad-document/2-from-fcstd-folder.py, without FreeCAD"""
+  import shutil
+  from conftest import SCENES
+  from freecad.optics_design_workbench_amd.jupyter_utils import FreecadDocument
+  src = os.path.join(SCENES, 'GettingStarted.FCStd')
+  with FreecadDocument(src, workInTempCopy=True) as f:
+    assert f.Sphere.Radius.get() == pytest.approx(9.8275862)
+    f.Sphere.Radius = 10.5
+    assert float(f.Sphere.Radius) == 10.5
+    f.OpticalSimulationSettings.EndAfterRays = '1e3'
+    assert f.OpticalSimulationSettings.EndAfterRays.get() == '1e3'
+    label = f.document().OpticalPointSource._props['Label']
+    assert getattr(f, label).PowerDensity.get() == 'exp(-theta^2/0.01)'           # resolved by label
+    assert f.OpticalPointSource.PowerDensity == getattr(f, label).PowerDensity     # and by internal name
+    with pytest.raises(AttributeError):
+      f.NoSuchObject
+    tmp = f._tmp
+  assert not os.path.exists(tmp)
+
+
+@pytest.mark.gpu
+def test_freecad_document_run_simulation(native_lib):
+  """examples/1-getting-started/optimize-spotsize.ipynb cell 9 pattern"""
+  from conftest import SCENES
+  from freecad.optics_design_workbench_amd.jupyter_utils import FreecadDocument
+  with FreecadDocument(os.path.join(SCENES, 'GettingStarted.FCStd'), workInTempCopy=True) as f:
+    f.OpticalSimulationSettings.EndAfterRays = '2e4'
+    sizes = []
+    for r in (9.5, 10.25, 11.0):
+      f.Sphere.Radius = r
+      raw = f.runSimulation('true')
+      h = raw.loadHits('*')
+      assert len(h) > 1.9e4
+      p = h.points()
+      sizes.append(float(np.sqrt(((p - np.median(p, axis=0))**2).sum(1).mean())))
+    assert len(f.rawFolders()) == 3
+    assert sizes[1] < sizes[0] and sizes[1] < sizes[2]     # best focus near R = 10.27
+    hist = f.latestRawFolder().loadHits('*').histogram(bins=30)
+    assert hist.hist.sum() == len(h)
