@@ -24,7 +24,7 @@ namespace {
 
 constexpr int kGuide = 1 << 16;
 constexpr int kBvhThreshold = 16;  // brute force (scalar loads) below this many primitives
-constexpr int kBvhLeaf = 2;
+constexpr int kBvhLeaf = 4;
 
 std::string g_error;
 
@@ -48,7 +48,7 @@ struct odw_ctx {
   bool bvh_dirty = true;
 
   DevBuf prim_f64, prim_hdr, prim_i32, cond_i32, group_f64, group_i32, group_gdir, seq_mask;
-  DevBuf bvh_box, bvh_link, bvh_prims;
+  DevBuf bvh_nodes, bvh_prims;
   DevBuf phi_tab, t_tab, t_guide, d_source, d_det;
   DeviceSource h_source;
   DeviceDetector h_det;
@@ -160,60 +160,101 @@ Box world_box(const double* pf, int type, double slack) {
   return b;
 }
 
+// BVH node, 64 bytes = one cache line: the boxes of BOTH children in float32
+// (rounded outward), so one fetch decides where to go next.  child >= 0: inner
+// node index; count > 0: leaf = `count` primitives from bvh_prims[child].
+struct BvhNode {
+  float lo0[3], hi0[3], lo1[3], hi1[3];
+  int32_t child0, child1, count0, count1;
+};
+static_assert(sizeof(BvhNode) == 64, "BvhNode must be one 64-byte line");
+
+float round_down(double v) {
+  float f = (float)v;
+  return (double)f > v ? std::nextafterf(f, -INFINITY) : f;
+}
+float round_up(double v) {
+  float f = (float)v;
+  return (double)f < v ? std::nextafterf(f, INFINITY) : f;
+}
+
+// Surface-area-heuristic build (full sweep on the three axes).  Measured on
+// hugeArray: 33 node visits and 3.0 primitive tests per segment against 57 /
+// 5.8 with median splits.
 struct BvhBuilder {
   const std::vector<Box>& boxes;
-  std::vector<int> order;
-  std::vector<double> node_box;
-  std::vector<int32_t> node_link;
+  std::vector<int> order;       // leaf primitive order
+  std::vector<BvhNode> nodes;
   int max_depth = 0;
 
-  explicit BvhBuilder(const std::vector<Box>& b) : boxes(b) {
-    order.resize(b.size());
-    for (size_t i = 0; i < b.size(); ++i) order[i] = (int)i;
+  explicit BvhBuilder(const std::vector<Box>& b) : boxes(b) {}
+
+  static double area(const Box& b) {
+    const double ex = b.hi[0] - b.lo[0], ey = b.hi[1] - b.lo[1], ez = b.hi[2] - b.lo[2];
+    return 2.0 * (ex * ey + ey * ez + ez * ex);
   }
 
-  int build(int first, int count, int depth) {
+  struct Ref { int32_t child, count; Box box; };
+
+  // builds the subtree over ids; returns either a leaf ref or an inner node ref
+  Ref build(std::vector<int>& ids, int depth) {
     max_depth = std::max(max_depth, depth);
-    const int id = (int)(node_link.size() / 4);
-    node_box.resize(node_box.size() + 6);
-    node_link.resize(node_link.size() + 4);
-    Box bb, cb;
+    Box bb;
     bb.reset();
-    cb.reset();
-    for (int i = first; i < first + count; ++i) {
-      const Box& b = boxes[order[i]];
-      bb.grow(b);
-      for (int a = 0; a < 3; ++a) {
-        const double c = 0.5 * (b.lo[a] + b.hi[a]);
-        cb.lo[a] = std::min(cb.lo[a], c);
-        cb.hi[a] = std::max(cb.hi[a], c);
+    for (int i : ids) bb.grow(boxes[i]);
+    const int m = (int)ids.size();
+    auto make_leaf = [&]() {
+      Ref r;
+      r.child = (int32_t)order.size();
+      r.count = m;
+      r.box = bb;
+      for (int i : ids) order.push_back(i);
+      return r;
+    };
+    if (m <= 1) return make_leaf();
+    // SAH sweep
+    double best_cost = INFINITY;
+    int best_axis = -1, best_split = 0;
+    std::vector<int> sorted(ids), best_sorted;
+    std::vector<double> right_area(m);
+    for (int a = 0; a < 3; ++a) {
+      std::sort(sorted.begin(), sorted.end(), [&](int x, int y) {
+        const double cx = boxes[x].lo[a] + boxes[x].hi[a], cy = boxes[y].lo[a] + boxes[y].hi[a];
+        return cx < cy || (cx == cy && x < y);
+      });
+      Box r;
+      r.reset();
+      for (int i = m - 1; i > 0; --i) { r.grow(boxes[sorted[i]]); right_area[i] = area(r); }
+      Box l;
+      l.reset();
+      for (int i = 1; i < m; ++i) {
+        l.grow(boxes[sorted[i - 1]]);
+        const double cost = area(l) * i + right_area[i] * (m - i);
+        if (cost < best_cost) { best_cost = cost; best_axis = a; best_split = i; best_sorted = sorted; }
       }
     }
-    for (int a = 0; a < 3; ++a) { node_box[6 * id + a] = bb.lo[a]; node_box[6 * id + 3 + a] = bb.hi[a]; }
-    int axis = 0;
-    for (int a = 1; a < 3; ++a)
-      if (cb.hi[a] - cb.lo[a] > cb.hi[axis] - cb.lo[axis]) axis = a;
-    if (count <= kBvhLeaf || !(cb.hi[axis] > cb.lo[axis])) {
-      node_link[4 * id] = ~first;
-      node_link[4 * id + 1] = count;
-      node_link[4 * id + 2] = 0;
-      node_link[4 * id + 3] = 0;
-      return id;
+    // leaf if splitting does not pay (traversal step ~ 1 primitive test) and it is small
+    const double leaf_cost = area(bb) * m;
+    if (m <= kBvhLeaf && best_cost + area(bb) >= leaf_cost) return make_leaf();
+    if (best_axis < 0) return make_leaf();
+    std::vector<int> left(best_sorted.begin(), best_sorted.begin() + best_split);
+    std::vector<int> right(best_sorted.begin() + best_split, best_sorted.end());
+    const int id = (int)nodes.size();
+    nodes.emplace_back();
+    const Ref l = build(left, depth + 1);
+    const Ref r = build(right, depth + 1);
+    BvhNode& nd = nodes[id];
+    for (int k = 0; k < 3; ++k) {
+      nd.lo0[k] = round_down(l.box.lo[k]); nd.hi0[k] = round_up(l.box.hi[k]);
+      nd.lo1[k] = round_down(r.box.lo[k]); nd.hi1[k] = round_up(r.box.hi[k]);
     }
-    const int mid = first + count / 2;
-    std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + first + count,
-                     [&](int x, int y) {
-                       const double cx = boxes[x].lo[axis] + boxes[x].hi[axis];
-                       const double cy = boxes[y].lo[axis] + boxes[y].hi[axis];
-                       return cx < cy || (cx == cy && x < y);
-                     });
-    const int l = build(first, mid - first, depth + 1);
-    const int r = build(mid, first + count - mid, depth + 1);
-    node_link[4 * id] = l;
-    node_link[4 * id + 1] = r;
-    node_link[4 * id + 2] = axis;
-    node_link[4 * id + 3] = 0;
-    return id;
+    nd.child0 = l.child; nd.count0 = l.count;
+    nd.child1 = r.child; nd.count1 = r.count;
+    Ref out;
+    out.child = id;
+    out.count = 0;
+    out.box = bb;
+    return out;
   }
 };
 
@@ -238,18 +279,37 @@ int build_bvh(odw_ctx* ctx) {
     ctx->P.scene.prim_hdr = (const double*)ctx->prim_hdr.p;
   }
   if (n <= kBvhThreshold) return ODW_OK;
+  // float32 traversal boxes: enlarge by what float rounding of the ray origin
+  // and of the slab arithmetic can cost (see ray_box_f32 in odw_kernels.hip)
+  for (int p = 0; p < n; ++p)
+    for (int a = 0; a < 3; ++a) {
+      const double s = 1e-4 + 4e-7 * (std::fabs(boxes[p].lo[a]) + std::fabs(boxes[p].hi[a]));
+      boxes[p].lo[a] -= s;
+      boxes[p].hi[a] += s;
+    }
   BvhBuilder b(boxes);
-  b.build(0, n, 0);
-  if (b.max_depth + 1 > ODW_BVH_STACK) return fail(ctx, ODW_ERR_UNSUPPORTED, "BVH deeper than the LDS stack");
+  std::vector<int> ids(n);
+  for (int i = 0; i < n; ++i) ids[i] = i;
+  b.nodes.reserve((size_t)n);
+  const BvhBuilder::Ref root = b.build(ids, 0);
+  if (root.count > 0) {   // everything in one leaf: wrap it into a root node
+    BvhNode nd;
+    for (int k = 0; k < 3; ++k) {
+      nd.lo0[k] = round_down(root.box.lo[k]); nd.hi0[k] = round_up(root.box.hi[k]);
+      nd.lo1[k] = INFINITY; nd.hi1[k] = -INFINITY;
+    }
+    nd.child0 = root.child; nd.count0 = root.count;
+    nd.child1 = 0; nd.count1 = 0;
+    b.nodes.insert(b.nodes.begin(), nd);
+  }
+  if (b.max_depth + 2 > ODW_BVH_STACK) return fail(ctx, ODW_ERR_UNSUPPORTED, "BVH deeper than the LDS stack");
   int rc;
-  if ((rc = upload(ctx, ctx->bvh_box, b.node_box.data(), b.node_box.size() * sizeof(double)))) return rc;
-  if ((rc = upload(ctx, ctx->bvh_link, b.node_link.data(), b.node_link.size() * sizeof(int32_t)))) return rc;
+  if ((rc = upload(ctx, ctx->bvh_nodes, b.nodes.data(), b.nodes.size() * sizeof(BvhNode)))) return rc;
   if ((rc = upload(ctx, ctx->bvh_prims, b.order.data(), b.order.size() * sizeof(int)))) return rc;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host vectors die with this scope
-  ctx->P.scene.bvh_box = (const double*)ctx->bvh_box.p;
-  ctx->P.scene.bvh_link = (const int32_t*)ctx->bvh_link.p;
+  ctx->P.scene.bvh_nodes = (const float*)ctx->bvh_nodes.p;
   ctx->P.scene.bvh_prims = (const int32_t*)ctx->bvh_prims.p;
-  ctx->P.scene.n_nodes = (int)(b.node_link.size() / 4);
+  ctx->P.scene.n_nodes = (int)b.nodes.size();
   return ODW_OK;
 }
 
@@ -384,7 +444,7 @@ void odw_destroy(odw_ctx* ctx) {
   for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   for (auto& ev : ctx->free_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   DevBuf* all[] = {&ctx->prim_f64, &ctx->prim_hdr, &ctx->prim_i32, &ctx->cond_i32, &ctx->group_f64, &ctx->group_i32,
-                   &ctx->group_gdir, &ctx->seq_mask, &ctx->bvh_box, &ctx->bvh_link, &ctx->bvh_prims,
+                   &ctx->group_gdir, &ctx->seq_mask, &ctx->bvh_nodes, &ctx->bvh_prims,
                    &ctx->phi_tab, &ctx->t_tab, &ctx->t_guide, &ctx->d_source, &ctx->d_det, &ctx->hits, &ctx->hit_count, &ctx->chunk_counter, &ctx->hist,
                    &ctx->counters, &ctx->ray_o, &ctx->ray_d, &ctx->ray_p, &ctx->samp_t, &ctx->samp_phi,
                    &ctx->sort_keys[0], &ctx->sort_keys[1], &ctx->sort_vals[0], &ctx->sort_vals[1],

@@ -42,9 +42,9 @@ struct DeviceScene {
   const int32_t* group_i32;     // [64*4]
   const double* group_gdir;     // [64*3]
   const uint64_t* seq_mask;     // [seq_len]
-  // BVH (big scenes only): per node 6 f64 (lo xyz, hi xyz) + 4 i32
-  const double* bvh_box;        // [n_nodes*6]
-  const int32_t* bvh_link;      // [n_nodes*4] left, right, split axis, - | leaves: ~first, count
+  // BVH (big scenes only): 64-byte nodes = f32 boxes of both children
+  // (lo0 hi0 lo1 hi1, 12 floats) + child0, child1, count0, count1 (count > 0: leaf)
+  const float* bvh_nodes;       // [n_nodes*16]
   const int32_t* bvh_prims;     // leaf primitive order
   int32_t n_prims, n_groups, n_nodes;
   int32_t seq_enabled, seq_len;

@@ -595,47 +595,79 @@ __device__ __forceinline__ int nearest(const DeviceScene& sc, const SceneView& s
       intersect_prim(sv, q, p, type, g, flags, cond_word);
     }
   } else {
-    cf64 bvh_box = as_const(sc.bvh_box);
-    ci32 bvh_link = as_const(sc.bvh_link);
+    // BVH traversal in float32 (culling only: leaves are intersected in
+    // float64).  One 64-byte node fetch carries the boxes of both children.
+    // "while-while": every lane walks inner nodes (cheap, same code for all
+    // lanes) until it stands on a leaf or is done; only then are the leaf
+    // primitives intersected (expensive), so that part runs with as many
+    // lanes as possible.  Stack entries: >= 0 inner node, < -1 leaf
+    // (~(first | count << 24) - 1); node stack in LDS, one column per thread.
+    typedef const float ODW_CONST* cf32;
+    typedef float vf4 __attribute__((ext_vector_type(4)));
+    typedef int vi4 __attribute__((ext_vector_type(4)));
+    cf32 nodes = (cf32)(uintptr_t)sc.bvh_nodes;
     ci32 bvh_prims = as_const(sc.bvh_prims);
-    // "while-while" traversal: every lane first walks inner nodes (cheap,
-    // same code for all lanes) until it stands on a leaf or is done; only then
-    // are the leaf primitives intersected (expensive), so that part runs with
-    // as many lanes as possible instead of one lane at a time.
+    const float ofx = (float)start.x, ofy = (float)start.y, ofz = (float)start.z;
+    const float ivx = (float)inv.x, ivy = (float)inv.y, ivz = (float)inv.z;
     int sp = 0;
-    int node = 0;
+    int cur = 0;
     for (;;) {
-      int leaf_first = 0, leaf_count = 0;
-      while (node >= 0) {
-        const double cut = fmin(q.tmax, q.any.t + 2.0 * q.tol);
-        int nxt = -1;
-        if (ray_box(bvh_box + (size_t)node * 6, oi, inv, cut)) {
-          const int lk_x = bvh_link[4 * node], lk_y = bvh_link[4 * node + 1];
-          if (lk_x < 0) {            // leaf: ~first, count
-            leaf_first = ~lk_x;
-            leaf_count = lk_y;
-          } else {
-            // near child first: the left child holds the smaller centroids
-            // along the split axis
-            const bool fwd = comp(dn, bvh_link[4 * node + 2]) >= 0;
-            stack[sp * 256] = fwd ? lk_y : lk_x;  // LDS stack, one column per thread
-            ++sp;
-            nxt = fwd ? lk_x : lk_y;
-          }
+      while (cur >= 0) {
+        cf32 nd = nodes + (size_t)cur * 16;
+        const vf4 a0 = *reinterpret_cast<const vf4 ODW_CONST*>(nd);
+        const vf4 a1 = *reinterpret_cast<const vf4 ODW_CONST*>(nd + 4);
+        const vf4 a2 = *reinterpret_cast<const vf4 ODW_CONST*>(nd + 8);
+        const vi4 lk = *reinterpret_cast<const vi4 ODW_CONST*>(nd + 12);
+        // lo0 = a0.xyz, hi0 = (a0.w, a1.x, a1.y), lo1 = (a1.z, a1.w, a2.x), hi1 = a2.yzw
+        const float cutf = (float)fmin(q.tmax, q.any.t + 2.0 * q.tol) * 1.00001f + 1e-3f;
+        float tn0, tf0, tn1, tf1;
+        {
+          const float x0 = (a0.x - ofx) * ivx, x1 = (a0.w - ofx) * ivx;
+          const float y0 = (a0.y - ofy) * ivy, y1 = (a1.x - ofy) * ivy;
+          const float z0 = (a0.z - ofz) * ivz, z1 = (a1.y - ofz) * ivz;
+          tn0 = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+          tf0 = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
         }
-        if (nxt < 0 && sp > 0) {
+        {
+          const float x0 = (a1.z - ofx) * ivx, x1 = (a2.y - ofx) * ivx;
+          const float y0 = (a1.w - ofy) * ivy, y1 = (a2.z - ofy) * ivy;
+          const float z0 = (a2.x - ofz) * ivz, z1 = (a2.w - ofz) * ivz;
+          tn1 = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fminf(z0, z1));
+          tf1 = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+        }
+        // conservative acceptance: relative 1e-5 + absolute 1e-3 mm on t
+        const bool h0 = tf0 * 1.00001f + 1e-3f >= fmaxf(tn0, 0.f) * 0.99999f - 1e-3f && tn0 * 0.99999f - 1e-3f < cutf;
+        const bool h1 = tf1 * 1.00001f + 1e-3f >= fmaxf(tn1, 0.f) * 0.99999f - 1e-3f && tn1 * 0.99999f - 1e-3f < cutf;
+        const int r0 = lk.z > 0 ? -2 - (lk.x | (lk.z << 24)) : lk.x;
+        const int r1 = lk.w > 0 ? -2 - (lk.y | (lk.w << 24)) : lk.y;
+        if (h0 && h1) {
+          const bool first0 = tn0 <= tn1;
+          stack[sp * 256] = first0 ? r1 : r0;
+          ++sp;
+          cur = first0 ? r0 : r1;
+        } else if (h0 || h1) {
+          cur = h0 ? r0 : r1;
+        } else if (sp > 0) {
           --sp;
-          nxt = stack[sp * 256];
+          cur = stack[sp * 256];
+        } else {
+          cur = -1;
         }
-        node = nxt;
-        if (leaf_count) break;
       }
-      if (!leaf_count) break;        // stack exhausted
+      if (cur == -1) break;            // done
+      const int code = -2 - cur;       // leaf
+      const int leaf_first = code & 0xffffff, leaf_count = code >> 24;
       for (int i = 0; i < leaf_count; ++i) {
         const int p = bvh_prims[leaf_first + i];
         ci32 pi = sv.prim_i32 + 4 * p;
         const int g = pi[1];
         if ((mask >> g) & 1) intersect_prim(sv, q, p, pi[0], g, pi[2], pi[3]);
+      }
+      if (sp > 0) {
+        --sp;
+        cur = stack[sp * 256];
+      } else {
+        break;
       }
     }
   }
