@@ -278,7 +278,8 @@ int build_bvh(odw_ctx* ctx) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->P.scene.prim_hdr = (const double*)ctx->prim_hdr.p;
   }
-  if (n <= kBvhThreshold) return ODW_OK;
+  static const int bvh_threshold = [] { const char* e = getenv("ODW_BVH_THRESHOLD"); return e ? atoi(e) : kBvhThreshold; }();
+  if (n <= bvh_threshold) return ODW_OK;
   // float32 traversal boxes: enlarge by what float rounding of the ray origin
   // and of the slab arithmetic can cost (see ray_box_f32 in odw_kernels.hip)
   for (int p = 0; p < n; ++p)
