@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(CSRC, 'libodw_trace.so')
 _SOURCES = ['odw_capi.hip', 'odw_kernels.hip', 'odw_device.h']
 _HEADER = os.path.normpath(os.path.join(_HERE, '..', '..', 'include', 'odw_trace.h'))
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 CNT_NAMES = ['traced_rays', 'recorded_hits', 'segments', 'escaped', 'died', 'capped',
              'hist_overflow', 'hits_dropped']
 TRACE_RECORD_HITS, TRACE_HISTOGRAM = 1, 2
@@ -27,7 +27,7 @@ HIT_DTYPE = np.dtype([('point', '<f8', 3), ('direction', '<f8', 3), ('power', '<
 
 # every symbol include/odw_trace.h declares
 SYMBOLS = ['odw_abi_version', 'odw_create', 'odw_destroy', 'odw_last_error', 'odw_upload_scene',
-           'odw_upload_source', 'odw_set_limits', 'odw_set_detector', 'odw_reserve_hits', 'odw_trace',
+           'odw_upload_source', 'odw_upload_surface_samplers', 'odw_set_surface_seed', 'odw_set_limits', 'odw_set_detector', 'odw_reserve_hits', 'odw_trace',
            'odw_trace_rays', 'odw_sync', 'odw_reset_results', 'odw_reset_hits', 'odw_fetch_counters', 'odw_hit_count',
            'odw_fetch_hits', 'odw_fetch_histogram', 'odw_sample', 'odw_device_histogram',
            'odw_device_counters', 'odw_stream', 'odw_timing_enable', 'odw_timing_read']
@@ -52,6 +52,13 @@ class SourceDesc(C.Structure):
   _fields_ = [('xform', C.c_double * 12), ('focal_length', C.c_double), ('wavelength', C.c_double),
               ('power', C.c_double), ('n_phi_knots', C.c_int32), ('phi_edges', _pd), ('phi_cdf', _pd),
               ('n_t_knots', C.c_int32), ('n_t_rows', C.c_int32), ('t_edges', _pd), ('t_cdf', _pd)]
+
+
+class SurfaceSamplerDesc(C.Structure):
+  _fields_ = [('group', C.c_int32), ('kind', C.c_int32), ('family_axis', C.c_int32), ('n_family', C.c_int32),
+              ('family_lo', C.c_double), ('family_hi', C.c_double), ('n_phi_knots', C.c_int32),
+              ('phi_edges', _pd), ('phi_cdf', _pd), ('n_t_knots', C.c_int32), ('n_t_rows', C.c_int32),
+              ('t_edges', _pd), ('t_cdf', _pd)]
 
 
 class LimitsDesc(C.Structure):
@@ -169,3 +176,20 @@ def source_desc(src):
   for name in keep:
     setattr(d, name, keep[name].ctypes.data_as(_pd))
   return d, keep
+
+
+def surface_sampler_descs(samplers):
+  """array of odw_surface_sampler_desc for scene.surface_samplers"""
+  samplers = list(samplers or [])
+  arr = (SurfaceSamplerDesc * max(1, len(samplers)))()
+  keep = [arr]
+  for d, s in zip(arr, samplers):
+    phi_edges, phi_cdf = _arr(s.phi_edges, np.float64), _arr(s.phi_cdf, np.float64)
+    t_edges, t_cdf = _arr(s.t_edges, np.float64), _arr(s.t_cdf, np.float64)
+    keep += [phi_edges, phi_cdf, t_edges, t_cdf]
+    d.group, d.kind, d.family_axis, d.n_family = int(s.group), int(s.kind), int(s.axis), int(s.n_family)
+    d.family_lo, d.family_hi = float(s.lo), float(s.hi)
+    d.n_phi_knots, d.n_t_knots, d.n_t_rows = len(phi_edges), len(t_edges), int(t_cdf.shape[-2])
+    for name, a in (('phi_edges', phi_edges), ('phi_cdf', phi_cdf), ('t_edges', t_edges), ('t_cdf', t_cdf)):
+      setattr(d, name, a.ctypes.data_as(_pd))
+  return arr, len(samplers), keep

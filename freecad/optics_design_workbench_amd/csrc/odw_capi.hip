@@ -23,6 +23,7 @@ using namespace odw;
 namespace {
 
 constexpr int kGuide = 1 << 16;
+constexpr int kSurfaceGuide = 1 << 10;  // per row of a surface sampler (tables of ~1e3 knots)
 constexpr int kBvhThreshold = 16;  // brute force (scalar loads) below this many primitives
 constexpr int kBvhLeaf = 4;
 
@@ -55,6 +56,12 @@ struct odw_ctx {
   DevBuf hits, hit_count, hist, counters, chunk_counter;
   DevBuf ray_o, ray_d, ray_p, samp_t, samp_phi;
   DevBuf sort_keys[2], sort_vals[2], sort_tmp, sorted_rows;
+  // stochastic surfaces: one table set per sampler, descriptor block, (group, kind) -> index
+  struct SurfaceBufs { DevBuf phi_tab, t_tab, t_guide; };
+  std::vector<SurfaceBufs> surf_bufs;
+  DevBuf d_samplers, d_group_sampler;
+  int n_samplers = 0;
+  uint64_t surface_seed = 0;
   uint64_t hit_capacity = 0, n_bins = 0;
 
   TraceParams P;
@@ -351,8 +358,10 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
   TraceParams& P = ctx->P;
   P.first_ray = first;
   P.n_rays = n;
-  P.seed = seed;
+  P.seed = explicit_rays ? ctx->surface_seed : seed;
   P.flags = flags;
+  P.samplers = (const DeviceSurfaceSampler*)ctx->d_samplers.p;
+  P.group_sampler = (const int32_t*)ctx->d_group_sampler.p;
   P.ray_origins = explicit_rays ? (const double*)ctx->ray_o.p : nullptr;
   P.ray_dirs = explicit_rays ? (const double*)ctx->ray_d.p : nullptr;
   P.ray_powers = (explicit_rays && ctx->ray_p.p) ? (const double*)ctx->ray_p.p : nullptr;
@@ -384,10 +393,14 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
     }
     HIPCHK(ctx, hipEventRecord(ev.first, ctx->stream));
   }
-  if (P.scene.n_nodes)
-    hipLaunchKernelGGL(odw_trace_kernel<true>, dim3(grid), dim3(256), lds, ctx->stream, P);
-  else
-    hipLaunchKernelGGL(odw_trace_kernel<false>, dim3(grid), dim3(256), 0, ctx->stream, P);
+  const bool stoch = ctx->n_samplers > 0;
+  if (P.scene.n_nodes) {
+    if (stoch) hipLaunchKernelGGL((odw_trace_kernel<true, true>), dim3(grid), dim3(256), lds, ctx->stream, P);
+    else hipLaunchKernelGGL((odw_trace_kernel<true, false>), dim3(grid), dim3(256), lds, ctx->stream, P);
+  } else {
+    if (stoch) hipLaunchKernelGGL((odw_trace_kernel<false, true>), dim3(grid), dim3(256), 0, ctx->stream, P);
+    else hipLaunchKernelGGL((odw_trace_kernel<false, false>), dim3(grid), dim3(256), 0, ctx->stream, P);
+  }
   HIPCHK(ctx, hipGetLastError());
   if (ctx->timing) {
     HIPCHK(ctx, hipEventRecord(ev.second, ctx->stream));
@@ -451,6 +464,9 @@ void odw_destroy(odw_ctx* ctx) {
                    &ctx->sort_keys[0], &ctx->sort_keys[1], &ctx->sort_vals[0], &ctx->sort_vals[1],
                    &ctx->sort_tmp, &ctx->sorted_rows};
   for (DevBuf* b : all) release(*b);
+  for (auto& sb : ctx->surf_bufs) { release(sb.phi_tab); release(sb.t_tab); release(sb.t_guide); }
+  release(ctx->d_samplers);
+  release(ctx->d_group_sampler);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -526,6 +542,92 @@ int odw_upload_scene(odw_ctx* ctx, const odw_scene_desc* s) {
   d.ignore_mask = s->ignore_mask;
   ctx->have_scene = true;
   ctx->bvh_dirty = true;
+  ctx->n_samplers = 0;   // surface samplers belong to the previous scene's groups
+  return ODW_OK;
+}
+
+int odw_upload_surface_samplers(odw_ctx* ctx, const odw_surface_sampler_desc* samplers, int32_t n) {
+  if (!ctx || n < 0 || (n && !samplers)) return fail(ctx, ODW_ERR_INVALID, "odw_upload_surface_samplers: bad argument");
+  if (!ctx->have_scene) return fail(ctx, ODW_ERR_NO_SCENE, "odw_upload_surface_samplers before odw_upload_scene");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // a running launch may still read the old tables
+  ctx->n_samplers = 0;
+  if (n == 0) return ODW_OK;
+  std::vector<int32_t> gs(ODW_MAX_GROUPS * 2, -1);
+  std::vector<DeviceSurfaceSampler> ds((size_t)n);
+  if ((int)ctx->surf_bufs.size() < n) ctx->surf_bufs.resize((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    const odw_surface_sampler_desc& s = samplers[i];
+    if (s.group < 0 || s.group >= ctx->P.scene.n_groups || s.kind < ODW_SURF_PRIMARY || s.kind > ODW_SURF_MODIFY)
+      return fail(ctx, ODW_ERR_INVALID, "surface sampler: group/kind out of range");
+    if (gs[2 * s.group + s.kind] >= 0) return fail(ctx, ODW_ERR_INVALID, "surface sampler: duplicate (group, kind)");
+    if (s.n_family < 1 || s.family_axis < ODW_SURF_AXIS_NONE || s.family_axis > ODW_SURF_AXIS_THETA_REFL ||
+        (s.family_axis == ODW_SURF_AXIS_NONE && s.n_family != 1) ||
+        (s.n_family > 1 && !(s.family_hi > s.family_lo)))
+      return fail(ctx, ODW_ERR_INVALID, "surface sampler: family");
+    if (s.n_phi_knots < 2 || s.n_t_knots < 2 || s.n_t_rows < 1 ||
+        (s.n_t_rows != 1 && s.n_t_rows != s.n_phi_knots - 1))
+      return fail(ctx, ODW_ERR_INVALID, "surface sampler: table shape");
+    const size_t np = (size_t)s.n_phi_knots, nt = (size_t)s.n_t_knots, rows = (size_t)s.n_t_rows, nf = (size_t)s.n_family;
+    std::vector<double> ptab(nf * np * 2), ttab(nf * rows * nt * 2);
+    std::vector<int32_t> guide(nf * rows * (kSurfaceGuide + 1));
+    for (size_t k = 0; k < nf; ++k) {
+      const double* pc = s.phi_cdf + k * np;
+      if (pc[0] != 0.0 || pc[np - 1] != 1.0) return fail(ctx, ODW_ERR_INVALID, "surface sampler: phi cdf must run from 0 to 1");
+      for (size_t j = 0; j < np; ++j) {
+        if (j && pc[j] < pc[j - 1]) return fail(ctx, ODW_ERR_INVALID, "surface sampler: cdf not monotone");
+        ptab[(k * np + j) * 2] = pc[j];
+        ptab[(k * np + j) * 2 + 1] = s.phi_edges[j];
+      }
+      for (size_t r = 0; r < rows; ++r) {
+        const double* cdf = s.t_cdf + (k * rows + r) * nt;
+        if (cdf[0] != 0.0 || cdf[nt - 1] != 1.0) return fail(ctx, ODW_ERR_INVALID, "surface sampler: theta cdf rows must run from 0 to 1");
+        double* dst = ttab.data() + (k * rows + r) * nt * 2;
+        for (size_t j = 0; j < nt; ++j) {
+          if (j && cdf[j] < cdf[j - 1]) return fail(ctx, ODW_ERR_INVALID, "surface sampler: cdf not monotone");
+          dst[2 * j] = cdf[j];
+          dst[2 * j + 1] = s.t_edges[j];
+        }
+        int32_t* g = guide.data() + (k * rows + r) * (kSurfaceGuide + 1);
+        size_t j = 0;
+        for (int q = 0; q <= kSurfaceGuide; ++q) {
+          const double x = (double)q / (double)kSurfaceGuide;
+          while (j + 1 < nt && cdf[j + 1] <= x) ++j;
+          g[q] = (int32_t)j;
+        }
+      }
+    }
+    odw_ctx::SurfaceBufs& sb = ctx->surf_bufs[(size_t)i];
+    int rc;
+    if ((rc = upload(ctx, sb.phi_tab, ptab.data(), ptab.size() * sizeof(double)))) return rc;
+    if ((rc = upload(ctx, sb.t_tab, ttab.data(), ttab.size() * sizeof(double)))) return rc;
+    if ((rc = upload(ctx, sb.t_guide, guide.data(), guide.size() * sizeof(int32_t)))) return rc;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // staging vectors go out of scope
+    DeviceSurfaceSampler& d = ds[(size_t)i];
+    d.phi_tab = (const double*)sb.phi_tab.p;
+    d.t_tab = (const double*)sb.t_tab.p;
+    d.t_guide = (const int32_t*)sb.t_guide.p;
+    d.n_phi_knots = s.n_phi_knots;
+    d.n_t_knots = s.n_t_knots;
+    d.n_t_rows = s.n_t_rows;
+    d.n_guide = kSurfaceGuide;
+    d.axis = s.family_axis;
+    d.n_family = s.n_family;
+    d.lo = s.family_lo;
+    d.inv_step = s.n_family > 1 ? (double)(s.n_family - 1) / (s.family_hi - s.family_lo) : 0.0;
+    gs[2 * s.group + s.kind] = i;
+  }
+  int rc;
+  if ((rc = upload(ctx, ctx->d_samplers, ds.data(), ds.size() * sizeof(DeviceSurfaceSampler)))) return rc;
+  if ((rc = upload(ctx, ctx->d_group_sampler, gs.data(), gs.size() * sizeof(int32_t)))) return rc;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->n_samplers = n;
+  return ODW_OK;
+}
+
+int odw_set_surface_seed(odw_ctx* ctx, uint64_t seed) {
+  if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_set_surface_seed: null ctx");
+  ctx->surface_seed = seed;
   return ODW_OK;
 }
 

@@ -61,6 +61,17 @@ struct DeviceSource {
   int32_t finite_focal;
 };
 
+// one stochastic-surface sampler (odw_surface_sampler_desc): a family of
+// source-like tables, member k = one value of the per-hit constant
+struct DeviceSurfaceSampler {
+  const double* phi_tab;        // [n_family][n_phi_knots*2]
+  const double* t_tab;          // [n_family][rows*n_t_knots*2]
+  const int32_t* t_guide;       // [n_family][rows*(n_guide+1)]
+  int32_t n_phi_knots, n_t_knots, n_t_rows, n_guide;
+  int32_t axis, n_family;
+  double lo, inv_step;          // member = rint((c - lo) * inv_step), clamped
+};
+
 struct DeviceLimits {
   double max_ray_length, dist_tol, power_tol;
   int32_t max_intersections;
@@ -93,6 +104,8 @@ struct TraceParams {
   const DeviceDetector* det;
   int32_t det_enabled;
   double wavelength;            // nm; of the uploaded source, 500 if none (explicit rays)
+  const DeviceSurfaceSampler* samplers;   // stochastic surfaces (STOCH kernels only)
+  const int32_t* group_sampler;           // [64*2] sampler index of (group, kind) or -1
   DeviceOutputs out;
   const double* ray_origins;    // explicit initial conditions (or null)
   const double* ray_dirs;

@@ -114,12 +114,13 @@ __device__ __forceinline__ double inv_cdf(const double* __restrict__ tab, int lo
   return prod + a.y;
 }
 
-__device__ __forceinline__ void sample_source(csource sp_, double u_phi, double u_t,
+struct TableView {
+  const double* phi_tab; const double* t_tab; const int32_t* t_guide;
+  int n_phi_knots, n_t_knots, n_t_rows, n_guide;
+};
+__device__ __forceinline__ void sample_tables(const TableView& s, double u_phi, double u_t,
                                               double& t_out, double& phi_out) {
 #pragma clang fp contract(off)
-  struct { const double* phi_tab; const double* t_tab; const int32_t* t_guide; int n_phi_knots, n_t_knots, n_t_rows, n_guide; } s;
-  s.phi_tab = sp_->phi_tab; s.t_tab = sp_->t_tab; s.t_guide = sp_->t_guide;
-  s.n_phi_knots = sp_->n_phi_knots; s.n_t_knots = sp_->n_t_knots; s.n_t_rows = sp_->n_t_rows; s.n_guide = sp_->n_guide;
   const double phi = inv_cdf(s.phi_tab, 0, s.n_phi_knots - 1, u_phi);
   int row = 0;
   if (s.n_t_rows > 1) {
@@ -142,6 +143,14 @@ __device__ __forceinline__ void sample_source(csource sp_, double u_phi, double 
   const int hi = min(guide[k + 1] + 1, s.n_t_knots - 1);
   t_out = inv_cdf(tab, lo, hi, u_t);
   phi_out = phi;
+}
+
+__device__ __forceinline__ void sample_source(csource sp_, double u_phi, double u_t,
+                                              double& t_out, double& phi_out) {
+  TableView s;
+  s.phi_tab = sp_->phi_tab; s.t_tab = sp_->t_tab; s.t_guide = sp_->t_guide;
+  s.n_phi_knots = sp_->n_phi_knots; s.n_t_knots = sp_->n_t_knots; s.n_t_rows = sp_->n_t_rows; s.n_guide = sp_->n_guide;
+  sample_tables(s, u_phi, u_t, t_out, phi_out);
 }
 
 template <class P>
@@ -717,6 +726,58 @@ __device__ __forceinline__ d3 line_grating(d3 ray, double n1, double n2, d3 norm
   return S * -1.0;
 }
 
+// ------------------------------------------- stochastic surfaces (N3)
+// FreeCAD Rotation(axis, angle) * v; a zero axis is the identity
+__device__ __forceinline__ d3 rotate(d3 axis, double angle, d3 v) {
+  const double l2 = dot(axis, axis);
+  if (l2 == 0) return v;
+  const d3 k = axis * (1.0 / sqrt(l2));
+  double s, c;
+  sincos_bounded(angle, s, c);
+  return v * c + cross(k, v) * s + k * (dot(k, v) * (1.0 - c));
+}
+__device__ __forceinline__ double acos_clamped(double x) { return acos(fmax(-1.0, fmin(1.0, x))); }
+
+__device__ __forceinline__ void surface_draw(const DeviceSurfaceSampler* sp, double theta_in, double theta_refl,
+                                             uint64_t ray, uint64_t seed, uint32_t ordinal, uint32_t stream,
+                                             double& theta, double& phi) {
+  const DeviceSurfaceSampler S = *sp;
+  int k = 0;
+  if (S.axis != ODW_SURF_AXIS_NONE) {
+    const double c = S.axis == ODW_SURF_AXIS_THETA_IN ? theta_in : theta_refl;
+    k = (int)rint((c - S.lo) * S.inv_step);
+    k = max(0, min(S.n_family - 1, k));
+  }
+  TableView tv;
+  tv.phi_tab = S.phi_tab + (size_t)k * (size_t)S.n_phi_knots * 2;
+  tv.t_tab = S.t_tab + (size_t)k * (size_t)S.n_t_rows * (size_t)S.n_t_knots * 2;
+  tv.t_guide = S.t_guide + (size_t)k * (size_t)S.n_t_rows * (size_t)(S.n_guide + 1);
+  tv.n_phi_knots = S.n_phi_knots; tv.n_t_knots = S.n_t_knots; tv.n_t_rows = S.n_t_rows; tv.n_guide = S.n_guide;
+  uint32_t c0 = (uint32_t)ray, c1 = (uint32_t)(ray >> 32), c2 = ordinal, c3 = stream;
+  philox4x32_10(c0, c1, c2, c3, (uint32_t)seed, (uint32_t)(seed >> 32));
+  sample_tables(tv, u53(c0, c1), u53(c2, c3), theta, phi);
+}
+
+// OpticalGroupProxy.applyStochasticRayCorrections (optical_group.py:279-323)
+__device__ __noinline__ d3 scatter(const DeviceSurfaceSampler* samplers, int s_primary, int s_modify,
+                                   uint64_t ray, uint64_t seed, uint32_t ordinal, d3 din, d3 ideal, d3 n) {
+  if (s_primary < 0 && s_modify < 0) return ideal;
+  const double nl = sqrt(dot(n, n));
+  const double theta_in = acos_clamped(dot(din, n) / nl);
+  const double theta_refl = acos_clamped(dot(ideal, n) / (sqrt(dot(ideal, ideal)) * nl));
+  d3 out = ideal;
+  double theta, phi;
+  if (s_primary >= 0) {
+    surface_draw(samplers + s_primary, theta_in, theta_refl, ray, seed, ordinal, 1u + ODW_SURF_PRIMARY, theta, phi);
+    out = rotate(n, phi, rotate(cross(n, din), theta, n));
+  }
+  if (s_modify >= 0) {
+    surface_draw(samplers + s_modify, theta_in, theta_refl, ray, seed, ordinal, 1u + ODW_SURF_MODIFY, theta, phi);
+    out = rotate(out, phi, rotate(cross(out, din), theta, out));
+  }
+  return out * (1.0 / sqrt(dot(out, out)));
+}
+
 // ------------------------------------------------------- recording (K5)
 // Active lanes append one 64-B row each: one atomic per wave reserves the
 // block, lanes take consecutive slots by popcount prefix of the ballot.
@@ -787,7 +848,7 @@ __device__ __noinline__ RayInit generate_ray(const DeviceSource* sp, uint64_t ra
 #ifndef ODW_WAVES_PER_SIMD
 #define ODW_WAVES_PER_SIMD 4
 #endif
-template <bool BVH>
+template <bool BVH, bool STOCH>
 __global__ __launch_bounds__(256, ODW_WAVES_PER_SIMD) void odw_trace_kernel(const TraceParams P) {
   extern __shared__ int bvh_stack[];  // ODW_BVH_STACK x 256 ints (BVH variant only)
   // per-thread event counters live in LDS (one column per thread, ds_add_u32
@@ -900,7 +961,10 @@ __global__ __launch_bounds__(256, ODW_WAVES_PER_SIMD) void odw_trace_kernel(cons
         record_hit(P, P.first_ray + i, g, point, dir, power, entering, cnt_lds + threadIdx.x);
       }
       if (gtype == ODW_OPT_MIRROR) {
-        dir = mirror(dir, n);
+        const d3 ideal = mirror(dir, n);
+        if (STOCH) dir = scatter(P.samplers, P.group_sampler[2 * g], P.group_sampler[2 * g + 1], P.first_ray + i,
+                                 P.seed, (uint32_t)nint, dir, ideal, n);
+        else dir = ideal;
         power *= group_f64[4 * g + 1];
         ++seq;
       } else if (gtype == ODW_OPT_LENS) {
@@ -908,7 +972,10 @@ __global__ __launch_bounds__(256, ODW_WAVES_PER_SIMD) void odw_trace_kernel(cons
         double n2 = 1.0;
         if (entering) { medium = g; n2 = group_f64[4 * g]; }
         bool tir;
-        dir = snells_law(dir, n1, n2, n, tir);
+        const d3 ideal = snells_law(dir, n1, n2, n, tir);
+        if (STOCH) dir = scatter(P.samplers, P.group_sampler[2 * g], P.group_sampler[2 * g + 1], P.first_ray + i,
+                                 P.seed, (uint32_t)nint, dir, ideal, n);
+        else dir = ideal;
         if (!entering && !tir && medium == g) { medium = -1; ++seq; }
       } else if (gtype == ODW_OPT_ABSORBER) {
         power = 0;

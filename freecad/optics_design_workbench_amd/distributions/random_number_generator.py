@@ -130,6 +130,10 @@ class VectorRandomVariable:
         raise ValueError(f'found negative probability density, expression: {expr}')
       return p
 
+    with np.errstate(invalid='ignore', divide='ignore'):
+      return self._compile_tables(expr, syms, order, used, e0, e1, m0, m1, row, depends_on_last)
+
+  def _compile_tables(self, expr, syms, order, used, e0, e1, m0, m1, row, depends_on_last):
     if depends_on_last:
       cdf0 = np.empty((len(m1), len(e0)))
       marg = np.empty(len(m1))
@@ -172,6 +176,69 @@ class VectorRandomVariable:
     names = self._variableOrder or self._order
     out = np.array([res[k] for k in names])
     return out if N is not None else out[:, 0]
+
+
+  def drawPseudo(self, N, bins=None, overdrawFactor=0.1, overdrawIterations=50, constants=None):
+    """pseudo-random mode (random_number_generator.py:562-682): N samples whose
+    (theta, phi) histogram is thinned towards the expected one.  Each of the
+    `overdrawIterations` rounds adds N*overdrawFactor fresh draws, histograms
+    everything on a coarse grid and deletes random members of the most
+    over-populated bin until only N are left.  Consumes numpy's global RNG
+    in the reference's order: the result is the reference's, sample for
+    sample, from the same seed (tests/golden/pseudo_draws.npz)."""
+    if N <= 1:
+      raise ValueError('N must be greater than one in pseudo random mode')
+    if overdrawFactor <= 0:
+      raise ValueError('overdrawFactor must be greater than zero')
+    if overdrawIterations <= 1:
+      raise ValueError('overdrawIterations must be greater than one')
+    if not self._variableOrder:
+      raise ValueError('variableOrder must be passed to constructor to use pseudo random mode.')
+    if self._tables is None or (constants is not None and constants != self._constantsDict):
+      self.compile(**(constants or {}))
+    expr, syms, order, _ = self._prepare(**self._constantsDict)
+    by_name = {str(v): v for v in syms}
+    expected_fn = sy.lambdify([by_name[n] for n in reversed(self._variableOrder)], expr, modules=['numpy', 'scipy'])
+    nvar = len(self._variableOrder)
+    pool = None
+    for _ in range(round(int(overdrawIterations))):
+      fresh = self.draw(N=round(N * overdrawFactor))
+      if pool is None:
+        # the first round starts from (1 + factor) * N draws; its `fresh` block is discarded
+        pool = self.draw(N=round(N * (1 + overdrawFactor)))
+      else:
+        pool = np.concatenate([pool[..., ~np.isnan(pool[0])], fresh], axis=-1)
+      if bins is None:
+        bins = int((overdrawFactor * np.sqrt(overdrawIterations) * N)**(1 / (3 * nvar)))
+      hist, edges = np.histogramdd(pool.T, bins=bins)
+      centers = [(e[1:] + e[:-1]) / 2 for e in edges]
+      expected = expected_fn(*np.meshgrid(*reversed(centers)))
+      if not hasattr(expected, 'shape'):
+        expected = expected * np.ones(hist.shape)
+      while True:
+        excess = hist / hist.sum() - expected / expected.sum()
+        worst = np.argwhere(excess == excess.max())[0]
+        inside = None
+        for i, (e, b) in enumerate(zip(edges, worst)):
+          hit = np.logical_and(e[b] < pool[i], pool[i] <= e[b + 1])
+          inside = hit if inside is None else np.logical_and(inside, hit)
+        members = np.argwhere(inside)
+        if len(members) > 0:
+          victim = members[int(np.random.random() * members.shape[0])]
+          pool[(Ellipsis,) + tuple(victim)] = np.nan
+          hist[tuple(worst)] -= 1
+        else:
+          pool = pool[..., ~np.isnan(pool[0])]
+          pool = pool[..., -int(N):]
+          break
+        if np.sum(~np.isnan(pool[-1])) <= N:
+          break
+    result = pool[..., ~np.isnan(pool[0])]
+    if pool.shape[-1] / result.shape[-1] > 5:
+      import warnings
+      warnings.warn('pseudo random generation was not very successful, maybe bins '
+                    'or overdraw parameters have to be tweaked...')
+    return result[..., -int(round(N)):]
 
 
 class ScalarRandomVariable:

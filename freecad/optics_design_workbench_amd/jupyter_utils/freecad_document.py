@@ -141,10 +141,9 @@ class FreecadDocument:
     """run and return the RawFolder of the new run
     (freecad_document.py:640-770); endIf(rawFolder) -> bool ends a continuous
     run early"""
-    allowed = 'true singletrue fans singlefans'.split()
+    allowed = 'true pseudo singletrue singlepseudo fans'.split() + ['singlefans']
     if action not in allowed:
-      raise ValueError(f'illegal action {action}, expected one of {", ".join(allowed)} '
-                       f'(pseudo-random modes are not on the accelerated path)')
+      raise ValueError(f'illegal action {action}, expected one of {", ".join(allowed)}')
     store_box = {}
 
     def _end_if(store):

@@ -137,6 +137,7 @@ class BakedScene:
   group_labels: list = field(default_factory=list)
   prim_sources: list = field(default_factory=list)
   prim_to_world: list = field(default_factory=list)
+  surface_samplers: list = field(default_factory=list)   # freecad_elements.optical_group.BakedSurfaceSampler
 
   @property
   def n_prims(self):
@@ -172,18 +173,16 @@ def _abslen(v):
     return float('inf')
 
 
-def bakeScene(doc, source=None):
+def bakeScene(doc, source=None, surfaceFamily=None):
   """flat tables for all optical groups of `doc` as seen by `source`"""
   groups = opticalObjects(doc)
   if len(groups) > MAX_GROUPS:
     raise geometry.UnsupportedGeometry(f'{len(groups)} optical groups (limit {MAX_GROUPS})')
-  for g in groups:
-    for key in ('ReflectedProbabilityDensity', 'RefractedProbabilityDensity',
-                'RayModificationProbabilityDensity'):
-      if str(g._props.get(key, '') or '').strip():
-        raise NotImplementedError(
-            f'{g.Name}.{key} is set: stochastic surface corrections '
-            f'(optical_group.py:279-323) are not on the accelerated path yet (SURVEY 8f N3)')
+  # stochastic surfaces (optical_group.py:212-323): tables per (group, kind)
+  from ..freecad_elements import optical_group as _og
+  surface_samplers = []
+  for gi, g in enumerate(groups):
+    surface_samplers += _og.surfaceSamplers(g, gi, n_family=surfaceFamily or _og.DEFAULT_FAMILY)
   prims = []
   prim_group, prim_solid = [], []
   solid_id = 0
@@ -263,6 +262,7 @@ def bakeScene(doc, source=None):
       group_labels=[g._props.get('Label', g.Name) for g in groups],
       prim_sources=[p.source for p in prims],
       prim_to_world=[p.to_world for p in prims],
+      surface_samplers=surface_samplers,
   )
 
 

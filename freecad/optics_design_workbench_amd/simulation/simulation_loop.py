@@ -22,7 +22,7 @@ from . import results_store
 from .tracer import Tracer
 
 DEFAULT_SEED = 0x0D15EA5E
-_MODES = ('true', 'singletrue', 'fans', 'singlefans')
+_MODES = ('true', 'singletrue', 'pseudo', 'singlepseudo', 'fans', 'singlefans')
 
 
 def _limit(settings, key, default):
@@ -34,10 +34,15 @@ def _limit(settings, key, default):
 
 
 def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPath=None, store=None,
-                  raysPerLaunch=1 << 22, endIf=None, tracer=None, **traceKwargs):
+                  raysPerLaunch=1 << 22, endIf=None, tracer=None, pseudoIterationsPerLaunch=64,
+                  **traceKwargs):
   """trace `doc` until its simulation settings' end criteria are met.
 
   action       'true' (continuous Monte-Carlo) | 'singletrue' (one iteration)
+               | 'pseudo' / 'singlepseudo' (histogram-thinned draws of
+               VectorRandomVariable.drawPseudo, one call per iteration as in
+               point_source.py:670; the draws are the reference's serial host
+               algorithm, the rays are traced on the device)
                | 'fans' / 'singlefans' (ray fans, explicit initial conditions)
   resultsPath  `<doc>.OpticsDesign` folder to write the run folder into
                (None: keep results in memory only)
@@ -49,7 +54,11 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
   if action not in _MODES:
     raise ValueError(f'unexpected simulation mode {action!r}')
   settings = _bake.activeSimulationSettings(doc)
-  continuous = action == 'true'
+  continuous = action in ('true', 'pseudo')
+  pseudo = action in ('pseudo', 'singlepseudo')
+  if pseudo:
+    # the reference seeds numpy's global generator per worker (simulation_loop.py:813-820)
+    np.random.seed(int(seed) % (1 << 32))
   if store is None:
     store = results_store.SimulationResults(
         action, resultsPath=resultsPath,
@@ -84,10 +93,24 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
           d = np.array([r[1] for r in rays])
           tr.reserveHits(max(16, len(rays) * (lim.max_intersections + 1)))
           tr.reset()
+          tr.setSurfaceSeed(seed)
           tr.traceRays(o, d)
           tr.sync()
           n, iters = len(rays), 1
           meta = [r[2] for r in rays]
+        elif pseudo:
+          iters = 1 if not continuous else min(pseudoIterationsPerLaunch,
+                                               _iterations_for_launch(store, per_iter, raysPerLaunch))
+          vrv = point_source.getVrv(src)
+          ang = np.concatenate([vrv.drawPseudo(N=per_iter) for _ in range(iters)], axis=-1)
+          rays = [point_source.makeRay(bsrc, t, p) for t, p in ang.T]
+          n = len(rays)
+          tr.reserveHits(max(16, n * (lim.max_intersections + 1)))
+          tr.reset()
+          tr.setSurfaceSeed(seed)
+          tr.traceRays(np.array([r[0] for r in rays]), np.array([r[1] for r in rays]), first=first[src.Name])
+          tr.sync()
+          meta = None
         else:
           tr.setSource(bsrc)
           iters = 1 if not continuous else _iterations_for_launch(store, per_iter, raysPerLaunch)

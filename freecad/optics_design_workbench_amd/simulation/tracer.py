@@ -58,7 +58,13 @@ class Tracer:
   def setScene(self, scene):
     d, keep = _native.scene_desc(scene)
     self._chk(self._lib.odw_upload_scene(self._ctx, C.byref(d)), 'odw_upload_scene')
+    arr, n, keep = _native.surface_sampler_descs(getattr(scene, 'surface_samplers', None))
+    self._chk(self._lib.odw_upload_surface_samplers(self._ctx, arr, C.c_int32(n)), 'odw_upload_surface_samplers')
     self.scene = scene
+
+  def setSurfaceSeed(self, seed):
+    """Philox key of the stochastic-surface draws in traceRays launches"""
+    self._chk(self._lib.odw_set_surface_seed(self._ctx, C.c_uint64(int(seed))), 'odw_set_surface_seed')
 
   def setSource(self, source):
     d, keep = _native.source_desc(source)

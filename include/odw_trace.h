@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ODW_ABI_VERSION 1
+#define ODW_ABI_VERSION 2
 
 /* ---- return codes ------------------------------------------------------ */
 enum {
@@ -123,6 +123,39 @@ typedef struct odw_source_desc {
                            /* (random_number_generator.py:441)                */
 } odw_source_desc;
 
+/* Stochastic surface of a Mirror / Lens group =
+ * OpticalGroupProxy.applyStochasticRayCorrections (optical_group.py:279-323).
+ * The reference compiles a VectorRandomVariable over (theta, phi) per hit with
+ * the constants theta_in, phi_in = 0, theta_refl, phi_refl = 0
+ * (optical_group.py:212-269, 305-307); here the numeric-mode tables
+ * (random_number_generator.py:337-464) are tabulated ahead of the launch for
+ * a family of n_family equidistant values of ONE constant (family_axis); the
+ * member nearest to the hit's constant is sampled exactly like a source.
+ *   kind PRIMARY: Reflected- (mirror) / RefractedProbabilityDensity (lens):
+ *     out = Rot(normal, phi) * Rot(normal x dirIn, theta) * normal
+ *   kind MODIFY : RayModificationProbabilityDensity, applied afterwards:
+ *     out = Rot(out, phi) * Rot(out x dirIn, theta) * out
+ * (Rot(axis, angle) = FreeCAD Rotation; a zero axis is the identity.)
+ * Uniforms: Philox4x32-10, key = seed, counter = (ray_lo, ray_hi,
+ * intersection ordinal 1.., 1 + kind); words (0,1) -> u_phi, (2,3) -> u_theta. */
+enum { ODW_SURF_PRIMARY = 0, ODW_SURF_MODIFY = 1 };
+enum { ODW_SURF_AXIS_NONE = 0, ODW_SURF_AXIS_THETA_IN = 1, ODW_SURF_AXIS_THETA_REFL = 2 };
+typedef struct odw_surface_sampler_desc {
+  int32_t group;           /* index into the group tables (Mirror or Lens)    */
+  int32_t kind;            /* ODW_SURF_PRIMARY / ODW_SURF_MODIFY              */
+  int32_t family_axis;     /* ODW_SURF_AXIS_*; NONE: n_family must be 1       */
+  int32_t n_family;        /* member k is compiled for the constant value     */
+  double family_lo;        /*   family_lo + k (family_hi-family_lo)/(n_family-1) */
+  double family_hi;
+  int32_t n_phi_knots;
+  const double* phi_edges; /* [n_phi_knots]                                   */
+  const double* phi_cdf;   /* [n_family*n_phi_knots] each / its last entry    */
+  int32_t n_t_knots;
+  int32_t n_t_rows;        /* n_phi_knots-1, or 1 if the density is phi-free  */
+  const double* t_edges;   /* [n_t_knots]                                     */
+  const double* t_cdf;     /* [n_family*n_t_rows*n_t_knots]                   */
+} odw_surface_sampler_desc;
+
 /* Ray.traceRay keyword arguments + settings (ray.py:36-73, 283-288).        */
 typedef struct odw_limits {
   double max_ray_length;    /* MaxRayLengthScale * settings.MaxRayLength      */
@@ -187,6 +220,13 @@ const char* odw_last_error(const odw_ctx* ctx); /* NULL ctx: global message */
 int odw_upload_scene(odw_ctx* ctx, const odw_scene_desc* scene);
 /* replaces PointSourceProxy._getVrv/_rvArgs result, point_source.py:277-386 */
 int odw_upload_source(odw_ctx* ctx, const odw_source_desc* source);
+/* replaces OpticalGroupProxy._getVrv + per-hit compile, optical_group.py:212-323;
+ * call after odw_upload_scene (which clears them); n = 0 clears             */
+int odw_upload_surface_samplers(odw_ctx* ctx, const odw_surface_sampler_desc* samplers,
+                                int32_t n);
+/* Philox key of the surface draws in odw_trace_rays launches (odw_trace uses
+ * its own seed argument); default 0                                         */
+int odw_set_surface_seed(odw_ctx* ctx, uint64_t seed);
 int odw_set_limits(odw_ctx* ctx, const odw_limits* limits);
 int odw_set_detector(odw_ctx* ctx, const odw_detector_desc* det);
 /* capacity of the device hit list in rows (0 frees it)                     */

@@ -54,6 +54,13 @@ class DetectorDesc(C.Structure):
               ('y_lo', C.c_double), ('y_hi', C.c_double), ('nx', C.c_int32), ('ny', C.c_int32)]
 
 
+class SurfaceSamplerDesc(C.Structure):
+  _fields_ = [('group', C.c_int32), ('kind', C.c_int32), ('family_axis', C.c_int32), ('n_family', C.c_int32),
+              ('family_lo', C.c_double), ('family_hi', C.c_double), ('n_phi_knots', C.c_int32),
+              ('phi_edges', _pd), ('phi_cdf', _pd), ('n_t_knots', C.c_int32), ('n_t_rows', C.c_int32),
+              ('t_edges', _pd), ('t_cdf', _pd)]
+
+
 def build(force=False):
   if force or not os.path.exists(_LIB_PATH) or \
       os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, 'odw_oracle.c')):
@@ -151,6 +158,35 @@ def detector_desc(det):
   return d
 
 
+_surface_keep = None
+
+
+def set_surface_samplers(samplers, explicit_ray_seed=0):
+  """register the stochastic-surface tables (scene.surface_samplers) for the
+  following trace calls; None / [] clears"""
+  global _surface_keep
+  samplers = list(samplers or [])
+  arr = (SurfaceSamplerDesc * max(1, len(samplers)))()
+  keep = [arr]
+  for d, s in zip(arr, samplers):
+    phi_edges, phi_cdf = _arr(s.phi_edges, np.float64), _arr(s.phi_cdf, np.float64)
+    t_edges, t_cdf = _arr(s.t_edges, np.float64), _arr(s.t_cdf, np.float64)
+    keep += [phi_edges, phi_cdf, t_edges, t_cdf]
+    d.group, d.kind, d.family_axis, d.n_family = int(s.group), int(s.kind), int(s.axis), int(s.n_family)
+    d.family_lo, d.family_hi = float(s.lo), float(s.hi)
+    d.n_phi_knots, d.n_t_knots, d.n_t_rows = len(phi_edges), len(t_edges), int(t_cdf.shape[-2])
+    d.phi_edges, d.phi_cdf, d.t_edges, d.t_cdf = (_p(a, _pd) for a in (phi_edges, phi_cdf, t_edges, t_cdf))
+  _surface_keep = keep
+  lib().odw_oracle_set_surface_samplers(arr, C.c_int32(len(samplers)), C.c_uint64(int(explicit_ray_seed)))
+
+
+def scatter(group, ray, seed, ordinal, din, ideal, normal):
+  a, b, c = ((C.c_double * 3)(*v) for v in (din, ideal, normal))
+  out = (C.c_double * 3)()
+  lib().odw_oracle_scatter(C.c_int(group), C.c_uint64(ray), C.c_uint64(seed), C.c_uint32(ordinal), a, b, c, out)
+  return np.array(out[:])
+
+
 def philox(ctr, key):
   c = (C.c_uint32 * 4)(*ctr)
   k = (C.c_uint32 * 2)(*key)
@@ -205,6 +241,7 @@ def _result(hits, nh, hist, cnt, det):
 def trace(sc, src, lim, first, n, seed, det=None, flags=TRACE_RECORD_HITS | TRACE_HISTOGRAM,
           hit_capacity=None, nthreads=1):
   s, q, l, d = scene_desc(sc), source_desc(src), limits_desc(lim), detector_desc(det)
+  set_surface_samplers(getattr(sc, 'surface_samplers', None))
   cap = int(hit_capacity if hit_capacity is not None else max(16, 2 * n))
   hits = np.zeros(cap, dtype=HIT_DTYPE)
   nh = C.c_uint64(0)
@@ -221,8 +258,9 @@ def trace(sc, src, lim, first, n, seed, det=None, flags=TRACE_RECORD_HITS | TRAC
 
 
 def trace_rays(sc, lim, origins, dirs, powers=None, wavelength=500.0, first=0, det=None,
-               flags=TRACE_RECORD_HITS | TRACE_HISTOGRAM, nthreads=1):
+               flags=TRACE_RECORD_HITS | TRACE_HISTOGRAM, nthreads=1, surface_seed=0):
   s, l, d = scene_desc(sc), limits_desc(lim), detector_desc(det)
+  set_surface_samplers(getattr(sc, 'surface_samplers', None), surface_seed)
   origins = _arr(origins, np.float64).reshape(-1, 3)
   dirs = _arr(dirs, np.float64).reshape(-1, 3)
   n = len(origins)

@@ -559,6 +559,99 @@ static v3 line_grating(v3 ray, double n1, double n2, v3 normal, double wavelengt
 }
 
 /* ------------------------------------------------------------------ */
+/* OpticalGroupProxy.applyStochasticRayCorrections                     */
+/* (optical_group.py:279-323) with the per-hit VectorRandomVariable    */
+/* compile replaced by a family of pre-tabulated numeric-mode tables   */
+/* (include/odw_trace.h, odw_surface_sampler_desc).                    */
+/* ------------------------------------------------------------------ */
+static const odw_surface_sampler_desc* g_samplers = NULL;
+static int g_n_samplers = 0;
+static uint64_t g_surface_seed = 0;
+
+/* test-side registration: the descriptors (and their tables) must stay
+ * alive until the next call; n = 0 clears */
+int odw_oracle_set_surface_samplers(const odw_surface_sampler_desc* s, int32_t n, uint64_t explicit_ray_seed) {
+  g_samplers = n > 0 ? s : NULL;
+  g_n_samplers = n > 0 ? n : 0;
+  g_surface_seed = explicit_ray_seed;
+  return ODW_OK;
+}
+
+static const odw_surface_sampler_desc* find_sampler(int group, int kind) {
+  for (int i = 0; i < g_n_samplers; ++i)
+    if (g_samplers[i].group == group && g_samplers[i].kind == kind) return &g_samplers[i];
+  return NULL;
+}
+
+/* FreeCAD Rotation(axis, angle) * v (Base::Rotation::setValue normalises the
+ * axis, a zero axis leaves the vector unchanged) */
+static v3 rotate(v3 axis, double angle, v3 v) {
+  double l2 = dot(axis, axis);
+  if (l2 == 0) return v;
+  v3 k = mul(axis, 1.0 / sqrt(l2));
+  double s = sin(angle), c = cos(angle);
+  return add(add(mul(v, c), mul(cross(k, v), s)), mul(k, dot(k, v) * (1.0 - c)));
+}
+
+static double acos_clamped(double x) { return acos(fmax(-1.0, fmin(1.0, x))); }
+
+static void surface_draw(const odw_surface_sampler_desc* S, double theta_in, double theta_refl,
+                         uint64_t ray, uint64_t seed, uint32_t ordinal, uint32_t stream,
+                         double* theta, double* phi) {
+  int k = 0;
+  if (S->family_axis != ODW_SURF_AXIS_NONE) {
+    double c = S->family_axis == ODW_SURF_AXIS_THETA_IN ? theta_in : theta_refl;
+    double inv_step = (double)(S->n_family - 1) / (S->family_hi - S->family_lo);
+    k = (int)rint((c - S->family_lo) * inv_step);
+    if (k < 0) k = 0;
+    if (k > S->n_family - 1) k = S->n_family - 1;
+  }
+  odw_source_desc t;
+  memset(&t, 0, sizeof t);
+  t.n_phi_knots = S->n_phi_knots;
+  t.phi_edges = S->phi_edges;
+  t.phi_cdf = S->phi_cdf + (size_t)k * (size_t)S->n_phi_knots;
+  t.n_t_knots = S->n_t_knots;
+  t.n_t_rows = S->n_t_rows;
+  t.t_edges = S->t_edges;
+  t.t_cdf = S->t_cdf + (size_t)k * (size_t)S->n_t_rows * (size_t)S->n_t_knots;
+  uint32_t ctr[4] = {(uint32_t)ray, (uint32_t)(ray >> 32), ordinal, stream};
+  uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  uint32_t w[4];
+  odw_oracle_philox(ctr, key, w);
+  sample_one(&t, u53(w[0], w[1]), u53(w[2], w[3]), theta, phi);
+}
+
+static v3 scatter(int group, uint64_t ray, uint64_t seed, uint32_t ordinal, v3 din, v3 ideal, v3 n) {
+  const odw_surface_sampler_desc* prim = find_sampler(group, ODW_SURF_PRIMARY);
+  const odw_surface_sampler_desc* modi = find_sampler(group, ODW_SURF_MODIFY);
+  if (!prim && !modi) return ideal;
+  double nl = len(n);
+  double theta_in = acos_clamped(dot(din, n) / nl);
+  double theta_refl = acos_clamped(dot(ideal, n) / (len(ideal) * nl));
+  v3 out = ideal;
+  double theta, phi;
+  if (prim) {
+    surface_draw(prim, theta_in, theta_refl, ray, seed, ordinal, 1u + ODW_SURF_PRIMARY, &theta, &phi);
+    out = rotate(n, phi, rotate(cross(n, din), theta, n));
+  }
+  if (modi) {
+    surface_draw(modi, theta_in, theta_refl, ray, seed, ordinal, 1u + ODW_SURF_MODIFY, &theta, &phi);
+    out = rotate(out, phi, rotate(cross(out, din), theta, out));
+  }
+  return mul(out, 1.0 / len(out));
+}
+
+/* one applyStochasticRayCorrections call with explicit vectors (unit tests) */
+int odw_oracle_scatter(int group, uint64_t ray, uint64_t seed, uint32_t ordinal, const double* din,
+                       const double* ideal, const double* normal, double* out) {
+  v3 r = scatter(group, ray, seed, ordinal, V(din[0], din[1], din[2]), V(ideal[0], ideal[1], ideal[2]),
+                 V(normal[0], normal[1], normal[2]));
+  out[0] = r.x; out[1] = r.y; out[2] = r.z;
+  return ODW_OK;
+}
+
+/* ------------------------------------------------------------------ */
 /* Ray.traceRay (ray.py:36-281)                                        */
 /* ------------------------------------------------------------------ */
 typedef struct {
@@ -597,7 +690,7 @@ static void record_hit(sink* sk, const odw_detector_desc* det, uint32_t flags,
 
 static void trace_one(const odw_scene_desc* sc, const odw_limits* lim,
                       const odw_detector_desc* det, double wavelength, uint32_t flags,
-                      uint64_t ray, v3 point, v3 dir, double power, sink* sk) {
+                      uint64_t ray, uint64_t seed, v3 point, v3 dir, double power, sink* sk) {
   int seq = 0, nint = 0, medium = -1;
   for (;;) {
     if (nint >= lim->max_intersections) { sk->cnt[ODW_CNT_CAPPED]++; break; }
@@ -626,7 +719,8 @@ static void trace_one(const odw_scene_desc* sc, const odw_limits* lim,
 
     int type = sc->group_type[g];
     if (type == ODW_OPT_MIRROR) {
-      dir = mirror(dir, n);
+      v3 din = mul(dir, 1.0 / len(dir));
+      dir = scatter(g, ray, seed, (uint32_t)nint, din, mirror(dir, n), n);
       power *= sc->group_refl[g];
       seq++;
     } else if (type == ODW_OPT_LENS) {
@@ -640,7 +734,8 @@ static void trace_one(const odw_scene_desc* sc, const odw_limits* lim,
         n2 = 1.0;
       }
       int tir;
-      dir = snells_law(mul(dir, 1.0 / len(dir)), n1, n2, n, &tir);
+      v3 din = mul(dir, 1.0 / len(dir));
+      dir = scatter(g, ray, seed, (uint32_t)nint, din, snells_law(din, n1, n2, n, &tir), n);
       if (!entering && !tir && medium == g) { medium = -1; seq++; }
     } else if (type == ODW_OPT_GRATING) {
       v3 gd = V(sc->group_grating_dir[3 * g], sc->group_grating_dir[3 * g + 1],
@@ -735,7 +830,8 @@ static int run(const odw_scene_desc* sc, const odw_source_desc* src, const odw_l
           make_ray(src, t, phi, &o, &d);
           pw = src->power;
         }
-        trace_one(sc, lim, det, src ? src->wavelength : 500.0, flags, first + i, o, d, pw, &sk);
+        trace_one(sc, lim, det, src ? src->wavelength : 500.0, flags, first + i,
+                  origins ? g_surface_seed : seed, o, d, pw, &sk);
       }
       chunk_hits[ci] = sk.hits;
       chunk_n[ci] = sk.n;

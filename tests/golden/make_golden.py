@@ -290,9 +290,82 @@ def make_fan_rays(io, rng, pbd):
   np.savez_compressed(os.path.join(OUT, 'fan_rays.npz'), **out)
 
 
+# stochastic surfaces: OpticalGroupProxy._getVrv (optical_group.py:212-269)
+# builds VectorRandomVariable('('+density+')', variableOrder=('theta','phi'),
+# variableDomains=...) with default resolutions and compiles it per hit with
+# the constants theta_in, phi_in, theta_refl, phi_refl (:305)
+SURFACE_CASES = [
+  # test/50-old-tests/mirror-diffuse.FCStd
+  ('lambert_mirror', 'cos(theta)**2 * abs(sin(theta))', (-np.pi, -np.pi / 2), (-np.pi, np.pi), [0.3]),
+  ('lobe_theta_in', 'exp(-(theta-theta_in)**2/0.05)*(1+0.5*cos(phi-phi_in))', (0, np.pi / 2), (0, 2 * np.pi),
+   [0.0, 40 * (np.pi / 2) / 128, np.pi / 2]),
+  ('glossy_refl', 'exp(-(theta-theta_refl)**2/0.02)*abs(sin(theta))', (np.pi / 2, np.pi), (-np.pi, np.pi),
+   [16 * (np.pi / 2) / 128, 100 * (np.pi / 2) / 128]),
+]
+
+
+def make_surface(rng):
+  N = 2048
+  out = {}
+  for name, dens, tdom, pdom, theta_ins in SURFACE_CASES:
+    vrv = rng.VectorRandomVariable(probabilityDensity='(' + dens + ')', variableOrder=('theta', 'phi'),
+                                   variableDomains=dict(theta=tdom, phi=pdom))
+    out[name + '_density'] = np.array(dens)
+    out[name + '_theta_domain'] = np.array(tdom)
+    out[name + '_phi_domain'] = np.array(pdom)
+    out[name + '_theta_in'] = np.array(theta_ins)
+    for j, c in enumerate(theta_ins):
+      vrv.compile(disableAnalytical=True, theta_in=c, phi_in=0, theta_refl=np.pi - c, phi_refl=0)
+      assert vrv.mode() == 'numeric'
+      np.random.seed(11 + j)
+      th, ph = vrv.draw(N=N)
+      np.random.seed(11 + j)
+      u_phi = np.random.random_sample(N)
+      _ = np.random.random_sample(N)
+      u_th = np.random.random_sample(N)
+      out[f'{name}_{j}_theta'] = np.asarray(th, dtype=np.float64)
+      out[f'{name}_{j}_phi'] = np.asarray(ph, dtype=np.float64)
+      out[f'{name}_{j}_u_phi'] = u_phi
+      out[f'{name}_{j}_u_theta'] = u_th
+      kw_p = vrv._transformLambdas[1][0][0].__kwdefaults__
+      gp_p = np.array(kw_p['gridProbs'], dtype=np.float64)
+      out[f'{name}_{j}_phi_cdf'] = gp_p / gp_p[-1]
+    print('surface', name, 'mean theta', float(np.mean(out[f'{name}_0_theta'])))
+  np.savez_compressed(os.path.join(OUT, 'surface_samplers.npz'), **out)
+
+
+# VectorRandomVariable.drawPseudo (random_number_generator.py:562-682) as the
+# sources call it (point_source.py:670): N = RaysPerIteration
+PSEUDO_CASES = [
+  ('c3', '(exp(-theta**2/(1e-2)**2))*abs(sin(theta))', (0, np.pi / 4), (0, 2 * np.pi), 1e5, 1e2, 100),
+  ('wide', '(exp(-theta**2/0.3**2)*(1.5+cos(2*phi)))*abs(sin(theta))', (0, 1.0), (0, 2 * np.pi), 2001, 41, 400),
+]
+
+
+def make_pseudo(rng):
+  out = {}
+  for name, dens, tdom, pdom, tres, pres, N in PSEUDO_CASES:
+    vrv = rng.VectorRandomVariable(
+        probabilityDensity=dens, variableOrder=('theta', 'phi'),
+        variableDomains=dict(theta=tdom, phi=pdom),
+        numericalResolutions=dict(theta=tres, phi=pres))
+    vrv.compile(disableAnalytical=True)
+    for seed in (3, 4):
+      np.random.seed(seed)
+      draws = np.asarray(vrv.drawPseudo(N=N), dtype=np.float64)
+      out[f'{name}_seed{seed}'] = draws
+      out[f'{name}_seed{seed}_next'] = np.random.random_sample(4)   # RNG state after the call
+    out[name + '_args'] = np.array(json.dumps(dict(density=dens, theta_domain=tdom, phi_domain=pdom,
+                                                   theta_res=tres, phi_res=pres, N=N)))
+    print('pseudo', name, out[f'{name}_seed3'].shape, out[f'{name}_seed3'][:, :3])
+  np.savez_compressed(os.path.join(OUT, 'pseudo_draws.npz'), **out)
+
+
 if __name__ == '__main__':
   io, pbd, rng, hist, hits = load_reference_modules()
   make_sampler(rng)
   make_fan_grid(rng)
   make_hist(hits)
   make_fan_rays(io, rng, pbd)
+  make_surface(rng)
+  make_pseudo(rng)

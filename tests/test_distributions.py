@@ -73,3 +73,26 @@ def test_point_source_rv_args():
   assert a2['variableOrder'] == ('r', 'phi')
   with pytest.raises(ValueError):
     point_source.rvArgs(proj.sourceObject, 'exp(-r**2)')   # r forbidden at f=0
+
+
+@pytest.mark.parametrize('name', ['c3', 'wide'])
+def test_draw_pseudo_matches_reference(name):
+  """pseudo-random mode (random_number_generator.py:562-682): same samples and
+  same RNG consumption as the reference's drawPseudo from the same numpy seed"""
+  import json
+  from freecad.optics_design_workbench_amd.distributions import VectorRandomVariable
+  g = np.load(os.path.join(GOLDEN, 'pseudo_draws.npz'))
+  a = json.loads(str(g[name + '_args']))
+  vrv = VectorRandomVariable(a['density'], variableOrder=('theta', 'phi'),
+                             variableDomains=dict(theta=tuple(a['theta_domain']), phi=tuple(a['phi_domain'])),
+                             numericalResolutions=dict(theta=a['theta_res'], phi=a['phi_res']))
+  for seed in (3, 4):
+    np.random.seed(seed)
+    d = vrv.drawPseudo(N=a['N'])
+    assert d.shape == (2, a['N'])
+    assert np.array_equal(d, g[f'{name}_seed{seed}'])
+    assert np.array_equal(np.random.random_sample(4), g[f'{name}_seed{seed}_next'])
+  with pytest.raises(ValueError):
+    vrv.drawPseudo(N=1)
+  with pytest.raises(ValueError):
+    vrv.drawPseudo(N=10, overdrawFactor=0)

@@ -218,3 +218,84 @@ def test_limits_and_sequence(tracer, oracle):
   g, gc, r, rc = run_both(tracer, oracle, sc2, lim, o, d)
   assert rc['segments'] <= 4 * len(o)
   assert_same(g, gc, r, rc)
+
+
+def test_stochastic_surfaces(tracer, oracle):
+  """applyStochasticRayCorrections on the device (optical_group.py:279-323):
+  a diffuse mirror (family over theta_in + azimuth dependence), a glossy lens
+  with a ray modification, an ideal mirror in the same scene; every draw is
+  keyed by (ray, intersection ordinal), so whole trajectories must agree"""
+  sc, lim = build([
+      ('Mirror', lambda d: [make.makeBox(d, 'M1', 30, 30, 1, base=(-15, -15, 20))],
+       dict(ReflectedProbabilityDensity='cos(theta)**2*abs(sin(theta))*(1+0.5*cos(phi))*exp(-theta_in)',
+            PowerThetaDomain='-pi, -pi/2', PowerPhiDomain='-pi, pi',
+            RayModificationProbabilityDensity='exp(-theta**2/0.01)', ModifyThetaDomain='0, 0.3',
+            ModifyPhiDomain='0, 2*pi')),
+      ('Lens', lambda d: [make.makeSphere(d, 'L1', 6, base=(0, 0, -15))],
+       dict(RefractiveIndex=1.5, RefractedProbabilityDensity='exp(-(theta-theta_refl)**2/0.002)',
+            PowerThetaDomain='0, pi', PowerPhiDomain='-0.2, 0.2')),
+      ('Mirror', lambda d: [make.makeBox(d, 'M2', 30, 1, 30, base=(-15, 25, -15))],
+       dict(name='OpticalMirrorGroup2')),
+      ('Absorber', lambda d: [make.makeBox(d, 'Wall', 400, 400, 1, base=(-200, -200, -60))], {}),
+  ], settings=dict(MaxIntersections=12))
+  assert [(s.group, s.kind, s.axis) for s in sc.surface_samplers] == [(0, 0, 1), (0, 1, 0), (1, 0, 2)]
+  o, d = aimed_rays(20000, [[0, 0, 20], [0, 0, -15], [0, 25, 0]], 3.0, 11, radius=45.0)
+  tracer.setSurfaceSeed(4242)
+  tracer.setScene(sc)
+  tracer.setLimits(lim)
+  tracer.setDetector(None)
+  tracer.reserveHits(len(o) * (lim.max_intersections + 1))
+  tracer.reset()
+  tracer.traceRays(o, d)
+  tracer.sync()
+  g, gc = tracer.hits(), tracer.counters()
+  ref = oracle.trace_rays(sc, lim, o, d, surface_seed=4242, nthreads=8)
+  r, rc = ref['hits'], ref['counters']
+  assert rc['recorded_hits'] > 30000
+  # the scattered directions differ from the ideal ones: a seed change moves the hits
+  other = oracle.trace_rays(sc, lim, o[:2000], d[:2000], surface_seed=1, nthreads=8)['hits']
+  assert not np.array_equal(other['tag'], r['tag'][:len(other)]) or \
+      np.abs(other['point'] - r['point'][:len(other)]).max() > 1e-3
+  assert_same_short_paths(g, gc, r, rc, len(o), max_len=12)
+  tracer.setSurfaceSeed(0)
+
+
+def test_stochastic_mirror_seeded_launch(tracer, oracle):
+  """odw_trace (in-kernel generation) with a diffuse mirror: surface draws are
+  keyed by the launch seed; counters, tags and histogram bins identical"""
+  from freecad.optics_design_workbench_amd.freecad_elements import point_source
+  doc = Document()
+  make.makeMirror(doc, [make.makeBox(doc, length=20, width=20, height=1, base=(-10, -10, 10))],
+                  ReflectedProbabilityDensity='cos(theta)**2 * abs(sin(theta))', PowerThetaDomain='-pi, -pi/2',
+                  PowerPhiDomain='-pi, pi')
+  make.makeAbsorber(doc, [make.makeBox(doc, length=400, width=400, height=1, base=(-200, -200, -50))])
+  make.makeSimulationSettings(doc, MaxRayLength=1e4)
+  src = make.makePointSource(doc, PowerDensity='exp(-theta**2/1e-2)')
+  sc, lim, bs = bake.bakeScene(doc, src), bake.bakeLimits(doc, src), point_source.bakeSource(doc, src)
+  det = dict(group=1, origin=[0, 0, -49], ex=[1, 0, 0], ey=[0, 1, 0], x_lo=-200, x_hi=200, y_lo=-200, y_hi=200,
+             nx=64, ny=64)
+  n = 200000
+  tracer.setScene(sc); tracer.setSource(bs); tracer.setLimits(lim); tracer.setDetector(det)
+  tracer.reserveHits(n)
+  tracer.reset()
+  tracer.trace(5000, n, 77)
+  tracer.sync()
+  g, gc, gh = tracer.hits(), tracer.counters(), tracer.histogram()
+  ref = oracle.trace(sc, bs, lim, 5000, n, 77, det=det, nthreads=8)
+  assert gc == ref['counters']
+  assert np.array_equal(g['tag'], ref['hits']['tag'])
+  assert np.array_equal(gh, ref['hist'])
+  assert np.abs(g['point'] - ref['hits']['point']).max() < 1e-7
+  assert np.abs(g['direction'] - ref['hits']['direction']).max() < 1e-9
+  # most of the diffusely reflected light lands on the big catcher
+  assert gc['recorded_hits'] > 0.5 * n
+  # re-uploading a scene without stochastic groups switches the samplers off again
+  sc2 = bake.bakeScene(doc, src)
+  sc2.surface_samplers = []
+  tracer.setScene(sc2)
+  tracer.reset()
+  tracer.trace(5000, 1000, 77)
+  tracer.sync()
+  ref2 = oracle.trace(sc2, bs, lim, 5000, 1000, 77, det=det)
+  assert tracer.counters() == ref2['counters']
+  tracer.setDetector(None)

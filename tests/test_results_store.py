@@ -97,6 +97,12 @@ def test_run_simulation_end_criteria_on_device(native_lib, tmp_path):
   store = runSimulation(doc, 'fans')
   h = store.hits().hits
   assert store.totalTracedRays == 40 and {'fanIndex', 'rayIndex', 'totalRaysInFan'} <= set(h)
+  # pseudo-random modes: histogram-thinned host draws traced on the device
+  store = runSimulation(doc, 'singlepseudo')
+  assert store.totalTracedRays == 100 and store.totalIterations == 1 and len(store.hits()) > 90
+  st.EndAfterRays = '1e3'
+  store = runSimulation(doc, 'pseudo', pseudoIterationsPerLaunch=4)
+  assert 1000 < store.totalTracedRays <= 1400 and len(store.hits()) > 900
 
 
 def test_freecad_document_property_api(tmp_path):

@@ -1,0 +1,231 @@
+"""Stochastic surfaces: OpticalGroupProxy.applyStochasticRayCorrections
+(optical_group.py:279-323).
+
+Pins:
+  * the tables of every family member equal the reference's numeric-mode
+    compile with that member's constants: same draws, bit for bit, from the
+    same uniforms (golden: tests/golden/surface_samplers.npz, produced by the
+    reference's VectorRandomVariable);
+  * the oracle's scatter = those tables + FreeCAD's Rotation algebra
+    (restated here with numpy quaternions, independent of the oracle's
+    Rodrigues form);
+  * physics: a Lambert-like mirror (test/50-old-tests/mirror-diffuse.FCStd's
+    density) scatters into the density's own angular distribution.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from freecad.optics_design_workbench_amd.freecad_elements import make, optical_group
+from freecad.optics_design_workbench_amd.scene import Document, bake
+
+
+@pytest.fixture(scope='module')
+def golden():
+  return np.load(os.path.join(GOLDEN, 'surface_samplers.npz'))
+
+
+def _group(kind, **props):
+  doc = Document()
+  g = make.makeOpticalGroup(doc, kind, [make.makeBox(doc)], **props)
+  return g
+
+
+def _dom(d):
+  return f'{float(d[0])!r}, {float(d[1])!r}'
+
+
+CASES = ['lambert_mirror', 'lobe_theta_in', 'glossy_refl']
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_family_tables_match_reference(golden, name):
+  g = _group('Mirror', ReflectedProbabilityDensity=str(golden[name + '_density']),
+             PowerThetaDomain=_dom(golden[name + '_theta_domain']),
+             PowerPhiDomain=_dom(golden[name + '_phi_domain']))
+  (s,) = optical_group.surfaceSamplers(g, 0)
+  assert s.kind == optical_group.PRIMARY
+  if name == 'lambert_mirror':
+    assert s.axis == optical_group.AXIS_NONE and s.n_family == 1
+  else:
+    assert s.n_family == optical_group.DEFAULT_FAMILY
+  from freecad.optics_design_workbench_amd.distributions import SamplerTables
+  for j, c in enumerate(golden[name + '_theta_in']):
+    # glossy_refl depends on theta_refl only: the reference compiled it with
+    # theta_refl = pi - theta_in, the family axis is theta_refl itself
+    const = np.pi - c if s.axis == optical_group.AXIS_THETA_REFL else c
+    k = s.member(const)
+    if s.axis != optical_group.AXIS_NONE:
+      assert abs(s.constant(k) - const) < 1e-12      # golden constants sit on family knots
+    t = SamplerTables(s.t_edges, s.t_cdf[k], s.phi_edges, s.phi_cdf[k])
+    assert np.array_equal(t.phi_cdf, golden[f'{name}_{j}_phi_cdf'])
+    th, ph = t.draw(golden[f'{name}_{j}_u_phi'], golden[f'{name}_{j}_u_theta'])
+    assert np.array_equal(ph, golden[f'{name}_{j}_phi'])
+    assert np.array_equal(th, golden[f'{name}_{j}_theta'])
+
+
+def test_dirac_modification_is_identity_and_others_are_rejected():
+  g = _group('Lens', RayModificationProbabilityDensity='DiracDelta(theta)')
+  assert optical_group.surfaceSamplers(g, 0) == []
+  g = _group('Mirror', RayModificationProbabilityDensity='DiracDelta(theta)*DiracDelta(phi)')
+  assert optical_group.surfaceSamplers(g, 0) == []
+  # absorbers never scatter (ray.py:270-272), whatever the property holds
+  g = _group('Absorber', RayModificationProbabilityDensity='DiracDelta(theta-1)')
+  assert optical_group.surfaceSamplers(g, 0) == []
+  with pytest.raises(NotImplementedError):
+    optical_group.surfaceSamplers(_group('Mirror', ReflectedProbabilityDensity='DiracDelta(theta-theta_refl)'), 0)
+  with pytest.raises(ValueError):     # modification draws have no constants (optical_group.py:317)
+    optical_group.surfaceSamplers(_group('Mirror', RayModificationProbabilityDensity='exp(-(theta-theta_in)**2)'), 0)
+  with pytest.raises(ValueError):
+    optical_group.surfaceSamplers(_group('Mirror', ReflectedProbabilityDensity='exp(-theta**2)*foo'), 0)
+
+
+# --- FreeCAD's Rotation algebra, restated with quaternions ------------------
+def _quat(axis, angle):
+  """Base::Rotation::setValue(axis, angle): q = (n sin(a/2), cos(a/2)), the
+  axis normalised unless its length is zero"""
+  a = np.asarray(axis, float)
+  l = np.linalg.norm(a)
+  if l != 0:
+    a = a / l
+  return np.concatenate([a * np.sin(angle / 2), [np.cos(angle / 2)]])
+
+
+def _qmul(a, b):
+  """Base::Rotation::multRight; setValue(q0..q3) normalises the product"""
+  x1, y1, z1, w1 = a
+  x2, y2, z2, w2 = b
+  q = np.array([w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2, w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2,
+                w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2, w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2])
+  return q / np.linalg.norm(q)
+
+
+def _qrot(q, v):
+  """Base::Rotation::multVec"""
+  x, y, z, w = q
+  x2, y2, z2 = x * x, y * y, z * z
+  xy, xz, yz, xw, yw, zw = x * y, x * z, y * z, x * w, y * w, z * w
+  return np.array([(1 - 2 * (y2 + z2)) * v[0] + 2 * (xy - zw) * v[1] + 2 * (xz + yw) * v[2],
+                   2 * (xy + zw) * v[0] + (1 - 2 * (x2 + z2)) * v[1] + 2 * (yz - xw) * v[2],
+                   2 * (xz - yw) * v[0] + 2 * (yz + xw) * v[1] + (1 - 2 * (x2 + y2)) * v[2]])
+
+
+def _u53(a, b):
+  return ((a >> 5) * 67108864.0 + (b >> 6)) / 9007199254740992.0
+
+
+def _reference_scatter(oracle, samplers, ray, seed, ordinal, din, ideal, n):
+  """applyStochasticRayCorrections with the tables in place of the per-hit compile"""
+  from freecad.optics_design_workbench_amd.distributions import SamplerTables
+  nn = n / np.linalg.norm(n)
+  theta_in = np.arccos(np.clip(din @ nn, -1, 1))
+  theta_refl = np.arccos(np.clip(ideal / np.linalg.norm(ideal) @ nn, -1, 1))
+  out = ideal
+  for s in sorted(samplers, key=lambda s: s.kind):
+    c = theta_in if s.axis == optical_group.AXIS_THETA_IN else theta_refl
+    k = s.member(c)
+    w = oracle.philox([ray & 0xFFFFFFFF, ray >> 32, ordinal, 1 + s.kind], [seed & 0xFFFFFFFF, seed >> 32])
+    t = SamplerTables(s.t_edges, s.t_cdf[k], s.phi_edges, s.phi_cdf[k])
+    th, ph = t.draw(np.array([_u53(w[0], w[1])]), np.array([_u53(w[2], w[3])]))
+    base = n if s.kind == optical_group.PRIMARY else out
+    q = _qmul(_quat(base, ph[0]), _quat(np.cross(base, din), th[0]))
+    out = _qrot(q, base)
+  return out / np.linalg.norm(out)
+
+
+def test_oracle_scatter_follows_freecad_rotations(oracle):
+  g = _group('Mirror', ReflectedProbabilityDensity='exp(-(theta-theta_refl)**2/0.02)*(2+cos(phi))',
+             PowerThetaDomain='pi/2, pi', PowerPhiDomain='-pi, pi',
+             RayModificationProbabilityDensity='exp(-theta**2/0.01)', ModifyThetaDomain='0, 0.5',
+             ModifyPhiDomain='0, 2*pi')
+  samplers = optical_group.surfaceSamplers(g, 3, n_family=33)
+  assert [s.kind for s in samplers] == [0, 1] and samplers[0].axis == optical_group.AXIS_THETA_REFL
+  oracle.set_surface_samplers(samplers)
+  rs = np.random.RandomState(5)
+  worst = 0
+  for i in range(300):
+    n = rs.normal(size=3); n /= np.linalg.norm(n)
+    din = rs.normal(size=3); din /= np.linalg.norm(din)
+    if din @ n < 0:
+      n = -n                                     # getNormal: along the travel direction
+    if i == 7:
+      din = n.copy()                             # normal incidence: zero rotation axis = identity
+    ideal = din - 2 * n * (din @ n)
+    got = oracle.scatter(3, 1000 + i, 0xABCDEF0123, 1 + i % 5, din, ideal, n)
+    want = _reference_scatter(oracle, samplers, 1000 + i, 0xABCDEF0123, 1 + i % 5, din, ideal, n)
+    worst = max(worst, np.abs(got - want).max())
+    # a group without samplers keeps the ideal direction untouched
+    assert np.array_equal(oracle.scatter(2, 1000 + i, 1, 1, din, ideal, n), ideal)
+  oracle.set_surface_samplers(None)
+  assert worst < 1e-12
+
+
+def _diffuse_scene(density, theta_dom, phi_dom, **mirror_props):
+  doc = Document()
+  make.makeMirror(doc, [make.makeBox(doc, length=20, width=20, height=1, base=(-10, -10, 10))],
+                  ReflectedProbabilityDensity=density, PowerThetaDomain=theta_dom, PowerPhiDomain=phi_dom,
+                  **mirror_props)
+  # catcher below the source: every back-scattered ray ends here
+  make.makeAbsorber(doc, [make.makeBox(doc, length=4000, width=4000, height=1, base=(-2000, -2000, -50))])
+  make.makeSimulationSettings(doc, MaxRayLength=1e5)
+  src = make.makePointSource(doc, PowerDensity='exp(-theta**2/1e-4)')
+  return doc, src, bake.bakeScene(doc, src), bake.bakeLimits(doc, src)
+
+
+def test_lambert_mirror_distribution(oracle):
+  """mirror-diffuse.FCStd's density cos(theta)^2 |sin(theta)| on [-pi, -pi/2]:
+  the polar angle of the scattered rays (from the inward normal) follows it"""
+  from freecad.optics_design_workbench_amd.freecad_elements import point_source
+  doc, src, sc, lim = _diffuse_scene('cos(theta)**2 * abs(sin(theta))', '-pi, -pi/2', '-pi, pi')
+  assert len(sc.surface_samplers) == 1
+  res = oracle.trace(sc, point_source.bakeSource(doc, src), lim, 0, 40000, 99, nthreads=4)
+  h = res['hits']
+  assert res['counters']['traced_rays'] == 40000 and len(h) > 39000
+  d = h['direction']
+  assert np.abs(np.linalg.norm(d, axis=1) - 1).max() < 1e-12
+  # normal along travel at the mirror = +z; theta in [-pi, -pi/2] -> angle from +z in [pi/2, pi]
+  ang = np.arccos(np.clip(d[:, 2], -1, 1))
+  assert ang.min() >= np.pi / 2 - 1e-9
+  x = np.linspace(np.pi / 2, np.pi, 2001)
+  pdf = np.cos(x)**2 * np.abs(np.sin(x))
+  cdf = np.concatenate([[0], np.cumsum((pdf[1:] + pdf[:-1]) / 2)]); cdf /= cdf[-1]
+  ks = np.abs(np.searchsorted(np.sort(ang), x) / len(ang) - cdf).max()
+  assert ks < 1.95 / np.sqrt(len(ang))           # Kolmogorov-Smirnov, alpha = 0.1 %
+  az = np.arctan2(d[:, 1], d[:, 0])
+  hist, _ = np.histogram(az, bins=16, range=(-np.pi, np.pi))
+  assert np.abs(hist - len(az) / 16).max() < 5 * np.sqrt(len(az) / 16)
+
+
+def test_specular_lobe_follows_incidence(oracle):
+  """a narrow lobe around theta_refl (family over theta_refl): scattered rays
+  stay within the lobe of the specular direction, for oblique incidence too"""
+  doc = Document()
+  make.makeMirror(doc, [make.makeBox(doc, length=40, width=40, height=1, base=(-20, -20, 10))],
+                  ReflectedProbabilityDensity='exp(-(theta-theta_refl)**2/1e-4)', PowerThetaDomain='pi/2, pi',
+                  PowerPhiDomain='-1e-9, 1e-9')
+  make.makeSimulationSettings(doc, MaxRayLength=1e5)
+  src = make.makePointSource(doc)
+  sc = bake.bakeScene(doc, src, surfaceFamily=257)
+  sc.group_record = np.ones_like(sc.group_record)
+  lim = bake.bakeLimits(doc, src, maxIntersections=1)
+  n = 2000
+  rs = np.random.RandomState(3)
+  inc = rs.uniform(0.05, 1.2, n)                  # incidence angles
+  o = np.stack([-10 * np.tan(inc), np.zeros(n), np.zeros(n)], axis=1)
+  d = np.stack([np.sin(inc), np.zeros(n), np.cos(inc)], axis=1)
+  # second pass from the scattered state: trace the scattered rays' directions via a second bounce-free scene
+  res = oracle.trace_rays(sc, lim, o, d, surface_seed=17)
+  assert len(res['hits']) == n
+  # hit rows hold the incoming direction; the scattered one is observed by scattering explicitly
+  oracle.set_surface_samplers(sc.surface_samplers)
+  worst = 0
+  for i in range(0, n, 20):
+    nrm = np.array([0.0, 0.0, 1.0])
+    ideal = d[i] - 2 * nrm * (d[i] @ nrm)
+    out = oracle.scatter(0, i, 17, 1, d[i], ideal, nrm)
+    worst = max(worst, np.arccos(np.clip(out @ ideal, -1, 1)))
+  oracle.set_surface_samplers(None)
+  # lobe sigma 0.007 rad + nearest-member error <= pi/256/2
+  assert worst < 5 * 0.00707 + np.pi / 512 + 1e-3
