@@ -361,6 +361,66 @@ def make_pseudo(rng):
   np.savez_compressed(os.path.join(OUT, 'pseudo_draws.npz'), **out)
 
 
+def fan_math_inputs():
+  """synthetic fan-mode hit sets on the plane z = 30: two fans x 21 rays on
+  gently bent lines, with duplicates (two hits of one ray), missing rays and,
+  in case 'caustic', a fold where the ray order reverses"""
+  cases = {}
+  rs = np.random.RandomState(21)
+  for name in ('regular', 'caustic', 'nozero'):
+    pts, ray, fan, tot = [], [], [], []
+    for f, ang in enumerate((0.2, 1.9)):
+      for i in range(-10, 11):
+        if name == 'nozero' and i == 0:
+          continue
+        if (f, i) in ((0, 7), (1, -3), (1, -2)):
+          continue                       # rays that missed the detector
+        s = i * 0.8 + 0.01 * i**2
+        if name == 'caustic' and i > 5:
+          s = 5 * 0.8 + 0.25 - (i - 5) * 0.3   # fold back
+        bend = 0.02 * s**2
+        x = s * np.cos(ang) - bend * np.sin(ang) + 1.5
+        y = s * np.sin(ang) + bend * np.cos(ang) - 0.7
+        for rep in range(2 if (f, i) == (0, 3) else 1):
+          pts.append([x + 1e-3 * rep, y, 30.0]); ray.append(i); fan.append(f); tot.append(21)
+    n = len(pts)
+    dirs = np.tile([0.0, 0.0, 1.0], (n, 1)) + rs.normal(0, 1e-3, (n, 3))
+    cases[name] = dict(points=np.array(pts), directions=dirs, powers=np.ones(n),
+                       isEntering=np.ones(n, dtype=int), rayIndex=np.array(ray), fanIndex=np.array(fan),
+                       totalRaysInFan=np.array(tot), totalFanCount=np.full(n, 2))
+  return cases
+
+
+def make_fan_math(hits_mod):
+  import warnings
+  out = {}
+  for name, d in fan_math_inputs().items():
+    h = hits_mod.Hits({k: v.copy() for k, v in d.items()})
+    with warnings.catch_warnings():
+      warnings.simplefilter('ignore')
+      out[name + '_center'] = np.asarray(h.fanCenter())
+      out[name + '_centerDists'] = np.asarray(h.fanCenterDists())
+      out[name + '_neighborDists'] = np.asarray(h.fanNeighborDists())
+      out[name + '_curvs'] = np.asarray(h.fanCurvs())
+      out[name + '_missing'] = np.asarray(h.fanMissingRays())
+      out[name + '_skipped'] = np.asarray(h.fanSkippedRays())
+      out[name + '_healthy'] = np.asarray(h.fanSymmetryHealthy())
+      out[name + '_raysPerFan'] = np.asarray(h.raysPerFan())
+      out[name + '_fanCount'] = np.asarray(h.fanCount())
+      for i, v in h.fanEstimatedPowerDensities().items():
+        out[f'{name}_density_{int(i)}'] = np.asarray(v)
+      for i, v in h.fanEstimatedCausticIntensities().items():
+        out[f'{name}_caustic_{int(i)}'] = np.asarray(v)
+      xs = np.linspace(-9, 9, 37)
+      for i, fn in h.fanEstimatedPowerDensityFuncs().items():
+        out[f'{name}_densityfunc_{int(i)}'] = np.asarray(fn(xs))
+      for i, fn in h.fanEstimatedCausticIntensityFuncs().items():
+        out[f'{name}_causticfunc_{int(i)}'] = np.asarray([fn(-9.0, 9.0), fn(0.0, 1.0), fn(3.9, 4.1)], dtype=float)
+    print('fan math', name, out[name + '_center'], out[name + '_missing'], out[name + '_skipped'],
+          out[name + '_healthy'])
+  np.savez_compressed(os.path.join(OUT, 'fan_math.npz'), **out)
+
+
 if __name__ == '__main__':
   io, pbd, rng, hist, hits = load_reference_modules()
   make_sampler(rng)
@@ -369,3 +429,4 @@ if __name__ == '__main__':
   make_fan_rays(io, rng, pbd)
   make_surface(rng)
   make_pseudo(rng)
+  make_fan_math(hits)

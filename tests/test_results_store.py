@@ -97,6 +97,9 @@ def test_run_simulation_end_criteria_on_device(native_lib, tmp_path):
   store = runSimulation(doc, 'fans')
   h = store.hits().hits
   assert store.totalTracedRays == 40 and {'fanIndex', 'rayIndex', 'totalRaysInFan'} <= set(h)
+  fans = store.hits()
+  assert fans.supportsFanMath() and fans.fanCount() == 2 and fans.raysPerFan() == 20
+  assert fans.fanNeighborDists().shape[0] == 3 and np.isfinite(fans.fanCenter()).all()
   # pseudo-random modes: histogram-thinned host draws traced on the device
   store = runSimulation(doc, 'singlepseudo')
   assert store.totalTracedRays == 100 and store.totalIterations == 1 and len(store.hits()) > 90
