@@ -27,7 +27,7 @@ HIT_DTYPE = np.dtype([('point', '<f8', 3), ('direction', '<f8', 3), ('power', '<
 
 # every symbol include/odw_trace.h declares
 SYMBOLS = ['odw_abi_version', 'odw_create', 'odw_destroy', 'odw_last_error', 'odw_upload_scene',
-           'odw_upload_source', 'odw_upload_surface_samplers', 'odw_set_surface_seed', 'odw_set_limits', 'odw_set_detector', 'odw_reserve_hits', 'odw_trace',
+           'odw_upload_source', 'odw_upload_surface_source', 'odw_generate_rays', 'odw_upload_surface_samplers', 'odw_set_surface_seed', 'odw_set_wavelength', 'odw_set_limits', 'odw_set_detector', 'odw_reserve_hits', 'odw_trace',
            'odw_trace_rays', 'odw_sync', 'odw_reset_results', 'odw_reset_hits', 'odw_fetch_counters', 'odw_hit_count',
            'odw_fetch_hits', 'odw_fetch_histogram', 'odw_sample', 'odw_device_histogram',
            'odw_device_counters', 'odw_stream', 'odw_timing_enable', 'odw_timing_read']
@@ -59,6 +59,14 @@ class SurfaceSamplerDesc(C.Structure):
               ('family_lo', C.c_double), ('family_hi', C.c_double), ('n_phi_knots', C.c_int32),
               ('phi_edges', _pd), ('phi_cdf', _pd), ('n_t_knots', C.c_int32), ('n_t_rows', C.c_int32),
               ('t_edges', _pd), ('t_cdf', _pd)]
+
+
+class SurfaceSourceDesc(C.Structure):
+  _fields_ = [('wavelength', C.c_double), ('power', C.c_double), ('dist_tol', C.c_double),
+              ('n_prims', C.c_int32), ('prim_type', _pi), ('prim_flags', _pi), ('prim_xform', _pd),
+              ('prim_params', _pd), ('prim_cond_off', _pi), ('n_conds', C.c_int32), ('cond_prim', _pi),
+              ('cond_inside', _pi), ('n_faces', C.c_int32), ('face_prim', _pi), ('face_id', _pi),
+              ('face_area', _pd), ('n_t_knots', C.c_int32), ('t_edges', _pd), ('t_cdf', _pd)]
 
 
 class LimitsDesc(C.Structure):
@@ -193,3 +201,23 @@ def surface_sampler_descs(samplers):
     for name, a in (('phi_edges', phi_edges), ('phi_cdf', phi_cdf), ('t_edges', t_edges), ('t_cdf', t_cdf)):
       setattr(d, name, a.ctypes.data_as(_pd))
   return arr, len(samplers), keep
+
+
+def surface_source_desc(src):
+  """odw_surface_source_desc for a freecad_elements.surface_source.BakedSurfaceSource"""
+  keep = dict(prim_type=_arr(src.prim_type, np.int32), prim_flags=_arr(src.prim_flags, np.int32),
+              prim_xform=_arr(src.prim_xform, np.float64), prim_params=_arr(src.prim_params, np.float64),
+              prim_cond_off=_arr(src.prim_cond_off, np.int32),
+              cond_prim=_arr(src.cond_prim if len(src.cond_prim) else [0], np.int32),
+              cond_inside=_arr(src.cond_inside if len(src.cond_inside) else [0], np.int32),
+              face_prim=_arr(src.face_prim, np.int32), face_id=_arr(src.face_id, np.int32),
+              face_area=_arr(src.face_area, np.float64), t_edges=_arr(src.t_edges, np.float64),
+              t_cdf=_arr(src.t_cdf, np.float64))
+  d = SurfaceSourceDesc()
+  d.wavelength, d.power, d.dist_tol = float(src.wavelength), float(src.power), float(src.dist_tol)
+  d.n_prims, d.n_conds, d.n_faces = len(keep['prim_type']), len(src.cond_prim), len(keep['face_prim'])
+  d.n_t_knots = len(keep['t_edges'])
+  for name, typ in SurfaceSourceDesc._fields_:
+    if name in keep:
+      setattr(d, name, keep[name].ctypes.data_as(typ))
+  return d, keep

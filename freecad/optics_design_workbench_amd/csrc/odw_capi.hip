@@ -62,6 +62,10 @@ struct odw_ctx {
   DevBuf d_samplers, d_group_sampler;
   int n_samplers = 0;
   uint64_t surface_seed = 0;
+  // surface source (emitter) tables + the explicit-ray staging of its launches
+  DevBuf em_prim_f64, em_prim_i32, em_cond, em_face_i32, em_face_cdf, em_t_tab, em_t_guide, em_o, em_d;
+  DeviceEmitter h_emitter;
+  bool emitter_active = false;   // the most recently uploaded source is a surface source
   uint64_t hit_capacity = 0, n_bins = 0;
 
   TraceParams P;
@@ -344,7 +348,8 @@ __global__ void hit_gather_kernel(const odw_hit* __restrict__ hits, const uint32
 }
 
 int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32_t flags,
-                 bool explicit_rays) {
+                 const double* ray_o, const double* ray_d, const double* ray_p) {
+  const bool explicit_rays = ray_o != nullptr;
   if (!ctx->have_scene || !ctx->have_limits) return fail(ctx, ODW_ERR_NO_SCENE, "scene/limits not uploaded");
   if (!explicit_rays && !ctx->have_source) return fail(ctx, ODW_ERR_NO_SCENE, "source not uploaded");
   if (n == 0) return ODW_OK;
@@ -358,13 +363,13 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
   TraceParams& P = ctx->P;
   P.first_ray = first;
   P.n_rays = n;
-  P.seed = explicit_rays ? ctx->surface_seed : seed;
+  P.seed = seed;
   P.flags = flags;
   P.samplers = (const DeviceSurfaceSampler*)ctx->d_samplers.p;
   P.group_sampler = (const int32_t*)ctx->d_group_sampler.p;
-  P.ray_origins = explicit_rays ? (const double*)ctx->ray_o.p : nullptr;
-  P.ray_dirs = explicit_rays ? (const double*)ctx->ray_d.p : nullptr;
-  P.ray_powers = (explicit_rays && ctx->ray_p.p) ? (const double*)ctx->ray_p.p : nullptr;
+  P.ray_origins = ray_o;
+  P.ray_dirs = ray_d;
+  P.ray_powers = ray_p;
   P.out.hits = (odw_hit*)ctx->hits.p;
   P.out.hit_capacity = ctx->hit_capacity;
   P.out.hit_count = (unsigned long long*)ctx->hit_count.p;
@@ -409,6 +414,19 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
   return ODW_OK;
 }
 
+constexpr uint64_t kEmitChunk = 1ull << 24;
+
+int emit_rays(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed) {
+  int rc;
+  if ((rc = ensure(ctx, ctx->em_o, std::min<uint64_t>(n, kEmitChunk) * 3 * sizeof(double)))) return rc;
+  if ((rc = ensure(ctx, ctx->em_d, std::min<uint64_t>(n, kEmitChunk) * 3 * sizeof(double)))) return rc;
+  const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + 255) / 256, (uint64_t)ctx->n_cu * 16));
+  hipLaunchKernelGGL(odw_emit_kernel, dim3(grid), dim3(256), 0, ctx->stream, ctx->h_emitter, first, n, seed,
+                     (double*)ctx->em_o.p, (double*)ctx->em_d.p);
+  HIPCHK(ctx, hipGetLastError());
+  return ODW_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -433,6 +451,7 @@ int odw_create(int device, odw_ctx** out) {
   std::memset(&ctx->det_desc, 0, sizeof ctx->det_desc);
   std::memset(&ctx->h_source, 0, sizeof ctx->h_source);
   std::memset(&ctx->h_det, 0, sizeof ctx->h_det);
+  std::memset(&ctx->h_emitter, 0, sizeof ctx->h_emitter);
   if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&ctx->stream)) != hipSuccess) {
     fail(nullptr, ODW_ERR_DEVICE, std::string("odw_create: ") + hipGetErrorString(e));
     delete ctx;
@@ -464,6 +483,9 @@ void odw_destroy(odw_ctx* ctx) {
                    &ctx->sort_keys[0], &ctx->sort_keys[1], &ctx->sort_vals[0], &ctx->sort_vals[1],
                    &ctx->sort_tmp, &ctx->sorted_rows};
   for (DevBuf* b : all) release(*b);
+  for (DevBuf* b : {&ctx->em_prim_f64, &ctx->em_prim_i32, &ctx->em_cond, &ctx->em_face_i32, &ctx->em_face_cdf,
+                    &ctx->em_t_tab, &ctx->em_t_guide, &ctx->em_o, &ctx->em_d})
+    release(*b);
   for (auto& sb : ctx->surf_bufs) { release(sb.phi_tab); release(sb.t_tab); release(sb.t_guide); }
   release(ctx->d_samplers);
   release(ctx->d_group_sampler);
@@ -625,6 +647,12 @@ int odw_upload_surface_samplers(odw_ctx* ctx, const odw_surface_sampler_desc* sa
   return ODW_OK;
 }
 
+int odw_set_wavelength(odw_ctx* ctx, double wavelength_nm) {
+  if (!ctx || !(wavelength_nm > 0)) return fail(ctx, ODW_ERR_INVALID, "odw_set_wavelength: bad argument");
+  ctx->P.wavelength = wavelength_nm;
+  return ODW_OK;
+}
+
 int odw_set_surface_seed(odw_ctx* ctx, uint64_t seed) {
   if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_set_surface_seed: null ctx");
   ctx->surface_seed = seed;
@@ -685,6 +713,117 @@ int odw_upload_source(odw_ctx* ctx, const odw_source_desc* s) {
   ctx->P.source = (const DeviceSource*)ctx->d_source.p;
   ctx->P.wavelength = s->wavelength;
   ctx->have_source = true;
+  ctx->emitter_active = false;
+  return ODW_OK;
+}
+
+int odw_upload_surface_source(odw_ctx* ctx, const odw_surface_source_desc* s) {
+  if (!ctx || !s) return fail(ctx, ODW_ERR_INVALID, "odw_upload_surface_source: null argument");
+  if (s->n_prims < 1 || s->n_faces < 1 || s->n_conds < 0 || s->n_t_knots < 2 || !(s->dist_tol > 0))
+    return fail(ctx, ODW_ERR_INVALID, "odw_upload_surface_source: counts out of range");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  const int n = s->n_prims;
+  std::vector<double> pf((size_t)n * 16);
+  std::vector<int32_t> pi((size_t)n * 4);
+  for (int p = 0; p < n; ++p) {
+    if (s->prim_type[p] < ODW_PRIM_BOX || s->prim_type[p] > ODW_PRIM_TORUS)
+      return fail(ctx, ODW_ERR_UNSUPPORTED, "surface source: unknown primitive type");
+    const int off = s->prim_cond_off[p], cnt = s->prim_cond_off[p + 1] - off;
+    if (off < 0 || cnt < 0 || off + cnt > s->n_conds) return fail(ctx, ODW_ERR_INVALID, "surface source: bad condition offsets");
+    std::memcpy(&pf[16 * (size_t)p], s->prim_xform + 12 * (size_t)p, 12 * sizeof(double));
+    std::memcpy(&pf[16 * (size_t)p + 12], s->prim_params + 4 * (size_t)p, 4 * sizeof(double));
+    pi[4 * p] = s->prim_type[p];
+    pi[4 * p + 1] = s->prim_flags[p];
+    pi[4 * p + 2] = off;
+    pi[4 * p + 3] = cnt;
+  }
+  std::vector<int32_t> cond((size_t)std::max(1, s->n_conds), 0);
+  for (int c = 0; c < s->n_conds; ++c) {
+    if (s->cond_prim[c] < 0 || s->cond_prim[c] >= n) return fail(ctx, ODW_ERR_INVALID, "surface source: condition primitive out of range");
+    cond[c] = s->cond_prim[c] | (s->cond_inside[c] ? (int32_t)0x80000000 : 0);
+  }
+  static const int n_faces_of[5] = {6, 1, 3, 3, 1};
+  std::vector<int32_t> fi((size_t)s->n_faces * 2);
+  std::vector<double> fc((size_t)s->n_faces + 1, 0.0);
+  double total = 0;
+  for (int f = 0; f < s->n_faces; ++f) {
+    const int p = s->face_prim[f];
+    if (p < 0 || p >= n || s->face_id[f] < 0 || s->face_id[f] >= n_faces_of[s->prim_type[p]] || !(s->face_area[f] >= 0))
+      return fail(ctx, ODW_ERR_INVALID, "surface source: face out of range");
+    fi[2 * f] = p;
+    fi[2 * f + 1] = s->face_id[f];
+    total += s->face_area[f];
+  }
+  if (!(total > 0)) return fail(ctx, ODW_ERR_INVALID, "surface source: emitting faces have no area");
+  double run = 0;
+  for (int f = 0; f < s->n_faces; ++f) { run += s->face_area[f]; fc[f + 1] = run / total; }
+  fc[s->n_faces] = 1.0;
+  const int nt = s->n_t_knots;
+  if (s->t_cdf[0] != 0.0 || s->t_cdf[nt - 1] != 1.0) return fail(ctx, ODW_ERR_INVALID, "surface source: theta cdf must run from 0 to 1");
+  std::vector<double> ttab((size_t)nt * 2);
+  for (int i = 0; i < nt; ++i) {
+    if (i && s->t_cdf[i] < s->t_cdf[i - 1]) return fail(ctx, ODW_ERR_INVALID, "surface source: cdf not monotone");
+    ttab[2 * i] = s->t_cdf[i];
+    ttab[2 * i + 1] = s->t_edges[i];
+  }
+  std::vector<int32_t> guide((size_t)kGuide + 1);
+  for (int k = 0, j = 0; k <= kGuide; ++k) {
+    const double x = (double)k / (double)kGuide;
+    while (j + 1 < nt && s->t_cdf[j + 1] <= x) ++j;
+    guide[k] = j;
+  }
+  int rc;
+  if ((rc = upload(ctx, ctx->em_prim_f64, pf.data(), pf.size() * sizeof(double)))) return rc;
+  if ((rc = upload(ctx, ctx->em_prim_i32, pi.data(), pi.size() * sizeof(int32_t)))) return rc;
+  if ((rc = upload(ctx, ctx->em_cond, cond.data(), cond.size() * sizeof(int32_t)))) return rc;
+  if ((rc = upload(ctx, ctx->em_face_i32, fi.data(), fi.size() * sizeof(int32_t)))) return rc;
+  if ((rc = upload(ctx, ctx->em_face_cdf, fc.data(), fc.size() * sizeof(double)))) return rc;
+  if ((rc = upload(ctx, ctx->em_t_tab, ttab.data(), ttab.size() * sizeof(double)))) return rc;
+  if ((rc = upload(ctx, ctx->em_t_guide, guide.data(), guide.size() * sizeof(int32_t)))) return rc;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  DeviceEmitter& e = ctx->h_emitter;
+  e.prim_f64 = (const double*)ctx->em_prim_f64.p;
+  e.prim_i32 = (const int32_t*)ctx->em_prim_i32.p;
+  e.cond_i32 = (const int32_t*)ctx->em_cond.p;
+  e.face_i32 = (const int32_t*)ctx->em_face_i32.p;
+  e.face_cdf = (const double*)ctx->em_face_cdf.p;
+  e.t_tab = (const double*)ctx->em_t_tab.p;
+  e.t_guide = (const int32_t*)ctx->em_t_guide.p;
+  e.n_faces = s->n_faces;
+  e.n_t_knots = nt;
+  e.n_guide = kGuide;
+  e.dist_tol = s->dist_tol;
+  e.wavelength = s->wavelength;
+  e.power = s->power;
+  ctx->P.wavelength = s->wavelength;
+  ctx->have_source = true;
+  ctx->emitter_active = true;
+  return ODW_OK;
+}
+
+int odw_generate_rays(odw_ctx* ctx, uint64_t first_ray, uint64_t n_rays, uint64_t seed, double* origins,
+                      double* directions) {
+  if (!ctx || !origins || !directions) return fail(ctx, ODW_ERR_INVALID, "odw_generate_rays: bad argument");
+  if (!ctx->have_source) return fail(ctx, ODW_ERR_NO_SCENE, "source not uploaded");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  for (uint64_t off = 0; off < n_rays; off += kEmitChunk) {
+    const uint64_t m = std::min<uint64_t>(kEmitChunk, n_rays - off);
+    int rc;
+    if (ctx->emitter_active) {
+      if ((rc = emit_rays(ctx, first_ray + off, m, seed))) return rc;
+    } else {
+      if ((rc = ensure(ctx, ctx->em_o, m * 3 * sizeof(double)))) return rc;
+      if ((rc = ensure(ctx, ctx->em_d, m * 3 * sizeof(double)))) return rc;
+      const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((m + 255) / 256, (uint64_t)ctx->n_cu * 16));
+      hipLaunchKernelGGL(odw_make_rays_kernel, dim3(grid), dim3(256), 0, ctx->stream, ctx->P.source, first_ray + off,
+                         m, seed, (double*)ctx->em_o.p, (double*)ctx->em_d.p);
+      HIPCHK(ctx, hipGetLastError());
+    }
+    HIPCHK(ctx, hipMemcpyAsync(origins + 3 * off, ctx->em_o.p, m * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(directions + 3 * off, ctx->em_d.p, m * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  }
   return ODW_OK;
 }
 
@@ -749,7 +888,19 @@ int odw_reserve_hits(odw_ctx* ctx, uint64_t capacity) {
 int odw_trace(odw_ctx* ctx, uint64_t first_ray, uint64_t n_rays, uint64_t seed, uint32_t flags) {
   if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_trace: null ctx");
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  return launch_trace(ctx, first_ray, n_rays, seed, flags, false);
+  if (!ctx->emitter_active) return launch_trace(ctx, first_ray, n_rays, seed, flags, nullptr, nullptr, nullptr);
+  // surface source: initial conditions are generated into a staging buffer,
+  // kEmitChunk rays at a time, and traced as explicit rays (same stream: the
+  // next chunk's generation waits for the previous chunk's trace)
+  for (uint64_t off = 0; off < n_rays; off += kEmitChunk) {
+    const uint64_t m = std::min<uint64_t>(kEmitChunk, n_rays - off);
+    int rc = emit_rays(ctx, first_ray + off, m, seed);
+    if (rc) return rc;
+    rc = launch_trace(ctx, first_ray + off, m, seed, flags, (const double*)ctx->em_o.p,
+                      (const double*)ctx->em_d.p, nullptr);
+    if (rc) return rc;
+  }
+  return ODW_OK;
 }
 
 int odw_trace_rays(odw_ctx* ctx, uint64_t first_ray, uint64_t n_rays, const double* origins,
@@ -764,10 +915,9 @@ int odw_trace_rays(odw_ctx* ctx, uint64_t first_ray, uint64_t n_rays, const doub
   if ((rc = upload(ctx, ctx->ray_d, directions, n_rays * 3 * sizeof(double)))) return rc;
   if (powers) {
     if ((rc = upload(ctx, ctx->ray_p, powers, n_rays * sizeof(double)))) return rc;
-  } else {
-    release(ctx->ray_p);
   }
-  rc = launch_trace(ctx, first_ray, n_rays, 0, flags, true);
+  rc = launch_trace(ctx, first_ray, n_rays, ctx->surface_seed, flags, (const double*)ctx->ray_o.p,
+                    (const double*)ctx->ray_d.p, powers ? (const double*)ctx->ray_p.p : nullptr);
   if (rc) return rc;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // caller's arrays may go away
   return ODW_OK;
@@ -872,7 +1022,7 @@ int odw_fetch_histogram(odw_ctx* ctx, uint64_t* out, uint64_t n_bins) {
 int odw_sample(odw_ctx* ctx, uint64_t first_ray, uint64_t n_rays, uint64_t seed, double* theta_out,
                double* phi_out) {
   if (!ctx || !theta_out || !phi_out) return fail(ctx, ODW_ERR_INVALID, "odw_sample: bad argument");
-  if (!ctx->have_source) return fail(ctx, ODW_ERR_NO_SCENE, "source not uploaded");
+  if (!ctx->have_source || ctx->emitter_active) return fail(ctx, ODW_ERR_NO_SCENE, "point source not uploaded");
   if (n_rays == 0) return ODW_OK;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   int rc;

@@ -72,6 +72,19 @@ struct DeviceSurfaceSampler {
   double lo, inv_step;          // member = rint((c - lo) * inv_step), clamped
 };
 
+// surface source (odw_surface_source_desc)
+struct DeviceEmitter {
+  const double* prim_f64;       // [n_prims*16] global->local rows, params
+  const int32_t* prim_i32;      // [n_prims*4] type, flags, cond_off, cond_cnt
+  const int32_t* cond_i32;      // prim | inside<<31
+  const int32_t* face_i32;      // [n_faces*2] prim, face
+  const double* face_cdf;       // [n_faces+1] cumulative untrimmed area / total
+  const double* t_tab;          // [n_t_knots*2] (cdf, edge)
+  const int32_t* t_guide;       // [n_guide+1]
+  int32_t n_faces, n_t_knots, n_guide;
+  double dist_tol, wavelength, power;
+};
+
 struct DeviceLimits {
   double max_ray_length, dist_tol, power_tol;
   int32_t max_intersections;

@@ -215,7 +215,8 @@ __device__ __forceinline__ void make_ray(csource s, double t_or_r, double phi,
 }
 
 // ----------------------------------------------------------- primitives
-__device__ __forceinline__ double prim_sdist(int type, cf64 par, d3 p) {
+template <class PP>
+__device__ __forceinline__ double prim_sdist(int type, PP par, d3 p) {
   switch (type) {
     case ODW_PRIM_BOX: {
       const double dx = fmax(-p.x, p.x - par[0]);
@@ -1032,6 +1033,139 @@ __global__ __launch_bounds__(256) void odw_sample_kernel(const DeviceSource* sp,
     sample_source(as_const(sp), up, ut, t, phi);
     t_out[i] = t;
     phi_out[i] = phi;
+  }
+}
+
+
+// --------------------------------------------------------- surface source
+// SurfaceSourceProxy._generateRays(mode='true') (surface_source.py:519-553)
+#define ODW_EMIT_MAX_ATTEMPTS 4096
+__device__ __forceinline__ void philox_pair(uint64_t ray, uint64_t seed, uint32_t c2, uint32_t c3,
+                                            double& a, double& b) {
+  uint32_t c0 = (uint32_t)ray, c1 = (uint32_t)(ray >> 32);
+  philox4x32_10(c0, c1, c2, c3, (uint32_t)seed, (uint32_t)(seed >> 32));
+  a = u53(c0, c1);
+  b = u53(c2, c3);
+}
+
+// point, outward normal and tangent (d/du of the face's parametrisation) of
+// face `face` of a primitive at face coordinates (ua, ub) in [0,1)^2; returns
+// the acceptance probability of the point (torus: area element / its maximum)
+__device__ __forceinline__ double face_point(int type, const double* par, int face, double ua, double ub,
+                                             d3& p, d3& n, d3& t) {
+  const double two_pi = 6.283185307179586;
+  if (type == ODW_PRIM_BOX) {
+    const int a = face >> 1, b1 = (a + 1) % 3, b2 = (a + 2) % 3;
+    double c[3];
+    c[a] = (face & 1) ? par[a] : 0.0;
+    c[b1] = ua * par[b1];
+    c[b2] = ub * par[b2];
+    p = mk(c[0], c[1], c[2]);
+    const double s = (face & 1) ? 1.0 : -1.0;
+    n = mk(a == 0 ? s : 0.0, a == 1 ? s : 0.0, a == 2 ? s : 0.0);
+    t = mk(b1 == 0 ? 1.0 : 0.0, b1 == 1 ? 1.0 : 0.0, b1 == 2 ? 1.0 : 0.0);
+    return 1.0;
+  }
+  double sa, ca;
+  sincos_bounded(two_pi * ua, sa, ca);
+  if (type == ODW_PRIM_SPHERE) {
+    const double z = 2.0 * ub - 1.0, r = sqrt(fmax(0.0, 1.0 - z * z));
+    n = mk(r * ca, r * sa, z);
+    p = n * par[0];
+    t = mk(-sa, ca, 0.0);
+    return 1.0;
+  }
+  if (type == ODW_PRIM_TORUS) {
+    double sv, cv;
+    sincos_bounded(two_pi * ub, sv, cv);
+    const double rho = par[0] + par[1] * cv;
+    p = mk(rho * ca, rho * sa, par[1] * sv);
+    n = mk(cv * ca, cv * sa, sv);
+    t = mk(-sa, ca, 0.0);
+    return rho / (par[0] + par[1]);
+  }
+  // cylinder / cone
+  const double r1 = par[0], r2 = (type == ODW_PRIM_CONE) ? par[1] : par[0];
+  const double h = (type == ODW_PRIM_CONE) ? par[2] : par[1];
+  if (face == 0) {
+    double z;                               // area element ~ radius(z)
+    if (r1 == r2) z = h * ub;
+    else z = h * (sqrt(r1 * r1 + ub * (r2 * r2 - r1 * r1)) - r1) / (r2 - r1);
+    const double k = (r2 - r1) / h, r = r1 + k * z;
+    p = mk(r * ca, r * sa, z);
+    const double inv = 1.0 / sqrt(1.0 + k * k);
+    n = mk(ca * inv, sa * inv, -k * inv);
+    t = mk(-sa, ca, 0.0);
+    return 1.0;
+  }
+  const double rr = (face == 1 ? r1 : r2) * sqrt(ub);
+  p = mk(rr * ca, rr * sa, face == 1 ? 0.0 : h);
+  n = mk(0.0, 0.0, face == 1 ? -1.0 : 1.0);
+  t = mk(1.0, 0.0, 0.0);
+  return 1.0;
+}
+
+__global__ __launch_bounds__(256) void odw_emit_kernel(const DeviceEmitter E, uint64_t first, uint64_t n, uint64_t seed,
+                                                       double* __restrict__ origins, double* __restrict__ dirs) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint64_t ray = first + i;
+    d3 gp = mk(0, 0, 0), gn = mk(0, 0, 1), gt = mk(1, 0, 0);
+    for (uint32_t attempt = 0; attempt < ODW_EMIT_MAX_ATTEMPTS; ++attempt) {
+      double u_face, u_acc, ua, ub;
+      philox_pair(ray, seed, attempt, 3u, u_face, u_acc);
+      philox_pair(ray, seed, attempt, 4u, ua, ub);
+      int f = 0;
+      while (f + 1 < E.n_faces && u_face >= E.face_cdf[f + 1]) ++f;
+      const int prim = E.face_i32[2 * f], face = E.face_i32[2 * f + 1];
+      const double* pf = E.prim_f64 + (size_t)prim * 16;
+      const int32_t* pi = E.prim_i32 + 4 * prim;
+      d3 p, nl, tl;
+      const double accept = face_point(pi[0], pf + 12, face, ua, ub, p, nl, tl);
+      if (u_acc >= accept) continue;
+      if (pi[1] & ODW_FLAG_FLIP_NORMAL) nl = nl * -1.0;
+      // local -> global: x = R^T (p - t)
+      const d3 q = mk(p.x - pf[3], p.y - pf[7], p.z - pf[11]);
+      gp = xf_vec_t(pf, q);
+      bool ok = true;
+      for (int c = pi[2]; c < pi[2] + pi[3] && ok; ++c) {
+        const int cw = E.cond_i32[c];
+        const int qp = cw & 0x7fffffff;
+        const double* of = E.prim_f64 + (size_t)qp * 16;
+        const double sd = prim_sdist(E.prim_i32[4 * qp], of + 12, xf_point(of, gp));
+        if (cw < 0) { if (sd > E.dist_tol) ok = false; }
+        else { if (sd < -E.dist_tol) ok = false; }
+      }
+      if (!ok) continue;
+      gn = xf_vec_t(pf, nl);
+      gt = xf_vec_t(pf, tl);
+      break;
+    }
+    double u_t, u_phi;
+    philox_pair(ray, seed, 0u, 5u, u_t, u_phi);
+    const int k = (int)(u_t * (double)E.n_guide);
+    const double theta = inv_cdf(E.t_tab, E.t_guide[k], min(E.t_guide[k + 1] + 1, E.n_t_knots - 1), u_t);
+    const double phi = 6.283185307179586 * u_phi;
+    d3 d = rotate(gn, phi, rotate(gt, theta, gn));
+    d = d * (1.0 / sqrt(dot(d, d)));
+    origins[3 * i] = gp.x; origins[3 * i + 1] = gp.y; origins[3 * i + 2] = gp.z;
+    dirs[3 * i] = d.x; dirs[3 * i + 1] = d.y; dirs[3 * i + 2] = d.z;
+  }
+}
+
+// point source: initial conditions only (odw_generate_rays)
+__global__ __launch_bounds__(256) void odw_make_rays_kernel(const DeviceSource* sp, uint64_t first, uint64_t n,
+                                                            uint64_t seed, double* __restrict__ origins,
+                                                            double* __restrict__ dirs) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    double up, ut, t, phi;
+    d3 o, d;
+    ray_uniforms(first + i, seed, up, ut);
+    sample_source(as_const(sp), up, ut, t, phi);
+    make_ray(as_const(sp), t, phi, o, d);
+    origins[3 * i] = o.x; origins[3 * i + 1] = o.y; origins[3 * i + 2] = o.z;
+    dirs[3 * i] = d.x; dirs[3 * i + 1] = d.y; dirs[3 * i + 2] = d.z;
   }
 }
 

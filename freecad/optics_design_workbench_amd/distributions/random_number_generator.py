@@ -269,6 +269,39 @@ class ScalarRandomVariable:
     self._sym = sy.Symbol(var, real=True, **kw)
     self._expr = expr.subs(sy.Symbol(var), self._sym)
 
+  def tables(self, **constants):
+    """numeric-mode inverse-CDF table of the single variable
+    (random_number_generator.py:337-369, 372-464 with one variable):
+    -> (edges, cdf / cdf[-1])"""
+    if self._expr is None or constants:
+      self.compile(**constants)
+    l1, l2 = self._domain
+    if not np.isfinite(l1) or not np.isfinite(l2):
+      raise ValueError(f'numerical solution requires finite limits, but found limits [{l1}, {l2}]')
+    res = self._resolution if self._resolution else 5 + int(1e6)
+    edges = np.linspace(l1, l2, _odd(res))
+    mid = (edges[1:] + edges[:-1]) / 2
+    p = sy.lambdify(self._sym, self._expr, modules=['numpy', 'scipy'])(mid)
+    if not hasattr(p, 'shape') or np.shape(p) != mid.shape:
+      p = mid * 0 + p
+    if (p < 0).any():
+      raise ValueError(f'found negative probability density, expression: {self._expr}')
+    cdf = np.concatenate([[0.0], np.cumsum(p)])
+    return edges, cdf / cdf[-1]
+
+  def mode(self):
+    return 'numeric'
+
+  def draw(self, N=None, **constants):
+    """host draw with numpy's global RNG in the reference's order
+    (random_number_generator.py:492-528): u, one unused block"""
+    edges, cdf = self.tables(**constants)
+    n = 1 if N is None else max(1, int(round(N)))
+    u = np.random.random_sample(n)
+    np.random.random_sample(n)
+    v = np.interp(u, cdf, edges)
+    return v if N is not None else v[0]
+
   def findGrid(self, N, constants=None):
     if self._expr is None or constants:
       self.compile(**(constants or {}))

@@ -125,3 +125,14 @@ def makeSimulationSettings(doc, name='OpticalSimulationSettings', **props):
   return doc.addObject('Part::FeaturePython', name,
                        Proxy={'module': 'freecad.optics_design_workbench.freecad_elements.simulation_settings',
                               'class': 'SimulationSettingsProxy', 'state': {}}, **p)
+
+
+def makeReplaySource(doc, replayFromDir, name='OpticalReplaySource', placement=None, **props):
+  """ReplaySourceProxy (replay_source.py:30-38): replays the hits below `replayFromDir` as rays"""
+  p = dict(ReplayFromDir=str(replayFromDir), Wavelength=500.0, RecordRays=False, IgnoredOpticalElements=[],
+           RaysPerIterationScale=1.0, MaxIntersectionsScale=1.0, MaxRayLengthScale=1.0)
+  p.update(props)
+  return doc.addObject('App::LinkGroupPython', name,
+                       Proxy={'module': 'freecad.optics_design_workbench.freecad_elements.replay_source',
+                              'class': 'ReplaySourceProxy', 'state': {}},
+                       ElementList=[], Placement=placement or Placement.identity(), **p)

@@ -17,8 +17,8 @@ from .placement import Placement
 
 OPTICAL_TYPES = ['Mirror', 'Lens', 'Grating', 'Absorber', 'Vacuum']
 MAX_GROUPS = 64
-_SOURCE_PROXIES = ('PointSourceProxy',)
-_UNSUPPORTED_SOURCES = ('SurfaceSourceProxy', 'ReplaySourceProxy')
+_SOURCE_PROXIES = ('PointSourceProxy', 'SurfaceSourceProxy', 'ReplaySourceProxy')
+_UNSUPPORTED_SOURCES = ()
 
 
 # ---------------------------------------------------------------------------

@@ -97,6 +97,8 @@ def _parse_property(prop, zf):
     return child.attrib['value'].lower() == 'true'
   if tag == 'String':
     return child.attrib['value']
+  if tag == 'Path':
+    return child.attrib.get('value', '')
   if tag == 'PropertyPlacement':
     a = child.attrib
     return Placement(base=(float(a['Px']), float(a['Py']), float(a['Pz'])),
@@ -108,6 +110,17 @@ def _parse_property(prop, zf):
     return child.attrib.get('value') or None
   if tag == 'LinkList':
     return [l.attrib['value'] for l in child.findall('Link')]
+  if tag == 'LinkSubList':
+    # [(object name, [sub-element names])], consecutive entries of one object merged
+    # (App::PropertyLinkSubList.getValue groups them the same way)
+    out = []
+    for l in child.findall('Link'):
+      name, sub = l.attrib.get('obj'), l.attrib.get('sub', '')
+      if out and out[-1][0] == name:
+        out[-1][1].append(sub)
+      else:
+        out.append((name, [sub]))
+    return out
   if tag == 'XLink':
     return child.attrib.get('name') or None
   if tag == 'LinkSub':
@@ -148,6 +161,14 @@ _PROXY_PROPERTIES = {
       'ThetaResolutionNumericMode RadiusResolutionNumericMode PhiResolutionNumericMode Fans FanPhi0 RaysPerFan '
       'FanModePowerSpan RecordRays IgnoredOpticalElements RaysPerIterationScale MaxIntersectionsScale '
       'MaxRayLengthScale').split(),
+  ('freecad.optics_design_workbench.freecad_elements.surface_source', 'SurfaceSourceProxy'): (
+      'ActiveSurfaces PowerDensity UVSamplingInitialResolution UVSamplingMaxRelAreaElementChange FanModeRayCount '
+      'Wavelength ThetaDomain RandomNumberGeneratorMode ThetaResolutionNumericMode RadiusResolutionNumericMode '
+      'FanModePowerSpan RecordRays IgnoredOpticalElements RaysPerIterationScale MaxIntersectionsScale '
+      'MaxRayLengthScale').split(),
+  ('freecad.optics_design_workbench.freecad_elements.replay_source', 'ReplaySourceProxy'): (
+      'ReplayFromDir RecordRays IgnoredOpticalElements RaysPerIterationScale MaxIntersectionsScale '
+      'MaxRayLengthScale Wavelength').split(),
   ('freecad.optics_design_workbench.freecad_elements.simulation_settings', 'SimulationSettingsProxy'): (
       'Active EnableStoreSingleShotData EndAfterIterations EndAfterRays EndAfterHits RaysPerIteration '
       'MaxIntersections DistanceTolerance MaxRayLength ShowRaysInContinuousMode WorkerProcessCount SequentialMode '
@@ -211,6 +232,9 @@ class Document:
         t = obj._types.get(k, '')
         if t in ('App::PropertyLink', 'App::PropertyXLink', 'App::PropertyLinkGlobal'):
           obj._props[k] = self._by_name.get(v) if isinstance(v, str) else None
+        elif t == 'App::PropertyLinkSubList':
+          obj._props[k] = [(self._by_name[n], [x for x in subs if x]) for n, subs in (v or [])
+                           if n in self._by_name]
         elif t in ('App::PropertyLinkList', 'App::PropertyLinkListGlobal'):
           obj._props[k] = [self._by_name[n] for n in (v or []) if n in self._by_name]
     repairProxies(self)

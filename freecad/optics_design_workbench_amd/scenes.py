@@ -18,6 +18,11 @@ class BakedProject:
   sourceObject: object
 
 
+def _bakeLightSource(doc, source):
+  from .simulation.simulation_loop import bakeLightSource
+  return bakeLightSource(doc, source)
+
+
 def bakeProject(doc, source=None, **traceKwargs):
   """document (or path) -> BakedProject for its first (or the given) source.
   traceKwargs: maxRayLength, maxIntersections, powerTol, distTol as in
@@ -32,7 +37,7 @@ def bakeProject(doc, source=None, **traceKwargs):
   elif isinstance(source, str):
     source = doc.getObject(source) or doc.getObjectsByLabel(source)[0]
   return BakedProject(document=doc, scene=_bake.bakeScene(doc, source),
-                      source=point_source.bakeSource(doc, source),
+                      source=_bakeLightSource(doc, source),
                       limits=_bake.bakeLimits(doc, source, **traceKwargs), sourceObject=source)
 
 

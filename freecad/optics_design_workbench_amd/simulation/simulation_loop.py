@@ -16,7 +16,7 @@ several GPUs of this process' node through `parallel`.
 """
 import numpy as np
 
-from ..freecad_elements import point_source
+from ..freecad_elements import point_source, replay_source, surface_source
 from ..scene import bake as _bake
 from . import results_store
 from .tracer import Tracer
@@ -79,15 +79,45 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
     baked = []
     for src in sources:
       scene = _bake.bakeScene(doc, src)
-      baked.append((src, scene, point_source.bakeSource(doc, src), _bake.bakeLimits(doc, src, **traceKwargs)))
+      baked.append((src, scene, bakeLightSource(doc, src, seed), _bake.bakeLimits(doc, src, **traceKwargs)))
     first = {src.Name: 0 for src in sources}
+    ended = False
     while True:
       for src, scene, bsrc, lim in baked:
         per_iter = max(1, int(round(rpi * bsrc.rays_per_iteration_scale)))
         tr.setScene(scene)
         tr.setLimits(lim)
         tr.setDetector(None)
-        if action in ('fans', 'singlefans'):
+        if isinstance(bsrc, replay_source.BakedReplay):
+          # replay_source.py:116-166: no fans; true and pseudo modes alike take the next
+          # RaysPerIteration rays of the stock; an exhausted stock ends the simulation
+          if action in ('fans', 'singlefans'):
+            continue
+          iters = 1 if not continuous else _iterations_for_launch(store, per_iter, raysPerLaunch)
+          o, d, wl, pw = bsrc.take(iters * per_iter)
+          n, iters, meta = len(o), max(1, -(-len(o) // per_iter)), None
+          if n:
+            tr.reserveHits(max(16, n * (lim.max_intersections + 1)))
+            tr.reset()
+            tr.setSurfaceSeed(seed)
+            done = 0
+            for w in np.unique(wl):          # one launch per wavelength (gratings)
+              sel = wl == w
+              tr.setWavelength(w)
+              tr.traceRays(o[sel], d[sel], pw[sel], first=first[src.Name] + done)
+              done += int(sel.sum())
+            tr.sync()
+          if bsrc.remaining == 0:
+            import warnings
+            warnings.warn(f'replay light source {src.Name} ran out of rays, canceling simulation...')
+            ended = True
+          if not n:
+            continue
+        elif action in ('fans', 'singlefans'):
+          if isinstance(bsrc, surface_source.BakedSurfaceSource):
+            raise NotImplementedError(
+                f'{src.Name}: fan mode of surface sources (equidistant UV grids, '
+                f'surface_source.py:119-266) is not on the accelerated path')
           rays = point_source.generateFanRays(src, bsrc)
           o = np.array([r[0] for r in rays])
           d = np.array([r[1] for r in rays])
@@ -98,7 +128,8 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
           tr.sync()
           n, iters = len(rays), 1
           meta = [r[2] for r in rays]
-        elif pseudo:
+        elif pseudo and isinstance(bsrc, point_source.BakedSource):
+          # (surface sources treat 'pseudo' like 'true', surface_source.py:521)
           iters = 1 if not continuous else min(pseudoIterationsPerLaunch,
                                                _iterations_for_launch(store, per_iter, raysPerLaunch))
           vrv = point_source.getVrv(src)
@@ -128,12 +159,22 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
         store.incrementRayCount(n)
         store.incrementIterationCount(iters)
       store.flush()
-      if not continuous or store.reachedEnd() or (endIf is not None and endIf(store)):
+      if ended or not continuous or store.reachedEnd() or (endIf is not None and endIf(store)):
         break
   finally:
     if own:
       tr.close()
   return store
+
+
+def bakeLightSource(doc, src, seed=0):
+  """device-side description of a light source by proxy class"""
+  cls = src.ProxyClass
+  if cls == 'ReplaySourceProxy':
+    return replay_source.bakeReplaySource(doc, src, seed)
+  if cls == 'SurfaceSourceProxy':
+    return surface_source.bakeSurfaceSource(doc, src)
+  return point_source.bakeSource(doc, src)
 
 
 def _iterations_for_launch(store, per_iter, raysPerLaunch):

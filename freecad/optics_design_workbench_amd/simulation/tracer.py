@@ -66,10 +66,29 @@ class Tracer:
     """Philox key of the stochastic-surface draws in traceRays launches"""
     self._chk(self._lib.odw_set_surface_seed(self._ctx, C.c_uint64(int(seed))), 'odw_set_surface_seed')
 
+  def setWavelength(self, wavelength_nm):
+    """wavelength of the following launches (explicit rays); setSource resets it"""
+    self._chk(self._lib.odw_set_wavelength(self._ctx, C.c_double(float(wavelength_nm))), 'odw_set_wavelength')
+
   def setSource(self, source):
-    d, keep = _native.source_desc(source)
-    self._chk(self._lib.odw_upload_source(self._ctx, C.byref(d)), 'odw_upload_source')
+    """point source (BakedSource) or surface source (BakedSurfaceSource)"""
+    if hasattr(source, 'face_prim'):
+      d, keep = _native.surface_source_desc(source)
+      self._chk(self._lib.odw_upload_surface_source(self._ctx, C.byref(d)), 'odw_upload_surface_source')
+    else:
+      d, keep = _native.source_desc(source)
+      self._chk(self._lib.odw_upload_source(self._ctx, C.byref(d)), 'odw_upload_source')
     self.source = source
+
+  def generateRays(self, first, n, seed):
+    """initial conditions only (returnInitialConditions, generic_source.py:57): origins, directions"""
+    o = np.empty((int(n), 3))
+    d = np.empty((int(n), 3))
+    pd = C.POINTER(C.c_double)
+    self._chk(self._lib.odw_generate_rays(self._ctx, C.c_uint64(int(first)), C.c_uint64(int(n)),
+                                          C.c_uint64(int(seed)), o.ctypes.data_as(pd), d.ctypes.data_as(pd)),
+              'odw_generate_rays')
+    return o, d
 
   def setLimits(self, lim):
     d = _native.LimitsDesc(float(lim.max_ray_length), int(lim.max_intersections),

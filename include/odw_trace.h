@@ -156,6 +156,42 @@ typedef struct odw_surface_sampler_desc {
   const double* t_cdf;     /* [n_family*n_t_rows*n_t_knots]                   */
 } odw_surface_sampler_desc;
 
+/* Surface source = SurfaceSourceProxy._generateRays(mode='true')
+ * (surface_source.py:519-553): a ray starts at a uniformly distributed point
+ * of the emitting faces (the reference picks a face by area and draws (u,v)
+ * from a sampled area-element grid, :440-464, :394-412; here the analytic
+ * faces are sampled exactly), its direction is
+ *   Rot(normal, phi) * Rot(tangent, theta) * normal        (:104-106)
+ * with theta from the scalar random variable of PowerDensity over ThetaDomain
+ * (numeric mode table) and phi uniform in [0, 2 pi).
+ * Emitting solids are primitives in the scene's encoding with their own
+ * boolean trimming conditions; a sampled point that a condition trims away
+ * is rejected together with its face choice, so faces weigh in by their
+ * TRIMMED area.  Uniforms: Philox4x32-10, key = seed, counter =
+ * (ray_lo, ray_hi, attempt, 3) -> face, acceptance; (.., attempt, 4) -> the
+ * two face coordinates; (ray_lo, ray_hi, 0, 5) -> theta, phi.               */
+typedef struct odw_surface_source_desc {
+  double wavelength;            /* nm                                         */
+  double power;                 /* initial ray power (1)                      */
+  double dist_tol;              /* SurfaceSourceProxy._getDistTol, :111-116   */
+  int32_t n_prims;
+  const int32_t* prim_type;     /* [n_prims] ODW_PRIM_*                       */
+  const int32_t* prim_flags;    /* [n_prims] ODW_FLAG_FLIP_NORMAL             */
+  const double*  prim_xform;    /* [n_prims*12] global->local rows (R|t)      */
+  const double*  prim_params;   /* [n_prims*4]                                */
+  const int32_t* prim_cond_off; /* [n_prims+1]                                */
+  int32_t n_conds;
+  const int32_t* cond_prim;     /* [n_conds] index into THIS primitive list   */
+  const int32_t* cond_inside;   /* [n_conds]                                  */
+  int32_t n_faces;
+  const int32_t* face_prim;     /* [n_faces]                                  */
+  const int32_t* face_id;       /* [n_faces] face bit position (see above)    */
+  const double*  face_area;     /* [n_faces] area of the UNTRIMMED face       */
+  int32_t n_t_knots;
+  const double* t_edges;        /* [n_t_knots] theta                          */
+  const double* t_cdf;          /* [n_t_knots] / last entry                   */
+} odw_surface_source_desc;
+
 /* Ray.traceRay keyword arguments + settings (ray.py:36-73, 283-288).        */
 typedef struct odw_limits {
   double max_ray_length;    /* MaxRayLengthScale * settings.MaxRayLength      */
@@ -220,6 +256,9 @@ const char* odw_last_error(const odw_ctx* ctx); /* NULL ctx: global message */
 int odw_upload_scene(odw_ctx* ctx, const odw_scene_desc* scene);
 /* replaces PointSourceProxy._getVrv/_rvArgs result, point_source.py:277-386 */
 int odw_upload_source(odw_ctx* ctx, const odw_source_desc* source);
+/* replaces SurfaceSourceProxy._generateRays(mode='true'), surface_source.py:519-553;
+ * the most recently uploaded source (point or surface) feeds odw_trace      */
+int odw_upload_surface_source(odw_ctx* ctx, const odw_surface_source_desc* source);
 /* replaces OpticalGroupProxy._getVrv + per-hit compile, optical_group.py:212-323;
  * call after odw_upload_scene (which clears them); n = 0 clears             */
 int odw_upload_surface_samplers(odw_ctx* ctx, const odw_surface_sampler_desc* samplers,
@@ -227,6 +266,10 @@ int odw_upload_surface_samplers(odw_ctx* ctx, const odw_surface_sampler_desc* sa
 /* Philox key of the surface draws in odw_trace_rays launches (odw_trace uses
  * its own seed argument); default 0                                         */
 int odw_set_surface_seed(odw_ctx* ctx, uint64_t seed);
+/* wavelength (nm) of the following launches: Ray(..., wavelength=...) of
+ * ReplaySourceProxy._generateRays (replay_source.py:155); odw_upload_source
+ * resets it to the source's own                                              */
+int odw_set_wavelength(odw_ctx* ctx, double wavelength_nm);
 int odw_set_limits(odw_ctx* ctx, const odw_limits* limits);
 int odw_set_detector(odw_ctx* ctx, const odw_detector_desc* det);
 /* capacity of the device hit list in rows (0 frees it)                     */
@@ -256,6 +299,11 @@ int odw_fetch_histogram(odw_ctx* ctx, uint64_t* out, uint64_t n_bins);
 /* sampler only (diagnostics/tests): theta-or-radius and phi of each ray    */
 int odw_sample(odw_ctx* ctx, uint64_t first_ray, uint64_t n_rays, uint64_t seed,
                double* theta_out, double* phi_out);
+
+/* initial conditions only ("returnInitialConditions", generic_source.py:57):
+ * origin and direction [n*3] of each ray of the uploaded source             */
+int odw_generate_rays(odw_ctx* ctx, uint64_t first_ray, uint64_t n_rays, uint64_t seed,
+                      double* origins, double* directions);
 
 /* device-side handles for collectives (RCCL reduce through torch)          */
 int odw_device_histogram(odw_ctx* ctx, void** dptr, uint64_t* n_bins);

@@ -54,6 +54,14 @@ class DetectorDesc(C.Structure):
               ('y_lo', C.c_double), ('y_hi', C.c_double), ('nx', C.c_int32), ('ny', C.c_int32)]
 
 
+class SurfaceSourceDesc(C.Structure):
+  _fields_ = [('wavelength', C.c_double), ('power', C.c_double), ('dist_tol', C.c_double),
+              ('n_prims', C.c_int32), ('prim_type', _pi), ('prim_flags', _pi), ('prim_xform', _pd),
+              ('prim_params', _pd), ('prim_cond_off', _pi), ('n_conds', C.c_int32), ('cond_prim', _pi),
+              ('cond_inside', _pi), ('n_faces', C.c_int32), ('face_prim', _pi), ('face_id', _pi),
+              ('face_area', _pd), ('n_t_knots', C.c_int32), ('t_edges', _pd), ('t_cdf', _pd)]
+
+
 class SurfaceSamplerDesc(C.Structure):
   _fields_ = [('group', C.c_int32), ('kind', C.c_int32), ('family_axis', C.c_int32), ('n_family', C.c_int32),
               ('family_lo', C.c_double), ('family_hi', C.c_double), ('n_phi_knots', C.c_int32),
@@ -300,3 +308,41 @@ def nearest(sc, lim, start, direction, medium=-1, seq_idx=0):
 
 def threads():
   return int(lib().odw_oracle_threads())
+
+
+def surface_source_desc(src):
+  """odw_surface_source_desc for a freecad_elements.surface_source.BakedSurfaceSource"""
+  keep = dict(prim_type=_arr(src.prim_type, np.int32), prim_flags=_arr(src.prim_flags, np.int32),
+              prim_xform=_arr(src.prim_xform, np.float64), prim_params=_arr(src.prim_params, np.float64),
+              prim_cond_off=_arr(src.prim_cond_off, np.int32),
+              cond_prim=_arr(src.cond_prim if len(src.cond_prim) else [0], np.int32),
+              cond_inside=_arr(src.cond_inside if len(src.cond_inside) else [0], np.int32),
+              face_prim=_arr(src.face_prim, np.int32), face_id=_arr(src.face_id, np.int32),
+              face_area=_arr(src.face_area, np.float64), t_edges=_arr(src.t_edges, np.float64),
+              t_cdf=_arr(src.t_cdf, np.float64))
+  d = SurfaceSourceDesc()
+  d.wavelength, d.power, d.dist_tol = float(src.wavelength), float(src.power), float(src.dist_tol)
+  d.n_prims, d.n_conds, d.n_faces = len(keep['prim_type']), len(src.cond_prim), len(keep['face_prim'])
+  d.n_t_knots = len(keep['t_edges'])
+  for name, typ in SurfaceSourceDesc._fields_:
+    if name in keep:
+      setattr(d, name, keep[name].ctypes.data_as(typ))
+  return _Keep(d, keep)
+
+
+def surface_rays(src, first, n, seed):
+  """initial conditions of a surface source (odw_oracle_surface_rays)"""
+  s = surface_source_desc(src)
+  o = np.empty((n, 3))
+  d = np.empty((n, 3))
+  rc = lib().odw_oracle_surface_rays(C.byref(s.desc), C.c_uint64(first), C.c_uint64(n), C.c_uint64(seed),
+                                     _p(o, _pd), _p(d, _pd))
+  if rc != 0:
+    raise RuntimeError(f'odw_oracle_surface_rays failed: {rc}')
+  return o, d
+
+
+def trace_surface(sc, src, lim, first, n, seed, **kw):
+  """surface source + trace: rays `first`.. of stream `seed`, surface draws keyed by the same seed"""
+  o, d = surface_rays(src, first, n, seed)
+  return trace_rays(sc, lim, o, d, wavelength=src.wavelength, first=first, surface_seed=seed, **kw)

@@ -899,6 +899,127 @@ int odw_oracle_make_rays(const odw_source_desc* src, uint64_t first, uint64_t n,
   return ODW_OK;
 }
 
+/* ------------------------------------------------------------------ */
+/* SurfaceSourceProxy._generateRays(mode='true')                       */
+/* (surface_source.py:519-553, _makeRay :87-108) on analytic faces;    */
+/* sampling rule and Philox counters: include/odw_trace.h,             */
+/* odw_surface_source_desc.                                            */
+/* ------------------------------------------------------------------ */
+static void philox_pair(uint64_t ray, uint64_t seed, uint32_t c2, uint32_t c3, double* a, double* b) {
+  uint32_t ctr[4] = {(uint32_t)ray, (uint32_t)(ray >> 32), c2, c3};
+  uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  uint32_t w[4];
+  odw_oracle_philox(ctr, key, w);
+  *a = u53(w[0], w[1]);
+  *b = u53(w[2], w[3]);
+}
+
+static double face_point(int type, const double* par, int face, double ua, double ub, v3* p, v3* n, v3* t) {
+  const double two_pi = 6.283185307179586;
+  if (type == ODW_PRIM_BOX) {
+    int a = face >> 1, b1 = (a + 1) % 3, b2 = (a + 2) % 3;
+    double c[3], nn[3] = {0, 0, 0}, tt[3] = {0, 0, 0};
+    c[a] = (face & 1) ? par[a] : 0.0;
+    c[b1] = ua * par[b1];
+    c[b2] = ub * par[b2];
+    nn[a] = (face & 1) ? 1.0 : -1.0;
+    tt[b1] = 1.0;
+    *p = V(c[0], c[1], c[2]); *n = V(nn[0], nn[1], nn[2]); *t = V(tt[0], tt[1], tt[2]);
+    return 1.0;
+  }
+  double sa = sin(two_pi * ua), ca = cos(two_pi * ua);
+  if (type == ODW_PRIM_SPHERE) {
+    double z = 2.0 * ub - 1.0, r = sqrt(fmax(0.0, 1.0 - z * z));
+    *n = V(r * ca, r * sa, z);
+    *p = mul(*n, par[0]);
+    *t = V(-sa, ca, 0.0);
+    return 1.0;
+  }
+  if (type == ODW_PRIM_TORUS) {
+    double sv = sin(two_pi * ub), cv = cos(two_pi * ub);
+    double rho = par[0] + par[1] * cv;
+    *p = V(rho * ca, rho * sa, par[1] * sv);
+    *n = V(cv * ca, cv * sa, sv);
+    *t = V(-sa, ca, 0.0);
+    return rho / (par[0] + par[1]);
+  }
+  double r1 = par[0], r2 = (type == ODW_PRIM_CONE) ? par[1] : par[0];
+  double h = (type == ODW_PRIM_CONE) ? par[2] : par[1];
+  if (face == 0) {
+    double z;
+    if (r1 == r2) z = h * ub;
+    else z = h * (sqrt(r1 * r1 + ub * (r2 * r2 - r1 * r1)) - r1) / (r2 - r1);
+    double k = (r2 - r1) / h, r = r1 + k * z;
+    double inv = 1.0 / sqrt(1.0 + k * k);
+    *p = V(r * ca, r * sa, z);
+    *n = V(ca * inv, sa * inv, -k * inv);
+    *t = V(-sa, ca, 0.0);
+    return 1.0;
+  }
+  double rr = (face == 1 ? r1 : r2) * sqrt(ub);
+  *p = V(rr * ca, rr * sa, face == 1 ? 0.0 : h);
+  *n = V(0.0, 0.0, face == 1 ? -1.0 : 1.0);
+  *t = V(1.0, 0.0, 0.0);
+  return 1.0;
+}
+
+static v3 xf_vec_inv(const double* m, v3 v) { /* R^T v */
+  return V(m[0] * v.x + m[4] * v.y + m[8] * v.z, m[1] * v.x + m[5] * v.y + m[9] * v.z,
+           m[2] * v.x + m[6] * v.y + m[10] * v.z);
+}
+
+int odw_oracle_surface_rays(const odw_surface_source_desc* s, uint64_t first, uint64_t n, uint64_t seed,
+                            double* origins, double* dirs) {
+  if (!s || s->n_faces < 1) return ODW_ERR_INVALID;
+  double total = 0;
+  for (int f = 0; f < s->n_faces; ++f) total += s->face_area[f];
+  double* cdf = (double*)malloc(((size_t)s->n_faces + 1) * sizeof(double));
+  double run = 0;
+  cdf[0] = 0;
+  for (int f = 0; f < s->n_faces; ++f) { run += s->face_area[f]; cdf[f + 1] = run / total; }
+  cdf[s->n_faces] = 1.0;
+  for (uint64_t i = 0; i < n; ++i) {
+    uint64_t ray = first + i;
+    v3 gp = V(0, 0, 0), gn = V(0, 0, 1), gt = V(1, 0, 0);
+    for (uint32_t attempt = 0; attempt < 4096; ++attempt) {
+      double u_face, u_acc, ua, ub;
+      philox_pair(ray, seed, attempt, 3u, &u_face, &u_acc);
+      philox_pair(ray, seed, attempt, 4u, &ua, &ub);
+      int f = 0;
+      while (f + 1 < s->n_faces && u_face >= cdf[f + 1]) ++f;
+      int prim = s->face_prim[f], face = s->face_id[f];
+      const double* m = s->prim_xform + 12 * (size_t)prim;
+      v3 p, nl, tl;
+      double accept = face_point(s->prim_type[prim], s->prim_params + 4 * (size_t)prim, face, ua, ub, &p, &nl, &tl);
+      if (u_acc >= accept) continue;
+      if (s->prim_flags[prim] & ODW_FLAG_FLIP_NORMAL) nl = mul(nl, -1.0);
+      gp = xf_vec_inv(m, V(p.x - m[3], p.y - m[7], p.z - m[11]));
+      int ok = 1;
+      for (int c = s->prim_cond_off[prim]; c < s->prim_cond_off[prim + 1] && ok; ++c) {
+        int qp = s->cond_prim[c];
+        double sd = prim_sdist(s->prim_type[qp], s->prim_params + 4 * (size_t)qp,
+                               xf_point(s->prim_xform + 12 * (size_t)qp, gp));
+        if (s->cond_inside[c]) { if (sd > s->dist_tol) ok = 0; }
+        else { if (sd < -s->dist_tol) ok = 0; }
+      }
+      if (!ok) continue;
+      gn = xf_vec_inv(m, nl);
+      gt = xf_vec_inv(m, tl);
+      break;
+    }
+    double u_t, u_phi;
+    philox_pair(ray, seed, 0u, 5u, &u_t, &u_phi);
+    double theta = odw_oracle_interp(u_t, s->t_cdf, s->t_edges, s->n_t_knots);
+    double phi = 6.283185307179586 * u_phi;
+    v3 d = rotate(gn, phi, rotate(gt, theta, gn));
+    d = mul(d, 1.0 / len(d));
+    origins[3 * i] = gp.x; origins[3 * i + 1] = gp.y; origins[3 * i + 2] = gp.z;
+    dirs[3 * i] = d.x; dirs[3 * i + 1] = d.y; dirs[3 * i + 2] = d.z;
+  }
+  free(cdf);
+  return ODW_OK;
+}
+
 /* single nearest-hit query, for unit tests of the geometry */
 int odw_oracle_nearest(const odw_scene_desc* sc, const odw_limits* lim, const double* start,
                        const double* dir, int medium, int seq_idx, int* prim, int* face,

@@ -361,6 +361,34 @@ def make_pseudo(rng):
   np.savez_compressed(os.path.join(OUT, 'pseudo_draws.npz'), **out)
 
 
+# SurfaceSourceProxy draws theta from ScalarRandomVariable(**_rvArgs(..., scalarRandomVar=True))
+# (surface_source.py:531, point_source.py:371-386): no Jacobian, one variable
+SCALAR_CASES = [
+  ('lambert_cos2', 'cos(theta)**2', (0, np.pi / 4), 1e5),          # test/21-simulation-modes/main.FCStd
+  ('gauss', 'exp(-theta**2/0.05)', (0, np.pi / 2), 20001),
+  ('const', '1', (0.1, 1.2), 1001),
+]
+
+
+def make_scalar(rng):
+  out = {}
+  N = 4096
+  for name, dens, dom, res in SCALAR_CASES:
+    srv = rng.ScalarRandomVariable(probabilityDensity=dens, variable='theta', variableDomain=dom,
+                                   numericalResolution=res)
+    srv.compile(disableAnalytical=True)
+    assert srv.mode() == 'numeric'
+    np.random.seed(21)
+    th = np.asarray(srv.draw(N=N), dtype=np.float64)
+    np.random.seed(21)
+    u = np.random.random_sample(N)
+    out[name + '_theta'] = th
+    out[name + '_u'] = u
+    out[name + '_args'] = np.array(json.dumps(dict(density=dens, domain=dom, res=res)))
+    print('scalar', name, th[:3])
+  np.savez_compressed(os.path.join(OUT, 'scalar_draws.npz'), **out)
+
+
 def fan_math_inputs():
   """synthetic fan-mode hit sets on the plane z = 30: two fans x 21 rays on
   gently bent lines, with duplicates (two hits of one ray), missing rays and,
@@ -430,3 +458,4 @@ if __name__ == '__main__':
   make_surface(rng)
   make_pseudo(rng)
   make_fan_math(hits)
+  make_scalar(rng)

@@ -27,6 +27,10 @@ SCENES = {
   'lens-overlap': 'test/50-old-tests/lens-overlap.FCStd',
   'global-placement-main': 'test/22-global-placement/main.FCStd',
   'nested-structure': 'test/22-global-placement/nested-structure.FCStd',
+  'simulation-modes-main': 'test/21-simulation-modes/main.FCStd',
+  'mirror-diffuse': 'test/50-old-tests/mirror-diffuse.FCStd',
+  'playground': 'test/50-old-tests/playground.FCStd',
+  'grating': 'test/50-old-tests/grating.FCStd',
 }
 
 if __name__ == '__main__':
