@@ -367,8 +367,11 @@ __device__ __forceinline__ void intersect_prim(const SceneView& sv, Query& q, in
     // inside the face rectangle (+- tol).  All faces of a primitive share its
     // group, so without trimming conditions only the nearest valid hit can be
     // selected: the three entry faces are tried first, the three exit faces
-    // only if no entry face qualifies (ray starts inside / on the box) or the
-    // box is trimmed (a nearer candidate may then be rejected by its trim).
+    // only if no entry face qualifies (ray starts inside / on the box), the
+    // box is trimmed (a nearer candidate may then be rejected by its trim), or
+    // the ray misses the exact box (last entry plane behind the first exit
+    // plane): passing an edge within the tolerance it can meet the widened
+    // rectangle of an exit face before that of an entry face.
     const double ix = frcp(d.x), iy = frcp(d.y), iz = frcp(d.z);
     const double ax = -o.x * ix, ay = -o.y * iy, az = -o.z * iz;            // plane at 0
     const double bx = fma(par[0], ix, ax), by = fma(par[1], iy, ay), bz = fma(par[2], iz, az);
@@ -389,7 +392,9 @@ __device__ __forceinline__ void intersect_prim(const SceneView& sv, Query& q, in
     ODW_BOX_FACE(pz ? az : bz, pz ? 4 : 5, o.x, d.x, par[0], o.y, d.y, par[1]);
     c.t0 = bt;
     c.f0 = bf;
-    if (cond_cnt || !(bt < INFINITY)) {
+    const double t_in = fmax(fmax(px ? ax : bx, py ? ay : by), pz ? az : bz);
+    const double t_out = fmin(fmin(px ? bx : ax, py ? by : ay), pz ? bz : az);
+    if (cond_cnt || !(bt < INFINITY) || !(t_in < t_out)) {
       bt = INFINITY;
       bf = 0;
       ODW_BOX_FACE(px ? bx : ax, px ? 1 : 0, o.y, d.y, par[1], o.z, d.z, par[2]);

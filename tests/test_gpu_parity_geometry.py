@@ -299,3 +299,28 @@ def test_stochastic_mirror_seeded_launch(tracer, oracle):
   ref2 = oracle.trace(sc2, bs, lim, 5000, 1000, 77, det=det)
   assert tracer.counters() == ref2['counters']
   tracer.setDetector(None)
+
+
+def test_box_edges_within_tolerance(tracer, oracle):
+  """DistanceTolerance 1e-2 (test/50-old-tests/playground.FCStd): a ray that
+  passes a box edge within the tolerance meets the widened rectangle of an
+  exit face before that of an entry face; the nearest of ALL six faces counts"""
+  sc, lim = build([
+      ('Mirror', lambda d: [make.makeBox(d, 'B1', 10, 8, 1, base=(-5, -4, 0), quat=quat((1, 2, 0), 17))], {}),
+      ('Lens', lambda d: [make.makeBox(d, 'B2', 6, 6, 6, base=(10, -3, -3), quat=quat((0, 1, 1), 31))],
+       dict(RefractiveIndex=1.4)),
+      ('Absorber', lambda d: [make.makeBox(d, 'Wall', 300, 300, 1, base=(-150, -150, -40))], {}),
+  ], settings=dict(DistanceTolerance='1e-2', MaxIntersections=20))
+  assert lim.dist_tol == 1e-2
+  # targets on the edges and corners of both boxes
+  targets = []
+  for p in (0, 1):
+    tw, size = sc.prim_to_world[p], sc.prim_params[p][:3]
+    for a in np.linspace(0, 1, 9):
+      for e in ((a, 0, 0), (a, 1, 0), (a, 0, 1), (a, 1, 1), (0, a, 0), (1, a, 0), (0, a, 1), (1, a, 1),
+                (0, 0, a), (1, 0, a), (0, 1, a), (1, 1, a)):
+        targets.append(tw * (np.array(e) * size))
+  o, d = aimed_rays(60000, targets, 0.02, 5, radius=40.0)
+  g, gc, r, rc = run_both(tracer, oracle, sc, lim, o, d)
+  assert rc['recorded_hits'] > 40000
+  assert_same_short_paths(g, gc, r, rc, len(o), max_len=20)
