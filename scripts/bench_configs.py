@@ -69,6 +69,17 @@ def main():
     r['config'] = name
     print(json.dumps(r), flush=True)
     out.append(r)
+  # the reference's test scenes for the rows SURVEY 8(f) marks "next": stochastic
+  # surfaces (STOCH kernel), surface source (emit kernel + explicit-ray trace), gratings
+  for name, scene in (('N3 mirror-diffuse (cos^2 diffuse mirror, parallel beam)', 'mirror-diffuse'),
+                      ('N3 grating (reflection grating)', 'grating'),
+                      ('N3 playground (lens + mirror, tol 1e-2)', 'playground'),
+                      ('N4 simulation-modes-main (surface source, ball lens)', 'simulation-modes-main')):
+    proj = scenes.bakeProject(os.path.join(SC, scene + '.FCStd'))
+    r = run(tr, proj, int(2e7 * q), int(2e7 * q), None)
+    r['config'] = name
+    print(json.dumps(r), flush=True)
+    out.append(r)
   # C5: radius sweep, one re-bake per radius (host) + 1e7 rays each
   doc = open_fcstd(os.path.join(SC, 'GettingStarted.FCStd'))
   radii = np.linspace(9, 11, 64 if not args.quick else 8)
