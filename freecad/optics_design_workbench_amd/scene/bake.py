@@ -96,6 +96,62 @@ def globalPlacements(doc, obj, ignoreLinks=False):
   return [pl for pl, _ in allPlacementsAndPaths(doc, obj, ignoreLinks)]
 
 
+def allCoordinateTransformMatrices(doc, obj, ignoreLinks=False):
+  """[gpM, gpMi, pM, pMi] (4x4 arrays) per representation of obj
+  (freecad_elements/common.py:110-123)"""
+  own = obj.Placement if obj.hasProperty('Placement') else Placement.identity()
+  return [[pl.m.copy(), pl.inverse().m.copy(), own.m.copy(), own.inverse().m.copy()]
+          for pl, _ in allPlacementsAndPaths(doc, obj, ignoreLinks)]
+
+
+_GLOBAL_INFO_SKIP = set('Placement Proxy Shape ShapeMaterial ColoredElements ElementList ExpressionEngine '
+                        'LinkedChildren VisibilityList Visibility Height Length Width MapMode MapPathParameter '
+                        'MapReversed'.split())
+
+
+def _exportable(value):
+  """property values as the reference exports them (freecad_elements/__init__.py:55-91):
+  document objects by their exported properties, lists element-wise, other values as they are"""
+  from .fcstd import DocumentObject
+  if isinstance(value, DocumentObject):
+    return _propertiesToDict(value)
+  if isinstance(value, (list, tuple)):
+    return [_exportable(v) for v in value]
+  if isinstance(value, np.ndarray):
+    return value.copy()
+  if isinstance(value, Placement):
+    return str(value)
+  return value
+
+
+def _propertiesToDict(obj):
+  if obj is None:
+    return None
+  res = {k: _exportable(v) for k, v in obj._props.items()
+         if not k.startswith('_') and not k.startswith('Attach') and k not in _GLOBAL_INFO_SKIP}
+  res['Name'] = obj.Name
+  return res
+
+
+def collectGlobalInfo(doc):
+  """globally relevant info about the simulation project, the content of
+  `global-info.pkl` (freecad_elements/__init__.py:48-115): active settings,
+  light sources (placements without links) and optical objects with their
+  properties, placement paths and transformation matrices"""
+
+  def objToDict(obj, ignoreLinks=False):
+    props = _propertiesToDict(obj)
+    reps = allPlacementsAndPaths(doc, obj, ignoreLinks)
+    mats = allCoordinateTransformMatrices(doc, obj, ignoreLinks)
+    return dict(name=props.pop('Name'), label=props.pop('Label', obj.Name), properties=props,
+                placementPathsAndMatrices=[dict(path=list(path), gpM=m[0], gpMi=m[1], pM=m[2], pMi=m[3])
+                                           for (_, path), m in zip(reps, mats)])
+
+  return dict(activeSimulationSettings=_propertiesToDict(activeSimulationSettings(doc)),
+              lightSources=[objToDict(s, ignoreLinks=True) for s in lightSources(doc)],
+              opticalObjects=[objToDict(o) for o in opticalObjects(doc)])
+
+
 def tracingSequence(settings):
   """SimulationSettingsProxy.getTracingSequence (simulation_settings.py:158-196):
   non-empty SequentialModeElements_NN lists in ascending order"""

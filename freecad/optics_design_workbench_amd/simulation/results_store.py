@@ -59,6 +59,13 @@ def updateResultEntry(result, key, value):
     result[key] = np.concatenate([result[key], value], axis=0)
 
 
+def _atomic_pickle(path, obj):
+  tmp = f'{path}.tmp{os.getpid()}'
+  with open(tmp, 'wb') as f:
+    pickle.dump(obj, f)
+  os.replace(tmp, path)
+
+
 class SimulationResults:
 
   def __init__(self, simulationType, resultsPath=None, simulationRunFolder=None,
@@ -83,6 +90,45 @@ class SimulationResults:
     self.t0 = time.time()
     self._hits = {}          # (sourceName, sourceLabel, objName, objLabel) -> list of dicts
     self._flushed = {}       # same key -> merged dict kept for in-memory access
+
+  # -- global info, progress, status flags --------------------------------------
+  def dumpGlobalInfo(self, info):
+    """`global-info.pkl` of the run folder, written once (results_store.py:333-336)"""
+    if self.basePath is None:
+      return
+    path = os.path.join(self.runFolderPath(), 'global-info.pkl')
+    if not os.path.exists(path):
+      _atomic_pickle(path, info)
+
+  def dumpProgress(self):
+    """`progress/master-%09d` summary of the run (results_store.py:508-538):
+    counters + end criteria; files older than the last ten are removed"""
+    if self.basePath is None:
+      return
+    folder = os.path.join(self.runFolderPath(), 'progress')
+    os.makedirs(folder, exist_ok=True)
+    idx = getattr(self, '_masterProgressDumpIdx', 0)
+    _atomic_pickle(os.path.join(folder, f'master-{idx:09d}'),
+                   dict(simulationType=self.simulationType, totalIterations=self.totalIterations,
+                        totalTracedRays=self.totalTracedRays, totalRecordedHits=self.totalRecordedHits,
+                        totalRecordedRays=0, endAfterIterations=self.endAfterIterations,
+                        endAfterRays=self.endAfterRays, endAfterHits=self.endAfterHits))
+    old = os.path.join(folder, f'master-{idx - 10:09d}')
+    if os.path.exists(old):
+      os.remove(old)
+    self._masterProgressDumpIdx = idx + 1
+
+  def setStatus(self, name, state):
+    """flag files of the results folder: simulation-is-running / -canceled / -done
+    (simulation_loop.py:174-269)"""
+    if self.basePath is None:
+      return
+    path = os.path.join(self.basePath, name)
+    if state and not os.path.exists(path):
+      os.makedirs(self.basePath, exist_ok=True)
+      open(path, 'w').close()
+    elif not state and os.path.exists(path):
+      os.remove(path)
 
   def runFolderPath(self):
     return None if self.basePath is None else os.path.join(self.basePath, self.simulationRunFolder)
@@ -165,6 +211,18 @@ class RawFolder:
 
   def path(self):
     return os.path.relpath(self._path)
+
+  def loadGlobalInfo(self):
+    with open(os.path.join(self._path, 'global-info.pkl'), 'rb') as f:
+      return pickle.load(f)
+
+  def loadProgress(self):
+    """the latest `progress/master-*` summary (None if the run wrote none)"""
+    files = sorted(glob.glob(os.path.join(self._path, 'progress', 'master-*')))
+    if not files:
+      return None
+    with open(files[-1], 'rb') as f:
+      return pickle.load(f)
 
   def loadHits(self, pattern='*'):
     if pattern == '*':

@@ -75,7 +75,12 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
   rpi = float(settings._props.get('RaysPerIteration', 100)) if settings is not None else 100.0
   own = tracer is None
   tr = tracer or Tracer(device)
+  store.setStatus('simulation-is-done', False)
+  store.setStatus('simulation-is-canceled', False)
+  store.setStatus('simulation-is-running', True)
+  failed = True
   try:
+    store.dumpGlobalInfo(_bake.collectGlobalInfo(doc))
     baked = []
     for src in sources:
       scene = _bake.bakeScene(doc, src)
@@ -159,9 +164,15 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
         store.incrementRayCount(n)
         store.incrementIterationCount(iters)
       store.flush()
+      store.dumpProgress()
       if ended or not continuous or store.reachedEnd() or (endIf is not None and endIf(store)):
         break
+    failed = False
   finally:
+    # any exception cancels the run (simulation_loop.py:715-723)
+    store.setStatus('simulation-is-canceled', failed)
+    store.setStatus('simulation-is-done', not failed)
+    store.setStatus('simulation-is-running', False)
     if own:
       tr.close()
   return store
