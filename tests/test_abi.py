@@ -40,7 +40,9 @@ def test_struct_layouts():
   assert C.sizeof(_native.SourceDesc) == 12 * 8 + 3 * 8 + 8 + 16 + 8 + 16
   from oracle import capi
   for a, b in ((capi.SceneDesc, _native.SceneDesc), (capi.SourceDesc, _native.SourceDesc),
-               (capi.LimitsDesc, _native.LimitsDesc), (capi.DetectorDesc, _native.DetectorDesc)):
+               (capi.LimitsDesc, _native.LimitsDesc), (capi.DetectorDesc, _native.DetectorDesc),
+               (capi.SurfaceSamplerDesc, _native.SurfaceSamplerDesc),
+               (capi.SurfaceSourceDesc, _native.SurfaceSourceDesc)):
     assert C.sizeof(a) == C.sizeof(b)
     assert [f[0] for f in a._fields_] == [f[0] for f in b._fields_]
 

@@ -1,0 +1,131 @@
+"""Error behaviour of the C-ABI on a device: return codes instead of
+exceptions at the boundary (include/odw_trace.h), converted to exceptions by
+the binding like the reference raises ValueError / RuntimeError
+(ray.py:235-237, random_number_generator.py:344-358, simulation_loop.py:715-723).
+Edge cases: empty launches, overflowing hit lists, limits of the tables."""
+import copy
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import project
+from freecad.optics_design_workbench_amd import _native
+from freecad.optics_design_workbench_amd.freecad_elements import make
+from freecad.optics_design_workbench_amd.scene import Document, bake
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def tr(native_lib):
+  from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
+  t = Tracer(0)
+  yield t
+  t.close()
+
+
+def test_calls_before_upload_fail_loudly(tr):
+  with pytest.raises(_native.NativeError, match='no scene'):
+    tr.trace(0, 10, 1)
+  pr = project('minimal')
+  tr.setScene(pr.scene)
+  tr.setLimits(pr.limits)
+  with pytest.raises(_native.NativeError, match='source'):
+    tr.trace(0, 10, 1)                       # no source yet
+  with pytest.raises(_native.NativeError):
+    tr.sample(0, 10, 1)
+  tr.setSource(pr.source)
+  with pytest.raises(_native.NativeError, match='capacity'):
+    tr.trace(0, 10, 1)                       # hit rows requested, no hit list reserved
+  tr.trace(0, 10, 1, record_hits=False)      # fine without rows
+  tr.sync()
+  assert tr.counters()['traced_rays'] == 10
+  with pytest.raises(ValueError):
+    tr.histogram()                           # no detector set
+
+
+def test_invalid_tables_are_rejected(tr, native_lib):
+  pr = project('minimal')
+  bad = copy.copy(pr.scene)
+  bad.prim_group = pr.scene.prim_group + 7   # group index out of range
+  with pytest.raises(_native.NativeError, match='invalid'):
+    tr.setScene(bad)
+  bad = copy.copy(pr.scene)
+  bad.prim_type = np.full_like(pr.scene.prim_type, 9)
+  with pytest.raises(_native.NativeError, match='unsupported'):
+    tr.setScene(bad)
+  src = copy.copy(pr.source)
+  src.tables = copy.copy(pr.source.tables)
+  src.tables.phi_cdf = pr.source.tables.phi_cdf * 0.5       # does not end at 1
+  with pytest.raises(_native.NativeError, match='invalid'):
+    tr.setSource(src)
+  lim = copy.copy(pr.limits)
+  lim.dist_tol = 0.0
+  with pytest.raises(_native.NativeError):
+    tr.setLimits(lim)
+  with pytest.raises(_native.NativeError):
+    tr.setDetector(dict(group=0, origin=[0, 0, 0], ex=[1, 0, 0], ey=[0, 1, 0], x_lo=1, x_hi=-1, y_lo=0, y_hi=1,
+                        nx=4, ny=4))
+  ctx = C.c_void_p()
+  assert native_lib.odw_create(99, C.byref(ctx)) == 1         # bad device index
+  assert native_lib.odw_create(0, None) == 1
+  assert native_lib.odw_trace(None, 0, 1, 1, 0) == 1
+  assert native_lib.odw_last_error(None)
+
+
+def test_empty_and_overflowing_launches(tr, oracle):
+  pr = project('lensesAndMirrors')
+  tr.setScene(pr.scene); tr.setSource(pr.source); tr.setLimits(pr.limits)
+  tr.reserveHits(1000)
+  tr.reset()
+  tr.trace(0, 0, 1)                          # empty launch: nothing happens
+  tr.sync()
+  assert tr.counters()['traced_rays'] == 0 and len(tr.hits()) == 0
+  tr.trace(0, 5000, 1)                       # more hits than capacity: dropped and counted, never written
+  tr.sync()
+  c = tr.counters()
+  assert c['recorded_hits'] > 4900 and c['hits_dropped'] == c['recorded_hits'] - 1000
+  h = tr.hits()
+  assert len(h) == 1000
+  ref = oracle.trace(pr.scene, pr.source, pr.limits, 0, 5000, 1)
+  assert c['recorded_hits'] == ref['counters']['recorded_hits']
+  # the kept rows are rows of the full result (which ones is scheduling dependent)
+  full = {(int(t), round(float(p[0]), 6)) for t, p in zip(ref['hits']['tag'], ref['hits']['point'])}
+  assert all((int(t), round(float(p[0]), 6)) in full for t, p in zip(h['tag'], h['point']))
+  tr.resetHits()
+  assert tr.hitCount() == 0 and tr.counters()['recorded_hits'] == c['recorded_hits']   # counters keep running
+  # a single ray, the last index of a 2^40 window
+  tr.trace((1 << 40) - 1, 1, 1)
+  tr.sync()
+  assert tr.counters()['traced_rays'] == 5001
+
+
+def test_group_and_sequence_limits(tr, oracle):
+  """64 optical groups (ODW_MAX_GROUPS, the width of the relevance masks) and a
+  100-step sequence (ODW_MAX_SEQUENCE); one more group is rejected on the host"""
+  doc = Document()
+  groups = []
+  for i in range(64):
+    kind = 'Vacuum' if i < 63 else 'Absorber'
+    groups.append(make.makeOpticalGroup(doc, kind, [make.makeBox(doc, f'B{i}', 10, 10, 0.5, base=(-5, -5, 5 + 2 * i))],
+                                        name=f'G{i}', RecordHits=True))
+  seq = {f'SequentialModeElements_{i:02d}': [groups[i]] for i in range(64)}
+  make.makeSimulationSettings(doc, SequentialMode=True, MaxIntersections=200.0, **seq)
+  src = make.makePointSource(doc, PowerDensity='exp(-theta**2/1e-4)')
+  from freecad.optics_design_workbench_amd.freecad_elements import point_source
+  sc, lim, bs = bake.bakeScene(doc, src), bake.bakeLimits(doc, src), point_source.bakeSource(doc, src)
+  assert sc.n_groups == 64 and len(sc.seq_mask) == 64 and sc.n_prims == 64
+  tr.setScene(sc); tr.setSource(bs); tr.setLimits(lim); tr.setDetector(None)
+  n = 2000
+  tr.reserveHits(n * 70)
+  tr.reset()
+  tr.trace(0, n, 3)
+  tr.sync()
+  g, gc = tr.hits(), tr.counters()
+  ref = oracle.trace(sc, bs, lim, 0, n, 3, hit_capacity=n * 70)
+  assert gc == ref['counters'] and gc['recorded_hits'] == 64 * n     # each step's plate once: entering only
+  assert np.array_equal(g['tag'], ref['hits']['tag'])
+  make.makeOpticalGroup(doc, 'Vacuum', [make.makeBox(doc, 'B64')], name='G64')
+  with pytest.raises(ValueError):
+    bake.bakeScene(doc, src)
