@@ -13,7 +13,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 
-from freecad.optics_design_workbench_amd import scenes
+from freecad.optics_design_workbench_amd import _native, scenes
+
+if os.environ.get('ODW_VARIANT_LIB'):      # kernel experiments: a library built with other -D flags
+  _native.LIB_PATH = os.path.abspath(os.environ['ODW_VARIANT_LIB'])
 from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
 
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 100000000
@@ -45,6 +48,8 @@ def run(label, record_hits=True, histogram=True, cap=None, reps=3):
 
 
 run('full')
+if os.environ.get('ODW_ABLATE_QUICK'):
+  sys.exit(0)
 run('no hit rows', record_hits=False)
 run('no histogram', histogram=False)
 run('no recording at all', record_hits=False, histogram=False)
