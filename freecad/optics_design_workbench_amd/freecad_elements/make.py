@@ -31,7 +31,10 @@ _SETTINGS_DEFAULTS = dict(
     Active=True, EnableStoreSingleShotData=False, EndAfterIterations='inf', EndAfterRays='1e4',
     EndAfterHits='inf', RaysPerIteration=100.0, MaxIntersections=100.0, DistanceTolerance='1e-6',
     MaxRayLength=1000.0, ShowRaysInContinuousMode=True, WorkerProcessCount='num_cpus',
-    SequentialMode=False, SequentialModeElements_00=[])
+    SequentialMode=False, SequentialModeElements_00=[],
+    StoreHitInitPoint=False, StoreHitInitDirection=False, StoreHitInitPower=False, StoreHitInitWavelength=False,
+    StoreHitInitPhi=False, StoreHitInitTheta=False, StoreHitRayIndex=False, StoreHitFanIndex=False,
+    StoreHitTotalFanCount=False, StoreHitTotalRaysInFan=False)
 
 
 def _placement(base=(0, 0, 0), quat=(0, 0, 0, 1), placement=None):

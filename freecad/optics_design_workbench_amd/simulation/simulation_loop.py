@@ -73,6 +73,7 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
   if not sources:
     raise ValueError('document has no light source')
   rpi = float(settings._props.get('RaysPerIteration', 100)) if settings is not None else 100.0
+  enabled = enabledHitMetadata(settings)
   own = tracer is None
   tr = tracer or Tracer(device)
   store.setStatus('simulation-is-done', False)
@@ -100,7 +101,10 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
             continue
           iters = 1 if not continuous else _iterations_for_launch(store, per_iter, raysPerLaunch)
           o, d, wl, pw = bsrc.take(iters * per_iter)
-          n, iters, meta = len(o), max(1, -(-len(o) // per_iter)), None
+          n, iters = len(o), max(1, -(-len(o) // per_iter))
+          order = np.concatenate([np.nonzero(wl == w)[0] for w in np.unique(wl)]) if n else np.zeros(0, int)
+          per_ray = dict(initPoint=o[order], initDirection=d[order], initPower=pw[order], initWavelength=wl[order])
+          base = first[src.Name]
           if n:
             tr.reserveHits(max(16, n * (lim.max_intersections + 1)))
             tr.reset()
@@ -131,8 +135,10 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
           tr.setSurfaceSeed(seed)
           tr.traceRays(o, d)
           tr.sync()
-          n, iters = len(rays), 1
-          meta = [r[2] for r in rays]
+          n, iters, base = len(rays), 1, 0
+          per_ray = dict(initPoint=o, initDirection=d, initPower=np.ones(n), initWavelength=np.full(n, bsrc.wavelength))
+          for key in ('fanIndex', 'rayIndex', 'totalFanCount', 'totalRaysInFan', 'initPhi', 'initTheta'):
+            per_ray[key] = np.array([r[2][key] for r in rays])
         elif pseudo and isinstance(bsrc, point_source.BakedSource):
           # (surface sources treat 'pseudo' like 'true', surface_source.py:521)
           iters = 1 if not continuous else min(pseudoIterationsPerLaunch,
@@ -144,9 +150,12 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
           tr.reserveHits(max(16, n * (lim.max_intersections + 1)))
           tr.reset()
           tr.setSurfaceSeed(seed)
-          tr.traceRays(np.array([r[0] for r in rays]), np.array([r[1] for r in rays]), first=first[src.Name])
+          o, d = np.array([r[0] for r in rays]), np.array([r[1] for r in rays])
+          tr.traceRays(o, d, first=first[src.Name])
           tr.sync()
-          meta = None
+          base = first[src.Name]
+          per_ray = dict(initPoint=o, initDirection=d, initPower=np.ones(n), initWavelength=np.full(n, bsrc.wavelength),
+                         initPhi=ang[1], initTheta=ang[0] if np.isfinite(bsrc.focal_length) else np.full(n, np.nan))
         else:
           tr.setSource(bsrc)
           iters = 1 if not continuous else _iterations_for_launch(store, per_iter, raysPerLaunch)
@@ -155,12 +164,13 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
           tr.reset()
           tr.trace(first[src.Name], n, seed)
           tr.sync()
-          meta = None
+          base = first[src.Name]
+          per_ray = _DeviceInitialConditions(tr, bsrc, base, n, seed)
         first[src.Name] += n
         cnt = tr.counters()
         if cnt['hits_dropped']:
           raise RuntimeError(f'{cnt["hits_dropped"]} hit rows did not fit the device buffer')
-        _store_hits(store, tr.hits(), scene, src, meta)
+        _store_hits(store, tr.hits(), scene, src, per_ray, base, enabled)
         store.incrementRayCount(n)
         store.incrementIterationCount(iters)
       store.flush()
@@ -200,17 +210,61 @@ def _iterations_for_launch(store, per_iter, raysPerLaunch):
   return max(1, need)
 
 
-def _store_hits(store, rows, scene, src, meta):
+_METADATA_KEYS = ('initPoint', 'initDirection', 'initPower', 'initWavelength', 'initPhi', 'initTheta', 'rayIndex',
+                  'fanIndex', 'totalFanCount', 'totalRaysInFan')
+
+
+def enabledHitMetadata(settings):
+  """metadata keys stored with every hit: the `StoreHit<Key>` switches of the
+  active simulation settings (ray.py:55-65, simulation_settings.py:55-76);
+  without a settings object nothing is stored (ray.py:74-75)"""
+  if settings is None:
+    return ()
+  on = {k[8:].lower() for k, v in settings._props.items() if k.startswith('StoreHit') and v}
+  return tuple(k for k in _METADATA_KEYS if k.lower() in on)
+
+
+class _DeviceInitialConditions:
+  """initial conditions of device-generated rays, recomputed on demand from the
+  counter-based stream (the reference carries them along in Ray.metadata)"""
+
+  def __init__(self, tracer, bsrc, first, n, seed):
+    self._tr, self._src, self._first, self._n, self._seed = tracer, bsrc, first, n, seed
+    self._cache = {}
+
+  def __contains__(self, key):
+    if key in ('initPoint', 'initDirection', 'initPower', 'initWavelength'):
+      return True
+    return key in ('initPhi', 'initTheta') and isinstance(self._src, point_source.BakedSource)
+
+  def __getitem__(self, key):
+    if key in ('initPoint', 'initDirection'):
+      if 'rays' not in self._cache:
+        self._cache['rays'] = self._tr.generateRays(self._first, self._n, self._seed)
+      return self._cache['rays'][0 if key == 'initPoint' else 1]
+    if key in ('initPhi', 'initTheta'):
+      if 'angles' not in self._cache:
+        self._cache['angles'] = self._tr.sample(self._first, self._n, self._seed)
+      t, phi = self._cache['angles']
+      if key == 'initPhi':
+        return phi
+      return t if np.isfinite(self._src.focal_length) else np.full(self._n, np.nan)
+    if key == 'initPower':
+      return np.full(self._n, self._src.power)
+    if key == 'initWavelength':
+      return np.full(self._n, self._src.wavelength)
+    raise KeyError(key)
+
+
+def _store_hits(store, rows, scene, src, per_ray, base, enabled):
   tags = rows['tag']
   grp = ((tags >> np.uint64(48)) & np.uint64(0x7FFF)).astype(np.int64)
-  ray = (tags & np.uint64(0xFFFFFFFFFFFF)).astype(np.int64)
+  ray = (tags & np.uint64(0xFFFFFFFFFFFF)).astype(np.int64) - int(base)
+  keys = [k for k in enabled if k in per_ray]
+  columns = {k: per_ray[k] for k in keys}
   for g in np.unique(grp):
     sel = grp == g
-    extra = {}
-    if meta is not None:
-      # fan metadata of the ray each hit belongs to (ray.py:57-65 StoreHit* keys)
-      for key in ('fanIndex', 'rayIndex', 'totalFanCount', 'totalRaysInFan'):
-        extra[key] = np.array([meta[i][key] for i in ray[sel]])
+    extra = {k: np.asarray(v)[ray[sel]] for k, v in columns.items()}
     store.addRayHits(src.Name, src._props.get('Label', src.Name), scene.group_names[g],
                      scene.group_labels[g], rows['point'][sel], rows['direction'][sel],
                      rows['power'][sel], (tags[sel] >> np.uint64(63)).astype(np.int64), **extra)

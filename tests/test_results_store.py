@@ -101,11 +101,32 @@ def test_run_simulation_end_criteria_on_device(native_lib, tmp_path):
   store = runSimulation(doc, 'singletrue')
   assert store.totalTracedRays == 100 and store.totalIterations == 1
   store = runSimulation(doc, 'fans')
+  # metadata travels with the hits only if the settings' StoreHit* switches are on (ray.py:55-65)
+  assert store.totalTracedRays == 40 and set(store.hits().hits) == {'source', 'obj', 'points', 'directions',
+                                                                    'powers', 'isEntering'}
+  assert not store.hits().supportsFanMath()
+  for k in ('StoreHitFanIndex', 'StoreHitRayIndex', 'StoreHitTotalRaysInFan', 'StoreHitTotalFanCount',
+            'StoreHitInitPhi', 'StoreHitInitTheta'):
+    setattr(st, k, True)
+  store = runSimulation(doc, 'fans')
   h = store.hits().hits
-  assert store.totalTracedRays == 40 and {'fanIndex', 'rayIndex', 'totalRaysInFan'} <= set(h)
+  assert {'fanIndex', 'rayIndex', 'totalRaysInFan', 'totalFanCount', 'initPhi', 'initTheta'} <= set(h)
+  assert 'initPoint' not in h
   fans = store.hits()
   assert fans.supportsFanMath() and fans.fanCount() == 2 and fans.raysPerFan() == 20
   assert fans.fanNeighborDists().shape[0] == 3 and np.isfinite(fans.fanCenter()).all()
+  # initial conditions of device-generated rays, recomputed from the counter-based stream
+  for k in ('StoreHitInitPoint', 'StoreHitInitDirection', 'StoreHitInitPower', 'StoreHitInitWavelength'):
+    setattr(st, k, True)
+  store = runSimulation(doc, 'singletrue', seed=77)
+  h = store.hits().hits
+  m = len(h['points'])
+  assert m > 90 and h['initPoint'].shape == (m, 3) and h['initDirection'].shape == (m, 3)
+  assert np.allclose(h['initPoint'], 0) and np.all(h['initPower'] == 1) and np.all(h['initWavelength'] == 500)
+  th, ph = h['initTheta'], h['initPhi']
+  want = np.stack([np.sin(th) * np.sin(ph), -np.sin(th) * np.cos(ph), np.cos(th)], axis=1)   # source at the origin, +z
+  assert np.abs(h['initDirection'] - want).max() < 1e-12
+  assert 'fanIndex' not in h                     # Monte-Carlo rays carry no fan metadata
   # pseudo-random modes: histogram-thinned host draws traced on the device
   store = runSimulation(doc, 'singlepseudo')
   assert store.totalTracedRays == 100 and store.totalIterations == 1 and len(store.hits()) > 90
