@@ -41,3 +41,61 @@ def reduceResults(tracer, dist, torch, dst=0):
   tensors = [torch.as_tensor(v, device=torch.device('cuda', tracer.device)) for v in views]
   reduceTensors(dist, tensors, dst=dst)
   torch.cuda.synchronize()
+
+
+class Ranks:
+  """the process group of a multi-GPU `runSimulation`: one process per GPU
+  (torch.distributed; backend nccl = RCCL on the GPU box, gloo in the CPU
+  tests).  The only exchanges are a handful of int64 totals per launch (so
+  that every rank evaluates the end criteria on the job's totals) and the
+  run-folder name; hit rows never travel between ranks -- each rank writes its
+  own `*-hits.pkl` files into the shared run folder, which is how the
+  reference's worker processes merge their results
+  (simulation_loop.py:450-507, freecad_document.py:1491-1504)."""
+
+  def __init__(self, dist=None, device=None):
+    self.dist = dist
+    self.rank = dist.get_rank() if dist is not None else 0
+    self.world = dist.get_world_size() if dist is not None else 1
+    self._device = device
+
+  @classmethod
+  def detect(cls, dist=None, device=None):
+    """`dist` given: use it; otherwise an initialised torch.distributed group is
+    picked up when the process was started by a launcher (WORLD_SIZE > 1)"""
+    import os
+    import sys
+    if dist is None and int(os.environ.get('WORLD_SIZE', '1')) > 1 and 'torch' in sys.modules:
+      import torch.distributed as td
+      if td.is_available() and td.is_initialized():
+        dist = td
+    return cls(dist, device)
+
+  def _tensor_device(self):
+    import torch
+    if self.dist.get_backend() == 'nccl':
+      return torch.device('cuda', self._device if self._device is not None else torch.cuda.current_device())
+    return torch.device('cpu')
+
+  def sum(self, values):
+    """element-wise sum of a short list of integers over all ranks"""
+    if self.world == 1:
+      return [int(v) for v in values]
+    import torch
+    t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=self._tensor_device())
+    self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+    return [int(v) for v in t.cpu()]
+
+  def broadcast(self, obj, src=0):
+    if self.world == 1:
+      return obj
+    box = [obj if self.rank == src else None]
+    self.dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+  def shard(self, first, n):
+    return shardRange(first, n, self.rank, self.world)
+
+  def barrier(self):
+    if self.world > 1:
+      self.dist.barrier()

@@ -18,7 +18,7 @@ import numpy as np
 
 from ..freecad_elements import point_source, replay_source, surface_source
 from ..scene import bake as _bake
-from . import results_store
+from . import parallel, results_store
 from .tracer import Tracer
 
 DEFAULT_SEED = 0x0D15EA5E
@@ -35,7 +35,7 @@ def _limit(settings, key, default):
 
 def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPath=None, store=None,
                   raysPerLaunch=1 << 22, endIf=None, tracer=None, pseudoIterationsPerLaunch=64,
-                  **traceKwargs):
+                  dist=None, **traceKwargs):
   """trace `doc` until its simulation settings' end criteria are met.
 
   action       'true' (continuous Monte-Carlo) | 'singletrue' (one iteration)
@@ -48,6 +48,11 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
                (None: keep results in memory only)
   endIf        optional callback(store) -> bool, checked between launches
                (FreecadDocument.runSimulation's endIf)
+  dist         torch.distributed (initialised): one process per GPU, every launch's
+               ray index range is sharded over the ranks, each rank writes its own
+               hit files into the shared run folder, the end criteria see the
+               job's totals (`parallel.Ranks`); picked up automatically under a
+               launcher (WORLD_SIZE > 1)
   traceKwargs  maxRayLength, maxIntersections, powerTol, distTol (ray.py:36-38)
   -> SimulationResults
   """
@@ -59,9 +64,15 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
   if pseudo:
     # the reference seeds numpy's global generator per worker (simulation_loop.py:813-820)
     np.random.seed(int(seed) % (1 << 32))
+  ranks = parallel.Ranks.detect(dist, device)
   if store is None:
+    runFolder = None
+    if resultsPath is not None and ranks.world > 1:
+      # every rank writes into the run folder rank 0 creates
+      runFolder = ranks.broadcast(f'raw/simulation-run-{results_store.latestRunIndex(resultsPath) + 1:06d}'
+                                  if ranks.rank == 0 else None)
     store = results_store.SimulationResults(
-        action, resultsPath=resultsPath,
+        action, resultsPath=resultsPath, simulationRunFolder=runFolder,
         endAfterIterations=_limit(settings, 'EndAfterIterations', np.inf) if continuous else 0,
         endAfterRays=_limit(settings, 'EndAfterRays', np.inf) if continuous else np.inf,
         endAfterHits=_limit(settings, 'EndAfterHits', np.inf) if continuous else np.inf)
@@ -76,12 +87,15 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
   enabled = enabledHitMetadata(settings)
   own = tracer is None
   tr = tracer or Tracer(device)
-  store.setStatus('simulation-is-done', False)
-  store.setStatus('simulation-is-canceled', False)
-  store.setStatus('simulation-is-running', True)
+  master = ranks.rank == 0
+  if master:
+    store.setStatus('simulation-is-done', False)
+    store.setStatus('simulation-is-canceled', False)
+    store.setStatus('simulation-is-running', True)
   failed = True
   try:
-    store.dumpGlobalInfo(_bake.collectGlobalInfo(doc))
+    if master:
+      store.dumpGlobalInfo(_bake.collectGlobalInfo(doc))
     baked = []
     for src in sources:
       scene = _bake.bakeScene(doc, src)
@@ -91,9 +105,9 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
     while True:
       for src, scene, bsrc, lim in baked:
         per_iter = max(1, int(round(rpi * bsrc.rays_per_iteration_scale)))
-        tr.setScene(scene)
-        tr.setLimits(lim)
-        tr.setDetector(None)
+        base = first[src.Name]
+        # -- what this launch traces: device-generated rays or explicit initial conditions ----
+        explicit = None          # (origins, directions, powers or None, wavelengths or None)
         if isinstance(bsrc, replay_source.BakedReplay):
           # replay_source.py:116-166: no fans; true and pseudo modes alike take the next
           # RaysPerIteration rays of the stock; an exhausted stock ends the simulation
@@ -102,20 +116,10 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
           iters = 1 if not continuous else _iterations_for_launch(store, per_iter, raysPerLaunch)
           o, d, wl, pw = bsrc.take(iters * per_iter)
           n, iters = len(o), max(1, -(-len(o) // per_iter))
-          order = np.concatenate([np.nonzero(wl == w)[0] for w in np.unique(wl)]) if n else np.zeros(0, int)
-          per_ray = dict(initPoint=o[order], initDirection=d[order], initPower=pw[order], initWavelength=wl[order])
-          base = first[src.Name]
-          if n:
-            tr.reserveHits(max(16, n * (lim.max_intersections + 1)))
-            tr.reset()
-            tr.setSurfaceSeed(seed)
-            done = 0
-            for w in np.unique(wl):          # one launch per wavelength (gratings)
-              sel = wl == w
-              tr.setWavelength(w)
-              tr.traceRays(o[sel], d[sel], pw[sel], first=first[src.Name] + done)
-              done += int(sel.sum())
-            tr.sync()
+          order = np.argsort(wl, kind='stable')          # one launch per wavelength (gratings)
+          explicit = (o[order], d[order], pw[order], wl[order])
+          per_ray = dict(initPoint=explicit[0], initDirection=explicit[1], initPower=explicit[2],
+                         initWavelength=explicit[3])
           if bsrc.remaining == 0:
             import warnings
             warnings.warn(f'replay light source {src.Name} ran out of rays, canceling simulation...')
@@ -128,15 +132,10 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
                 f'{src.Name}: fan mode of surface sources (equidistant UV grids, '
                 f'surface_source.py:119-266) is not on the accelerated path')
           rays = point_source.generateFanRays(src, bsrc)
-          o = np.array([r[0] for r in rays])
-          d = np.array([r[1] for r in rays])
-          tr.reserveHits(max(16, len(rays) * (lim.max_intersections + 1)))
-          tr.reset()
-          tr.setSurfaceSeed(seed)
-          tr.traceRays(o, d)
-          tr.sync()
           n, iters, base = len(rays), 1, 0
-          per_ray = dict(initPoint=o, initDirection=d, initPower=np.ones(n), initWavelength=np.full(n, bsrc.wavelength))
+          explicit = (np.array([r[0] for r in rays]), np.array([r[1] for r in rays]), None, None)
+          per_ray = dict(initPoint=explicit[0], initDirection=explicit[1], initPower=np.ones(n),
+                         initWavelength=np.full(n, bsrc.wavelength))
           for key in ('fanIndex', 'rayIndex', 'totalFanCount', 'totalRaysInFan', 'initPhi', 'initTheta'):
             per_ray[key] = np.array([r[2][key] for r in rays])
         elif pseudo and isinstance(bsrc, point_source.BakedSource):
@@ -147,42 +146,68 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
           ang = np.concatenate([vrv.drawPseudo(N=per_iter) for _ in range(iters)], axis=-1)
           rays = [point_source.makeRay(bsrc, t, p) for t, p in ang.T]
           n = len(rays)
-          tr.reserveHits(max(16, n * (lim.max_intersections + 1)))
-          tr.reset()
-          tr.setSurfaceSeed(seed)
-          o, d = np.array([r[0] for r in rays]), np.array([r[1] for r in rays])
-          tr.traceRays(o, d, first=first[src.Name])
-          tr.sync()
-          base = first[src.Name]
-          per_ray = dict(initPoint=o, initDirection=d, initPower=np.ones(n), initWavelength=np.full(n, bsrc.wavelength),
-                         initPhi=ang[1], initTheta=ang[0] if np.isfinite(bsrc.focal_length) else np.full(n, np.nan))
+          explicit = (np.array([r[0] for r in rays]), np.array([r[1] for r in rays]), None, None)
+          per_ray = dict(initPoint=explicit[0], initDirection=explicit[1], initPower=np.ones(n),
+                         initWavelength=np.full(n, bsrc.wavelength), initPhi=ang[1],
+                         initTheta=ang[0] if np.isfinite(bsrc.focal_length) else np.full(n, np.nan))
         else:
-          tr.setSource(bsrc)
           iters = 1 if not continuous else _iterations_for_launch(store, per_iter, raysPerLaunch)
           n = iters * per_iter
-          tr.reserveHits(max(16, min(n * (lim.max_intersections + 1), 4 * n + 1024)))
-          tr.reset()
-          tr.trace(first[src.Name], n, seed)
-          tr.sync()
-          base = first[src.Name]
-          per_ray = _DeviceInitialConditions(tr, bsrc, base, n, seed)
-        first[src.Name] += n
+          per_ray = None
+        # -- this rank's share of the launch ---------------------------------------------------
+        lo, m = ranks.shard(0, n)
+        tr.setScene(scene)
+        tr.setLimits(lim)
+        tr.setDetector(None)
+        tr.reserveHits(max(16, min(m * (lim.max_intersections + 1), 4 * m + 1024) if explicit is None
+                           else m * (lim.max_intersections + 1)))
+        tr.reset()
+        if explicit is None:
+          tr.setSource(bsrc)
+          if m:
+            tr.trace(base + lo, m, seed)
+          per_ray, index_base = _DeviceInitialConditions(tr, bsrc, base + lo, m, seed), base + lo
+        else:
+          o, d, pw, wl = (a[lo:lo + m] if a is not None else None for a in explicit)
+          tr.setSurfaceSeed(seed)
+          index_base = base
+          if wl is None:
+            if m:
+              tr.traceRays(o, d, pw, first=base + lo)
+          else:
+            for w in np.unique(wl):
+              sel = np.nonzero(wl == w)[0]                 # contiguous: the launch is ordered by wavelength
+              tr.setWavelength(w)
+              tr.traceRays(o[sel], d[sel], pw[sel], first=base + lo + int(sel[0]))
+        tr.sync()
+        first[src.Name] = base + n
         cnt = tr.counters()
         if cnt['hits_dropped']:
           raise RuntimeError(f'{cnt["hits_dropped"]} hit rows did not fit the device buffer')
-        _store_hits(store, tr.hits(), scene, src, per_ray, base, enabled)
+        before = store.totalRecordedHits
+        _store_hits(store, tr.hits(), scene, src, per_ray, index_base, enabled)
+        mine = store.totalRecordedHits - before
+        (everyone,) = ranks.sum([mine])
+        store.totalRecordedHits += everyone - mine         # every rank sees the job's totals
         store.incrementRayCount(n)
         store.incrementIterationCount(iters)
       store.flush()
-      store.dumpProgress()
-      if ended or not continuous or store.reachedEnd() or (endIf is not None and endIf(store)):
+      if master:
+        store.dumpProgress()
+      stop = ended or not continuous or store.reachedEnd()
+      if not stop and endIf is not None:
+        (votes,) = ranks.sum([1 if endIf(store) else 0])
+        stop = votes > 0
+      if stop:
         break
+    ranks.barrier()
     failed = False
   finally:
     # any exception cancels the run (simulation_loop.py:715-723)
-    store.setStatus('simulation-is-canceled', failed)
-    store.setStatus('simulation-is-done', not failed)
-    store.setStatus('simulation-is-running', False)
+    if master or failed:
+      store.setStatus('simulation-is-canceled', failed)
+      store.setStatus('simulation-is-done', not failed)
+      store.setStatus('simulation-is-running', False)
     if own:
       tr.close()
   return store

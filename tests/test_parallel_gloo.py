@@ -75,3 +75,71 @@ def test_two_rank_reduce_matches_single(tmp_path, oracle):
   ref = oracle.trace(pr.scene, pr.source, pr.limits, 1000, 30001, 77, det=det)
   assert np.array_equal(got['hist'].reshape(64, 64), ref['hist'].astype(np.int64))
   assert [int(v) for v in got['cnt']] == [ref['counters'][k] for k in oracle.CNT_NAMES]
+
+
+RUN_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], 'tests'))
+import numpy as np, torch, torch.distributed as dist
+from oracle_tracer import OracleTracer
+from freecad.optics_design_workbench_amd.scene import open_fcstd
+from freecad.optics_design_workbench_amd.simulation import runSimulation, resultsFolderPath
+dist.init_process_group('gloo')
+doc = open_fcstd(sys.argv[2])
+st = doc.OpticalSimulationSettings
+st.EndAfterRays, st.EndAfterHits = 'inf', '1500'
+st.StoreHitInitPhi = True
+store = runSimulation(doc, 'true', seed=42, resultsPath=resultsFolderPath(sys.argv[2]), raysPerLaunch=700,
+                      tracer=OracleTracer(nthreads=1))              # torch.distributed is picked up (WORLD_SIZE=2)
+assert store.totalRecordedHits > 1500, store.totalRecordedHits     # the job's total, on every rank
+local = len(store.hits())
+total = torch.tensor([local]); dist.all_reduce(total)
+assert int(total) == store.totalRecordedHits and 0 < local < store.totalRecordedHits
+st.EndAfterHits = 'inf'
+fans = runSimulation(doc, 'fans', resultsPath=resultsFolderPath(sys.argv[2]), tracer=OracleTracer(nthreads=1), dist=dist)
+assert fans.totalTracedRays == 40
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_run_simulation(tmp_path, oracle):
+  """runSimulation under a 2-rank launcher: launches are sharded by ray index,
+  both ranks write into ONE run folder, the end criterion sees the job's totals;
+  the merged result is the single-process result, row for row"""
+  import shutil
+  from conftest import SCENES
+  from oracle_tracer import OracleTracer
+  from freecad.optics_design_workbench_amd.scene import open_fcstd
+  from freecad.optics_design_workbench_amd.simulation import rawFolders, resultsFolderPath, runSimulation
+  path = str(tmp_path / 'GettingStarted.FCStd')
+  shutil.copy(os.path.join(SCENES, 'GettingStarted.FCStd'), path)
+  script = tmp_path / 'run_worker.py'
+  script.write_text(RUN_WORKER)
+  with socket.socket() as s:
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+         '--master-addr', '127.0.0.1', '--master-port', str(port), str(script), ROOT, path]
+  res = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS='1'), capture_output=True, text=True, timeout=600)
+  assert res.returncode == 0, res.stdout + res.stderr
+  folders = rawFolders(resultsFolderPath(path))
+  assert len(folders) == 2                                    # one folder per run, shared by the ranks
+  merged = folders[0].loadHits('*').hits
+  files = [f for _, _, fs in os.walk(folders[0]._path) for f in fs if f.endswith('-hits.pkl')]
+  assert len({f.split('-pid')[1].split('-')[0] for f in files}) == 2      # both processes wrote hit files
+  doc = open_fcstd(path)
+  st = doc.OpticalSimulationSettings
+  st.EndAfterRays, st.EndAfterHits = 'inf', '1500'
+  st.StoreHitInitPhi = True
+  single = runSimulation(doc, 'true', seed=42, raysPerLaunch=700, tracer=OracleTracer()).hits().hits
+
+  def rows(h):
+    a = np.concatenate([h['points'], h['directions'], h['powers'][:, None], h['initPhi'][:, None]], axis=1)
+    return a[np.lexsort(a.T[::-1])]
+
+  assert len(merged['points']) == len(single['points']) > 1500
+  assert np.array_equal(rows(merged), rows(single))
+  fan_hits = folders[1].loadHits('*').hits
+  assert len(fan_hits['points']) > 30
+  assert folders[0].loadProgress()['totalRecordedHits'] == len(single['points'])

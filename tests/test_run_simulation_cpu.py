@@ -1,0 +1,106 @@
+"""runSimulation's host logic with the oracle standing in for the device
+(tests/oracle_tracer.py): the reference's end criteria
+(test/21-simulation-modes/run-simulations.py:47-69), modes, metadata switches,
+run-folder output.  The same assertions run against the real device in
+tests/test_results_store.py / test_surface_source.py (-m gpu)."""
+import os
+import shutil
+import warnings
+
+import numpy as np
+import pytest
+
+from conftest import SCENES
+from oracle_tracer import OracleTracer
+from freecad.optics_design_workbench_amd.scene import open_fcstd
+from freecad.optics_design_workbench_amd.simulation import latestRawFolder, resultsFolderPath, runSimulation
+
+
+@pytest.fixture()
+def doc_path(tmp_path):
+  path = str(tmp_path / 'GettingStarted.FCStd')
+  shutil.copy(os.path.join(SCENES, 'GettingStarted.FCStd'), path)
+  return path
+
+
+def test_end_criteria_and_run_folder(doc_path, oracle):
+  doc = open_fcstd(doc_path)
+  st = doc.OpticalSimulationSettings
+  tr = OracleTracer()
+  st.EndAfterRays, st.EndAfterHits = 'inf', '1e3'
+  store = runSimulation(doc, 'true', resultsPath=resultsFolderPath(doc_path), raysPerLaunch=400, tracer=tr)
+  assert 999 < len(store.hits()) <= 1400
+  raw = latestRawFolder(resultsFolderPath(doc_path))
+  assert len(raw.loadHits('*')) == len(store.hits())
+  assert raw.loadProgress()['totalRecordedHits'] == len(store.hits())
+  assert raw.loadGlobalInfo()['lightSources'][0]['name'] == 'OpticalPointSource'
+  assert 'simulation-is-done' in os.listdir(resultsFolderPath(doc_path))
+  st.EndAfterRays, st.EndAfterHits = '1e3', 'inf'
+  store = runSimulation(doc, 'true', tracer=tr)
+  assert 1000 < store.totalTracedRays <= 1100 and len(store.hits()) > 100
+  st.EndAfterRays = 'inf'
+  store = runSimulation(doc, 'true', endIf=lambda s: s.totalRecordedHits > 500, raysPerLaunch=300, tracer=tr)
+  assert len(store.hits()) > 500
+  with pytest.raises(ValueError):
+    runSimulation(doc, 'true', tracer=tr)
+  with pytest.raises(ValueError):
+    runSimulation(doc, 'sometimes', tracer=tr)
+  # a failing run leaves the canceled flag (simulation_loop.py:715-723)
+  class Broken(OracleTracer):
+    def trace(self, *a, **k):
+      raise RuntimeError('device lost')
+  with pytest.raises(RuntimeError, match='device lost'):
+    runSimulation(doc, 'singletrue', resultsPath=resultsFolderPath(doc_path), tracer=Broken())
+  flags = set(os.listdir(resultsFolderPath(doc_path)))
+  assert 'simulation-is-canceled' in flags and 'simulation-is-running' not in flags
+
+
+def test_modes_and_metadata_switches(doc_path, oracle):
+  doc = open_fcstd(doc_path)
+  st = doc.OpticalSimulationSettings
+  tr = OracleTracer()
+  plain = {'source', 'obj', 'points', 'directions', 'powers', 'isEntering'}
+  store = runSimulation(doc, 'singletrue', tracer=tr)
+  assert store.totalTracedRays == 100 and store.totalIterations == 1 and set(store.hits().hits) == plain
+  store = runSimulation(doc, 'fans', tracer=tr)
+  assert store.totalTracedRays == 40 and set(store.hits().hits) == plain
+  for k in ('StoreHitFanIndex', 'StoreHitRayIndex', 'StoreHitTotalRaysInFan', 'StoreHitInitPhi', 'StoreHitInitTheta',
+            'StoreHitInitPoint', 'StoreHitInitDirection'):
+    setattr(st, k, True)
+  with warnings.catch_warnings():
+    warnings.simplefilter('ignore')
+    fans = runSimulation(doc, 'fans', tracer=tr).hits()
+    assert fans.supportsFanMath() and fans.fanCount() == 2 and fans.raysPerFan() == 20
+    assert 'totalFanCount' not in fans.hits and np.isfinite(fans.fanCenter()).all()
+  h = runSimulation(doc, 'singletrue', seed=5, tracer=tr).hits().hits
+  th, ph = h['initTheta'], h['initPhi']
+  want = np.stack([np.sin(th) * np.sin(ph), -np.sin(th) * np.cos(ph), np.cos(th)], axis=1)
+  assert np.abs(h['initDirection'] - want).max() < 1e-12 and np.allclose(h['initPoint'], 0)
+  assert 'fanIndex' not in h and 'initPower' not in h
+  # pseudo-random: same draws as VectorRandomVariable.drawPseudo under the run's numpy seed
+  h = runSimulation(doc, 'singlepseudo', seed=11, tracer=tr).hits().hits
+  from freecad.optics_design_workbench_amd.freecad_elements import point_source
+  np.random.seed(11)
+  ang = point_source.getVrv(doc.OpticalPointSource).drawPseudo(N=100)
+  assert set(np.round(h['initTheta'], 12)) <= set(np.round(ang[0], 12)) and len(h['initTheta']) > 90
+  st.EndAfterRays = '300'
+  store = runSimulation(doc, 'pseudo', pseudoIterationsPerLaunch=2, tracer=tr)
+  assert 300 < store.totalTracedRays <= 500 and store.totalIterations == store.totalTracedRays // 100
+
+
+def test_surface_source_scene_end_criteria(tmp_path, oracle):
+  """test/21-simulation-modes/run-simulations.py with the document's two settings objects"""
+  from freecad.optics_design_workbench_amd.jupyter_utils import FreecadDocument
+  path = str(tmp_path / 'main.FCStd')
+  shutil.copy(os.path.join(SCENES, 'simulation-modes-main.FCStd'), path)
+  with FreecadDocument(path) as f:
+    for active, other in ((f.cfg, f.sequentialCfg), (f.sequentialCfg, f.cfg)):
+      active.Active, other.Active = True, False
+      active.EndAfterRays, active.EndAfterHits = 'inf', 1e3
+      r = f.runSimulation('true', raysPerLaunch=1 << 11, tracer=OracleTracer())
+      assert len(r.loadHits('*')) > 999
+      active.EndAfterRays, active.EndAfterHits = 1e3, 'inf'
+      r = f.runSimulation('true', tracer=OracleTracer())
+      assert len(r.loadHits('*')) > 100
+    with pytest.raises(NotImplementedError):
+      f.runSimulation('fans', tracer=OracleTracer())
