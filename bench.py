@@ -133,12 +133,13 @@ def main():
     # correction applied; see profiles/traffic.json).  PMC cannot be collected
     # from inside the process, so the figure is only attached when the
     # workload matches the profiled one.
-    traffic = traffic_src = None
+    traffic = traffic_src = traffic_bytes = None
     tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
     if os.path.exists(tpath):
       tj = json.load(open(tpath))
       if tj.get('rays_per_launch') == n_per and record_hits:
-        traffic = tj['hbm_bytes_per_launch'] / avg_kernel_s / 1e9
+        traffic_bytes = tj['hbm_bytes_per_launch']
+        traffic = traffic_bytes / avg_kernel_s / 1e9       # same unit as `achieved`
         traffic_src = tj.get('source')
     out = {
         'metric': 'Monte-Carlo rays/sec (whole node), lensesAndMirrors.FCStd',
@@ -152,7 +153,8 @@ def main():
                    'record_hit_rows': record_hits, 'histogram': '1024x1024 u64',
                    'parallelism': f'ray-index sharding x{world}, one RCCL reduce'},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_src,
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_bytes_per_launch': traffic_bytes,
+                     'algorithmic_bytes_per_launch': bytes_per_ray * n_per, 'traffic_source': traffic_src,
                      'kernel': 'odw_trace_kernel', 'avg_kernel_ms': avg_kernel_s * 1e3,
                      'algorithmic_bytes_per_ray': bytes_per_ray},
     }
