@@ -498,6 +498,12 @@ int odw_upload_scene(odw_ctx* ctx, const odw_scene_desc* s) {
   if (s->n_prims < 0 || s->n_groups < 0 || s->n_groups > ODW_MAX_GROUPS || s->seq_len < 0 ||
       s->seq_len > ODW_MAX_SEQUENCE || s->n_conds < 0 || s->n_conds >= (1 << 24))
     return fail(ctx, ODW_ERR_INVALID, "odw_upload_scene: counts out of range");
+  if ((s->n_prims > 0 && (!s->prim_type || !s->prim_group || !s->prim_flags || !s->prim_xform || !s->prim_params ||
+                          !s->prim_cond_off)) ||
+      (s->n_conds > 0 && (!s->cond_prim || !s->cond_inside)) ||
+      (s->n_groups > 0 && (!s->group_type || !s->group_ior || !s->group_refl || !s->group_abslen || !s->group_record)) ||
+      (s->seq_len > 0 && !s->seq_mask))
+    return fail(ctx, ODW_ERR_INVALID, "odw_upload_scene: null table pointer");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const int n = s->n_prims;
   ctx->h_prim_f64.assign((size_t)n * 16, 0.0);
@@ -590,6 +596,8 @@ int odw_upload_surface_samplers(odw_ctx* ctx, const odw_surface_sampler_desc* sa
     if (s.n_phi_knots < 2 || s.n_t_knots < 2 || s.n_t_rows < 1 ||
         (s.n_t_rows != 1 && s.n_t_rows != s.n_phi_knots - 1))
       return fail(ctx, ODW_ERR_INVALID, "surface sampler: table shape");
+    if (!s.phi_edges || !s.phi_cdf || !s.t_edges || !s.t_cdf)
+      return fail(ctx, ODW_ERR_INVALID, "surface sampler: null table pointer");
     const size_t np = (size_t)s.n_phi_knots, nt = (size_t)s.n_t_knots, rows = (size_t)s.n_t_rows, nf = (size_t)s.n_family;
     std::vector<double> ptab(nf * np * 2), ttab(nf * rows * nt * 2);
     std::vector<int32_t> guide(nf * rows * (kSurfaceGuide + 1));
@@ -664,6 +672,8 @@ int odw_upload_source(odw_ctx* ctx, const odw_source_desc* s) {
   if (s->n_phi_knots < 2 || s->n_t_knots < 2 || s->n_t_rows < 1 ||
       (s->n_t_rows != 1 && s->n_t_rows != s->n_phi_knots - 1))
     return fail(ctx, ODW_ERR_INVALID, "odw_upload_source: table shape");
+  if (!s->phi_edges || !s->phi_cdf || !s->t_edges || !s->t_cdf)
+    return fail(ctx, ODW_ERR_INVALID, "odw_upload_source: null table pointer");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const int np = s->n_phi_knots, nt = s->n_t_knots, rows = s->n_t_rows;
   if (s->phi_cdf[0] != 0.0 || s->phi_cdf[np - 1] != 1.0)
@@ -721,6 +731,9 @@ int odw_upload_surface_source(odw_ctx* ctx, const odw_surface_source_desc* s) {
   if (!ctx || !s) return fail(ctx, ODW_ERR_INVALID, "odw_upload_surface_source: null argument");
   if (s->n_prims < 1 || s->n_faces < 1 || s->n_conds < 0 || s->n_t_knots < 2 || !(s->dist_tol > 0))
     return fail(ctx, ODW_ERR_INVALID, "odw_upload_surface_source: counts out of range");
+  if (!s->prim_type || !s->prim_flags || !s->prim_xform || !s->prim_params || !s->prim_cond_off || !s->face_prim ||
+      !s->face_id || !s->face_area || !s->t_edges || !s->t_cdf || (s->n_conds > 0 && (!s->cond_prim || !s->cond_inside)))
+    return fail(ctx, ODW_ERR_INVALID, "odw_upload_surface_source: null table pointer");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   const int n = s->n_prims;

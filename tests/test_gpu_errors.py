@@ -67,6 +67,10 @@ def test_invalid_tables_are_rejected(tr, native_lib):
   with pytest.raises(_native.NativeError):
     tr.setDetector(dict(group=0, origin=[0, 0, 0], ex=[1, 0, 0], ey=[0, 1, 0], x_lo=1, x_hi=-1, y_lo=0, y_hi=1,
                         nx=4, ny=4))
+  empty = _native.SceneDesc()
+  empty.n_prims = 3                                           # counts without tables
+  assert native_lib.odw_upload_scene(tr._ctx, C.byref(empty)) == 1
+  assert b'null table' in native_lib.odw_last_error(tr._ctx)
   ctx = C.c_void_p()
   assert native_lib.odw_create(99, C.byref(ctx)) == 1         # bad device index
   assert native_lib.odw_create(0, None) == 1
