@@ -20,32 +20,86 @@ import os
 import shutil
 import tempfile
 
+import numpy as np
+
 from ..scene.fcstd import Document
 from ..simulation import results_store, simulation_loop
+
+
+class _RotationView:
+  """what `Placement.Rotation` looks like from a notebook: Axis, Angle (radians)"""
+
+  def __init__(self, placement):
+    self.Axis, self.Angle = placement.axisAngle()
+
+  def __repr__(self):
+    return f'Rotation (axis={self.Axis.tolist()}, angle={self.Angle})'
 
 
 class FreecadProperty:
   '''
   One property of a document object; `get()`/`set()` like the reference's
   FreecadProperty (freecad_document.py:176-413).  Comparisons, float() and
-  str() act on the value.
+  str() act on the value.  Attribute paths below a Placement can be read and
+  assigned like in a FreeCAD shell (`f.Source.Placement.Rotation.Angle = 0.3`,
+  `f.Box.Placement.Base.z = 12`): the reference forwards such lines to FreeCAD
+  (:225-232), here the placement is rebuilt and written back.
   '''
 
-  def __init__(self, obj, name):
+  def __init__(self, obj, name, path=()):
     self.__dict__['_obj'] = obj
     self.__dict__['_name'] = name
+    self.__dict__['_path'] = tuple(path)
 
   def get(self):
-    return self._obj._props[self._name]
+    from ..scene.placement import Placement
+    v = self._obj._props[self._name]
+    for key in self._path:
+      if isinstance(v, Placement) and key == 'Rotation':
+        v = _RotationView(v)
+      elif isinstance(v, np.ndarray) and key in ('x', 'y', 'z'):
+        v = float(v['xyz'.index(key)])
+      else:
+        v = getattr(v, key)
+    return v
 
   def set(self, value):
-    setattr(self._obj, self._name, value)
+    from ..scene.placement import Placement
+    if isinstance(value, FreecadProperty):
+      value = value.get()
+    if not self._path:
+      setattr(self._obj, self._name, value)
+      return
+    root = self._obj._props[self._name]
+    path = self._path
+    if isinstance(root, Placement):
+      axis, angle = root.axisAngle()
+      if path == ('Base',):
+        new = root.withBase(value)
+      elif len(path) == 2 and path[0] == 'Base' and path[1] in ('x', 'y', 'z'):
+        b = root.Base
+        b['xyz'.index(path[1])] = float(value)
+        new = root.withBase(b)
+      elif path == ('Rotation', 'Angle'):
+        new = root.withRotation(axis, float(value))        # radians, as in FreeCAD
+      elif path == ('Rotation', 'Axis'):
+        new = root.withRotation(value, angle)
+      else:
+        raise AttributeError(f'cannot assign {self._obj.Name}.{self._name}.{".".join(path)}')
+      setattr(self._obj, self._name, new)
+      return
+    if isinstance(root, np.ndarray) and len(path) == 1 and path[0] in ('x', 'y', 'z'):
+      new = root.copy()
+      new['xyz'.index(path[0])] = float(value)
+      setattr(self._obj, self._name, new)
+      return
+    raise AttributeError(f'cannot assign {self._obj.Name}.{self._name}.{".".join(path)}')
 
   def getStr(self):
     return str(self.get())
 
   def __repr__(self):
-    return f'<FreecadProperty {self._obj.Name}.{self._name}, value: {self.getStr()}>'
+    return f'<FreecadProperty {self._obj.Name}.{".".join((self._name,) + self._path)}, value: {self.getStr()}>'
 
   def __float__(self):
     return float(self.get())
@@ -53,8 +107,17 @@ class FreecadProperty:
   def __eq__(self, other):
     return self.get() == (other.get() if isinstance(other, FreecadProperty) else other)
 
-  def __getattr__(self, key):            # e.g. Placement.Base
-    return getattr(self.get(), key)
+  def __getattr__(self, key):            # e.g. Placement.Base, Placement.Rotation.Angle
+    if key.startswith('__'):
+      raise AttributeError(key)
+    value = self.get()
+    from ..scene.placement import Placement
+    if isinstance(value, (Placement, _RotationView)) or (isinstance(value, np.ndarray) and key in ('x', 'y', 'z')):
+      return FreecadProperty(self._obj, self._name, self._path + (key,))
+    return getattr(value, key)
+
+  def __setattr__(self, key, value):
+    FreecadProperty(self._obj, self._name, self._path + (key,)).set(value)
 
 
 class FreecadObject:

@@ -66,6 +66,38 @@ class Placement:
   def Rotation(self):
     return self.m[:3, :3].copy()
 
+  def axisAngle(self):
+    """(unit axis, angle in radians) with the angle in [0, pi] like FreeCAD's
+    Rotation.Axis / Rotation.Angle; the identity reports the z axis"""
+    r = self.m[:3, :3]
+    angle = float(np.arccos(np.clip((np.trace(r) - 1) / 2, -1, 1)))
+    v = np.array([r[2, 1] - r[1, 2], r[0, 2] - r[2, 0], r[1, 0] - r[0, 1]])
+    n = np.linalg.norm(v)
+    if n > 1e-12:
+      return v / n, angle
+    if angle < 1e-6:
+      return np.array([0.0, 0.0, 1.0]), 0.0
+    # angle = pi: axis from the symmetric part
+    d = np.clip((np.diag(r) + 1) / 2, 0, None)
+    axis = np.sqrt(d)
+    k = int(np.argmax(axis))
+    for j in range(3):
+      if j != k and r[k, j] + r[j, k] < 0:
+        axis[j] = -axis[j]
+    return axis / np.linalg.norm(axis), angle
+
+  def withRotation(self, axis, angle_rad):
+    """same Base, rotation about `axis` by `angle_rad` (any real number, like
+    assigning FreeCAD's Rotation.Angle)"""
+    out = Placement(matrix=self.m)
+    out.m[:3, :3] = from_axis_angle(axis, angle_rad)
+    return out
+
+  def withBase(self, base):
+    out = Placement(matrix=self.m)
+    out.m[:3, 3] = np.asarray(base, dtype=np.float64)
+    return out
+
   def rows12(self):
     """(R|t) rows, the 12-double layout of odw_trace.h"""
     return np.ascontiguousarray(self.m[:3, :]).reshape(12)

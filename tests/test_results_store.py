@@ -150,6 +150,16 @@ def test_freecad_document_property_api(tmp_path):
     label = f.document().OpticalPointSource._props['Label']
     assert getattr(f, label).PowerDensity.get() == 'exp(-theta^2/0.01)'           # resolved by label
     assert f.OpticalPointSource.PowerDensity == getattr(f, label).PowerDensity     # and by internal name
+    # attribute paths below a Placement, as in a FreeCAD shell (angle in radians)
+    f.Sphere.Placement.Base.z = -7.5
+    assert np.allclose(f.Sphere.Placement.Base.get(), [0, 0, -7.5]) and float(f.Sphere.Placement.Base.z) == -7.5
+    f.Cube.Placement.Rotation.Angle = 0.25
+    axis, angle = f.Cube.Placement.get().axisAngle()
+    assert abs(angle - 0.25) < 1e-12 and abs(float(f.Cube.Placement.Rotation.Angle) - 0.25) < 1e-12
+    f.Cube.Placement.Rotation.Axis = (0, 0, 1)
+    assert np.allclose(f.Cube.Placement.get().Rotation, [[np.cos(.25), -np.sin(.25), 0], [np.sin(.25), np.cos(.25), 0], [0, 0, 1]])
+    with pytest.raises(AttributeError):
+      f.Cube.Placement.Rotation.Nonsense = 1
     with pytest.raises(AttributeError):
       f.NoSuchObject
     tmp = f._tmp
