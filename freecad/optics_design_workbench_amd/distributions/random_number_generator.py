@@ -47,11 +47,17 @@ class SamplerTables:
     if self.n_rows == 1:
       return np.interp(u_first, self.t_cdf[0], self.t_edges), v1
     mids = (self.phi_edges[1:] + self.phi_edges[:-1]) / 2
-    rows = np.abs(mids[None, :] - np.asarray(v1)[:, None]).argmin(axis=1)
+    v1 = np.asarray(v1)
+    # argmin_i |mid_i - v1| (first minimum), evaluated on the cell containing v1 and its two neighbours
+    cell = np.clip(np.searchsorted(self.phi_edges, v1, side='right') - 1, 0, len(mids) - 1)
+    cand = np.clip(cell[:, None] + np.array([-1, 0, 1])[None, :], 0, len(mids) - 1)
+    rows = cand[np.arange(len(v1)), np.abs(mids[cand] - v1[:, None]).argmin(axis=1)]
     v0 = np.empty_like(v1)
-    for r in np.unique(rows):
-      sel = rows == r
-      v0[sel] = np.interp(u_first[sel], self.t_cdf[r], self.t_edges)
+    order = np.argsort(rows, kind='stable')
+    bounds = np.searchsorted(rows[order], np.arange(self.n_rows + 1))
+    for r in np.nonzero(bounds[1:] > bounds[:-1])[0]:
+      idx = order[bounds[r]:bounds[r + 1]]
+      v0[idx] = np.interp(u_first[idx], self.t_cdf[r], self.t_edges)
     return v0, v1
 
 
@@ -313,13 +319,6 @@ class ScalarRandomVariable:
     Y = sy.lambdify(self._sym, self._expr, modules=['numpy', 'scipy'])(X)
     if not hasattr(Y, 'shape'):
       Y = Y * np.ones(X.shape)
-    # cell-centred cumulative density -> equidistant quantiles
-    nodes = np.empty(len(X) + 1)
-    nodes[0] = X[0] - (X[1] - X[0]) / 2
-    nodes[1:-1] = (X[:-1] + X[1:]) / 2
-    nodes[-1] = X[-1] + (X[-1] - X[-2]) / 2
-    cum = np.concatenate([[0], np.cumsum(Y)])
-    cum = (cum - cum.min()) / (cum.max() - cum.min())
-    quantiles = np.linspace(0, 1, int(round(N)))[1:-1]
-    pts = np.concatenate([[X[0]], np.interp(quantiles, cum, nodes), [X[-1]]])
+    from .points_by_density import generatePointsWithGivenDensity1D
+    pts = generatePointsWithGivenDensity1D((X, Y), N)
     return pts[(pts >= X.min()) & (pts <= X.max())]
