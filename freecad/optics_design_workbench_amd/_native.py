@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(CSRC, 'libodw_trace.so')
 _SOURCES = ['odw_capi.hip', 'odw_kernels.hip', 'odw_device.h']
 _HEADER = os.path.normpath(os.path.join(_HERE, '..', '..', 'include', 'odw_trace.h'))
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 CNT_NAMES = ['traced_rays', 'recorded_hits', 'segments', 'escaped', 'died', 'capped',
              'hist_overflow', 'hits_dropped']
 TRACE_RECORD_HITS, TRACE_HISTOGRAM = 1, 2
@@ -45,7 +45,7 @@ class SceneDesc(C.Structure):
               ('group_abslen', _pd), ('group_record', _pi), ('group_grating_type', _pi),
               ('group_grating_lpm', _pd), ('group_grating_dir', _pd), ('group_grating_order', _pi),
               ('seq_enabled', C.c_int32), ('seq_len', C.c_int32), ('seq_mask', _pu),
-              ('ignore_mask', C.c_uint64)]
+              ('ignore_mask', C.c_uint64), ('tri_normals', _pd)]
 
 
 class SourceDesc(C.Structure):
@@ -164,12 +164,19 @@ def scene_desc(sc):
       group_grating_dir=_arr(sc.group_grating_dir, np.float64),
       group_grating_order=_arr(sc.group_grating_order, np.int32),
       seq_mask=_arr(sc.seq_mask, np.uint64))
+  if getattr(sc, 'tri_normals', None) is not None:
+    keep_tri = _arr(sc.tri_normals, np.float64).reshape(-1, 9)
+    if len(keep_tri) != len(sc.prim_type):
+      raise ValueError('tri_normals needs one row of 9 values per primitive')
   d = SceneDesc()
   d.n_prims, d.n_conds, d.n_groups = len(keep['prim_type']), len(keep['cond_prim']), len(keep['group_type'])
   for name, typ in SceneDesc._fields_:
     if name in keep:
       setattr(d, name, keep[name].ctypes.data_as(typ))
   d.seq_enabled, d.seq_len, d.ignore_mask = int(sc.seq_enabled), len(keep['seq_mask']), int(sc.ignore_mask)
+  if getattr(sc, 'tri_normals', None) is not None:
+    keep['tri_normals'] = keep_tri
+    d.tri_normals = keep_tri.ctypes.data_as(_pd)
   return d, keep
 
 

@@ -26,6 +26,7 @@ constexpr int kGuide = 1 << 16;
 constexpr int kSurfaceGuide = 1 << 10;  // per row of a surface sampler (tables of ~1e3 knots)
 constexpr int kBvhThreshold = 16;  // brute force (scalar loads) below this many primitives
 constexpr int kBvhLeaf = 4;
+constexpr int kBvhSweepMax = 2048;       // nodes with more primitives use binned SAH
 
 std::string g_error;
 
@@ -49,7 +50,7 @@ struct odw_ctx {
   bool bvh_dirty = true;
 
   DevBuf prim_f64, prim_hdr, prim_i32, cond_i32, group_f64, group_i32, group_gdir, seq_mask;
-  DevBuf bvh_nodes, bvh_prims;
+  DevBuf bvh_nodes, bvh_prims, tri_nrm;
   DevBuf phi_tab, t_tab, t_guide, d_source, d_det;
   DeviceSource h_source;
   DeviceDetector h_det;
@@ -150,10 +151,19 @@ struct Box {
 };
 
 Box world_box(const double* pf, int type, double slack) {
-  double lo[3], hi[3];
-  local_bounds(type, pf + 12, lo, hi);
   Box b;
   b.reset();
+  if (type == ODW_PRIM_TRIANGLE) {   // v0, e1, e2 in global coordinates
+    for (int i = 0; i < 3; ++i) {
+      const double a = pf[i], c1 = pf[i] + pf[3 + i], c2 = pf[i] + pf[6 + i];
+      const double s = slack + 1e-9 * (std::fabs(a) + std::fabs(c1) + std::fabs(c2));
+      b.lo[i] = std::min(a, std::min(c1, c2)) - s;
+      b.hi[i] = std::max(a, std::max(c1, c2)) + s;
+    }
+    return b;
+  }
+  double lo[3], hi[3];
+  local_bounds(type, pf + 12, lo, hi);
   for (int c = 0; c < 8; ++c) {
     const double l[3] = {(c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2]};
     // global = R^T (local - t)
@@ -197,8 +207,14 @@ struct BvhBuilder {
   std::vector<int> order;       // leaf primitive order
   std::vector<BvhNode> nodes;
   int max_depth = 0;
+  // from this depth on only median splits down to leaves of kBvhLeaf: whatever
+  // the SAH did above, the tree stays within the traversal stack
+  int balanced_depth;
 
-  explicit BvhBuilder(const std::vector<Box>& b) : boxes(b) {}
+  explicit BvhBuilder(const std::vector<Box>& b) : boxes(b) {
+    const double n = (double)std::max<size_t>(b.size(), 8);
+    balanced_depth = std::max(2, ODW_BVH_STACK - 2 - (int)std::ceil(std::log2(n / kBvhLeaf)) - 1);
+  }
 
   static double area(const Box& b) {
     const double ex = b.hi[0] - b.lo[0], ey = b.hi[1] - b.lo[1], ez = b.hi[2] - b.lo[2];
@@ -223,6 +239,8 @@ struct BvhBuilder {
       return r;
     };
     if (m <= 1) return make_leaf();
+    if (depth >= balanced_depth && m <= kBvhLeaf) return make_leaf();
+    if (m > kBvhSweepMax || depth >= balanced_depth) return build_big(ids, depth, bb);
     // SAH sweep
     double best_cost = INFINITY;
     int best_axis = -1, best_split = 0;
@@ -250,6 +268,81 @@ struct BvhBuilder {
     if (best_axis < 0) return make_leaf();
     std::vector<int> left(best_sorted.begin(), best_sorted.begin() + best_split);
     std::vector<int> right(best_sorted.begin() + best_split, best_sorted.end());
+    return inner(left, right, depth, bb);
+  }
+
+  // big nodes (meshes): binned SAH over 32 bins of the centroid range, O(m) per
+  // node; from balanced_depth on: median splits, which bound the remaining
+  // depth by log2(m / kBvhLeaf)
+  Ref build_big(std::vector<int>& ids, int depth, const Box& bb) {
+    const int m = (int)ids.size();
+    Box cb;
+    cb.reset();
+    for (int i : ids)
+      for (int a = 0; a < 3; ++a) {
+        const double c = boxes[i].lo[a] + boxes[i].hi[a];
+        cb.lo[a] = std::min(cb.lo[a], c);
+        cb.hi[a] = std::max(cb.hi[a], c);
+      }
+    int axis = 0;
+    for (int a = 1; a < 3; ++a) if (cb.hi[a] - cb.lo[a] > cb.hi[axis] - cb.lo[axis]) axis = a;
+    auto centroid = [&](int i, int a) { return boxes[i].lo[a] + boxes[i].hi[a]; };
+    std::vector<int> left, right;
+    bool split_done = false;
+    if (depth < balanced_depth && cb.hi[axis] > cb.lo[axis]) {
+      constexpr int kBins = 32;
+      double best_cost = INFINITY;
+      int best_axis = -1, best_bin = 0;
+      for (int a = 0; a < 3; ++a) {
+        const double ext = cb.hi[a] - cb.lo[a];
+        if (!(ext > 0)) continue;
+        Box bins[kBins];
+        int cnt[kBins] = {0};
+        for (auto& b : bins) b.reset();
+        for (int i : ids) {
+          const int k = std::min(kBins - 1, (int)((centroid(i, a) - cb.lo[a]) / ext * kBins));
+          bins[k].grow(boxes[i]);
+          ++cnt[k];
+        }
+        double ra[kBins];
+        int rc[kBins];
+        Box r;
+        r.reset();
+        int c = 0;
+        for (int k = kBins - 1; k > 0; --k) { r.grow(bins[k]); c += cnt[k]; ra[k] = c ? area(r) : 0.0; rc[k] = c; }
+        Box l;
+        l.reset();
+        c = 0;
+        for (int k = 1; k < kBins; ++k) {
+          l.grow(bins[k - 1]);
+          c += cnt[k - 1];
+          if (c == 0 || rc[k] == 0) continue;
+          const double cost = area(l) * c + ra[k] * rc[k];
+          if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = k; }
+        }
+      }
+      if (best_axis >= 0) {
+        const double ext = cb.hi[best_axis] - cb.lo[best_axis];
+        for (int i : ids) {
+          const int k = std::min(kBins - 1, (int)((centroid(i, best_axis) - cb.lo[best_axis]) / ext * kBins));
+          (k < best_bin ? left : right).push_back(i);
+        }
+        split_done = !left.empty() && !right.empty();
+      }
+    }
+    if (!split_done) {   // median split along the widest centroid axis
+      std::vector<int> sorted(ids);
+      std::nth_element(sorted.begin(), sorted.begin() + m / 2, sorted.end(), [&](int x, int y) {
+        const double cx = centroid(x, axis), cy = centroid(y, axis);
+        return cx < cy || (cx == cy && x < y);
+      });
+      left.assign(sorted.begin(), sorted.begin() + m / 2);
+      right.assign(sorted.begin() + m / 2, sorted.end());
+    }
+    return inner(left, right, depth, bb);
+  }
+
+  Ref inner(std::vector<int>& left, std::vector<int>& right, int depth, const Box& bb) {
     const int id = (int)nodes.size();
     nodes.emplace_back();
     const Ref l = build(left, depth + 1);
@@ -290,7 +383,9 @@ int build_bvh(odw_ctx* ctx) {
     ctx->P.scene.prim_hdr = (const double*)ctx->prim_hdr.p;
   }
   static const int bvh_threshold = [] { const char* e = getenv("ODW_BVH_THRESHOLD"); return e ? atoi(e) : kBvhThreshold; }();
-  if (n <= bvh_threshold) return ODW_OK;
+  bool has_triangles = false;
+  for (int p = 0; p < n && !has_triangles; ++p) has_triangles = ctx->h_prim_i32[4 * p] == ODW_PRIM_TRIANGLE;
+  if (n <= bvh_threshold && !has_triangles) return ODW_OK;   // triangles are only known to the BVH kernels
   // float32 traversal boxes: enlarge by what float rounding of the ray origin
   // and of the slab arithmetic can cost (see ray_box_f32 in odw_kernels.hip)
   for (int p = 0; p < n; ++p)
@@ -484,7 +579,7 @@ void odw_destroy(odw_ctx* ctx) {
                    &ctx->sort_tmp, &ctx->sorted_rows};
   for (DevBuf* b : all) release(*b);
   for (DevBuf* b : {&ctx->em_prim_f64, &ctx->em_prim_i32, &ctx->em_cond, &ctx->em_face_i32, &ctx->em_face_cdf,
-                    &ctx->em_t_tab, &ctx->em_t_guide, &ctx->em_o, &ctx->em_d})
+                    &ctx->em_t_tab, &ctx->em_t_guide, &ctx->em_o, &ctx->em_d, &ctx->tri_nrm})
     release(*b);
   for (auto& sb : ctx->surf_bufs) { release(sb.phi_tab); release(sb.t_tab); release(sb.t_guide); }
   release(ctx->d_samplers);
@@ -510,13 +605,33 @@ int odw_upload_scene(odw_ctx* ctx, const odw_scene_desc* s) {
   ctx->h_prim_i32.assign((size_t)n * 4, 0);
   for (int p = 0; p < n; ++p) {
     const int type = s->prim_type[p], group = s->prim_group[p];
-    if (type < ODW_PRIM_BOX || type > ODW_PRIM_TORUS) return fail(ctx, ODW_ERR_UNSUPPORTED, "unknown primitive type");
+    if (type < ODW_PRIM_BOX || type > ODW_PRIM_TRIANGLE) return fail(ctx, ODW_ERR_UNSUPPORTED, "unknown primitive type");
     if (group < 0 || group >= s->n_groups) return fail(ctx, ODW_ERR_INVALID, "primitive group out of range");
     const int off = s->prim_cond_off[p], cnt = s->prim_cond_off[p + 1] - off;
     if (off < 0 || cnt < 0 || cnt > 255 || off + cnt > s->n_conds)
       return fail(ctx, ODW_ERR_INVALID, "bad condition offsets");
-    std::memcpy(&ctx->h_prim_f64[16 * (size_t)p], s->prim_xform + 12 * (size_t)p, 12 * sizeof(double));
-    std::memcpy(&ctx->h_prim_f64[16 * (size_t)p + 12], s->prim_params + 4 * (size_t)p, 4 * sizeof(double));
+    if (type == ODW_PRIM_TRIANGLE) {
+      if (cnt) return fail(ctx, ODW_ERR_UNSUPPORTED, "triangles cannot carry trimming conditions");
+      const double* v = s->prim_xform + 12 * (size_t)p;
+      double* d = &ctx->h_prim_f64[16 * (size_t)p];
+      double e1[3], e2[3], e3[3], nn[3];
+      for (int k = 0; k < 3; ++k) { d[k] = v[k]; e1[k] = v[3 + k] - v[k]; e2[k] = v[6 + k] - v[k]; e3[k] = e2[k] - e1[k]; }
+      nn[0] = e1[1] * e2[2] - e1[2] * e2[1];
+      nn[1] = e1[2] * e2[0] - e1[0] * e2[2];
+      nn[2] = e1[0] * e2[1] - e1[1] * e2[0];
+      const double a2 = std::sqrt(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);   // twice the area
+      if (!(a2 > 0) || !std::isfinite(a2)) return fail(ctx, ODW_ERR_INVALID, "degenerate triangle");
+      auto len3 = [](const double* x) { return std::sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]); };
+      for (int k = 0; k < 3; ++k) { d[3 + k] = e1[k]; d[6 + k] = e2[k]; d[9 + k] = nn[k] / a2; }
+      // a point at distance tol outside an edge has barycentric coordinate -tol/altitude
+      d[12] = len3(e2) / a2;   // u: distance from edge (v0, v2)
+      d[13] = len3(e1) / a2;   // v: distance from edge (v0, v1)
+      d[14] = len3(e3) / a2;   // u+v: distance from edge (v1, v2)
+      d[15] = 0.0;
+    } else {
+      std::memcpy(&ctx->h_prim_f64[16 * (size_t)p], s->prim_xform + 12 * (size_t)p, 12 * sizeof(double));
+      std::memcpy(&ctx->h_prim_f64[16 * (size_t)p + 12], s->prim_params + 4 * (size_t)p, 4 * sizeof(double));
+    }
     ctx->h_prim_i32[4 * p] = type;
     ctx->h_prim_i32[4 * p + 1] = group;
     ctx->h_prim_i32[4 * p + 2] = s->prim_flags[p];
@@ -525,6 +640,8 @@ int odw_upload_scene(odw_ctx* ctx, const odw_scene_desc* s) {
   std::vector<int32_t> cond((size_t)std::max(1, s->n_conds), 0);
   for (int c = 0; c < s->n_conds; ++c) {
     if (s->cond_prim[c] < 0 || s->cond_prim[c] >= n) return fail(ctx, ODW_ERR_INVALID, "condition primitive out of range");
+    if (s->prim_type[s->cond_prim[c]] == ODW_PRIM_TRIANGLE)
+      return fail(ctx, ODW_ERR_UNSUPPORTED, "trimming against a triangle (no inside/outside of a facet)");
     cond[c] = s->cond_prim[c] | (s->cond_inside[c] ? (int32_t)0x80000000 : 0);
   }
   std::vector<double> gf(ODW_MAX_GROUPS * 4, 0.0), gd(ODW_MAX_GROUPS * 3, 0.0);
@@ -552,8 +669,12 @@ int odw_upload_scene(odw_ctx* ctx, const odw_scene_desc* s) {
   if ((rc = upload(ctx, ctx->group_i32, gi.data(), gi.size() * sizeof(int32_t)))) return rc;
   if ((rc = upload(ctx, ctx->group_gdir, gd.data(), gd.size() * sizeof(double)))) return rc;
   if ((rc = upload(ctx, ctx->seq_mask, seq.data(), seq.size() * sizeof(uint64_t)))) return rc;
+  if (s->tri_normals && n > 0) {
+    if ((rc = upload(ctx, ctx->tri_nrm, s->tri_normals, (size_t)n * 9 * sizeof(double)))) return rc;
+  }
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   DeviceScene& d = ctx->P.scene;
+  d.tri_nrm = (s->tri_normals && n > 0) ? (const double*)ctx->tri_nrm.p : nullptr;
   d.prim_f64 = (const double*)ctx->prim_f64.p;
   d.prim_i32 = (const int32_t*)ctx->prim_i32.p;
   d.cond_i32 = (const int32_t*)ctx->cond_i32.p;
@@ -741,7 +862,7 @@ int odw_upload_surface_source(odw_ctx* ctx, const odw_surface_source_desc* s) {
   std::vector<int32_t> pi((size_t)n * 4);
   for (int p = 0; p < n; ++p) {
     if (s->prim_type[p] < ODW_PRIM_BOX || s->prim_type[p] > ODW_PRIM_TORUS)
-      return fail(ctx, ODW_ERR_UNSUPPORTED, "surface source: unknown primitive type");
+      return fail(ctx, ODW_ERR_UNSUPPORTED, "surface source: emission from analytic primitives only");
     const int off = s->prim_cond_off[p], cnt = s->prim_cond_off[p + 1] - off;
     if (off < 0 || cnt < 0 || off + cnt > s->n_conds) return fail(ctx, ODW_ERR_INVALID, "surface source: bad condition offsets");
     std::memcpy(&pf[16 * (size_t)p], s->prim_xform + 12 * (size_t)p, 12 * sizeof(double));

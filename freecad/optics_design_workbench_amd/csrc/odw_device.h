@@ -2,6 +2,8 @@
 //
 // Layout in HBM (all read-only during a launch, L2/scalar-cache resident):
 //   prim_f64 : n_prims x 16 f64   rows 0..11 global->local (R|t), 12..15 params
+//              (TRIANGLE: v0, e1 = v1-v0, e2 = v2-v0, unit facet normal | barycentric slack per unit of
+//               tolerance for u, v, u+v; unused)
 //   prim_hdr : n_prims x 64 B     global bounding box (6 f64) + type, group, flags, conds (4 i32)
 //   prim_i32 : n_prims x 4  i32   type, group, flags|facemask<<8, cond_off|cnt<<24
 //   cond_i32 : n_conds      i32   prim | inside<<31
@@ -46,6 +48,7 @@ struct DeviceScene {
   // (lo0 hi0 lo1 hi1, 12 floats) + child0, child1, count0, count1 (count > 0: leaf)
   const float* bvh_nodes;       // [n_nodes*16]
   const int32_t* bvh_prims;     // leaf primitive order
+  const double* tri_nrm;        // [n_prims*9] vertex normals of TRIANGLE primitives, or null (facet normals)
   int32_t n_prims, n_groups, n_nodes;
   int32_t seq_enabled, seq_len;
   uint64_t ignore_mask, all_mask;

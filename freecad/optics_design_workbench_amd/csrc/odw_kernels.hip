@@ -536,6 +536,42 @@ __device__ __forceinline__ void intersect_prim(const SceneView& sv, Query& q, in
   }
 }
 
+// One facet of a tessellated face (ODW_PRIM_TRIANGLE, BVH kernels only):
+// Moeller-Trumbore in float64; prim_f64 rows = v0, e1, e2, unit facet normal,
+// then the barycentric slack per unit of tolerance (a hit within distTol of
+// the facet counts, like `dist(p, trimmed face) < distTol`, ray.py:424-426).
+__device__ __forceinline__ void intersect_tri(const SceneView& sv, Query& q, int p, int group) {
+  cf64 pf = sv.prim_f64 + (size_t)p * 16;
+  const d3 e1 = mk(pf[3], pf[4], pf[5]), e2 = mk(pf[6], pf[7], pf[8]);
+  const d3 pv = cross(q.dn, e2);
+  const double det = dot(e1, pv);
+  if (det == 0) return;                              // ray parallel to the facet's plane
+  const double inv = frcp(det);
+  const d3 tv = q.start - mk(pf[0], pf[1], pf[2]);
+  const double u = dot(tv, pv) * inv;
+  const d3 qv = cross(tv, e1);
+  const double v = dot(q.dn, qv) * inv;
+  const double tol = q.tol;
+  if (u < -tol * pf[12] || v < -tol * pf[13] || u + v > 1.0 + tol * pf[14]) return;
+  consider(sv, q, dot(e2, qv) * inv, p, 0, group, 0, 0);
+}
+
+// facet or interpolated normal of a triangle at the global point gp
+__device__ __forceinline__ d3 tri_normal(cf64 pf, const double* __restrict__ vn, d3 gp) {
+  const d3 ng = mk(pf[9], pf[10], pf[11]);
+  if (!vn) return ng;
+  const d3 e1 = mk(pf[3], pf[4], pf[5]), e2 = mk(pf[6], pf[7], pf[8]);
+  const d3 tv = gp - mk(pf[0], pf[1], pf[2]);
+  const d3 nn = cross(e1, e2);
+  const double inv = frcp(dot(nn, nn));
+  const double u = dot(cross(tv, e2), nn) * inv, v = dot(cross(e1, tv), nn) * inv;
+  const double w = 1.0 - u - v;
+  const d3 n = mk(w * vn[0] + u * vn[3] + v * vn[6], w * vn[1] + u * vn[4] + v * vn[7],
+                  w * vn[2] + u * vn[5] + v * vn[8]);
+  const double l2 = dot(n, n);
+  return l2 > 0 ? n * frsqrt(l2) : ng;
+}
+
 // outward normal of face `face` of primitive p at local point lp
 __device__ __forceinline__ d3 face_normal(int type, cf64 par, int face, d3 lp) {
   if (type == ODW_PRIM_BOX) {
@@ -676,7 +712,10 @@ __device__ __forceinline__ int nearest(const DeviceScene& sc, const SceneView& s
         const int p = bvh_prims[leaf_first + i];
         ci32 pi = sv.prim_i32 + 4 * p;
         const int g = pi[1];
-        if ((mask >> g) & 1) intersect_prim(sv, q, p, pi[0], g, pi[2], pi[3]);
+        if ((mask >> g) & 1) {
+          if (pi[0] == ODW_PRIM_TRIANGLE) intersect_tri(sv, q, p, g);
+          else intersect_prim(sv, q, p, pi[0], g, pi[2], pi[3]);
+        }
       }
       if (sp > 0) {
         --sp;
@@ -955,9 +994,15 @@ __global__ __launch_bounds__(256, ODW_WAVES_PER_SIMD) void odw_trace_kernel(cons
         else if (L < INFINITY) power = exp(-t_hit / L);
       }
       // getNormal (ray.py:455-480): outward normal -> along the travel direction
-      d3 n = face_normal(pi[0], pf + 12, face, xf_point(pf, point));
-      if (pi[2] & ODW_FLAG_FLIP_NORMAL) n = n * -1.0;
-      n = xf_vec_t(pf, n);
+      d3 n;
+      if (BVH && pi[0] == ODW_PRIM_TRIANGLE) {
+        n = tri_normal(pf, sc.tri_nrm ? sc.tri_nrm + (size_t)prim * 9 : nullptr, point);
+        if (pi[2] & ODW_FLAG_FLIP_NORMAL) n = n * -1.0;
+      } else {
+        n = face_normal(pi[0], pf + 12, face, xf_point(pf, point));
+        if (pi[2] & ODW_FLAG_FLIP_NORMAL) n = n * -1.0;
+        n = xf_vec_t(pf, n);
+      }
       const bool entering = dot(dir, n) < 0;
       if (entering) n = n * -1.0;
       const int g = pi[1];

@@ -139,3 +139,25 @@ def makeReplaySource(doc, replayFromDir, name='OpticalReplaySource', placement=N
                        Proxy={'module': 'freecad.optics_design_workbench.freecad_elements.replay_source',
                               'class': 'ReplaySourceProxy', 'state': {}},
                        ElementList=[], Placement=placement or Placement.identity(), **p)
+
+
+def makeMesh(doc, vertices, triangles, vertexNormals=None, name='Mesh', **pl):
+  """a tessellated shape (what FreeCAD's `Shape.tessellate(tol)` or an STL export gives):
+  vertices (n,3), triangles (m,3) counter-clockwise seen from outside, optional unit
+  normals per vertex for smooth shading of curved faces"""
+  props = dict(Vertices=np.asarray(vertices, dtype=np.float64).reshape(-1, 3),
+               Triangles=np.asarray(triangles, dtype=np.int64).reshape(-1, 3), Placement=_placement(**pl))
+  if vertexNormals is not None:
+    props['VertexNormals'] = np.asarray(vertexNormals, dtype=np.float64).reshape(-1, 3)
+  return doc.addObject('Mesh::Feature', name, **props)
+
+
+def makeTessellated(doc, solid, segments=48, smooth=True, name=None):
+  """mesh of a primitive solid object (Part::Sphere / Cylinder / Cone / Torus / Box) at the same placement"""
+  from ..scene import geometry
+  node = geometry._primitive_of(solid)
+  if node is None:
+    raise geometry.UnsupportedGeometry(f'{solid.Name}: only primitive solids can be tessellated without FreeCAD')
+  v, tri, vn = geometry.tessellate(node.kind, node.params, segments)
+  return makeMesh(doc, v, tri, vn if smooth else None, name=name or solid.Name + 'Mesh',
+                  placement=solid.Placement)

@@ -194,6 +194,7 @@ class BakedScene:
   prim_sources: list = field(default_factory=list)
   prim_to_world: list = field(default_factory=list)
   surface_samplers: list = field(default_factory=list)   # freecad_elements.optical_group.BakedSurfaceSampler
+  tri_normals: np.ndarray = None                         # (n_prims, 9) vertex normals of TRIANGLE primitives, or None
 
   @property
   def n_prims(self):
@@ -241,6 +242,7 @@ def bakeScene(doc, source=None, surfaceFamily=None):
     surface_samplers += _og.surfaceSamplers(g, gi, n_family=surfaceFamily or _og.DEFAULT_FAMILY)
   prims = []
   prim_group, prim_solid = [], []
+  meshes = []                    # (group, solid id, world vertices, triangles, world normals or None, source)
   solid_id = 0
   for gi, g in enumerate(groups):
     for gp in globalPlacements(doc, g):
@@ -248,6 +250,11 @@ def bakeScene(doc, source=None, surfaceFamily=None):
       # contains the group's own placement
       for child in g._props.get('ElementList') or []:
         for tree in geometry.solids_of(child):
+          if tree.op == 'mesh':
+            node = geometry.Node('mesh', gp * tree.placement, tree.mesh, source=tree.source)
+            meshes.append((gi, solid_id) + geometry.meshWorld(node) + (tree.source,))
+            solid_id += 1
+            continue
           flat = geometry.flatten(tree, gp)
           for fp in flat:
             fp.index = len(prims)
@@ -292,13 +299,39 @@ def bakeScene(doc, source=None, surfaceFamily=None):
       if o in groups:
         ignore |= 1 << groups.index(o)
 
+  # tessellated shapes: one TRIANGLE primitive per facet, appended after the analytic ones
+  # (vertices in global coordinates in the 12 doubles of the frame; no conditions)
+  n_tri = sum(len(m[3]) for m in meshes)
+  tri_xform = np.zeros((n_tri, 12))
+  tri_group, tri_solid = np.zeros(n_tri, dtype=np.int32), np.zeros(n_tri, dtype=np.int32)
+  tri_normals = np.zeros((n + n_tri, 9)) if any(m[4] is not None for m in meshes) else None
+  at = 0
+  for gi, sid, v, tri, vn, _ in meshes:
+    k = len(tri)
+    tri_xform[at:at + k, 0:9] = v[tri].reshape(k, 9)
+    tri_group[at:at + k], tri_solid[at:at + k] = gi, sid
+    if tri_normals is not None:
+      if vn is not None:
+        tri_normals[n + at:n + at + k] = vn[tri].reshape(k, 9)
+      else:                                        # facet normals for meshes without vertex normals
+        e1, e2 = v[tri[:, 1]] - v[tri[:, 0]], v[tri[:, 2]] - v[tri[:, 0]]
+        fn = np.cross(e1, e2)
+        tri_normals[n + at:n + at + k] = np.tile(fn / np.linalg.norm(fn, axis=1)[:, None], (1, 3))
+    at += k
+  cond_off = cond_off + [cond_off[-1]] * n_tri
+
   return BakedScene(
-      prim_type=np.array([p.kind for p in prims], dtype=np.int32),
-      prim_group=np.array(prim_group, dtype=np.int32),
-      prim_solid=np.array(prim_solid, dtype=np.int32),
-      prim_flags=np.array([(1 if p.flip else 0) | (p.facemask << 8) for p in prims], dtype=np.int32),
-      prim_xform=np.array([p.to_world.inverse().rows12() for p in prims], dtype=np.float64).reshape(n, 12),
-      prim_params=np.array([p.params for p in prims], dtype=np.float64).reshape(n, 4),
+      tri_normals=tri_normals,
+      prim_type=np.concatenate([np.array([p.kind for p in prims], dtype=np.int32),
+                                np.full(n_tri, geometry.TRIANGLE, dtype=np.int32)]),
+      prim_group=np.concatenate([np.array(prim_group, dtype=np.int32), tri_group]),
+      prim_solid=np.concatenate([np.array(prim_solid, dtype=np.int32), tri_solid]),
+      prim_flags=np.concatenate([np.array([(1 if p.flip else 0) | (p.facemask << 8) for p in prims], dtype=np.int32),
+                                 np.full(n_tri, 1 << 8, dtype=np.int32)]),
+      prim_xform=np.concatenate([np.array([p.to_world.inverse().rows12() for p in prims],
+                                          dtype=np.float64).reshape(n, 12), tri_xform]),
+      prim_params=np.concatenate([np.array([p.params for p in prims], dtype=np.float64).reshape(n, 4),
+                                  np.zeros((n_tri, 4))]),
       prim_cond_off=np.array(cond_off, dtype=np.int32),
       cond_prim=np.array(cond_prim, dtype=np.int32),
       cond_inside=np.array(cond_inside, dtype=np.int32),
@@ -316,8 +349,8 @@ def bakeScene(doc, source=None, surfaceFamily=None):
       ignore_mask=ignore,
       group_names=[g.Name for g in groups],
       group_labels=[g._props.get('Label', g.Name) for g in groups],
-      prim_sources=[p.source for p in prims],
-      prim_to_world=[p.to_world for p in prims],
+      prim_sources=[p.source for p in prims] + [m[5] for m in meshes for _ in range(len(m[3]))],
+      prim_to_world=[p.to_world for p in prims] + [None] * n_tri,
       surface_samplers=surface_samplers,
   )
 

@@ -14,9 +14,9 @@ import numpy as np
 
 from .placement import Placement
 
-BOX, SPHERE, CYLINDER, CONE, TORUS = range(5)
-KIND_NAMES = ['box', 'sphere', 'cylinder', 'cone', 'torus']
-N_FACES = {BOX: 6, SPHERE: 1, CYLINDER: 3, CONE: 3, TORUS: 1}
+BOX, SPHERE, CYLINDER, CONE, TORUS, TRIANGLE = range(6)
+KIND_NAMES = ['box', 'sphere', 'cylinder', 'cone', 'torus', 'triangle']
+N_FACES = {BOX: 6, SPHERE: 1, CYLINDER: 3, CONE: 3, TORUS: 1, TRIANGLE: 1}
 
 
 class UnsupportedGeometry(ValueError):
@@ -26,8 +26,9 @@ class UnsupportedGeometry(ValueError):
 
 @dataclass
 class Node:
-  op: str                       # 'prim' | 'common' | 'cut' | 'fuse'
+  op: str                       # 'prim' | 'common' | 'cut' | 'fuse' | 'mesh'
   placement: Placement = field(default_factory=Placement.identity)
+  mesh: tuple = None            # op 'mesh': (vertices (n,3), triangles (m,3) int, vertex normals (n,3) or None)
   kind: int = -1
   params: tuple = ()
   children: list = field(default_factory=list)
@@ -64,7 +65,7 @@ def _primitive_of(obj):
 def _moved(nodes, placement):
   out = []
   for n in nodes:
-    out.append(Node(n.op, placement * n.placement, n.kind, n.params, n.children, n.source))
+    out.append(Node(n.op, placement * n.placement, n.mesh, n.kind, n.params, n.children, n.source))
   return out
 
 
@@ -84,11 +85,23 @@ def solids_of(obj, with_own_placement=True, _depth=0):
   prim = _primitive_of(obj)
   if prim is not None:
     return _moved([prim], own)
+  if t == 'Mesh::Feature' and obj.hasProperty('Triangles'):
+    # a tessellated shape held in memory (freecad_elements.make.makeMesh / makeTessellated, scene.stl):
+    # facets counter-clockwise seen from outside, optional unit normals per vertex
+    v = np.asarray(obj.Vertices, dtype=np.float64).reshape(-1, 3)
+    tri = np.asarray(obj.Triangles, dtype=np.int64).reshape(-1, 3)
+    vn = obj._props.get('VertexNormals')
+    vn = None if vn is None else np.asarray(vn, dtype=np.float64).reshape(-1, 3)
+    if len(tri) == 0 or tri.min() < 0 or tri.max() >= len(v) or (vn is not None and vn.shape != v.shape):
+      raise UnsupportedGeometry(f'{obj.Name}: inconsistent mesh arrays')
+    return _moved([Node('mesh', mesh=(v, tri, vn), source=obj.Name)], own)
 
   def one(child):
     s = solids_of(child, _depth=_depth + 1)
     if len(s) != 1:
       raise UnsupportedGeometry(f'{obj.Name}: boolean operand {child.Name} is not a single solid')
+    if s[0].op == 'mesh':
+      raise UnsupportedGeometry(f'{obj.Name}: booleans of tessellated shapes need FreeCAD')
     return s[0]
 
   if t in ('Part::MultiCommon', 'Part::MultiFuse'):
@@ -265,3 +278,91 @@ def _prune_faces(prims, slack=1e-3):
       if keep:
         mask |= 1 << f
     fp.facemask = mask
+
+
+# ---------------------------------------------------------------------------
+# tessellation of the analytic primitives (what FreeCAD's Shape.tessellate
+# returns for such faces): test vehicle of the triangle path and the form in
+# which shapes with non-quadric surfaces reach the tracer
+# ---------------------------------------------------------------------------
+def meshWorld(node):
+  """world-space arrays of a 'mesh' node: vertices (n,3), triangles, normals"""
+  v, tri, vn = node.mesh
+  R, t = node.placement.m[:3, :3], node.placement.m[:3, 3]
+  return v @ R.T + t, tri, (None if vn is None else vn @ R.T)
+
+
+def _grid(nu, nv, point, normal, wrap_u=True):
+  """triangulated (u, v) grid: point(u, v), normal(u, v) with u in [0,1) periodic"""
+  us = np.linspace(0, 1, nu + 1)
+  vs = np.linspace(0, 1, nv + 1)
+  U, V = np.meshgrid(us, vs, indexing='ij')
+  if wrap_u:
+    U[-1, :] = U[0, :]            # periodic in u: the seam vertices coincide exactly (watertight)
+  P, N = point(U, V).reshape(-1, 3), normal(U, V).reshape(-1, 3)
+  idx = np.arange((nu + 1) * (nv + 1)).reshape(nu + 1, nv + 1)
+  a, b, c, d = idx[:-1, :-1], idx[1:, :-1], idx[1:, 1:], idx[:-1, 1:]
+  tri = np.concatenate([np.stack([a, b, c], -1).reshape(-1, 3), np.stack([a, c, d], -1).reshape(-1, 3)])
+  return P, tri, N
+
+
+def tessellate(kind, params, segments=48):
+  """-> (vertices, triangles, vertex normals) of a primitive in its local frame;
+  facets counter-clockwise seen from outside; every face has its own vertices
+  (no normal smoothing across edges).  Degenerate facets (poles, apex) are dropped."""
+  n = int(segments)
+  two_pi = 2 * np.pi
+  parts = []
+  st = lambda *a: np.stack(np.broadcast_arrays(*a), axis=-1)
+  if kind == SPHERE:
+    R = params[0]
+    m = max(2, n // 2)
+    pt = lambda U, V: st(R * np.sin(np.pi * V) * np.cos(two_pi * U), R * np.sin(np.pi * V) * np.sin(two_pi * U),
+                         -R * np.cos(np.pi * V))
+    parts.append(_grid(n, m, pt, lambda U, V: pt(U, V) / R))
+  elif kind == TORUS:
+    R1, R2 = params[0], params[1]
+    nr = lambda U, V: st(np.cos(two_pi * V) * np.cos(two_pi * U), np.cos(two_pi * V) * np.sin(two_pi * U),
+                         np.sin(two_pi * V))
+    pt = lambda U, V: st((R1 + R2 * np.cos(two_pi * V)) * np.cos(two_pi * U),
+                         (R1 + R2 * np.cos(two_pi * V)) * np.sin(two_pi * U), R2 * np.sin(two_pi * V))
+    parts.append(_grid(n, max(3, n // 2), pt, nr))
+  elif kind in (CYLINDER, CONE):
+    r1, r2, h = (params[0], params[0], params[1]) if kind == CYLINDER else (params[0], params[1], params[2])
+    k = (r2 - r1) / h
+    inv = 1 / np.sqrt(1 + k * k)
+    pt = lambda U, V: st((r1 + k * h * V) * np.cos(two_pi * U), (r1 + k * h * V) * np.sin(two_pi * U), h * V)
+    nr = lambda U, V: st(np.cos(two_pi * U) * inv, np.sin(two_pi * U) * inv, -k * inv + 0 * V)
+    parts.append(_grid(n, max(1, n // 8), pt, nr))
+    for r, z, s in ((r1, 0.0, -1.0), (r2, h, 1.0)):
+      if r > 0:
+        # disc: u angle, v radius; (d/du) x (d/dv) = tangent x radial: clockwise u gives +z
+        dp = lambda U, V, r=r, z=z, s=s: st(r * V * np.cos(-s * two_pi * U), r * V * np.sin(-s * two_pi * U), z + 0 * V)
+        dn = lambda U, V, s=s: st(0 * U, 0 * U, s + 0 * V)
+        parts.append(_grid(n, max(1, n // 8), dp, dn))
+  elif kind == BOX:
+    L = np.array(params[:3], dtype=np.float64)
+    for a in range(3):
+      b1, b2 = (a + 1) % 3, (a + 2) % 3
+      for s in (0, 1):
+        def pt(U, V, a=a, b1=b1, b2=b2, s=s):
+          c = [None] * 3
+          c[a] = L[a] * s + 0 * U
+          # (b1, b2, a) is right-handed: u along b1, v along b2 gives normal +a; swap for the low face
+          c[b1], c[b2] = (L[b1] * U, L[b2] * V) if s else (L[b1] * V, L[b2] * U)
+          return st(*c)
+        def nr(U, V, a=a, s=s):
+          c = [0 * U, 0 * U, 0 * U]
+          c[a] = (1.0 if s else -1.0) + 0 * U
+          return st(*c)
+        parts.append(_grid(1, 1, pt, nr, wrap_u=False))
+  else:
+    raise UnsupportedGeometry(f'cannot tessellate primitive kind {kind}')
+  V, T, N, off = [], [], [], 0
+  for p, t, nn in parts:
+    V.append(p); T.append(t + off); N.append(nn)
+    off += len(p)
+  V, T, N = np.concatenate(V), np.concatenate(T), np.concatenate(N)
+  e1, e2 = V[T[:, 1]] - V[T[:, 0]], V[T[:, 2]] - V[T[:, 0]]
+  area2 = np.linalg.norm(np.cross(e1, e2), axis=1)
+  return V, T[area2 > 1e-12 * max(1.0, float(np.abs(V).max()))**2], N

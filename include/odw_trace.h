@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ODW_ABI_VERSION 2
+#define ODW_ABI_VERSION 3
 
 /* ---- return codes ------------------------------------------------------ */
 enum {
@@ -42,17 +42,26 @@ enum {
 /*  CYLINDER axis +z, z in [0,H]          params = R, H, -, -               */
 /*  CONE     axis +z, z in [0,H]          params = R1(z=0), R2(z=H), H, -   */
 /*  TORUS    axis +z                      params = R1 (ring), R2 (tube)     */
+/*  TRIANGLE one facet of a tessellated face (shapes whose surfaces are not */
+/*           quadrics: STEP imports, B-splines -- what FreeCAD's            */
+/*           `Shape.tessellate(tol)` returns).  No local frame: prim_xform  */
+/*           holds v0, v1, v2 in GLOBAL coordinates (9 doubles, 3 unused),  */
+/*           counter-clockwise seen from outside the solid; a hit counts if */
+/*           it lies within distTol of the facet.  Normals: the facet's, or */
+/*           interpolated from tri_normals.  Triangles cannot carry or be   */
+/*           referenced by trimming conditions.                             */
 enum {
   ODW_PRIM_BOX = 0,
   ODW_PRIM_SPHERE = 1,
   ODW_PRIM_CYLINDER = 2,
   ODW_PRIM_CONE = 3,
-  ODW_PRIM_TORUS = 4
+  ODW_PRIM_TORUS = 4,
+  ODW_PRIM_TRIANGLE = 5
 };
 
 /* face bit positions inside prim_flags >> ODW_FACEMASK_SHIFT               */
 /*  BOX: 0:-x 1:+x 2:-y 3:+y 4:-z 5:+z ; CYL/CONE: 0:lateral 1:z=0 2:z=H    */
-/*  SPHERE/TORUS: 0                                                         */
+/*  SPHERE/TORUS/TRIANGLE: 0                                                */
 #define ODW_FLAG_FLIP_NORMAL 0x1 /* face normals point INTO the primitive   */
                                  /* (tool of a Part::Cut)                   */
 #define ODW_FACEMASK_SHIFT 8
@@ -103,6 +112,10 @@ typedef struct odw_scene_desc {
   int32_t seq_len;              /* <= ODW_MAX_SEQUENCE                        */
   const uint64_t* seq_mask;     /* [seq_len] bit g set: group g in step       */
   uint64_t ignore_mask;         /* source.IgnoredOpticalElements              */
+  /* smooth shading of tessellated faces: unit normals of the surface at the
+   * three vertices of each TRIANGLE primitive (rows of other primitives are
+   * ignored); NULL: facet normals                                           */
+  const double* tri_normals;    /* [n_prims*9] or NULL                        */
 } odw_scene_desc;
 
 /* Point source = PointSourceProxy (point_source.py:32-70) after

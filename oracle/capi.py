@@ -34,7 +34,7 @@ class SceneDesc(C.Structure):
               ('group_abslen', _pd), ('group_record', _pi), ('group_grating_type', _pi),
               ('group_grating_lpm', _pd), ('group_grating_dir', _pd), ('group_grating_order', _pi),
               ('seq_enabled', C.c_int32), ('seq_len', C.c_int32), ('seq_mask', _pu),
-              ('ignore_mask', C.c_uint64)]
+              ('ignore_mask', C.c_uint64), ('tri_normals', _pd)]
 
 
 class SourceDesc(C.Structure):
@@ -118,6 +118,10 @@ def scene_desc(sc):
       group_grating_dir=_arr(sc.group_grating_dir, np.float64),
       group_grating_order=_arr(sc.group_grating_order, np.int32),
       seq_mask=_arr(sc.seq_mask, np.uint64))
+  if getattr(sc, 'tri_normals', None) is not None:
+    keep_tri = _arr(sc.tri_normals, np.float64).reshape(-1, 9)
+    if len(keep_tri) != len(sc.prim_type):
+      raise ValueError('tri_normals needs one row of 9 values per primitive')
   d = SceneDesc()
   d.n_prims = len(k['prim_type'])
   d.n_conds = len(k['cond_prim'])
@@ -128,6 +132,9 @@ def scene_desc(sc):
   d.seq_enabled = int(sc.seq_enabled)
   d.seq_len = len(k['seq_mask'])
   d.ignore_mask = int(sc.ignore_mask)
+  if getattr(sc, 'tri_normals', None) is not None:
+    k['tri_normals'] = keep_tri
+    d.tri_normals = _p(keep_tri, _pd)
   return _Keep(d, k)
 
 

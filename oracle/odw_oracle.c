@@ -475,6 +475,43 @@ static nearest_hit nearest(const odw_scene_desc* sc, const odw_limits* lim, v3 s
     int g = sc->prim_group[p];
     if (!((mask >> g) & 1)) continue;
     const double* M = sc->prim_xform + 12 * (size_t)p;
+    if (sc->prim_type[p] == ODW_PRIM_TRIANGLE) {
+      /* one facet of a tessellated face (include/odw_trace.h): v0, v1, v2 in
+       * global coordinates; a hit within distTol of the facet counts */
+      v3 v0 = V(M[0], M[1], M[2]);
+      v3 e1 = sub(V(M[3], M[4], M[5]), v0), e2 = sub(V(M[6], M[7], M[8]), v0);
+      v3 nn = cross(e1, e2);
+      double a2 = len(nn);
+      v3 pv = cross(dn, e2);
+      double det = dot(e1, pv);
+      if (det == 0) continue;
+      v3 tv = sub(start, v0);
+      double u = dot(tv, pv) / det;
+      v3 qv = cross(tv, e1);
+      double v = dot(dn, qv) / det;
+      if (u < -tol * (len(e2) / a2) || v < -tol * (len(e1) / a2) || u + v > 1.0 + tol * (len(sub(e2, e1)) / a2))
+        continue;
+      double t = dot(e2, qv) / det;
+      if (!(t > tol) || !(t < max_len + tol)) continue;
+      v3 gp = add(start, mul(dn, t));
+      v3 ng = mul(nn, 1.0 / a2);
+      if (sc->tri_normals) {
+        const double* vn = sc->tri_normals + 9 * (size_t)p;
+        v3 tg = sub(gp, v0);
+        double inv = 1.0 / dot(nn, nn);
+        double bu = dot(cross(tg, e2), nn) * inv, bv = dot(cross(e1, tg), nn) * inv, bw = 1.0 - bu - bv;
+        v3 ni = V(bw * vn[0] + bu * vn[3] + bv * vn[6], bw * vn[1] + bu * vn[4] + bv * vn[7],
+                  bw * vn[2] + bu * vn[5] + bv * vn[8]);
+        if (dot(ni, ni) > 0) ng = mul(ni, 1.0 / len(ni));
+      }
+      if (sc->prim_flags[p] & ODW_FLAG_FLIP_NORMAL) ng = mul(ng, -1.0);
+      nearest_hit h;
+      h.found = 1; h.prim = p; h.face = 0; h.group = g; h.dist = t;
+      h.point = gp; h.normal = ng;
+      if (better(t, p, 0, any.dist, any.prim, any.face)) any = h;
+      if (g != medium && better(t, p, 0, oth.dist, oth.prim, oth.face)) oth = h;
+      continue;
+    }
     /* ray in local coordinates: lstart = M*start, ldir = M*(start+dir)-lstart
      * (ray.py:348-349) */
     v3 lstart = xf_point(M, start);

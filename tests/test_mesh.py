@@ -1,0 +1,179 @@
+"""Tessellated shapes (triangle-mesh / BVH fallback for faces that
+are not quadrics): ODW_PRIM_TRIANGLE through bake, oracle and device.
+
+The reference has no such path (OpenCASCADE intersects the exact surfaces), so
+the pins are geometric: closed, outward-oriented tessellations; a tessellated
+lens converges to the analytic lens as the facets shrink; the device equals
+the oracle facet for facet."""
+import os
+
+import numpy as np
+import pytest
+
+from freecad.optics_design_workbench_amd.freecad_elements import make, point_source
+from freecad.optics_design_workbench_amd.scene import Document, bake, geometry, stl
+
+
+@pytest.mark.parametrize('kind, par, volume', [
+  (geometry.SPHERE, (5, 0, 0, 0), 4 / 3 * np.pi * 125), (geometry.TORUS, (10, 2, 0, 0), 2 * np.pi**2 * 40),
+  (geometry.CYLINDER, (2, 5, 0, 0), np.pi * 20), (geometry.CONE, (3, 1, 4, 0), np.pi * 4 / 3 * 13),
+  (geometry.CONE, (3, 0, 4, 0), np.pi * 12), (geometry.BOX, (2, 3, 4, 0), 24.0)])
+def test_tessellations_are_closed_and_outward(kind, par, volume):
+  V, T, N = geometry.tessellate(kind, par, 96)
+  p = V[T]
+  fn = np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0])
+  vn = N[T].sum(axis=1)
+  assert np.einsum('ij,ij->i', fn, vn).min() > 0                 # facets wound like the surface normals
+  assert np.abs(np.linalg.norm(N, axis=1) - 1).max() < 1e-12
+  vol = np.einsum('ij,ij->i', p[:, 0], np.cross(p[:, 1], p[:, 2])).sum() / 6   # divergence theorem: closed + outward
+  assert abs(vol - volume) < 5e-3 * volume            # inscribed polyhedra: a few 1e-3 at 96 segments
+  # every edge is shared by exactly two facets once the per-face vertices are welded
+  Vw, Tw = stl.weld(V, T, tol=1e-9)
+  e = np.sort(np.concatenate([Tw[:, [0, 1]], Tw[:, [1, 2]], Tw[:, [2, 0]]]), axis=1)
+  _, counts = np.unique(e, axis=0, return_counts=True)
+  assert np.all(counts == 2)
+
+
+def test_stl_round_trip_and_crease_normals(tmp_path):
+  V, T, N = geometry.tessellate(geometry.CYLINDER, (2, 5, 0, 0), 48)
+  path = str(tmp_path / 'cyl.stl')
+  stl.writeSTL(path, V, T)
+  Vr, Tr = stl.readSTL(path)
+  assert len(Tr) == len(T) and len(Vr) < len(V)                  # welded
+  open(str(tmp_path / 'a.stl'), 'w').write(
+      'solid a\nfacet normal 0 0 1\nouter loop\nvertex 0 0 0\nvertex 1 0 0\nvertex 0 1 0\nendloop\nendfacet\nendsolid a\n')
+  va, ta = stl.readSTL(str(tmp_path / 'a.stl'))
+  assert va.shape == (3, 3) and va[ta].tolist() == [[[0, 0, 0], [1, 0, 0], [0, 1, 0]]]   # winding kept
+  Vs, Ts, Ns = stl.smoothNormals(Vr, Tr, creaseAngleDeg=30)
+  # lateral vertices get radial normals, cap vertices axial ones: the rim stays sharp
+  rad = np.hypot(Vs[:, 0], Vs[:, 1])
+  axial = np.abs(Ns[:, 2]) > 0.99
+  lateral = ~axial
+  assert axial.sum() > 10 and lateral.sum() > 10
+  radial = np.stack([Vs[lateral, 0], Vs[lateral, 1]], 1) / rad[lateral, None]
+  assert np.abs(np.einsum('ij,ij->i', radial, Ns[lateral, :2]) - 1).max() < 1e-3     # float32 file
+  with pytest.raises(ValueError):
+    open(str(tmp_path / 'bad.stl'), 'w').write('hello')
+    stl.readSTL(str(tmp_path / 'bad.stl'))
+
+
+def _lens_scene(segments=None, smooth=True, n_src='exp(-theta**2/0.05**2)'):
+  doc = Document()
+  sp = make.makeSphere(doc, 'S', 5, base=(0, 0, 30))
+  el = [sp] if segments is None else [make.makeTessellated(doc, sp, segments, smooth=smooth)]
+  make.makeLens(doc, el, RefractiveIndex=1.5)
+  make.makeAbsorber(doc, [make.makeBox(doc, 'A', 100, 100, 1, base=(-50, -50, 60))])
+  make.makeSimulationSettings(doc)
+  src = make.makePointSource(doc, PowerDensity=n_src)
+  return doc, bake.bakeScene(doc, src), bake.bakeLimits(doc, src), point_source.bakeSource(doc, src)
+
+
+def test_bake_of_meshes():
+  _, sc, _, _ = _lens_scene(32)
+  tri = sc.prim_type == geometry.TRIANGLE
+  assert tri.sum() == sc.n_prims - 1 and sc.prim_type[0] == geometry.BOX        # analytic primitives first
+  assert sc.tri_normals.shape == (sc.n_prims, 9) and np.all(sc.tri_normals[0] == 0)
+  v = sc.prim_xform[tri][:, :9].reshape(-1, 3, 3)
+  assert np.abs(np.linalg.norm(v - [0, 0, 30], axis=2) - 5).max() < 1e-12        # placed vertices on the sphere
+  assert np.all(sc.prim_cond_off == 0) and np.all(sc.prim_group[tri] == 0)
+  assert sc.tri_normals is not None and _lens_scene(32, smooth=False)[1].tri_normals is None
+  doc = Document()
+  m = make.makeTessellated(doc, make.makeSphere(doc, 'S', 5), 16)
+  cut = make.makeCut(doc, make.makeBox(doc, 'B'), m)
+  make.makeLens(doc, [cut])
+  make.makeSimulationSettings(doc)
+  with pytest.raises(geometry.UnsupportedGeometry):
+    bake.bakeScene(doc, make.makePointSource(doc))
+
+
+def test_tessellated_lens_converges_to_the_analytic_lens(oracle):
+  """ball lens, same rays: hit positions on the screen approach the analytic
+  ones like the chord error (~1/segments^2) with interpolated normals; facet
+  normals alone leave an error of the order of the facet angle"""
+  n = 3000
+  _, a, lim, src = _lens_scene()
+  exact = oracle.trace(a, src, lim, 0, n, 1, nthreads=4)
+  ref = exact['hits']['point']
+  err = {}
+  for seg in (24, 48, 96):
+    _, m, lim, src = _lens_scene(seg)
+    r = oracle.trace(m, src, lim, 0, n, 1, nthreads=4)
+    assert r['counters'] == exact['counters']
+    err[seg] = np.sqrt(np.mean(np.sum((r['hits']['point'] - ref)**2, axis=1)))
+  assert err[48] < 0.45 * err[24] and err[96] < 0.45 * err[48] and err[96] < 0.05
+  _, flat, lim, src = _lens_scene(96, smooth=False)
+  flat_err = np.sqrt(np.mean(np.sum((oracle.trace(flat, src, lim, 0, n, 1, nthreads=4)['hits']['point'] - ref)**2, axis=1)))
+  assert flat_err > 5 * err[96]
+
+
+# ---------------------------------------------------------------------------
+@pytest.fixture(scope='module')
+def tracer(native_lib):
+  from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
+  tr = Tracer(0)
+  yield tr
+  tr.close()
+
+
+def _mixed_scene():
+  """tessellated torus lens + tessellated (facet-normal) cone mirror + analytic sphere lens + wall"""
+  doc = Document()
+  to = make.makeTorus(doc, 'T', 8, 2.5, base=(0, 0, 20))
+  co = make.makeCone(doc, 'C', 4, 1, 6, base=(14, 0, 18), quat=(np.sin(0.3), 0, 0, np.cos(0.3)))
+  make.makeLens(doc, [make.makeTessellated(doc, to, 40)], RefractiveIndex=1.4, RecordHits=True)
+  make.makeMirror(doc, [make.makeTessellated(doc, co, 24, smooth=False)], RecordHits=True)
+  make.makeLens(doc, [make.makeSphere(doc, 'S', 3, base=(-12, 0, 20))], RefractiveIndex=1.7, RecordHits=True,
+                name='OpticalLensGroup2')
+  make.makeAbsorber(doc, [make.makeBox(doc, 'W', 300, 300, 1, base=(-150, -150, 60))])
+  make.makeSimulationSettings(doc, MaxIntersections=30.0)
+  src = make.makePointSource(doc, PowerDensity='1', ThetaDomain='0, 0.9')
+  return bake.bakeScene(doc, src), bake.bakeLimits(doc, src), point_source.bakeSource(doc, src)
+
+
+@pytest.mark.gpu
+def test_device_equals_oracle_on_meshes(tracer, oracle):
+  sc, lim, src = _mixed_scene()
+  assert (sc.prim_type == geometry.TRIANGLE).sum() > 1500
+  n = 20000
+  tracer.setScene(sc); tracer.setSource(src); tracer.setLimits(lim); tracer.setDetector(None)
+  tracer.reserveHits(n * 31)
+  tracer.reset()
+  tracer.trace(0, n, 7)
+  tracer.sync()
+  g, gc = tracer.hits(), tracer.counters()
+  ref = oracle.trace(sc, src, lim, 0, n, 7, hit_capacity=n * 31, nthreads=8)
+  r, rc = ref['hits'], ref['counters']
+  assert rc['recorded_hits'] > 1.5 * n
+  # rays trapped inside the torus lens bounce many times and amplify rounding: compare short paths exactly
+  m48 = np.uint64(0xFFFFFFFFFFFF)
+  gr, rr = (g['tag'] & m48).astype(np.int64), (r['tag'] & m48).astype(np.int64)
+  cg, cr = np.bincount(gr, minlength=n), np.bincount(rr, minlength=n)
+  ok = (cg == cr) & (cg <= 8)
+  assert ok.mean() > 0.97 and (cg != cr).mean() < 5e-3
+  sg, sr = ok[gr], ok[rr]
+  assert np.array_equal(g['tag'][sg], r['tag'][sr])
+  dp = np.abs(g['point'][sg] - r['point'][sr]).max(axis=1)
+  assert (dp < 1e-7).mean() > 0.999 and dp.max() < 1e-3
+  assert gc['traced_rays'] == rc['traced_rays'] == n
+
+
+@pytest.mark.gpu
+def test_large_mesh_matches_analytic_statistics(tracer):
+  """2e5 facets (BVH with binned SAH): the ball-lens spot of the tessellated
+  lens equals the analytic one within the facet error, all rays accounted for"""
+  n = 400000
+  res = {}
+  for seg in (None, 448):
+    _, sc, lim, src = _lens_scene(seg)
+    tracer.setScene(sc); tracer.setSource(src); tracer.setLimits(lim); tracer.setDetector(None)
+    tracer.reserveHits(n + 1024)
+    tracer.reset()
+    tracer.trace(0, n, 3)
+    tracer.sync()
+    c, h = tracer.counters(), tracer.hits()
+    assert c['traced_rays'] == n and c['recorded_hits'] + c['escaped'] + c['capped'] >= n - 5
+    res[seg] = (c, h['point'][np.argsort((h['tag'] & np.uint64(0xFFFFFFFFFFFF)))])
+  assert sc.n_prims > 190000
+  ca, cm = res[None][0], res[448][0]
+  assert ca['recorded_hits'] == cm['recorded_hits'] and abs(ca['segments'] - cm['segments']) < 20
+  assert np.sqrt(np.mean(np.sum((res[None][1] - res[448][1])**2, axis=1))) < 5e-3
