@@ -25,7 +25,7 @@ namespace {
 constexpr int kGuide = 1 << 16;
 constexpr int kSurfaceGuide = 1 << 10;  // per row of a surface sampler (tables of ~1e3 knots)
 constexpr int kBvhThreshold = 16;  // brute force (scalar loads) below this many primitives
-constexpr int kBvhLeaf = 4;
+const int kBvhLeaf = [] { const char* e = getenv("ODW_BVH_LEAF"); const int v = e ? atoi(e) : 0; return v > 0 && v < 200 ? v : 8; }();   // largest leaf the SAH may form (measured: 8 >= 4 > 2 > 1 on meshes)
 constexpr int kBvhSweepMax = 2048;       // nodes with more primitives use binned SAH
 
 std::string g_error;
