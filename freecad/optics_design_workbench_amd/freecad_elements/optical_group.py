@@ -83,12 +83,31 @@ def _is_identity_dirac(expr):
     return False
 
 
+def _is_ideal_dirac(expr):
+  """c * DiracDelta(theta - theta_refl) [* DiracDelta(phi - phi_refl)]: the ideal
+  direction with certainty (the default the reference's authors have in mind for
+  Reflected/RefractedProbabilityDensity, optical_group.py:39-41, 50-52)"""
+  theta, phi, tr, pr = (sy.Symbol(n) for n in ('theta', 'phi', 'theta_refl', 'phi_refl'))
+  d_theta, d_phi = sy.DiracDelta(theta - tr), sy.DiracDelta(phi - pr)
+  if not expr.has(d_theta):
+    return False
+  rest = expr.subs(d_theta, 1).subs(d_phi, 1)
+  if rest.has(sy.DiracDelta) or rest.free_symbols:
+    return False
+  try:
+    return bool(rest.evalf() > 0)
+  except TypeError:
+    return False
+
+
 def _bakeOne(obj, group_index, kind, density, theta_dom, phi_dom, optical_type, n_family):
   expr = sy.sympify(density)
   names = {str(s) for s in expr.free_symbols}
   if expr.has(sy.DiracDelta):
     if kind == MODIFY and _is_identity_dirac(expr):
       return None
+    if kind == PRIMARY and _is_ideal_dirac(expr):
+      return None        # theta = theta_refl, phi = phi_refl = 0: Rot(n x d, theta_refl) n is the ideal direction
     raise NotImplementedError(
         f'{obj.Name}: density "{density}" contains DiracDelta terms other than the identity '
         f'modification DiracDelta(theta); discrete events '

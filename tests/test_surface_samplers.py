@@ -74,8 +74,12 @@ def test_dirac_modification_is_identity_and_others_are_rejected():
   # absorbers never scatter (ray.py:270-272), whatever the property holds
   g = _group('Absorber', RayModificationProbabilityDensity='DiracDelta(theta-1)')
   assert optical_group.surfaceSamplers(g, 0) == []
+  # the ideal direction with certainty = an ideal surface
+  for dens in ('DiracDelta(theta-theta_refl) * DiracDelta(phi-phi_refl)', 'DiracDelta(theta-theta_refl)'):
+    assert optical_group.surfaceSamplers(_group('Mirror', ReflectedProbabilityDensity=dens), 0) == []
+    assert optical_group.surfaceSamplers(_group('Lens', RefractedProbabilityDensity=dens), 0) == []
   with pytest.raises(NotImplementedError):
-    optical_group.surfaceSamplers(_group('Mirror', ReflectedProbabilityDensity='DiracDelta(theta-theta_refl)'), 0)
+    optical_group.surfaceSamplers(_group('Mirror', ReflectedProbabilityDensity='DiracDelta(theta-theta_in)'), 0)
   with pytest.raises(ValueError):     # modification draws have no constants (optical_group.py:317)
     optical_group.surfaceSamplers(_group('Mirror', RayModificationProbabilityDensity='exp(-(theta-theta_in)**2)'), 0)
   with pytest.raises(ValueError):
