@@ -601,6 +601,8 @@ int odw_upload_scene(odw_ctx* ctx, const odw_scene_desc* s) {
     return fail(ctx, ODW_ERR_INVALID, "odw_upload_scene: null table pointer");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const int n = s->n_prims;
+  int max_solid = 0;
+  for (int p = 0; p < n && s->prim_solid; ++p) max_solid = std::max(max_solid, s->prim_solid[p]);
   ctx->h_prim_f64.assign((size_t)n * 16, 0.0);
   ctx->h_prim_i32.assign((size_t)n * 4, 0);
   for (int p = 0; p < n; ++p) {
@@ -634,7 +636,11 @@ int odw_upload_scene(odw_ctx* ctx, const odw_scene_desc* s) {
     }
     ctx->h_prim_i32[4 * p] = type;
     ctx->h_prim_i32[4 * p + 1] = group;
-    ctx->h_prim_i32[4 * p + 2] = s->prim_flags[p];
+    // flags | facemask << 8 in the low half, solid id above; scenes with more solids than fit lose the
+    // convex-solid shortcut, nothing else
+    const int solid = s->prim_solid ? s->prim_solid[p] : 0;
+    const bool fits = s->prim_solid && solid >= 0 && solid < 0x7fff && max_solid < 0x7fff;
+    ctx->h_prim_i32[4 * p + 2] = ((s->prim_flags[p] & 0xffff) & (fits ? ~0 : ~ODW_FLAG_CONVEX)) | ((fits ? solid : 0x7fff) << ODW_SOLID_SHIFT);
     ctx->h_prim_i32[4 * p + 3] = off | (cnt << 24);
   }
   std::vector<int32_t> cond((size_t)std::max(1, s->n_conds), 0);

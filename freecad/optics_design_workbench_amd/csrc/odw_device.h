@@ -21,6 +21,8 @@
 
 namespace odw {
 
+#define ODW_SOLID_SHIFT 16   // prim_i32 flags word: flags | facemask << 8 | solid id << 16
+
 struct d3 {
   double x, y, z;
 };

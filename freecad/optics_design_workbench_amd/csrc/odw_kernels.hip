@@ -352,7 +352,7 @@ __device__ __forceinline__ void intersect_prim(const SceneView& sv, Query& q, in
                                                int flags, int cond_word) {
   cf64 pf = sv.prim_f64 + (size_t)p * 16;
   const int cond_off = cond_word & 0xffffff, cond_cnt = (cond_word >> 24) & 0xff;
-  const int fmask = flags >> ODW_FACEMASK_SHIFT;
+  const int fmask = (flags >> ODW_FACEMASK_SHIFT) & 0xff;
   cf64 par = pf + 12;
   const double tol = q.tol;
   const d3 o = xf_point(pf, q.start);
@@ -617,7 +617,7 @@ template <bool BVH>
 __device__ __forceinline__ int nearest(const DeviceScene& sc, const SceneView& sv,
                                        const DeviceLimits& lim, d3 start, d3 dn, int medium,
                                        uint64_t mask, double& t_hit, int& face,
-                                       int* __restrict__ stack) {
+                                       int* __restrict__ stack, int skip_solid) {
   Query q;
   q.start = start; q.dn = dn; q.tol = lim.dist_tol; q.tmax = lim.max_ray_length + lim.dist_tol;
   q.medium = medium;
@@ -639,6 +639,8 @@ __device__ __forceinline__ int nearest(const DeviceScene& sc, const SceneView& s
       } else {
         if (!((umask >> g) & 1)) continue;
       }
+      // a ray that has just left a convex solid cannot meet it again
+      if ((flags >> ODW_SOLID_SHIFT) == skip_solid) continue;
       // candidates farther than the nearest hit + 2*distTol can never be
       // selected (ray.py:432,440): shrink the search like the reference does
       const double cut = fmin(q.tmax, q.any.t + 2.0 * q.tol);
@@ -712,7 +714,7 @@ __device__ __forceinline__ int nearest(const DeviceScene& sc, const SceneView& s
         const int p = bvh_prims[leaf_first + i];
         ci32 pi = sv.prim_i32 + 4 * p;
         const int g = pi[1];
-        if ((mask >> g) & 1) {
+        if (((mask >> g) & 1) && (pi[2] >> ODW_SOLID_SHIFT) != skip_solid) {
           if (pi[0] == ODW_PRIM_TRIANGLE) intersect_tri(sv, q, p, g);
           else intersect_prim(sv, q, p, pi[0], g, pi[2], pi[3]);
         }
@@ -927,6 +929,7 @@ __global__ __launch_bounds__(256, ODW_WAVES_PER_SIMD) void odw_trace_kernel(cons
   d3 point = mk(0, 0, 0), dir = mk(0, 0, 1);
   double power = 0;
   int seq = 0, nint = 0, medium = -1;
+  int skip = -1;     // solid the ray has just left, if that solid is convex (it cannot be met again)
   for (;;) {
     const uint64_t idle = __ballot(!alive);
     // refill when the wave is empty or enough lanes are idle to make the
@@ -961,7 +964,7 @@ __global__ __launch_bounds__(256, ODW_WAVES_PER_SIMD) void odw_trace_kernel(cons
         // `dir` stays a unit vector: mirror() preserves length, snells_law() and
         // line_grating() return unit vectors for unit input; the reference
         // renormalises every segment (ray.py:377), a no-op up to rounding
-        seq = 0; nint = 0; medium = -1;
+        seq = 0; nint = 0; medium = -1; skip = -1;
         alive = true;
       }
       next += take;
@@ -979,7 +982,7 @@ __global__ __launch_bounds__(256, ODW_WAVES_PER_SIMD) void odw_trace_kernel(cons
       double t_hit;
       int face;
       const int prim = nearest<BVH>(sc, sv, lim, point, dir, medium, mask, t_hit, face,
-                                    bvh_stack + threadIdx.x);
+                                    bvh_stack + threadIdx.x, skip);
       if (prim < 0) {
         ODW_COUNT(ODW_CNT_ESCAPED);
         alive = false;
@@ -1054,6 +1057,8 @@ __global__ __launch_bounds__(256, ODW_WAVES_PER_SIMD) void odw_trace_kernel(cons
           if (!tir) { medium = -1; ++seq; }
         }
       }
+      // outward normal of the solid = n against the travel direction when entering
+      skip = ((pi[2] & ODW_FLAG_CONVEX) && (entering ? -dot(dir, n) : dot(dir, n)) > 0) ? (pi[2] >> ODW_SOLID_SHIFT) : -1;
       if (alive && power < lim.power_tol) { ODW_COUNT(ODW_CNT_DIED); alive = false; }
       }
       }

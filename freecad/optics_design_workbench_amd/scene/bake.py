@@ -256,7 +256,9 @@ def bakeScene(doc, source=None, surfaceFamily=None):
             solid_id += 1
             continue
           flat = geometry.flatten(tree, gp)
+          convex = geometry.is_convex(tree)
           for fp in flat:
+            fp.convex = convex
             fp.index = len(prims)
             prims.append(fp)
             prim_group.append(gi)
@@ -326,7 +328,8 @@ def bakeScene(doc, source=None, surfaceFamily=None):
                                 np.full(n_tri, geometry.TRIANGLE, dtype=np.int32)]),
       prim_group=np.concatenate([np.array(prim_group, dtype=np.int32), tri_group]),
       prim_solid=np.concatenate([np.array(prim_solid, dtype=np.int32), tri_solid]),
-      prim_flags=np.concatenate([np.array([(1 if p.flip else 0) | (p.facemask << 8) for p in prims], dtype=np.int32),
+      prim_flags=np.concatenate([np.array([(1 if p.flip else 0) | (2 if getattr(p, 'convex', False) else 0) | (p.facemask << 8)
+                                           for p in prims], dtype=np.int32),
                                  np.full(n_tri, 1 << 8, dtype=np.int32)]),
       prim_xform=np.concatenate([np.array([p.to_world.inverse().rows12() for p in prims],
                                           dtype=np.float64).reshape(n, 12), tri_xform]),

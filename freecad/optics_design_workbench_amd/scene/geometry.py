@@ -210,6 +210,16 @@ def _assign(node, conds, flip):
     _assign(kids[1], conds + _inside_conj(kids[0]), not flip)
 
 
+def is_convex(node):
+  """True for solids a straight line meets in one interval: box, sphere,
+  cylinder, cone and intersections (Common) of such"""
+  if node.op == 'prim':
+    return node.kind in (BOX, SPHERE, CYLINDER, CONE)
+  if node.op == 'common':
+    return all(is_convex(c) for c in node.children)
+  return False
+
+
 def flatten(tree, acc=None):
   """CSG tree -> [FlatPrim] (every leaf once; conditions reference leaves)"""
   out = []

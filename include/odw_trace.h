@@ -64,6 +64,12 @@ enum {
 /*  SPHERE/TORUS/TRIANGLE: 0                                                */
 #define ODW_FLAG_FLIP_NORMAL 0x1 /* face normals point INTO the primitive   */
                                  /* (tool of a Part::Cut)                   */
+#define ODW_FLAG_CONVEX 0x2      /* the primitive's solid (prim_solid) is convex:*/
+                                 /* a box, sphere, cylinder, cone or a Common of */
+                                 /* such.  A ray that leaves a convex solid      */
+                                 /* (direction . outward normal > 0) cannot meet */
+                                 /* it again: its primitives are not tested for  */
+                                 /* the next segment.                            */
 #define ODW_FACEMASK_SHIFT 8
 
 /* ---- optical types: OpticalGroupProxy.OpticalType enumeration order ----- */
@@ -87,7 +93,8 @@ typedef struct odw_scene_desc {
   int32_t n_prims;
   const int32_t* prim_type;     /* [n_prims] ODW_PRIM_*                       */
   const int32_t* prim_group;    /* [n_prims] index into group tables          */
-  const int32_t* prim_solid;    /* [n_prims] shell id (informational)         */
+  const int32_t* prim_solid;    /* [n_prims] id of the solid (shell) the      */
+                                /* primitive bounds, see ODW_FLAG_CONVEX      */
   const int32_t* prim_flags;    /* [n_prims] ODW_FLAG_* | facemask<<8         */
   const double*  prim_xform;    /* [n_prims*12] global->local, rows (R|t)     */
   const double*  prim_params;   /* [n_prims*4]                                */

@@ -460,8 +460,19 @@ static int better(double t, int prim, int face, double bt, int bprim, int bface)
   return face < bface;
 }
 
+static nearest_hit nearest_skipping(const odw_scene_desc* sc, const odw_limits* lim, v3 start,
+                                    v3 dir, int medium, int seq_idx, int skip_solid);
+
 static nearest_hit nearest(const odw_scene_desc* sc, const odw_limits* lim, v3 start,
                            v3 dir, int medium, int seq_idx) {
+  return nearest_skipping(sc, lim, start, dir, medium, seq_idx, -1);
+}
+
+/* skip_solid: the convex solid the ray has just left (ODW_FLAG_CONVEX,
+ * include/odw_trace.h): a straight line meets a convex solid in one interval,
+ * so none of its faces can be met again; -1: none */
+static nearest_hit nearest_skipping(const odw_scene_desc* sc, const odw_limits* lim, v3 start,
+                                    v3 dir, int medium, int seq_idx, int skip_solid) {
   const double tol = lim->dist_tol;
   const double max_len = lim->max_ray_length;
   uint64_t mask = relevant_mask(sc, seq_idx);
@@ -474,6 +485,7 @@ static nearest_hit nearest(const odw_scene_desc* sc, const odw_limits* lim, v3 s
   for (int p = 0; p < sc->n_prims; ++p) {
     int g = sc->prim_group[p];
     if (!((mask >> g) & 1)) continue;
+    if (skip_solid >= 0 && sc->prim_solid && sc->prim_solid[p] == skip_solid) continue;
     const double* M = sc->prim_xform + 12 * (size_t)p;
     if (sc->prim_type[p] == ODW_PRIM_TRIANGLE) {
       /* one facet of a tessellated face (include/odw_trace.h): v0, v1, v2 in
@@ -728,12 +740,12 @@ static void record_hit(sink* sk, const odw_detector_desc* det, uint32_t flags,
 static void trace_one(const odw_scene_desc* sc, const odw_limits* lim,
                       const odw_detector_desc* det, double wavelength, uint32_t flags,
                       uint64_t ray, uint64_t seed, v3 point, v3 dir, double power, sink* sk) {
-  int seq = 0, nint = 0, medium = -1;
+  int seq = 0, nint = 0, medium = -1, skip_solid = -1;
   for (;;) {
     if (nint >= lim->max_intersections) { sk->cnt[ODW_CNT_CAPPED]++; break; }
     nint++;
     sk->cnt[ODW_CNT_SEGMENTS]++;
-    nearest_hit h = nearest(sc, lim, point, dir, medium, seq);
+    nearest_hit h = nearest_skipping(sc, lim, point, dir, medium, seq, skip_solid);
     if (!h.found) { sk->cnt[ODW_CNT_ESCAPED]++; break; }
     v3 prev = point;
     int prev_medium = medium;
@@ -804,6 +816,13 @@ static void trace_one(const odw_scene_desc* sc, const odw_limits* lim,
       seq++;
     } else if (type == ODW_OPT_VACUUM) {
       seq++;
+    }
+    /* leaving a convex solid (outgoing direction along its outward normal): its
+     * primitives are not candidates of the next segment */
+    skip_solid = -1;
+    if ((sc->prim_flags[h.prim] & ODW_FLAG_CONVEX) && sc->prim_solid) {
+      double along = dot(dir, n);              /* n points along the incoming travel direction */
+      if ((entering ? -along : along) > 0) skip_solid = sc->prim_solid[h.prim];
     }
     if (power < lim->power_tol) { sk->cnt[ODW_CNT_DIED]++; break; }
   }
