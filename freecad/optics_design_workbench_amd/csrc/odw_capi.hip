@@ -23,6 +23,8 @@ using namespace odw;
 namespace {
 
 constexpr int kGuide = 1 << 16;
+constexpr uint32_t kHitBlock = 512;            // hit-list slots a wave reserves per atomic (big hit lists only)
+constexpr uint64_t kHitBlockMinRows = 1ull << 22;
 constexpr int kSurfaceGuide = 1 << 10;  // per row of a surface sampler (tables of ~1e3 knots)
 constexpr int kBvhThreshold = 16;  // brute force (scalar loads) below this many primitives
 const int kBvhLeaf = [] { const char* e = getenv("ODW_BVH_LEAF"); const int v = e ? atoi(e) : 0; return v > 0 && v < 200 ? v : 8; }();   // largest leaf the SAH may form (measured: 8 >= 4 > 2 > 1 on meshes)
@@ -67,7 +69,8 @@ struct odw_ctx {
   DevBuf em_prim_f64, em_prim_i32, em_cond, em_face_i32, em_face_cdf, em_t_tab, em_t_guide, em_o, em_d;
   DeviceEmitter h_emitter;
   bool emitter_active = false;   // the most recently uploaded source is a surface source
-  uint64_t hit_capacity = 0, n_bins = 0;
+  uint64_t hit_capacity = 0, n_bins = 0;   // hit_capacity: rows the caller asked for
+  uint64_t hit_slots = 0;                  // rows allocated (capacity + slack for block reservations)
 
   TraceParams P;
   odw_detector_desc det_desc;
@@ -425,7 +428,8 @@ __global__ void hit_keys_kernel(const odw_hit* __restrict__ hits, uint64_t n, ui
                                 uint32_t* __restrict__ vals) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
-    keys[i] = ODW_HIT_RAY(hits[i].tag);
+    const uint64_t tag = hits[i].tag;
+    keys[i] = tag == ODW_TAG_UNUSED ? (1ull << 48) : ODW_HIT_RAY(tag);   // unused slots sort behind every ray
     vals[i] = (uint32_t)i;
   }
 }
@@ -466,7 +470,10 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
   P.ray_dirs = ray_d;
   P.ray_powers = ray_p;
   P.out.hits = (odw_hit*)ctx->hits.p;
-  P.out.hit_capacity = ctx->hit_capacity;
+  P.out.hit_capacity = ctx->hit_slots;
+  // block reservations need room for the unused slots they can leave behind: < 64 per block and the
+  // last block of every wave of the grid
+  P.out.hit_block = 0;
   P.out.hit_count = (unsigned long long*)ctx->hit_count.p;
   P.out.hist = (unsigned long long*)ctx->hist.p;
   P.out.counters = (unsigned long long*)ctx->counters.p;
@@ -479,6 +486,8 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
   const uint64_t n_chunks = (n + ODW_CHUNK - 1) / ODW_CHUNK;
   const uint64_t cap = (uint64_t)ctx->n_cu * grid_mult;
   const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_chunks + 3) / 4, cap));
+  if (ctx->hit_slots >= ctx->hit_capacity + ctx->hit_capacity / 8 + 64 + (uint64_t)grid * 4 * kHitBlock)
+    P.out.hit_block = kHitBlock;
   HIPCHK(ctx, hipMemsetAsync(ctx->chunk_counter.p, 0, sizeof(uint64_t), ctx->stream));
   const size_t lds = P.scene.n_nodes ? (size_t)ODW_BVH_STACK * 256 * sizeof(int) : 0;
 
@@ -555,7 +564,7 @@ int odw_create(int device, odw_ctx** out) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
   int rc = ensure(ctx, ctx->counters, ODW_CNT_COUNT * sizeof(uint64_t));
-  if (!rc) rc = ensure(ctx, ctx->hit_count, sizeof(uint64_t));
+  if (!rc) rc = ensure(ctx, ctx->hit_count, 2 * sizeof(uint64_t));
   if (!rc) rc = ensure(ctx, ctx->chunk_counter, sizeof(uint64_t));
   if (!rc) rc = ensure(ctx, ctx->hist, 16);
   if (rc) { g_error = ctx->err; odw_destroy(ctx); return rc; }
@@ -1014,13 +1023,20 @@ int odw_reserve_hits(odw_ctx* ctx, uint64_t capacity) {
   if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_reserve_hits: null ctx");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  if (capacity == 0) { release(ctx->hits); ctx->hit_capacity = 0; return ODW_OK; }
+  if (capacity == 0) { release(ctx->hits); ctx->hit_capacity = ctx->hit_slots = 0; return ODW_OK; }
   if (capacity > ctx->hit_capacity) {
     release(ctx->hits);
-    ctx->hit_capacity = 0;
-    int rc = ensure(ctx, ctx->hits, capacity * sizeof(odw_hit));
+    ctx->hit_capacity = ctx->hit_slots = 0;
+    // big lists get slack for block reservations (launch_trace): an eighth (unused slots at block
+    // changes) + one block per wave of the largest grid
+    uint64_t slots = capacity;
+    if (capacity >= kHitBlockMinRows) slots += capacity / 8 + 64 + (uint64_t)ctx->n_cu * 8 * 4 * kHitBlock;
+    int rc = ensure(ctx, ctx->hits, slots * sizeof(odw_hit));
     if (rc) return rc;
     ctx->hit_capacity = capacity;
+    ctx->hit_slots = slots;
+    // a new buffer: rows recorded so far are gone
+    HIPCHK(ctx, hipMemsetAsync(ctx->hit_count.p, 0, 2 * sizeof(uint64_t), ctx->stream));
   }
   return ODW_OK;
 }
@@ -1074,7 +1090,7 @@ int odw_reset_results(odw_ctx* ctx) {
   if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_reset_results: null ctx");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, ODW_CNT_COUNT * sizeof(uint64_t), ctx->stream));
-  HIPCHK(ctx, hipMemsetAsync(ctx->hit_count.p, 0, sizeof(uint64_t), ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->hit_count.p, 0, 2 * sizeof(uint64_t), ctx->stream));
   if (ctx->n_bins) HIPCHK(ctx, hipMemsetAsync(ctx->hist.p, 0, ctx->n_bins * sizeof(uint64_t), ctx->stream));
   return ODW_OK;
 }
@@ -1082,7 +1098,7 @@ int odw_reset_results(odw_ctx* ctx) {
 int odw_reset_hits(odw_ctx* ctx) {
   if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_reset_hits: null ctx");
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  HIPCHK(ctx, hipMemsetAsync(ctx->hit_count.p, 0, sizeof(uint64_t), ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->hit_count.p, 0, 2 * sizeof(uint64_t), ctx->stream));
   return ODW_OK;
 }
 
@@ -1096,20 +1112,27 @@ int odw_fetch_counters(odw_ctx* ctx, uint64_t* out, int32_t n) {
   return ODW_OK;
 }
 
+// slots handed out (clamped to the buffer) and how many of them hold rows
+static int hit_slots_used(odw_ctx* ctx, uint64_t* used, uint64_t* rows) {
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  uint64_t v[2] = {0, 0};
+  HIPCHK(ctx, hipMemcpyAsync(v, ctx->hit_count.p, sizeof v, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  *used = std::min<uint64_t>(v[0], ctx->hit_slots);
+  *rows = *used > v[1] ? *used - v[1] : 0;
+  return ODW_OK;
+}
+
 int odw_hit_count(odw_ctx* ctx, uint64_t* n) {
   if (!ctx || !n) return fail(ctx, ODW_ERR_INVALID, "odw_hit_count: bad argument");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
-  uint64_t v = 0;
-  HIPCHK(ctx, hipMemcpyAsync(&v, ctx->hit_count.p, sizeof v, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  *n = std::min<uint64_t>(v, ctx->hit_capacity);
-  return ODW_OK;
+  uint64_t used = 0;
+  return hit_slots_used(ctx, &used, n);
 }
 
 int odw_fetch_hits(odw_ctx* ctx, odw_hit* out, uint64_t capacity, uint64_t* n) {
   if (!ctx || !n) return fail(ctx, ODW_ERR_INVALID, "odw_fetch_hits: bad argument");
-  uint64_t have = 0;
-  int rc = odw_hit_count(ctx, &have);
+  uint64_t used = 0, have = 0;
+  int rc = hit_slots_used(ctx, &used, &have);
   if (rc) return rc;
   *n = have;
   if (!out || capacity == 0) return ODW_OK;
@@ -1117,29 +1140,29 @@ int odw_fetch_hits(odw_ctx* ctx, odw_hit* out, uint64_t capacity, uint64_t* n) {
   if (have) {
     // append order is scheduling dependent; a ray's own rows are appended in
     // bounce order, so a STABLE sort by ray index gives (ray, bounce) order.
-    // Done on the device: LSD radix sort of (ray index -> row number) pairs
-    // (hipCUB, stable), then a gather of the 64-byte rows, then one D2H copy.
-    if (have > 0x7FFFFFFFull) return fail(ctx, ODW_ERR_CAPACITY, "odw_fetch_hits: more than 2^31 rows per fetch");
-    int rc;
+    // Done on the device: LSD radix sort of (ray index -> slot number) pairs
+    // (hipCUB, stable; unused slots of block reservations sort to the end),
+    // then a gather of the 64-byte rows, then one D2H copy.
+    if (used > 0x7FFFFFFFull) return fail(ctx, ODW_ERR_CAPACITY, "odw_fetch_hits: more than 2^31 rows per fetch");
     for (int k = 0; k < 2; ++k) {
-      if ((rc = ensure(ctx, ctx->sort_keys[k], have * sizeof(uint64_t)))) return rc;
-      if ((rc = ensure(ctx, ctx->sort_vals[k], have * sizeof(uint32_t)))) return rc;
+      if ((rc = ensure(ctx, ctx->sort_keys[k], used * sizeof(uint64_t)))) return rc;
+      if ((rc = ensure(ctx, ctx->sort_vals[k], used * sizeof(uint32_t)))) return rc;
     }
     if ((rc = ensure(ctx, ctx->sorted_rows, have * sizeof(odw_hit)))) return rc;
     uint64_t* k_in = (uint64_t*)ctx->sort_keys[0].p;
     uint64_t* k_out = (uint64_t*)ctx->sort_keys[1].p;
     uint32_t* v_in = (uint32_t*)ctx->sort_vals[0].p;
     uint32_t* v_out = (uint32_t*)ctx->sort_vals[1].p;
-    const unsigned blocks = (unsigned)((have + 255) / 256);
+    const unsigned blocks = (unsigned)((used + 255) / 256);
     hipLaunchKernelGGL(hit_keys_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const odw_hit*)ctx->hits.p,
-                       have, k_in, v_in);
+                       used, k_in, v_in);
     HIPCHK(ctx, hipGetLastError());
     size_t tmp_bytes = 0;
-    HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k_in, k_out, v_in, v_out, (int)have, 0, 48,
+    HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k_in, k_out, v_in, v_out, (int)used, 0, 49,
                                                    ctx->stream));
     if ((rc = ensure(ctx, ctx->sort_tmp, tmp_bytes))) return rc;
-    HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(ctx->sort_tmp.p, tmp_bytes, k_in, k_out, v_in, v_out, (int)have,
-                                                   0, 48, ctx->stream));
+    HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(ctx->sort_tmp.p, tmp_bytes, k_in, k_out, v_in, v_out, (int)used,
+                                                   0, 49, ctx->stream));
     const unsigned gblocks = (unsigned)((have * 4 + 255) / 256);
     hipLaunchKernelGGL(hit_gather_kernel, dim3(gblocks), dim3(256), 0, ctx->stream, (const odw_hit*)ctx->hits.p,
                        v_out, have, (odw_hit*)ctx->sorted_rows.p);

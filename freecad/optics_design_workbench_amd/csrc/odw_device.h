@@ -21,6 +21,7 @@
 
 namespace odw {
 
+#define ODW_TAG_UNUSED 0xFFFFFFFFFFFFFFFFull   // tag of a hit-list slot that was reserved but not written
 #define ODW_SOLID_SHIFT 16   // prim_i32 flags word: flags | facemask << 8 | solid id << 16
 
 struct d3 {
@@ -105,7 +106,8 @@ struct DeviceDetector {
 struct DeviceOutputs {
   odw_hit* hits;
   uint64_t hit_capacity;
-  unsigned long long* hit_count;       // device counter
+  unsigned long long* hit_count;       // [0] slots handed out, [1] of these: unused (marked with ODW_TAG_UNUSED)
+  uint32_t hit_block;                  // 0: one reservation per append; else slots per reservation of a wave
   unsigned long long* hist;            // nx*ny
   unsigned long long* counters;        // ODW_CNT_COUNT
   unsigned long long* chunk_counter;   // next unassigned chunk of this launch (zeroed per launch)

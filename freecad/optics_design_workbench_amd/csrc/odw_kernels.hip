@@ -828,17 +828,54 @@ __device__ __noinline__ d3 scatter(const DeviceSurfaceSampler* samplers, int s_p
 // ------------------------------------------------------- recording (K5)
 // Active lanes append one 64-B row each: one atomic per wave reserves the
 // block, lanes take consecutive slots by popcount prefix of the ballot.
+// block change of a wave's hit-list reservation (rare: out of line): the slots the old block has
+// left (< number of recording lanes) are marked unused, a new block is taken
+__device__ __noinline__ void next_hit_block(odw_hit* hits, uint64_t capacity, unsigned long long* hit_count,
+                                            uint32_t block, volatile uint32_t* hit_state, uint32_t hit_used,
+                                            uint32_t rank, bool leader) {
+  const uint64_t old_base = ((uint64_t)hit_state[1] << 32) | hit_state[0];
+  const uint32_t left = block - hit_used;
+  if (rank < left && old_base + hit_used + rank < capacity) hits[old_base + hit_used + rank].tag = ODW_TAG_UNUSED;
+  if (leader) {
+    const unsigned long long base = atomicAdd(hit_count, (unsigned long long)block);
+    if (left) atomicAdd(hit_count + 1, (unsigned long long)left);
+    hit_state[0] = (uint32_t)base;
+    hit_state[1] = (uint32_t)(base >> 32);
+  }
+}
+
 __device__ __forceinline__ void record_hit(const TraceParams& P, uint64_t ray, int group, d3 p, d3 d,
-                                           double power, bool entering, uint32_t* cnt) {
+                                           double power, bool entering, uint32_t* cnt,
+                                           volatile uint32_t* hit_state) {
   if (P.flags & ODW_TRACE_RECORD_HITS) {
     const uint64_t active = __ballot(1);
     const int lane = __lane_id();
     const int leader = __ffsll((unsigned long long)active) - 1;
-    unsigned long long base = 0;
-    if (lane == leader) base = atomicAdd(P.out.hit_count, (unsigned long long)__popcll(active));
-    const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base);
-    const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
-    const uint64_t slot = (((uint64_t)bhi << 32) | blo) + __popcll(active & ((1ull << lane) - 1ull));
+    const uint32_t n_act = __popcll(active);
+    const uint32_t rank = __popcll(active & ((1ull << lane) - 1ull));
+    uint64_t slot;
+    if (P.out.hit_block) {
+      // One atomic per wave and append serialises 1.5e6 appends of a launch on a single counter at
+      // the memory side (1.2 - 3 ms of a 20 ms launch, measured).  A wave therefore takes hit_block
+      // slots at a time and hands them out itself; slots it cannot use (< 64 at a block change, the
+      // rest of its last block at the end) are marked ODW_TAG_UNUSED and dropped by odw_fetch_hits.
+      // the wave's block lives in LDS (base lo, base hi, used): only the recording lanes are active
+      // here, a register copy would go stale in the others
+      uint32_t hit_used = hit_state[2];
+      if (hit_used + n_act > P.out.hit_block) {
+        next_hit_block(P.out.hits, P.out.hit_capacity, P.out.hit_count, P.out.hit_block, hit_state, hit_used, rank,
+                       lane == leader);
+        hit_used = 0;
+      }
+      slot = (((uint64_t)hit_state[1] << 32) | hit_state[0]) + hit_used + rank;
+      if (lane == leader) hit_state[2] = hit_used + n_act;
+    } else {
+      unsigned long long base = 0;
+      if (lane == leader) base = atomicAdd(P.out.hit_count, (unsigned long long)n_act);
+      const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base);
+      const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+      slot = (((uint64_t)bhi << 32) | blo) + rank;
+    }
     if (slot < P.out.hit_capacity) {
       double2* row = reinterpret_cast<double2*>(P.out.hits + slot);
       const uint64_t tag = (ray & 0xFFFFFFFFFFFFull) | ((uint64_t)group << 48) | ((uint64_t)entering << 63);
@@ -930,6 +967,10 @@ __global__ __launch_bounds__(256, ODW_WAVES_PER_SIMD) void odw_trace_kernel(cons
   double power = 0;
   int seq = 0, nint = 0, medium = -1;
   int skip = -1;     // solid the ray has just left, if that solid is convex (it cannot be met again)
+  // per wave: block of hit-list slots (base lo, base hi) and how many are taken (full: none reserved yet)
+  __shared__ uint32_t hit_lds[4 * 4];
+  if (threadIdx.x < 16) hit_lds[threadIdx.x] = (threadIdx.x & 3) == 2 ? P.out.hit_block : 0u;
+  __syncthreads();
   for (;;) {
     const uint64_t idle = __ballot(!alive);
     // refill when the wave is empty or enough lanes are idle to make the
@@ -1012,7 +1053,8 @@ __global__ __launch_bounds__(256, ODW_WAVES_PER_SIMD) void odw_trace_kernel(cons
       const int gtype = group_i32[4 * g];
       if (group_i32[4 * g + 1]) {
         ODW_COUNT(ODW_CNT_RECORDED_HITS);
-        record_hit(P, P.first_ray + i, g, point, dir, power, entering, cnt_lds + threadIdx.x);
+        record_hit(P, P.first_ray + i, g, point, dir, power, entering, cnt_lds + threadIdx.x,
+                   hit_lds + (threadIdx.x >> 6) * 4);
       }
       if (gtype == ODW_OPT_MIRROR) {
         const d3 ideal = mirror(dir, n);
@@ -1067,6 +1109,15 @@ __global__ __launch_bounds__(256, ODW_WAVES_PER_SIMD) void odw_trace_kernel(cons
         ODW_COUNT(ODW_CNT_TRACED_RAYS);
       }
     }
+  }
+  // slots of the last block this wave never filled
+  const uint32_t hit_used = hit_lds[(threadIdx.x >> 6) * 4 + 2];
+  const uint64_t hit_base = ((uint64_t)hit_lds[(threadIdx.x >> 6) * 4 + 1] << 32) | hit_lds[(threadIdx.x >> 6) * 4];
+  if (P.out.hit_block && hit_used < P.out.hit_block) {
+    const uint32_t left = P.out.hit_block - hit_used;
+    for (uint32_t k = __lane_id(); k < left; k += 64)
+      if (hit_base + hit_used + k < P.out.hit_capacity) P.out.hits[hit_base + hit_used + k].tag = ODW_TAG_UNUSED;
+    if (__lane_id() == 0) atomicAdd(P.out.hit_count + 1, (unsigned long long)left);
   }
   // counters: wave reduction, one atomic per wave and counter
 #pragma unroll
