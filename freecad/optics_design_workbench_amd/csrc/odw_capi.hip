@@ -25,6 +25,7 @@ namespace {
 constexpr int kGuide = 1 << 16;
 constexpr uint32_t kHitBlock = 512;            // hit-list slots a wave reserves per atomic (big hit lists only)
 constexpr uint64_t kHitBlockMinRows = 1ull << 22;
+constexpr int kPhiGuide = 1 << 8;        // azimuth table of a source (~1e2 knots)
 constexpr int kSurfaceGuide = 1 << 10;  // per row of a surface sampler (tables of ~1e3 knots)
 constexpr int kBvhThreshold = 16;  // brute force (scalar loads) below this many primitives
 const int kBvhLeaf = [] { const char* e = getenv("ODW_BVH_LEAF"); const int v = e ? atoi(e) : 0; return v > 0 && v < 200 ? v : 8; }();   // largest leaf the SAH may form (measured: 8 >= 4 > 2 > 1 on meshes)
@@ -53,7 +54,7 @@ struct odw_ctx {
 
   DevBuf prim_f64, prim_hdr, prim_i32, cond_i32, group_f64, group_i32, group_gdir, seq_mask;
   DevBuf bvh_nodes, bvh_prims, tri_nrm;
-  DevBuf phi_tab, t_tab, t_guide, d_source, d_det;
+  DevBuf phi_tab, t_tab, t_guide, phi_guide, d_source, d_det;
   DeviceSource h_source;
   DeviceDetector h_det;
   DevBuf hits, hit_count, hist, counters, chunk_counter;
@@ -588,7 +589,7 @@ void odw_destroy(odw_ctx* ctx) {
                    &ctx->sort_tmp, &ctx->sorted_rows};
   for (DevBuf* b : all) release(*b);
   for (DevBuf* b : {&ctx->em_prim_f64, &ctx->em_prim_i32, &ctx->em_cond, &ctx->em_face_i32, &ctx->em_face_cdf,
-                    &ctx->em_t_tab, &ctx->em_t_guide, &ctx->em_o, &ctx->em_d, &ctx->tri_nrm})
+                    &ctx->em_t_tab, &ctx->em_t_guide, &ctx->em_o, &ctx->em_d, &ctx->tri_nrm, &ctx->phi_guide})
     release(*b);
   for (auto& sb : ctx->surf_bufs) { release(sb.phi_tab); release(sb.t_tab); release(sb.t_guide); }
   release(ctx->d_samplers);
@@ -840,6 +841,13 @@ int odw_upload_source(odw_ctx* ctx, const odw_source_desc* s) {
   if ((rc = upload(ctx, ctx->phi_tab, ptab.data(), ptab.size() * sizeof(double)))) return rc;
   if ((rc = upload(ctx, ctx->t_tab, ttab.data(), ttab.size() * sizeof(double)))) return rc;
   if ((rc = upload(ctx, ctx->t_guide, guide.data(), guide.size() * sizeof(int32_t)))) return rc;
+  std::vector<int32_t> pguide(kPhiGuide + 1);
+  for (int k = 0, j = 0; k <= kPhiGuide; ++k) {
+    const double x = (double)k / (double)kPhiGuide;
+    while (j + 1 < np && s->phi_cdf[j + 1] <= x) ++j;
+    pguide[k] = j;
+  }
+  if ((rc = upload(ctx, ctx->phi_guide, pguide.data(), pguide.size() * sizeof(int32_t)))) return rc;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   DeviceSource& d = ctx->h_source;
   std::memcpy(d.m, s->xform, sizeof d.m);
@@ -850,6 +858,8 @@ int odw_upload_source(odw_ctx* ctx, const odw_source_desc* s) {
   d.phi_tab = (const double*)ctx->phi_tab.p;
   d.t_tab = (const double*)ctx->t_tab.p;
   d.t_guide = (const int32_t*)ctx->t_guide.p;
+  d.phi_guide = (const int32_t*)ctx->phi_guide.p;
+  d.n_phi_guide = kPhiGuide;
   d.n_phi_knots = np;
   d.n_t_knots = nt;
   d.n_t_rows = rows;

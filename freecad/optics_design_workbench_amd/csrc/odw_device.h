@@ -63,7 +63,8 @@ struct DeviceSource {
   const double* phi_tab;        // [n_phi_knots*2] (cdf, edge)
   const double* t_tab;          // [rows*n_t_knots*2]
   const int32_t* t_guide;       // [rows*(GUIDE+1)] bracket guide for the inverse CDF
-  int32_t n_phi_knots, n_t_knots, n_t_rows, n_guide;
+  const int32_t* phi_guide;     // [n_phi_guide+1] the same for the azimuth table
+  int32_t n_phi_knots, n_t_knots, n_t_rows, n_guide, n_phi_guide;
   int32_t finite_focal;
 };
 

@@ -117,11 +117,18 @@ __device__ __forceinline__ double inv_cdf(const double* __restrict__ tab, int lo
 struct TableView {
   const double* phi_tab; const double* t_tab; const int32_t* t_guide;
   int n_phi_knots, n_t_knots, n_t_rows, n_guide;
+  const int32_t* phi_guide; int n_phi_guide;      // optional (null: plain binary search)
 };
 __device__ __forceinline__ void sample_tables(const TableView& s, double u_phi, double u_t,
                                               double& t_out, double& phi_out) {
 #pragma clang fp contract(off)
-  const double phi = inv_cdf(s.phi_tab, 0, s.n_phi_knots - 1, u_phi);
+  int plo = 0, phi_hi = s.n_phi_knots - 1;
+  if (s.phi_guide) {                     // bracket from the guide: two independent loads instead of a chain of ~7
+    const int k = (int)(u_phi * (double)s.n_phi_guide);
+    plo = s.phi_guide[k];
+    phi_hi = min(s.phi_guide[k + 1] + 1, s.n_phi_knots - 1);
+  }
+  const double phi = inv_cdf(s.phi_tab, plo, phi_hi, u_phi);
   int row = 0;
   if (s.n_t_rows > 1) {
     // argmin_i |mid_i - phi| (first minimum): the candidate is the cell that
@@ -150,6 +157,7 @@ __device__ __forceinline__ void sample_source(csource sp_, double u_phi, double 
   TableView s;
   s.phi_tab = sp_->phi_tab; s.t_tab = sp_->t_tab; s.t_guide = sp_->t_guide;
   s.n_phi_knots = sp_->n_phi_knots; s.n_t_knots = sp_->n_t_knots; s.n_t_rows = sp_->n_t_rows; s.n_guide = sp_->n_guide;
+  s.phi_guide = sp_->phi_guide; s.n_phi_guide = sp_->n_phi_guide;
   sample_tables(s, u_phi, u_t, t_out, phi_out);
 }
 
@@ -800,6 +808,7 @@ __device__ __forceinline__ void surface_draw(const DeviceSurfaceSampler* sp, dou
   tv.t_tab = S.t_tab + (size_t)k * (size_t)S.n_t_rows * (size_t)S.n_t_knots * 2;
   tv.t_guide = S.t_guide + (size_t)k * (size_t)S.n_t_rows * (size_t)(S.n_guide + 1);
   tv.n_phi_knots = S.n_phi_knots; tv.n_t_knots = S.n_t_knots; tv.n_t_rows = S.n_t_rows; tv.n_guide = S.n_guide;
+  tv.phi_guide = nullptr; tv.n_phi_guide = 0;
   uint32_t c0 = (uint32_t)ray, c1 = (uint32_t)(ray >> 32), c2 = ordinal, c3 = stream;
   philox4x32_10(c0, c1, c2, c3, (uint32_t)seed, (uint32_t)(seed >> 32));
   sample_tables(tv, u53(c0, c1), u53(c2, c3), theta, phi);
