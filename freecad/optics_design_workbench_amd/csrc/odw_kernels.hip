@@ -10,8 +10,11 @@
 //   K3 interact   normal, entering test, mirror / Snell / absorb / vacuum /
 //                 grating, medium + sequence state (ray.py:91-281, 455-539)
 //   K5 record     wave-aggregated append of 64-B hit rows (ballot + popcount
-//                 prefix, one atomic per wave) and u64 histogram scatter
+//                 prefix; slots reserved per wave, 512 at a time for big
+//                 lists) and u64 histogram scatter
 //                 (optical_group.py:206-209 -> results_store.py:641-648)
+// plus, in the kernel variants that need them: stochastic surfaces (scatter),
+// triangle primitives (BVH kernels), and the surface-source emission kernel.
 // Ray state lives in registers for the whole life of the ray; the scene is
 // read through wave-uniform (scalar) loads.  float64 throughout, like the
 // reference (FreeCAD Vector/Matrix are double).
@@ -835,8 +838,9 @@ __device__ __noinline__ d3 scatter(const DeviceSurfaceSampler* samplers, int s_p
 }
 
 // ------------------------------------------------------- recording (K5)
-// Active lanes append one 64-B row each: one atomic per wave reserves the
-// block, lanes take consecutive slots by popcount prefix of the ballot.
+// Active lanes append one 64-B row each: lanes take consecutive slots by
+// popcount prefix of the ballot, the slots come from the wave's reserved block
+// (big lists) or from one atomic per append (small lists, exact fill).
 // block change of a wave's hit-list reservation (rare: out of line): the slots the old block has
 // left (< number of recording lanes) are marked unused, a new block is taken
 __device__ __noinline__ void next_hit_block(odw_hit* hits, uint64_t capacity, unsigned long long* hit_count,
