@@ -487,8 +487,9 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
   const uint64_t n_chunks = (n + ODW_CHUNK - 1) / ODW_CHUNK;
   const uint64_t cap = (uint64_t)ctx->n_cu * grid_mult;
   const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_chunks + 3) / 4, cap));
-  if (ctx->hit_slots >= ctx->hit_capacity + ctx->hit_capacity / 8 + 64 + (uint64_t)grid * 4 * kHitBlock)
-    P.out.hit_block = kHitBlock;
+  if (!P.scene.n_nodes &&
+      ctx->hit_slots >= ctx->hit_capacity + ctx->hit_capacity / 8 + 64 + (uint64_t)grid * 4 * kHitBlock)
+    P.out.hit_block = kHitBlock;     // flat kernels only (see record_hit)
   HIPCHK(ctx, hipMemsetAsync(ctx->chunk_counter.p, 0, sizeof(uint64_t), ctx->stream));
   const size_t lds = P.scene.n_nodes ? (size_t)ODW_BVH_STACK * 256 * sizeof(int) : 0;
 

@@ -857,6 +857,7 @@ __device__ __noinline__ void next_hit_block(odw_hit* hits, uint64_t capacity, un
   }
 }
 
+template <bool BLOCKS>
 __device__ __forceinline__ void record_hit(const TraceParams& P, uint64_t ray, int group, d3 p, d3 d,
                                            double power, bool entering, uint32_t* cnt,
                                            volatile uint32_t* hit_state) {
@@ -867,7 +868,7 @@ __device__ __forceinline__ void record_hit(const TraceParams& P, uint64_t ray, i
     const uint32_t n_act = __popcll(active);
     const uint32_t rank = __popcll(active & ((1ull << lane) - 1ull));
     uint64_t slot;
-    if (P.out.hit_block) {
+    if (BLOCKS && P.out.hit_block) {
       // One atomic per wave and append serialises 1.5e6 appends of a launch on a single counter at
       // the memory side (1.2 - 3 ms of a 20 ms launch, measured).  A wave therefore takes hit_block
       // slots at a time and hands them out itself; slots it cannot use (< 64 at a block change, the
@@ -935,6 +936,17 @@ __device__ __noinline__ RayInit generate_ray(const DeviceSource* sp, uint64_t ra
   return r;
 }
 
+// LDS of the hit-list block reservations: exists only where it is used
+template <bool ON> struct HitBlockState {
+  __device__ static __forceinline__ uint32_t* lds() {
+    __shared__ uint32_t state[4 * 4];
+    return state;
+  }
+};
+template <> struct HitBlockState<false> {
+  __device__ static __forceinline__ uint32_t* lds() { return nullptr; }
+};
+
 // ------------------------------------------------------------ the kernel
 #ifndef ODW_CHUNK
 #define ODW_CHUNK 2048ull      // rays per hand-out unit (32 per lane)
@@ -981,9 +993,13 @@ __global__ __launch_bounds__(256, ODW_WAVES_PER_SIMD) void odw_trace_kernel(cons
   int seq = 0, nint = 0, medium = -1;
   int skip = -1;     // solid the ray has just left, if that solid is convex (it cannot be met again)
   // per wave: block of hit-list slots (base lo, base hi) and how many are taken (full: none reserved yet)
-  __shared__ uint32_t hit_lds[4 * 4];
-  if (threadIdx.x < 16) hit_lds[threadIdx.x] = (threadIdx.x & 3) == 2 ? P.out.hit_block : 0u;
-  __syncthreads();
+  // (flat kernels only: the BVH kernels' node stacks + counters fill the 160 KB of a CU exactly at
+  //  4 blocks -- 64 more bytes would cost a quarter of the occupancy)
+  uint32_t* hit_lds = HitBlockState<!BVH>::lds();
+  if (!BVH) {
+    if (threadIdx.x < 16) hit_lds[threadIdx.x] = (threadIdx.x & 3) == 2 ? P.out.hit_block : 0u;
+    __syncthreads();
+  }
   for (;;) {
     const uint64_t idle = __ballot(!alive);
     // refill when the wave is empty or enough lanes are idle to make the
@@ -1066,8 +1082,10 @@ __global__ __launch_bounds__(256, ODW_WAVES_PER_SIMD) void odw_trace_kernel(cons
       const int gtype = group_i32[4 * g];
       if (group_i32[4 * g + 1]) {
         ODW_COUNT(ODW_CNT_RECORDED_HITS);
-        record_hit(P, P.first_ray + i, g, point, dir, power, entering, cnt_lds + threadIdx.x,
-                   hit_lds + (threadIdx.x >> 6) * 4);
+        // (block reservations only in the flat kernels: in the BVH kernels their state costs more
+        // registers than the atomics cost time)
+        record_hit<!BVH>(P, P.first_ray + i, g, point, dir, power, entering, cnt_lds + threadIdx.x,
+                         hit_lds + (threadIdx.x >> 6) * 4);
       }
       if (gtype == ODW_OPT_MIRROR) {
         const d3 ideal = mirror(dir, n);
@@ -1124,9 +1142,9 @@ __global__ __launch_bounds__(256, ODW_WAVES_PER_SIMD) void odw_trace_kernel(cons
     }
   }
   // slots of the last block this wave never filled
-  const uint32_t hit_used = hit_lds[(threadIdx.x >> 6) * 4 + 2];
-  const uint64_t hit_base = ((uint64_t)hit_lds[(threadIdx.x >> 6) * 4 + 1] << 32) | hit_lds[(threadIdx.x >> 6) * 4];
-  if (P.out.hit_block && hit_used < P.out.hit_block) {
+  const uint32_t hit_used = BVH ? 0u : hit_lds[(threadIdx.x >> 6) * 4 + 2];
+  const uint64_t hit_base = BVH ? 0ull : ((uint64_t)hit_lds[(threadIdx.x >> 6) * 4 + 1] << 32) | hit_lds[(threadIdx.x >> 6) * 4];
+  if (!BVH && P.out.hit_block && hit_used < P.out.hit_block) {
     const uint32_t left = P.out.hit_block - hit_used;
     for (uint32_t k = __lane_id(); k < left; k += 64)
       if (hit_base + hit_used + k < P.out.hit_capacity) P.out.hits[hit_base + hit_used + k].tag = ODW_TAG_UNUSED;
