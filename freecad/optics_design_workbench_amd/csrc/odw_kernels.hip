@@ -851,7 +851,10 @@ __device__ __noinline__ void next_hit_block(odw_hit* hits, uint64_t capacity, un
   if (rank < left && old_base + hit_used + rank < capacity) hits[old_base + hit_used + rank].tag = ODW_TAG_UNUSED;
   if (leader) {
     const unsigned long long base = atomicAdd(hit_count, (unsigned long long)block);
-    if (left) atomicAdd(hit_count + 1, (unsigned long long)left);
+    // unused slots are counted where they exist (beyond the buffer nothing is stored or counted)
+    const uint64_t at = old_base + hit_used;
+    const uint64_t in_buf = at < capacity ? (capacity - at < left ? capacity - at : left) : 0;
+    if (in_buf) atomicAdd(hit_count + 1, (unsigned long long)in_buf);
     hit_state[0] = (uint32_t)base;
     hit_state[1] = (uint32_t)(base >> 32);
   }
@@ -1148,7 +1151,9 @@ __global__ __launch_bounds__(256, ODW_WAVES_PER_SIMD) void odw_trace_kernel(cons
     const uint32_t left = P.out.hit_block - hit_used;
     for (uint32_t k = __lane_id(); k < left; k += 64)
       if (hit_base + hit_used + k < P.out.hit_capacity) P.out.hits[hit_base + hit_used + k].tag = ODW_TAG_UNUSED;
-    if (__lane_id() == 0) atomicAdd(P.out.hit_count + 1, (unsigned long long)left);
+    const uint64_t at = hit_base + hit_used;
+    const uint64_t in_buf = at < P.out.hit_capacity ? (P.out.hit_capacity - at < left ? P.out.hit_capacity - at : left) : 0;
+    if (__lane_id() == 0 && in_buf) atomicAdd(P.out.hit_count + 1, (unsigned long long)in_buf);
   }
   // counters: wave reduction, one atomic per wave and counter
 #pragma unroll

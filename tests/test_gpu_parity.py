@@ -189,3 +189,26 @@ def test_block_reserved_hit_list_equals_exact_list(tracer, oracle):
   assert len(rows['blocks']) == len(rows['exact']) == len(ref) > 3 * n
   assert rows['blocks'].tobytes() == rows['exact'].tobytes()
   assert np.array_equal(rows['blocks']['tag'], ref['tag'])
+
+
+def test_block_reserved_hit_list_overflow(tracer):
+  """more hits than the (block-reserved) list holds: every stored row is a real
+  hit, stored + dropped = recorded, at least the requested capacity is stored"""
+  pr = project('minimal')                          # one hit per ray
+  cap, n = 1 << 22, 12_000_000
+  tracer.setScene(pr.scene); tracer.setSource(pr.source); tracer.setLimits(pr.limits); tracer.setDetector(None)
+  tracer.reserveHits(cap)
+  tracer.reset()
+  tracer.trace(0, n, 4)
+  tracer.sync()
+  c = tracer.counters()
+  assert c['recorded_hits'] == n and c['hits_dropped'] > 0
+  stored = tracer.hitCount()
+  assert stored + c['hits_dropped'] == n and stored >= cap
+  h = tracer.hits()
+  assert len(h) == stored
+  ray = (h['tag'] & np.uint64(0xFFFFFFFFFFFF)).astype(np.int64)
+  assert np.all(np.diff(ray) > 0) and ray[0] >= 0 and ray[-1] < n        # sorted, unique, real rays
+  assert np.abs(h['point'][:, 2] - 15.0).max() < 1e-9                     # every row is a hit on the detector face
+  tracer.reset()
+  assert tracer.hitCount() == 0
