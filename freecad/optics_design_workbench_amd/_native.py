@@ -17,19 +17,20 @@ LIB_PATH = os.path.join(CSRC, 'libodw_trace.so')
 _SOURCES = ['odw_capi.hip', 'odw_kernels.hip', 'odw_device.h']
 _HEADER = os.path.normpath(os.path.join(_HERE, '..', '..', 'include', 'odw_trace.h'))
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 CNT_NAMES = ['traced_rays', 'recorded_hits', 'segments', 'escaped', 'died', 'capped',
              'hist_overflow', 'hits_dropped']
-TRACE_RECORD_HITS, TRACE_HISTOGRAM = 1, 2
+TRACE_RECORD_HITS, TRACE_HISTOGRAM, TRACE_RECORD_SEGMENTS = 1, 2, 4
 ERRORS = {1: 'invalid argument', 2: 'device error', 3: 'no scene', 4: 'capacity', 5: 'unsupported'}
 
 HIT_DTYPE = np.dtype([('point', '<f8', 3), ('direction', '<f8', 3), ('power', '<f8'), ('tag', '<u8')])
+SEGMENT_DTYPE = np.dtype([('p1', '<f8', 3), ('p2', '<f8', 3), ('power', '<f8'), ('tag', '<u8')])
 
 # every symbol include/odw_trace.h declares
 SYMBOLS = ['odw_abi_version', 'odw_create', 'odw_destroy', 'odw_last_error', 'odw_upload_scene',
-           'odw_upload_source', 'odw_upload_surface_source', 'odw_generate_rays', 'odw_upload_surface_samplers', 'odw_set_surface_seed', 'odw_set_wavelength', 'odw_set_limits', 'odw_set_detector', 'odw_reserve_hits', 'odw_trace',
+           'odw_upload_source', 'odw_upload_surface_source', 'odw_generate_rays', 'odw_upload_surface_samplers', 'odw_set_surface_seed', 'odw_set_wavelength', 'odw_set_limits', 'odw_set_detector', 'odw_reserve_hits', 'odw_reserve_segments', 'odw_trace',
            'odw_trace_rays', 'odw_sync', 'odw_reset_results', 'odw_reset_hits', 'odw_fetch_counters', 'odw_hit_count',
-           'odw_fetch_hits', 'odw_fetch_histogram', 'odw_sample', 'odw_device_histogram',
+           'odw_fetch_hits', 'odw_fetch_histogram', 'odw_segment_count', 'odw_fetch_segments', 'odw_reset_segments', 'odw_sample', 'odw_device_histogram',
            'odw_device_counters', 'odw_stream', 'odw_timing_enable', 'odw_timing_read']
 
 _pd = C.POINTER(C.c_double)

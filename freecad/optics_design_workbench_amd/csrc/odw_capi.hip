@@ -58,6 +58,8 @@ struct odw_ctx {
   DeviceSource h_source;
   DeviceDetector h_det;
   DevBuf hits, hit_count, hist, counters, chunk_counter;
+  DevBuf segs, seg_count;                  // RecordRays segment list
+  uint64_t seg_capacity = 0;
   DevBuf ray_o, ray_d, ray_p, samp_t, samp_phi;
   DevBuf sort_keys[2], sort_vals[2], sort_tmp, sorted_rows;
   // stochastic surfaces: one table set per sampler, descriptor block, (group, kind) -> index
@@ -435,6 +437,16 @@ __global__ void hit_keys_kernel(const odw_hit* __restrict__ hits, uint64_t n, ui
   }
 }
 
+__global__ void seg_keys_kernel(const odw_segment* __restrict__ segs, uint64_t n, uint64_t* __restrict__ keys,
+                                uint32_t* __restrict__ vals) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const uint64_t tag = segs[i].tag;
+    keys[i] = (ODW_SEG_RAY(tag) << 12) | ODW_SEG_ORDINAL(tag);    // 52 bits
+    vals[i] = (uint32_t)i;
+  }
+}
+
 // four lanes move one 64-byte row (16 B each): coalesced reads of the index
 // list, 64-B gathers, fully coalesced writes
 __global__ void hit_gather_kernel(const odw_hit* __restrict__ hits, const uint32_t* __restrict__ order,
@@ -459,6 +471,12 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
   }
   if ((flags & ODW_TRACE_RECORD_HITS) && ctx->hit_capacity == 0)
     return fail(ctx, ODW_ERR_CAPACITY, "ODW_TRACE_RECORD_HITS without odw_reserve_hits");
+  if (flags & ODW_TRACE_RECORD_SEGMENTS) {
+    if (ctx->seg_capacity == 0)
+      return fail(ctx, ODW_ERR_CAPACITY, "ODW_TRACE_RECORD_SEGMENTS without odw_reserve_segments");
+    if (first + n > ODW_SEG_MAX_RAY || ctx->P.lim.max_intersections > ODW_SEG_MAX_ORDINAL)
+      return fail(ctx, ODW_ERR_INVALID, "ODW_TRACE_RECORD_SEGMENTS: ray index or max_intersections beyond the row tag");
+  }
   if ((flags & ODW_TRACE_HISTOGRAM) && !ctx->P.det_enabled) flags &= ~ODW_TRACE_HISTOGRAM;
   TraceParams& P = ctx->P;
   P.first_ray = first;
@@ -479,6 +497,9 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
   P.out.hist = (unsigned long long*)ctx->hist.p;
   P.out.counters = (unsigned long long*)ctx->counters.p;
   P.out.chunk_counter = (unsigned long long*)ctx->chunk_counter.p;
+  P.out.segs = (odw_segment*)ctx->segs.p;
+  P.out.seg_capacity = ctx->seg_capacity;
+  P.out.seg_count = (unsigned long long*)ctx->seg_count.p;
 
   // persistent waves: one grid that fills the chip (4 blocks of 256 threads
   // per CU at 4 waves/SIMD, x2 so that a CU never waits for a block launch);
@@ -505,12 +526,20 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
     HIPCHK(ctx, hipEventRecord(ev.first, ctx->stream));
   }
   const bool stoch = ctx->n_samplers > 0;
-  if (P.scene.n_nodes) {
-    if (stoch) hipLaunchKernelGGL((odw_trace_kernel<true, true>), dim3(grid), dim3(256), lds, ctx->stream, P);
-    else hipLaunchKernelGGL((odw_trace_kernel<true, false>), dim3(grid), dim3(256), lds, ctx->stream, P);
+  if (flags & ODW_TRACE_RECORD_SEGMENTS) {
+    if (P.scene.n_nodes) {
+      if (stoch) hipLaunchKernelGGL((odw_trace_kernel<true, true, true>), dim3(grid), dim3(256), lds, ctx->stream, P);
+      else hipLaunchKernelGGL((odw_trace_kernel<true, false, true>), dim3(grid), dim3(256), lds, ctx->stream, P);
+    } else {
+      if (stoch) hipLaunchKernelGGL((odw_trace_kernel<false, true, true>), dim3(grid), dim3(256), 0, ctx->stream, P);
+      else hipLaunchKernelGGL((odw_trace_kernel<false, false, true>), dim3(grid), dim3(256), 0, ctx->stream, P);
+    }
+  } else if (P.scene.n_nodes) {
+    if (stoch) hipLaunchKernelGGL((odw_trace_kernel<true, true, false>), dim3(grid), dim3(256), lds, ctx->stream, P);
+    else hipLaunchKernelGGL((odw_trace_kernel<true, false, false>), dim3(grid), dim3(256), lds, ctx->stream, P);
   } else {
-    if (stoch) hipLaunchKernelGGL((odw_trace_kernel<false, true>), dim3(grid), dim3(256), 0, ctx->stream, P);
-    else hipLaunchKernelGGL((odw_trace_kernel<false, false>), dim3(grid), dim3(256), 0, ctx->stream, P);
+    if (stoch) hipLaunchKernelGGL((odw_trace_kernel<false, true, false>), dim3(grid), dim3(256), 0, ctx->stream, P);
+    else hipLaunchKernelGGL((odw_trace_kernel<false, false, false>), dim3(grid), dim3(256), 0, ctx->stream, P);
   }
   HIPCHK(ctx, hipGetLastError());
   if (ctx->timing) {
@@ -568,10 +597,12 @@ int odw_create(int device, odw_ctx** out) {
   int rc = ensure(ctx, ctx->counters, ODW_CNT_COUNT * sizeof(uint64_t));
   if (!rc) rc = ensure(ctx, ctx->hit_count, 2 * sizeof(uint64_t));
   if (!rc) rc = ensure(ctx, ctx->chunk_counter, sizeof(uint64_t));
+  if (!rc) rc = ensure(ctx, ctx->seg_count, sizeof(uint64_t));
   if (!rc) rc = ensure(ctx, ctx->hist, 16);
   if (rc) { g_error = ctx->err; odw_destroy(ctx); return rc; }
   (void)hipMemsetAsync(ctx->counters.p, 0, ctx->counters.bytes, ctx->stream);
   (void)hipMemsetAsync(ctx->hit_count.p, 0, ctx->hit_count.bytes, ctx->stream);
+  (void)hipMemsetAsync(ctx->seg_count.p, 0, ctx->seg_count.bytes, ctx->stream);
   *out = ctx;
   return ODW_OK;
 }
@@ -587,7 +618,7 @@ void odw_destroy(odw_ctx* ctx) {
                    &ctx->phi_tab, &ctx->t_tab, &ctx->t_guide, &ctx->d_source, &ctx->d_det, &ctx->hits, &ctx->hit_count, &ctx->chunk_counter, &ctx->hist,
                    &ctx->counters, &ctx->ray_o, &ctx->ray_d, &ctx->ray_p, &ctx->samp_t, &ctx->samp_phi,
                    &ctx->sort_keys[0], &ctx->sort_keys[1], &ctx->sort_vals[0], &ctx->sort_vals[1],
-                   &ctx->sort_tmp, &ctx->sorted_rows};
+                   &ctx->sort_tmp, &ctx->sorted_rows, &ctx->segs, &ctx->seg_count};
   for (DevBuf* b : all) release(*b);
   for (DevBuf* b : {&ctx->em_prim_f64, &ctx->em_prim_i32, &ctx->em_cond, &ctx->em_face_i32, &ctx->em_face_cdf,
                     &ctx->em_t_tab, &ctx->em_t_guide, &ctx->em_o, &ctx->em_d, &ctx->tri_nrm, &ctx->phi_guide})
@@ -1052,6 +1083,23 @@ int odw_reserve_hits(odw_ctx* ctx, uint64_t capacity) {
   return ODW_OK;
 }
 
+int odw_reserve_segments(odw_ctx* ctx, uint64_t capacity) {
+  if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_reserve_segments: null ctx");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (capacity == 0) { release(ctx->segs); ctx->seg_capacity = 0; return ODW_OK; }
+  if (capacity > 0x7FFFFFFFull) return fail(ctx, ODW_ERR_CAPACITY, "odw_reserve_segments: more than 2^31 rows");
+  if (capacity > ctx->seg_capacity) {
+    release(ctx->segs);
+    ctx->seg_capacity = 0;
+    int rc = ensure(ctx, ctx->segs, capacity * sizeof(odw_segment));
+    if (rc) return rc;
+    ctx->seg_capacity = capacity;
+    HIPCHK(ctx, hipMemsetAsync(ctx->seg_count.p, 0, sizeof(uint64_t), ctx->stream));
+  }
+  return ODW_OK;
+}
+
 int odw_trace(odw_ctx* ctx, uint64_t first_ray, uint64_t n_rays, uint64_t seed, uint32_t flags) {
   if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_trace: null ctx");
   HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1102,7 +1150,15 @@ int odw_reset_results(odw_ctx* ctx) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, ODW_CNT_COUNT * sizeof(uint64_t), ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(ctx->hit_count.p, 0, 2 * sizeof(uint64_t), ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(ctx->seg_count.p, 0, sizeof(uint64_t), ctx->stream));
   if (ctx->n_bins) HIPCHK(ctx, hipMemsetAsync(ctx->hist.p, 0, ctx->n_bins * sizeof(uint64_t), ctx->stream));
+  return ODW_OK;
+}
+
+int odw_reset_segments(odw_ctx* ctx) {
+  if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_reset_segments: null ctx");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipMemsetAsync(ctx->seg_count.p, 0, sizeof(uint64_t), ctx->stream));
   return ODW_OK;
 }
 
@@ -1181,6 +1237,53 @@ int odw_fetch_hits(odw_ctx* ctx, odw_hit* out, uint64_t capacity, uint64_t* n) {
     HIPCHK(ctx, hipMemcpyAsync(out, ctx->sorted_rows.p, have * sizeof(odw_hit), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   }
+  return ODW_OK;
+}
+
+int odw_segment_count(odw_ctx* ctx, uint64_t* n, uint64_t* dropped) {
+  if (!ctx || !n) return fail(ctx, ODW_ERR_INVALID, "odw_segment_count: bad argument");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  uint64_t wanted = 0;
+  HIPCHK(ctx, hipMemcpyAsync(&wanted, ctx->seg_count.p, sizeof wanted, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  *n = std::min<uint64_t>(wanted, ctx->seg_capacity);
+  if (dropped) *dropped = wanted - *n;
+  return ODW_OK;
+}
+
+int odw_fetch_segments(odw_ctx* ctx, odw_segment* out, uint64_t capacity, uint64_t* n) {
+  if (!ctx || !n) return fail(ctx, ODW_ERR_INVALID, "odw_fetch_segments: bad argument");
+  uint64_t have = 0;
+  int rc = odw_segment_count(ctx, &have, nullptr);
+  if (rc) return rc;
+  *n = have;
+  if (!out || capacity == 0 || have == 0) return ODW_OK;
+  if (have > capacity) return fail(ctx, ODW_ERR_CAPACITY, "odw_fetch_segments: output buffer too small");
+  // same device-side ordering as the hit list, with the explicit key (ray, ordinal)
+  static_assert(sizeof(odw_segment) == sizeof(odw_hit), "rows share the gather kernel");
+  for (int k = 0; k < 2; ++k) {
+    if ((rc = ensure(ctx, ctx->sort_keys[k], have * sizeof(uint64_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->sort_vals[k], have * sizeof(uint32_t)))) return rc;
+  }
+  if ((rc = ensure(ctx, ctx->sorted_rows, have * sizeof(odw_segment)))) return rc;
+  uint64_t* k_in = (uint64_t*)ctx->sort_keys[0].p;
+  uint64_t* k_out = (uint64_t*)ctx->sort_keys[1].p;
+  uint32_t* v_in = (uint32_t*)ctx->sort_vals[0].p;
+  uint32_t* v_out = (uint32_t*)ctx->sort_vals[1].p;
+  hipLaunchKernelGGL(seg_keys_kernel, dim3((unsigned)((have + 255) / 256)), dim3(256), 0, ctx->stream,
+                     (const odw_segment*)ctx->segs.p, have, k_in, v_in);
+  HIPCHK(ctx, hipGetLastError());
+  size_t tmp_bytes = 0;
+  HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k_in, k_out, v_in, v_out, (int)have, 0, 52,
+                                                 ctx->stream));
+  if ((rc = ensure(ctx, ctx->sort_tmp, tmp_bytes))) return rc;
+  HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(ctx->sort_tmp.p, tmp_bytes, k_in, k_out, v_in, v_out, (int)have, 0,
+                                                 52, ctx->stream));
+  hipLaunchKernelGGL(hit_gather_kernel, dim3((unsigned)((have * 4 + 255) / 256)), dim3(256), 0, ctx->stream,
+                     (const odw_hit*)ctx->segs.p, v_out, have, (odw_hit*)ctx->sorted_rows.p);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpyAsync(out, ctx->sorted_rows.p, have * sizeof(odw_segment), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return ODW_OK;
 }
 

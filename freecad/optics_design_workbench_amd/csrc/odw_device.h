@@ -112,6 +112,9 @@ struct DeviceOutputs {
   unsigned long long* hist;            // nx*ny
   unsigned long long* counters;        // ODW_CNT_COUNT
   unsigned long long* chunk_counter;   // next unassigned chunk of this launch (zeroed per launch)
+  odw_segment* segs;                   // ODW_TRACE_RECORD_SEGMENTS (RecordRays sources)
+  uint64_t seg_capacity;
+  unsigned long long* seg_count;       // rows wanted so far (may exceed the capacity)
 };
 
 // Kernel argument.  The source and detector blocks live in device memory and

@@ -921,6 +921,23 @@ __device__ __forceinline__ void record_hit(const TraceParams& P, uint64_t ray, i
   }
 }
 
+// RecordRays (generic_source.py:78-118): one row per segment Ray.traceRay yields.  Only a
+// handful of rays are recorded this way (the reference draws and pickles them one by one),
+// so: one atomic per append, and kernels of their own (SEG) that the bulk launches never run.
+__device__ __noinline__ void record_segment(odw_segment* segs, uint64_t capacity, unsigned long long* seg_count,
+                                            uint64_t ray, int ordinal, int medium, d3 p1, d3 p2, double power) {
+  const uint64_t slot = atomicAdd(seg_count, 1ull);
+  if (slot < capacity) {
+    double2* row = reinterpret_cast<double2*>(segs + slot);
+    const uint64_t tag = (ray & 0xFFFFFFFFFFull) | ((uint64_t)(ordinal & 0xFFF) << 40) |
+                         ((uint64_t)((medium + 1) & 0xFFF) << 52);
+    row[0] = make_double2(p1.x, p1.y);
+    row[1] = make_double2(p1.z, p2.x);
+    row[2] = make_double2(p2.y, p2.z);
+    row[3] = make_double2(power, __longlong_as_double((long long)tag));
+  }
+}
+
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
@@ -960,7 +977,7 @@ template <> struct HitBlockState<false> {
 #ifndef ODW_WAVES_PER_SIMD
 #define ODW_WAVES_PER_SIMD 4
 #endif
-template <bool BVH, bool STOCH>
+template <bool BVH, bool STOCH, bool SEG>
 __global__ __launch_bounds__(256, ODW_WAVES_PER_SIMD) void odw_trace_kernel(const TraceParams P) {
   extern __shared__ int bvh_stack[];  // ODW_BVH_STACK x 256 ints (BVH variant only)
   // per-thread event counters live in LDS (one column per thread, ds_add_u32
@@ -1056,6 +1073,9 @@ __global__ __launch_bounds__(256, ODW_WAVES_PER_SIMD) void odw_trace_kernel(cons
       int face;
       const int prim = nearest<BVH>(sc, sv, lim, point, dir, medium, mask, t_hit, face,
                                     bvh_stack + threadIdx.x, skip);
+      if (SEG)   // (p1, p2), power at p1, medium of the segment (ray.py:104-117)
+        record_segment(P.out.segs, P.out.seg_capacity, P.out.seg_count, P.first_ray + i, nint - 1, medium, point,
+                       point + dir * (prim < 0 ? lim.max_ray_length : t_hit), power);
       if (prim < 0) {
         ODW_COUNT(ODW_CNT_ESCAPED);
         alive = false;

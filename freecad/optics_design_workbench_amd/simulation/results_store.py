@@ -87,9 +87,12 @@ class SimulationResults:
     self.totalIterations = 0
     self.totalTracedRays = 0
     self.totalRecordedHits = 0
+    self.totalRecordedRays = 0
     self.t0 = time.time()
     self._hits = {}          # (sourceName, sourceLabel, objName, objLabel) -> list of dicts
     self._flushed = {}       # same key -> merged dict kept for in-memory access
+    self._rays = {}          # (sourceName, sourceLabel) -> list of ray dicts (RecordRays)
+    self._flushedRays = {}
 
   # -- global info, progress, status flags --------------------------------------
   def dumpGlobalInfo(self, info):
@@ -111,7 +114,7 @@ class SimulationResults:
     _atomic_pickle(os.path.join(folder, f'master-{idx:09d}'),
                    dict(simulationType=self.simulationType, totalIterations=self.totalIterations,
                         totalTracedRays=self.totalTracedRays, totalRecordedHits=self.totalRecordedHits,
-                        totalRecordedRays=0, endAfterIterations=self.endAfterIterations,
+                        totalRecordedRays=self.totalRecordedRays, endAfterIterations=self.endAfterIterations,
                         endAfterRays=self.endAfterRays, endAfterHits=self.endAfterHits))
     old = os.path.join(folder, f'master-{idx - 10:09d}')
     if os.path.exists(old):
@@ -143,6 +146,13 @@ class SimulationResults:
       d[k] = np.asarray(v)
     self._hits.setdefault((source, sourceLabel, obj, objLabel), []).append(d)
     self.totalRecordedHits += len(d['points'])
+
+  def addRays(self, source, sourceLabel, rays):
+    """bulk form of addRay + addSegment + rayComplete (results_store.py:628-639,
+    232-260): `rays` = one dict(points, powers, media) per completed ray"""
+    rays = list(rays)
+    self._rays.setdefault((source, sourceLabel), []).extend(rays)
+    self.totalRecordedRays += len(rays)
 
   def incrementRayCount(self, n=1):
     self.totalTracedRays += int(n)
@@ -180,6 +190,25 @@ class SimulationResults:
         with open(os.path.join(folder, f'{stamp}-hits.pkl'), 'wb') as f:
           pickle.dump(merged, f)
     self._hits = {}
+    # recorded rays: one pickled list of ray dictionaries per source (results_store.py:380-403)
+    for key, rays in self._rays.items():
+      self._flushedRays.setdefault(key, []).extend(rays)
+      if self.basePath is not None and rays:
+        folder = os.path.join(self.runFolderPath(), f'source-{key[1]}')
+        os.makedirs(folder, exist_ok=True)
+        with open(os.path.join(folder, f'{stamp}-rays.pkl'), 'wb') as f:
+          pickle.dump(rays, f)
+    self._rays = {}
+
+  def rays(self, pattern='*'):
+    """every recorded ray so far (in-memory `loadRays`)"""
+    self.flush()
+    out = []
+    for (src, srcLabel), rays in self._flushedRays.items():
+      rel = f'source-{srcLabel}'
+      if pattern in ('*', '**') or fnmatch.fnmatch(rel, pattern) or fnmatch.fnmatch(rel, f'*{pattern}*'):
+        out.extend(rays)
+    return out
 
   def hits(self, pattern='*'):
     """everything recorded so far as one `Hits` (in-memory `loadHits`)"""
@@ -236,6 +265,21 @@ class RawFolder:
       for k, v in data.items():
         updateResultEntry(result, k, v)
     return Hits(result)
+
+  def loadRays(self, pattern='*'):
+    """the rays of sources with RecordRays: a list of dictionaries
+    (points (k+1, 3), powers (k,), media [k]), one per ray, as
+    SimulationResults.flush pickles them (results_store.py:380-399).  (The
+    reference's own loadRays, freecad_document.py:1488-1504, merges the files
+    like hit dictionaries and so rejects these lists; here they are
+    concatenated.)"""
+    if pattern == '*':
+      pattern = '**'
+    out = []
+    for p in sorted(glob.iglob(f'{self._path}/{pattern}/*-rays.pkl', recursive=True)):
+      with open(p, 'rb') as f:
+        out.extend(pickle.load(f))
+    return out
 
 
 def rawFolders(resultsPath):

@@ -19,9 +19,10 @@ import numpy as np
 from ..freecad_elements import point_source, replay_source, surface_source
 from ..scene import bake as _bake
 from . import parallel, results_store
-from .tracer import Tracer
+from .tracer import Tracer, segmentsToRays
 
 DEFAULT_SEED = 0x0D15EA5E
+_RECORD_RAYS_PER_LAUNCH = 1 << 16
 _MODES = ('true', 'singletrue', 'pseudo', 'singlepseudo', 'fans', 'singlefans')
 
 
@@ -106,6 +107,10 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
       for src, scene, bsrc, lim in baked:
         per_iter = max(1, int(round(rpi * bsrc.rays_per_iteration_scale)))
         base = first[src.Name]
+        # RecordRays (generic_source.py:26, 78-118): every segment of every ray is kept, so
+        # launches of such a source stay small
+        record_rays = bool(src._props.get('RecordRays', False))
+        rpl = min(raysPerLaunch, _RECORD_RAYS_PER_LAUNCH) if record_rays else raysPerLaunch
         # -- what this launch traces: device-generated rays or explicit initial conditions ----
         explicit = None          # (origins, directions, powers or None, wavelengths or None)
         if isinstance(bsrc, replay_source.BakedReplay):
@@ -113,7 +118,7 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
           # RaysPerIteration rays of the stock; an exhausted stock ends the simulation
           if action in ('fans', 'singlefans'):
             continue
-          iters = 1 if not continuous else _iterations_for_launch(store, per_iter, raysPerLaunch)
+          iters = 1 if not continuous else _iterations_for_launch(store, per_iter, rpl)
           o, d, wl, pw = bsrc.take(iters * per_iter)
           n, iters = len(o), max(1, -(-len(o) // per_iter))
           order = np.argsort(wl, kind='stable')          # one launch per wavelength (gratings)
@@ -141,7 +146,7 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
         elif pseudo and isinstance(bsrc, point_source.BakedSource):
           # (surface sources treat 'pseudo' like 'true', surface_source.py:521)
           iters = 1 if not continuous else min(pseudoIterationsPerLaunch,
-                                               _iterations_for_launch(store, per_iter, raysPerLaunch))
+                                               _iterations_for_launch(store, per_iter, rpl))
           vrv = point_source.getVrv(src)
           ang = np.concatenate([vrv.drawPseudo(N=per_iter) for _ in range(iters)], axis=-1)
           rays = [point_source.makeRay(bsrc, t, p) for t, p in ang.T]
@@ -151,7 +156,7 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
                          initWavelength=np.full(n, bsrc.wavelength), initPhi=ang[1],
                          initTheta=ang[0] if np.isfinite(bsrc.focal_length) else np.full(n, np.nan))
         else:
-          iters = 1 if not continuous else _iterations_for_launch(store, per_iter, raysPerLaunch)
+          iters = 1 if not continuous else _iterations_for_launch(store, per_iter, rpl)
           n = iters * per_iter
           per_ray = None
         # -- this rank's share of the launch ---------------------------------------------------
@@ -161,11 +166,13 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
         tr.setDetector(None)
         tr.reserveHits(max(16, min(m * (lim.max_intersections + 1), 4 * m + 1024) if explicit is None
                            else m * (lim.max_intersections + 1)))
+        if record_rays:
+          tr.reserveSegments(max(16, min(m * lim.max_intersections, (1 << 31) - 1)))
         tr.reset()
         if explicit is None:
           tr.setSource(bsrc)
           if m:
-            tr.trace(base + lo, m, seed)
+            tr.trace(base + lo, m, seed, record_segments=record_rays)
           per_ray, index_base = _DeviceInitialConditions(tr, bsrc, base + lo, m, seed), base + lo
         else:
           o, d, pw, wl = (a[lo:lo + m] if a is not None else None for a in explicit)
@@ -173,12 +180,12 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
           index_base = base
           if wl is None:
             if m:
-              tr.traceRays(o, d, pw, first=base + lo)
+              tr.traceRays(o, d, pw, first=base + lo, record_segments=record_rays)
           else:
             for w in np.unique(wl):
               sel = np.nonzero(wl == w)[0]                 # contiguous: the launch is ordered by wavelength
               tr.setWavelength(w)
-              tr.traceRays(o[sel], d[sel], pw[sel], first=base + lo + int(sel[0]))
+              tr.traceRays(o[sel], d[sel], pw[sel], first=base + lo + int(sel[0]), record_segments=record_rays)
         tr.sync()
         first[src.Name] = base + n
         cnt = tr.counters()
@@ -187,6 +194,11 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
         before = store.totalRecordedHits
         _store_hits(store, tr.hits(), scene, src, per_ray, index_base, enabled)
         mine = store.totalRecordedHits - before
+        if record_rays:
+          _, dropped = tr.segmentCount()
+          if dropped:
+            raise RuntimeError(f'{dropped} ray segments did not fit the device buffer')
+          store.addRays(src.Name, src._props.get('Label', src.Name), segmentsToRays(tr.segments(), scene))
         (everyone,) = ranks.sum([mine])
         store.totalRecordedHits += everyone - mine         # every rank sees the job's totals
         store.incrementRayCount(n)

@@ -11,7 +11,7 @@ import ctypes as C
 import numpy as np
 
 from .. import _native
-from .._native import CNT_NAMES, HIT_DTYPE, TRACE_HISTOGRAM, TRACE_RECORD_HITS
+from .._native import CNT_NAMES, HIT_DTYPE, SEGMENT_DTYPE, TRACE_HISTOGRAM, TRACE_RECORD_HITS, TRACE_RECORD_SEGMENTS
 
 
 class _CudaArrayView:
@@ -115,18 +115,24 @@ class Tracer:
   def reserveHits(self, capacity):
     self._chk(self._lib.odw_reserve_hits(self._ctx, C.c_uint64(int(capacity))), 'odw_reserve_hits')
 
+  def reserveSegments(self, capacity):
+    """room for the rows of sources with RecordRays (one per ray segment)"""
+    self._chk(self._lib.odw_reserve_segments(self._ctx, C.c_uint64(int(capacity))), 'odw_reserve_segments')
+
   # -- tracing --------------------------------------------------------------
   @staticmethod
-  def _flags(record_hits, histogram):
-    return (TRACE_RECORD_HITS if record_hits else 0) | (TRACE_HISTOGRAM if histogram else 0)
+  def _flags(record_hits, histogram, record_segments=False):
+    return ((TRACE_RECORD_HITS if record_hits else 0) | (TRACE_HISTOGRAM if histogram else 0)
+            | (TRACE_RECORD_SEGMENTS if record_segments else 0))
 
-  def trace(self, first, n, seed, record_hits=True, histogram=True):
+  def trace(self, first, n, seed, record_hits=True, histogram=True, record_segments=False):
     """asynchronous: rays first..first+n-1 of Philox stream `seed`"""
-    self._chk(self._lib.odw_trace(self._ctx, C.c_uint64(int(first)), C.c_uint64(int(n)),
-                                  C.c_uint64(int(seed)), C.c_uint32(self._flags(record_hits, histogram))),
+    self._chk(self._lib.odw_trace(self._ctx, C.c_uint64(int(first)), C.c_uint64(int(n)), C.c_uint64(int(seed)),
+                                  C.c_uint32(self._flags(record_hits, histogram, record_segments))),
               'odw_trace')
 
-  def traceRays(self, origins, directions, powers=None, first=0, record_hits=True, histogram=True):
+  def traceRays(self, origins, directions, powers=None, first=0, record_hits=True, histogram=True,
+                record_segments=False):
     o = np.ascontiguousarray(origins, dtype=np.float64).reshape(-1, 3)
     d = np.ascontiguousarray(directions, dtype=np.float64).reshape(-1, 3)
     if o.shape != d.shape:
@@ -136,7 +142,7 @@ class Tracer:
     self._chk(self._lib.odw_trace_rays(
         self._ctx, C.c_uint64(int(first)), C.c_uint64(len(o)), o.ctypes.data_as(pd), d.ctypes.data_as(pd),
         p.ctypes.data_as(pd) if p is not None else None,
-        C.c_uint32(self._flags(record_hits, histogram))), 'odw_trace_rays')
+        C.c_uint32(self._flags(record_hits, histogram, record_segments))), 'odw_trace_rays')
 
   def sync(self):
     self._chk(self._lib.odw_sync(self._ctx), 'odw_sync')
@@ -168,6 +174,24 @@ class Tracer:
     got = C.c_uint64(0)
     self._chk(self._lib.odw_fetch_hits(self._ctx, out.ctypes.data_as(C.c_void_p), C.c_uint64(n),
                                        C.byref(got)), 'odw_fetch_hits')
+    return out[:int(got.value)]
+
+  def resetSegments(self):
+    self._chk(self._lib.odw_reset_segments(self._ctx), 'odw_reset_segments')
+
+  def segmentCount(self):
+    """(rows in the segment list, rows that did not fit)"""
+    n, dropped = C.c_uint64(0), C.c_uint64(0)
+    self._chk(self._lib.odw_segment_count(self._ctx, C.byref(n), C.byref(dropped)), 'odw_segment_count')
+    return int(n.value), int(dropped.value)
+
+  def segments(self):
+    """recorded ray segments sorted by (ray index, ordinal)"""
+    n, _ = self.segmentCount()
+    out = np.zeros(n, dtype=SEGMENT_DTYPE)
+    got = C.c_uint64(0)
+    self._chk(self._lib.odw_fetch_segments(self._ctx, out.ctypes.data_as(C.c_void_p), C.c_uint64(n),
+                                           C.byref(got)), 'odw_fetch_segments')
     return out[:int(got.value)]
 
   def histogram(self):
@@ -212,6 +236,28 @@ class Tracer:
     ms, n = C.c_double(0), C.c_uint64(0)
     self._chk(self._lib.odw_timing_read(self._ctx, C.byref(ms), C.byref(n)), 'odw_timing_read')
     return float(ms.value), int(n.value)
+
+
+def segmentsToRays(segs, scene):
+  """rows sorted by (ray, ordinal) -> one dictionary per ray, the layout
+  SimulationResultsSingleRay.dump pickles (results_store.py:241-257):
+  points (k+1, 3) = every segment's start + the end of the last one,
+  powers (k,), media (k names, None = vacuum); plus globalRayIndex"""
+  if len(segs) == 0:
+    return []
+  tags = segs['tag']
+  ray = (tags & np.uint64(0xFFFFFFFFFF)).astype(np.int64)
+  medium = ((tags >> np.uint64(52)) & np.uint64(0xFFF)).astype(np.int64) - 1
+  starts = np.flatnonzero(np.r_[True, ray[1:] != ray[:-1]])
+  ends = np.r_[starts[1:], len(segs)]
+  names = list(scene.group_names)
+  out = []
+  for a, b in zip(starts, ends):
+    out.append(dict(points=np.vstack([segs['p1'][a:b], segs['p2'][b - 1:b]]),
+                    powers=np.array(segs['power'][a:b]),
+                    media=[names[m] if m >= 0 else None for m in medium[a:b]],
+                    globalRayIndex=int(ray[a])))
+  return out
 
 
 def hitsToDict(hits, scene, sourceName='', group=None):

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ODW_ABI_VERSION 3
+#define ODW_ABI_VERSION 4
 
 /* ---- return codes ------------------------------------------------------ */
 enum {
@@ -247,6 +247,26 @@ typedef struct odw_hit {
 #define ODW_HIT_GROUP(tag)    (((tag) >> 48) & 0x7FFF)
 #define ODW_HIT_ENTERING(tag) ((tag) >> 63)
 
+/* One ray segment as Ray.traceRay yields it (ray.py:104-117) and
+ * SimulationResultsSingleRay.addSegment keeps it for sources with RecordRays
+ * (generic_source.py:78-118, results_store.py:232-257): (p1, p2), the power
+ * at p1 and the medium the segment runs through.  A ray that finds no
+ * intersection ends with p2 = p1 + direction * max_ray_length (ray.py:107).
+ * 64 bytes.  tag = ray_index (40 bits) | ordinal << 40 (12 bits; 0 = first
+ * segment) | (medium group + 1) << 52 (0 = vacuum).                         */
+typedef struct odw_segment {
+  double p1[3];
+  double p2[3];
+  double power;
+  uint64_t tag;
+} odw_segment;
+
+#define ODW_SEG_RAY(tag)     ((tag) & 0xFFFFFFFFFFull)
+#define ODW_SEG_ORDINAL(tag) (((tag) >> 40) & 0xFFF)
+#define ODW_SEG_MEDIUM(tag)  ((int32_t)(((tag) >> 52) & 0xFFF) - 1)
+#define ODW_SEG_MAX_RAY      (1ull << 40)   /* first_ray + n_rays of a recording launch */
+#define ODW_SEG_MAX_ORDINAL  4096           /* max_intersections of a recording launch  */
+
 /* counters (u64), SimulationResults counters results_store.py:306-310       */
 enum {
   ODW_CNT_TRACED_RAYS = 0,   /* incrementRayCount, generic_source.py:141     */
@@ -263,6 +283,7 @@ enum {
 /* trace flags */
 #define ODW_TRACE_RECORD_HITS 0x1 /* append odw_hit rows                      */
 #define ODW_TRACE_HISTOGRAM   0x2 /* bin into the detector histogram          */
+#define ODW_TRACE_RECORD_SEGMENTS 0x4 /* append odw_segment rows (RecordRays) */
 
 typedef struct odw_ctx odw_ctx;
 
@@ -294,6 +315,9 @@ int odw_set_limits(odw_ctx* ctx, const odw_limits* limits);
 int odw_set_detector(odw_ctx* ctx, const odw_detector_desc* det);
 /* capacity of the device hit list in rows (0 frees it)                     */
 int odw_reserve_hits(odw_ctx* ctx, uint64_t capacity);
+/* capacity of the device segment list in rows (0 frees it); needed by
+ * launches with ODW_TRACE_RECORD_SEGMENTS                                   */
+int odw_reserve_segments(odw_ctx* ctx, uint64_t capacity);
 
 /* replaces one or many runSimulationIteration calls (generic_source.py:51):
  * rays first_ray .. first_ray+n_rays-1 of the global Philox stream `seed`
@@ -309,13 +333,18 @@ int odw_trace_rays(odw_ctx* ctx, uint64_t first_ray, uint64_t n_rays,
 int odw_sync(odw_ctx* ctx);
 
 /* results --------------------------------------------------------------- */
-int odw_reset_results(odw_ctx* ctx); /* zero counters, hits, histogram      */
+int odw_reset_results(odw_ctx* ctx); /* zero counters, hits, segments, histogram */
 int odw_reset_hits(odw_ctx* ctx);    /* recycle the hit list only (flush)   */
 int odw_fetch_counters(odw_ctx* ctx, uint64_t* out, int32_t n);
 int odw_hit_count(odw_ctx* ctx, uint64_t* n);
 /* copies min(n_hits, capacity) rows, sorted by (ray index, bounce order)   */
 int odw_fetch_hits(odw_ctx* ctx, odw_hit* out, uint64_t capacity, uint64_t* n);
 int odw_fetch_histogram(odw_ctx* ctx, uint64_t* out, uint64_t n_bins);
+/* rows in the segment list and rows that did not fit into it               */
+int odw_segment_count(odw_ctx* ctx, uint64_t* n, uint64_t* dropped);
+/* copies the rows sorted by (ray index, ordinal); NULL out: count only      */
+int odw_fetch_segments(odw_ctx* ctx, odw_segment* out, uint64_t capacity, uint64_t* n);
+int odw_reset_segments(odw_ctx* ctx); /* recycle the segment list            */
 /* sampler only (diagnostics/tests): theta-or-radius and phi of each ray    */
 int odw_sample(odw_ctx* ctx, uint64_t first_ray, uint64_t n_rays, uint64_t seed,
                double* theta_out, double* phi_out);

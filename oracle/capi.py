@@ -20,6 +20,7 @@ CNT_NAMES = ['traced_rays', 'recorded_hits', 'segments', 'escaped', 'died', 'cap
 TRACE_RECORD_HITS, TRACE_HISTOGRAM = 1, 2
 
 HIT_DTYPE = np.dtype([('point', '<f8', 3), ('direction', '<f8', 3), ('power', '<f8'), ('tag', '<u8')])
+SEGMENT_DTYPE = np.dtype([('p1', '<f8', 3), ('p2', '<f8', 3), ('power', '<f8'), ('tag', '<u8')])
 
 _pd = C.POINTER(C.c_double)
 _pi = C.POINTER(C.c_int32)
@@ -294,6 +295,34 @@ def trace_rays(sc, lim, origins, dirs, powers=None, wavelength=500.0, first=0, d
   if rc != 0:
     raise RuntimeError(f'odw_oracle_trace_rays failed: {rc}')
   return _result(hits, nh, hist, cnt, det)
+
+
+def trace_segments(sc, lim, src=None, first=0, n=0, seed=0, origins=None, dirs=None, powers=None,
+                   wavelength=500.0, surface_seed=0):
+  """segments of every ray sorted by (ray, ordinal): rays first..first+n-1 of the
+  sampler `src`, or explicit initial conditions"""
+  s, l = scene_desc(sc), limits_desc(lim)
+  q = source_desc(src) if src is not None else None
+  set_surface_samplers(getattr(sc, 'surface_samplers', None), surface_seed)
+  pw = None
+  if origins is not None:
+    origins = _arr(origins, np.float64).reshape(-1, 3)
+    dirs = _arr(dirs, np.float64).reshape(-1, 3)
+    n = len(origins)
+    pw = _arr(powers, np.float64) if powers is not None else None
+  cap = max(16, int(n) * max(1, int(lim.max_intersections)))
+  segs = np.zeros(cap, dtype=SEGMENT_DTYPE)
+  ns = C.c_uint64(0)
+  cnt = np.zeros(len(CNT_NAMES), dtype=np.uint64)
+  rc = lib().odw_oracle_trace_segments(
+      C.byref(s.desc), C.byref(q.desc) if q is not None else None, C.byref(l), C.c_double(wavelength),
+      C.c_uint64(first), C.c_uint64(n), C.c_uint64(seed),
+      _p(origins, _pd) if origins is not None else None, _p(dirs, _pd) if origins is not None else None,
+      _p(pw, _pd) if pw is not None else None,
+      segs.ctypes.data_as(C.c_void_p), C.c_uint64(cap), C.byref(ns), _p(cnt, _pu))
+  if rc != 0:
+    raise RuntimeError(f'odw_oracle_trace_segments failed: {rc}')
+  return dict(segments=segs[:ns.value], counters={k: int(v) for k, v in zip(CNT_NAMES, cnt)})
 
 
 def nearest(sc, lim, start, direction, medium=-1, seq_idx=0):

@@ -707,7 +707,22 @@ typedef struct {
   odw_hit* hits; uint64_t cap; uint64_t n;
   uint64_t* hist;
   uint64_t cnt[ODW_CNT_COUNT];
+  odw_segment* segs; uint64_t seg_cap; uint64_t seg_n;   /* grows */
 } sink;
+
+/* SimulationResultsSingleRay.addSegment (results_store.py:238-239) fed by the
+ * tuples Ray.traceRay yields (ray.py:104-117) */
+static void record_segment(sink* sk, uint64_t ray, int ordinal, int medium, v3 p1, v3 p2, double power) {
+  if (sk->seg_n == sk->seg_cap) {
+    sk->seg_cap = sk->seg_cap ? 2 * sk->seg_cap : 64;
+    sk->segs = (odw_segment*)realloc(sk->segs, sk->seg_cap * sizeof(odw_segment));
+  }
+  odw_segment* g = &sk->segs[sk->seg_n++];
+  g->p1[0] = p1.x; g->p1[1] = p1.y; g->p1[2] = p1.z;
+  g->p2[0] = p2.x; g->p2[1] = p2.y; g->p2[2] = p2.z;
+  g->power = power;
+  g->tag = (ray & 0xFFFFFFFFFFull) | ((uint64_t)(ordinal & 0xFFF) << 40) | ((uint64_t)((medium + 1) & 0xFFF) << 52);
+}
 
 static void record_hit(sink* sk, const odw_detector_desc* det, uint32_t flags,
                        uint64_t ray, int group, v3 p, v3 d, double power, int entering) {
@@ -746,6 +761,9 @@ static void trace_one(const odw_scene_desc* sc, const odw_limits* lim,
     nint++;
     sk->cnt[ODW_CNT_SEGMENTS]++;
     nearest_hit h = nearest_skipping(sc, lim, point, dir, medium, seq, skip_solid);
+    if (flags & ODW_TRACE_RECORD_SEGMENTS)
+      record_segment(sk, ray, nint - 1, medium, point,
+                     h.found ? h.point : add(point, mul(dir, lim->max_ray_length / len(dir))), power);
     if (!h.found) { sk->cnt[ODW_CNT_ESCAPED]++; break; }
     v3 prev = point;
     int prev_medium = medium;
@@ -834,18 +852,27 @@ static void trace_one(const odw_scene_desc* sc, const odw_limits* lim,
 /* ------------------------------------------------------------------ */
 #define CHUNK 4096
 
+typedef struct { odw_segment* segs; uint64_t cap; uint64_t* n; } seg_out;
+
 static int run(const odw_scene_desc* sc, const odw_source_desc* src, const odw_limits* lim,
                const odw_detector_desc* det, uint64_t first, uint64_t n, uint64_t seed,
                const double* origins, const double* dirs, const double* powers,
                uint32_t flags, odw_hit* hits, uint64_t cap, uint64_t* n_hits,
-               uint64_t* hist, uint64_t* counters, int nthreads) {
+               uint64_t* hist, uint64_t* counters, int nthreads, const seg_out* so) {
   if (!sc || !lim || sc->n_groups > ODW_MAX_GROUPS) return ODW_ERR_INVALID;
+  if (!so) flags &= ~(uint32_t)ODW_TRACE_RECORD_SEGMENTS;
+  odw_segment** chunk_segs = NULL;
+  uint64_t* chunk_seg_n = NULL;
   if (!origins && !src) return ODW_ERR_INVALID;
   uint64_t nchunks = (n + CHUNK - 1) / CHUNK;
   size_t nbins = det ? (size_t)det->nx * (size_t)det->ny : 0;
   /* per-chunk private hit lists keep the output in ray order under OpenMP */
   odw_hit** chunk_hits = (odw_hit**)calloc(nchunks ? nchunks : 1, sizeof(odw_hit*));
   uint64_t* chunk_n = (uint64_t*)calloc(nchunks ? nchunks : 1, sizeof(uint64_t));
+  if (so) {
+    chunk_segs = (odw_segment**)calloc(nchunks ? nchunks : 1, sizeof(odw_segment*));
+    chunk_seg_n = (uint64_t*)calloc(nchunks ? nchunks : 1, sizeof(uint64_t));
+  }
   uint64_t total[ODW_CNT_COUNT] = {0};
   int max_hits_per_ray = lim->max_intersections > 0 ? lim->max_intersections : 1;
   (void)nthreads;
@@ -891,6 +918,7 @@ static int run(const odw_scene_desc* sc, const odw_source_desc* src, const odw_l
       }
       chunk_hits[ci] = sk.hits;
       chunk_n[ci] = sk.n;
+      if (so) { chunk_segs[ci] = sk.segs; chunk_seg_n[ci] = sk.seg_n; }
       for (int k = 0; k < ODW_CNT_COUNT; ++k) lcnt[k] += sk.cnt[k];
     }
 #ifdef _OPENMP
@@ -911,6 +939,16 @@ static int run(const odw_scene_desc* sc, const odw_source_desc* src, const odw_l
     free(chunk_hits[ci]);
   }
   free(chunk_hits); free(chunk_n);
+  if (so) {   /* per-chunk lists are in (ray, ordinal) order already */
+    uint64_t ns = 0;
+    for (uint64_t ci = 0; ci < nchunks; ++ci) {
+      for (uint64_t k = 0; k < chunk_seg_n[ci]; ++k)
+        if (so->segs && ns < so->cap) so->segs[ns++] = chunk_segs[ci][k];
+      free(chunk_segs[ci]);
+    }
+    free(chunk_segs); free(chunk_seg_n);
+    if (so->n) *so->n = ns;
+  }
   total[ODW_CNT_HITS_DROPPED] += dropped;
   if (n_hits) *n_hits = nh;
   if (counters) for (int k = 0; k < ODW_CNT_COUNT; ++k) counters[k] += total[k];
@@ -923,7 +961,7 @@ int odw_oracle_trace(const odw_scene_desc* sc, const odw_source_desc* src,
                      odw_hit* hits, uint64_t cap, uint64_t* n_hits, uint64_t* hist,
                      uint64_t* counters, int nthreads) {
   return run(sc, src, lim, det, first, n, seed, NULL, NULL, NULL, flags, hits, cap, n_hits,
-             hist, counters, nthreads);
+             hist, counters, nthreads, NULL);
 }
 
 int odw_oracle_trace_rays(const odw_scene_desc* sc, const odw_limits* lim,
@@ -937,7 +975,28 @@ int odw_oracle_trace_rays(const odw_scene_desc* sc, const odw_limits* lim,
   s.wavelength = wavelength;
   s.power = 1.0;
   return run(sc, &s, lim, det, first, n, 0, origins, dirs, powers, flags, hits, cap, n_hits,
-             hist, counters, nthreads);
+             hist, counters, nthreads, NULL);
+}
+
+/* the segments of every ray (RecordRays, generic_source.py:78-118), sorted by
+ * (ray, ordinal); origins == NULL: rays of the sampler `src`, else explicit
+ * initial conditions with the wavelength given */
+int odw_oracle_trace_segments(const odw_scene_desc* sc, const odw_source_desc* src,
+                              const odw_limits* lim, double wavelength, uint64_t first, uint64_t n,
+                              uint64_t seed, const double* origins, const double* dirs,
+                              const double* powers, odw_segment* segs, uint64_t cap,
+                              uint64_t* n_segs, uint64_t* counters) {
+  seg_out so = {segs, cap, n_segs};
+  if (origins) {
+    odw_source_desc s;
+    memset(&s, 0, sizeof s);
+    s.wavelength = wavelength;
+    s.power = 1.0;
+    return run(sc, &s, lim, NULL, first, n, 0, origins, dirs, powers, ODW_TRACE_RECORD_SEGMENTS, NULL, 0,
+               NULL, NULL, counters, 0, &so);
+  }
+  return run(sc, src, lim, NULL, first, n, seed, NULL, NULL, NULL, ODW_TRACE_RECORD_SEGMENTS, NULL, 0,
+             NULL, NULL, counters, 0, &so);
 }
 
 /* initial conditions only: origin/direction of sampled rays (pins _makeRay) */

@@ -45,14 +45,21 @@ class OracleTracer:
   def reserveHits(self, capacity):
     self._capacity = int(capacity)
 
+  def reserveSegments(self, capacity):
+    self._seg_capacity = int(capacity)
+
   # -- results ---------------------------------------------------------------
   def reset(self):
     self._hits = []
     self._cnt = {k: 0 for k in capi.CNT_NAMES}
     self._hist = None
+    self._segs = []
 
   def resetHits(self):
     self._hits = []
+
+  def resetSegments(self):
+    self._segs = []
 
   def _absorb(self, r):
     for k, v in r['counters'].items():
@@ -62,10 +69,18 @@ class OracleTracer:
     if 'hist' in r:
       self._hist = r['hist'] if self._hist is None else self._hist + r['hist']
 
-  def trace(self, first, n, seed, record_hits=True, histogram=True):
+  def trace(self, first, n, seed, record_hits=True, histogram=True, record_segments=False):
     if n == 0:
       return
     flags = (1 if record_hits else 0) | (2 if histogram else 0)
+    if record_segments:
+      if hasattr(self.source, 'face_prim'):
+        o, d = capi.surface_rays(self.source, int(first), int(n), int(seed))
+        g = capi.trace_segments(self.scene, self.limits, origins=o, dirs=d, wavelength=self.source.wavelength,
+                                first=int(first), surface_seed=int(seed))
+      else:
+        g = capi.trace_segments(self.scene, self.limits, src=self.source, first=int(first), n=int(n), seed=int(seed))
+      self._segs.append(g['segments'])
     if hasattr(self.source, 'face_prim'):
       r = capi.trace_surface(self.scene, self.source, self.limits, int(first), int(n), int(seed), det=self._det,
                              flags=flags, nthreads=self._nthreads)
@@ -74,9 +89,14 @@ class OracleTracer:
                      hit_capacity=int(n) * (self.limits.max_intersections + 1), nthreads=self._nthreads)
     self._absorb(r)
 
-  def traceRays(self, origins, directions, powers=None, first=0, record_hits=True, histogram=True):
+  def traceRays(self, origins, directions, powers=None, first=0, record_hits=True, histogram=True,
+                record_segments=False):
     wl = self._wavelength if self._wavelength is not None else getattr(getattr(self, 'source', None), 'wavelength', 500.0)
     flags = (1 if record_hits else 0) | (2 if histogram else 0)
+    if record_segments:
+      self._segs.append(capi.trace_segments(self.scene, self.limits, origins=origins, dirs=directions, powers=powers,
+                                            wavelength=wl, first=int(first),
+                                            surface_seed=self._surface_seed)['segments'])
     self._absorb(capi.trace_rays(self.scene, self.limits, origins, directions, powers, wavelength=wl, first=int(first),
                                  det=self._det, flags=flags, nthreads=self._nthreads, surface_seed=self._surface_seed))
 
@@ -95,6 +115,17 @@ class OracleTracer:
     h = np.concatenate(self._hits)
     ray = (h['tag'] & np.uint64(0xFFFFFFFFFFFF)).astype(np.int64)
     return h[np.argsort(ray, kind='stable')]
+
+  def segmentCount(self):
+    return sum(len(g) for g in self._segs), 0
+
+  def segments(self):
+    if not self._segs:
+      return np.zeros(0, dtype=capi.SEGMENT_DTYPE)
+    g = np.concatenate(self._segs)
+    tag = g['tag']
+    key = ((tag & np.uint64(0xFFFFFFFFFF)) << np.uint64(12)) | ((tag >> np.uint64(40)) & np.uint64(0xFFF))
+    return g[np.argsort(key, kind='stable')]
 
   def histogram(self):
     if self._det is None:
