@@ -4,9 +4,11 @@ An .FCStd file is a zip; `Document.xml` lists every document object with its
 typed properties.  This module parses exactly the property kinds the hot path
 needs (SURVEY 7.1): parametric Part primitives, booleans, App::Link, Draft
 link arrays, App::LinkGroupPython optical groups / light sources and the
-simulation settings object.  BRep payloads (`*.brp`) are never read: the
-geometry is rebuilt from the parametric features, which is what makes the GPU
-box (no FreeCAD) self-sufficient.
+simulation settings object.  Geometry is rebuilt from the parametric features,
+which is what makes the GPU box (no FreeCAD) self-sufficient; the BRep
+payloads (`*.brp`) are kept as bytes and read only for objects that have no
+parametric recipe (`Part::Feature` imports, `PartDesign::Body`:
+scene/brep.py, scene/brep_mesh.py).
 
 It mirrors what the reference reaches through the FreeCAD API
 (`obj.Placement`, `obj.Radius`, `group.ElementList`, `obj.Proxy` class names;
@@ -145,7 +147,25 @@ def _parse_property(prop, zf):
     return [Placement(base=v[:3], quat=v[3:]) for v in vals]
   if tag == 'BoolList':
     return [c == '1' for c in child.attrib.get('value', '')]
+  if tag == 'Part':
+    # Part::PropertyPartShape: the BRep text travels as a member of the zip; kept as bytes and
+    # parsed only for objects that have no parametric recipe (scene/brep.py)
+    fname = child.attrib.get('file')
+    if not fname or zf is None or fname not in zf.namelist():
+      return None
+    data = zf.read(fname)
+    return BRepPayload(fname, data) if data else None
   return None
+
+
+class BRepPayload:
+  """the `<Object>.Shape.brp` member of an FCStd file (OpenCASCADE BRep text)"""
+
+  def __init__(self, name, data):
+    self.name, self.data = name, data
+
+  def __repr__(self):
+    return f'<BRepPayload {self.name}, {len(self.data)} bytes>'
 
 
 # property tables of the workbench proxies (optical_group.py:29-96,

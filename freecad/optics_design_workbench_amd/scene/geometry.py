@@ -140,10 +140,31 @@ def solids_of(obj, with_own_placement=True, _depth=0):
     return _moved(out, own)
 
   if t in ('Part::Feature', 'Part::FeaturePython') or t.startswith('PartDesign') or t.startswith('Sketcher'):
-    raise UnsupportedGeometry(
-        f'{obj.Name} ({t}): only a BRep payload is stored; baking it needs FreeCAD '
-        f'(tessellation fallback, SURVEY 8f N4)')
+    return _moved([_brep_node(obj)], own)
   return []
+
+
+BREP_DEFLECTION = 1e-3      # mm between a facet and the exact surface (`Shape.tessellate(tol)`)
+_BREP_CACHE = {}
+
+
+def _brep_node(obj):
+  """objects without a parametric recipe (STEP imports, PartDesign bodies): the facets of their
+  stored boundary representation, in the object's own coordinates (FreeCAD keeps the Placement
+  as the location of the stored shape: it is taken off here and applied by the caller)"""
+  from . import brep, brep_mesh
+  payload = obj._props.get('Shape')
+  if payload is None or not getattr(payload, 'data', None):
+    raise UnsupportedGeometry(f'{obj.Name} ({obj.TypeId}): no parametric recipe and no stored BRep payload')
+  key = (payload.name, len(payload.data), hash(payload.data), BREP_DEFLECTION)
+  if key not in _BREP_CACHE:
+    try:
+      m = brep_mesh.tessellate(brep.load(payload.data), deflection=BREP_DEFLECTION, keep_root_location=False)
+    except brep.BRepError as e:
+      raise UnsupportedGeometry(f'{obj.Name} ({obj.TypeId}): BRep payload {payload.name}: {e}') from e
+    _BREP_CACHE[key] = m
+  m = _BREP_CACHE[key]
+  return Node('mesh', mesh=(m.vertices, m.triangles, m.normals), source=obj.Name)
 
 
 # ---------------------------------------------------------------------------

@@ -69,7 +69,7 @@ def _atomic_pickle(path, obj):
 class SimulationResults:
 
   def __init__(self, simulationType, resultsPath=None, simulationRunFolder=None,
-               endAfterIterations=np.inf, endAfterRays=np.inf, endAfterHits=np.inf):
+               endAfterIterations=np.inf, endAfterRays=np.inf, endAfterHits=np.inf, owner=True):
     self.simulationType = simulationType
     self.basePath = resultsPath
     self.simulationRunFolder = simulationRunFolder
@@ -78,7 +78,8 @@ class SimulationResults:
         self.simulationRunFolder = f'raw/simulation-run-{latestRunIndex(resultsPath) + 1:06d}'
       path = self.runFolderPath()
       os.makedirs(path, exist_ok=True)
-      if not any(f.startswith('uid-') for f in os.listdir(path)):
+      # (several ranks share one run folder: its uid file is written by one of them)
+      if owner and not any(f.startswith('uid-') for f in os.listdir(path)):
         open(os.path.join(path, f'uid-{uuid.uuid4()}'), 'w').close()
       os.makedirs(os.path.join(resultsPath, 'notebooks'), exist_ok=True)
     self.endAfterIterations = endAfterIterations

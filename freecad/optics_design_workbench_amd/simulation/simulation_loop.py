@@ -76,7 +76,9 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
         action, resultsPath=resultsPath, simulationRunFolder=runFolder,
         endAfterIterations=_limit(settings, 'EndAfterIterations', np.inf) if continuous else 0,
         endAfterRays=_limit(settings, 'EndAfterRays', np.inf) if continuous else np.inf,
-        endAfterHits=_limit(settings, 'EndAfterHits', np.inf) if continuous else np.inf)
+        endAfterHits=_limit(settings, 'EndAfterHits', np.inf) if continuous else np.inf,
+        owner=ranks.rank == 0)
+    ranks.barrier()
   if continuous and not (np.isfinite(store.endAfterIterations) or np.isfinite(store.endAfterRays)
                          or np.isfinite(store.endAfterHits)) and endIf is None:
     raise ValueError('continuous simulation without any end criterion (EndAfterIterations / '

@@ -6,8 +6,10 @@ Run in the authoring container only (needs /root/reference):
     python tests/golden/make_scenes.py
 
 An FCStd file is a zip of data files.  Only `Document.xml` (object list and
-property values) and the binary `PlacementList*` members (Draft link-array
-placements) are kept; BRep payloads, GUI state and thumbnails are dropped.
+property values), the binary `PlacementList*` members (Draft link-array
+placements) and the BRep payloads named in BREP (shapes of objects without a
+parametric recipe, plus three primitives whose volumes are known in closed
+form) are kept; other payloads, GUI state and thumbnails are dropped.
 The fixtures are data (scene descriptions), not code.
 """
 import os
@@ -31,6 +33,18 @@ SCENES = {
   'mirror-diffuse': 'test/50-old-tests/mirror-diffuse.FCStd',
   'playground': 'test/50-old-tests/playground.FCStd',
   'grating': 'test/50-old-tests/grating.FCStd',
+  'edmund-optics-lens': 'test/50-old-tests/edmund-optics-lens.FCStd',
+  'mirror': 'test/50-old-tests/mirror.FCStd',
+  'imported-stepfile-as-surface-source': 'test/80-surface-source-slow/imported-stepfile-as-surface-source.FCStd',
+  'external-file': 'test/22-global-placement/external-file.FCStd',
+  'external-file2': 'test/22-global-placement/external-file2.FCStd',
+}
+
+BREP = {
+  'nested-structure': ['Body.Shape.brp', 'Box.Shape.brp', 'Sphere.Shape.brp', 'Cylinder.Shape.brp'],
+  'edmund-optics-lens': ['Part__Feature.Shape.brp', 'Part__Feature001.Shape.brp'],
+  'mirror': ['Body.Shape.brp'],
+  'imported-stepfile-as-surface-source': ['Part__Feature.Shape.brp', 'Part__Feature001.Shape.brp'],
 }
 
 if __name__ == '__main__':
@@ -43,6 +57,7 @@ if __name__ == '__main__':
     dst = os.path.join(OUT, name + '.FCStd')
     with zipfile.ZipFile(src) as zin, zipfile.ZipFile(dst, 'w', zipfile.ZIP_DEFLATED) as zout:
       for info in zin.infolist():
-        if info.filename == 'Document.xml' or info.filename.startswith('PlacementList'):
+        if (info.filename == 'Document.xml' or info.filename.startswith('PlacementList')
+            or info.filename in BREP.get(name, ())):
           zout.writestr(info.filename, zin.read(info.filename))
     print(name, os.path.getsize(src), '->', os.path.getsize(dst))

@@ -60,11 +60,25 @@ def test_proxy_repair_and_nested_bake():
   assert np.allclose(sc.prim_to_world[0].m, exp.m)
 
 
-def test_nested_body_is_rejected_loudly():
-  """nested-structure.FCStd contains a PartDesign::Body (sketch based, BRep
-  only): it cannot be rebuilt without OpenCASCADE and must not be guessed"""
-  import pytest
-  from freecad.optics_design_workbench_amd import scenes
-  from freecad.optics_design_workbench_amd.scene import UnsupportedGeometry
-  with pytest.raises(UnsupportedGeometry):
-    scenes.bakeProject(os.path.join(SCENES, 'nested-structure.FCStd'))
+def test_nested_body_is_baked_from_its_brep_payload():
+  """nested-structure.FCStd contains a PartDesign::Body (a padded hexagon: BRep only).  Its facets
+  stand where the chain of placements puts the stored shape: every global placement of the mirror
+  group o Part001 o Body.Placement o (shape in the body's own coordinates)"""
+  from freecad.optics_design_workbench_amd.scene import bake, open_fcstd
+  doc = open_fcstd(os.path.join(SCENES, 'nested-structure.FCStd'))
+  sc = bake.bakeScene(doc, bake.lightSources(doc)[0])
+  g = list(sc.group_names).index('OpticalMirrorGroup001')
+  tri = np.asarray(sc.prim_xform)[(sc.prim_group == g) & (sc.prim_type == 5)][:, :9].reshape(-1, 3)
+  placements = bake.globalPlacements(doc, doc.getObject('OpticalMirrorGroup001'))
+  assert len(placements) == 3 and len(tri) == 3 * 20 * len(placements)      # 20 facets of 3 corners per prism
+  k = np.arange(6) * np.pi / 3
+  hexagon = np.concatenate([np.stack([2 * np.cos(k), 2 * np.sin(k), np.full(6, z)], axis=1) for z in (0.0, 10.0)])
+  want = []
+  for pl in placements:
+    m = (pl * doc.Part001.Placement * doc.Body.Placement).m
+    want.append(hexagon @ m[:3, :3].T + m[:3, 3])
+  want = np.concatenate(want)
+  d = np.abs(tri[:, None, :] - want[None, :, :]).sum(axis=2).min(axis=1)
+  assert d.max() < 1e-9                                   # every facet corner is a corner of a placed prism
+  d = np.abs(want[:, None, :] - tri[None, :, :]).sum(axis=2).min(axis=1)
+  assert d.max() < 1e-9                                   # and every corner is used
