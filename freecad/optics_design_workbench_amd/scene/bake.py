@@ -25,17 +25,19 @@ _UNSUPPORTED_SOURCES = ()
 # find.* equivalents (freecad_elements/find.py)
 # ---------------------------------------------------------------------------
 def lightSources(doc):
-  return [o for o in doc.Objects
+  # (all find.* functions look through the simulating document and every document its links lead
+  #  into: find._allObjects, freecad_elements/find.py:24-56)
+  return [o for o in doc.allObjects()
           if o.TypeId == 'App::LinkGroupPython' and o.ProxyClass in _SOURCE_PROXIES + _UNSUPPORTED_SOURCES]
 
 
 def opticalObjects(doc):
-  return [o for o in doc.Objects
+  return [o for o in doc.allObjects()
           if o.TypeId == 'App::LinkGroupPython' and o.ProxyClass == 'OpticalGroupProxy']
 
 
 def simulationSettings(doc):
-  return [o for o in doc.Objects
+  return [o for o in doc.allObjects()
           if o.TypeId == 'Part::FeaturePython' and o.ProxyClass == 'SimulationSettingsProxy']
 
 
@@ -65,15 +67,18 @@ def allPlacementsAndPaths(doc, obj, ignoreLinks=False, _depth=0):
   link's own placements, replacing obj.Placement unless LinkTransform is set.
   DocumentObjectGroups have no placement and are transparent: an object listed
   in a group and in the Part around that group is one instance (paths are
-  compared without groups)."""
+  compared without groups).
+  Objects of documents the project links into are represented through those
+  links only: a chain that ends at the top level of another document is not part
+  of the global model (common.py:62-65)."""
   if _depth > 100:
     raise RuntimeError('allPlacementsAndPaths reached recursion depth 100')
   own = obj.Placement if obj.hasProperty('Placement') else Placement.identity()
   out = []
-  containers = doc.parents_of(obj)
-  links = [] if ignoreLinks else [o for o in doc.Objects
+  containers = obj._doc.parents_of(obj)
+  links = [] if ignoreLinks else [o for o in doc.allObjects()
                                   if _is_link(o) and o._props.get('LinkedObject') is obj]
-  if not containers:
+  if not containers and obj._doc is doc:
     out.append((own, (obj.Name,)))
   for c in containers:
     transparent = c.TypeId == 'App::DocumentObjectGroup'

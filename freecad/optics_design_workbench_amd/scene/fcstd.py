@@ -124,7 +124,9 @@ def _parse_property(prop, zf):
         out.append((name, [sub]))
     return out
   if tag == 'XLink':
-    return child.attrib.get('name') or None
+    # App::PropertyXLink: object `name` of this document, or of the document `file` (relative path)
+    name, fname = child.attrib.get('name') or None, child.attrib.get('file') or ''
+    return ExternalRef(fname, name) if (name and fname) else name
   if tag == 'LinkSub':
     return child.attrib.get('value') or None
   if tag == 'Python':
@@ -156,6 +158,16 @@ def _parse_property(prop, zf):
     data = zf.read(fname)
     return BRepPayload(fname, data) if data else None
   return None
+
+
+class ExternalRef:
+  """target of an App::PropertyXLink that lives in another FCStd file"""
+
+  def __init__(self, file, name):
+    self.file, self.name = file, name
+
+  def __repr__(self):
+    return f'<ExternalRef {self.file}#{self.name}>'
 
 
 class BRepPayload:
@@ -217,13 +229,48 @@ def repairProxies(doc):
 class Document:
   """The parsed document: `doc.Objects`, `doc.getObject(name)`, `doc.<Name>`."""
 
-  def __init__(self, path=None):
+  def __init__(self, path=None, _loaded=None):
     self.FileName = path
     self.Objects = []
     self._by_name = {}
     self._revision = 0
+    # documents reached through links into other files (App::Link with an XLink target), by
+    # absolute path; shared by all documents of one project so that a file is loaded once
+    self._loaded = _loaded if _loaded is not None else {}
+    self._external = []
     if path is not None:
+      import os
+      self._loaded[os.path.abspath(path)] = self
       self._load(path)
+
+  def externalDocument(self, relpath):
+    """the document a link points into (`relpath` relative to this file), or None if it is missing"""
+    import os
+    if self.FileName is None:
+      return None
+    full = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(self.FileName)), relpath))
+    if full not in self._loaded:
+      if not os.path.exists(full):
+        return None
+      Document(full, _loaded=self._loaded)
+    ext = self._loaded[full]
+    if ext is not self and ext not in self._external:
+      self._external.append(ext)
+    return ext
+
+  def allDocuments(self):
+    """this document and every document reachable from it through links
+    (find._allObjects, freecad_elements/find.py:24-56)"""
+    out, todo = [], [self]
+    while todo:
+      d = todo.pop(0)
+      if d not in out:
+        out.append(d)
+        todo.extend(d._external)
+    return out
+
+  def allObjects(self):
+    return [o for d in self.allDocuments() for o in d.Objects]
 
   # -- loading ------------------------------------------------------------
   def _load(self, path):
@@ -250,7 +297,12 @@ class Document:
     for obj in self.Objects:
       for k, v in list(obj._props.items()):
         t = obj._types.get(k, '')
-        if t in ('App::PropertyLink', 'App::PropertyXLink', 'App::PropertyLinkGlobal'):
+        if isinstance(v, ExternalRef):
+          ext = self.externalDocument(v.file)
+          obj._props[k] = ext.getObject(v.name) if ext is not None else None
+          if obj._props[k] is None:
+            obj._props['_unresolved_' + k] = repr(v)
+        elif t in ('App::PropertyLink', 'App::PropertyXLink', 'App::PropertyLinkGlobal'):
           obj._props[k] = self._by_name.get(v) if isinstance(v, str) else None
         elif t == 'App::PropertyLinkSubList':
           obj._props[k] = [(self._by_name[n], [x for x in subs if x]) for n, subs in (v or [])
@@ -263,6 +315,11 @@ class Document:
   # -- API ----------------------------------------------------------------
   def _touch(self):
     self._revision += 1
+
+  @property
+  def revision(self):
+    """changes when any document of the project changes"""
+    return sum(d._revision for d in self.allDocuments())
 
   def getObject(self, name):
     return self._by_name.get(name)

@@ -70,7 +70,7 @@ def test_nested_body_is_baked_from_its_brep_payload():
   g = list(sc.group_names).index('OpticalMirrorGroup001')
   tri = np.asarray(sc.prim_xform)[(sc.prim_group == g) & (sc.prim_type == 5)][:, :9].reshape(-1, 3)
   placements = bake.globalPlacements(doc, doc.getObject('OpticalMirrorGroup001'))
-  assert len(placements) == 3 and len(tri) == 3 * 20 * len(placements)      # 20 facets of 3 corners per prism
+  assert len(placements) == 1 and len(tri) == 3 * 20 * len(placements)      # 20 facets of 3 corners per prism
   k = np.arange(6) * np.pi / 3
   hexagon = np.concatenate([np.stack([2 * np.cos(k), 2 * np.sin(k), np.full(6, z)], axis=1) for z in (0.0, 10.0)])
   want = []

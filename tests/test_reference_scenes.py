@@ -3,6 +3,8 @@ surfaces, gratings, negative and infinite focal lengths), loaded from the
 reduced fixtures and run through the oracle on CPU and -- marked gpu -- through
 the device, with the reference tests' own acceptance criteria where it has any
 (test/50-old-tests/run-simulations.py:104-115: playground records > 99 hits)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -47,3 +49,74 @@ def test_scene_parity_on_device(native_lib, oracle, name):
   assert np.array_equal(g['tag'], ref['hits']['tag'])
   assert np.abs(g['point'] - ref['hits']['point']).max() < 1e-7
   assert np.abs(g['direction'] - ref['hits']['direction']).max() < 1e-9
+
+
+# ---------------------------------------------------------------------------
+# test/22-global-placement/z-nested.py: a project that reaches its optics through
+# App::Parts, groups, links and links into two other FCStd files (one of which
+# links on into the other), with a PartDesign body (BRep only) as one mirror
+# ---------------------------------------------------------------------------
+def _nested_document():
+  import os
+  from conftest import SCENES
+  from freecad.optics_design_workbench_amd.scene import open_fcstd
+  return open_fcstd(os.path.join(SCENES, 'nested-structure.FCStd'))
+
+
+def test_deeply_nested_project_works(oracle):
+  """test_deeplyNestedProjectWorks: runSimulation('true') (EndAfterRays = 100, 5 rays per
+  iteration); more than 90 rays hit the absorber"""
+  from oracle_tracer import OracleTracer
+  from freecad.optics_design_workbench_amd.scene import bake
+  from freecad.optics_design_workbench_amd.simulation import runSimulation
+  doc = _nested_document()
+  files = [os.path.basename(d.FileName) for d in doc.allDocuments()]
+  assert files == ['nested-structure.FCStd', 'external-file.FCStd', 'external-file2.FCStd']
+  # optical groups of the linked files count (find._allObjects) and stand where the links put them
+  groups = {(os.path.basename(o._doc.FileName), o.Name): bake.allPlacementsAndPaths(doc, o)
+            for o in bake.opticalObjects(doc)}
+  assert len(groups) == 6
+  (pl, path), = groups[('external-file2.FCStd', 'OpticalLensGroup')]
+  assert path == ('Part', 'Link', 'Part002', 'Link', 'Part', 'OpticalLensGroup')
+  assert np.allclose(pl.Base, (-17.0, 0.0, 8.5))
+  (pl, path), = groups[('external-file.FCStd', 'OpticalMirrorGroup')]
+  assert path == ('Link001', 'Part', 'Part001', 'OpticalMirrorGroup')
+  store = runSimulation(doc, 'true', tracer=OracleTracer())
+  assert 100 < store.totalTracedRays <= 105
+  assert len(store.hits()) > 90
+
+
+def test_missing_linked_file_is_reported(tmp_path):
+  import shutil
+  from conftest import SCENES
+  from freecad.optics_design_workbench_amd.scene import bake, open_fcstd
+  shutil.copy(os.path.join(SCENES, 'nested-structure.FCStd'), tmp_path / 'nested-structure.FCStd')
+  doc = open_fcstd(str(tmp_path / 'nested-structure.FCStd'))
+  assert len(doc.allDocuments()) == 1
+  assert doc.getObject('Link002').LinkedObject is None
+  assert 'external-file2.FCStd' in doc.getObject('Link002')._props['_unresolved_LinkedObject']
+
+
+@pytest.mark.gpu
+def test_deeply_nested_project_on_device(native_lib, oracle):
+  from freecad.optics_design_workbench_amd.scene import bake
+  from freecad.optics_design_workbench_amd.simulation import runSimulation
+  from freecad.optics_design_workbench_amd.simulation.simulation_loop import bakeLightSource
+  from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
+  doc = _nested_document()
+  store = runSimulation(doc, 'true')
+  assert len(store.hits()) > 90
+  src = bake.lightSources(doc)[0]
+  sc, bs, lim = bake.bakeScene(doc, src), bakeLightSource(doc, src, 0), bake.bakeLimits(doc, src)
+  n = 20000
+  ref = oracle.trace(sc, bs, lim, 0, n, 5, flags=1, nthreads=0)
+  with Tracer(0) as tr:
+    tr.setScene(sc); tr.setSource(bs); tr.setLimits(lim); tr.setDetector(None)
+    tr.reserveHits(2 * n)
+    tr.reset()
+    tr.trace(0, n, 5, histogram=False)
+    tr.sync()
+    assert tr.counters() == ref['counters']
+    h = tr.hits()
+  assert np.array_equal(h['tag'], ref['hits']['tag']) and len(h) > 0.9 * n
+  assert np.abs(h['point'] - ref['hits']['point']).max() < 1e-7
