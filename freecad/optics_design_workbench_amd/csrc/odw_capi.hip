@@ -69,7 +69,7 @@ struct odw_ctx {
   int n_samplers = 0;
   uint64_t surface_seed = 0;
   // surface source (emitter) tables + the explicit-ray staging of its launches
-  DevBuf em_prim_f64, em_prim_i32, em_cond, em_face_i32, em_face_cdf, em_t_tab, em_t_guide, em_o, em_d;
+  DevBuf em_prim_f64, em_prim_i32, em_cond, em_face_i32, em_face_cdf, em_t_tab, em_t_guide, em_o, em_d, em_tri_nrm;
   DeviceEmitter h_emitter;
   bool emitter_active = false;   // the most recently uploaded source is a surface source
   uint64_t hit_capacity = 0, n_bins = 0;   // hit_capacity: rows the caller asked for
@@ -621,7 +621,7 @@ void odw_destroy(odw_ctx* ctx) {
                    &ctx->sort_tmp, &ctx->sorted_rows, &ctx->segs, &ctx->seg_count};
   for (DevBuf* b : all) release(*b);
   for (DevBuf* b : {&ctx->em_prim_f64, &ctx->em_prim_i32, &ctx->em_cond, &ctx->em_face_i32, &ctx->em_face_cdf,
-                    &ctx->em_t_tab, &ctx->em_t_guide, &ctx->em_o, &ctx->em_d, &ctx->tri_nrm, &ctx->phi_guide})
+                    &ctx->em_t_tab, &ctx->em_t_guide, &ctx->em_o, &ctx->em_d, &ctx->em_tri_nrm, &ctx->tri_nrm, &ctx->phi_guide})
     release(*b);
   for (auto& sb : ctx->surf_bufs) { release(sb.phi_tab); release(sb.t_tab); release(sb.t_guide); }
   release(ctx->d_samplers);
@@ -918,9 +918,11 @@ int odw_upload_surface_source(odw_ctx* ctx, const odw_surface_source_desc* s) {
   std::vector<double> pf((size_t)n * 16);
   std::vector<int32_t> pi((size_t)n * 4);
   for (int p = 0; p < n; ++p) {
-    if (s->prim_type[p] < ODW_PRIM_BOX || s->prim_type[p] > ODW_PRIM_TORUS)
-      return fail(ctx, ODW_ERR_UNSUPPORTED, "surface source: emission from analytic primitives only");
+    if (s->prim_type[p] < ODW_PRIM_BOX || s->prim_type[p] > ODW_PRIM_TRIANGLE)
+      return fail(ctx, ODW_ERR_UNSUPPORTED, "surface source: unknown primitive kind");
     const int off = s->prim_cond_off[p], cnt = s->prim_cond_off[p + 1] - off;
+    if (s->prim_type[p] == ODW_PRIM_TRIANGLE && cnt != 0)
+      return fail(ctx, ODW_ERR_INVALID, "surface source: facets cannot carry trimming conditions");
     if (off < 0 || cnt < 0 || off + cnt > s->n_conds) return fail(ctx, ODW_ERR_INVALID, "surface source: bad condition offsets");
     std::memcpy(&pf[16 * (size_t)p], s->prim_xform + 12 * (size_t)p, 12 * sizeof(double));
     std::memcpy(&pf[16 * (size_t)p + 12], s->prim_params + 4 * (size_t)p, 4 * sizeof(double));
@@ -931,10 +933,11 @@ int odw_upload_surface_source(odw_ctx* ctx, const odw_surface_source_desc* s) {
   }
   std::vector<int32_t> cond((size_t)std::max(1, s->n_conds), 0);
   for (int c = 0; c < s->n_conds; ++c) {
-    if (s->cond_prim[c] < 0 || s->cond_prim[c] >= n) return fail(ctx, ODW_ERR_INVALID, "surface source: condition primitive out of range");
+    if (s->cond_prim[c] < 0 || s->cond_prim[c] >= n || s->prim_type[s->cond_prim[c]] == ODW_PRIM_TRIANGLE)
+      return fail(ctx, ODW_ERR_INVALID, "surface source: condition primitive out of range");
     cond[c] = s->cond_prim[c] | (s->cond_inside[c] ? (int32_t)0x80000000 : 0);
   }
-  static const int n_faces_of[5] = {6, 1, 3, 3, 1};
+  static const int n_faces_of[6] = {6, 1, 3, 3, 1, 1};
   std::vector<int32_t> fi((size_t)s->n_faces * 2);
   std::vector<double> fc((size_t)s->n_faces + 1, 0.0);
   double total = 0;
@@ -972,8 +975,10 @@ int odw_upload_surface_source(odw_ctx* ctx, const odw_surface_source_desc* s) {
   if ((rc = upload(ctx, ctx->em_face_cdf, fc.data(), fc.size() * sizeof(double)))) return rc;
   if ((rc = upload(ctx, ctx->em_t_tab, ttab.data(), ttab.size() * sizeof(double)))) return rc;
   if ((rc = upload(ctx, ctx->em_t_guide, guide.data(), guide.size() * sizeof(int32_t)))) return rc;
+  if (s->tri_normals && (rc = upload(ctx, ctx->em_tri_nrm, s->tri_normals, (size_t)n * 9 * sizeof(double)))) return rc;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   DeviceEmitter& e = ctx->h_emitter;
+  e.tri_nrm = s->tri_normals ? (const double*)ctx->em_tri_nrm.p : nullptr;
   e.prim_f64 = (const double*)ctx->em_prim_f64.p;
   e.prim_i32 = (const int32_t*)ctx->em_prim_i32.p;
   e.cond_i32 = (const int32_t*)ctx->em_cond.p;

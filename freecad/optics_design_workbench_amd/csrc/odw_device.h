@@ -88,6 +88,7 @@ struct DeviceEmitter {
   const double* face_cdf;       // [n_faces+1] cumulative untrimmed area / total
   const double* t_tab;          // [n_t_knots*2] (cdf, edge)
   const int32_t* t_guide;       // [n_guide+1]
+  const double* tri_nrm;        // [n_prims*9] vertex normals of TRIANGLE primitives, or null
   int32_t n_faces, n_t_knots, n_guide;
   double dist_tol, wavelength, power;
 };

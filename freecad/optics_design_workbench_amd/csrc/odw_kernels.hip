@@ -1277,11 +1277,33 @@ __global__ __launch_bounds__(256) void odw_emit_kernel(const DeviceEmitter E, ui
       double u_face, u_acc, ua, ub;
       philox_pair(ray, seed, attempt, 3u, u_face, u_acc);
       philox_pair(ray, seed, attempt, 4u, ua, ub);
-      int f = 0;
-      while (f + 1 < E.n_faces && u_face >= E.face_cdf[f + 1]) ++f;
+      int f = 0, hi = E.n_faces - 1;          // largest f with cdf[f] <= u_face
+      while (f < hi) {
+        const int mid = (f + hi + 1) >> 1;
+        if (u_face >= E.face_cdf[mid]) f = mid; else hi = mid - 1;
+      }
       const int prim = E.face_i32[2 * f], face = E.face_i32[2 * f + 1];
       const double* pf = E.prim_f64 + (size_t)prim * 16;
       const int32_t* pi = E.prim_i32 + 4 * prim;
+      if (pi[0] == ODW_PRIM_TRIANGLE) {       // a facet of a tessellated face: global coordinates, no conditions
+#pragma clang fp contract(off)
+        const d3 v0 = mk(pf[0], pf[1], pf[2]);
+        const d3 e1 = mk(pf[3], pf[4], pf[5]) - v0, e2 = mk(pf[6], pf[7], pf[8]) - v0;
+        double a = ua, b = ub;
+        if (a + b > 1.0) { a = 1.0 - a; b = 1.0 - b; }
+        gp = v0 + (e1 * a + e2 * b);
+        const d3 fn = cross(e1, e2);
+        gn = fn * (1.0 / sqrt(dot(fn, fn)));
+        if (E.tri_nrm) {
+          const double* vn = E.tri_nrm + (size_t)prim * 9;
+          const d3 mix = mk(vn[0], vn[1], vn[2]) * (1.0 - a - b) + (mk(vn[3], vn[4], vn[5]) * a + mk(vn[6], vn[7], vn[8]) * b);
+          gn = mix * (1.0 / sqrt(dot(mix, mix)));
+        }
+        if (pi[1] & ODW_FLAG_FLIP_NORMAL) gn = gn * -1.0;
+        gt = e1 - gn * dot(e1, gn);
+        gt = gt * (1.0 / sqrt(dot(gt, gt)));
+        break;
+      }
       d3 p, nl, tl;
       const double accept = face_point(pi[0], pf + 12, face, ua, ub, p, nl, tl);
       if (u_acc >= accept) continue;

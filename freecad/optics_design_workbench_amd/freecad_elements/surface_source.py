@@ -52,6 +52,7 @@ class BakedSurfaceSource:
   label: str = ''
   rays_per_iteration_scale: float = 1.0
   prim_to_world: list = None
+  tri_normals: np.ndarray = None   # (n,9) vertex normals of TRIANGLE rows (facets of tessellated faces)
 
 
 def faceArea(kind, params, face):
@@ -93,13 +94,38 @@ def distTol(doc):
   return max(tol, 1e-9)
 
 
+def _meshFacets(obj, part, tree, container, subs):
+  """facets of the selected faces of a tessellated shape (BRep import), in global coordinates:
+  -> (corners (k, 9), vertex normals (k, 9) or None, areas (k,))"""
+  v, tri, vn = geometry.meshWorld(geometry.Node('mesh', container * tree.placement, tree.mesh))
+  if subs:
+    table = tree.mesh[3] if len(tree.mesh) > 3 else None
+    if table is None:
+      raise geometry.UnsupportedGeometry(f'{obj.Name}: {part.Name} is a plain mesh without faces; select the whole body')
+    keep = []
+    for name in subs:
+      if not name.startswith('Face') or not 1 <= int(name[4:]) <= len(table):
+        raise geometry.UnsupportedGeometry(f'{obj.Name}: {part.Name} has no sub-element {name!r} ({len(table)} faces)')
+      f = table[int(name[4:]) - 1]
+      keep.append(np.arange(f.first, f.first + f.count))
+    tri = tri[np.concatenate(keep)]
+  a, b, c = v[tri[:, 0]], v[tri[:, 1]], v[tri[:, 2]]
+  area = 0.5 * np.linalg.norm(np.cross(b - a, c - a), axis=1)
+  corners = np.concatenate([a, b, c], axis=1)
+  normals = None if vn is None else np.concatenate([vn[tri[:, 0]], vn[tri[:, 1]], vn[tri[:, 2]]], axis=1)
+  return corners, normals, area
+
+
 def bakeSurfaceSource(doc, obj):
-  prims, faces = [], []
+  prims, faces, facets = [], [], []
   for part, subs in obj._props.get('ActiveSurfaces') or []:
     own = part.Placement if part.hasProperty('Placement') else None
     for gp in _bake.globalPlacements(doc, part):
       container = gp * own.inverse() if own is not None else gp     # solids_of() applies part.Placement itself
       for tree in geometry.solids_of(part):
+        if tree.op == 'mesh':
+          facets.append(_meshFacets(obj, part, tree, container, subs))
+          continue
         flat = geometry.flatten(tree, container)
         base = len(prims)
         for k, fp in enumerate(flat):
@@ -117,7 +143,7 @@ def bakeSurfaceSource(doc, obj):
             for f in range(geometry.N_FACES[fp.kind]):
               if (fp.facemask >> f) & 1 and faceArea(fp.kind, fp.params, f) > 0:
                 faces.append((fp, f))
-  if not faces:
+  if not faces and not facets:
     raise ValueError(f'surface source {obj.Name} has no ActiveSurfaces selected for emission')
   cond_off, cond_prim, cond_inside = [0], [], []
   for fp in prims:
@@ -131,17 +157,35 @@ def bakeSurfaceSource(doc, obj):
   t_edges, t_cdf = srv.tables()
   obj._props['RandomNumberGeneratorMode'] = srv.mode()
   n = len(prims)
+  prim_type = np.array([p.kind for p in prims], dtype=np.int32)
+  prim_flags = np.array([1 if p.flip else 0 for p in prims], dtype=np.int32)
+  prim_xform = np.array([p.to_world.inverse().rows12() for p in prims], dtype=np.float64).reshape(n, 12)
+  prim_params = np.array([p.params for p in prims], dtype=np.float64).reshape(n, 4)
+  face_prim = np.array([fp.index for fp, _ in faces], dtype=np.int32)
+  face_id = np.array([f for _, f in faces], dtype=np.int32)
+  face_area = np.array([faceArea(fp.kind, fp.params, f) for fp, f in faces], dtype=np.float64)
+  tri_normals = None
+  if facets:
+    # one TRIANGLE row + one face per facet, after the analytic primitives (whose condition indices stay valid)
+    corners = np.concatenate([c for c, _, _ in facets])
+    k = len(corners)
+    smooth = all(nrm is not None for _, nrm, _ in facets)
+    if smooth:
+      tri_normals = np.concatenate([np.zeros((n, 9))] + [nrm for _, nrm, _ in facets])
+    prim_type = np.concatenate([prim_type, np.full(k, geometry.TRIANGLE, dtype=np.int32)])
+    prim_flags = np.concatenate([prim_flags, np.zeros(k, dtype=np.int32)])
+    prim_xform = np.concatenate([prim_xform, np.hstack([corners, np.zeros((k, 3))])])
+    prim_params = np.concatenate([prim_params, np.zeros((k, 4))])
+    cond_off = cond_off + [cond_off[-1]] * k
+    face_prim = np.concatenate([face_prim, np.arange(n, n + k, dtype=np.int32)])
+    face_id = np.concatenate([face_id, np.zeros(k, dtype=np.int32)])
+    face_area = np.concatenate([face_area, np.concatenate([a for _, _, a in facets])])
   return BakedSurfaceSource(
       wavelength=float(obj._props.get('Wavelength', 500)), power=1.0, dist_tol=distTol(doc),
-      prim_type=np.array([p.kind for p in prims], dtype=np.int32),
-      prim_flags=np.array([1 if p.flip else 0 for p in prims], dtype=np.int32),
-      prim_xform=np.array([p.to_world.inverse().rows12() for p in prims], dtype=np.float64).reshape(n, 12),
-      prim_params=np.array([p.params for p in prims], dtype=np.float64).reshape(n, 4),
+      prim_type=prim_type, prim_flags=prim_flags, prim_xform=prim_xform, prim_params=prim_params,
       prim_cond_off=np.array(cond_off, dtype=np.int32), cond_prim=np.array(cond_prim, dtype=np.int32),
       cond_inside=np.array(cond_inside, dtype=np.int32),
-      face_prim=np.array([fp.index for fp, _ in faces], dtype=np.int32),
-      face_id=np.array([f for _, f in faces], dtype=np.int32),
-      face_area=np.array([faceArea(fp.kind, fp.params, f) for fp, f in faces], dtype=np.float64),
+      face_prim=face_prim, face_id=face_id, face_area=face_area,
       t_edges=t_edges, t_cdf=t_cdf, name=obj.Name, label=obj._props.get('Label', obj.Name),
       rays_per_iteration_scale=float(obj._props.get('RaysPerIterationScale', 1)),
-      prim_to_world=[p.to_world for p in prims])
+      prim_to_world=[p.to_world for p in prims], tri_normals=tri_normals)

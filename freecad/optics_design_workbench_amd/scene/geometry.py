@@ -164,7 +164,7 @@ def _brep_node(obj):
       raise UnsupportedGeometry(f'{obj.Name} ({obj.TypeId}): BRep payload {payload.name}: {e}') from e
     _BREP_CACHE[key] = m
   m = _BREP_CACHE[key]
-  return Node('mesh', mesh=(m.vertices, m.triangles, m.normals), source=obj.Name)
+  return Node('mesh', mesh=(m.vertices, m.triangles, m.normals, m.faces), source=obj.Name)
 
 
 # ---------------------------------------------------------------------------
@@ -318,7 +318,7 @@ def _prune_faces(prims, slack=1e-3):
 # ---------------------------------------------------------------------------
 def meshWorld(node):
   """world-space arrays of a 'mesh' node: vertices (n,3), triangles, normals"""
-  v, tri, vn = node.mesh
+  v, tri, vn = node.mesh[:3]     # (BRep shapes carry their face table as a fourth entry)
   R, t = node.placement.m[:3, :3], node.placement.m[:3, 3]
   return v @ R.T + t, tri, (None if vn is None else vn @ R.T)
 

@@ -189,7 +189,14 @@ typedef struct odw_surface_sampler_desc {
  * is rejected together with its face choice, so faces weigh in by their
  * TRIMMED area.  Uniforms: Philox4x32-10, key = seed, counter =
  * (ray_lo, ray_hi, attempt, 3) -> face, acceptance; (.., attempt, 4) -> the
- * two face coordinates; (ray_lo, ray_hi, 0, 5) -> theta, phi.               */
+ * two face coordinates; (ray_lo, ray_hi, 0, 5) -> theta, phi.
+ * Faces of tessellated shapes (BRep imports) emit facet by facet: an
+ * ODW_PRIM_TRIANGLE primitive (prim_xform = v0, v1, v2 in global coordinates
+ * as in odw_scene_desc, no conditions) with one face of the facet's area; the
+ * point is v0 + a (v1-v0) + b (v2-v0) with (a, b) = the two face coordinates
+ * folded into a + b <= 1, the normal the facet's or, with tri_normals, the
+ * normalised barycentric mix of the three vertex normals, the tangent the
+ * part of v1-v0 perpendicular to it.                                        */
 typedef struct odw_surface_source_desc {
   double wavelength;            /* nm                                         */
   double power;                 /* initial ray power (1)                      */
@@ -210,6 +217,8 @@ typedef struct odw_surface_source_desc {
   int32_t n_t_knots;
   const double* t_edges;        /* [n_t_knots] theta                          */
   const double* t_cdf;          /* [n_t_knots] / last entry                   */
+  const double* tri_normals;    /* [n_prims*9] unit vertex normals of TRIANGLE
+                                 * primitives (other rows ignored), or NULL   */
 } odw_surface_source_desc;
 
 /* Ray.traceRay keyword arguments + settings (ray.py:36-73, 283-288).        */

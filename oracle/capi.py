@@ -60,7 +60,7 @@ class SurfaceSourceDesc(C.Structure):
               ('n_prims', C.c_int32), ('prim_type', _pi), ('prim_flags', _pi), ('prim_xform', _pd),
               ('prim_params', _pd), ('prim_cond_off', _pi), ('n_conds', C.c_int32), ('cond_prim', _pi),
               ('cond_inside', _pi), ('n_faces', C.c_int32), ('face_prim', _pi), ('face_id', _pi),
-              ('face_area', _pd), ('n_t_knots', C.c_int32), ('t_edges', _pd), ('t_cdf', _pd)]
+              ('face_area', _pd), ('n_t_knots', C.c_int32), ('t_edges', _pd), ('t_cdf', _pd), ('tri_normals', _pd)]
 
 
 class SurfaceSamplerDesc(C.Structure):
@@ -356,6 +356,10 @@ def surface_source_desc(src):
               face_prim=_arr(src.face_prim, np.int32), face_id=_arr(src.face_id, np.int32),
               face_area=_arr(src.face_area, np.float64), t_edges=_arr(src.t_edges, np.float64),
               t_cdf=_arr(src.t_cdf, np.float64))
+  if getattr(src, 'tri_normals', None) is not None:
+    keep['tri_normals'] = _arr(src.tri_normals, np.float64).reshape(-1, 9)
+    if len(keep['tri_normals']) != len(keep['prim_type']):
+      raise ValueError('tri_normals needs one row of 9 values per primitive')
   d = SurfaceSourceDesc()
   d.wavelength, d.power, d.dist_tol = float(src.wavelength), float(src.power), float(src.dist_tol)
   d.n_prims, d.n_conds, d.n_faces = len(keep['prim_type']), len(src.cond_prim), len(keep['face_prim'])

@@ -1100,10 +1100,31 @@ int odw_oracle_surface_rays(const odw_surface_source_desc* s, uint64_t first, ui
       double u_face, u_acc, ua, ub;
       philox_pair(ray, seed, attempt, 3u, &u_face, &u_acc);
       philox_pair(ray, seed, attempt, 4u, &ua, &ub);
-      int f = 0;
-      while (f + 1 < s->n_faces && u_face >= cdf[f + 1]) ++f;
+      int f = 0, hi = s->n_faces - 1;         /* largest f with cdf[f] <= u_face */
+      while (f < hi) {
+        int mid = (f + hi + 1) >> 1;
+        if (u_face >= cdf[mid]) f = mid; else hi = mid - 1;
+      }
       int prim = s->face_prim[f], face = s->face_id[f];
       const double* m = s->prim_xform + 12 * (size_t)prim;
+      if (s->prim_type[prim] == ODW_PRIM_TRIANGLE) {     /* a facet of a tessellated face */
+        v3 v0 = V(m[0], m[1], m[2]), e1 = sub(V(m[3], m[4], m[5]), v0), e2 = sub(V(m[6], m[7], m[8]), v0);
+        double a = ua, b = ub;
+        if (a + b > 1.0) { a = 1.0 - a; b = 1.0 - b; }
+        gp = add(v0, add(mul(e1, a), mul(e2, b)));
+        v3 fn = cross(e1, e2);
+        gn = mul(fn, 1.0 / len(fn));
+        if (s->tri_normals) {
+          const double* vn = s->tri_normals + 9 * (size_t)prim;
+          v3 mix = add(mul(V(vn[0], vn[1], vn[2]), 1.0 - a - b),
+                       add(mul(V(vn[3], vn[4], vn[5]), a), mul(V(vn[6], vn[7], vn[8]), b)));
+          gn = mul(mix, 1.0 / len(mix));
+        }
+        if (s->prim_flags[prim] & ODW_FLAG_FLIP_NORMAL) gn = mul(gn, -1.0);
+        gt = sub(e1, mul(gn, dot(e1, gn)));
+        gt = mul(gt, 1.0 / len(gt));
+        break;
+      }
       v3 p, nl, tl;
       double accept = face_point(s->prim_type[prim], s->prim_params + 4 * (size_t)prim, face, ua, ub, &p, &nl, &tl);
       if (u_acc >= accept) continue;

@@ -177,3 +177,89 @@ def test_reference_end_criteria_with_surface_source(native_lib, tmp_path):
       assert len(r.loadHits('*')) > 1e3
       r = f.runSimulation('singlepseudo')          # surface sources: pseudo = true (surface_source.py:521)
       assert len(r.loadHits('*')) > 5
+
+
+# ---------------------------------------------------------------------------
+# faces of tessellated shapes (BRep imports, meshes) emit facet by facet
+# ---------------------------------------------------------------------------
+def test_tessellated_faces_emit_like_the_exact_surface(oracle):
+  from scipy import stats
+  doc = Document()
+  ball = make.makeSphere(doc, 'S', 5, base=(3, -2, 7))
+  exact = surface_source.bakeSurfaceSource(doc, _source(doc, [(ball, [])], ThetaDomain='0, pi/3'))
+  mesh = make.makeTessellated(doc, ball, 64)
+  s = surface_source.bakeSurfaceSource(doc, _source(doc, [(mesh, [])], ThetaDomain='0, pi/3'))
+  assert (s.prim_type == geometry.TRIANGLE).all() and s.tri_normals.shape == (len(s.prim_type), 9)
+  assert abs(s.face_area.sum() - 4 * np.pi * 25) < 0.01 * 4 * np.pi * 25 and not len(s.cond_prim)
+  n = 40000
+  o, d = oracle.surface_rays(s, 0, n, 4)
+  eo, ed = oracle.surface_rays(exact, 0, n, 4)
+  r = o - np.array([3, -2, 7.0])
+  dist = np.linalg.norm(r, axis=1)
+  assert dist.max() <= 5 + 1e-9 and dist.min() > 5 * np.cos(np.pi / 32) - 1e-3          # on the facets
+  # uniform over the area (z of a uniform point on a sphere is uniform) and the same density of
+  # the polar angle against the (interpolated = radial) normal as the exact surface
+  assert stats.kstest((r[:, 2] / dist + 1) / 2, 'uniform').pvalue > 1e-3
+  cos_m = np.einsum('ij,ij->i', d, r / dist[:, None])
+  cos_e = np.einsum('ij,ij->i', ed, (eo - np.array([3, -2, 7.0])) / 5)
+  assert cos_m.min() > np.cos(np.pi / 3) - 2e-3
+  assert stats.ks_2samp(cos_m, cos_e).pvalue > 1e-3
+  # without vertex normals the facet normal is used
+  flat = make.makeTessellated(doc, ball, 16, smooth=False)
+  f = surface_source.bakeSurfaceSource(doc, _source(doc, [(flat, [])], ThetaDomain='0, 1e-9'))
+  assert f.tri_normals is None
+  o, d = oracle.surface_rays(f, 0, 2000, 4)
+  x = f.prim_xform[:, :9].reshape(-1, 3, 3)
+  fn = np.cross(x[:, 1] - x[:, 0], x[:, 2] - x[:, 0])
+  fn /= np.linalg.norm(fn, axis=1, keepdims=True)
+  assert np.abs(np.abs(d @ fn.T).max(axis=1) - 1).max() < 1e-9                          # along one facet's normal
+  with pytest.raises(geometry.UnsupportedGeometry, match='without faces'):
+    surface_source.bakeSurfaceSource(doc, _source(doc, [(mesh, ['Face1'])]))
+
+
+def test_faces_of_an_imported_shape_emit(oracle):
+  """test/80-surface-source-slow: faces 2 and 6 of an imported aspheric lens (the two halves of
+  its B-spline front surface) emit; `runSimulation('true')` runs to its end criterion"""
+  from oracle_tracer import OracleTracer
+  from freecad.optics_design_workbench_amd.simulation import runSimulation
+  doc = open_fcstd(os.path.join(SCENES, 'imported-stepfile-as-surface-source.FCStd'))
+  src = bake.lightSources(doc)[0]
+  s = surface_source.bakeSurfaceSource(doc, src)
+  assert (s.prim_type == geometry.TRIANGLE).all() and len(s.face_area) > 5000
+  half = len(s.face_area) // 2
+  assert abs(s.face_area[:half].sum() - s.face_area[half:].sum()) < 1e-6 * s.face_area.sum()    # mirror images
+  o, d = oracle.surface_rays(s, 0, 20000, 2)
+  # all points on the emitting facets (the front surface, wherever the link places the lens),
+  # both halves used alike, directions in a cos^2 lobe about the outward normals
+  x = s.prim_xform[:, :9].reshape(-1, 3, 3)
+  assert (o.min(axis=0) >= x.reshape(-1, 3).min(axis=0) - 1e-9).all()
+  assert (o.max(axis=0) <= x.reshape(-1, 3).max(axis=0) + 1e-9).all()
+  ca, cb = x[:half].reshape(-1, 3).mean(axis=0), x[half:].reshape(-1, 3).mean(axis=0)
+  nearer_a = np.linalg.norm(o - ca, axis=1) < np.linalg.norm(o - cb, axis=1)
+  assert abs(nearer_a.mean() - 0.5) < 0.02
+  fn = np.cross(x[:, 1] - x[:, 0], x[:, 2] - x[:, 0]).sum(axis=0)
+  assert (d @ (fn / np.linalg.norm(fn)) > 0).mean() > 0.9
+  doc.OpticalSimulationSettings.EndAfterRays = '500'
+  store = runSimulation(doc, 'true', tracer=OracleTracer())
+  assert 500 < store.totalTracedRays <= 600
+  with pytest.raises(geometry.UnsupportedGeometry, match='no sub-element'):
+    src.ActiveSurfaces = [(src.ActiveSurfaces[0][0], ['Face13'])]
+    surface_source.bakeSurfaceSource(doc, src)
+
+
+@pytest.mark.gpu
+def test_device_facet_emission_matches_oracle(tracer, oracle):
+  doc = open_fcstd(os.path.join(SCENES, 'imported-stepfile-as-surface-source.FCStd'))
+  s = surface_source.bakeSurfaceSource(doc, bake.lightSources(doc)[0])
+  tracer.setSource(s)
+  n = 200000
+  go, gd = tracer.generateRays(10, n, 5)
+  ro, rd = oracle.surface_rays(s, 10, n, 5)
+  assert np.abs(go - ro).max() < 1e-10 and np.abs(gd - rd).max() < 1e-10
+  box = Document()
+  flat = make.makeTessellated(box, make.makeSphere(box, 'S', 5), 16, smooth=False)
+  f = surface_source.bakeSurfaceSource(box, _source(box, [(flat, [])], ThetaDomain='0, pi/4'))
+  tracer.setSource(f)
+  go, gd = tracer.generateRays(0, 50000, 6)
+  ro, rd = oracle.surface_rays(f, 0, 50000, 6)
+  assert np.abs(go - ro).max() < 1e-10 and np.abs(gd - rd).max() < 1e-10
