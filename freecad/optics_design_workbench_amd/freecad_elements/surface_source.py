@@ -122,7 +122,9 @@ def bakeSurfaceSource(doc, obj):
     own = part.Placement if part.hasProperty('Placement') else None
     for gp in _bake.globalPlacements(doc, part):
       container = gp * own.inverse() if own is not None else gp     # solids_of() applies part.Placement itself
-      for tree in geometry.solids_of(part):
+      # (named faces of a BRep import are faces of its stored shape: facets, also where the solid
+      #  itself is traced as exact CSG)
+      for tree in geometry.solids_of(part, brepFacets=bool(subs)):
         if tree.op == 'mesh':
           facets.append(_meshFacets(obj, part, tree, container, subs))
           continue

@@ -172,6 +172,26 @@ class Revolved(Geometry):
       nrm = (np.cos(v) * e + np.sin(v) * self.n) * np.sign(self.r + self.extra * np.cos(v) + 1e-300)
     return nrm * hand
 
+  def invert(self, x, hint):
+    """parameters of points x on the surface; angles are taken into the period around `hint`
+    ((n, 2), e.g. the stored p-curve), which also stands in where u is undefined (poles, apex)"""
+    d = np.asarray(x, float) - self.p
+    z, ex, ey = d @ self.n, d @ self.dx, d @ self.dy
+    rho = np.hypot(ex, ey)
+    u = np.arctan2(ey, ex)
+    u = hint[:, 0] + (u - hint[:, 0] + np.pi) % (2 * np.pi) - np.pi
+    u = np.where(rho > 1e-9 * max(abs(self.r), 1.0), u, hint[:, 0])
+    if self.kind == 'cylinder':
+      v = z
+    elif self.kind == 'cone':
+      v = z / np.cos(self.extra)
+    elif self.kind == 'sphere':
+      v = np.arctan2(z, rho)
+    else:
+      v = np.arctan2(z, rho - self.r)
+      v = hint[:, 1] + (v - hint[:, 1] + np.pi) % (2 * np.pi) - np.pi
+    return np.stack([u, v], axis=1)
+
   def steps(self, tol):
     """parameter steps (du, dv) that keep the chord error below tol"""
     def ang(r):
@@ -221,11 +241,22 @@ class BSplineSurface(Geometry):
 
   def normal(self, u, v):
     u, v = np.asarray(u, float), np.asarray(v, float)
-    hu, hv = 1e-6 * (self.u1 - self.u0), 1e-6 * (self.v1 - self.v0)
-    du = self.eval(np.minimum(u + hu, self.u1), v) - self.eval(np.maximum(u - hu, self.u0), v)
-    dv = self.eval(u, np.minimum(v + hv, self.v1)) - self.eval(u, np.maximum(v - hv, self.v0))
-    n = np.cross(du, dv)
-    return n / np.maximum(np.linalg.norm(n, axis=1, keepdims=True), 1e-300)
+
+    def cross(u, v):
+      hu, hv = 1e-6 * (self.u1 - self.u0), 1e-6 * (self.v1 - self.v0)
+      du = self.eval(np.minimum(u + hu, self.u1), v) - self.eval(np.maximum(u - hu, self.u0), v)
+      dv = self.eval(u, np.minimum(v + hv, self.v1)) - self.eval(u, np.maximum(v - hv, self.v0))
+      return np.cross(du, dv)
+    n = cross(u, v)
+    length = np.linalg.norm(n, axis=1)
+    # where the parametrisation degenerates (the apex of a surface of revolution: a whole
+    # boundary line is one point) the normal is the limit from just inside the patch
+    bad = length < 1e-6 * max(length.max(), 1e-300)
+    if bad.any():
+      um, vm = 0.5 * (self.u0 + self.u1), 0.5 * (self.v0 + self.v1)
+      n[bad] = cross(u[bad] + 1e-4 * (um - u[bad]), v[bad] + 1e-4 * (vm - v[bad]))
+      length = np.linalg.norm(n, axis=1)
+    return n / np.maximum(length, 1e-300)[:, None]
 
 
 class TrimmedSurface(Geometry):

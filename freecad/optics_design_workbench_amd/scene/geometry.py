@@ -33,6 +33,8 @@ class Node:
   params: tuple = ()
   children: list = field(default_factory=list)
   source: str = ''              # document object name
+  facemask: int = -1            # op 'prim': faces that exist (-1: all); auxiliary primitives of
+                                # recognised BRep solids (scene/brep_csg.py) contribute one face
 
 
 def _close(a, b, tol=1e-9):
@@ -65,7 +67,7 @@ def _primitive_of(obj):
 def _moved(nodes, placement):
   out = []
   for n in nodes:
-    out.append(Node(n.op, placement * n.placement, n.mesh, n.kind, n.params, n.children, n.source))
+    out.append(Node(n.op, placement * n.placement, n.mesh, n.kind, n.params, n.children, n.source, n.facemask))
   return out
 
 
@@ -73,7 +75,7 @@ def _is_draft_array(obj):
   return obj.ProxyClass == 'Array' and (obj.ProxyModule or '').startswith('draftobjects')
 
 
-def solids_of(obj, with_own_placement=True, _depth=0):
+def solids_of(obj, with_own_placement=True, _depth=0, brepFacets=False):
   """-> list of CSG trees (one per shell) of `obj`, in the coordinates of
   obj's container.  `with_own_placement=False` drops obj.Placement (an
   App::Link with LinkTransform=false replaces it by its own)."""
@@ -97,7 +99,7 @@ def solids_of(obj, with_own_placement=True, _depth=0):
     return _moved([Node('mesh', mesh=(v, tri, vn), source=obj.Name)], own)
 
   def one(child):
-    s = solids_of(child, _depth=_depth + 1)
+    s = solids_of(child, _depth=_depth + 1, brepFacets=brepFacets)
     if len(s) != 1:
       raise UnsupportedGeometry(f'{obj.Name}: boolean operand {child.Name} is not a single solid')
     if s[0].op == 'mesh':
@@ -116,13 +118,13 @@ def solids_of(obj, with_own_placement=True, _depth=0):
     if target is None:
       return []
     link_transform = bool(obj._props.get('LinkTransform', False))
-    base = solids_of(target, with_own_placement=link_transform, _depth=_depth + 1)
+    base = solids_of(target, with_own_placement=link_transform, _depth=_depth + 1, brepFacets=brepFacets)
     count = int(obj._props.get('ElementCount', 0) or 0)
     plist = obj._props.get('PlacementList') or []
     if _is_draft_array(obj):
       count = int(obj._props.get('Count', len(plist)) or len(plist))
       if not bool((obj._props.get('Proxy') or {}).get('state', {}).get('use_link', True)):
-        base = solids_of(target, _depth=_depth + 1)
+        base = solids_of(target, _depth=_depth + 1, brepFacets=brepFacets)
     if count > 0:
       if len(plist) < count:
         raise UnsupportedGeometry(f'{obj.Name}: array without stored PlacementList')
@@ -136,11 +138,11 @@ def solids_of(obj, with_own_placement=True, _depth=0):
     key = 'ElementList' if t.startswith('App::LinkGroup') else ('Links' if t == 'Part::Compound' else 'Group')
     out = []
     for c in obj._props.get(key) or []:
-      out.extend(solids_of(c, _depth=_depth + 1))
+      out.extend(solids_of(c, _depth=_depth + 1, brepFacets=brepFacets))
     return _moved(out, own)
 
   if t in ('Part::Feature', 'Part::FeaturePython') or t.startswith('PartDesign') or t.startswith('Sketcher'):
-    return _moved([_brep_node(obj)], own)
+    return _moved([_brep_node(obj, facets=brepFacets)], own)
   return []
 
 
@@ -148,23 +150,43 @@ BREP_DEFLECTION = 1e-3      # mm between a facet and the exact surface (`Shape.t
 _BREP_CACHE = {}
 
 
-def _brep_node(obj):
-  """objects without a parametric recipe (STEP imports, PartDesign bodies): the facets of their
-  stored boundary representation, in the object's own coordinates (FreeCAD keeps the Placement
-  as the location of the stored shape: it is taken off here and applied by the caller)"""
-  from . import brep, brep_mesh
+BREP_EXACT = True           # solids bounded by quadrics / tori only: exact CSG instead of facets
+
+
+def _brep_node(obj, facets=False):
+  """objects without a parametric recipe (STEP imports, PartDesign bodies): their stored
+  boundary representation, in the object's own coordinates (FreeCAD keeps the Placement as the
+  location of the stored shape: it is taken off here and applied by the caller) -- as exact
+  CSG over the analytic primitives where the solid is an intersection of quadric half-spaces
+  (scene/brep_csg.py: catalogue lenses, prisms, plates), as facets otherwise or on request"""
+  from . import brep, brep_csg, brep_mesh
   payload = obj._props.get('Shape')
   if payload is None or not getattr(payload, 'data', None):
     raise UnsupportedGeometry(f'{obj.Name} ({obj.TypeId}): no parametric recipe and no stored BRep payload')
   key = (payload.name, len(payload.data), hash(payload.data), BREP_DEFLECTION)
   if key not in _BREP_CACHE:
     try:
-      m = brep_mesh.tessellate(brep.load(payload.data), deflection=BREP_DEFLECTION, keep_root_location=False)
+      parsed = brep.load(payload.data)
+      m = brep_mesh.tessellate(parsed, deflection=BREP_DEFLECTION, keep_root_location=False)
+      exact = brep_csg.recognise(parsed, m)
     except brep.BRepError as e:
       raise UnsupportedGeometry(f'{obj.Name} ({obj.TypeId}): BRep payload {payload.name}: {e}') from e
-    _BREP_CACHE[key] = m
-  m = _BREP_CACHE[key]
+    _BREP_CACHE[key] = (m, exact)
+  m, exact = _BREP_CACHE[key]
+  if exact is not None and BREP_EXACT and not facets:
+    return _named(_copy_tree(exact[0]), obj.Name)
   return Node('mesh', mesh=(m.vertices, m.triangles, m.normals, m.faces), source=obj.Name)
+
+
+def _copy_tree(n):
+  return Node(n.op, n.placement, n.mesh, n.kind, n.params, [_copy_tree(c) for c in n.children], n.source, n.facemask)
+
+
+def _named(n, name):
+  n.source = name
+  for c in n.children:
+    _named(c, name)
+  return n
 
 
 # ---------------------------------------------------------------------------
@@ -186,7 +208,7 @@ def _leaves(node, acc, out):
   pl = acc * node.placement
   if node.op == 'prim':
     fp = FlatPrim(node.kind, tuple(float(p) for p in node.params), pl, False, [],
-                  (1 << N_FACES[node.kind]) - 1, node.source)
+                  ((1 << N_FACES[node.kind]) - 1) & node.facemask, node.source)
     node._flat = fp
     out.append(fp)
   else:
@@ -297,6 +319,8 @@ def _prune_faces(prims, slack=1e-3):
   for fp in prims:
     mask = 0
     for f in range(N_FACES[fp.kind]):
+      if not (fp.facemask >> f) & 1:
+        continue
       flo, fhi = world_aabb(fp.to_world, *face_local_bounds(fp.kind, fp.params, f))
       keep = True
       for other, inside in fp.conds:

@@ -8,10 +8,15 @@ Pins, on the shape payloads of the reference's own test documents
   * the mesher: closed surfaces (every edge shared by exactly two facets),
     volumes of the shapes whose volume is known in closed form, vertices on
     the exact surface, outward unit normals, deflection control;
-  * the tracer: a PartDesign body made of planes gives the same hits as the
-    equivalent parametric box; the tessellated achromat of
-    edmund-optics-lens.FCStd images like the same lens built from exact
-    spheres and a cylinder;
+  * the recogniser (scene/brep_csg.py): solids that are intersections of quadric
+    half-spaces become exact CSG -- the achromat of edmund-optics-lens.FCStd
+    is found to be Common(sphere, sphere, cylinder) and Cut(Common(sphere,
+    cylinder), sphere), each within its bounding box, and traces like the same
+    lens built by hand; shapes that
+    are not (an L-shaped prism, the aspheric lens) keep their facets;
+  * the tracer on facets: a PartDesign body made of planes gives the same hits
+    as the equivalent parametric box; the tessellated achromat images like
+    the exact one;
   * (-m gpu) device = oracle on these scenes.
 """
 import os
@@ -22,7 +27,7 @@ import pytest
 
 from conftest import SCENES, project
 from freecad.optics_design_workbench_amd.freecad_elements import make
-from freecad.optics_design_workbench_amd.scene import Document, bake, brep, brep_mesh, open_fcstd
+from freecad.optics_design_workbench_amd.scene import Document, bake, brep, brep_csg, brep_mesh, geometry, open_fcstd
 from freecad.optics_design_workbench_amd.scene.geometry import UnsupportedGeometry
 from freecad.optics_design_workbench_amd.scene.placement import Placement
 from freecad.optics_design_workbench_amd.simulation.simulation_loop import bakeLightSource
@@ -133,6 +138,75 @@ def test_unsupported_payloads_fail_loudly():
     bake.bakeScene(doc, make.makePointSource(doc))
 
 
+# ---------------------------------------------------------------- exact CSG
+def _shape(tree):
+  if tree.op == 'prim':
+    return geometry.KIND_NAMES[tree.kind]
+  return tree.op + '(' + ', '.join(_shape(c) for c in tree.children) + ')'
+
+
+@pytest.mark.parametrize('scene,member,expected', [
+    ('nested-structure', 'Box.Shape.brp', 'common(box, box, box, box, box, box, box)'),
+    ('nested-structure', 'Body.Shape.brp', 'common(box, box, box, box, box, box, box, box, box)'),
+    ('nested-structure', 'Sphere.Shape.brp', 'sphere'),
+    ('nested-structure', 'Cylinder.Shape.brp', 'common(cylinder, box, box, box)'),
+    ('edmund-optics-lens', 'Part__Feature.Shape.brp', 'common(sphere, sphere, cylinder, box)'),
+    ('edmund-optics-lens', 'Part__Feature001.Shape.brp', 'cut(common(sphere, cylinder, box), sphere)'),
+    ('imported-stepfile-as-surface-source', 'Part__Feature.Shape.brp', None),       # 73 faces, holes, pockets
+    ('imported-stepfile-as-surface-source', 'Part__Feature001.Shape.brp', None),    # B-spline surfaces
+])
+def test_solids_of_quadric_half_spaces_are_recognised(scene, member, expected):
+  P = brep.load(payload(scene, member))
+  m = brep_mesh.tessellate(P, deflection=1e-3, keep_root_location=False)
+  r = brep_csg.recognise(P, m)
+  # (the last box of a Common is the shape's bounding box, an operand without faces: the
+  #  intersection of the half-spaces can have components elsewhere)
+  assert (None if r is None else _shape(r[0])) == expected
+  if r is None:
+    return
+  # the tree describes the same solid: the facet corners lie on its boundary, points pushed
+  # a little along the outward normals are outside, pushed inwards inside
+  flat = geometry.flatten(r[0])
+
+  def inside(x):
+    ok = np.ones(len(x), dtype=bool)
+    for fp in flat:
+      local = (x - fp.to_world.m[:3, 3]) @ fp.to_world.m[:3, :3]
+      lo, hi = geometry.local_bounds(fp.kind, fp.params)
+      if fp.kind == geometry.BOX:
+        i = ((local >= lo) & (local <= hi)).all(axis=1)
+      elif fp.kind == geometry.SPHERE:
+        i = np.linalg.norm(local, axis=1) <= fp.params[0]
+      else:
+        i = (np.hypot(local[:, 0], local[:, 1]) <= fp.params[0]) & (local[:, 2] >= 0) & (local[:, 2] <= fp.params[1])
+      ok &= (i != fp.flip)             # tools of a Cut count from outside
+    return ok
+  c = m.vertices[m.triangles].mean(axis=1)
+  n = m.normals[m.triangles].mean(axis=1)
+  n /= np.linalg.norm(n, axis=1, keepdims=True)
+  assert inside(c - 2e-2 * n).mean() > 0.995 and not inside(c + 2e-2 * n).any()
+
+
+def test_non_convex_prism_keeps_its_facets():
+  """an L-shaped prism is not the intersection of its faces' half-spaces"""
+  text = payload('nested-structure', 'Body.Shape.brp').decode()
+  P = brep.load(text)
+  m = brep_mesh.tessellate(P, keep_root_location=False)
+  assert brep_csg.recognise(P, m) is not None
+  # move one corner of the hexagon inwards: vertices and the lines through them, both ends
+  P2 = brep.load(text)
+  moved = 0
+  for ts in P2.tshapes.values():
+    if ts.kind == 'Ve' and abs(ts.point[0] - 2.0) < 1e-9 and abs(ts.point[1]) < 1e-9:
+      ts.point = ts.point * np.array([0.1, 1, 1])
+      moved += 1
+  assert moved == 2
+  # the two side faces at that corner now are not planar quadrilaterals of their stored planes:
+  # the recogniser sees facet corners off the surface and declines
+  m2 = brep_mesh.tessellate(P2, keep_root_location=False)
+  assert brep_csg.recognise(P2, m2) is None
+
+
 # ---------------------------------------------------------------- tracing
 def _trace(oracle, doc, n, seed=7, first=0):
   src = bake.lightSources(doc)[0]
@@ -140,12 +214,27 @@ def _trace(oracle, doc, n, seed=7, first=0):
   return sc, oracle.trace(sc, bs, lim, first, n, seed, flags=1, nthreads=0)
 
 
-def test_planar_body_traces_like_the_parametric_box(oracle):
-  """mirror.FCStd: a PartDesign body (100 x 100 x 1 plate, BRep only) as a mirror.  Facets of
-  planar faces are exact, so the same plate as a Part::Box gives the same hits."""
+@pytest.fixture()
+def facets_only():
+  old = geometry.BREP_EXACT
+  geometry.BREP_EXACT = False
+  yield
+  geometry.BREP_EXACT = old
+
+
+@pytest.mark.parametrize('exact', [True, False])
+def test_planar_body_traces_like_the_parametric_box(oracle, exact):
+  """mirror.FCStd: a PartDesign body (100 x 100 x 1 plate, BRep only) as a mirror.  Recognised as
+  the Common of six half-spaces, or as 12 facets (exact for planar faces): either way the same
+  plate as a Part::Box gives the same hits."""
   doc = open_fcstd(os.path.join(SCENES, 'mirror.FCStd'))
-  sc, a = _trace(oracle, doc, 4000)
-  assert (sc.prim_type == 5).sum() == 12
+  old = geometry.BREP_EXACT
+  geometry.BREP_EXACT = exact
+  try:
+    sc, a = _trace(oracle, doc, 4000)
+  finally:
+    geometry.BREP_EXACT = old
+  assert (sc.prim_type == 5).sum() == (0 if exact else 12)
   body = doc.getObject('Body')
   group = [o for o in doc.Objects if body in (o._props.get('ElementList') or [])][0]
   box = make.makeBox(doc, 'Plate', 100, 100, 1, placement=body.Placement)
@@ -179,7 +268,20 @@ def _achromat_documents():
   return doc, ref
 
 
-def test_tessellated_achromat_images_like_the_exact_lens(oracle):
+def test_recognised_achromat_is_the_exact_lens(oracle):
+  """the STEP achromat, recognised, against the same lens built by hand: same primitives up to
+  the auxiliary cylinders' lengths, so the same hits to rounding"""
+  doc, ref = _achromat_documents()
+  n = 4000
+  sc, a = _trace(oracle, doc, n)
+  sc2, b = _trace(oracle, ref, n)
+  assert (sc.prim_type == 5).sum() == 0 and len(sc.prim_type) == len(sc2.prim_type) + 2 == 9
+  assert a['counters'] == b['counters'] and np.array_equal(a['hits']['tag'], b['hits']['tag'])
+  assert np.abs(a['hits']['point'] - b['hits']['point']).max() < 1e-7
+  assert np.abs(a['hits']['direction'] - b['hits']['direction']).max() < 1e-9
+
+
+def test_tessellated_achromat_images_like_the_exact_lens(oracle, facets_only):
   doc, ref = _achromat_documents()
   n = 4000
   sc, a = _trace(oracle, doc, n)
@@ -196,7 +298,6 @@ def test_tessellated_achromat_images_like_the_exact_lens(oracle):
   d = b['hits']['direction'][ib]
   assert np.abs(d[:, :2]).max() < 2e-3
   # a coarser mesh is visibly worse: the comparison measures the tessellation
-  from freecad.optics_design_workbench_amd.scene import geometry
   old = geometry.BREP_DEFLECTION
   try:
     geometry.BREP_DEFLECTION = 5e-2
@@ -210,7 +311,7 @@ def test_tessellated_achromat_images_like_the_exact_lens(oracle):
 
 # ---------------------------------------------------------------- device
 @pytest.mark.gpu
-def test_device_equals_oracle_on_brep_scenes(native_lib, oracle):
+def test_device_equals_oracle_on_brep_scenes(native_lib, oracle, facets_only):
   from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
   doc, _ = _achromat_documents()
   plate = open_fcstd(os.path.join(SCENES, 'mirror.FCStd'))

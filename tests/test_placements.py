@@ -64,9 +64,14 @@ def test_nested_body_is_baked_from_its_brep_payload():
   """nested-structure.FCStd contains a PartDesign::Body (a padded hexagon: BRep only).  Its facets
   stand where the chain of placements puts the stored shape: every global placement of the mirror
   group o Part001 o Body.Placement o (shape in the body's own coordinates)"""
-  from freecad.optics_design_workbench_amd.scene import bake, open_fcstd
+  from freecad.optics_design_workbench_amd.scene import bake, geometry, open_fcstd
   doc = open_fcstd(os.path.join(SCENES, 'nested-structure.FCStd'))
-  sc = bake.bakeScene(doc, bake.lightSources(doc)[0])
+  old = geometry.BREP_EXACT
+  geometry.BREP_EXACT = False          # as facets: their corners are the prism's (the exact form is eight half-spaces)
+  try:
+    sc = bake.bakeScene(doc, bake.lightSources(doc)[0])
+  finally:
+    geometry.BREP_EXACT = old
   g = list(sc.group_names).index('OpticalMirrorGroup001')
   tri = np.asarray(sc.prim_xform)[(sc.prim_group == g) & (sc.prim_type == 5)][:, :9].reshape(-1, 3)
   placements = bake.globalPlacements(doc, doc.getObject('OpticalMirrorGroup001'))
