@@ -47,6 +47,10 @@ class DocumentObject:
   def __setattr__(self, key, value):
     self._props[key] = value
     self._doc._touch()
+    # a shape-defining property of an object with a stored shape changed: stored shapes of the
+    # project may be out of date (placements are applied at bake time and do not count)
+    if key not in ('Placement', 'Label', 'Visibility') and self._props.get('Shape') is not None:
+      self._doc._shape_revision = getattr(self._doc, '_shape_revision', 0) + 1
 
   def hasProperty(self, key):
     return key in self._props
@@ -320,6 +324,11 @@ class Document:
   def revision(self):
     """changes when any document of the project changes"""
     return sum(d._revision for d in self.allDocuments())
+
+  @property
+  def shapesAsSaved(self):
+    """no shape-defining property was written since the project was loaded"""
+    return not any(getattr(d, '_shape_revision', 0) for d in self.allDocuments())
 
   def getObject(self, name):
     return self._by_name.get(name)

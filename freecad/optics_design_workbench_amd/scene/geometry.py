@@ -78,7 +78,22 @@ def _is_draft_array(obj):
 def solids_of(obj, with_own_placement=True, _depth=0, brepFacets=False):
   """-> list of CSG trees (one per shell) of `obj`, in the coordinates of
   obj's container.  `with_own_placement=False` drops obj.Placement (an
-  App::Link with LinkTransform=false replaces it by its own)."""
+  App::Link with LinkTransform=false replaces it by its own).
+  Features the parametric recipe cannot express (partial revolutions, booleans of imported
+  shapes, nested disjunctions) fall back to the shape FreeCAD computed and stored with the
+  object, as long as the project is as it was saved (a property written since then may have
+  changed the shape; placements are applied here and do not count)."""
+  try:
+    return _solids_by_recipe(obj, with_own_placement, _depth, brepFacets)
+  except UnsupportedGeometry as e:
+    payload = obj._props.get('Shape')
+    if getattr(payload, 'data', None) and obj._doc.shapesAsSaved:
+      own = obj.Placement if obj.hasProperty('Placement') and with_own_placement else Placement.identity()
+      return _moved([_brep_node(obj, facets=brepFacets)], own)
+    raise e
+
+
+def _solids_by_recipe(obj, with_own_placement=True, _depth=0, brepFacets=False):
   if _depth > 50:
     raise UnsupportedGeometry(f'{obj.Name}: link recursion')
   own = obj.Placement if obj.hasProperty('Placement') and with_own_placement else Placement.identity()

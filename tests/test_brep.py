@@ -339,3 +339,20 @@ def test_device_equals_oracle_on_brep_scenes(native_lib, oracle, facets_only):
       dd = np.abs(h['direction'] - ref['hits']['direction']).max(axis=1)
       assert (dp < 1e-9).mean() > 0.999 and (dd < 1e-9).mean() > 0.999
       assert dp.max() < 1e-3 and dd.max() < 1e-4
+
+
+def test_stored_shape_stands_in_where_the_recipe_ends(oracle):
+  """a feature the parametric rebuild cannot express falls back to the shape FreeCAD stored with
+  the object -- until a shape-defining property is written (the stored shape may then be stale)"""
+  doc = open_fcstd(os.path.join(SCENES, 'nested-structure.FCStd'))
+  sphere = doc.getObject('Sphere')
+  assert geometry.solids_of(sphere)[0].op == 'prim'
+  sphere._props['Angle3'] = 180.0                 # as if the file had been saved with a half sphere
+  node, = geometry.solids_of(sphere)              # the stored shape (here still the full sphere), recognised
+  assert node.op == 'prim' and node.kind == geometry.SPHERE and node.source == 'Sphere'
+  assert np.allclose((node.placement).Base, sphere.Placement.Base)
+  sphere.Placement = sphere.Placement             # placements do not invalidate stored shapes
+  assert geometry.solids_of(sphere)[0].kind == geometry.SPHERE
+  sphere.Radius = 4.0                             # ... shape-defining properties do
+  with pytest.raises(UnsupportedGeometry, match='partial spheres'):
+    geometry.solids_of(sphere)
