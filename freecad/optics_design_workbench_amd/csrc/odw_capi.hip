@@ -49,6 +49,7 @@ struct odw_ctx {
   // host copies needed for lazy (re)builds
   std::vector<double> h_prim_f64;
   std::vector<int32_t> h_prim_i32;
+  std::vector<int32_t> h_cond;            // prim | inside << 31
   bool have_scene = false, have_source = false, have_limits = false;
   bool bvh_dirty = true;
 
@@ -376,8 +377,28 @@ int build_bvh(odw_ctx* ctx) {
   const double slack = 2.0 * (ctx->have_limits ? ctx->P.lim.dist_tol : 1e-2);
   std::vector<Box> boxes(n);
   std::vector<double> flat((size_t)std::max(1, n) * 8, 0.0);   // 64-byte headers
-  for (int p = 0; p < n; ++p) {
+  for (int p = 0; p < n; ++p)
     boxes[p] = world_box(ctx->h_prim_f64.data() + 16 * (size_t)p, ctx->h_prim_i32[4 * p], slack);
+  // A face that exists only inside other primitives (operands of a Common, the base of a Cut for
+  // its tool) lies in their boxes too: the box of a lens cap is the lens, not the sphere.
+  // Primitives without faces (pure operands) and faces that cannot exist get a box no ray meets.
+  std::vector<Box> full = boxes;
+  std::vector<char> dead(n, 0);
+  for (int p = 0; p < n; ++p) {
+    const int cw = ctx->h_prim_i32[4 * p + 3], off = cw & 0xffffff, cnt = (cw >> 24) & 0xff;
+    for (int c = off; c < off + cnt && c < (int)ctx->h_cond.size(); ++c) {
+      if (ctx->h_cond[c] >= 0) continue;                       // must be OUTSIDE that one: no bound
+      const Box& o = full[ctx->h_cond[c] & 0x7fffffff];
+      for (int a = 0; a < 3; ++a) {
+        boxes[p].lo[a] = std::max(boxes[p].lo[a], o.lo[a]);
+        boxes[p].hi[a] = std::min(boxes[p].hi[a], o.hi[a]);
+      }
+    }
+    const int facemask = (ctx->h_prim_i32[4 * p + 2] >> ODW_FACEMASK_SHIFT) & 0xff;
+    dead[p] = facemask == 0 || boxes[p].lo[0] > boxes[p].hi[0] || boxes[p].lo[1] > boxes[p].hi[1] ||
+              boxes[p].lo[2] > boxes[p].hi[2];
+    if (dead[p])
+      for (int a = 0; a < 3; ++a) boxes[p].lo[a] = boxes[p].hi[a] = 1e30;
     double* h = flat.data() + 8 * (size_t)p;
     for (int a = 0; a < 3; ++a) { h[a] = boxes[p].lo[a]; h[3 + a] = boxes[p].hi[a]; }
     std::memcpy(h + 6, &ctx->h_prim_i32[4 * (size_t)p], 4 * sizeof(int32_t));
@@ -401,8 +422,11 @@ int build_bvh(odw_ctx* ctx) {
       boxes[p].hi[a] += s;
     }
   BvhBuilder b(boxes);
-  std::vector<int> ids(n);
-  for (int i = 0; i < n; ++i) ids[i] = i;
+  std::vector<int> ids;
+  ids.reserve(n);
+  for (int i = 0; i < n; ++i)
+    if (!dead[i]) ids.push_back(i);
+  if (ids.empty() && n > 0) ids.push_back(0);   // (a far-away box: the tree needs one leaf)
   b.nodes.reserve((size_t)n);
   const BvhBuilder::Ref root = b.build(ids, 0);
   if (root.count > 0) {   // everything in one leaf: wrap it into a root node
@@ -692,6 +716,7 @@ int odw_upload_scene(odw_ctx* ctx, const odw_scene_desc* s) {
       return fail(ctx, ODW_ERR_UNSUPPORTED, "trimming against a triangle (no inside/outside of a facet)");
     cond[c] = s->cond_prim[c] | (s->cond_inside[c] ? (int32_t)0x80000000 : 0);
   }
+  ctx->h_cond = cond;
   std::vector<double> gf(ODW_MAX_GROUPS * 4, 0.0), gd(ODW_MAX_GROUPS * 3, 0.0);
   std::vector<int32_t> gi(ODW_MAX_GROUPS * 4, 0);
   for (int g = 0; g < s->n_groups; ++g) {
