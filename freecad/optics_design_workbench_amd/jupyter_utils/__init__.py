@@ -2,6 +2,7 @@
 (jupyter_utils/__init__.py:11-16): FreecadDocument, RawFolder, Hits, Histogram"""
 from .hits import Hits
 from .histogram import Histogram
+from .transforms import applyTransformation, applyTransformationWithoutTranslation
 
 
 def __getattr__(name):
@@ -10,7 +11,7 @@ def __getattr__(name):
   if name in ('FreecadDocument', 'FreecadObject', 'FreecadProperty'):
     from . import freecad_document
     return getattr(freecad_document, name)
-  if name in ('RawFolder', 'rawFolders', 'latestRawFolder'):
+  if name in ('RawFolder', 'RawFolderRange', 'rawFolders', 'rawFolderByIndex', 'latestRawFolder'):
     from ..simulation import results_store
     return getattr(results_store, name)
   raise AttributeError(name)

@@ -98,6 +98,12 @@ class FreecadProperty:
   def getStr(self):
     return str(self.get())
 
+  def getFloat(self):
+    return float(self.get())
+
+  def getInt(self):
+    return int(self.get())
+
   def __repr__(self):
     return f'<FreecadProperty {self._obj.Name}.{".".join((self._name,) + self._path)}, value: {self.getStr()}>'
 
@@ -179,6 +185,36 @@ class FreecadDocument:
       shutil.rmtree(self._tmp, ignore_errors=True)
     self._tmp = None
 
+  def path(self):
+    return self._path
+
+  def resultsPath(self):
+    return self._resultsPath
+
+  def isWorkInTempCopy(self):
+    return self._tmp is not None
+
+  def purgeTempFolder(self):
+    """remove the temporary working copy's results (freecad_document.py:546-552)"""
+    if self._tmp and os.path.isdir(self._resultsPath):
+      shutil.rmtree(self._resultsPath, ignore_errors=True)
+
+  def disableFastMode(self):
+    """the reference's fast mode skips document recomputes in its FreeCAD child process
+    (freecad_document.py:940-972); there is no such process here: nothing to switch"""
+
+  def open(self):
+    return self
+
+  def isRunning(self):
+    return True
+
+  def save(self):
+    raise NotImplementedError('writing FCStd files needs FreeCAD; property changes live in this session only')
+
+  def __repr__(self):
+    return f'<FreecadDocument {os.path.basename(self._path)}>'
+
   # -- objects -----------------------------------------------------------------
   def getObject(self, nameOrLabel):
     doc = self.__dict__['_doc']
@@ -227,3 +263,6 @@ class FreecadDocument:
 
   def latestRawFolder(self):
     return results_store.latestRawFolder(self._resultsPath)
+
+  def rawFolderByIndex(self, index=-1):
+    return results_store.rawFolderByIndex(index, self._resultsPath)

@@ -242,6 +242,38 @@ class RawFolder:
   def path(self):
     return os.path.relpath(self._path)
 
+  def tree(self, _path=None):
+    """nested dictionaries of the folder structure; files are summarised as
+    '<n hit files>' / '<n ray files>' / '<n unknown files>' entries (freecad_document.py:1437-1463)"""
+    path = _path or self._path
+    result, kinds = {}, []
+    for d in os.scandir(path):
+      if d.is_dir():
+        result[d.name] = self.tree(d.path)
+      elif d.name.endswith('-hits.pkl'):
+        kinds.append('hit')
+      elif d.name.endswith('-rays.pkl'):
+        kinds.append('ray')
+      elif not (d.name.startswith('uid-') or d.name.startswith('.')):
+        kinds.append('unknown')
+    for k in set(kinds):
+      result[f'<{kinds.count(k)} {k} files>'] = None
+    return result
+
+  def printTree(self, _node=None, _prefix='  '):
+    if _node is None:
+      print(f'{os.path.basename(self._path)}/')
+      _node = self.tree()
+    for k, v in sorted(_node.items()):
+      if v is None:
+        print(_prefix + k)
+      else:
+        print(_prefix + k + '/')
+        self.printTree(v, _prefix + '  ')
+
+  def reload(self):
+    pass                       # nothing is cached here
+
   def loadGlobalInfo(self):
     with open(os.path.join(self._path, 'global-info.pkl'), 'rb') as f:
       return pickle.load(f)
@@ -283,12 +315,77 @@ class RawFolder:
     return out
 
 
-def rawFolders(resultsPath):
-  raw = os.path.join(resultsPath, 'raw')
-  names = sorted(f for f in os.listdir(raw) if f.startswith('simulation-run-')) if os.path.isdir(raw) else []
-  return [RawFolder(os.path.join(raw, n)) for n in names]
+def _rawBase(basePath='.'):
+  """the `raw` folder a path belongs to (freecad_document.py:1341-1360): a single
+  `*.OpticsDesign` folder below basePath is entered, otherwise the parents are searched"""
+  basePath = os.path.abspath(basePath)
+  sims = [p for p in os.listdir(basePath) if p.endswith('.OpticsDesign') and os.path.isdir(os.path.join(basePath, p))] \
+      if os.path.isdir(basePath) else []
+  if len(sims) == 1 and not os.path.exists(os.path.join(basePath, 'raw')):
+    basePath = os.path.join(basePath, sims[0])
+  while not os.path.exists(os.path.join(basePath, 'raw')) and basePath != os.path.dirname(basePath):
+    basePath = os.path.dirname(basePath)
+  raw = os.path.join(basePath, 'raw')
+  if not os.path.exists(raw):
+    raise ValueError(f'failed to find "raw" folder in any parent directory of {basePath!r}')
+  folders = sorted(d for d in os.listdir(raw) if d.startswith('simulation-run-'))
+  return raw, folders, [int(d[len('simulation-run-'):]) for d in folders]
 
 
-def latestRawFolder(resultsPath):
-  f = rawFolders(resultsPath)
-  return f[-1] if f else None
+class RawFolderRange:
+  """several run folders at once (freecad_document.py:1506-1539): iterable, sliceable,
+  `loadHits` / `loadRays` merge the folders' results"""
+
+  def __init__(self, paths):
+    self._paths = [p._path if isinstance(p, RawFolder) else p for p in paths]
+
+  def __iter__(self):
+    return iter([RawFolder(p) for p in self._paths])
+
+  def __len__(self):
+    return len(self._paths)
+
+  def __bool__(self):
+    return bool(self._paths)
+
+  def __getitem__(self, i):
+    sel = self._paths[i]
+    return RawFolder(sel) if isinstance(sel, str) else RawFolderRange(sel)
+
+  def paths(self):
+    return [os.path.relpath(p) for p in self._paths]
+
+  def loadHits(self, pattern='*'):
+    result = {}
+    for r in self:
+      for k, v in r.loadHits(pattern).items():
+        updateResultEntry(result, k, v)
+    return Hits(result)
+
+  def loadRays(self, pattern='*'):
+    return [ray for r in self for ray in r.loadRays(pattern)]
+
+
+def rawFolders(basePath='.'):
+  """RawFolderRange of all run folders under basePath (a results folder, a project folder with one
+  `.OpticsDesign` folder, or anything below a `raw` folder)"""
+  try:
+    raw, folders, _ = _rawBase(basePath)
+  except ValueError:
+    return RawFolderRange([])
+  return RawFolderRange([os.path.join(raw, f) for f in folders])
+
+
+def rawFolderByIndex(index=-1, basePath='.'):
+  """index >= 0: the run folder of that number; negative: counted from the latest"""
+  raw, folders, indices = _rawBase(basePath)
+  if index >= 0:
+    if index not in indices:
+      raise ValueError(f'simulation-run folder with index {index} does not exist')
+    return RawFolder(os.path.join(raw, folders[indices.index(index)]))
+  return RawFolder(os.path.join(raw, folders[index]))
+
+
+def latestRawFolder(basePath='.'):
+  f = rawFolders(basePath)
+  return f[-1] if len(f) else None

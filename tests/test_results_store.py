@@ -229,3 +229,45 @@ def test_global_info_progress_and_status_files(tmp_path):
   assert os.path.exists(os.path.join(base, 'simulation-is-running'))
   store.setStatus('simulation-is-running', False)
   assert not os.path.exists(os.path.join(base, 'simulation-is-running'))
+
+
+def test_raw_folder_helpers(tmp_path, oracle):
+  """rawFolders / rawFolderByIndex / RawFolderRange / RawFolder.tree
+  (jupyter_utils/freecad_document.py:1341-1539) on runs of the oracle-backed loop"""
+  import shutil
+  from conftest import SCENES
+  from oracle_tracer import OracleTracer
+  from freecad.optics_design_workbench_amd import jupyter_utils
+  from freecad.optics_design_workbench_amd.scene import open_fcstd
+  from freecad.optics_design_workbench_amd.simulation import resultsFolderPath, runSimulation
+  path = str(tmp_path / 'GettingStarted.FCStd')
+  shutil.copy(os.path.join(SCENES, 'GettingStarted.FCStd'), path)
+  doc = open_fcstd(path)
+  doc.OpticalPointSource.RecordRays = True
+  stores = [runSimulation(doc, 'singletrue', resultsPath=resultsFolderPath(path), tracer=OracleTracer(), seed=s)
+            for s in (1, 2, 3)]
+  for base in (str(tmp_path), resultsFolderPath(path), os.path.join(resultsFolderPath(path), 'raw', 'simulation-run-000001')):
+    rng = jupyter_utils.rawFolders(base)
+    assert isinstance(rng, jupyter_utils.RawFolderRange) and len(rng) == 3
+  assert [os.path.basename(p) for p in rng.paths()] == [f'simulation-run-{i:06d}' for i in range(3)]
+  assert len(rng.loadHits('*')) == sum(len(s.hits()) for s in stores)
+  assert len(rng[1:].loadHits('*')) == sum(len(s.hits()) for s in stores[1:])
+  assert len(rng.loadRays()) == 300 and isinstance(rng[0], jupyter_utils.RawFolder)
+  assert jupyter_utils.rawFolderByIndex(1, base).path() == rng[1].path()
+  assert jupyter_utils.rawFolderByIndex(-1, base).path() == jupyter_utils.latestRawFolder(base).path() == rng[2].path()
+  with pytest.raises(ValueError):
+    jupyter_utils.rawFolderByIndex(7, base)
+  tree = rng[0].tree()
+  src = tree['source-OpticalPointSource']
+  assert src['<1 ray files>'] is None and any('<1 hit files>' in v for v in src.values() if isinstance(v, dict))
+  rng[0].printTree()
+  assert len(jupyter_utils.rawFolders(str(tmp_path / 'nowhere'))) == 0 if os.path.isdir(tmp_path / 'nowhere') else True
+  # transforms of global-info matrices
+  m = np.eye(4); m[:3, 3] = (1, 2, 3); m[:3, :3] = [[0, -1, 0], [1, 0, 0], [0, 0, 1]]
+  p = np.array([[1.0, 0, 0], [0, 2.0, 0]])
+  assert np.allclose(jupyter_utils.applyTransformation(p, m), [[1, 3, 3], [-1, 2, 3]])
+  assert np.allclose(jupyter_utils.applyTransformationWithoutTranslation(p, m), [[0, 1, 0], [-2, 0, 0]])
+  with jupyter_utils.FreecadDocument(path, workInTempCopy=True) as f:
+    f.disableFastMode()
+    assert f.isWorkInTempCopy() and f.path().endswith('GettingStarted.FCStd') and f.resultsPath().endswith('.OpticsDesign')
+    assert f.Sphere.Radius.getFloat() == float(f.Sphere.Radius) and f.OpticalSimulationSettings.RaysPerIteration.getInt() == 100
