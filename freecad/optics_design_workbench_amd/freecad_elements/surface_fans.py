@@ -1,0 +1,286 @@
+"""Fan mode of surface sources: rays along the face normals on a grid of roughly
+equidistant points (SurfaceSourceProxy._makeSurfaceGrid / _generateRays(mode='fans'),
+freecad_elements/surface_source.py:119-268, 467-519).
+
+The reference builds the grid from four facilities of an OpenCASCADE face:
+`ParameterRange`, `valueAt(u, v)`, "is this point on the face" (distance to the
+face below the distance tolerance) and `derivative1At(u, v)` -- a rectilinear
+(u, v) grid over the parameter range, refined in five passes that estimate how
+much of the range the face fills, the effective lengths of the two parameter
+lines and whether the area element is uniform along one parameter, and then thin
+out the rows where parameter lines crowd (poles of a sphere).  `FaceView` offers
+the same four facilities for the faces this build knows: faces of stored BRep
+shapes (scene/brep.py: surface + trimming wires) and the faces of the untrimmed
+parametric primitives in OpenCASCADE's parametrisations.  The grid logic is
+restated on top of it; rays are handed to the tracer as explicit initial
+conditions (`odw_trace_rays`).
+"""
+import warnings
+
+import numpy as np
+
+from ..scene import geometry
+from ..scene.placement import Placement
+
+
+class FaceView:
+  """a face in global coordinates: range = (u0, u1, v0, v1), area,
+  value(u, v) -> point, valid(u, v, point) -> bool, derivatives(u, v) -> (dS/du, dS/dv), normal(u, v)"""
+
+  def __init__(self, rng, area, value, valid, normal, derivatives):
+    self.range, self.area, self.value, self.valid, self.normal = rng, area, value, valid, normal
+    # exact derivatives (OpenCASCADE's derivative1At is analytic): the grid logic compares area
+    # elements against distTol^2, which difference quotients of ordinary accuracy do not survive
+    self.derivatives = derivatives
+
+
+# ------------------------------------------------------------------ faces of primitives
+def _primitive_faces(kind, params, to_world, names, dist_tol):
+  """FaceViews of an untrimmed primitive in OpenCASCADE's parametrisations; names: 'Face<k>' or all"""
+  from . import surface_source
+  R, t = to_world.m[:3, :3], to_world.m[:3, 3]
+  world = lambda p: R @ np.asarray(p, float) + t
+  wdir = lambda d: R @ np.asarray(d, float)
+  two_pi = 2 * np.pi
+  p = params
+  faces = {}
+  if kind == geometry.BOX:
+    for f in range(6):
+      a, b1, b2 = f >> 1, ((f >> 1) + 1) % 3, ((f >> 1) + 2) % 3
+      n = np.zeros(3)
+      n[a] = 1.0 if f & 1 else -1.0
+
+      def value(u, v, a=a, b1=b1, b2=b2, f=f):
+        c = np.zeros(3)
+        c[a], c[b1], c[b2] = (p[a] if f & 1 else 0.0), u, v
+        return world(c)
+      e1, e2 = np.zeros(3), np.zeros(3)
+      e1[b1] = e2[b2] = 1.0
+      faces[f] = FaceView((0.0, p[b1], 0.0, p[b2]), p[b1] * p[b2], value, lambda u, v, x: True,
+                          lambda u, v, n=n: wdir(n), lambda u, v, e1=e1, e2=e2: (wdir(e1), wdir(e2)))
+  elif kind == geometry.SPHERE:
+    r = p[0]
+    unit = lambda u, v: np.array([np.cos(v) * np.cos(u), np.cos(v) * np.sin(u), np.sin(v)])
+    faces[0] = FaceView((0.0, two_pi, -np.pi / 2, np.pi / 2), 4 * np.pi * r * r, lambda u, v: world(r * unit(u, v)),
+                        lambda u, v, x: True, lambda u, v: wdir(unit(u, v)),
+                        lambda u, v: (wdir([-r * np.cos(v) * np.sin(u), r * np.cos(v) * np.cos(u), 0.0]),
+                                      wdir([-r * np.sin(v) * np.cos(u), -r * np.sin(v) * np.sin(u), r * np.cos(v)])))
+  elif kind == geometry.TORUS:
+    r1, r2 = p[0], p[1]
+    faces[0] = FaceView(
+        (0.0, two_pi, 0.0, two_pi), 4 * np.pi**2 * r1 * r2,
+        lambda u, v: world([(r1 + r2 * np.cos(v)) * np.cos(u), (r1 + r2 * np.cos(v)) * np.sin(u), r2 * np.sin(v)]),
+        lambda u, v, x: True, lambda u, v: wdir([np.cos(v) * np.cos(u), np.cos(v) * np.sin(u), np.sin(v)]),
+        lambda u, v: (wdir([-(r1 + r2 * np.cos(v)) * np.sin(u), (r1 + r2 * np.cos(v)) * np.cos(u), 0.0]),
+                      wdir([-r2 * np.sin(v) * np.cos(u), -r2 * np.sin(v) * np.sin(u), r2 * np.cos(v)])))
+  elif kind in (geometry.CYLINDER, geometry.CONE):
+    r1, r2, h = (p[0], p[0], p[1]) if kind == geometry.CYLINDER else (p[0], p[1], p[2])
+    slant = np.hypot(h, r2 - r1)
+    k = (r2 - r1) / h
+
+    def lateral(u, v):
+      z = h * v / slant
+      r = r1 + k * z
+      return world([r * np.cos(u), r * np.sin(u), z])
+    inv = 1.0 / np.sqrt(1 + k * k)
+    faces[0] = FaceView((0.0, two_pi, 0.0, slant), np.pi * (r1 + r2) * slant, lateral, lambda u, v, x: True,
+                        lambda u, v: wdir([np.cos(u) * inv, np.sin(u) * inv, -k * inv]),
+                        lambda u, v: (wdir([-(r1 + k * h * v / slant) * np.sin(u), (r1 + k * h * v / slant) * np.cos(u), 0.0]),
+                                      wdir([k * h / slant * np.cos(u), k * h / slant * np.sin(u), h / slant])))
+    for f, rr, z, s in ((1, r1, 0.0, -1.0), (2, r2, h, 1.0)):
+      if rr > 0:
+        faces[f] = FaceView((-rr, rr, -rr, rr), np.pi * rr * rr, lambda u, v, z=z: world([u, v, z]),
+                            lambda u, v, x, rr=rr: np.hypot(u, v) <= rr + dist_tol,
+                            lambda u, v, s=s: wdir([0.0, 0.0, s]),
+                            lambda u, v: (wdir([1.0, 0.0, 0.0]), wdir([0.0, 1.0, 0.0])))
+  else:
+    raise geometry.UnsupportedGeometry(f'no fan grid for primitive kind {kind}')
+  if names:
+    return [faces[surface_source._faceIndex(kind, params, n)] for n in names]
+  # whole body: OpenCASCADE's face order (surface_source._faceIndex)
+  out, k = [], 1
+  while True:
+    try:
+      out.append(faces[surface_source._faceIndex(kind, params, f'Face{k}')])
+    except geometry.UnsupportedGeometry:
+      return out
+    k += 1
+
+
+# ------------------------------------------------------------------ faces of stored shapes
+def _brep_faces(payload, name, to_world, names, dist_tol):
+  from ..scene import brep, brep_mesh
+  from ..scene.brep_mesh import _inside, _xf
+  P = brep.load(payload.data)
+  base = np.linalg.inv(P.locations[P.root[2]])        # the stored root location is the object's Placement
+  M = to_world.m
+  mesh = brep_mesh.tessellate(P, deflection=geometry.BREP_DEFLECTION, keep_root_location=False)
+  mesher = brep_mesh._Mesher(P, 1e-4 * max(float(np.ptp(mesh.vertices, axis=0).max()), 1e-9), 256)
+  all_faces = P.faces()
+  if names:
+    picks = []
+    for n in names:
+      if not n.startswith('Face') or not 1 <= int(n[4:]) <= len(all_faces):
+        raise geometry.UnsupportedGeometry(f'{name} has no sub-element {n!r} ({len(all_faces)} faces)')
+      picks.append(int(n[4:]) - 1)
+  else:
+    picks = range(len(all_faces))
+  out = []
+  for k in picks:
+    fidx, loc, rev = all_faces[k]
+    f = P.tshapes[fidx]
+    surf = P.surfaces[f.surface - 1]
+    local = base @ loc @ P.locations[f.surface_loc]
+    loc_surf = M @ local
+    loops, _ = mesher._loops(f, base @ loc, surf, np.linalg.inv(local), 64)
+    uv = np.concatenate(loops)[:, :2]
+    edge_pts = np.concatenate([_xf(loc_surf, surf.eval(l[:, 0], l[:, 1])) for l in loops])
+
+    def value(u, v, surf=surf, loc_surf=loc_surf):
+      return _xf(loc_surf, surf.eval(np.array([u]), np.array([v])))[0]
+
+    def valid(u, v, x, loops=loops, edge_pts=edge_pts):
+      if _inside(np.array([[u, v]]), loops)[0]:
+        return True
+      return bool(np.linalg.norm(edge_pts - x, axis=1).min() < max(dist_tol, 1e-6))   # on the rim
+
+    def normal(u, v, surf=surf, loc_surf=loc_surf, rev=rev):
+      n = loc_surf[:3, :3] @ surf.normal(np.array([u]), np.array([v]))[0]
+      n = n / np.linalg.norm(n)
+      return -n if rev else n
+    def derivatives(u, v, surf=surf, loc_surf=loc_surf):
+      du, dv = surf.d1(np.array([u]), np.array([v]))
+      return loc_surf[:3, :3] @ du[0], loc_surf[:3, :3] @ dv[0]
+    out.append(FaceView((uv[:, 0].min(), uv[:, 0].max(), uv[:, 1].min(), uv[:, 1].max()), mesh.faces[k].area,
+                        value, valid, normal, derivatives))
+  return out
+
+
+def facesOf(doc, source):
+  """[FaceView] of a surface source's ActiveSurfaces, one set per global placement of each part
+  (surface_source.py:436-459)"""
+  from . import surface_source
+  from ..scene import bake as _bake
+  tol = surface_source.distTol(doc)
+  out = []
+  for part, subs in source._props.get('ActiveSurfaces') or []:
+    own = part.Placement if part.hasProperty('Placement') else None
+    names = [s for s in subs if s]
+    for gp in _bake.globalPlacements(doc, part):
+      container = gp * own.inverse() if own is not None else gp     # solids_of() applies part.Placement itself
+      for tree in geometry.solids_of(part, brepFacets=True):
+        pl = container * tree.placement
+        if tree.op == 'prim':
+          out.extend(_primitive_faces(tree.kind, tree.params, pl, names, tol))
+        elif tree.op == 'mesh' and len(tree.mesh) > 4:
+          out.extend(_brep_faces(tree.mesh[4], tree.source, pl, names, tol))
+        else:
+          raise NotImplementedError(
+              f'{source.Name}: fan grids are built on faces of primitives and of stored shapes; '
+              f'{tree.source or part.Name} is a {tree.op}')
+  return out
+
+
+# ------------------------------------------------------------------ the grid
+def makeSurfaceGrid(face, totalGridPoints, distTol):
+  """-> [((u, v), point, (dS/du, dS/dv))]: roughly equidistant points on the face
+  (_makeSurfaceGrid, surface_source.py:119-267: five passes, see the module docstring)"""
+  limits = dict(u=(face.range[0], face.range[1]), v=(face.range[2], face.range[3]))
+  sizes = dict(u=face.range[1] - face.range[0], v=face.range[3] - face.range[2])
+  uniform, fill, eff = None, 1.0, sizes
+  for depth in range(5):
+    order = 'uv' if eff['u'] >= eff['v'] else 'vu'
+    if uniform is not None:
+      order = uniform + ('v' if uniform == 'u' else 'u')
+    axes = []
+    for p, q in zip(order, order[::-1]):
+      n = max(5, 1 + int(2 * np.round(np.sqrt(eff[p] / eff[q] * totalGridPoints / fill) / 2)))
+      axes.append(np.linspace(limits[p][0], limits[p][1], n))
+    P1, P2 = axes
+    s1, s2 = P1[1] - P1[0], P2[1] - P2[0]
+    uv = (lambda a, b: (a, b)) if order == 'uv' else (lambda a, b: (b, a))
+    pts = [[face.value(*uv(a, b)) for b in P2] for a in P1]
+    ok = [[bool(face.valid(*uv(a, b), pts[i][j])) for j, b in enumerate(P2)] for i, a in enumerate(P1)]
+    der = [[uv(*face.derivatives(*uv(a, b))) if ok[i][j] else (None, None) for j, b in enumerate(P2)]
+           for i, a in enumerate(P1)]
+    d1 = [[None if d[0] is None else float(np.linalg.norm(d[0])) for d in row] for row in der]
+    d2 = [[None if d[1] is None else float(np.linalg.norm(d[1])) for d in row] for row in der]
+    area = [[None if a is None else a * b for a, b in zip(r1, r2)] for r1, r2 in zip(d1, d2)]
+    known = lambda seq: [x for x in seq if x is not None]
+
+    def is_uniform(rows):
+      for row in rows:
+        vals = known(row)
+        if vals:
+          avg = float(np.mean(vals))
+          if any(abs(x - avg) * s1 * s2 >= distTol**2 for x in vals):
+            return False
+      return True
+    if is_uniform(area):
+      uniform = order[0]
+    elif is_uniform(list(zip(*area))):
+      uniform = order[1]
+    else:
+      uniform = None
+    len1 = sum(max(known(row)) for row in d1 if known(row)) * s1
+    len2 = sum(max(known(col)) for col in zip(*d2) if known(col)) * s2
+    eff = {order[0]: len1, order[1]: len2}
+    if uniform is not None:
+      # rows whose second parameter line is short (towards a pole) keep every 2^k-th point
+      for i, row in enumerate(d2):
+        row_len = max(1e-20, s2 * sum(known(row)))
+        keep = 2.0 ** np.round(np.log2(len2 / row_len)) if len2 > 0 else 1.0
+        if keep > len(ok[i]):
+          for j in range(1, len(ok[i])):
+            ok[i][j] = False
+        else:
+          for j in range(len(ok[i])):
+            if j % keep != 0:
+              ok[i][j] = False
+    count = sum(sum(row) for row in ok)
+    fill = max(fill / 10, count / (len(P1) * len(P2)))
+  # very small requests: drop every other row / column of what the minimum 5 x 5 grid produced
+  drops = [lambda i, j: False, lambda i, j: i % 2 == 0 or j % 2 == 0,
+           lambda i, j: ((i + 1) // 2) % 2 == 0 or ((j + 1) // 2) % 2 == 0]
+  while drops and totalGridPoints < 20 and count > totalGridPoints:
+    drop = drops.pop(0)
+    ok = [[ok[i][j] and not drop(i, j) for j in range(len(P2))] for i in range(len(P1))]
+    count = sum(sum(row) for row in ok)
+  return [(uv(a, b), pts[i][j], uv(*der[i][j])) for i, a in enumerate(P1) for j, b in enumerate(P2) if ok[i][j]]
+
+
+def _custom_round(x):
+  """ray counts per face: 1, 4, 9 or any integer above (surface_source.py:476)"""
+  return int(np.round(x)) if x > 9 else [1, 4, 9][int(np.argmin(np.abs(x - np.array([1, 4, 9]))))]
+
+
+def generateFanRays(doc, source):
+  """-> [(origin, direction, metadata)] of `_generateRays(mode='fans')` (surface_source.py:467-519):
+  faces share FanModeRayCount by area, each gets a grid of normal rays"""
+  from . import surface_source
+  tol = surface_source.distTol(doc)
+  faces = facesOf(doc, source)
+  if not faces:
+    warnings.warn(f'surface source {source.Name} has no ActiveFaces selected for emission')
+    return []
+  areas = np.array([f.area for f in faces], dtype=np.float64)
+  weights = areas / areas.sum()
+  total = float(source._props.get('FanModeRayCount', 100))
+  wanted = sum(_custom_round(w * total) for w in weights)
+  skip = max(0.0, 1 - total / wanted)
+  if skip > 0.3:
+    warnings.warn(f'cannot place rays on all surfaces, because this would require {wanted} rays, which exceeds '
+                  f'FanModeRayCount={total:g}. Skipping {1e2 * skip:.0f}% of faces.')
+  else:
+    skip = 0.0
+  rays, face_i = [], 0.0
+  for w, face in zip(weights, faces):
+    if skip > 0:
+      step = skip / w * len(faces)
+      if np.round(face_i) != np.round(face_i + step):
+        continue
+      face_i += step
+    for (u, v), point, (du, dv) in makeSurfaceGrid(face, _custom_round(w * total), tol):
+      n = face.normal(u, v)
+      rays.append((np.asarray(point, float), n / np.linalg.norm(n), dict(initPhi=0.0, initTheta=0.0)))
+  return rays

@@ -134,6 +134,11 @@ class Plane(Geometry):
     d = np.asarray(x, float) - self.p
     return d @ self.dx, d @ self.dy
 
+  def d1(self, u, v):
+    """(dS/du, dS/dv), each (n, 3)"""
+    n = len(np.atleast_1d(u))
+    return np.tile(self.dx, (n, 1)), np.tile(self.dy, (n, 1))
+
 
 class Revolved(Geometry):
   """cylinder / cone / sphere / torus in OCC's parametrisation (u = angle about n)"""
@@ -171,6 +176,20 @@ class Revolved(Geometry):
     else:
       nrm = (np.cos(v) * e + np.sin(v) * self.n) * np.sign(self.r + self.extra * np.cos(v) + 1e-300)
     return nrm * hand
+
+  def d1(self, u, v):
+    """(dS/du, dS/dv), each (n, 3): exact"""
+    u = np.asarray(u, float)[:, None]
+    v = np.asarray(v, float)[:, None]
+    e = np.cos(u) * self.dx + np.sin(u) * self.dy          # radial direction
+    t = -np.sin(u) * self.dx + np.cos(u) * self.dy         # its derivative
+    if self.kind == 'cylinder':
+      return self.r * t, np.tile(self.n, (len(u), 1))
+    if self.kind == 'cone':
+      return (self.r + v * np.sin(self.extra)) * t, np.sin(self.extra) * e + np.cos(self.extra) * self.n
+    if self.kind == 'sphere':
+      return self.r * np.cos(v) * t, -self.r * np.sin(v) * e + self.r * np.cos(v) * self.n
+    return (self.r + self.extra * np.cos(v)) * t, -self.extra * np.sin(v) * e + self.extra * np.cos(v) * self.n
 
   def invert(self, x, hint):
     """parameters of points x on the surface; angles are taken into the period around `hint`
@@ -257,6 +276,20 @@ class BSplineSurface(Geometry):
       n[bad] = cross(u[bad] + 1e-4 * (um - u[bad]), v[bad] + 1e-4 * (vm - v[bad]))
       length = np.linalg.norm(n, axis=1)
     return n / np.maximum(length, 1e-300)[:, None]
+
+
+  def d1(self, u, v):
+    """(dS/du, dS/dv): five-point differences (truncation and rounding both ~1e-13 relative)"""
+    u, v = np.asarray(u, float), np.asarray(v, float)
+    out = []
+    for axis, (a, b) in enumerate(((self.u0, self.u1), (self.v0, self.v1))):
+      h = 1e-3 * (b - a)
+      x = u if axis == 0 else v
+      c = np.clip(x, a + 2 * h, b - 2 * h)         # the stencil stays inside the patch
+      ev = (lambda t: self.eval(t, v)) if axis == 0 else (lambda t: self.eval(u, t))
+      d = (-ev(c + 2 * h) + 8 * ev(c + h) - 8 * ev(c - h) + ev(c - 2 * h)) / (12 * h)
+      out.append(d)
+    return out[0], out[1]
 
 
 class TrimmedSurface(Geometry):

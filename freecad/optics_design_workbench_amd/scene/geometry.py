@@ -190,7 +190,7 @@ def _brep_node(obj, facets=False):
   m, exact = _BREP_CACHE[key]
   if exact is not None and BREP_EXACT and not facets:
     return _named(_copy_tree(exact[0]), obj.Name)
-  return Node('mesh', mesh=(m.vertices, m.triangles, m.normals, m.faces), source=obj.Name)
+  return Node('mesh', mesh=(m.vertices, m.triangles, m.normals, m.faces, payload), source=obj.Name)
 
 
 def _copy_tree(n):
@@ -357,7 +357,7 @@ def _prune_faces(prims, slack=1e-3):
 # ---------------------------------------------------------------------------
 def meshWorld(node):
   """world-space arrays of a 'mesh' node: vertices (n,3), triangles, normals"""
-  v, tri, vn = node.mesh[:3]     # (BRep shapes carry their face table as a fourth entry)
+  v, tri, vn = node.mesh[:3]     # (BRep shapes carry their face table and payload as further entries)
   R, t = node.placement.m[:3, :3], node.placement.m[:3, 3]
   return v @ R.T + t, tri, (None if vn is None else vn @ R.T)
 

@@ -16,7 +16,7 @@ several GPUs of this process' node through `parallel`.
 """
 import numpy as np
 
-from ..freecad_elements import point_source, replay_source, surface_source
+from ..freecad_elements import point_source, replay_source, surface_fans, surface_source
 from ..scene import bake as _bake
 from . import parallel, results_store
 from .tracer import Tracer, segmentsToRays
@@ -134,16 +134,19 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
           if not n:
             continue
         elif action in ('fans', 'singlefans'):
-          if isinstance(bsrc, surface_source.BakedSurfaceSource):
-            raise NotImplementedError(
-                f'{src.Name}: fan mode of surface sources (equidistant UV grids, '
-                f'surface_source.py:119-266) is not on the accelerated path')
-          rays = point_source.generateFanRays(src, bsrc)
+          surface = isinstance(bsrc, surface_source.BakedSurfaceSource)
+          # surface sources: normal rays on a grid of roughly equidistant points of every face
+          # (surface_source.py:467-519); point sources: fans through the optical axis
+          rays = surface_fans.generateFanRays(doc, src) if surface else point_source.generateFanRays(src, bsrc)
           n, iters, base = len(rays), 1, 0
+          if not n:
+            continue
           explicit = (np.array([r[0] for r in rays]), np.array([r[1] for r in rays]), None, None)
           per_ray = dict(initPoint=explicit[0], initDirection=explicit[1], initPower=np.ones(n),
                          initWavelength=np.full(n, bsrc.wavelength))
-          for key in ('fanIndex', 'rayIndex', 'totalFanCount', 'totalRaysInFan', 'initPhi', 'initTheta'):
+          keys = ('initPhi', 'initTheta') if surface else ('fanIndex', 'rayIndex', 'totalFanCount', 'totalRaysInFan',
+                                                            'initPhi', 'initTheta')
+          for key in keys:
             per_ray[key] = np.array([r[2][key] for r in rays])
         elif pseudo and isinstance(bsrc, point_source.BakedSource):
           # (surface sources treat 'pseudo' like 'true', surface_source.py:521)

@@ -102,5 +102,5 @@ def test_surface_source_scene_end_criteria(tmp_path, oracle):
       active.EndAfterRays, active.EndAfterHits = 1e3, 'inf'
       r = f.runSimulation('true', tracer=OracleTracer())
       assert len(r.loadHits('*')) > 100
-    with pytest.raises(NotImplementedError):
-      f.runSimulation('fans', tracer=OracleTracer())
+    r = f.runSimulation('fans', tracer=OracleTracer())       # normal rays on an 11 x 11 grid of Face5
+    assert r.loadProgress()['totalTracedRays'] == 121 and len(r.loadHits('*')) > 20

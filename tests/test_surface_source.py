@@ -263,3 +263,73 @@ def test_device_facet_emission_matches_oracle(tracer, oracle):
   go, gd = tracer.generateRays(0, 50000, 6)
   ro, rd = oracle.surface_rays(f, 0, 50000, 6)
   assert np.abs(go - ro).max() < 1e-10 and np.abs(gd - rd).max() < 1e-10
+
+
+# ---------------------------------------------------------------------------
+# fan mode: normal rays on a grid of roughly equidistant points (surface_source.py:119-268, 467-519)
+# ---------------------------------------------------------------------------
+def _fan_points(doc, parts, count):
+  from freecad.optics_design_workbench_amd.freecad_elements import surface_fans
+  src = _source(doc, parts, FanModeRayCount=count)
+  rays = surface_fans.generateFanRays(doc, src)
+  return np.array([r[0] for r in rays]), np.array([r[1] for r in rays])
+
+
+def test_fan_grid_on_a_square_face_is_the_reference_recipe():
+  """one 10 x 10 face, 100 rays: both axes get max(5, 1 + 2 round(sqrt(100) / 2)) = 11 points,
+  rim included, every pass finds the face filled and uniform"""
+  doc = Document()
+  box = make.makeBox(doc, 'B', 10, 10, 3, base=(1, 2, 3))
+  o, d = _fan_points(doc, [(box, ['Face6'])], 100)
+  assert len(o) == 121 and np.all(o[:, 2] == 6.0) and np.all(d == [0, 0, 1])
+  assert np.allclose(np.unique(o[:, 0]), 1 + np.arange(11)) and np.allclose(np.unique(o[:, 1]), 2 + np.arange(11))
+  # a 20 x 5 face: the longer parameter comes first.  The passes measure the lengths of the
+  # parameter lines as (number of points) x step, so they see 21 x 6.25, 21.1 x 5.83, 21 x 5.83, ...
+  # and settle on 21 x 7 points (by hand from surface_source.py:149-153, 213-215)
+  slab = make.makeBox(doc, 'S', 20, 5, 1)
+  o, _ = _fan_points(doc, [(slab, ['Face6'])], 100)
+  assert len(np.unique(o[:, 0].round(9))) == 21 and len(np.unique(o[:, 1].round(9))) == 7
+  # few rays: the minimum 5 x 5 grid loses its even rows and columns (2 x 2 points are left), and for
+  # a single ray every other one of those (surface_source.py:255-263)
+  for want, got in ((9, 4), (4, 4), (1, 1)):
+    o, _ = _fan_points(doc, [(box, ['Face6'])], want)
+    assert len(o) == got
+
+
+def test_fan_grid_is_roughly_equidistant_on_curved_and_trimmed_faces():
+  from scipy.spatial import cKDTree
+  doc = Document()
+  ball = make.makeSphere(doc, 'S', 5)
+  o, d = _fan_points(doc, [(ball, [])], 400)
+  assert 250 < len(o) < 700
+  assert np.abs(np.linalg.norm(o, axis=1) - 5).max() < 1e-9 and np.abs(d - o / 5).max() < 1e-9     # radial rays
+  uniq = np.unique(o.round(9), axis=0)          # the seam (u = 0 and 2 pi) and the poles repeat
+  nn = cKDTree(uniq).query(uniq, k=2)[0][:, 1]
+  assert nn.max() < 3.5 * np.median(nn)         # rows towards the poles are thinned: no crowding, no gaps
+  lat = np.arcsin(uniq[:, 2] / 5)
+  per_row = [np.sum(np.abs(lat - l) < 1e-6) for l in np.unique(lat.round(6))]
+  assert per_row[len(per_row) // 2] >= 4 * min(per_row[1], per_row[-2])
+  # a cylinder's cap: the parameter range is the square around the disc, a fifth of it is empty
+  cyl = make.makeCylinder(doc, 'C', 4, 6)
+  o, d = _fan_points(doc, [(cyl, ['Face2'])], 200)
+  assert np.all(o[:, 2] == 6.0) and np.all(d == [0, 0, 1]) and np.hypot(o[:, 0], o[:, 1]).max() <= 4 + 1e-9
+  assert 150 < len(o) < 300
+  # faces share the rays by area: lateral face 2 pi 4 6, caps pi 16 each
+  o, _ = _fan_points(doc, [(cyl, [])], 300)
+  side = (o[:, 2] > 1e-9) & (o[:, 2] < 6 - 1e-9)
+  assert 0.35 < side.mean() < 0.75          # (the rows on the two rims are not counted)
+
+
+def test_fan_mode_of_the_reference_scenes(oracle):
+  """test/21-simulation-modes (Face5 of a box above a ball lens) and test/80 (two faces of an
+  imported aspheric lens): `runSimulation('fans')` traces the normal rays"""
+  from oracle_tracer import OracleTracer
+  from freecad.optics_design_workbench_amd.simulation import runSimulation
+  doc = open_fcstd(os.path.join(SCENES, 'simulation-modes-main.FCStd'))
+  store = runSimulation(doc, 'fans', tracer=OracleTracer())
+  assert store.totalTracedRays == 121
+  hits = store.hits()
+  assert 20 < len(hits) <= 121 and np.all(hits._get('initTheta') == 0)
+  doc = open_fcstd(os.path.join(SCENES, 'imported-stepfile-as-surface-source.FCStd'))
+  store = runSimulation(doc, 'fans', tracer=OracleTracer())
+  assert 80 < store.totalTracedRays < 160
