@@ -16,7 +16,6 @@ import sympy as sy
 
 from .. import distributions
 from ..scene import bake as _bake
-from ..scene.placement import Placement, from_axis_angle
 
 
 def parsedDomain(domain, default='0,1'):

@@ -20,7 +20,6 @@ import warnings
 import numpy as np
 
 from ..scene import geometry
-from ..scene.placement import Placement
 
 
 class FaceView:

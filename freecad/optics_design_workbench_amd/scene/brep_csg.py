@@ -23,7 +23,7 @@ surfaces): those shapes keep their facets.
 """
 import numpy as np
 
-from . import brep, brep_mesh
+from . import brep_mesh
 from .placement import Placement
 
 BOX, SPHERE, CYLINDER, CONE, TORUS = range(5)
