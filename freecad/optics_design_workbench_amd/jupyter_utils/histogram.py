@@ -60,3 +60,56 @@ class Histogram:
                        '(created with binCoords="polar" argument)')
     return ((self.binX[1:] + self.binX[:-1]) / 2, (self.binY[:-1] + self.binY[1:]) / 2,
             self.hist / self.binAreas)
+
+  def scaledHist(self, scale='max'):
+    """hit density per bin area, transposed for plotting; scale 'max' normalises to the peak,
+    a number divides by it, None leaves the density as it is (Histogram.plot, histogram.py:108-113)"""
+    h = (self.hist / self.binAreas).T
+    if scale == 'max':
+      return h / h.max()
+    return h if scale is None else h / scale
+
+  def plot(self, cbar={}, title=None, scale='max', **kwargs):
+    """pcolormesh of the density on the current matplotlib axes (polar axes for polar bins;
+    histogram.py:91-148); cbar: keyword arguments of the colour bar, anything but a dict: none"""
+    import matplotlib.pyplot as plt
+    polar = self._binCoords == 'polar'
+    ax = plt.gca()
+    if (ax.name == 'polar') != polar:
+      fig = ax.figure
+      spec = ax.get_subplotspec()
+      ax.remove()
+      ax = fig.add_subplot(spec, projection='polar' if polar else 'rectilinear')
+      plt.sca(ax)
+    h = self.scaledHist(scale)
+    bx = self.binX
+    if polar:
+      up = int(np.ceil(200 / len(bx)))          # finer azimuth steps: round cells
+      if up > 1:
+        bx = np.concatenate([np.linspace(a, b, up + 1)[:-1] for a, b in zip(bx[:-1], bx[1:])] + [bx[-1:]])
+        h = np.repeat(h, up, axis=1)
+    mesh = ax.pcolormesh(*np.meshgrid(bx, self.binY), h, **kwargs)
+    if isinstance(cbar, dict):
+      plt.colorbar(mesh, ax=ax, **cbar).set_label('hit density per bin')
+    if title is None:
+      n, p, o = self._planeNormal, self._xInPlaneVec, self._origin
+      title = (f'plane normal = [{n[0]:.2f}, {n[1]:.2f}, {n[2]:.2f}],\n'
+               f'projected $x$ = [{p[0]:.2f}, {p[1]:.2f}, {p[2]:.2f}]'
+               + ('' if np.allclose(o, 0) else f',\norigin = [{o[0]:.2e}, {o[1]:.2e}]'))
+    ax.set_title(title, fontsize=10, **(dict(y=1.09) if polar else {}))
+    if not polar:
+      ax.axis('equal')
+      ax.set_xlabel(r'projected $x$')
+      ax.set_ylabel(r'projected $y$')
+    ax.set_aspect('equal')
+    return mesh
+
+  def plotByAzimuth(self):
+    """radial density profiles, one line per azimuth bin (histogram.py:163-166)"""
+    import matplotlib.pyplot as plt
+    phi, r, h = self.byAzimuth()
+    for p, row in zip(phi, h):
+      plt.plot(r, row, label=f'$\\phi={p / np.pi:.1f}\\pi$')
+    plt.xlabel('radius $r$')
+    plt.ylabel('hit density per bin')
+    plt.legend()

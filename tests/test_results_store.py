@@ -271,3 +271,26 @@ def test_raw_folder_helpers(tmp_path, oracle):
     f.disableFastMode()
     assert f.isWorkInTempCopy() and f.path().endswith('GettingStarted.FCStd') and f.resultsPath().endswith('.OpticsDesign')
     assert f.Sphere.Radius.getFloat() == float(f.Sphere.Radius) and f.OpticalSimulationSettings.RaysPerIteration.getInt() == 100
+
+
+def test_histogram_plots():
+  """Histogram.plot / plotByAzimuth (jupyter_utils/histogram.py:91-166) on an off-screen canvas"""
+  import matplotlib
+  matplotlib.use('Agg')
+  import matplotlib.pyplot as plt
+  from freecad.optics_design_workbench_amd.jupyter_utils import Histogram
+  rng = np.random.default_rng(3)
+  x, y = rng.normal(0, 1, 20000), rng.normal(0, 2, 20000)
+  h = Histogram(x, y, planeNormal=(0, 0, 1), xInPlaneVec=(1, 0, 0), bins=40)
+  assert h.scaledHist().max() == 1.0 and np.allclose(h.scaledHist(None), h.hist.T)
+  plt.figure()
+  mesh = h.plot()
+  assert mesh.get_array().max() == 1.0 and plt.gca().get_xlabel() == 'projected $x$'
+  hp = Histogram(x, y, planeNormal=(0, 0, 1), xInPlaneVec=(1, 0, 0), binCoords='polar', radius=4, bins=(12, 20))
+  plt.figure()
+  hp.plot(cbar=None, scale=None)
+  assert plt.gca().name == 'polar'
+  plt.figure()
+  hp.plotByAzimuth()
+  assert len(plt.gca().get_lines()) == 12
+  plt.close('all')
