@@ -126,6 +126,31 @@ class Hits:
     X, Y = self.planeProject3dPoints(points, planeNormal=planeNormal, xInPlaneVec=xInPlaneVec).T
     return Histogram(X, Y, planeNormal=planeNormal, xInPlaneVec=xInPlaneVec, **kwargs)
 
+  def plot(self, hueKey=None, hueLabel=None, planeNormal=None, xInPlaneVec=None, plotKey='points', **kwargs):
+    """scatter plot of the hits projected into their plane, optionally coloured by a metadata
+    column (jupyter_utils/hits.py:196-222)"""
+    import matplotlib.pyplot as plt
+    if plotKey not in self.hits:
+      return None
+    if planeNormal is None or xInPlaneVec is None:
+      planeNormal, xInPlaneVec = self.detectPlaneNormal(points=self.hits[plotKey], planeNormal=planeNormal,
+                                                        xInPlaneVec=xInPlaneVec)
+    X, Y = self.planeProject3dPoints(self.hits[plotKey], planeNormal=planeNormal, xInPlaneVec=xInPlaneVec).T
+    kwargs.setdefault('s', 4)
+    if hueKey is not None:
+      sc = plt.scatter(X, Y, c=np.asarray(self.hits[hueKey]), cmap=kwargs.pop('cmap', 'hsv'), **kwargs)
+      plt.colorbar(sc).set_label(hueLabel or hueKey)
+    else:
+      sc = plt.scatter(X, Y, **kwargs)
+    n, p = planeNormal, xInPlaneVec
+    plt.title(f'plane normal = [{n[0]:.2f}, {n[1]:.2f}, {n[2]:.2f}],\n'
+              f'projected $x$ = [{p[0]:.2f}, {p[1]:.2f}, {p[2]:.2f}]', fontsize=10)
+    plt.xlabel('projected $x$')
+    plt.ylabel('projected $y$')
+    plt.gca().axis('equal')
+    plt.gca().set_aspect('equal')
+    return sc
+
   # ====================================================
   # fan math (jupyter_utils/hits.py:227-444)
 

@@ -293,4 +293,11 @@ def test_histogram_plots():
   plt.figure()
   hp.plotByAzimuth()
   assert len(plt.gca().get_lines()) == 12
+  from freecad.optics_design_workbench_amd.jupyter_utils import Hits
+  pts = np.stack([x[:500], y[:500], np.full(500, 7.0)], axis=1)
+  hits = Hits(dict(points=pts, directions=np.tile([0, 0, 1.0], (500, 1)), fanIndex=np.arange(500) % 3))
+  plt.figure()
+  sc = hits.plot(hueKey='fanIndex')
+  assert len(sc.get_offsets()) == 500 and 'plane normal' in plt.gca().get_title()
+  assert Hits({}).plot() is None
   plt.close('all')
