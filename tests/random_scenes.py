@@ -1,0 +1,60 @@
+"""Random scenes for the randomised parity checks (tests/test_gpu_fuzz.py, scripts/fuzz_parity.py):
+primitives and booleans of random kind, size and placement, overlapping at random, in optical groups
+of random type; all groups record, so whole trajectories are compared.  TEST INFRASTRUCTURE."""
+import numpy as np
+
+from freecad.optics_design_workbench_amd.freecad_elements import make
+from freecad.optics_design_workbench_amd.scene import Document, bake
+
+
+def rquat(rs):
+  q = rs.normal(0, 1, 4)
+  return tuple(q / np.linalg.norm(q))
+
+
+def solid(doc, rs, k, centre):
+  kind = rs.choice(['box', 'sphere', 'cylinder', 'cone', 'torus'], p=[0.3, 0.3, 0.2, 0.1, 0.1])
+  pl = dict(base=tuple(centre + rs.normal(0, 1.0, 3)), quat=rquat(rs))
+  s = rs.uniform(2, 6)
+  if kind == 'box':
+    return make.makeBox(doc, f'B{k}', *(rs.uniform(2, 8, 3)), **pl)
+  if kind == 'sphere':
+    return make.makeSphere(doc, f'S{k}', s, **pl)
+  if kind == 'cylinder':
+    return make.makeCylinder(doc, f'C{k}', s * 0.6, rs.uniform(3, 9), **pl)
+  if kind == 'cone':
+    return make.makeCone(doc, f'K{k}', s * 0.7, s * rs.uniform(0.0, 0.6), rs.uniform(3, 8), **pl)
+  return make.makeTorus(doc, f'T{k}', s, s * rs.uniform(0.15, 0.4), **pl)
+
+
+def scene(rs):
+  doc = Document()
+  targets = []
+  k = 0
+  for g in range(rs.randint(2, 6)):
+    centre = rs.uniform(-18, 18, 3)
+    targets.append(centre)
+    a = solid(doc, rs, k, centre); k += 1
+    r = rs.rand()
+    if r < 0.45:
+      elem = a
+    else:
+      b = solid(doc, rs, k, centre + rs.normal(0, 1.5, 3)); k += 1
+      elem = (make.makeCommon(doc, [a, b], f'X{k}') if r < 0.65 else
+              make.makeCut(doc, a, b, f'X{k}') if r < 0.85 else make.makeFuse(doc, [a, b], f'X{k}'))
+    kind = rs.choice(['Mirror', 'Lens', 'Absorber', 'Vacuum'], p=[0.3, 0.4, 0.15, 0.15])
+    props = dict(RefractiveIndex=float(rs.uniform(1.2, 2.0))) if kind == 'Lens' else {}
+    make.makeOpticalGroup(doc, kind, [elem], **props)
+  make.makeSimulationSettings(doc, MaxIntersections=float(rs.choice([6, 12, 30])))
+  src = make.makePointSource(doc)
+  sc = bake.bakeScene(doc, src)
+  sc.group_record = np.ones_like(sc.group_record)
+  return sc, bake.bakeLimits(doc, src), np.array(targets)
+
+
+def rays(rs, targets, n, radius=60.0, spread=2.5):
+  o = rs.normal(0, 1, (n, 3))
+  o = o / np.linalg.norm(o, axis=1)[:, None] * radius
+  t = targets[rs.randint(0, len(targets), n)] + rs.normal(0, spread, (n, 3))
+  d = t - o
+  return o, d / np.linalg.norm(d, axis=1)[:, None]
