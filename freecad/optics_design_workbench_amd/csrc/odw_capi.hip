@@ -433,7 +433,11 @@ int build_bvh(odw_ctx* ctx) {
     BvhNode nd;
     for (int k = 0; k < 3; ++k) {
       nd.lo0[k] = round_down(root.box.lo[k]); nd.hi0[k] = round_up(root.box.hi[k]);
-      nd.lo1[k] = INFINITY; nd.hi1[k] = -INFINITY;
+      // the second child does not exist.  Its box must be one no ray meets: an inverted box
+      // (lo = +inf, hi = -inf) passes the slab test for every ray (min = -inf, max = +inf on
+      // each axis) and would send the traversal back to node 0 for ever; a point far away fails
+      // it for every direction
+      nd.lo1[k] = 3.0e38f; nd.hi1[k] = 3.0e38f;
     }
     nd.child0 = root.child; nd.count0 = root.count;
     nd.child1 = 0; nd.count1 = 0;

@@ -44,15 +44,17 @@ with Tracer(0) as tr:
     ref = oracle.trace_rays(sc, lim, o, d, nthreads=0)
     r = ref['hits']
     done += 1
+    if done % 10 == 0:
+      print(json.dumps(dict(progress=done)), flush=True)
     same_tags = len(g) == len(r) and np.array_equal(g['tag'], r['tag'])
     if not same_tags:
       # rays whose hit sequences differ
       gr = (g['tag'] & np.uint64(0xFFFFFFFFFFFF)).astype(np.int64)
       rr = (r['tag'] & np.uint64(0xFFFFFFFFFFFF)).astype(np.int64)
       cg, cr = np.bincount(gr, minlength=n_rays), np.bincount(rr, minlength=n_rays)
-      rays = np.flatnonzero(cg != cr)
+      which = np.flatnonzero(cg != cr)
       bad['tags'] += 1
-      print(json.dumps(dict(scene=s, kind='tags', rays_differing=int(len(rays)), first=rays[:5].tolist(),
+      print(json.dumps(dict(scene=s, kind='tags', rays_differing=int(len(which)), first=which[:5].tolist(),
                             prims=[int(x) for x in sc.prim_type], counters_gpu=gc, counters_ref=ref['counters'])), flush=True)
       continue
     if len(g):

@@ -177,3 +177,33 @@ def test_large_mesh_matches_analytic_statistics(tracer):
   ca, cm = res[None][0], res[448][0]
   assert ca['recorded_hits'] == cm['recorded_hits'] and abs(ca['segments'] - cm['segments']) < 20
   assert np.sqrt(np.mean(np.sum((res[None][1] - res[448][1])**2, axis=1))) < 5e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(120)
+def test_single_leaf_tree_terminates(native_lib, oracle):
+  """a mesh of one facet (and one of four overlapping ones) makes a tree that is a single leaf:
+  the root is a wrapper whose second child does not exist.  Round 1 found its inverted box being
+  met by every ray, which sent the traversal back to the root for ever (randomised parity run with
+  the BVH kernels forced)."""
+  from freecad.optics_design_workbench_amd.freecad_elements import make
+  from freecad.optics_design_workbench_amd.scene import Document, bake
+  from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
+  for tris in ([[0, 1, 2]], [[0, 1, 2], [0, 2, 3], [0, 3, 1], [1, 3, 2]]):
+    doc = Document()
+    v = np.array([[-5, -5, 20.0], [5, -5, 20.0], [0, 5, 20.0], [0, 0, 24.0]])
+    make.makeMirror(doc, [make.makeMesh(doc, v, np.array(tris))], RecordHits=True)
+    make.makeSimulationSettings(doc)
+    src = make.makePointSource(doc, PowerDensity='1', ThetaDomain='0, 0.3')
+    from freecad.optics_design_workbench_amd.simulation.simulation_loop import bakeLightSource
+    sc, bs, lim = bake.bakeScene(doc, src), bakeLightSource(doc, src, 0), bake.bakeLimits(doc, src)
+    n = 20000
+    with Tracer(0) as tr:
+      tr.setScene(sc); tr.setSource(bs); tr.setLimits(lim); tr.setDetector(None)
+      tr.reserveHits(4 * n)
+      tr.reset()
+      tr.trace(0, n, 1, histogram=False)
+      tr.sync()
+      ref = oracle.trace(sc, bs, lim, 0, n, 1, flags=1, nthreads=0)
+      assert tr.counters() == ref['counters'] and ref['counters']['recorded_hits'] > 1000
+      assert np.array_equal(tr.hits()['tag'], ref['hits']['tag'])
