@@ -355,6 +355,9 @@ __device__ __forceinline__ void cand_min2(Cands& c, double t, int f) {
   c.f0 = lt0 ? f : c.f0;
 }
 
+#ifndef ODW_TORUS_PLAIN
+#define ODW_TORUS_PLAIN 96     // plain distance steps before the curvature bound joins in
+#endif
 // every face of primitive p against the ray: untrimmed analytic surface,
 // natural face bounds with tolerance (ray.py:411-426).  The candidates are
 // collected first and judged by ONE copy of consider() (code size: the hot
@@ -479,6 +482,13 @@ __device__ __forceinline__ void intersect_prim(const SceneView& sv, Query& q, in
     // f(s) = |(rho - R1, z)| - R2 (|df/ds| <= 1, so a step of |f| cannot
     // jump over the surface), each sign change polished by bracketed Newton.
     // No coefficient arrays, no calls: the state is a dozen registers.
+    // Grazing chords make the plain step crawl: it grows by the sine of the grazing angle only
+    // (a ray scattered back into the tube at 1e-3 rad needs 2e4 steps; a capped march lost such
+    // roots).  A march still running after ODW_TORUS_PLAIN steps therefore uses the curvature
+    // bound as well: along the line |f''| <= K = 2 (1/rr + 1/rho) within half of min(rr, rho) of
+    // the point (rr = f + R2: distance from the tube's centre circle, rho: from the axis); with
+    // F = |f| and G >= (secant slope of |f| over the last step) - K h_last, the surface cannot be
+    // reached before (G + sqrt(G^2 + 2 K F)) / K -- sqrt(2 F / K) when running along it.
     const double s_begin = fmax(s_lo, 0.5 * tol - t0);   // roots with t <= tol/2 are rejected anyway
     const double step_min = 1e-7 * R2;
     double sc = s_begin, fc;
@@ -488,13 +498,25 @@ __device__ __forceinline__ void intersect_prim(const SceneView& sv, Query& q, in
       fc = fsqrt(a * a + pz * pz) - R2;
     }
     int nfound = 0;
-    for (int it = 0; it < 4096 && sc < s_hi && nfound < 4; ++it) {
-      const double sn = fmin(sc + fmax(fabs(fc), step_min), s_hi);
-      double fn;
+    double h = fmax(fabs(fc), step_min);
+    for (int it = 0; it < 16384 && sc < s_hi && nfound < 4; ++it) {
+      const double sn = fmin(sc + h, s_hi);
+      double fn, rho;
       {
         const double px = cc.x + sn * d.x, py = cc.y + sn * d.y, pz = cc.z + sn * d.z;
-        const double a = fsqrt(px * px + py * py) - R1;
+        rho = fsqrt(px * px + py * py);
+        const double a = rho - R1;
         fn = fsqrt(a * a + pz * pz) - R2;
+      }
+      h = fmax(fabs(fn), step_min);
+      if (it >= ODW_TORUS_PLAIN && (fc > 0) == (fn > 0)) {
+        const double hp = sn - sc, rr = fn + R2, room = 0.5 * fmin(rr, rho);
+        if (hp <= room) {
+          const double K = 2.0 * (frcp(rr) + frcp(rho));
+          const double G = (fabs(fn) - fabs(fc)) * frcp(hp) - K * hp;
+          const double hs = 0.99 * (G + fsqrt(G * G + 2.0 * K * fabs(fn))) * frcp(K);
+          h = fmax(h, fmin(hs, room));            // (a NaN from a pole of the bound drops out)
+        }
       }
       if ((fc > 0) != (fn > 0)) {
         double lo = sc, hi = sn, x = sn;

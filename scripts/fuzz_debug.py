@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""one scene of the randomised parity run in detail: python scripts/fuzz_debug.py seed scene rays rich"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np
+from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
+from oracle import capi as oracle
+from random_scenes import rays, scene
+seed0, s, n, rich = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4] == '1'
+rs = np.random.RandomState(seed0 * 100003 + s)
+sc, lim, targets = scene(rs, rich)
+o, d = rays(rs, targets, n)
+print('prims', sc.prim_type.tolist(), 'groups', sc.prim_group.tolist(), 'types', sc.group_type.tolist(), 'seq', sc.seq_enabled, [hex(int(m)) for m in sc.seq_mask],
+      'samplers', [(x.group, x.kind, x.axis) for x in sc.surface_samplers], 'refl', sc.group_refl.tolist(), 'abslen', sc.group_abslen.tolist(), 'maxint', lim.max_intersections)
+with Tracer(0) as tr:
+  tr.setScene(sc); tr.setLimits(lim); tr.setDetector(None)
+  tr.reserveHits(n * (lim.max_intersections + 1)); tr.reserveSegments(n * lim.max_intersections)
+  tr.reset(); tr.setSurfaceSeed(s + 17)
+  tr.traceRays(o, d, record_segments=True); tr.sync()
+  g, gs = tr.hits(), tr.segments()
+r = oracle.trace_rays(sc, lim, o, d, nthreads=0, surface_seed=s + 17)['hits']
+rseg = oracle.trace_segments(sc, lim, origins=o, dirs=d, surface_seed=s + 17)['segments']
+gr = (g['tag'] & np.uint64(0xFFFFFFFFFFFF)).astype(np.int64); rr = (r['tag'] & np.uint64(0xFFFFFFFFFFFF)).astype(np.int64)
+bad = np.flatnonzero(np.bincount(gr, minlength=n) != np.bincount(rr, minlength=n))
+print('differing rays', len(bad), bad[:10])
+sr_g = (gs['tag'] & np.uint64(0xFFFFFFFFFF)).astype(np.int64); sr_r = (rseg['tag'] & np.uint64(0xFFFFFFFFFF)).astype(np.int64)
+for b in bad[:3]:
+  a, c = gs[sr_g == b], rseg[sr_r == b]
+  print('ray', b, 'segments gpu', len(a), 'oracle', len(c))
+  for k in range(max(len(a), len(c))):
+    ga = a[k] if k < len(a) else None; oc = c[k] if k < len(c) else None
+    print('  ', k, 'gpu', None if ga is None else (np.round(ga['p2'], 6).tolist(), round(float(ga['power']), 6), (int(ga['tag']) >> 52) - 1),
+          '| oracle', None if oc is None else (np.round(oc['p2'], 6).tolist(), round(float(oc['power']), 6), (int(oc['tag']) >> 52) - 1))
+  hg, hr = g[gr == b], r[rr == b]
+  print('   hits gpu', [(int(t >> np.uint64(48)) & 0x7fff, int(t >> np.uint64(63))) for t in hg['tag']], 'oracle', [(int(t >> np.uint64(48)) & 0x7fff, int(t >> np.uint64(63))) for t in hr['tag']])

@@ -2,7 +2,8 @@
 """Randomised parity: random scenes of primitives and booleans (random kinds, sizes, placements,
 optical types, overlaps), random rays aimed at them, device vs oracle on whole trajectories
 (all groups record).  Prints one JSON line per scene that differs and a summary.
-  python scripts/fuzz_parity.py [scenes] [rays] [seed]
+  python scripts/fuzz_parity.py [scenes] [rays] [seed] [rich]
+(rich = 1: also tessellated solids, stochastic surfaces, gratings, absorbing media, sequential mode)
 Differences are classified: `tags` (a different sequence of hits: a real disagreement unless the
 scene is chaotic -- many bounces between curved mirrors amplify rounding) and `coords` (same hits,
 coordinates apart by more than 1e-7 mm).
@@ -23,6 +24,7 @@ from random_scenes import rays, scene
 n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 n_rays = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
 seed0 = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+rich = len(sys.argv) > 4 and sys.argv[4] == '1'
 
 
 bad = dict(tags=0, coords=0)
@@ -31,17 +33,18 @@ with Tracer(0) as tr:
   for s in range(n_scenes):
     rs = np.random.RandomState(seed0 * 100003 + s)
     try:
-      sc, lim, targets = scene(rs)
+      sc, lim, targets = scene(rs, rich)
     except Exception as e:                         # nested disjunctions etc.: not a parity matter
       continue
     o, d = rays(rs, targets, n_rays)
     tr.setScene(sc); tr.setLimits(lim); tr.setDetector(None)
     tr.reserveHits(n_rays * (lim.max_intersections + 1))
     tr.reset()
+    tr.setSurfaceSeed(s + 17)
     tr.traceRays(o, d)
     tr.sync()
     g, gc = tr.hits(), tr.counters()
-    ref = oracle.trace_rays(sc, lim, o, d, nthreads=0)
+    ref = oracle.trace_rays(sc, lim, o, d, nthreads=0, surface_seed=s + 17)
     r = ref['hits']
     done += 1
     if done % 10 == 0:

@@ -27,16 +27,21 @@ def solid(doc, rs, k, centre):
   return make.makeTorus(doc, f'T{k}', s, s * rs.uniform(0.15, 0.4), **pl)
 
 
-def scene(rs):
+def scene(rs, rich=False):
+  """rich: also tessellated solids (triangle primitives, BVH kernels), stochastic surfaces,
+  gratings, absorbing media, partly reflecting mirrors and sequential mode"""
   doc = Document()
   targets = []
   k = 0
+  groups = []
   for g in range(rs.randint(2, 6)):
     centre = rs.uniform(-18, 18, 3)
     targets.append(centre)
     a = solid(doc, rs, k, centre); k += 1
     r = rs.rand()
-    if r < 0.45:
+    if rich and r < 0.2:
+      elem = make.makeTessellated(doc, a, int(rs.choice([6, 12, 20])), smooth=bool(rs.rand() < 0.6))
+    elif r < 0.45:
       elem = a
     else:
       b = solid(doc, rs, k, centre + rs.normal(0, 1.5, 3)); k += 1
@@ -44,8 +49,29 @@ def scene(rs):
               make.makeCut(doc, a, b, f'X{k}') if r < 0.85 else make.makeFuse(doc, [a, b], f'X{k}'))
     kind = rs.choice(['Mirror', 'Lens', 'Absorber', 'Vacuum'], p=[0.3, 0.4, 0.15, 0.15])
     props = dict(RefractiveIndex=float(rs.uniform(1.2, 2.0))) if kind == 'Lens' else {}
-    make.makeOpticalGroup(doc, kind, [elem], **props)
-  make.makeSimulationSettings(doc, MaxIntersections=float(rs.choice([6, 12, 30])))
+    if rich:
+      if kind == 'Mirror' and rs.rand() < 0.3:
+        kind, props = 'Grating', dict(GratingType='Reflection', GratingLinesPerMillimeter=float(rs.uniform(200, 900)),
+                                      GratingDiffractionOrder=int(rs.choice([-1, 1, 2])),
+                                      GratingLinesOrientation=tuple(rs.normal(0, 1, 3)))
+      elif kind == 'Mirror':
+        props = dict(Reflectivity=float(rs.uniform(0.3, 1.0)))
+        if rs.rand() < 0.5:
+          props['ReflectedProbabilityDensity'] = str(rs.choice(['cos(theta-theta_refl)**8', 'exp(-(theta-theta_refl)**2/0.02)']))
+        if rs.rand() < 0.3:
+          props['RayModificationProbabilityDensity'] = 'exp(-theta**2/0.001)'
+      elif kind == 'Lens':
+        if rs.rand() < 0.4:
+          props['AbsorptionLength'] = float(rs.uniform(2, 30))
+        if rs.rand() < 0.3:
+          props['RefractedProbabilityDensity'] = 'exp(-(theta-theta_refl)**2/0.005)'
+    groups.append(make.makeOpticalGroup(doc, kind, [elem], **props))
+  settings = dict(MaxIntersections=float(rs.choice([6, 12, 30])))
+  if rich and rs.rand() < 0.25:
+    settings['SequentialMode'] = True
+    for step, i in enumerate(rs.permutation(len(groups))):
+      settings[f'SequentialModeElements_{step:02d}'] = [groups[i]]
+  make.makeSimulationSettings(doc, **settings)
   src = make.makePointSource(doc)
   sc = bake.bakeScene(doc, src)
   sc.group_record = np.ones_like(sc.group_record)

@@ -11,7 +11,10 @@ from random_scenes import rays, scene
 pytestmark = pytest.mark.gpu
 
 
-def test_random_scenes_device_equals_oracle(native_lib, oracle):
+@pytest.mark.parametrize('rich', [False, True])
+def test_random_scenes_device_equals_oracle(native_lib, oracle, rich):
+  """rich: also tessellated solids (BVH kernels), stochastic surfaces, gratings, absorbing media,
+  partly reflecting mirrors, sequential mode"""
   from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
   n = 5000
   scenes = differing_rays = total = 0
@@ -19,17 +22,18 @@ def test_random_scenes_device_equals_oracle(native_lib, oracle):
     for s in range(40):
       rs = np.random.RandomState(7 * 100003 + s)
       try:
-        sc, lim, targets = scene(rs)
+        sc, lim, targets = scene(rs, rich)
       except Exception:               # a nesting the CSG flattening declines: not a parity matter
         continue
       o, d = rays(rs, targets, n)
       tr.setScene(sc); tr.setLimits(lim); tr.setDetector(None)
       tr.reserveHits(n * (lim.max_intersections + 1))
       tr.reset()
+      tr.setSurfaceSeed(s + 17)
       tr.traceRays(o, d)
       tr.sync()
       g = tr.hits()
-      r = oracle.trace_rays(sc, lim, o, d, nthreads=0)['hits']
+      r = oracle.trace_rays(sc, lim, o, d, nthreads=0, surface_seed=s + 17)['hits']
       scenes += 1
       total += n
       gr = (g['tag'] & np.uint64(0xFFFFFFFFFFFF)).astype(np.int64)
