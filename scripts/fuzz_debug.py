@@ -7,9 +7,10 @@ import numpy as np
 from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
 from oracle import capi as oracle
 from random_scenes import rays, scene
-seed0, s, n, rich = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4] == '1'
+seed0, s, n = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+rich, crowded = sys.argv[4] in ('1', '2'), sys.argv[4] in ('2', '3')
 rs = np.random.RandomState(seed0 * 100003 + s)
-sc, lim, targets = scene(rs, rich)
+sc, lim, targets = scene(rs, rich, crowded)
 o, d = rays(rs, targets, n)
 print('prims', sc.prim_type.tolist(), 'groups', sc.prim_group.tolist(), 'types', sc.group_type.tolist(), 'seq', sc.seq_enabled, [hex(int(m)) for m in sc.seq_mask],
       'samplers', [(x.group, x.kind, x.axis) for x in sc.surface_samplers], 'refl', sc.group_refl.tolist(), 'abslen', sc.group_abslen.tolist(), 'maxint', lim.max_intersections)

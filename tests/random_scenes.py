@@ -27,14 +27,16 @@ def solid(doc, rs, k, centre):
   return make.makeTorus(doc, f'T{k}', s, s * rs.uniform(0.15, 0.4), **pl)
 
 
-def scene(rs, rich=False):
+def scene(rs, rich=False, crowded=False):
   """rich: also tessellated solids (triangle primitives, BVH kernels), stochastic surfaces,
-  gratings, absorbing media, partly reflecting mirrors and sequential mode"""
+  gratings, absorbing media, partly reflecting mirrors and sequential mode;
+  crowded: 8-20 groups (more than 16 primitives: BVH kernels on analytic primitives with
+  trimming conditions) and the distance tolerances the reference's documents use (1e-6 ... 1e-2)"""
   doc = Document()
   targets = []
   k = 0
   groups = []
-  for g in range(rs.randint(2, 6)):
+  for g in range(rs.randint(8, 21) if crowded else rs.randint(2, 6)):
     centre = rs.uniform(-18, 18, 3)
     targets.append(centre)
     a = solid(doc, rs, k, centre); k += 1
@@ -67,6 +69,8 @@ def scene(rs, rich=False):
           props['RefractedProbabilityDensity'] = 'exp(-(theta-theta_refl)**2/0.005)'
     groups.append(make.makeOpticalGroup(doc, kind, [elem], **props))
   settings = dict(MaxIntersections=float(rs.choice([6, 12, 30])))
+  if crowded:
+    settings['DistanceTolerance'] = str(rs.choice(['1e-6', '1e-4', '1e-2']))
   if rich and rs.rand() < 0.25:
     settings['SequentialMode'] = True
     for step, i in enumerate(rs.permutation(len(groups))):
