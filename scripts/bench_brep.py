@@ -2,7 +2,7 @@
 """Throughput of the reference's cemented achromat (edmund-optics-lens.FCStd, two STEP imports):
 recognised as exact CSG (scene/brep_csg.py, the default), as facets (triangle primitives + BVH),
 and built by hand from exact spheres and a cylinder.  Measured on one MI355X, 2e7 rays:
-3.5e9 / 9.7e8 / 4.1e9 rays/s.
+4.4e9 / 1.0e9 / 4.3e9 rays/s.
   python scripts/bench_brep.py [rays]
 """
 import json
