@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Randomised parity of surface-source emission: random emitting solids (primitives, booleans,
+tessellated ones), random face selections, device `odw_generate_rays` vs oracle.
+  python scripts/fuzz_emitters.py [cases] [rays] [seed]
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np
+
+from freecad.optics_design_workbench_amd.freecad_elements import make, surface_source
+from freecad.optics_design_workbench_amd.scene import Document
+from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
+from oracle import capi as oracle
+import random_scenes
+from test_surface_source import _source
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 50000
+seed0 = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+bad = done = 0
+with Tracer(0) as tr:
+  for s in range(cases):
+    rs = np.random.RandomState(seed0 * 100003 + s)
+    doc = Document()
+    parts = []
+    for k in range(rs.randint(1, 4)):
+      a = random_scenes.solid(doc, rs, 10 * k, rs.uniform(-10, 10, 3))
+      r = rs.rand()
+      if r < 0.4:
+        subs = []
+        if a.TypeId == 'Part::Box' and rs.rand() < 0.5:
+          subs = [f'Face{i}' for i in sorted(rs.choice(np.arange(1, 7), rs.randint(1, 4), replace=False))]
+        parts.append((a, subs))
+      elif r < 0.6:
+        parts.append((make.makeTessellated(doc, a, int(rs.choice([6, 10, 16])), smooth=bool(rs.rand() < 0.5)), []))
+      else:
+        b = random_scenes.solid(doc, rs, 10 * k + 1, np.asarray(a.Placement.Base) + rs.normal(0, 1.5, 3))
+        op = rs.rand()
+        parts.append((make.makeCommon(doc, [a, b], f'X{k}') if op < 0.35 else make.makeCut(doc, a, b, f'X{k}') if op < 0.7
+                      else make.makeFuse(doc, [a, b], f'X{k}'), []))
+    try:
+      src = surface_source.bakeSurfaceSource(doc, _source(doc, parts, ThetaDomain=f'0, {rs.uniform(0.1, 1.5):.3f}',
+                                                          PowerDensity=str(rs.choice(['cos(theta)**2', '1', 'exp(-theta^2/0.05)']))))
+    except Exception as e:
+      continue
+    tr.setSource(src)
+    first = int(rs.randint(0, 1 << 30))
+    go, gd = tr.generateRays(first, n, 77 + s)
+    ro, rd = oracle.surface_rays(src, first, n, 77 + s)
+    done += 1
+    do, dd = np.abs(go - ro).max(), np.abs(gd - rd).max()
+    if do > 1e-9 or dd > 1e-9:
+      bad += 1
+      print(json.dumps(dict(case=s, origin_dev=float(do), dir_dev=float(dd), rays=int((np.abs(go - ro).max(axis=1) > 1e-9).sum()),
+                            prims=[int(x) for x in src.prim_type][:20])), flush=True)
+print(json.dumps(dict(cases=done, rays_each=n, differing=bad)))
