@@ -327,8 +327,10 @@ class Payload:
     if 'CASCADE Topology V' not in head:
       raise BRepError('not an OpenCASCADE BRep text payload')
     self.version = int(head.split('Topology V')[1][0])
-    if self.version > 2:
-      raise BRepError(f'BRep format version {self.version} is not read (V1 / V2 are)')
+    if self.version > 3:
+      raise BRepError(f'BRep format version {self.version} is not read (V1 - V3 are)')
+    # (V2 adds the UV end points of p-curves, V3 normals to stored triangulations -- which are
+    #  not read in any version)
     self._seek('Locations')
     self.locations = self._read_locations()
     self._seek('Curve2ds')
@@ -511,7 +513,7 @@ class Payload:
           pc, surf, loc = self._int(), self._int(), self._int()
           first, last = self._float(), self._float()
           if self.version >= 2:
-            self._floats(4)
+            self._floats(4)                   # UV of the two ends (written since format version 2)
           s.pcurves.append((pc, None, surf, loc, first, last))
         elif t == 3:
           pc = self._int()
@@ -523,7 +525,7 @@ class Payload:
           surf, loc = self._int(), self._int()
           first, last = self._float(), self._float()
           if self.version >= 2:
-            self._floats(8)
+            self._floats(4)                   # UV points of the second p-curve (UVPoints2)
           s.pcurves.append((pc, pc2, surf, loc, first, last))
         elif t == 4:
           self._next(); self._int(); self._int(); self._int(); self._int()

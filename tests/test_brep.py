@@ -356,3 +356,22 @@ def test_stored_shape_stands_in_where_the_recipe_ends(oracle):
   sphere.Radius = 4.0                             # ... shape-defining properties do
   with pytest.raises(UnsupportedGeometry, match='partial spheres'):
     geometry.solids_of(sphere)
+
+
+def test_format_version_2_payloads():
+  """since format version 2 every p-curve representation is followed by the UV of its two ends
+  (BRepTools_ShapeSet::WriteGeometry); version 3 only changes stored triangulations"""
+  import re
+  text = payload('nested-structure', 'Cylinder.Shape.brp').decode()
+  body = text.split('TShapes', 1)
+  # edge representations "2 <pcurve> <surface> <location> <first> <last>" and "3 <pc> <pc2><cont> ..."
+  v2 = re.sub(r'(?m)^(2  \d+ \d+ \d+ \S+ \S+)$', r'\1\n0.25 0.5 0.75 1', body[1])
+  v2 = re.sub(r'(?m)^(3  \d+ \d+\S* \d+ \d+ \S+ \S+)$', r'\1\n0.25 0.5 0.75 1', v2)
+  assert v2 != body[1]
+  for version in (2, 3):
+    P2 = brep.load(body[0].replace('Topology V1', f'Topology V{version}') + 'TShapes' + v2)
+    m1 = brep_mesh.tessellate(brep.load(text))
+    m2 = brep_mesh.tessellate(P2)
+    assert np.array_equal(m1.triangles, m2.triangles) and np.array_equal(m1.vertices, m2.vertices)
+  with pytest.raises(brep.BRepError, match='version 4'):
+    brep.load(text.replace('Topology V1', 'Topology V4'))
