@@ -20,6 +20,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# RCCL / cross-process device memory on this pool needs dmabuf IPC (the image exports it already)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 SCENE = os.path.join(ROOT, 'tests', 'golden', 'scenes', 'lensesAndMirrors.FCStd')
 SEED = 0x0D15EA5E
