@@ -375,3 +375,45 @@ def test_format_version_2_payloads():
     assert np.array_equal(m1.triangles, m2.triangles) and np.array_equal(m1.vertices, m2.vertices)
   with pytest.raises(brep.BRepError, match='version 4'):
     brep.load(text.replace('Topology V1', 'Topology V4'))
+
+
+@pytest.mark.parametrize('scene,obj', [('nested-structure', 'Body'), ('mirror', 'Body'), ('edmund-optics-lens', 'Part__Feature'),
+                                       ('edmund-optics-lens', 'Part__Feature001')])
+def test_recognised_solids_and_their_facets_are_hit_alike(oracle, scene, obj):
+  """the exact CSG a stored solid is recognised as, and the facets of the same solid: rays from all
+  around meet both in the same places (first hits within twice the deflection of the facets)"""
+  src_doc = open_fcstd(os.path.join(SCENES, scene + '.FCStd'))
+  part = src_doc.getObject(obj)
+  first_hits = []
+  for exact in (True, False):
+    doc = Document()
+    copy = doc.addObject(part.TypeId, 'Part', Shape=part._props['Shape'], Placement=part.Placement)
+    make.makeMirror(doc, [copy], RecordHits=True)
+    make.makeSimulationSettings(doc, MaxIntersections=1.0)
+    src = make.makePointSource(doc)
+    old = geometry.BREP_EXACT
+    geometry.BREP_EXACT = exact
+    try:
+      sc, lim = bake.bakeScene(doc, src), bake.bakeLimits(doc, src)
+    finally:
+      geometry.BREP_EXACT = old
+    assert ((sc.prim_type == 5).sum() == 0) == exact
+    if exact:
+      v = np.asarray(geometry.solids_of(copy, brepFacets=True)[0].mesh[0])
+      centre, size = (v.min(0) + v.max(0)) / 2, np.linalg.norm(v.max(0) - v.min(0))
+      centre = copy.Placement.m[:3, :3] @ centre + copy.Placement.m[:3, 3]
+      rs = np.random.RandomState(5)
+      o = rs.normal(0, 1, (6000, 3))
+      o = centre + o / np.linalg.norm(o, axis=1)[:, None] * 2.5 * size
+      d = centre + rs.normal(0, 0.3 * size, (6000, 3)) - o
+      d /= np.linalg.norm(d, axis=1)[:, None]
+    h = oracle.trace_rays(sc, lim, o, d, flags=1)['hits']
+    ray = (h['tag'] & np.uint64(0xFFFFFFFFFFFF)).astype(np.int64)
+    pts = np.full((len(o), 3), np.nan)
+    pts[ray] = h['point']
+    first_hits.append(pts)
+  a, b = first_hits
+  both = np.isfinite(a[:, 0]) & np.isfinite(b[:, 0])
+  assert both.sum() > 1500 and (np.isfinite(a[:, 0]) != np.isfinite(b[:, 0])).mean() < 0.01
+  dev = np.linalg.norm(a[both] - b[both], axis=1)
+  assert np.quantile(dev, 0.995) < 2e-2 * 1.0 and np.median(dev) < 2e-3, (np.median(dev), dev.max())
