@@ -85,6 +85,10 @@ def allPlacementsAndPaths(doc, obj, ignoreLinks=False, _depth=0):
     for pl, path in allPlacementsAndPaths(doc, c, ignoreLinks, _depth + 1):
       out.append((pl * own, (path[:-1] if transparent else path) + (obj.Name,)))
   for l in links:
+    if abs(geometry._link_scale(l) - 1.0) > 1e-12:
+      # (solids inside a scaled link are scaled by geometry.solids_of; an optical group or a light
+      #  source there would need a placement that is not rigid)
+      raise geometry.UnsupportedGeometry(f'{obj.Name} is reached through the scaled link {l.Name}')
     keep_own = own if bool(l._props.get('LinkTransform', False)) else Placement.identity()
     for pl, path in allPlacementsAndPaths(doc, l, ignoreLinks, _depth + 1):
       out.append((pl * keep_own, path + (obj.Name,)))

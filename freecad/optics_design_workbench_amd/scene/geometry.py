@@ -71,6 +71,36 @@ def _moved(nodes, placement):
   return out
 
 
+def _link_scale(obj):
+  """the uniform scale of an App::Link (properties Scale / ScaleVector); other scales have no
+  counterpart among the analytic primitives (a sphere would become an ellipsoid)"""
+  v = obj._props.get('ScaleVector')
+  s = obj._props.get('Scale')
+  if v is not None:
+    v = np.asarray(v, dtype=np.float64).ravel()
+    if len(v) == 3:
+      if np.abs(v - v[0]).max() > 1e-12 * max(1.0, abs(v[0])):
+        raise UnsupportedGeometry(f'{obj.Name}: link with a different scale per axis {v.tolist()}')
+      return float(v[0])
+  return float(s) if isinstance(s, (int, float)) else 1.0
+
+
+def _scaled(nodes, s, name=''):
+  """trees magnified by s about the origin of their container (App::Link.Scale)"""
+  if abs(s - 1.0) <= 1e-12:
+    return nodes
+  if not s > 0:
+    raise UnsupportedGeometry(f'{name}: link scale {s}')
+
+  def one(n):
+    pl = Placement(matrix=np.vstack([np.hstack([n.placement.m[:3, :3], (n.placement.m[:3, 3] * s)[:, None]]), [0, 0, 0, 1]]))
+    mesh = n.mesh
+    if mesh is not None:
+      mesh = (np.asarray(mesh[0]) * s,) + tuple(mesh[1:3])       # (face table and payload describe the unscaled shape)
+    return Node(n.op, pl, mesh, n.kind, tuple(p * s for p in n.params), [one(c) for c in n.children], n.source, n.facemask)
+  return [one(n) for n in nodes]
+
+
 def _is_draft_array(obj):
   return obj.ProxyClass == 'Array' and (obj.ProxyModule or '').startswith('draftobjects')
 
@@ -140,9 +170,13 @@ def _solids_by_recipe(obj, with_own_placement=True, _depth=0, brepFacets=False):
       count = int(obj._props.get('Count', len(plist)) or len(plist))
       if not bool((obj._props.get('Proxy') or {}).get('state', {}).get('use_link', True)):
         base = solids_of(target, _depth=_depth + 1, brepFacets=brepFacets)
+    base = _scaled(base, _link_scale(obj), obj.Name)
     if count > 0:
       if len(plist) < count:
         raise UnsupportedGeometry(f'{obj.Name}: array without stored PlacementList')
+      scales = obj._props.get('ScaleList')
+      if isinstance(scales, list) and any(np.abs(np.asarray(v, float) - 1.0).max() > 1e-12 for v in scales[:count]):
+        raise UnsupportedGeometry(f'{obj.Name}: link array with scaled elements')
       out = []
       for pl in plist[:count]:
         out.extend(_moved(base, pl))

@@ -87,3 +87,33 @@ def test_nested_body_is_baked_from_its_brep_payload():
   assert d.max() < 1e-9                                   # every facet corner is a corner of a placed prism
   d = np.abs(want[:, None, :] - tri[None, :, :]).sum(axis=2).min(axis=1)
   assert d.max() < 1e-9                                   # and every corner is used
+
+
+def test_link_scale():
+  """App::Link.Scale: solids shown through a scaled link are magnified about the link's origin;
+  a different scale per axis, and optical groups behind a scaled link, are refused"""
+  import pytest
+  from freecad.optics_design_workbench_amd.freecad_elements import make
+  from freecad.optics_design_workbench_amd.scene import Document, Placement, bake, geometry
+  doc = Document()
+  ball = make.makeSphere(doc, 'S', 2.0, base=(1, 0, 0))
+  box = make.makeBox(doc, 'B', 1, 2, 3, base=(0, 4, 0))
+  both = make.makeCommon(doc, [ball, make.makeCylinder(doc, 'C', 1.5, 8, base=(1, 0, -4))], 'X')
+  for target, check in ((ball, lambda n: n.kind == geometry.SPHERE and n.params[0] == 5.0 and np.allclose(n.placement.Base, (12.5, 20, 30))),
+                        (box, lambda n: n.params[:3] == (2.5, 5.0, 7.5) and np.allclose(n.placement.Base, (10, 30, 30))),
+                        (both, lambda n: n.op == 'common' and n.children[0].params[0] == 5.0
+                         and np.allclose(n.children[1].placement.Base, (2.5, 0, -10)) and n.children[1].params[:2] == (3.75, 20.0))):
+    link = doc.addObject('App::Link', 'L', LinkedObject=target, LinkTransform=True, Scale=2.5, ScaleVector=np.array([2.5, 2.5, 2.5]),
+                         Placement=Placement(base=(10, 20, 30)))
+    node, = geometry.solids_of(link)
+    assert check(node), node
+  link.ScaleVector = np.array([1.0, 2.0, 1.0])
+  with pytest.raises(geometry.UnsupportedGeometry, match='per axis'):
+    geometry.solids_of(link)
+  link.ScaleVector = np.array([2.0, 2.0, 2.0])
+  part = doc.addObject('App::Part', 'P', Group=[])
+  grp = make.makeMirror(doc, [box])
+  part.Group = [grp]
+  doc.addObject('App::Link', 'LP', LinkedObject=part, Scale=2.0, ScaleVector=np.array([2.0, 2.0, 2.0]))
+  with pytest.raises(geometry.UnsupportedGeometry, match='scaled link'):
+    bake.allPlacementsAndPaths(doc, grp)
