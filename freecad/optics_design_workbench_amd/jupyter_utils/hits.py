@@ -27,9 +27,62 @@ def _sphere_dirs(phis, thetas):
   return P, T, np.stack([np.cos(P) * np.sin(T), np.sin(P) * np.sin(T), np.cos(T)], axis=1)
 
 
+def _thinned(a, limit):
+  """every k-th row, k chosen so that about `limit` rows remain"""
+  return a[::1 + int(a.shape[0] / limit)]
+
+
+def _incoming_only(directions, entering):
+  """without the rows of rays leaving a transparent detector, unless leaving rays are the majority
+  (steadies the sign of the plane normal)"""
+  if np.sum(entering == 0) < .51 * len(entering):
+    return directions[entering != 0]
+  return directions
+
+
+def _flattest_direction(cloud, angleTol):
+  """direction along which the cloud has the smallest extent: 30 x 30 grid over half the unit sphere
+  (a plane has two normals), then 10 x 10 grids 1.1 cells around the best one until the cells are
+  smaller than angleTol"""
+  phis, thetas = np.linspace(0, np.pi, 30), np.linspace(-np.pi / 2, np.pi / 2, 30)
+  while True:
+    cell = (phis[1] - phis[0], thetas[1] - thetas[0])
+    P, T, normals = _sphere_dirs(phis, thetas)
+    extent = normals @ cloud.T
+    k = int(np.argmin(extent.max(axis=1) - extent.min(axis=1)))
+    phis = np.linspace(P[k] - 1.1 * cell[0], P[k] + 1.1 * cell[0], 10)
+    thetas = np.linspace(T[k] - 1.1 * cell[1], T[k] + 1.1 * cell[1], 10)
+    if max(phis[1] - phis[0], thetas[1] - thetas[0]) < angleTol:
+      return np.array([np.cos(P[k]) * np.sin(T[k]), np.sin(P[k]) * np.sin(T[k]), np.cos(T[k])])
+
+
+def _against(normal, rays):
+  """the normal or its opposite, whichever the rays run against: clear if 90 % of them agree,
+  else by the median, with a warning"""
+  along = rays @ normal
+  lo, mid, hi = np.quantile(along, 0.1), np.quantile(along, 0.5), np.quantile(along, 0.9)
+  if lo > 0:
+    return -normal
+  if hi < 0:
+    return normal
+  warnings.warn('unsure of result when trying to auto-detect sign of plane normal, '
+                'avoid relying on the sign of the planeNormal')
+  return -normal if mid < 0 else normal
+
+
+def _in_plane_x(normal, hint):
+  """x axis in the plane: normal x (normal x a), a = the hint or the coordinate axis that gives the
+  longest cross product (numerically safest); signed so that its components sum to >= 0"""
+  crosses = [np.cross(normal, a) for a in ([hint] if hint is not None else list(_UNIT))]
+  longest = crosses[int(np.argmax([np.linalg.norm(c) for c in crosses]))]
+  x = np.cross(normal, longest)
+  return -x if x.sum() < 0 else x
+
+
 class Hits:
   '''
-  Class representing a hit coordinate point cloud.
+  The hits of a simulation run as a point cloud with metadata columns: plane detection and
+  projection, histograms, plots, and the fan-mode estimates.
   '''
 
   def __init__(self, hits):
@@ -65,91 +118,61 @@ class Hits:
   # ---------------------------------------------------------------------
   def detectPlaneNormal(self, points=None, directions=None, planeNormal=None, xInPlaneVec=None,
                         maxPointCountConsidered=300, angleTol=1e-9):
-    if points is None:
-      points = self.points()
+    """(unit normal of the plane the hit cloud is flattest along, pointing against the incoming rays;
+    in-plane x axis) -- jupyter_utils/hits.py:96-174: nested angular grid search over half the sphere
+    on a thinned cloud, sign from the quantiles of direction . normal, x axis from the coordinate
+    axis least parallel to the normal (or the caller's hint)"""
+    cloud = self.points() if points is None else points
     if directions is None:
-      directions = self.directions()
-      entering = self.isEntering()
-      if np.sum(entering == 0) < .51 * len(entering):
-        directions = directions[entering != 0]
-    pts = points[::1 + int(points.shape[0] / maxPointCountConsidered)]
-    drs = directions[::1 + int(directions.shape[0] / maxPointCountConsidered)]
-
+      directions = _incoming_only(self.directions(), self.isEntering())
+    cloud, rays = _thinned(cloud, maxPointCountConsidered), _thinned(directions, maxPointCountConsidered)
     if planeNormal is None:
-      phis, thetas = np.linspace(0, np.pi, 30), np.linspace(-np.pi / 2, np.pi / 2, 30)
-      while True:
-        dphi, dtheta = phis[1] - phis[0], thetas[1] - thetas[0]
-        P, T, normals = _sphere_dirs(phis, thetas)
-        proj = normals @ pts.T
-        k = int(np.argmin(proj.max(axis=1) - proj.min(axis=1)))
-        phis = np.linspace(P[k] - 1.1 * dphi, P[k] + 1.1 * dphi, 10)
-        thetas = np.linspace(T[k] - 1.1 * dtheta, T[k] + 1.1 * dtheta, 10)
-        if phis[1] - phis[0] < angleTol and thetas[1] - thetas[0] < angleTol:
-          planeNormal = np.array([np.cos(P[k]) * np.sin(T[k]), np.sin(P[k]) * np.sin(T[k]), np.cos(T[k])])
-          break
-
-    # the normal points against the incoming rays
-    along = drs @ planeNormal
-    if np.quantile(along, 0.1) > 0:
-      planeNormal = -planeNormal
-    elif np.quantile(along, 0.9) >= 0:
-      if np.quantile(along, 0.5) < 0:
-        planeNormal = -planeNormal
-      warnings.warn('unsure of result when trying to auto-detect sign of plane normal, '
-                    'avoid relying on the sign of the planeNormal')
-
-    axes = [xInPlaneVec] if xInPlaneVec is not None else list(_UNIT)
-    crosses = [np.cross(planeNormal, a) for a in axes]
-    projY = crosses[int(np.argmax([np.linalg.norm(c) for c in crosses]))]
-    xInPlaneVec = np.cross(planeNormal, projY)
-    if xInPlaneVec.sum() < 0:
-      xInPlaneVec = -xInPlaneVec
-    return planeNormal, xInPlaneVec
+      planeNormal = _flattest_direction(cloud, angleTol)
+    planeNormal = _against(planeNormal, rays)
+    return planeNormal, _in_plane_x(planeNormal, xInPlaneVec)
 
   def planeProject3dPoints(self, points=None, planeNormal=None, xInPlaneVec=None, returnZ=False):
+    """(n, 2) coordinates in the plane's own axes (x, normal x x); returnZ adds the height above it"""
     if points is None:
       points = self.points()
     if planeNormal is None or xInPlaneVec is None:
       planeNormal, xInPlaneVec = self.detectPlaneNormal(planeNormal=planeNormal, xInPlaneVec=xInPlaneVec)
-    ex = xInPlaneVec / np.linalg.norm(xInPlaneVec)
-    ey = np.cross(planeNormal, xInPlaneVec)
-    ey = ey / np.linalg.norm(ey)
-    cols = [np.dot(points, ex), np.dot(points, ey)]
-    if returnZ:
-      cols.append(np.dot(points, planeNormal / np.linalg.norm(planeNormal)))
-    return np.array(cols).T
+    axes = [xInPlaneVec, np.cross(planeNormal, xInPlaneVec)] + ([planeNormal] if returnZ else [])
+    return np.array([np.dot(points, a / np.linalg.norm(a)) for a in axes]).T
+
+  def _flat(self, key, planeNormal, xInPlaneVec, detectOn=None):
+    """columns of hits[key] in plane coordinates + the plane used"""
+    if planeNormal is None or xInPlaneVec is None:
+      planeNormal, xInPlaneVec = self.detectPlaneNormal(points=detectOn, planeNormal=planeNormal, xInPlaneVec=xInPlaneVec)
+    xy = self.planeProject3dPoints(self.hits[key], planeNormal=planeNormal, xInPlaneVec=xInPlaneVec)
+    return xy[:, 0], xy[:, 1], planeNormal, xInPlaneVec
 
   def histogram(self, planeNormal=None, xInPlaneVec=None, key='points', **kwargs):
-    points = self.hits[key]
-    if planeNormal is None or xInPlaneVec is None:
-      planeNormal, xInPlaneVec = self.detectPlaneNormal(planeNormal=planeNormal, xInPlaneVec=xInPlaneVec)
-    X, Y = self.planeProject3dPoints(points, planeNormal=planeNormal, xInPlaneVec=xInPlaneVec).T
-    return Histogram(X, Y, planeNormal=planeNormal, xInPlaneVec=xInPlaneVec, **kwargs)
+    x, y, n, ex = self._flat(key, planeNormal, xInPlaneVec)
+    return Histogram(x, y, planeNormal=n, xInPlaneVec=ex, **kwargs)
 
   def plot(self, hueKey=None, hueLabel=None, planeNormal=None, xInPlaneVec=None, plotKey='points', **kwargs):
-    """scatter plot of the hits projected into their plane, optionally coloured by a metadata
-    column (jupyter_utils/hits.py:196-222)"""
-    import matplotlib.pyplot as plt
+    """scatter plot of the hits in plane coordinates, optionally coloured by a metadata column
+    (jupyter_utils/hits.py:196-222); None if there is nothing to plot"""
     if plotKey not in self.hits:
       return None
-    if planeNormal is None or xInPlaneVec is None:
-      planeNormal, xInPlaneVec = self.detectPlaneNormal(points=self.hits[plotKey], planeNormal=planeNormal,
-                                                        xInPlaneVec=xInPlaneVec)
-    X, Y = self.planeProject3dPoints(self.hits[plotKey], planeNormal=planeNormal, xInPlaneVec=xInPlaneVec).T
-    kwargs.setdefault('s', 4)
-    if hueKey is not None:
-      sc = plt.scatter(X, Y, c=np.asarray(self.hits[hueKey]), cmap=kwargs.pop('cmap', 'hsv'), **kwargs)
-      plt.colorbar(sc).set_label(hueLabel or hueKey)
+    import matplotlib.pyplot as plt
+    x, y, n, ex = self._flat(plotKey, planeNormal, xInPlaneVec, detectOn=self.hits[plotKey])
+    style = dict(s=4)
+    style.update(kwargs)
+    if hueKey is None:
+      dots = plt.scatter(x, y, **style)
     else:
-      sc = plt.scatter(X, Y, **kwargs)
-    n, p = planeNormal, xInPlaneVec
-    plt.title(f'plane normal = [{n[0]:.2f}, {n[1]:.2f}, {n[2]:.2f}],\n'
-              f'projected $x$ = [{p[0]:.2f}, {p[1]:.2f}, {p[2]:.2f}]', fontsize=10)
-    plt.xlabel('projected $x$')
-    plt.ylabel('projected $y$')
-    plt.gca().axis('equal')
-    plt.gca().set_aspect('equal')
-    return sc
+      style.setdefault('cmap', 'hsv')
+      dots = plt.scatter(x, y, c=np.asarray(self.hits[hueKey]), **style)
+      plt.colorbar(dots).set_label(hueKey if hueLabel is None else hueLabel)
+    ax = plt.gca()
+    ax.set_title('plane normal = [%.2f, %.2f, %.2f],\nprojected $x$ = [%.2f, %.2f, %.2f]' % (*n, *ex), fontsize=10)
+    ax.set_xlabel('projected $x$')
+    ax.set_ylabel('projected $y$')
+    ax.axis('equal')
+    ax.set_aspect('equal')
+    return dots
 
   # ====================================================
   # fan math (jupyter_utils/hits.py:227-444)
@@ -158,13 +181,13 @@ class Hits:
     return all(k in self.hits.keys() for k in ('rayIndex', 'fanIndex', 'totalRaysInFan'))
 
   def _raiseIfNotFanMath(self):
+    if self.supportsFanMath():
+      return
+    need = 'fan math needs the metadata columns rayIndex, fanIndex and totalRaysInFan'
     if not len(self.hits):
-      raise ValueError('keys rayIndex, fanIndex and totalRaysInFan must exist in hits dictionary, '
-                       'but hits dictionary is empty')
-    if not self.supportsFanMath():
-      raise ValueError('keys rayIndex, fanIndex and totalRaysInFan must exist in hits dictionary, '
-                       'make sure you simulated in fan mode and enabled storing the respective metadata keys '
-                       'in the active SimulationSettings')
+      raise ValueError(need + ', but there are no hits at all')
+    raise ValueError(need + ': simulate in fan mode with StoreHitRayIndex, StoreHitFanIndex and '
+                     'StoreHitTotalRaysInFan switched on in the active simulation settings')
 
   def raysPerFan(self):
     self._raiseIfNotFanMath()
@@ -182,16 +205,18 @@ class Hits:
     """projected position of the central ray: ray 0 of each fan, or the
     midpoint of rays +1/-1 where ray 0 is absent; averaged over fans"""
     self._raiseIfNotFanMath()
-    rI, fI = self.hits['rayIndex'], self.hits['fanIndex']
-    pXY = self.planeProject3dPoints(self.hits['points'], **kwargs)
-    centers = []
-    for fanI in set(fI):
-      mine = fI == fanI
-      if 0 in rI[mine]:
-        centers.extend(pXY[mine & (rI == 0)])
-      elif +1 in rI[mine] and -1 in rI[mine]:
-        centers.extend((pXY[mine & (rI == +1)] + pXY[mine & (rI == -1)]) / 2)
-    return np.mean(centers, axis=0) if len(centers) else np.array([np.nan, np.nan])
+    ray, fan = self.hits['rayIndex'], self.hits['fanIndex']
+    xy = self.planeProject3dPoints(self.hits['points'], **kwargs)
+    found = []
+    for f in set(fan):
+      at = {i: xy[(fan == f) & (ray == i)] for i in (0, 1, -1)}
+      if len(at[0]):
+        found.extend(at[0])
+      elif len(at[1]) and len(at[-1]):
+        found.extend((at[1] + at[-1]) / 2)
+    if not found:
+      return np.array([np.nan, np.nan])
+    return np.mean(found, axis=0)
 
   def _fanGeometry(self, pCenter=None, **kwargs):
     key = ('geometry', None if pCenter is None else tuple(pCenter), tuple(sorted(kwargs.items())))
@@ -285,21 +310,24 @@ class Hits:
       return cache[key]
     if pCenter is None:
       pCenter = self.fanCenter()
-    cfI, crI, cdist = self.fanCenterDists(pCenter=pCenter)
-    nfI, nrI, ndist = self.fanNeighborDists()
+    c_fan, c_ray, c_dist = self.fanCenterDists(pCenter=pCenter)
+    n_fan, n_mid, n_dist = self.fanNeighborDists()
+
+    def radius(f, i):          # signed distance of ray i of fan f from the centre
+      return np.mean(c_dist[(c_fan == f) & (c_ray == i)])
     densities, caustics = {}, {}
-    for fanI in sorted(set(nfI)):
-      densities[fanI], caustics[fanI] = [], []
-      for between in sorted(nrI[fanI == nfI]):
-        # the two rays around the half-integer index (.6: around 0 these are -1 and +1)
-        r1, r2 = int(round(between - .6)), int(round(between + .6))
-        d1 = np.mean(cdist[(fanI == cfI) & (crI == r1)])
-        d2 = np.mean(cdist[(fanI == cfI) & (crI == r2)])
-        power = 1 / np.mean(ndist[(fanI == nfI) & (nrI == between)])
-        if d2 < d1:        # order of the rays reversed: a caustic fold
-          caustics[fanI].append([d2, d1, power])
+    for f in sorted(set(n_fan)):
+      smooth, folds = [], []
+      for mid in sorted(n_mid[n_fan == f]):
+        # the gap between two neighbouring rays, labelled by the mean of their indices: the rays are
+        # the integers .6 below and above it (around 0 that picks -1 and +1 when ray 0 is missing)
+        inner, outer = radius(f, int(round(mid - .6))), radius(f, int(round(mid + .6)))
+        power = 1 / np.mean(n_dist[(n_fan == f) & (n_mid == mid)])
+        if outer < inner:      # the rays have changed places: a caustic fold
+          folds.append([outer, inner, power])
         else:
-          densities[fanI].append([np.mean([d1, d2]), power])
+          smooth.append([np.mean([inner, outer]), power])
+      densities[f], caustics[f] = smooth, folds
     densityFuncs = {i: (lambda pos, _d=np.array(d).T: np.interp(pos, *_d, left=0, right=0))
                     for i, d in densities.items()}
     causticFuncs = {i: (lambda p1, p2, _d=np.array(d): sum(1 + abs(r1 - r2) for r1, r2, p in _d
