@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""one scene of the randomised parity run in detail: python scripts/fuzz_debug.py seed scene rays rich"""
+"""one scene of the randomised parity run in detail: python tests/fuzz_debug.py seed scene rays rich"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))   # TEST INFRASTRUCTURE
 import numpy as np
 from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
 from oracle import capi as oracle

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity of surface-source emission: random emitting solids (primitives, booleans,
 tessellated ones), random face selections, device `odw_generate_rays` vs oracle.
-  python scripts/fuzz_emitters.py [cases] [rays] [seed]
+  python tests/fuzz_emitters.py [cases] [rays] [seed]
 """
 import json
 import os
@@ -9,7 +9,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, os.path.join(ROOT, 'tests'))   # TEST INFRASTRUCTURE: a checker that runs the oracle next to the device
 import numpy as np
 
 from freecad.optics_design_workbench_amd.freecad_elements import make, surface_source

@@ -2,7 +2,7 @@
 """Randomised parity: random scenes of primitives and booleans (random kinds, sizes, placements,
 optical types, overlaps), random rays aimed at them, device vs oracle on whole trajectories
 (all groups record).  Prints one JSON line per scene that differs and a summary.
-  python scripts/fuzz_parity.py [scenes] [rays] [seed] [rich]
+  python tests/fuzz_parity.py [scenes] [rays] [seed] [rich]
 (rich = 1: also tessellated solids, stochastic surfaces, gratings, absorbing media, sequential mode;
  3: crowded scenes of 8-20 groups with the reference's distance tolerances; 2: both)
 Differences are classified: `tags` (a different sequence of hits: a real disagreement unless the

@@ -2,7 +2,7 @@
 """Randomised parity of the sampler path: random point sources (density expression, focal length
 finite / negative / infinite, domains, placement) over random scenes, `odw_trace` with a random
 detector window (any plane, all groups) and the segment list, device vs oracle.
-  python scripts/fuzz_sources.py [scenes] [rays] [seed]
+  python tests/fuzz_sources.py [scenes] [rays] [seed]
 """
 import json
 import os
@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, os.path.join(ROOT, 'tests'))   # TEST INFRASTRUCTURE: a checker that runs the oracle next to the device
 import numpy as np
 
 from freecad.optics_design_workbench_amd.freecad_elements import make

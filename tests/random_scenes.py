@@ -1,4 +1,4 @@
-"""Random scenes for the randomised parity checks (tests/test_gpu_fuzz.py, scripts/fuzz_parity.py):
+"""Random scenes for the randomised parity checks (tests/test_gpu_fuzz.py, tests/fuzz_parity.py):
 primitives and booleans of random kind, size and placement, overlapping at random, in optical groups
 of random type; all groups record, so whole trajectories are compared.  TEST INFRASTRUCTURE."""
 import numpy as np

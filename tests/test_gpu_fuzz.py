@@ -1,5 +1,5 @@
 """Randomised parity (-m gpu): 40 random scenes (tests/random_scenes.py) x 5000 rays, device vs
-oracle on whole trajectories.  `scripts/fuzz_parity.py` is the long form (150 scenes x 20000 rays,
+oracle on whole trajectories.  `tests/fuzz_parity.py` is the long form (150 scenes x 20000 rays,
 round 1: 141 scenes identical to 1e-7 mm, 8 with rounding amplified along trapped multi-bounce
 paths -- deviations grow geometrically from 1e-12 --, one ray of 3e6 with a different hit sequence
 after 30 bounces between tori)."""
