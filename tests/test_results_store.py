@@ -301,3 +301,28 @@ def test_histogram_plots():
   assert len(sc.get_offsets()) == 500 and 'plane normal' in plt.gca().get_title()
   assert Hits({}).plot() is None
   plt.close('all')
+
+
+@pytest.mark.gpu
+def test_recorded_rays_and_surface_fans_through_the_document_api(native_lib):
+  """the whole stack on the device: RecordRays -> `*-rays.pkl` -> loadRays; fan mode of a surface
+  source (test/21-simulation-modes/main.FCStd) and of an imported shape's faces (test/80)"""
+  from conftest import SCENES
+  from freecad.optics_design_workbench_amd.jupyter_utils import FreecadDocument
+  with FreecadDocument(os.path.join(SCENES, 'GettingStarted.FCStd'), workInTempCopy=True) as f:
+    f.OpticalPointSource.RecordRays = True
+    f.OpticalSimulationSettings.EndAfterRays = '250'
+    raw = f.runSimulation('true')
+    rays = raw.loadRays()
+    assert len(rays) == raw.loadProgress()['totalTracedRays'] > 250
+    ends = {tuple(r['points'][-1]) for r in rays}
+    assert all(tuple(p) in ends for p in raw.loadHits('*').points())
+    assert all(len(r['media']) == len(r['powers']) == len(r['points']) - 1 for r in rays)
+    assert any('OpticalLensGroup' in r['media'] for r in rays)
+  with FreecadDocument(os.path.join(SCENES, 'simulation-modes-main.FCStd'), workInTempCopy=True) as f:
+    raw = f.runSimulation('fans')
+    assert raw.loadProgress()['totalTracedRays'] == 121 and len(raw.loadHits('*')) > 20
+  with FreecadDocument(os.path.join(SCENES, 'imported-stepfile-as-surface-source.FCStd'), workInTempCopy=True) as f:
+    f.OpticalSimulationSettings.EndAfterRays = '2e4'
+    assert 80 < f.runSimulation('fans').loadProgress()['totalTracedRays'] < 160
+    assert f.runSimulation('true').loadProgress()['totalTracedRays'] > 2e4
