@@ -703,6 +703,12 @@ int odw_upload_scene(odw_ctx* ctx, const odw_scene_desc* s) {
     } else {
       std::memcpy(&ctx->h_prim_f64[16 * (size_t)p], s->prim_xform + 12 * (size_t)p, 12 * sizeof(double));
       std::memcpy(&ctx->h_prim_f64[16 * (size_t)p + 12], s->prim_params + 4 * (size_t)p, 4 * sizeof(double));
+      if (type == ODW_PRIM_SPHERE) {
+        // the kernel intersects spheres without their frame: centre in global coordinates = -R^T t
+        const double* m = &ctx->h_prim_f64[16 * (size_t)p];
+        for (int k = 0; k < 3; ++k)
+          ctx->h_prim_f64[16 * (size_t)p + 13 + k] = -(m[k] * m[3] + m[4 + k] * m[7] + m[8 + k] * m[11]);
+      }
     }
     ctx->h_prim_i32[4 * p] = type;
     ctx->h_prim_i32[4 * p + 1] = group;

@@ -369,12 +369,22 @@ __device__ __forceinline__ void intersect_prim(const SceneView& sv, Query& q, in
   const int fmask = (flags >> ODW_FACEMASK_SHIFT) & 0xff;
   cf64 par = pf + 12;
   const double tol = q.tol;
-  const d3 o = xf_point(pf, q.start);
-  const d3 d = xf_vec(pf, q.dn);
   Cands c;
   c.t0 = c.t1 = c.t2 = c.t3 = INFINITY;
   c.f0 = c.f1 = c.f2 = c.f3 = 0;
-
+  if (type == ODW_PRIM_SPHERE) {
+    // a sphere needs no frame: par[1..3] = its centre in global coordinates (filled in by the host)
+    if (fmask & 1) {
+      const d3 oc = q.start - mk(par[1], par[2], par[3]);
+      double t0, t1;
+      if (quad_roots_unit(dot(oc, q.dn), dot(oc, oc) - par[0] * par[0], t0, t1) == 2) {
+        c.t0 = t0;
+        c.t1 = t1;
+      }
+    }
+  } else {
+  const d3 o = xf_point(pf, q.start);
+  const d3 d = xf_vec(pf, q.dn);
   if (type == ODW_PRIM_BOX) {
     // Slab form of the six plane tests.  Per axis the ray meets the low/high
     // plane at tn <= tf; a face hit is valid when the other two coordinates lie
@@ -418,14 +428,6 @@ __device__ __forceinline__ void intersect_prim(const SceneView& sv, Query& q, in
       c.f1 = bf;
     }
 #undef ODW_BOX_FACE
-  } else if (type == ODW_PRIM_SPHERE) {
-    if (fmask & 1) {
-      double t0, t1;
-      if (quad_roots_unit(dot(o, d), dot(o, o) - par[0] * par[0], t0, t1) == 2) {
-        c.t0 = t0;
-        c.t1 = t1;
-      }
-    }
   } else if (type == ODW_PRIM_CYLINDER || type == ODW_PRIM_CONE) {
     const double R1 = par[0];
     const double R2 = (type == ODW_PRIM_CYLINDER) ? par[0] : par[1];
@@ -548,6 +550,7 @@ __device__ __forceinline__ void intersect_prim(const SceneView& sv, Query& q, in
       fc = fn;
     }
   }
+  }
   if (cond_cnt == 0) {
     // untrimmed: only the nearest admissible candidate can win
     double bt = INFINITY;
@@ -569,6 +572,14 @@ __device__ __forceinline__ void intersect_prim(const SceneView& sv, Query& q, in
   }
 }
 
+// squared distance of the point w from the segment 0 -> e
+__device__ __forceinline__ double seg_dist2(d3 w, d3 e) {
+#pragma clang fp contract(off)
+  const double s = fmin(fmax(dot(w, e) / dot(e, e), 0.0), 1.0);
+  const d3 r = w - e * s;
+  return dot(r, r);
+}
+
 // One facet of a tessellated face (ODW_PRIM_TRIANGLE, BVH kernels only):
 // Moeller-Trumbore in float64; prim_f64 rows = v0, e1, e2, unit facet normal,
 // then the barycentric slack per unit of tolerance (a hit within distTol of
@@ -586,6 +597,16 @@ __device__ __forceinline__ void intersect_tri(const SceneView& sv, Query& q, int
   const double v = dot(q.dn, qv) * inv;
   const double tol = q.tol;
   if (u < -tol * pf[12] || v < -tol * pf[13] || u + v > 1.0 + tol * pf[14]) return;
+  if (u < 0 || v < 0 || u + v > 1.0) {
+    // in the rim the bounds above allow (a parallelogram around the facet, far too long for
+    // slivers): the distance to the facet itself decides
+#pragma clang fp contract(off)
+    const d3 w = e1 * u + e2 * v;                      // hit point - v0, in the facet's plane
+    double best = seg_dist2(w, e1);
+    best = fmin(best, seg_dist2(w, e2));
+    best = fmin(best, seg_dist2(w - e1, e2 - e1));
+    if (best > tol * tol) return;
+  }
   consider(sv, q, dot(e2, qv) * inv, p, 0, group, 0, 0);
 }
 

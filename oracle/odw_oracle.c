@@ -435,6 +435,15 @@ static int prim_candidates(int type, const double* par, int facemask, v3 o, v3 d
   return n;
 }
 
+/* squared distance of the point w from the segment 0 -> e */
+static double seg_dist2(v3 w, v3 e) {
+  double s = dot(w, e) / dot(e, e);
+  if (s < 0) s = 0;
+  if (s > 1) s = 1;
+  v3 r = sub(w, mul(e, s));
+  return dot(r, r);
+}
+
 /* ------------------------------------------------------------------ */
 /* findNearestIntersection (ray.py:290-452)                            */
 /* ------------------------------------------------------------------ */
@@ -503,6 +512,17 @@ static nearest_hit nearest_skipping(const odw_scene_desc* sc, const odw_limits* 
       double v = dot(dn, qv) / det;
       if (u < -tol * (len(e2) / a2) || v < -tol * (len(e1) / a2) || u + v > 1.0 + tol * (len(sub(e2, e1)) / a2))
         continue;
+      if (u < 0 || v < 0 || u + v > 1.0) {
+        /* in the rim the bounds above allow (a parallelogram around the facet, far too long for
+         * slivers): the distance to the facet itself decides */
+        v3 w = add(mul(e1, u), mul(e2, v));              /* hit point - v0, in the facet's plane */
+        double best = seg_dist2(w, e1);
+        double other = seg_dist2(w, e2);
+        if (other < best) best = other;
+        other = seg_dist2(sub(w, e1), sub(e2, e1));
+        if (other < best) best = other;
+        if (best > tol * tol) continue;
+      }
       double t = dot(e2, qv) / det;
       if (!(t > tol) || !(t < max_len + tol)) continue;
       v3 gp = add(start, mul(dn, t));

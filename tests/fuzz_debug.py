@@ -4,6 +4,9 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))   # TEST INFRASTRUCTURE
 import numpy as np
+from freecad.optics_design_workbench_amd import _native
+if os.environ.get('ODW_VARIANT_LIB'):
+  _native.LIB_PATH = os.path.abspath(os.environ['ODW_VARIANT_LIB'])
 from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
 from oracle import capi as oracle
 from random_scenes import rays, scene
