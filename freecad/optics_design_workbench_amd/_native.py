@@ -46,7 +46,7 @@ class SceneDesc(C.Structure):
               ('group_abslen', _pd), ('group_record', _pi), ('group_grating_type', _pi),
               ('group_grating_lpm', _pd), ('group_grating_dir', _pd), ('group_grating_order', _pi),
               ('seq_enabled', C.c_int32), ('seq_len', C.c_int32), ('seq_mask', _pu),
-              ('ignore_mask', C.c_uint64), ('tri_normals', _pd)]
+              ('ignore_mask', C.c_uint64), ('tri_normals', _pd), ('tri_edges', _pi)]
 
 
 class SourceDesc(C.Structure):
@@ -178,6 +178,11 @@ def scene_desc(sc):
   if getattr(sc, 'tri_normals', None) is not None:
     keep['tri_normals'] = keep_tri
     d.tri_normals = keep_tri.ctypes.data_as(_pd)
+  if getattr(sc, 'tri_edges', None) is not None:
+    keep['tri_edges'] = _arr(sc.tri_edges, np.int32)
+    if len(keep['tri_edges']) != len(sc.prim_type):
+      raise ValueError('tri_edges needs one entry per primitive')
+    d.tri_edges = keep['tri_edges'].ctypes.data_as(_pi)
   return d, keep
 
 

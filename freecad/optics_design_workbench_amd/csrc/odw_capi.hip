@@ -699,6 +699,10 @@ int odw_upload_scene(odw_ctx* ctx, const odw_scene_desc* s) {
       d[12] = len3(e2) / a2;   // u: distance from edge (v0, v2)
       d[13] = len3(e1) / a2;   // v: distance from edge (v0, v1)
       d[14] = len3(e3) / a2;   // u+v: distance from edge (v1, v2)
+      // edges shared with a neighbouring facet of the same face are not widened (sign = marker)
+      const int face_edges = s->tri_edges ? s->tri_edges[p] : 7;
+      for (int k = 0; k < 3; ++k)
+        if (!((face_edges >> k) & 1)) d[12 + k] = -d[12 + k];
       d[15] = 0.0;
     } else {
       std::memcpy(&ctx->h_prim_f64[16 * (size_t)p], s->prim_xform + 12 * (size_t)p, 12 * sizeof(double));

@@ -596,9 +596,12 @@ __device__ __forceinline__ void intersect_tri(const SceneView& sv, Query& q, int
   const d3 qv = cross(tv, e1);
   const double v = dot(q.dn, qv) * inv;
   const double tol = q.tol;
-  if (u < -tol * pf[12] || v < -tol * pf[13] || u + v > 1.0 + tol * pf[14]) return;
-  if (u < 0 || v < 0 || u + v > 1.0) {
-    // in the rim the bounds above allow (a parallelogram around the facet, far too long for
+  // per edge: reach of the tolerance in barycentric units; negative = an edge shared with a
+  // neighbouring facet of the same face: closed up to rounding
+  const double s0 = pf[12], s1 = pf[13], s2 = pf[14];
+  if (u < -(s0 < 0 ? 1e-9 : tol * s0) || v < -(s1 < 0 ? 1e-9 : tol * s1) || u + v > 1.0 + (s2 < 0 ? 1e-9 : tol * s2)) return;
+  if ((u < 0 && s0 >= 0) || (v < 0 && s1 >= 0) || (u + v > 1.0 && s2 >= 0)) {
+    // beyond an edge of the face, inside the parallelogram the bounds above allow (far too long for
     // slivers): the distance to the facet itself decides
 #pragma clang fp contract(off)
     const d3 w = e1 * u + e2 * v;                      // hit point - v0, in the facet's plane

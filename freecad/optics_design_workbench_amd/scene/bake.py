@@ -204,6 +204,7 @@ class BakedScene:
   prim_to_world: list = field(default_factory=list)
   surface_samplers: list = field(default_factory=list)   # freecad_elements.optical_group.BakedSurfaceSampler
   tri_normals: np.ndarray = None                         # (n_prims, 9) vertex normals of TRIANGLE primitives, or None
+  tri_edges: np.ndarray = None                           # (n_prims,) bits: which facet edges are edges of the face
 
   @property
   def n_prims(self):
@@ -237,6 +238,33 @@ def _abslen(v):
     return float(v)
   except (TypeError, ValueError):
     return float('inf')
+
+
+def faceEdgeBits(tri, vertices=None):
+  """per facet, which of its edges belong to one facet only (bit 0: v0-v2, bit 1: v0-v1, bit 2: v1-v2):
+  the edges of the tessellated face.  A face = the facets connected through shared vertex indices
+  (different faces of a solid have their own vertices, so the seam between two faces is an edge of
+  both); inside a face, vertices at the same place count as one (the seam of a periodic surface and
+  the pole of a fan are stored once per column)."""
+  tri = np.asarray(tri, dtype=np.int64)
+  ids = tri
+  if vertices is not None and len(tri):
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    v = np.asarray(vertices, dtype=np.float64)
+    n = len(v)
+    rows = np.concatenate([tri[:, 0], tri[:, 1], tri[:, 2]])
+    cols = np.concatenate([tri[:, 1], tri[:, 2], tri[:, 0]])
+    _, comp = connected_components(coo_matrix((np.ones(len(rows)), (rows, cols)), shape=(n, n)), directed=False)
+    scale = max(float(np.abs(v).max()), 1e-300)
+    key = np.concatenate([comp[:, None], np.round(v / (1e-9 * scale)).astype(np.int64)], axis=1)
+    _, welded = np.unique(key, axis=0, return_inverse=True)
+    ids = welded.ravel()[tri]
+  pairs = np.stack([ids[:, [0, 2]], ids[:, [0, 1]], ids[:, [1, 2]]], axis=1)          # (m, 3, 2)
+  key = np.sort(pairs, axis=2).reshape(-1, 2)
+  _, inv, cnt = np.unique(key, axis=0, return_inverse=True, return_counts=True)
+  single = (cnt[inv.ravel()] == 1).reshape(-1, 3)
+  return (single[:, 0] * 1 + single[:, 1] * 2 + single[:, 2] * 4).astype(np.int32)
 
 
 def bakeScene(doc, source=None, surfaceFamily=None):
@@ -316,9 +344,11 @@ def bakeScene(doc, source=None, surfaceFamily=None):
   tri_xform = np.zeros((n_tri, 12))
   tri_group, tri_solid = np.zeros(n_tri, dtype=np.int32), np.zeros(n_tri, dtype=np.int32)
   tri_normals = np.zeros((n + n_tri, 9)) if any(m[4] is not None for m in meshes) else None
+  tri_edges = np.full(n + n_tri, 7, dtype=np.int32) if n_tri else None
   at = 0
   for gi, sid, v, tri, vn, _ in meshes:
     k = len(tri)
+    tri_edges[n + at:n + at + k] = faceEdgeBits(tri, v)
     tri_xform[at:at + k, 0:9] = v[tri].reshape(k, 9)
     tri_group[at:at + k], tri_solid[at:at + k] = gi, sid
     if tri_normals is not None:
@@ -332,7 +362,7 @@ def bakeScene(doc, source=None, surfaceFamily=None):
   cond_off = cond_off + [cond_off[-1]] * n_tri
 
   return BakedScene(
-      tri_normals=tri_normals,
+      tri_normals=tri_normals, tri_edges=tri_edges,
       prim_type=np.concatenate([np.array([p.kind for p in prims], dtype=np.int32),
                                 np.full(n_tri, geometry.TRIANGLE, dtype=np.int32)]),
       prim_group=np.concatenate([np.array(prim_group, dtype=np.int32), tri_group]),

@@ -123,6 +123,11 @@ typedef struct odw_scene_desc {
    * three vertices of each TRIANGLE primitive (rows of other primitives are
    * ignored); NULL: facet normals                                           */
   const double* tri_normals;    /* [n_prims*9] or NULL                        */
+  /* which edges of a TRIANGLE primitive are edges of the tessellated FACE (bit 0: edge v0-v2,
+   * bit 1: v0-v1, bit 2: v1-v2).  "Within distTol of the face" (ray.py:424-426) widens a facet
+   * across those only; across edges it shares with a neighbouring facet of the same face it is
+   * closed up to rounding (1e-9 in barycentric units).  NULL: every edge is a face edge.      */
+  const int32_t* tri_edges;     /* [n_prims] or NULL                          */
 } odw_scene_desc;
 
 /* Point source = PointSourceProxy (point_source.py:32-70) after

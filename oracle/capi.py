@@ -35,7 +35,7 @@ class SceneDesc(C.Structure):
               ('group_abslen', _pd), ('group_record', _pi), ('group_grating_type', _pi),
               ('group_grating_lpm', _pd), ('group_grating_dir', _pd), ('group_grating_order', _pi),
               ('seq_enabled', C.c_int32), ('seq_len', C.c_int32), ('seq_mask', _pu),
-              ('ignore_mask', C.c_uint64), ('tri_normals', _pd)]
+              ('ignore_mask', C.c_uint64), ('tri_normals', _pd), ('tri_edges', _pi)]
 
 
 class SourceDesc(C.Structure):
@@ -136,6 +136,11 @@ def scene_desc(sc):
   if getattr(sc, 'tri_normals', None) is not None:
     k['tri_normals'] = keep_tri
     d.tri_normals = _p(keep_tri, _pd)
+  if getattr(sc, 'tri_edges', None) is not None:
+    k['tri_edges'] = _arr(sc.tri_edges, np.int32)
+    if len(k['tri_edges']) != len(sc.prim_type):
+      raise ValueError('tri_edges needs one entry per primitive')
+    d.tri_edges = k['tri_edges'].ctypes.data_as(_pi)
   return _Keep(d, k)
 
 

@@ -510,11 +510,16 @@ static nearest_hit nearest_skipping(const odw_scene_desc* sc, const odw_limits* 
       double u = dot(tv, pv) / det;
       v3 qv = cross(tv, e1);
       double v = dot(dn, qv) / det;
-      if (u < -tol * (len(e2) / a2) || v < -tol * (len(e1) / a2) || u + v > 1.0 + tol * (len(sub(e2, e1)) / a2))
-        continue;
-      if (u < 0 || v < 0 || u + v > 1.0) {
-        /* in the rim the bounds above allow (a parallelogram around the facet, far too long for
-         * slivers): the distance to the facet itself decides */
+      /* per edge: reach of the tolerance in barycentric units; edges shared with a neighbouring
+       * facet of the same face (tri_edges) are closed up to rounding */
+      int fe = sc->tri_edges ? sc->tri_edges[p] : 7;
+      double a0 = (fe & 1) ? tol * (len(e2) / a2) : 1e-9;
+      double a1 = (fe & 2) ? tol * (len(e1) / a2) : 1e-9;
+      double a2e = (fe & 4) ? tol * (len(sub(e2, e1)) / a2) : 1e-9;
+      if (u < -a0 || v < -a1 || u + v > 1.0 + a2e) continue;
+      if ((u < 0 && (fe & 1)) || (v < 0 && (fe & 2)) || (u + v > 1.0 && (fe & 4))) {
+        /* beyond an edge of the face, inside the parallelogram the bounds above allow (far too
+         * long for slivers): the distance to the facet itself decides */
         v3 w = add(mul(e1, u), mul(e2, v));              /* hit point - v0, in the facet's plane */
         double best = seg_dist2(w, e1);
         double other = seg_dist2(w, e2);

@@ -207,3 +207,41 @@ def test_single_leaf_tree_terminates(native_lib, oracle):
       ref = oracle.trace(sc, bs, lim, 0, n, 1, flags=1, nthreads=0)
       assert tr.counters() == ref['counters'] and ref['counters']['recorded_hits'] > 1000
       assert np.array_equal(tr.hits()['tag'], ref['hits']['tag'])
+
+
+def test_tolerance_widens_facets_across_face_edges_only(oracle):
+  """`dist(point, face) < distTol` (ray.py:424-426) is about faces: a facet is widened across the
+  edges it has in common with the face's outline, not across those it shares with a neighbouring
+  facet of the same face.  With distTol = 1e-2 -- larger than the needles of a pole fan -- a
+  closed tessellated ball then gives the same hits as with 1e-6, and an open patch still catches
+  rays that pass within distTol of its rim."""
+  from freecad.optics_design_workbench_amd.freecad_elements import make
+  from freecad.optics_design_workbench_amd.scene import Document, bake
+  from freecad.optics_design_workbench_amd.scene.bake import faceEdgeBits
+  quad = np.array([[0, 1, 2], [0, 2, 3]])
+  assert faceEdgeBits(quad).tolist() == [6, 5]            # the diagonal (v0-v2) is interior in both
+  assert faceEdgeBits(np.array([[0, 1, 2]])).tolist() == [7]
+
+  def hits(tol, elements, o, d):
+    doc = Document()
+    make.makeMirror(doc, [e(doc) for e in elements], RecordHits=True)
+    make.makeSimulationSettings(doc, DistanceTolerance=str(tol), MaxIntersections=1.0)
+    src = make.makePointSource(doc)
+    sc, lim = bake.bakeScene(doc, src), bake.bakeLimits(doc, src)
+    return sc, oracle.trace_rays(sc, lim, o, d, flags=1)['hits']
+  rs = np.random.RandomState(2)
+  o = rs.normal(0, 1, (4000, 3)); o = o / np.linalg.norm(o, axis=1)[:, None] * 30
+  d = rs.normal(0, 1.5, (4000, 3)) - o; d /= np.linalg.norm(d, axis=1)[:, None]
+  ball = [lambda doc: make.makeTessellated(doc, make.makeSphere(doc, 'S', 5), 12)]
+  sc, fine = hits(1e-6, ball, o, d)
+  assert sc.tri_edges is not None and (sc.tri_edges[sc.prim_type == 5] != 7).all()      # a closed surface
+  _, coarse = hits(1e-2, ball, o, d)
+  assert np.array_equal(fine['tag'], coarse['tag']) and np.abs(fine['point'] - coarse['point']).max() < 1e-9
+  # an open patch: one facet; rays aimed just outside its rim
+  patch = [lambda doc: make.makeMesh(doc, np.array([[-1, -1, 0.0], [1, -1, 0], [0, 1, 0]]), np.array([[0, 1, 2]]))]
+  o2 = np.array([[0.0, -1.005, 5.0], [0.0, -1.02, 5.0], [0.0, -0.5, 5.0]])
+  d2 = np.tile([0.0, 0.0, -1.0], (3, 1))
+  _, h = hits(1e-2, patch, o2, d2)
+  assert [int(t) & 0xFFFFFFFF for t in h['tag']] == [0, 2]                 # 5e-3 outside: caught; 2e-2 outside: missed
+  _, h = hits(1e-6, patch, o2, d2)
+  assert [int(t) & 0xFFFFFFFF for t in h['tag']] == [2]
