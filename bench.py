@@ -30,14 +30,42 @@ RAY_STATE_BYTES = 64    # S, read + written once per segment
 HIT_BYTES = 64          # H, one row per recorded hit
 
 
+def host_cores():
+  """the cores this process may really use: its affinity mask, cut by the cgroup's CPU quota
+  (a GPU box hands a 16-CPU share of a 128-thread host to a one-GPU job)"""
+  n = len(os.sched_getaffinity(0))
+  for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+    try:
+      with open(path) as f:
+        words = f.read().split()
+      if path.endswith('cpu.max'):
+        quota, period = words[0], float(words[1])
+      else:
+        quota = words[0]
+        with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as f:
+          period = float(f.read())
+      if quota not in ('max', '-1'):
+        n = min(n, max(1, int(float(quota) / period + 0.5)))
+      break
+    except (OSError, ValueError, IndexError):
+      continue
+  return n
+
+
 def cpu_baseline(proj, det, seconds=12.0):
   """the CPU oracle (a port: the reference's own CPU path needs FreeCAD/OCC,
   absent here) on all host cores, bounded sample of the same workload"""
   from oracle import capi
-  threads = capi.threads()
-  chunk, done, t0 = 200_000, 0, time.perf_counter()
+  threads = min(capi.threads(), host_cores())
+  # the oracle hands out 4096 rays at a time to its threads: a call has to hold several such
+  # pieces per thread to keep all cores busy; one untimed call first (thread pool start-up,
+  # first touch of the 80 MB table)
+  chunk = max(200_000, threads * 4096 * 4)
+  capi.trace(proj.scene, proj.source, proj.limits, 0, threads * 4096, SEED, det=det, nthreads=threads,
+             hit_capacity=threads * 4096 + 16)
+  done, t0 = 0, time.perf_counter()
   while True:
-    capi.trace(proj.scene, proj.source, proj.limits, done, chunk, SEED, det=det, nthreads=0,
+    capi.trace(proj.scene, proj.source, proj.limits, done, chunk, SEED, det=det, nthreads=threads,
                hit_capacity=chunk + 16)
     done += chunk
     dt = time.perf_counter() - t0
