@@ -127,7 +127,8 @@ def lib():
     if not os.path.exists(LIB_PATH):
       raise NativeError(f'{LIB_PATH} is missing: run __graft_entry__.build() '
                         f'(or freecad.optics_design_workbench_amd._native.build()) first')
-    l = C.CDLL(LIB_PATH)
+    # ODW_TRACE_LIB: another build of the same library (kernel experiments, scripts/try_variants.sh)
+    l = C.CDLL(os.environ.get('ODW_TRACE_LIB') or LIB_PATH)
     l.odw_last_error.restype = C.c_char_p
     l.odw_last_error.argtypes = [C.c_void_p]
     l.odw_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
