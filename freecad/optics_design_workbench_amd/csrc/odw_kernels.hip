@@ -652,7 +652,9 @@ __device__ __forceinline__ d3 face_normal(int type, cf64 par, int face, d3 lp) {
 
 // slab test against a global AABB (already enlarged by the tolerance slack).
 // A NaN from 0*inf drops out of fmin/fmax, i.e. that axis does not cull.
+#ifndef ODW_BVH_STACK
 #define ODW_BVH_STACK 32
+#endif
 template <class P>
 __device__ __forceinline__ bool ray_box(P bx, d3 oi, d3 inv, double tmax) {
   // oi = origin * inv (component-wise): one fma per plane
@@ -1023,8 +1025,11 @@ template <> struct HitBlockState<false> {
 #ifndef ODW_WAVES_PER_SIMD
 #define ODW_WAVES_PER_SIMD 4
 #endif
+#ifndef ODW_WAVES_PER_SIMD_BVH
+#define ODW_WAVES_PER_SIMD_BVH 4
+#endif
 template <bool BVH, bool STOCH, bool SEG>
-__global__ __launch_bounds__(256, ODW_WAVES_PER_SIMD) void odw_trace_kernel(const TraceParams P) {
+__global__ __launch_bounds__(256, BVH ? ODW_WAVES_PER_SIMD_BVH : ODW_WAVES_PER_SIMD) void odw_trace_kernel(const TraceParams P) {
   extern __shared__ int bvh_stack[];  // ODW_BVH_STACK x 256 ints (BVH variant only)
   // per-thread event counters live in LDS (one column per thread, ds_add_u32
   // at the event): eight fewer VGPRs across the whole ray loop
