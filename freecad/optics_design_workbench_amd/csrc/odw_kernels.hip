@@ -391,8 +391,7 @@ __device__ __forceinline__ void intersect_prim(const SceneView& sv, Query& q, in
     // inside the face rectangle (+- tol).  All faces of a primitive share its
     // group, so without trimming conditions only the nearest valid hit can be
     // selected: the three entry faces are tried first, the three exit faces
-    // only if no entry face qualifies (ray starts inside / on the box), the
-    // box is trimmed (a nearer candidate may then be rejected by its trim), or
+    // only if no entry face qualifies (ray starts inside / on the box) or
     // the ray misses the exact box (last entry plane behind the first exit
     // plane): passing an edge within the tolerance it can meet the widened
     // rectangle of an exit face before that of an entry face.
@@ -400,6 +399,32 @@ __device__ __forceinline__ void intersect_prim(const SceneView& sv, Query& q, in
     const double ax = -o.x * ix, ay = -o.y * iy, az = -o.z * iz;            // plane at 0
     const double bx = fma(par[0], ix, ax), by = fma(par[1], iy, ay), bz = fma(par[2], iz, az);
     const bool px = d.x > 0, py = d.y > 0, pz = d.z > 0;
+    if (cond_cnt) {
+      // Trimmed box (operand of a boolean): any face can be rejected by its trim, so every valid
+      // face has to reach consider() -- within the tolerance of an edge the ray meets the widened
+      // rectangles of two entry (or two exit) faces.  Slots 0/2: the two nearest entry faces,
+      // 1/3: the two nearest exit faces (a third is possible only within distTol of a corner).
+#define ODW_BOX_FACE2(T, FACE, P1, D1, S1, P2, D2, S2, TA, FA, TB, FB)                          \
+      {                                                                                         \
+        const double t_ = (T);                                                                  \
+        const double u_ = fma(t_, D1, P1), v_ = fma(t_, D2, P2);                                \
+        const bool ok_ = ((fmask >> (FACE)) & 1) && t_ > tol && u_ >= -tol && u_ <= (S1) + tol && \
+                         v_ >= -tol && v_ <= (S2) + tol;                                        \
+        const bool a_ = ok_ && t_ < TA;                                                         \
+        const bool b_ = ok_ && !a_ && t_ < TB;                                                  \
+        TB = a_ ? TA : (b_ ? t_ : TB);                                                          \
+        FB = a_ ? FA : (b_ ? (FACE) : FB);                                                      \
+        TA = a_ ? t_ : TA;                                                                      \
+        FA = a_ ? (FACE) : FA;                                                                  \
+      }
+      ODW_BOX_FACE2(px ? ax : bx, px ? 0 : 1, o.y, d.y, par[1], o.z, d.z, par[2], c.t0, c.f0, c.t2, c.f2);
+      ODW_BOX_FACE2(py ? ay : by, py ? 2 : 3, o.z, d.z, par[2], o.x, d.x, par[0], c.t0, c.f0, c.t2, c.f2);
+      ODW_BOX_FACE2(pz ? az : bz, pz ? 4 : 5, o.x, d.x, par[0], o.y, d.y, par[1], c.t0, c.f0, c.t2, c.f2);
+      ODW_BOX_FACE2(px ? bx : ax, px ? 1 : 0, o.y, d.y, par[1], o.z, d.z, par[2], c.t1, c.f1, c.t3, c.f3);
+      ODW_BOX_FACE2(py ? by : ay, py ? 3 : 2, o.z, d.z, par[2], o.x, d.x, par[0], c.t1, c.f1, c.t3, c.f3);
+      ODW_BOX_FACE2(pz ? bz : az, pz ? 5 : 4, o.x, d.x, par[0], o.y, d.y, par[1], c.t1, c.f1, c.t3, c.f3);
+#undef ODW_BOX_FACE2
+    } else {
     double bt = INFINITY;
     int bf = 0;
 #define ODW_BOX_FACE(T, FACE, P1, D1, S1, P2, D2, S2)                                         \
@@ -418,7 +443,7 @@ __device__ __forceinline__ void intersect_prim(const SceneView& sv, Query& q, in
     c.f0 = bf;
     const double t_in = fmax(fmax(px ? ax : bx, py ? ay : by), pz ? az : bz);
     const double t_out = fmin(fmin(px ? bx : ax, py ? by : ay), pz ? bz : az);
-    if (cond_cnt || !(bt < INFINITY) || !(t_in < t_out)) {
+    if (!(bt < INFINITY) || !(t_in < t_out)) {
       bt = INFINITY;
       bf = 0;
       ODW_BOX_FACE(px ? bx : ax, px ? 1 : 0, o.y, d.y, par[1], o.z, d.z, par[2]);
@@ -428,6 +453,7 @@ __device__ __forceinline__ void intersect_prim(const SceneView& sv, Query& q, in
       c.f1 = bf;
     }
 #undef ODW_BOX_FACE
+    }
   } else if (type == ODW_PRIM_CYLINDER || type == ODW_PRIM_CONE) {
     const double R1 = par[0];
     const double R2 = (type == ODW_PRIM_CYLINDER) ? par[0] : par[1];
@@ -712,7 +738,9 @@ __device__ __forceinline__ int nearest(const DeviceScene& sc, const SceneView& s
     // "while-while": every lane walks inner nodes (cheap, same code for all
     // lanes) until it stands on a leaf or is done; only then are the leaf
     // primitives intersected (expensive), so that part runs with as many
-    // lanes as possible.  Stack entries: >= 0 inner node, < -1 leaf
+    // lanes as possible.  A lane that reaches its first leaf before the others
+    // parks it and walks on while some lane still looks for its first
+    // (hugeArray +9 %, meshes unchanged).  Stack entries: >= 0 inner node, < -1 leaf
     // (~(first | count << 24) - 1); node stack in LDS, one column per thread.
     typedef const float ODW_CONST* cf32;
     typedef float vf4 __attribute__((ext_vector_type(4)));
@@ -723,8 +751,13 @@ __device__ __forceinline__ int nearest(const DeviceScene& sc, const SceneView& s
     const float ivx = (float)inv.x, ivy = (float)inv.y, ivz = (float)inv.z;
     int sp = 0;
     int cur = 0;
+    int pend = -1;
     for (;;) {
-      while (cur >= 0) {
+      // (a lane with a parked leaf walks on only while some lane still looks for its first)
+      for (;;) {
+        // (the vote is taken by every lane still in this loop, before any of them leaves)
+        const unsigned long long looking = __ballot(cur >= 0 && pend == -1);
+        if (!(cur >= 0 && (pend == -1 || looking != 0ull))) break;
         cf32 nd = nodes + (size_t)cur * 16;
         const vf4 a0 = *reinterpret_cast<const vf4 ODW_CONST*>(nd);
         const vf4 a1 = *reinterpret_cast<const vf4 ODW_CONST*>(nd + 4);
@@ -765,9 +798,20 @@ __device__ __forceinline__ int nearest(const DeviceScene& sc, const SceneView& s
         } else {
           cur = -1;
         }
+        // a lane that reaches its first leaf parks it and keeps walking while
+        // the rest of the wave still walks (it would idle otherwise)
+        if (cur < -1 && pend == -1) {
+          pend = cur;
+          if (sp > 0) { --sp; cur = stack[sp * 256]; } else cur = -1;
+        }
       }
-      if (cur == -1) break;            // done
-      const int code = -2 - cur;       // leaf
+      int lf;
+      if (pend != -1) { lf = pend; pend = -1; }
+      else if (cur < -1) {
+        lf = cur;
+        if (sp > 0) { --sp; cur = stack[sp * 256]; } else cur = -1;
+      } else break;
+      const int code = -2 - lf;
       const int leaf_first = code & 0xffffff, leaf_count = code >> 24;
       for (int i = 0; i < leaf_count; ++i) {
         const int p = bvh_prims[leaf_first + i];
@@ -777,12 +821,6 @@ __device__ __forceinline__ int nearest(const DeviceScene& sc, const SceneView& s
           if (pi[0] == ODW_PRIM_TRIANGLE) intersect_tri(sv, q, p, g);
           else intersect_prim(sv, q, p, pi[0], g, pi[2], pi[3]);
         }
-      }
-      if (sp > 0) {
-        --sp;
-        cur = stack[sp * 256];
-      } else {
-        break;
       }
     }
   }
