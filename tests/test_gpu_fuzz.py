@@ -52,3 +52,27 @@ def test_random_scenes_device_equals_oracle(native_lib, oracle, rich):
       early = np.arange(len(gr)) - start < 4
       assert dev[early].max() < 1e-7, (s, float(dev[early].max()))
   assert scenes >= 30 and differing_rays <= 2, (scenes, differing_rays, total)
+
+
+def test_trimmed_box_face_met_within_tolerance_of_an_edge(native_lib, oracle):
+  """found by the long-form run (seed 102, crowded scene 3, ray 18561): inside a Fuse of a sphere and a
+  box the ray leaves the box through a face the trim rejects (the point lies inside the sphere by more
+  than distTol) and meets, 5e-3 mm beyond the edge, the widened rectangle of the neighbouring face,
+  which the trim accepts.  The device used to keep only the nearest valid exit face of a box."""
+  from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
+  rs = np.random.RandomState(102 * 100003 + 3)
+  sc, lim, targets = scene(rs, False, True)
+  o, d = rays(rs, targets, 20000)
+  o, d = o[18500:18600], d[18500:18600]
+  with Tracer(0) as tr:
+    tr.setScene(sc); tr.setLimits(lim); tr.setDetector(None)
+    tr.reserveHits(len(o) * (lim.max_intersections + 1))
+    tr.reset()
+    tr.traceRays(o, d)
+    tr.sync()
+    g = tr.hits()
+  r = oracle.trace_rays(sc, lim, o, d, nthreads=0)['hits']
+  assert np.array_equal(g['tag'], r['tag'])
+  ray = (r['tag'] & np.uint64(0xFFFFFFFFFFFF)).astype(np.int64)
+  assert (ray == 61).sum() == 5                       # the ray in question: five recorded hits
+  assert np.abs(g['point'] - r['point']).max() < 1e-7
