@@ -29,6 +29,8 @@ bad = dict(counters=0, tags=0, hist=0, segs=0, coords=0)
 done = 0
 with Tracer(0) as tr:
   for s in range(n_scenes):
+    if os.environ.get('ODW_FUZZ_ONLY') and s != int(os.environ['ODW_FUZZ_ONLY']):
+      continue                                     # (one scene in detail: its differing rays segment by segment)
     rs = np.random.RandomState(seed0 * 7919 + s)
     doc_rs = np.random.RandomState(seed0 * 100003 + s)
     try:
@@ -92,6 +94,15 @@ with Tracer(0) as tr:
     if [w for w in what if w != 'coords']:
       print(json.dumps(dict(scene=s, differs=what, focal=str(focal), density=dens, counters_gpu=gc, counters_ref=ref['counters'],
                             hist_diff=int(np.abs(gh.astype(np.int64) - ref['hist'].astype(np.int64)).sum()))), flush=True)
+    if os.environ.get('ODW_FUZZ_ONLY') and 'segs' in what:
+      ray_of = lambda a: (a['tag'] & np.uint64((1 << 40) - 1)).astype(np.int64)
+      cg, cr = np.bincount(ray_of(gs) - first, minlength=n), np.bincount(ray_of(rseg) - first, minlength=n)
+      print('prims', sc.prim_type.tolist(), 'groups', sc.prim_group.tolist(), 'group types', sc.group_type.tolist(),
+            'cond', sc.prim_cond_off.tolist(), 'tol', lim.dist_tol)
+      for i in np.flatnonzero(cg != cr)[:3]:
+        for name, a in (('gpu', gs), ('oracle', rseg)):
+          rows = a[ray_of(a) - first == i]
+          print(name, 'ray', int(i), [(np.round(r['p1'], 6).tolist(), np.round(r['p2'], 6).tolist(), int(r['tag'] >> np.uint64(52))) for r in rows])
     if done % 10 == 0:
       print(json.dumps(dict(progress=done)), flush=True)
 print(json.dumps(dict(scenes=done, rays_each=n, differing=bad)))
