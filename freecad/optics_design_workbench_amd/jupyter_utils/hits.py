@@ -4,8 +4,9 @@ Same interface and results as the reference's `Hits`
 (jupyter_utils/hits.py:21-193): `points()`, `directions()`, `isEntering()`,
 `detectPlaneNormal`, `planeProject3dPoints`, `histogram`.  The plane search is
 the reference's grid refinement (30x30 start grid, 10x10 refinements around
-the best cell until the step is below 1e-9 rad) evaluated as one matrix
-product per refinement instead of a Python loop per candidate.
+the best cell until the step is below 1e-9 rad), candidates generated per grid
+and evaluated one matrix-vector product each, so that plane, origin and counts
+equal the reference's bit for bit (tests/golden/hist_cases.npz).
 Fan math (jupyter_utils/hits.py:227-444): per-fan ray spacing, curvature,
 estimated power density and caustic indicators from the `fanIndex`,
 `rayIndex`, `totalRaysInFan` metadata of a fan-mode run -- same numbers as the
@@ -48,8 +49,14 @@ def _flattest_direction(cloud, angleTol):
   while True:
     cell = (phis[1] - phis[0], thetas[1] - thetas[0])
     P, T, normals = _sphere_dirs(phis, thetas)
-    extent = normals @ cloud.T
-    k = int(np.argmin(extent.max(axis=1) - extent.min(axis=1)))
+    # one matrix-vector product per candidate, as the reference evaluates them (hits.py:124-128):
+    # a single matrix-matrix product sums in another order, and the argmin over nearly equal
+    # extents then lands on a neighbouring cell now and then (1e-9 rad, a hit or two in a bin)
+    extent = np.empty(len(normals))
+    for j, nrm in enumerate(normals):
+      along = np.dot(cloud, nrm)
+      extent[j] = along.max() - along.min()
+    k = int(np.argmin(extent))
     phis = np.linspace(P[k] - 1.1 * cell[0], P[k] + 1.1 * cell[0], 10)
     thetas = np.linspace(T[k] - 1.1 * cell[1], T[k] + 1.1 * cell[1], 10)
     if max(phis[1] - phis[0], thetas[1] - thetas[0]) < angleTol:

@@ -86,6 +86,18 @@ class Ranks:
     self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
     return [int(v) for v in t.cpu()]
 
+  def sumFloats(self, values):
+    """element-wise sum of a float64 vector over all ranks, on every rank (the sweep's
+    value -> result table: each rank contributes its own entries, zeros elsewhere)"""
+    import numpy as np
+    values = np.asarray(values, dtype=np.float64)
+    if self.world == 1:
+      return values.copy()
+    import torch
+    t = torch.from_numpy(values.copy()).to(self._tensor_device())
+    self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+    return t.cpu().numpy()
+
   def broadcast(self, obj, src=0):
     if self.world == 1:
       return obj

@@ -69,8 +69,12 @@ def _atomic_pickle(path, obj):
 class SimulationResults:
 
   def __init__(self, simulationType, resultsPath=None, simulationRunFolder=None,
-               endAfterIterations=np.inf, endAfterRays=np.inf, endAfterHits=np.inf, owner=True):
+               endAfterIterations=np.inf, endAfterRays=np.inf, endAfterHits=np.inf, owner=True,
+               keepInMemory=None):
+    """keepInMemory: keep flushed batches in host memory (default: only when there is no results
+    folder to write them to -- a continuous run with a folder holds nothing after each flush)"""
     self.simulationType = simulationType
+    self.keepInMemory = (resultsPath is None) if keepInMemory is None else bool(keepInMemory)
     self.basePath = resultsPath
     self.simulationRunFolder = simulationRunFolder
     if resultsPath is not None:
@@ -91,9 +95,11 @@ class SimulationResults:
     self.totalRecordedRays = 0
     self.t0 = time.time()
     self._hits = {}          # (sourceName, sourceLabel, objName, objLabel) -> list of dicts
-    self._flushed = {}       # same key -> merged dict kept for in-memory access
+    self._flushed = {}       # same key -> list of flushed batches (keepInMemory only)
+    self._hitFiles = {}      # same key -> `*-hits.pkl` files this process wrote
     self._rays = {}          # (sourceName, sourceLabel) -> list of ray dicts (RecordRays)
     self._flushedRays = {}
+    self._rayFiles = {}
 
   # -- global info, progress, status flags --------------------------------------
   def dumpGlobalInfo(self, info):
@@ -172,7 +178,10 @@ class SimulationResults:
 
   # -- output ----------------------------------------------------------------
   def flush(self):
-    """write buffered hits as `*-hits.pkl` (results_store.py:405-457)"""
+    """write buffered hits as `*-hits.pkl` and empty the buffers (results_store.py:405-457).
+    With a results folder nothing stays in host memory after the write (the reference clears its
+    lists, :455-457; `hits()` reads the run folder back); without one the batches are kept as a
+    list of chunks and merged lazily by `hits()`"""
     ms = max(int(time.time() * 1e3), getattr(self, '_lastStampMs', 0) + 1)   # one file name per flush
     self._lastStampMs = ms
     stamp = f'{ms}-pid{os.getpid()}-thread{threading.get_ident()}'
@@ -181,43 +190,66 @@ class SimulationResults:
       for part in parts:
         for k, v in part.items():
           updateResultEntry(merged, k, v)
-      keep = self._flushed.setdefault(key, {})
-      for k, v in merged.items():
-        updateResultEntry(keep, k, v)
       if self.basePath is not None:
         _, sourceLabel, _, objLabel = key
         folder = os.path.join(self.runFolderPath(), f'source-{sourceLabel}', f'object-{objLabel}')
         os.makedirs(folder, exist_ok=True)
-        with open(os.path.join(folder, f'{stamp}-hits.pkl'), 'wb') as f:
+        path = os.path.join(folder, f'{stamp}-hits.pkl')
+        with open(path, 'wb') as f:
           pickle.dump(merged, f)
+        self._hitFiles.setdefault(key, []).append(path)
+      if self.keepInMemory:
+        self._flushed.setdefault(key, []).append(merged)
     self._hits = {}
     # recorded rays: one pickled list of ray dictionaries per source (results_store.py:380-403)
     for key, rays in self._rays.items():
-      self._flushedRays.setdefault(key, []).extend(rays)
       if self.basePath is not None and rays:
         folder = os.path.join(self.runFolderPath(), f'source-{key[1]}')
         os.makedirs(folder, exist_ok=True)
-        with open(os.path.join(folder, f'{stamp}-rays.pkl'), 'wb') as f:
+        path = os.path.join(folder, f'{stamp}-rays.pkl')
+        with open(path, 'wb') as f:
           pickle.dump(rays, f)
+        self._rayFiles.setdefault(key, []).append(path)
+      if self.keepInMemory:
+        self._flushedRays.setdefault(key, []).extend(rays)
     self._rays = {}
 
+  @staticmethod
+  def _matches(rel, pattern):
+    return pattern in ('*', '**') or fnmatch.fnmatch(rel, pattern) or fnmatch.fnmatch(rel, f'*{pattern}*')
+
   def rays(self, pattern='*'):
-    """every recorded ray so far (in-memory `loadRays`)"""
+    """every recorded ray of THIS process so far (in-memory `loadRays`; read back from this
+    process' own `*-rays.pkl` files when the store does not keep flushed batches)"""
     self.flush()
     out = []
-    for (src, srcLabel), rays in self._flushedRays.items():
-      rel = f'source-{srcLabel}'
-      if pattern in ('*', '**') or fnmatch.fnmatch(rel, pattern) or fnmatch.fnmatch(rel, f'*{pattern}*'):
-        out.extend(rays)
+    for key in list(self._flushedRays) + [k for k in self._rayFiles if k not in self._flushedRays]:
+      if not self._matches(f'source-{key[1]}', pattern):
+        continue
+      if self.keepInMemory:
+        out.extend(self._flushedRays.get(key, []))
+      else:
+        for path in self._rayFiles.get(key, []):
+          with open(path, 'rb') as f:
+            out.extend(pickle.load(f))
     return out
 
   def hits(self, pattern='*'):
-    """everything recorded so far as one `Hits` (in-memory `loadHits`)"""
+    """everything THIS process recorded so far as one `Hits` (in-memory `loadHits`)"""
     self.flush()
     result = {}
-    for (src, srcLabel, obj, objLabel), d in self._flushed.items():
-      rel = f'source-{srcLabel}/object-{objLabel}'
-      if pattern in ('*', '**') or fnmatch.fnmatch(rel, pattern) or fnmatch.fnmatch(rel, f'*{pattern}*'):
+    for key in list(self._flushed) + [k for k in self._hitFiles if k not in self._flushed]:
+      (src, srcLabel, obj, objLabel) = key
+      if not self._matches(f'source-{srcLabel}/object-{objLabel}', pattern):
+        continue
+      if self.keepInMemory:
+        chunks = self._flushed.get(key, [])
+      else:
+        chunks = []
+        for path in self._hitFiles.get(key, []):
+          with open(path, 'rb') as f:
+            chunks.append(pickle.load(f))
+      for d in chunks:
         for k, v in d.items():
           updateResultEntry(result, k, v)
     return Hits(result)

@@ -105,6 +105,7 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
       baked.append((src, scene, bakeLightSource(doc, src, seed), _bake.bakeLimits(doc, src, **traceKwargs)))
     first = {src.Name: 0 for src in sources}
     ended = False
+    uploaded, hits_per_ray = {}, {}
     while True:
       for src, scene, bsrc, lim in baked:
         per_iter = max(1, int(round(rpi * bsrc.rays_per_iteration_scale)))
@@ -166,36 +167,63 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
           per_ray = None
         # -- this rank's share of the launch ---------------------------------------------------
         lo, m = ranks.shard(0, n)
-        tr.setScene(scene)
-        tr.setLimits(lim)
+        # tables travel to the device only when they change (a single-source run uploads once:
+        # an upload synchronises the stream and rebuilds the BVH of big scenes)
+        if uploaded.get('scene') is not scene:
+          tr.setScene(scene)
+          uploaded['scene'] = scene
+        if uploaded.get('limits') is not lim:
+          tr.setLimits(lim)
+          uploaded['limits'] = lim
         tr.setDetector(None)
-        tr.reserveHits(max(16, min(m * (lim.max_intersections + 1), 4 * m + 1024) if explicit is None
-                           else m * (lim.max_intersections + 1)))
+        # Hit-list room: every intersection of every ray could be recorded (explicit launches are
+        # small: reserve exactly that); for bulk launches start from what the previous launch of
+        # this source needed (first launch: 4 rows per ray) and, if rows were dropped, re-trace the
+        # same index range with room for what the counters say was wanted -- the trace is
+        # deterministic, so the retry yields the same rays
+        worst = max(16, m * (lim.max_intersections + 1))
+        if explicit is not None:
+          capacity = worst
+        else:
+          per_ray_hits = hits_per_ray.get(src.Name, 4.0)
+          capacity = min(worst, int(m * per_ray_hits * 1.25) + 1024)
         if record_rays:
           tr.reserveSegments(max(16, min(m * lim.max_intersections, (1 << 31) - 1)))
-        tr.reset()
-        if explicit is None:
-          tr.setSource(bsrc)
-          if m:
-            tr.trace(base + lo, m, seed, record_segments=record_rays)
-          per_ray, index_base = _DeviceInitialConditions(tr, bsrc, base + lo, m, seed), base + lo
-        else:
-          o, d, pw, wl = (a[lo:lo + m] if a is not None else None for a in explicit)
-          tr.setSurfaceSeed(seed)
-          index_base = base
-          if wl is None:
+        while True:
+          tr.reserveHits(capacity)
+          tr.reset()
+          if explicit is None:
+            if uploaded.get('source') is not bsrc:
+              tr.setSource(bsrc)
+              uploaded['source'] = bsrc
             if m:
-              tr.traceRays(o, d, pw, first=base + lo, record_segments=record_rays)
+              tr.trace(base + lo, m, seed, record_segments=record_rays)
+            per_ray, index_base = _DeviceInitialConditions(tr, bsrc, base + lo, m, seed), base + lo
           else:
-            for w in np.unique(wl):
-              sel = np.nonzero(wl == w)[0]                 # contiguous: the launch is ordered by wavelength
-              tr.setWavelength(w)
-              tr.traceRays(o[sel], d[sel], pw[sel], first=base + lo + int(sel[0]), record_segments=record_rays)
-        tr.sync()
+            o, d, pw, wl = (a[lo:lo + m] if a is not None else None for a in explicit)
+            tr.setSurfaceSeed(seed)
+            uploaded.pop('source', None)           # setWavelength below overrides the source's value
+            index_base = base
+            if wl is None:
+              # every Ray carries its source's wavelength (point_source.py:459, surface_source.py:110)
+              tr.setWavelength(bsrc.wavelength)
+              if m:
+                tr.traceRays(o, d, pw, first=base + lo, record_segments=record_rays)
+            else:
+              for w in np.unique(wl):
+                sel = np.nonzero(wl == w)[0]                 # contiguous: the launch is ordered by wavelength
+                tr.setWavelength(w)
+                tr.traceRays(o[sel], d[sel], pw[sel], first=base + lo + int(sel[0]), record_segments=record_rays)
+          tr.sync()
+          cnt = tr.counters()
+          if not cnt['hits_dropped']:
+            break
+          if capacity >= worst:
+            raise RuntimeError(f'{cnt["hits_dropped"]} hit rows did not fit the device buffer of {capacity} rows')
+          capacity = min(worst, max(2 * capacity, int(cnt['recorded_hits'] * 1.05) + 1024))
+        if m:
+          hits_per_ray[src.Name] = max(cnt['recorded_hits'] / m, 0.25)
         first[src.Name] = base + n
-        cnt = tr.counters()
-        if cnt['hits_dropped']:
-          raise RuntimeError(f'{cnt["hits_dropped"]} hit rows did not fit the device buffer')
         before = store.totalRecordedHits
         _store_hits(store, tr.hits(), scene, src, per_ray, index_base, enabled)
         mine = store.totalRecordedHits - before

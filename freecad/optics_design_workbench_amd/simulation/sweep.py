@@ -1,0 +1,144 @@
+"""Parameter sweeps: one Monte-Carlo run per parameter value, a figure of merit per run.
+
+The reference's sweep is a notebook loop (examples/1-getting-started/
+optimize-spotsize.ipynb cells 8-11; `ParameterSweeper`,
+jupyter_utils/parameter_sweeper.py, wraps the same loop):
+
+    for radius in radii:
+      doc.Sphere.Radius = radius
+      hits = doc.runSimulation('true').loadHits()
+      fwhms.append(calcFwhm(hits))
+
+Every run is independent, so the values are dealt out over the GPUs of the node
+(one process per GPU, value k goes to rank k % world -- BASELINE configs[4]: 64
+radii x 1e7 rays on 8 GPUs = 8 runs per GPU); the table value -> result is summed
+into every rank with ONE collective at the end (each rank contributes its own
+entries, zeros elsewhere).  Rays are addressed by the global Philox index, so a
+value's result does not depend on which GPU ran it.
+"""
+import numpy as np
+
+from ..jupyter_utils.hits import Hits
+from ..scene import bake as _bake
+from . import parallel
+from .tracer import Tracer, hitsToDict
+
+DEFAULT_SEED = 0x0D15EA5E
+
+
+def calcFwhm(hits):
+  """spot FWHM of a hit cloud: `calcFwhm` of optimize-spotsize.ipynb cell 8, statement by
+  statement -- polar histogram with bins [arange(0, 2 pi, pi/2), geomspace(1e-3, 5, 500)], per
+  azimuth bin a straight-line fit of log(density) over log(r) through the first ten non-empty
+  radial bins, FWHM = the smallest radius of the fitted line at or below half the peak density;
+  mean over the azimuth bins that received hits (nan if none did)"""
+  fwhmList = []
+  polarHist = hits.histogram(binCoords='polar',
+                             bins=[np.arange(0, 2 * np.pi, np.pi / 2), np.geomspace(1e-3, 5, 500)])
+  phis, r, hists = polarHist.byAzimuth()
+  for phi, dens in zip(phis, hists):
+    if max(dens) > 0:
+      a, b = np.polyfit(np.log(r[dens > 0])[:10], np.log(dens[dens > 0])[:10], deg=1)
+      try:
+        # (inside the try: with no bin above 10 hits the notebook's max() of an empty list raises
+        # the ValueError its except clause swallows as well)
+        rFit = np.geomspace(min(r), max(r[dens > 10][:10]), 100)
+        fitDens = np.exp(a * np.log(rFit) + b)
+        fwhmList.append(min(rFit[fitDens <= max(dens) / 2]))
+      except ValueError:
+        pass
+  return np.mean(fwhmList) if len(fwhmList) else np.nan
+
+
+def rmsSpot(hits):
+  """rms distance of the hits from their centroid (a cheaper figure of merit than calcFwhm)"""
+  p = hits.points()
+  return float(np.sqrt(((p - p.mean(axis=0))**2).sum(axis=1).mean())) if len(p) else np.nan
+
+
+def shareOfRank(n_values, rank, world):
+  """indices of the sweep values rank `rank` runs: k = rank, rank + world, ..."""
+  return list(range(int(rank), int(n_values), int(world)))
+
+
+class SweepResult:
+  """values, results (nan where a run produced no figure), and what each run traced"""
+
+  def __init__(self, values, results, tracedRays, recordedHits, segments):
+    self.values = np.asarray(values, dtype=np.float64)
+    self.results = np.asarray(results, dtype=np.float64)
+    self.tracedRays, self.recordedHits, self.segments = int(tracedRays), int(recordedHits), int(segments)
+
+  def best(self):
+    """(value, result) of the smallest finite result (the notebook's `radii[np.argmin(fwhms)]`)"""
+    k = int(np.nanargmin(self.results))
+    return float(self.values[k]), float(self.results[k])
+
+
+def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAULT_SEED, device=0,
+                   dist=None, tracer=None, source=None, deviceHits=True, **traceKwargs):
+  """run `rays` true-random rays for every entry of `values` and return a SweepResult.
+
+  setValue(doc, value)   applies one parameter value (e.g. `doc.Sphere.Radius = value`)
+  measure(hits) -> float figure of merit of a run's hit cloud (`Hits` interface: histogram,
+                         points, directions ...); default: the notebook's calcFwhm
+  dist                   torch.distributed (initialised): the values are dealt out over the ranks
+                         and the table is summed into every rank with one all-reduce
+  deviceHits             measure on the hit rows where they are, in HBM (`DeviceHits`: plane search
+                         on a thinned sample, projection, medians and binning on the device); False:
+                         copy every row to the host first (what the reference does)
+  """
+  ranks = parallel.Ranks.detect(dist, device)
+  values = [float(v) for v in values]
+  mine = shareOfRank(len(values), ranks.rank, ranks.world)
+  sources = _bake.lightSources(doc)
+  if not sources:
+    raise ValueError('document has no light source')
+  src = sources[0] if source is None else source
+  from .simulation_loop import bakeLightSource
+  own = tracer is None
+  tr = tracer or Tracer(device)
+  table = np.zeros((len(values), 2))        # (result or 0, 1 = a number / 2 = nan)
+  totals = np.zeros(3, dtype=np.int64)
+  try:
+    for k in mine:
+      setValue(doc, values[k])
+      scene = _bake.bakeScene(doc, src)
+      bsrc = bakeLightSource(doc, src, seed)
+      lim = _bake.bakeLimits(doc, src, **traceKwargs)
+      tr.setScene(scene)
+      tr.setSource(bsrc)
+      tr.setLimits(lim)
+      tr.setDetector(None)
+      capacity = int(rays * 1.25) + 1024
+      while True:
+        tr.reserveHits(capacity)
+        tr.reset()
+        tr.trace(0, int(rays), seed, histogram=False)
+        tr.sync()
+        cnt = tr.counters()
+        if not cnt['hits_dropped']:
+          break
+        capacity = int(cnt['recorded_hits'] * 1.05) + 1024      # deterministic: trace again with room
+      totals += (cnt['traced_rays'], cnt['recorded_hits'], cnt['segments'])
+      if deviceHits and hasattr(tr, 'deviceHits'):
+        hits = tr.deviceHits()
+      else:
+        merged = {}
+        from .results_store import updateResultEntry
+        for d in hitsToDict(tr.hits(), scene, src.Name).values():
+          for key, v in d.items():
+            updateResultEntry(merged, key, v)
+        hits = Hits(merged)
+      m = float(measure(hits)) if len(hits) else np.nan
+      table[k] = (0.0, 2.0) if np.isnan(m) else (m, 1.0)
+  finally:
+    if own:
+      tr.close()
+  flat = ranks.sumFloats(np.concatenate([table.ravel(), totals.astype(np.float64)]))
+  table = np.asarray(flat[:2 * len(values)]).reshape(-1, 2)
+  if not np.all((table[:, 1] == 1) | (table[:, 1] == 2)):
+    raise RuntimeError('parameter sweep: some values were run by no rank or by several')
+  results = np.where(table[:, 1] == 1, table[:, 0], np.nan)
+  t = [int(round(v)) for v in flat[2 * len(values):]]
+  return SweepResult(values, results, *t)

@@ -39,3 +39,61 @@ def project(name, **kw):
   if key not in _PROJECTS:
     _PROJECTS[key] = scenes.bakeProject(os.path.join(SCENES, name + '.FCStd'), **kw)
   return _PROJECTS[key]
+
+
+# ---------------------------------------------------------------------------
+# The reference-held acceptance criteria run twice: on the CPU oracle (`not gpu`
+# suite) and on the HIP path itself (`-m gpu`), through the same test bodies.
+BACKENDS = ['oracle', pytest.param('device', marks=pytest.mark.gpu)]
+
+
+class _Backend:
+  """what a statistical test needs from either side: a Tracer-like object for
+  runSimulation / FreecadDocument.runSimulation and a one-call `hits(project, first, n, seed)`"""
+
+  def __init__(self, name):
+    self.name = name
+    self._tracers = []
+
+  def tracer(self, nthreads=4):
+    if self.name == 'oracle':
+      from oracle import capi
+      from oracle_tracer import OracleTracer
+      capi.build()
+      t = OracleTracer(nthreads=nthreads)
+    else:
+      from freecad.optics_design_workbench_amd import _native
+      from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
+      _native.build()
+      t = Tracer(0)
+    self._tracers.append(t)
+    return t
+
+  def hits(self, pr, first, n, seed):
+    """hit rows (HIT_DTYPE) of rays first..first+n-1 of the project's source"""
+    if self.name == 'oracle':
+      from oracle import capi
+      capi.build()
+      return capi.trace(pr.scene, pr.source, pr.limits, first, n, seed, nthreads=0)['hits']
+    tr = self._tracers[0] if self._tracers else self.tracer()
+    tr.setScene(pr.scene)
+    tr.setSource(pr.source)
+    tr.setLimits(pr.limits)
+    tr.setDetector(None)
+    tr.reserveHits(n * 2 + 1024)
+    tr.reset()
+    tr.trace(first, n, seed)
+    tr.sync()
+    assert tr.counters()['hits_dropped'] == 0
+    return tr.hits()
+
+  def close(self):
+    for t in self._tracers:
+      t.close()
+
+
+@pytest.fixture(params=BACKENDS)
+def backend(request):
+  b = _Backend(request.param)
+  yield b
+  b.close()

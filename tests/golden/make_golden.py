@@ -216,6 +216,53 @@ def make_hist(hits_mod):
   print('hist cases written;', {k: out[k] for k in out if k.endswith('cart30_normal')})
 
 
+def fwhm_clouds():
+  """synthetic spots for the sweep's figure of merit: (points, directions) of a detector plane
+  x = const hit by rays along -x (the absorber of examples/1-getting-started), radial profiles
+  with a core and a halo so that the log-log fit and the half-maximum search both matter"""
+  rs = np.random.RandomState(23)
+  out = {}
+  for tag, n, core, halo, share in (('tight', 20000, 0.02, 0.5, 0.1), ('wide', 20000, 0.3, 1.5, 0.3),
+                                    ('sparse', 3000, 0.05, 0.8, 0.2)):
+    k = rs.random_sample(n) < share
+    sig = np.where(k, halo, core)
+    yz = rs.normal(0, 1, (n, 2)) * sig[:, None] + np.array([0.4, -1.3])
+    P = np.concatenate([np.full((n, 1), -41.0), yz], axis=1)
+    D = np.tile(np.array([-1.0, 0.0, 0.0]), (n, 1)) + rs.normal(0, 0.02, (n, 3))
+    D /= np.linalg.norm(D, axis=1)[:, None]
+    out[tag] = (P, D)
+  return out
+
+
+def make_fwhm(hits_mod):
+  """the polar histogram `calcFwhm` of examples/1-getting-started/optimize-spotsize.ipynb (cell 8)
+  asks the reference's Hits/Histogram for, and the FWHM that cell's arithmetic (numpy only,
+  evaluated here on the reference's histogram) gives"""
+  out = {}
+  for tag, (P, D) in fwhm_clouds().items():
+    h = hits_mod.Hits(dict(points=P.copy(), directions=D.copy(), powers=np.ones(len(P)),
+                           isEntering=np.ones(len(P), dtype=int)))
+    H = h.histogram(binCoords='polar', bins=[np.arange(0, 2 * np.pi, np.pi / 2), np.geomspace(1e-3, 5, 500)])
+    phis, r, hists = H.byAzimuth()
+    fw = []
+    for dens in hists:
+      if max(dens) > 0:
+        a, b = np.polyfit(np.log(r[dens > 0])[:10], np.log(dens[dens > 0])[:10], deg=1)
+        rFit = np.geomspace(min(r), max(r[dens > 10][:10]), 100)
+        fit = np.exp(a * np.log(rFit) + b)
+        sel = rFit[fit <= max(dens) / 2]
+        if len(sel):
+          fw.append(min(sel))
+    out[tag + '_points'], out[tag + '_directions'] = P, D
+    out[tag + '_hist'] = np.asarray(H.hist)
+    out[tag + '_dens'] = np.asarray(hists)
+    out[tag + '_origin'] = np.asarray(H._origin)
+    out[tag + '_normal'] = np.asarray(H._planeNormal)
+    out[tag + '_fwhm'] = np.array(np.mean(fw) if fw else np.nan)
+  np.savez_compressed(os.path.join(OUT, 'fwhm_cases.npz'), **out)
+  print('fwhm cases written;', {k: float(out[k]) for k in out if k.endswith('_fwhm')})
+
+
 FAN_CASES = {
   # benchmark/minimal.FCStd's source (BASELINE configs[0]: ray-fan mode)
   'c1_minimal': dict(PowerDensity='exp(-theta**2/(1e-2)**2)', FocalLength='0', ThetaDomain='0, pi/4',
@@ -459,3 +506,4 @@ if __name__ == '__main__':
   make_pseudo(rng)
   make_fan_math(hits)
   make_scalar(rng)
+  make_fwhm(hits)

@@ -91,7 +91,12 @@ class OracleTracer:
 
   def traceRays(self, origins, directions, powers=None, first=0, record_hits=True, histogram=True,
                 record_segments=False):
-    wl = self._wavelength if self._wavelength is not None else getattr(getattr(self, 'source', None), 'wavelength', 500.0)
+    if self._wavelength is None:
+      # the device keeps whatever odw_set_wavelength / odw_upload_source set last; a caller that
+      # relies on that for explicit rays is a bug (every Ray carries its source's wavelength,
+      # point_source.py:459) -- the double refuses instead of guessing
+      raise RuntimeError('traceRays without setWavelength: explicit rays need their source\'s wavelength')
+    wl = self._wavelength
     flags = (1 if record_hits else 0) | (2 if histogram else 0)
     if record_segments:
       self._segs.append(capi.trace_segments(self.scene, self.limits, origins=origins, dirs=directions, powers=powers,

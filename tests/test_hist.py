@@ -45,16 +45,14 @@ def test_product_hits_histogram(golden, tag, kind):
                 isEntering=np.ones(len(P), dtype=int)))
   H = h.histogram(**KINDS[kind])
   key = f'{tag}_{kind}'
-  # plane search evaluates candidates with one matrix product (BLAS) instead of
-  # a per-candidate dot: angles agree to ~1e-9 rad, counts to a border case
-  assert np.abs(H._planeNormal - golden[key + '_normal']).max() < 1e-7
-  assert np.abs(H._xInPlaneVec - golden[key + '_xvec']).max() < 1e-7
-  assert np.abs(H._origin - golden[key + '_origin']).max() < 1e-6
-  assert H.hist.sum() == golden[key + '_hist'].sum()
-  assert np.abs(H.hist - golden[key + '_hist']).sum() <= 4
-  assert np.allclose(H.binX, golden[key + '_binX'], atol=1e-6)
-  assert np.allclose(H.binY, golden[key + '_binY'], atol=1e-6)
+  # same plane, same origin, same counts as the reference's own classes, bit for bit
+  assert np.array_equal(H._planeNormal, golden[key + '_normal'])
+  assert np.array_equal(H._xInPlaneVec, golden[key + '_xvec'])
+  assert np.array_equal(H._origin, golden[key + '_origin'])
+  assert np.array_equal(H.hist, golden[key + '_hist'])
+  assert np.array_equal(H.binX, golden[key + '_binX'])
+  assert np.array_equal(H.binY, golden[key + '_binY'])
   if kind.startswith('polar'):
     phi, r, dens = H.byAzimuth()
-    assert dens.shape == golden[key + '_az_dens'].shape
-    assert np.allclose(H.binAreas, golden[key + '_binAreas'], rtol=1e-6)
+    assert np.array_equal(dens, golden[key + '_az_dens'])
+    assert np.array_equal(H.binAreas, golden[key + '_binAreas'])

@@ -173,13 +173,13 @@ def test_max_intersections_and_power_tol(oracle):
   assert r['counters']['died'] == 1 and r['counters']['segments'] == 20
 
 
-def test_gaussian_spot_reference_acceptance(oracle):
+def test_gaussian_spot_reference_acceptance(backend):
   """test/50-old-tests/run-simulations.py:123-174: exp(-theta^2/1e-4) on a
   plane at 100 mm: fitted sigma within 30 % of 100*sqrt(1e-4) = 1 mm, centre
-  < 0.5 mm, > 0.8e5 hits for 1e5 rays"""
+  < 0.5 mm, > 0.8e5 hits for 1e5 rays.  (backend: the CPU oracle, and -- in the
+  gpu suite -- the HIP path itself)"""
   pr = project('gaussian')
-  r = oracle.trace(pr.scene, pr.source, pr.limits, 0, 100000, 11, nthreads=0)
-  p = r['hits']['point']
+  p = backend.hits(pr, 0, 100000, 11)['point']
   assert len(p) > 0.8e5
   assert np.abs(p[:, :2].mean(0)).max() < 0.5
   # density exp(-r^2/sigma^2)  <=>  per-axis std = sigma/sqrt(2)
@@ -214,7 +214,7 @@ def _rms_errors(hits_cls, points, dirs, dens, var, to_var):
 
 
 @pytest.mark.parametrize('mode', ['theta', 'r'])
-def test_monte_carlo_reference_acceptance(oracle, mode):
+def test_monte_carlo_reference_acceptance(backend, mode):
   """1-test-monte-carlo.ipynb: 5 densities x 3 domains, 1e5 hits each,
   cartesian(30) + polar(3x50) histograms vs the analytic density:
   median(rms) < 0.3, max < 3 (finite f) / < 1.5 (f = inf)"""
@@ -247,9 +247,9 @@ def test_monte_carlo_reference_acceptance(oracle, mode):
       # 10x10 mm absorber, so keep tracing batches until enough hits exist
       pts, drs, first = [], [], 0
       while sum(len(p) for p in pts) < 1e5 and first < 2e6:
-        r = oracle.trace(pr.scene, pr.source, pr.limits, first, 100000, 5, nthreads=0)
-        pts.append(r['hits']['point'])
-        drs.append(r['hits']['direction'])
+        rows = backend.hits(pr, first, 100000, 5)
+        pts.append(rows['point'])
+        drs.append(rows['direction'])
         first += 100000
       pts, drs = np.concatenate(pts), np.concatenate(drs)
       assert len(pts) >= 1e5

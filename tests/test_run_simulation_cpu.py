@@ -10,7 +10,7 @@ import warnings
 import numpy as np
 import pytest
 
-from conftest import SCENES
+from conftest import BACKENDS, SCENES
 from oracle_tracer import OracleTracer
 from freecad.optics_design_workbench_amd.scene import open_fcstd
 from freecad.optics_design_workbench_amd.simulation import latestRawFolder, resultsFolderPath, runSimulation
@@ -104,3 +104,32 @@ def test_surface_source_scene_end_criteria(tmp_path, oracle):
       assert len(r.loadHits('*')) > 100
     r = f.runSimulation('fans', tracer=OracleTracer())       # normal rays on an 11 x 11 grid of Face5
     assert r.loadProgress()['totalTracedRays'] == 121 and len(r.loadHits('*')) > 20
+
+
+@pytest.mark.parametrize('backend_name', BACKENDS)
+def test_explicit_launches_carry_the_source_wavelength(backend_name):
+  """every Ray carries wavelength=obj.Wavelength (point_source.py:459): a grating must diffract
+  the fans / pseudo-random rays of a 700 nm source like its true-random rays, not with the
+  500 nm default of a fresh context or with what an earlier launch left behind.  Also: hit
+  lists that outgrow the first guess of the device buffer are re-traced, not dropped."""
+  from conftest import _Backend
+  be = _Backend(backend_name)
+  try:
+    def run(mode, wavelength, tracer):
+      doc = open_fcstd(os.path.join(SCENES, 'grating.FCStd'))
+      (src,) = [o for o in doc.Objects if getattr(o, 'ProxyClass', '') == 'PointSourceProxy']
+      src.Wavelength = wavelength
+      with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        return runSimulation(doc, mode, seed=3, tracer=tracer).hits().hits
+
+    tr = be.tracer()
+    for mode in ('singlefans', 'singlepseudo', 'singletrue'):
+      a, b = run(mode, 500, tr), run(mode, 700, tr)
+      assert len(a['points']) and len(a['points']) == len(b['points']), mode
+      assert np.abs(a['points'] - b['points']).max() > 1e-3, mode       # the first order moves with the wavelength
+      # ... and what an earlier launch left in the context does not matter
+      again = run(mode, 500, tr)
+      assert np.array_equal(a['points'], again['points']), mode
+  finally:
+    be.close()

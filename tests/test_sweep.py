@@ -1,0 +1,102 @@
+"""The sweep's figure of merit and its partition over ranks.
+
+`calcFwhm` (examples/1-getting-started/optimize-spotsize.ipynb cell 8) is pinned by
+tests/golden/fwhm_cases.npz: the polar histogram the reference's own Hits / Histogram
+classes return for synthetic spots, and the FWHM the notebook's arithmetic gives on it
+(tests/golden/make_golden.py::make_fwhm)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, SCENES
+
+from freecad.optics_design_workbench_amd.jupyter_utils import Hits
+from freecad.optics_design_workbench_amd.simulation import sweep
+
+
+@pytest.fixture(scope='module')
+def golden():
+  return np.load(os.path.join(GOLDEN, 'fwhm_cases.npz'))
+
+
+@pytest.mark.parametrize('tag', ['tight', 'wide', 'sparse'])
+def test_calc_fwhm_matches_reference(golden, tag):
+  P, D = golden[tag + '_points'], golden[tag + '_directions']
+  h = Hits(dict(points=P.copy(), directions=D.copy(), powers=np.ones(len(P)), isEntering=np.ones(len(P), dtype=int)))
+  H = h.histogram(binCoords='polar', bins=[np.arange(0, 2 * np.pi, np.pi / 2), np.geomspace(1e-3, 5, 500)])
+  assert np.array_equal(H.hist, golden[tag + '_hist'])
+  assert np.array_equal(H._origin, golden[tag + '_origin'])
+  assert np.array_equal(H.byAzimuth()[2], golden[tag + '_dens'])
+  assert sweep.calcFwhm(h) == float(golden[tag + '_fwhm'])
+
+
+def test_calc_fwhm_of_nothing_is_nan():
+  far = np.array([[0.0, 100.0, 0.0], [0.0, -100.0, 50.0], [0.0, 30.0, -80.0], [0.0, 0.0, 0.0]])   # nothing within 5 mm of the median
+  h = Hits(dict(points=far, directions=np.tile([-1.0, 0, 0], (4, 1)), powers=np.ones(4), isEntering=np.ones(4, dtype=int)))
+  assert np.isnan(sweep.calcFwhm(h)) or sweep.calcFwhm(h) > 0
+
+
+def test_share_of_rank_is_a_partition():
+  for n in (0, 1, 7, 64):
+    for world in (1, 2, 3, 8):
+      got = sorted(k for r in range(world) for k in sweep.shareOfRank(n, r, world))
+      assert got == list(range(n))
+      sizes = [len(sweep.shareOfRank(n, r, world)) for r in range(world)]
+      assert max(sizes) - min(sizes) <= 1
+
+
+def _sweep(tracer, radii, rays, dist=None):
+  from freecad.optics_design_workbench_amd.scene import open_fcstd
+  doc = open_fcstd(os.path.join(SCENES, 'GettingStarted.FCStd'))
+
+  def setRadius(d, r):
+    d.Sphere.Radius = r
+  return sweep.parameterSweep(doc, setRadius, radii, rays=rays, seed=7, tracer=tracer, dist=dist, deviceHits=False)
+
+
+def test_radius_sweep_single_process(oracle):
+  from oracle_tracer import OracleTracer
+  radii = np.linspace(9, 11, 5)
+  res = _sweep(OracleTracer(nthreads=4), radii, 20000)
+  assert res.tracedRays == 5 * 20000 and np.isfinite(res.results).all()
+  assert 9 <= res.best()[0] <= 11
+  # the focus moves through the detector plane: spot sizes are not all alike
+  assert res.results.max() > 1.2 * res.results.min()
+
+
+SWEEP_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], 'tests'))
+import numpy as np, torch.distributed as dist
+from oracle_tracer import OracleTracer
+from test_sweep import _sweep
+dist.init_process_group('gloo')
+res = _sweep(OracleTracer(nthreads=2), np.linspace(9, 11, 5), 20000, dist=dist)
+np.save(sys.argv[2] + f'.rank{dist.get_rank()}.npy', np.concatenate([res.results, [res.tracedRays, res.recordedHits]]))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_radius_sweep_two_ranks_equals_single(tmp_path, oracle):
+  """BASELINE configs[4] partition (radii dealt out over the ranks, one all-reduce of the table):
+  both ranks end with the full table, equal to the single-process one bit for bit"""
+  from oracle_tracer import OracleTracer
+  script = tmp_path / 'sweep_worker.py'
+  script.write_text(SWEEP_WORKER)
+  out = str(tmp_path / 'table')
+  with socket.socket() as s:
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+         '--master-addr', '127.0.0.1', '--master-port', str(port), str(script), ROOT, out]
+  res = subprocess.run(cmd, env=dict(os.environ, OMP_NUM_THREADS='2'), capture_output=True, text=True, timeout=900)
+  assert res.returncode == 0, res.stdout + res.stderr
+  single = _sweep(OracleTracer(nthreads=4), np.linspace(9, 11, 5), 20000)
+  want = np.concatenate([single.results, [single.tracedRays, single.recordedHits]])
+  for r in (0, 1):
+    assert np.array_equal(np.load(out + f'.rank{r}.npy'), want)
