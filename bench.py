@@ -1,20 +1,34 @@
 #!/usr/bin/env python3
 """Headline benchmark: Monte-Carlo rays/second on benchmark/lensesAndMirrors.
 
-  python bench.py --gpus N --steps K --warmup W
-(N>1: launched by torch.distributed.run, one rank per GPU, RCCL.)
+  python bench.py --gpus N --steps K --warmup W [--config c3|c4|c5]
 
-A step = one pass of the hot path (generate -> trace to termination -> record
-64-B hit rows + detector histogram) over one batch of RAYS_PER_STEP rays per
-GPU; inputs (scene tables, CDF tables) are resident in HBM before the timed
-region.  Rays are addressed by a global Philox index, so every rank traces its
-own disjoint index range (weak scaling, no data-path collective); one RCCL
+N > 1 without a launcher: this script starts `python -m torch.distributed.run
+--nproc-per-node N bench.py ...` itself as a CHILD process -- before anything
+here touches the GPU -- relays its output and exits with its code.  Under a
+launcher (RANK / WORLD_SIZE in the environment) it is one rank of N, one rank
+per GPU, RCCL.  Fewer than N devices, or a launcher whose world size is not N,
+is an error: the line never reports another `n_gpus` than the one asked for.
+
+Configs (BASELINE.json `configs`):
+  c3 (default, the metric's config)  benchmark/lensesAndMirrors, 1e8 rays per step per GPU
+  c4  benchmark/hugeArray, 1e9 rays per step sharded over 8 GPUs = 1.25e8 per step per GPU
+      (weak scaling: the per-GPU share stays 1.25e8 for any N), one RCCL histogram reduce
+  c5  examples/1-getting-started radius sweep: 64 radii x 1e7 rays per step, the radii dealt
+      out over the ranks, spot size (the notebook's calcFwhm) per radius, table all-reduced
+
+A step (c3, c4) = one pass of the hot path (generate -> trace to termination ->
+record 64-B hit rows + detector histogram) over one batch of rays per GPU;
+inputs (scene tables, CDF tables) are resident in HBM before the timed region.
+Rays are addressed by a global Philox index, so every rank traces its own
+disjoint index range (weak scaling, no data-path collective); one RCCL
 sum-reduce of the detector histogram + counters to rank 0 closes the timed
 region.  Rank 0 prints one JSON line.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -23,11 +37,26 @@ sys.path.insert(0, ROOT)
 # RCCL / cross-process device memory on this pool needs dmabuf IPC (the image exports it already)
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
-SCENE = os.path.join(ROOT, 'tests', 'golden', 'scenes', 'lensesAndMirrors.FCStd')
+SCENES = os.path.join(ROOT, 'tests', 'golden', 'scenes')
 SEED = 0x0D15EA5E
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 RAY_STATE_BYTES = 64    # S, read + written once per segment
 HIT_BYTES = 64          # H, one row per recorded hit
+
+CONFIGS = {
+    'c3': dict(scene='lensesAndMirrors', rays=1e8, steps=5, warmup=1, kernel='odw_trace_kernel<false, false, false>',
+               workload='benchmark/lensesAndMirrors.FCStd, %.0e Monte-Carlo rays per step per GPU (BASELINE configs[2]), '
+                        'Gaussian point source sigma=1e-2, Philox4x32-10 seed 0x0D15EA5E'),
+    'c4': dict(scene='hugeArray', rays=1.25e8, steps=3, warmup=1, kernel='odw_trace_kernel<true, false, false>',
+               workload='benchmark/hugeArray.FCStd (1500 spheres, BVH kernel), %.3e Monte-Carlo rays per step per GPU = '
+                        'the 1/8 share of 1e9 (BASELINE configs[3]), Gaussian point source sigma=0.2, one RCCL '
+                        'histogram reduce'),
+    'c5': dict(scene='GettingStarted', rays=1e7, steps=1, warmup=0, kernel='odw_trace_kernel<false, false, false>',
+               workload='examples/1-getting-started/GettingStarted.FCStd, spherical-lens radius sweep: 64 radii '
+                        'linspace(9, 11, 64) x %.0e Monte-Carlo rays each per step (BASELINE configs[4]), spot size = '
+                        'calcFwhm of optimize-spotsize.ipynb per radius'),
+}
+N_RADII = 64
 
 
 def host_cores():
@@ -60,7 +89,10 @@ def cpu_baseline(proj, det, seconds=12.0):
   # the oracle hands out 4096 rays at a time to its threads: a call has to hold several such
   # pieces per thread to keep all cores busy; one untimed call first (thread pool start-up,
   # first touch of the 80 MB table)
-  chunk = max(200_000, threads * 4096 * 4)
+  big = proj.scene.n_prims > 64          # brute force over 1500 spheres: ~100x slower per ray
+  chunk = threads * 4096 * (1 if big else 4)
+  if not big:
+    chunk = max(200_000, chunk)
   capi.trace(proj.scene, proj.source, proj.limits, 0, threads * 4096, SEED, det=det, nthreads=threads,
              hit_capacity=threads * 4096 + 16)
   done, t0 = 0, time.perf_counter()
@@ -75,35 +107,56 @@ def cpu_baseline(proj, det, seconds=12.0):
               sample=f'{done} rays of the same workload (oracle/odw_oracle.c, OpenMP, {dt:.1f} s)')
 
 
-def main():
-  ap = argparse.ArgumentParser()
-  ap.add_argument('--gpus', type=int, default=1)
-  ap.add_argument('--steps', type=int, default=5)
-  ap.add_argument('--warmup', type=int, default=1)
-  ap.add_argument('--rays-per-step', type=float, default=1e8)
-  ap.add_argument('--no-cpu-baseline', action='store_true')
-  ap.add_argument('--no-hits', action='store_true', help='histogram only (diagnostic, not the metric)')
-  args = ap.parse_args()
-
-  rank = int(os.environ.get('RANK', 0))
-  local_rank = int(os.environ.get('LOCAL_RANK', 0))
-  world = int(os.environ.get('WORLD_SIZE', 1))
-  n_per = int(args.rays_per_step)
-
+def spawn_ranks(args, argv):
+  """--gpus N > 1 without a launcher: start the N ranks as a child process.  Nothing in this
+  process has touched the GPU yet (torch.cuda.device_count() only counts), and this process is
+  never replaced by another program: it waits for the child and exits with its code."""
+  import socket
   import torch
-  dist = None
-  if world > 1 or 'RANK' in os.environ:   # launched by torch.distributed.run (also with one rank)
-    import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+  have = torch.cuda.device_count()
+  if have < args.gpus:
+    sys.stderr.write(f'bench.py: --gpus {args.gpus} asked for, {have} device(s) present\n')
+    return 2
+  with socket.socket() as s:
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+         '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + argv
+  return subprocess.call(cmd, env=dict(os.environ, MASTER_ADDR='127.0.0.1'))
 
+
+def pmc_figures(cfg_name, n_per, record_hits):
+  """HBM traffic and VALU figures of the dominant kernel from the committed rocprofv3 PMC passes of
+  this same command (profiles/pmc_current.json: FETCH_SIZE / WRITE_SIZE / SQ_* in separate --pmc
+  runs, gfx950 correction applied).  PMC cannot be collected from inside the process, so the
+  figures are attached only when the workload matches the profiled one."""
+  path = os.path.join(ROOT, 'profiles', 'pmc_current.json')
+  if not os.path.exists(path):
+    return None
+  with open(path) as f:
+    allcfg = json.load(f)
+  tj = allcfg.get(cfg_name)
+  if not tj or tj.get('rays_per_launch') != n_per or not record_hits:
+    return None
+  return tj
+
+
+def run_trace_config(args, cfg_name, cfg, rank, local_rank, world, dist, torch):
   from freecad.optics_design_workbench_amd import scenes
   from freecad.optics_design_workbench_amd.simulation import parallel
   from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
 
-  proj = scenes.bakeProject(SCENE)
-  det = scenes.planeDetector(proj.scene, 'OpticalAbsorberGroup', nx=1024, ny=1024,
-                             toward=proj.source.xform[[3, 7, 11]])
+  n_per = int(args.rays_per_step if args.rays_per_step else cfg['rays'])
+  proj = scenes.bakeProject(os.path.join(SCENES, cfg['scene'] + '.FCStd'))
+  if cfg_name == 'c4':
+    # the absorbers are spheres (no planar face): their hits are binned in projection along the
+    # array's z axis, window = the footprint of the 10 x 10 x 5 array (pitch 5 mm) + margin
+    gi = proj.scene.group_index('OpticalAbsorberGroup')
+    det = dict(group=gi, origin=[-0.5, -0.5, 61.0], ex=[1.0, 0.0, 0.0], ey=[0.0, 1.0, 0.0],
+               x_lo=-25.0, x_hi=25.0, y_lo=-25.0, y_hi=25.0, nx=1024, ny=1024)
+  else:
+    det = scenes.planeDetector(proj.scene, 'OpticalAbsorberGroup', nx=1024, ny=1024,
+                               toward=proj.source.xform[[3, 7, 11]])
   tr = Tracer(local_rank)
   tr.setScene(proj.scene)
   tr.setSource(proj.source)
@@ -111,7 +164,8 @@ def main():
   tr.setDetector(det)
   record_hits = not args.no_hits
   if record_hits:
-    tr.reserveHits(n_per + 1024)   # <= 1 recorded hit per ray in this scene; reused every step
+    # c3: <= 1 recorded hit per ray; c4: 0.16 per ray (3 absorber layers of 15); reused every step
+    tr.reserveHits(n_per + 1024 if cfg_name != 'c4' else n_per // 2)
 
   def step(s):
     # hit rows of one step are the step's output; the buffer is recycled
@@ -147,10 +201,12 @@ def main():
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
+  out = None
   if rank == 0:
     cnt = tr.counters()       # after the reduce: whole job on rank 0
     total_rays = n_per * args.steps * world
     assert cnt['traced_rays'] == total_rays, (cnt, total_rays)
+    assert cnt['hits_dropped'] == 0, cnt
     hist_total = int(tr.histogram().sum())
     assert hist_total + cnt['hist_overflow'] == cnt['recorded_hits'], (hist_total, cnt)
     kbar = cnt['segments'] / cnt['traced_rays']
@@ -158,40 +214,185 @@ def main():
     bytes_per_ray = kbar * 2 * RAY_STATE_BYTES + hbar * HIT_BYTES
     avg_kernel_s = kernel_ms / 1e3 / max(1, launches)
     achieved = bytes_per_ray * n_per / avg_kernel_s / 1e9
-    # HBM traffic of one launch from the committed rocprofv3 PMC passes of this
-    # same command (FETCH_SIZE / WRITE_SIZE, separate --pmc runs, gfx950
-    # correction applied; see profiles/traffic.json).  PMC cannot be collected
-    # from inside the process, so the figure is only attached when the
-    # workload matches the profiled one.
-    traffic = traffic_src = traffic_bytes = None
-    tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
-    if os.path.exists(tpath):
-      tj = json.load(open(tpath))
-      if tj.get('rays_per_launch') == n_per and record_hits:
-        traffic_bytes = tj['hbm_bytes_per_launch']
-        traffic = traffic_bytes / avg_kernel_s / 1e9       # same unit as `achieved`
-        traffic_src = tj.get('source')
+    pmc = pmc_figures(cfg_name, n_per, record_hits)
+    traffic = traffic_bytes = valu = None
+    if pmc:
+      traffic_bytes = pmc['hbm_bytes_per_launch']
+      traffic = traffic_bytes / avg_kernel_s / 1e9       # same unit as `achieved`
+      valu = pmc.get('valu')
     out = {
-        'metric': 'Monte-Carlo rays/sec (whole node), lensesAndMirrors.FCStd',
+        'metric': 'Monte-Carlo rays/sec (whole node), lensesAndMirrors.FCStd' if cfg_name == 'c3'
+                  else f'Monte-Carlo rays/sec (whole node), {cfg["scene"]}.FCStd',
         'value': total_rays / dt, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-        'config': {'workload': 'benchmark/lensesAndMirrors.FCStd, %.0e Monte-Carlo rays per step per GPU '
-                               '(BASELINE configs[2]), Gaussian point source sigma=1e-2, Philox4x32-10 seed 0x0D15EA5E'
-                               % n_per,
+        'config': {'workload': cfg['workload'] % n_per, 'name': cfg_name,
                    'rays_per_step_per_gpu': n_per, 'segments_per_ray': kbar, 'hits_per_ray': hbar,
                    'record_hit_rows': record_hits, 'histogram': '1024x1024 u64',
                    'parallelism': f'ray-index sharding x{world}, one RCCL reduce'},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_bytes_per_launch': traffic_bytes,
-                     'algorithmic_bytes_per_launch': bytes_per_ray * n_per, 'traffic_source': traffic_src,
-                     'kernel': 'odw_trace_kernel', 'avg_kernel_ms': avg_kernel_s * 1e3,
-                     'algorithmic_bytes_per_ray': bytes_per_ray},
+                     'algorithmic_bytes_per_launch': bytes_per_ray * n_per,
+                     'traffic_source': pmc.get('source') if pmc else None,
+                     'kernel': cfg['kernel'], 'avg_kernel_ms': avg_kernel_s * 1e3,
+                     'algorithmic_bytes_per_ray': bytes_per_ray, 'valu': valu},
     }
+    if world == 1 and record_hits and cfg_name == 'c3' and not args.no_end_to_end:
+      out['end_to_end'] = end_to_end(tr, n_per, max(2, args.steps))
     if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline(proj, det)
-    print(json.dumps(out), flush=True)
   tr.close()
+  return out
+
+
+def end_to_end(tr, n_per, steps):
+  """PCIe-inclusive rate, reported beside `value` (never as it): every step's hit rows cross to
+  host memory, the copy of step k overlapping the trace of step k+1 (two row buffers, a copy
+  stream of its own, page-locked destination: `Tracer.traceStreaming`)"""
+  if not hasattr(tr, 'traceStreaming'):
+    return None
+  from freecad.optics_design_workbench_amd.simulation import parallel
+  tr.reset()
+  t0 = time.perf_counter()
+  rows = 0
+  for chunk in tr.traceStreaming(((parallel.shardFirst(s, 0, 1, n_per), n_per) for s in range(steps)), SEED,
+                                 capacity=n_per + 1024):
+    rows += len(chunk)
+  dt = time.perf_counter() - t0
+  return dict(rays_per_s=n_per * steps / dt, rows=rows, seconds=dt, gb_per_s=rows * 64 / dt / 1e9,
+              note='hit rows of every step copied to page-locked host memory (unordered), copy of step k '
+                   'overlapped with the trace of step k+1')
+
+
+def run_sweep_config(args, cfg, rank, local_rank, world, dist, torch):
+  import numpy as np
+  from freecad.optics_design_workbench_amd import scenes
+  from freecad.optics_design_workbench_amd.scene import open_fcstd
+  from freecad.optics_design_workbench_amd.simulation import sweep
+  from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
+
+  n_per = int(args.rays_per_step if args.rays_per_step else cfg['rays'])
+  radii = np.linspace(9, 11, args.radii)
+  doc = open_fcstd(os.path.join(SCENES, cfg['scene'] + '.FCStd'))
+
+  def setRadius(d, r):
+    d.Sphere.Radius = float(r)
+  tr = Tracer(local_rank)
+
+  def barrier():
+    tr.sync()
+    torch.cuda.synchronize()
+    if dist is not None:
+      dist.barrier()
+
+  def run():
+    return sweep.parameterSweep(doc, setRadius, radii, rays=n_per, seed=SEED, tracer=tr, dist=dist,
+                                measure=dict(fwhm=sweep.calcFwhm, rms=sweep.rmsSpot))
+
+  for _ in range(args.warmup):
+    run()
+  barrier()
+  tr.timingEnable(True)
+  tr.timingRead()
+  barrier()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    res = run()
+  barrier()
+  dt = time.perf_counter() - t0
+  kernel_ms, launches = tr.timingRead()
+  if dist is not None:
+    t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+  out = None
+  if rank == 0:
+    total_rays = n_per * len(radii) * args.steps
+    assert res.tracedRays == n_per * len(radii), (res.tracedRays, n_per, len(radii))
+    kbar = res.segments / res.tracedRays
+    hbar = res.recordedHits / res.tracedRays
+    bytes_per_ray = kbar * 2 * RAY_STATE_BYTES + hbar * HIT_BYTES
+    avg_kernel_s = kernel_ms / 1e3 / max(1, launches)
+    achieved = bytes_per_ray * n_per / avg_kernel_s / 1e9
+    best_r, best_f = res.best('fwhm') if np.isfinite(res.columns['fwhm']).any() else (float('nan'), float('nan'))
+    rms_r, rms_v = res.best('rms')
+    out = {
+        'metric': 'Monte-Carlo rays/sec (whole node), GettingStarted.FCStd radius sweep',
+        'value': total_rays / dt, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
+        'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': cfg['workload'] % n_per, 'name': 'c5', 'radii': len(radii),
+                   'rays_per_radius': n_per, 'segments_per_ray': kbar, 'hits_per_ray': hbar,
+                   'parallelism': f'radii dealt out over {world} rank(s), one RCCL all-reduce of the table',
+                   'spot_size': {'kind': 'calcFwhm (optimize-spotsize.ipynb cell 8)', 'radii': radii.tolist(),
+                                 'fwhm_mm': [None if np.isnan(v) else float(v) for v in res.columns['fwhm']],
+                                 'best_radius_mm': best_r, 'best_fwhm_mm': best_f,
+                                 'fwhm_note': 'null = the notebook\'s fit finds no half-maximum (its except clause '
+                                              'skips such azimuth bins): with 1e7 hits the innermost radial bins are '
+                                              'flat near the focus; the rms spot radius below stays defined',
+                                 'rms_spot_mm': [float(v) for v in res.columns['rms']],
+                                 'best_radius_by_rms_mm': rms_r, 'best_rms_spot_mm': rms_v}},
+        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                     'algorithmic_bytes_per_launch': bytes_per_ray * n_per, 'kernel': cfg['kernel'],
+                     'avg_kernel_ms': avg_kernel_s * 1e3, 'algorithmic_bytes_per_ray': bytes_per_ray,
+                     'note': 'launches of rank 0; a launch = one radius; per step the host also re-bakes the scene and '
+                             'searches the detector plane per radius (host-bound at 1e7 rays per radius)'},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+      proj = scenes.bakeProject(doc)
+      out['cpu_baseline'] = cpu_baseline(proj, None, seconds=8.0)
+  tr.close()
+  return out
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=None)
+  ap.add_argument('--warmup', type=int, default=None)
+  ap.add_argument('--config', choices=sorted(CONFIGS), default='c3')
+  ap.add_argument('--rays-per-step', type=float, default=None,
+                  help='rays per step per GPU (c5: per radius); default: the BASELINE size of the config')
+  ap.add_argument('--radii', type=int, default=N_RADII, help='c5: number of radii of the sweep')
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--no-end-to-end', action='store_true')
+  ap.add_argument('--no-hits', action='store_true', help='histogram only (diagnostic, not the metric)')
+  args = ap.parse_args()
+  cfg = CONFIGS[args.config]
+  if args.steps is None:
+    args.steps = cfg['steps']
+  if args.warmup is None:
+    args.warmup = cfg['warmup']
+  if args.gpus < 1:
+    ap.error('--gpus must be >= 1')
+
+  launched = 'RANK' in os.environ
+  if args.gpus > 1 and not launched:
+    sys.exit(spawn_ranks(args, sys.argv[1:]))
+  rank = int(os.environ.get('RANK', 0))
+  local_rank = int(os.environ.get('LOCAL_RANK', 0))
+  world = int(os.environ.get('WORLD_SIZE', 1))
+  if world != args.gpus:
+    sys.stderr.write(f'bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)\n')
+    sys.exit(2)
+
+  import torch
+  if torch.cuda.device_count() < world:
+    sys.stderr.write(f'bench.py: {world} rank(s) but {torch.cuda.device_count()} device(s) present\n')
+    sys.exit(2)
+  dist = None
+  if launched:   # launched by torch.distributed.run (also with one rank)
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+  if args.config == 'c5':
+    out = run_sweep_config(args, cfg, rank, local_rank, world, dist, torch)
+  else:
+    out = run_trace_config(args, args.config, cfg, rank, local_rank, world, dist, torch)
+  if rank == 0:
+    print(json.dumps(out), flush=True)
   if dist is not None:
     dist.barrier()
     dist.destroy_process_group()

@@ -63,6 +63,11 @@ struct odw_ctx {
   uint64_t seg_capacity = 0;
   DevBuf ray_o, ray_d, ray_p, samp_t, samp_phi;
   DevBuf sort_keys[2], sort_vals[2], sort_tmp, sorted_rows;
+  // post-hoc binning of the rows in HBM (odw_posthoc.hip): the selection = sort_vals[1][0 .. ph_n)
+  DevBuf ph_sel_entering, ph_flags, ph_x, ph_y, ph_sorted, ph_small, ph_part, ph_edges, ph_edges_b, ph_counts;
+  uint64_t ph_n = 0, ph_n_entering = 0;
+  int ph_group = -1;
+  bool ph_valid = false, ph_projected = false, ph_entering_built = false;
   // stochastic surfaces: one table set per sampler, descriptor block, (group, kind) -> index
   struct SurfaceBufs { DevBuf phi_tab, t_tab, t_guide; };
   std::vector<SurfaceBufs> surf_bufs;
@@ -75,6 +80,13 @@ struct odw_ctx {
   bool emitter_active = false;   // the most recently uploaded source is a surface source
   uint64_t hit_capacity = 0, n_bins = 0;   // hit_capacity: rows the caller asked for
   uint64_t hit_slots = 0;                  // rows allocated (capacity + slack for block reservations)
+  // second hit list (odw_swap_hit_lists): while one is traced into, the other is copied to the host
+  // on a stream of its own
+  DevBuf alt_hits, alt_hit_count;
+  uint64_t alt_capacity = 0, alt_slots = 0;
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t alt_ready = nullptr;          // recorded on the trace stream when the list was put aside
+  bool swapping = false;                   // lists are swapped: appends stay dense (no block reservations)
 
   TraceParams P;
   odw_detector_desc det_desc;
@@ -493,6 +505,7 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
   if (!ctx->have_scene || !ctx->have_limits) return fail(ctx, ODW_ERR_NO_SCENE, "scene/limits not uploaded");
   if (!explicit_rays && !ctx->have_source) return fail(ctx, ODW_ERR_NO_SCENE, "source not uploaded");
   if (n == 0) return ODW_OK;
+  ctx->ph_valid = false;           // the hit list is about to change
   if (ctx->bvh_dirty) {
     int rc = build_bvh(ctx);
     if (rc) return rc;
@@ -536,7 +549,7 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
   const uint64_t n_chunks = (n + ODW_CHUNK - 1) / ODW_CHUNK;
   const uint64_t cap = (uint64_t)ctx->n_cu * grid_mult;
   const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_chunks + 3) / 4, cap));
-  if (!P.scene.n_nodes &&
+  if (!P.scene.n_nodes && !ctx->swapping &&
       ctx->hit_slots >= ctx->hit_capacity + ctx->hit_capacity / 8 + 64 + (uint64_t)grid * 4 * kHitBlock)
     P.out.hit_block = kHitBlock;     // flat kernels only (see record_hit)
   HIPCHK(ctx, hipMemsetAsync(ctx->chunk_counter.p, 0, sizeof(uint64_t), ctx->stream));
@@ -654,6 +667,13 @@ void odw_destroy(odw_ctx* ctx) {
   for (auto& sb : ctx->surf_bufs) { release(sb.phi_tab); release(sb.t_tab); release(sb.t_guide); }
   release(ctx->d_samplers);
   release(ctx->d_group_sampler);
+  for (DevBuf* b : {&ctx->ph_sel_entering, &ctx->ph_flags, &ctx->ph_x, &ctx->ph_y, &ctx->ph_sorted, &ctx->ph_small,
+                    &ctx->ph_part, &ctx->ph_edges, &ctx->ph_edges_b, &ctx->ph_counts})
+    release(*b);
+  release(ctx->alt_hits);
+  release(ctx->alt_hit_count);
+  if (ctx->alt_ready) (void)hipEventDestroy(ctx->alt_ready);
+  if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -1192,6 +1212,7 @@ int odw_sync(odw_ctx* ctx) {
 int odw_reset_results(odw_ctx* ctx) {
   if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_reset_results: null ctx");
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  ctx->ph_valid = false;
   HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, ODW_CNT_COUNT * sizeof(uint64_t), ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(ctx->hit_count.p, 0, 2 * sizeof(uint64_t), ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(ctx->seg_count.p, 0, sizeof(uint64_t), ctx->stream));
@@ -1208,6 +1229,7 @@ int odw_reset_segments(odw_ctx* ctx) {
 
 int odw_reset_hits(odw_ctx* ctx) {
   if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_reset_hits: null ctx");
+  ctx->ph_valid = false;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipMemsetAsync(ctx->hit_count.p, 0, 2 * sizeof(uint64_t), ctx->stream));
   return ODW_OK;
@@ -1248,6 +1270,7 @@ int odw_fetch_hits(odw_ctx* ctx, odw_hit* out, uint64_t capacity, uint64_t* n) {
   *n = have;
   if (!out || capacity == 0) return ODW_OK;
   if (have > capacity) return fail(ctx, ODW_ERR_CAPACITY, "odw_fetch_hits: output buffer too small");
+  ctx->ph_valid = false;           // the sort buffers are shared with odw_hits_select
   if (have) {
     // append order is scheduling dependent; a ray's own rows are appended in
     // bounce order, so a STABLE sort by ray index gives (ray, bounce) order.
@@ -1284,6 +1307,52 @@ int odw_fetch_hits(odw_ctx* ctx, odw_hit* out, uint64_t capacity, uint64_t* n) {
   return ODW_OK;
 }
 
+int odw_swap_hit_lists(odw_ctx* ctx) {
+  if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_swap_hit_lists: null ctx");
+  if (ctx->hit_capacity == 0) return fail(ctx, ODW_ERR_CAPACITY, "odw_swap_hit_lists without odw_reserve_hits");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ctx->ph_valid = false;
+  if (!ctx->copy_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+  if (!ctx->alt_ready) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->alt_ready, hipEventDisableTiming));
+  if (ctx->alt_slots < ctx->hit_slots) {     // the other list gets the same room
+    HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
+    release(ctx->alt_hits);
+    int rc = ensure(ctx, ctx->alt_hits, ctx->hit_slots * sizeof(odw_hit));
+    if (!rc) rc = ensure(ctx, ctx->alt_hit_count, 2 * sizeof(uint64_t));
+    if (rc) return rc;
+    ctx->alt_capacity = ctx->hit_capacity;
+    ctx->alt_slots = ctx->hit_slots;
+    HIPCHK(ctx, hipMemsetAsync(ctx->alt_hit_count.p, 0, 2 * sizeof(uint64_t), ctx->stream));
+  }
+  // everything launched so far wrote into the list that is put aside now
+  HIPCHK(ctx, hipEventRecord(ctx->alt_ready, ctx->stream));
+  std::swap(ctx->hits, ctx->alt_hits);
+  std::swap(ctx->hit_count, ctx->alt_hit_count);
+  std::swap(ctx->hit_capacity, ctx->alt_capacity);
+  std::swap(ctx->hit_slots, ctx->alt_slots);
+  ctx->swapping = true;
+  return ODW_OK;
+}
+
+int odw_fetch_swapped_hits(odw_ctx* ctx, odw_hit* out, uint64_t capacity, uint64_t* n) {
+  if (!ctx || !n) return fail(ctx, ODW_ERR_INVALID, "odw_fetch_swapped_hits: bad argument");
+  if (!ctx->swapping || !ctx->copy_stream) return fail(ctx, ODW_ERR_INVALID, "odw_fetch_swapped_hits: odw_swap_hit_lists first");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  // the copy stream waits for the launches that filled the list, not for what runs on the trace
+  // stream since: the next launch proceeds while these rows cross PCIe
+  HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->alt_ready, 0));
+  uint64_t v[2] = {0, 0};
+  HIPCHK(ctx, hipMemcpyAsync(v, ctx->alt_hit_count.p, sizeof v, hipMemcpyDeviceToHost, ctx->copy_stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
+  const uint64_t have = std::min<uint64_t>(v[0], ctx->alt_slots);    // dense: no unused slots in swapped lists
+  *n = have;
+  if (!out || capacity == 0 || have == 0) return ODW_OK;
+  if (have > capacity) return fail(ctx, ODW_ERR_CAPACITY, "odw_fetch_swapped_hits: output buffer too small");
+  HIPCHK(ctx, hipMemcpyAsync(out, ctx->alt_hits.p, have * sizeof(odw_hit), hipMemcpyDeviceToHost, ctx->copy_stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
+  return ODW_OK;
+}
+
 int odw_segment_count(odw_ctx* ctx, uint64_t* n, uint64_t* dropped) {
   if (!ctx || !n) return fail(ctx, ODW_ERR_INVALID, "odw_segment_count: bad argument");
   HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -1297,6 +1366,7 @@ int odw_segment_count(odw_ctx* ctx, uint64_t* n, uint64_t* dropped) {
 
 int odw_fetch_segments(odw_ctx* ctx, odw_segment* out, uint64_t capacity, uint64_t* n) {
   if (!ctx || !n) return fail(ctx, ODW_ERR_INVALID, "odw_fetch_segments: bad argument");
+  ctx->ph_valid = false;           // the sort buffers are shared with odw_hits_select
   uint64_t have = 0;
   int rc = odw_segment_count(ctx, &have, nullptr);
   if (rc) return rc;
@@ -1405,3 +1475,5 @@ int odw_timing_read(odw_ctx* ctx, double* total_ms, uint64_t* launches) {
 }
 
 }  // extern "C"
+
+#include "odw_posthoc.hip"

@@ -1,0 +1,419 @@
+// odw_posthoc.hip -- the reference's post-hoc detector binning on the hit rows where they are.
+//
+// Reference: Hits.histogram (jupyter_utils/hits.py:176-193) = detectPlaneNormal on a thinned
+// sample (:96-174) -> planeProject3dPoints (:62-94) -> Histogram.__init__ (histogram.py:24-57):
+// median origin, numpy.histogram2d of (X, Y) or of (arctan2(X, Y), hypot(X, Y)).  The plane
+// search works on <= 300 rows and stays on the host (its arithmetic is numpy's, bit for bit);
+// everything that touches all M rows runs here, on the rows in HBM:
+//   select   rows of one group in (ray, bounce) order   radix sort of (ray index -> slot) pairs
+//   gather   every k-th selected row                     (the thinned sample, <= 300 rows)
+//   project  X = p . ex, Y = p . ey                      one 24-byte gather per row, no fma
+//   medians  + extrema of X and Y                        radix sort of the 8-byte keys
+//   bin      numpy.histogramdd's rule: searchsorted(edges, v, 'right') - 1, the last edge closed;
+//            counts in LDS (<= 8192 bins) or by global atomics
+// Included by odw_capi.hip (one translation unit).
+
+namespace {
+
+constexpr int kPhLdsBins = 8192;
+constexpr int kPhLdsEdges = 2048;
+
+__global__ void ph_keys_kernel(const odw_hit* __restrict__ hits, uint64_t n, int group, uint64_t* __restrict__ keys,
+                               uint32_t* __restrict__ vals, unsigned long long* __restrict__ counts) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool sel = false, leaving = false;
+  if (i < n) {
+    const uint64_t tag = hits[i].tag;
+    sel = tag != ODW_TAG_UNUSED && (group < 0 || (int)ODW_HIT_GROUP(tag) == group);
+    leaving = sel && !ODW_HIT_ENTERING(tag);
+    keys[i] = sel ? ODW_HIT_RAY(tag) : (1ull << 48);     // everything else sorts behind every ray
+    vals[i] = (uint32_t)i;
+  }
+  const unsigned long long bs = __ballot(sel), bl = __ballot(leaving);
+  if ((threadIdx.x & 63) == 0) {
+    if (bs) atomicAdd(counts, (unsigned long long)__popcll(bs));
+    if (bl) atomicAdd(counts + 1, (unsigned long long)__popcll(bl));
+  }
+}
+
+__global__ void ph_entering_flags_kernel(const odw_hit* __restrict__ hits, const uint32_t* __restrict__ sel, uint64_t m,
+                                         uint8_t* __restrict__ flags) {
+  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < m) flags[j] = ODW_HIT_ENTERING(hits[sel[j]].tag) ? 1 : 0;
+}
+
+// rows sel[j * stride], j < count: four lanes per 64-byte row
+__global__ void ph_gather_strided_kernel(const odw_hit* __restrict__ hits, const uint32_t* __restrict__ sel,
+                                         uint64_t stride, uint64_t count, odw_hit* __restrict__ out) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t row = t >> 2;
+  if (row < count) {
+    const double2* src = reinterpret_cast<const double2*>(hits + sel[row * stride]);
+    reinterpret_cast<double2*>(out + row)[t & 3] = src[t & 3];
+  }
+}
+
+// numpy.dot(points, axis): three products, summed left to right, no contraction
+__global__ void ph_project_kernel(const odw_hit* __restrict__ hits, const uint32_t* __restrict__ sel, uint64_t m, int key,
+                                  double ex0, double ex1, double ex2, double ey0, double ey1, double ey2,
+                                  double* __restrict__ X, double* __restrict__ Y) {
+#pragma clang fp contract(off)
+  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < m) {
+    const double* p = key ? hits[sel[j]].direction : hits[sel[j]].point;
+    const double a = p[0], b = p[1], c = p[2];
+    X[j] = a * ex0 + b * ex1 + c * ex2;
+    Y[j] = a * ey0 + b * ey1 + c * ey2;
+  }
+}
+
+// the two coordinates Histogram bins: cartesian (X - ox, Y - oy); polar (arctan2(X, Y), sqrt(X^2 + Y^2))
+__device__ __forceinline__ void ph_coords(double x, double y, double ox, double oy, int polar, double& a, double& b) {
+#pragma clang fp contract(off)
+  x = x - ox;
+  y = y - oy;
+  if (polar) {
+    a = atan2(x, y);
+    b = sqrt(x * x + y * y);
+  } else {
+    a = x;
+    b = y;
+  }
+}
+
+// min / max of both coordinates (for bin counts given as integers: numpy takes the data's range)
+__global__ void ph_range_kernel(const double* __restrict__ X, const double* __restrict__ Y, uint64_t m, double ox,
+                                double oy, int polar, double* __restrict__ part) {
+  double lo_a = INFINITY, hi_a = -INFINITY, lo_b = INFINITY, hi_b = -INFINITY;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
+    double a, b;
+    ph_coords(X[j], Y[j], ox, oy, polar, a, b);
+    lo_a = fmin(lo_a, a); hi_a = fmax(hi_a, a);
+    lo_b = fmin(lo_b, b); hi_b = fmax(hi_b, b);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    lo_a = fmin(lo_a, __shfl_xor(lo_a, off)); hi_a = fmax(hi_a, __shfl_xor(hi_a, off));
+    lo_b = fmin(lo_b, __shfl_xor(lo_b, off)); hi_b = fmax(hi_b, __shfl_xor(hi_b, off));
+  }
+  __shared__ double s[4][4];
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { s[w][0] = lo_a; s[w][1] = hi_a; s[w][2] = lo_b; s[w][3] = hi_b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 4; ++k) {
+      s[0][0] = fmin(s[0][0], s[k][0]); s[0][1] = fmax(s[0][1], s[k][1]);
+      s[0][2] = fmin(s[0][2], s[k][2]); s[0][3] = fmax(s[0][3], s[k][3]);
+    }
+    for (int k = 0; k < 4; ++k) part[4 * blockIdx.x + k] = s[0][k];
+  }
+}
+
+// numpy.searchsorted(edges, v, side='right') - 1, with v == edges[-1] moved into the last bin
+// (numpy/lib/_histograms_impl.py, histogramdd); -1: outside (or NaN)
+__device__ __forceinline__ int ph_bin(const double* __restrict__ edges, int n, double v) {
+  if (!(v >= edges[0]) || !(v <= edges[n - 1])) return -1;
+  int lo = 0, hi = n;                 // first index with edges[i] > v
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (edges[mid] <= v) lo = mid + 1; else hi = mid;
+  }
+  return v == edges[n - 1] ? n - 2 : lo - 1;
+}
+
+template <bool LDS_COUNTS>
+__global__ __launch_bounds__(256) void ph_bin_kernel(const double* __restrict__ X, const double* __restrict__ Y,
+                                                     uint64_t m, double ox, double oy, int polar,
+                                                     const double* __restrict__ edges_a, int na,
+                                                     const double* __restrict__ edges_b, int nb,
+                                                     unsigned long long* __restrict__ counts) {
+  __shared__ double s_edges[kPhLdsEdges];
+  __shared__ uint32_t s_counts[LDS_COUNTS ? kPhLdsBins : 1];
+  const bool edges_in_lds = na + nb <= kPhLdsEdges;
+  if (edges_in_lds) {
+    for (int k = threadIdx.x; k < na; k += blockDim.x) s_edges[k] = edges_a[k];
+    for (int k = threadIdx.x; k < nb; k += blockDim.x) s_edges[na + k] = edges_b[k];
+  }
+  const int nbins = (na - 1) * (nb - 1);
+  if (LDS_COUNTS)
+    for (int k = threadIdx.x; k < nbins; k += blockDim.x) s_counts[k] = 0;
+  __syncthreads();
+  const double* ea = edges_in_lds ? s_edges : edges_a;
+  const double* eb = edges_in_lds ? s_edges + na : edges_b;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
+    double a, b;
+    ph_coords(X[j], Y[j], ox, oy, polar, a, b);
+    const int ia = ph_bin(ea, na, a);
+    const int ib = ph_bin(eb, nb, b);
+    if (ia >= 0 && ib >= 0) {
+      const int k = ia * (nb - 1) + ib;
+      if (LDS_COUNTS) atomicAdd(&s_counts[k], 1u);
+      else atomicAdd(counts + k, 1ull);
+    }
+  }
+  if (LDS_COUNTS) {
+    __syncthreads();
+    for (int k = threadIdx.x; k < nbins; k += blockDim.x)
+      if (s_counts[k]) atomicAdd(counts + k, (unsigned long long)s_counts[k]);
+  }
+}
+
+// mean and centred second moments of the selected rows' points (two passes)
+__global__ void ph_moment_kernel(const odw_hit* __restrict__ hits, const uint32_t* __restrict__ sel, uint64_t m,
+                                 double cx, double cy, double cz, int squared, double* __restrict__ part) {
+  double sx = 0, sy = 0, sz = 0;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
+    const double* p = hits[sel[j]].point;
+    const double dx = p[0] - cx, dy = p[1] - cy, dz = p[2] - cz;
+    sx += squared ? dx * dx : dx;
+    sy += squared ? dy * dy : dy;
+    sz += squared ? dz * dz : dz;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    sx += __shfl_xor(sx, off); sy += __shfl_xor(sy, off); sz += __shfl_xor(sz, off);
+  }
+  __shared__ double s[4][3];
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { s[w][0] = sx; s[w][1] = sy; s[w][2] = sz; }
+  __syncthreads();
+  if (threadIdx.x == 0)
+    for (int k = 0; k < 3; ++k) part[3 * blockIdx.x + k] = s[0][k] + s[1][k] + s[2][k] + s[3][k];
+}
+
+int ph_need_selection(odw_ctx* ctx, const char* who) {
+  if (!ctx->ph_valid) return fail(ctx, ODW_ERR_INVALID, std::string(who) + ": odw_hits_select first (the hit list changed since)");
+  return ODW_OK;
+}
+
+int ph_need_projection(odw_ctx* ctx, const char* who) {
+  int rc = ph_need_selection(ctx, who);
+  if (rc) return rc;
+  if (!ctx->ph_projected) return fail(ctx, ODW_ERR_INVALID, std::string(who) + ": odw_hits_project first");
+  return ODW_OK;
+}
+
+// sorted copy of v[0..m) -> the two middle values and the extrema
+int ph_sorted_stats(odw_ctx* ctx, const double* v, uint64_t m, double out[4]) {
+  int rc;
+  if ((rc = ensure(ctx, ctx->ph_sorted, m * sizeof(double)))) return rc;
+  size_t tmp_bytes = 0;
+  HIPCHK(ctx, hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, v, (double*)ctx->ph_sorted.p, (int)m, 0, 64, ctx->stream));
+  if ((rc = ensure(ctx, ctx->sort_tmp, tmp_bytes))) return rc;
+  HIPCHK(ctx, hipcub::DeviceRadixSort::SortKeys(ctx->sort_tmp.p, tmp_bytes, v, (double*)ctx->ph_sorted.p, (int)m, 0, 64,
+                                                ctx->stream));
+  const double* s = (const double*)ctx->ph_sorted.p;
+  const uint64_t at[4] = {(m - 1) / 2, m / 2, 0, m - 1};      // numpy.median: mean of these two
+  for (int k = 0; k < 4; ++k)
+    HIPCHK(ctx, hipMemcpyAsync(out + k, s + at[k], sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return ODW_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int odw_load_hits(odw_ctx* ctx, const odw_hit* rows, uint64_t n) {
+  if (!ctx || (!rows && n)) return fail(ctx, ODW_ERR_INVALID, "odw_load_hits: bad argument");
+  int rc = odw_reserve_hits(ctx, std::max<uint64_t>(n, 16));
+  if (rc) return rc;
+  ctx->ph_valid = false;
+  if (n) HIPCHK(ctx, hipMemcpyAsync(ctx->hits.p, rows, n * sizeof(odw_hit), hipMemcpyHostToDevice, ctx->stream));
+  const uint64_t count[2] = {n, 0};
+  HIPCHK(ctx, hipMemcpyAsync(ctx->hit_count.p, count, sizeof count, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // the caller's rows and `count` may go away
+  return ODW_OK;
+}
+
+int odw_hits_select(odw_ctx* ctx, int32_t group, uint64_t* n_rows, uint64_t* n_leaving) {
+  if (!ctx || !n_rows) return fail(ctx, ODW_ERR_INVALID, "odw_hits_select: bad argument");
+  ctx->ph_valid = ctx->ph_projected = false;
+  uint64_t used = 0, have = 0;
+  int rc = hit_slots_used(ctx, &used, &have);
+  if (rc) return rc;
+  ctx->ph_n = ctx->ph_n_entering = 0;
+  *n_rows = 0;
+  if (n_leaving) *n_leaving = 0;
+  if (used > 0x7FFFFFFFull) return fail(ctx, ODW_ERR_CAPACITY, "odw_hits_select: more than 2^31 rows");
+  if (used) {
+    for (int k = 0; k < 2; ++k) {
+      if ((rc = ensure(ctx, ctx->sort_keys[k], used * sizeof(uint64_t)))) return rc;
+      if ((rc = ensure(ctx, ctx->sort_vals[k], used * sizeof(uint32_t)))) return rc;
+    }
+    if ((rc = ensure(ctx, ctx->ph_small, 64))) return rc;
+    HIPCHK(ctx, hipMemsetAsync(ctx->ph_small.p, 0, 2 * sizeof(uint64_t), ctx->stream));
+    uint64_t* k_in = (uint64_t*)ctx->sort_keys[0].p;
+    uint64_t* k_out = (uint64_t*)ctx->sort_keys[1].p;
+    uint32_t* v_in = (uint32_t*)ctx->sort_vals[0].p;
+    uint32_t* v_out = (uint32_t*)ctx->sort_vals[1].p;
+    hipLaunchKernelGGL(ph_keys_kernel, dim3((unsigned)((used + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const odw_hit*)ctx->hits.p, used, (int)group, k_in, v_in, (unsigned long long*)ctx->ph_small.p);
+    HIPCHK(ctx, hipGetLastError());
+    size_t tmp_bytes = 0;
+    HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k_in, k_out, v_in, v_out, (int)used, 0, 49,
+                                                   ctx->stream));
+    if ((rc = ensure(ctx, ctx->sort_tmp, tmp_bytes))) return rc;
+    HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(ctx->sort_tmp.p, tmp_bytes, k_in, k_out, v_in, v_out, (int)used, 0,
+                                                   49, ctx->stream));
+    uint64_t c[2] = {0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(c, ctx->ph_small.p, sizeof c, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->ph_n = c[0];
+    ctx->ph_n_entering = c[0] - c[1];
+    ctx->ph_entering_built = false;
+    *n_rows = c[0];
+    if (n_leaving) *n_leaving = c[1];
+  }
+  ctx->ph_group = group;
+  ctx->ph_valid = true;
+  return ODW_OK;
+}
+
+int odw_hits_gather(odw_ctx* ctx, int32_t entering_only, uint64_t stride, odw_hit* out, uint64_t capacity, uint64_t* n) {
+  if (!ctx || !n || stride == 0) return fail(ctx, ODW_ERR_INVALID, "odw_hits_gather: bad argument");
+  int rc = ph_need_selection(ctx, "odw_hits_gather");
+  if (rc) return rc;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const uint32_t* sel = (const uint32_t*)ctx->sort_vals[1].p;
+  uint64_t m = ctx->ph_n;
+  if (entering_only) {
+    // rows with isEntering != 0, still in (ray, bounce) order: flags + stream compaction
+    if (!ctx->ph_entering_built && m) {
+      if ((rc = ensure(ctx, ctx->ph_flags, m))) return rc;
+      if ((rc = ensure(ctx, ctx->ph_sel_entering, m * sizeof(uint32_t)))) return rc;
+      hipLaunchKernelGGL(ph_entering_flags_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream,
+                         (const odw_hit*)ctx->hits.p, sel, m, (uint8_t*)ctx->ph_flags.p);
+      HIPCHK(ctx, hipGetLastError());
+      size_t tmp_bytes = 0;
+      HIPCHK(ctx, hipcub::DeviceSelect::Flagged(nullptr, tmp_bytes, sel, (const uint8_t*)ctx->ph_flags.p,
+                                                (uint32_t*)ctx->ph_sel_entering.p, (uint64_t*)ctx->ph_small.p, (int)m,
+                                                ctx->stream));
+      if ((rc = ensure(ctx, ctx->sort_tmp, tmp_bytes))) return rc;
+      HIPCHK(ctx, hipcub::DeviceSelect::Flagged(ctx->sort_tmp.p, tmp_bytes, sel, (const uint8_t*)ctx->ph_flags.p,
+                                                (uint32_t*)ctx->ph_sel_entering.p, (uint64_t*)ctx->ph_small.p, (int)m,
+                                                ctx->stream));
+      ctx->ph_entering_built = true;
+    }
+    sel = (const uint32_t*)ctx->ph_sel_entering.p;
+    m = ctx->ph_n_entering;
+  }
+  const uint64_t count = (m + stride - 1) / stride;
+  *n = count;
+  if (!out || count == 0) return ODW_OK;
+  if (count > capacity) return fail(ctx, ODW_ERR_CAPACITY, "odw_hits_gather: output buffer too small");
+  if ((rc = ensure(ctx, ctx->sorted_rows, count * sizeof(odw_hit)))) return rc;
+  hipLaunchKernelGGL(ph_gather_strided_kernel, dim3((unsigned)((count * 4 + 255) / 256)), dim3(256), 0, ctx->stream,
+                     (const odw_hit*)ctx->hits.p, sel, stride, count, (odw_hit*)ctx->sorted_rows.p);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpyAsync(out, ctx->sorted_rows.p, count * sizeof(odw_hit), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return ODW_OK;
+}
+
+int odw_hits_project(odw_ctx* ctx, int32_t key, const double* ex, const double* ey, double* stats) {
+  if (!ctx || !ex || !ey || !stats) return fail(ctx, ODW_ERR_INVALID, "odw_hits_project: bad argument");
+  int rc = ph_need_selection(ctx, "odw_hits_project");
+  if (rc) return rc;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ctx->ph_projected = false;
+  const uint64_t m = ctx->ph_n;
+  if (m == 0) return fail(ctx, ODW_ERR_INVALID, "odw_hits_project: no rows selected");
+  if ((rc = ensure(ctx, ctx->ph_x, m * sizeof(double)))) return rc;
+  if ((rc = ensure(ctx, ctx->ph_y, m * sizeof(double)))) return rc;
+  hipLaunchKernelGGL(ph_project_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream,
+                     (const odw_hit*)ctx->hits.p, (const uint32_t*)ctx->sort_vals[1].p, m, (int)key, ex[0], ex[1], ex[2],
+                     ey[0], ey[1], ey[2], (double*)ctx->ph_x.p, (double*)ctx->ph_y.p);
+  HIPCHK(ctx, hipGetLastError());
+  if ((rc = ph_sorted_stats(ctx, (const double*)ctx->ph_x.p, m, stats))) return rc;
+  if ((rc = ph_sorted_stats(ctx, (const double*)ctx->ph_y.p, m, stats + 4))) return rc;
+  ctx->ph_projected = true;
+  return ODW_OK;
+}
+
+int odw_hits_range(odw_ctx* ctx, int32_t polar, const double* origin, double* range) {
+  if (!ctx || !origin || !range) return fail(ctx, ODW_ERR_INVALID, "odw_hits_range: bad argument");
+  int rc = ph_need_projection(ctx, "odw_hits_range");
+  if (rc) return rc;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const uint64_t m = ctx->ph_n;
+  const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((m + 255) / 256, (uint64_t)ctx->n_cu * 8));
+  if ((rc = ensure(ctx, ctx->ph_part, (size_t)grid * 4 * sizeof(double)))) return rc;
+  hipLaunchKernelGGL(ph_range_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const double*)ctx->ph_x.p,
+                     (const double*)ctx->ph_y.p, m, origin[0], origin[1], (int)polar, (double*)ctx->ph_part.p);
+  HIPCHK(ctx, hipGetLastError());
+  std::vector<double> part((size_t)grid * 4);
+  HIPCHK(ctx, hipMemcpyAsync(part.data(), ctx->ph_part.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  range[0] = range[2] = INFINITY;
+  range[1] = range[3] = -INFINITY;
+  for (unsigned b = 0; b < grid; ++b) {
+    range[0] = std::fmin(range[0], part[4 * b]); range[1] = std::fmax(range[1], part[4 * b + 1]);
+    range[2] = std::fmin(range[2], part[4 * b + 2]); range[3] = std::fmax(range[3], part[4 * b + 3]);
+  }
+  return ODW_OK;
+}
+
+int odw_hits_bin(odw_ctx* ctx, int32_t polar, const double* origin, const double* edges_a, int32_t n_a,
+                 const double* edges_b, int32_t n_b, uint64_t* counts) {
+  if (!ctx || !origin || !edges_a || !edges_b || !counts || n_a < 2 || n_b < 2)
+    return fail(ctx, ODW_ERR_INVALID, "odw_hits_bin: bad argument");
+  for (int k = 1; k < n_a; ++k) if (!(edges_a[k] >= edges_a[k - 1])) return fail(ctx, ODW_ERR_INVALID, "odw_hits_bin: edges must increase monotonically");
+  for (int k = 1; k < n_b; ++k) if (!(edges_b[k] >= edges_b[k - 1])) return fail(ctx, ODW_ERR_INVALID, "odw_hits_bin: edges must increase monotonically");
+  int rc = ph_need_projection(ctx, "odw_hits_bin");
+  if (rc) return rc;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const uint64_t m = ctx->ph_n;
+  const uint64_t nbins = (uint64_t)(n_a - 1) * (uint64_t)(n_b - 1);
+  if ((rc = upload(ctx, ctx->ph_edges, edges_a, (size_t)n_a * sizeof(double)))) return rc;
+  if ((rc = ensure(ctx, ctx->ph_edges_b, (size_t)n_b * sizeof(double)))) return rc;
+  HIPCHK(ctx, hipMemcpyAsync(ctx->ph_edges_b.p, edges_b, (size_t)n_b * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = ensure(ctx, ctx->ph_counts, nbins * sizeof(uint64_t)))) return rc;
+  HIPCHK(ctx, hipMemsetAsync(ctx->ph_counts.p, 0, nbins * sizeof(uint64_t), ctx->stream));
+  const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((m + 255) / 256, (uint64_t)ctx->n_cu * 8));
+  if (nbins <= (uint64_t)kPhLdsBins)
+    hipLaunchKernelGGL((ph_bin_kernel<true>), dim3(grid), dim3(256), 0, ctx->stream, (const double*)ctx->ph_x.p,
+                       (const double*)ctx->ph_y.p, m, origin[0], origin[1], (int)polar, (const double*)ctx->ph_edges.p,
+                       (int)n_a, (const double*)ctx->ph_edges_b.p, (int)n_b, (unsigned long long*)ctx->ph_counts.p);
+  else
+    hipLaunchKernelGGL((ph_bin_kernel<false>), dim3(grid), dim3(256), 0, ctx->stream, (const double*)ctx->ph_x.p,
+                       (const double*)ctx->ph_y.p, m, origin[0], origin[1], (int)polar, (const double*)ctx->ph_edges.p,
+                       (int)n_a, (const double*)ctx->ph_edges_b.p, (int)n_b, (unsigned long long*)ctx->ph_counts.p);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpyAsync(counts, ctx->ph_counts.p, nbins * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return ODW_OK;
+}
+
+int odw_hits_moments(odw_ctx* ctx, double* mean, double* var) {
+  if (!ctx || !mean || !var) return fail(ctx, ODW_ERR_INVALID, "odw_hits_moments: bad argument");
+  int rc = ph_need_selection(ctx, "odw_hits_moments");
+  if (rc) return rc;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const uint64_t m = ctx->ph_n;
+  if (m == 0) return fail(ctx, ODW_ERR_INVALID, "odw_hits_moments: no rows selected");
+  const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((m + 255) / 256, (uint64_t)ctx->n_cu * 8));
+  if ((rc = ensure(ctx, ctx->ph_part, (size_t)grid * 4 * sizeof(double)))) return rc;
+  std::vector<double> part((size_t)grid * 3);
+  double c[3] = {0, 0, 0};
+  for (int pass = 0; pass < 2; ++pass) {
+    hipLaunchKernelGGL(ph_moment_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const odw_hit*)ctx->hits.p,
+                       (const uint32_t*)ctx->sort_vals[1].p, m, c[0], c[1], c[2], pass, (double*)ctx->ph_part.p);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(part.data(), ctx->ph_part.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    double s[3] = {0, 0, 0};
+    for (unsigned b = 0; b < grid; ++b)
+      for (int k = 0; k < 3; ++k) s[k] += part[3 * b + k];
+    for (int k = 0; k < 3; ++k) {
+      if (pass == 0) { c[k] = s[k] / (double)m; mean[k] = c[k]; }
+      else var[k] = s[k] / (double)m;
+    }
+  }
+  return ODW_OK;
+}
+
+}  // extern "C"

@@ -51,6 +51,24 @@ class Histogram:
     else:
       raise ValueError(f'found invalid binCoord mode {binCoords!r}, expect one of "cartesian" or "polar"')
 
+  @classmethod
+  def fromBinned(cls, hist, binX, binY, planeNormal, xInPlaneVec, origin, binCoords):
+    """a Histogram around counts that were binned elsewhere (on the device, `DeviceHits.histogram`)
+    with this class' rules: same attributes as after __init__"""
+    self = cls.__new__(cls)
+    self._planeNormal, self._xInPlaneVec, self._origin = planeNormal, xInPlaneVec, np.asarray(origin)
+    self._binCoords = binCoords
+    self.hist, self.binX, self.binY = np.asarray(hist, dtype=np.float64), np.asarray(binX), np.asarray(binY)
+    if binCoords == 'cartesian':
+      self.X = (self.binX[1:] + self.binX[:-1]) / 2
+      self.Y = (self.binY[1:] + self.binY[:-1]) / 2
+      self.binAreas = 1
+    else:
+      dphi = np.diff(self.binX)[:, None]
+      r1, r2 = self.binY[:-1][None, :], self.binY[1:][None, :]
+      self.binAreas = dphi * (r1 + r2) / 2 * (r2 - r1)
+    return self
+
   def byAzimuth(self):
     '''
     Return histograms for each azimuthal angle bin. Only available in polar mode.

@@ -51,7 +51,12 @@ def calcFwhm(hits):
 
 
 def rmsSpot(hits):
-  """rms distance of the hits from their centroid (a cheaper figure of merit than calcFwhm)"""
+  """rms distance of the hits from their centroid: a figure of merit that stays defined where the
+  notebook's calcFwhm is not (with 1e7 hits the innermost ten radial bins are all filled and flat:
+  the fitted line never falls to half the peak, the notebook skips such azimuth bins and returns
+  nan near the focus)"""
+  if hasattr(hits, 'rmsSpot'):
+    return hits.rmsSpot()                 # DeviceHits: second moments on the device
   p = hits.points()
   return float(np.sqrt(((p - p.mean(axis=0))**2).sum(axis=1).mean())) if len(p) else np.nan
 
@@ -62,17 +67,20 @@ def shareOfRank(n_values, rank, world):
 
 
 class SweepResult:
-  """values, results (nan where a run produced no figure), and what each run traced"""
+  """values, one column of results per figure of merit (nan where a run produced none), and what
+  the runs traced.  `results` is the first (or only) column."""
 
-  def __init__(self, values, results, tracedRays, recordedHits, segments):
+  def __init__(self, values, columns, tracedRays, recordedHits, segments):
     self.values = np.asarray(values, dtype=np.float64)
-    self.results = np.asarray(results, dtype=np.float64)
+    self.columns = {k: np.asarray(v, dtype=np.float64) for k, v in columns.items()}
+    self.results = next(iter(self.columns.values()))
     self.tracedRays, self.recordedHits, self.segments = int(tracedRays), int(recordedHits), int(segments)
 
-  def best(self):
+  def best(self, column=None):
     """(value, result) of the smallest finite result (the notebook's `radii[np.argmin(fwhms)]`)"""
-    k = int(np.nanargmin(self.results))
-    return float(self.values[k]), float(self.results[k])
+    col = self.results if column is None else self.columns[column]
+    k = int(np.nanargmin(col))
+    return float(self.values[k]), float(col[k])
 
 
 def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAULT_SEED, device=0,
@@ -80,8 +88,9 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
   """run `rays` true-random rays for every entry of `values` and return a SweepResult.
 
   setValue(doc, value)   applies one parameter value (e.g. `doc.Sphere.Radius = value`)
-  measure(hits) -> float figure of merit of a run's hit cloud (`Hits` interface: histogram,
-                         points, directions ...); default: the notebook's calcFwhm
+  measure                figure of merit of a run's hit cloud: callable(hits) -> float, or a dict
+                         name -> callable for several columns (`Hits` interface: histogram, points,
+                         directions ...); default: the notebook's calcFwhm
   dist                   torch.distributed (initialised): the values are dealt out over the ranks
                          and the table is summed into every rank with one all-reduce
   deviceHits             measure on the hit rows where they are, in HBM (`DeviceHits`: plane search
@@ -90,15 +99,18 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
   """
   ranks = parallel.Ranks.detect(dist, device)
   values = [float(v) for v in values]
+  measures = dict(measure) if isinstance(measure, dict) else {'result': measure}
+  names = list(measures)
   mine = shareOfRank(len(values), ranks.rank, ranks.world)
   sources = _bake.lightSources(doc)
   if not sources:
     raise ValueError('document has no light source')
   src = sources[0] if source is None else source
+  from .results_store import updateResultEntry
   from .simulation_loop import bakeLightSource
   own = tracer is None
   tr = tracer or Tracer(device)
-  table = np.zeros((len(values), 2))        # (result or 0, 1 = a number / 2 = nan)
+  table = np.zeros((len(values), len(names), 2))        # (result or 0, 1 = a number / 2 = nan)
   totals = np.zeros(3, dtype=np.int64)
   try:
     for k in mine:
@@ -125,20 +137,20 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
         hits = tr.deviceHits()
       else:
         merged = {}
-        from .results_store import updateResultEntry
         for d in hitsToDict(tr.hits(), scene, src.Name).values():
           for key, v in d.items():
             updateResultEntry(merged, key, v)
         hits = Hits(merged)
-      m = float(measure(hits)) if len(hits) else np.nan
-      table[k] = (0.0, 2.0) if np.isnan(m) else (m, 1.0)
+      for j, name in enumerate(names):
+        m = float(measures[name](hits)) if len(hits) else np.nan
+        table[k, j] = (0.0, 2.0) if np.isnan(m) else (m, 1.0)
   finally:
     if own:
       tr.close()
   flat = ranks.sumFloats(np.concatenate([table.ravel(), totals.astype(np.float64)]))
-  table = np.asarray(flat[:2 * len(values)]).reshape(-1, 2)
-  if not np.all((table[:, 1] == 1) | (table[:, 1] == 2)):
+  table = np.asarray(flat[:table.size]).reshape(table.shape)
+  if not np.all((table[..., 1] == 1) | (table[..., 1] == 2)):
     raise RuntimeError('parameter sweep: some values were run by no rank or by several')
-  results = np.where(table[:, 1] == 1, table[:, 0], np.nan)
-  t = [int(round(v)) for v in flat[2 * len(values):]]
-  return SweepResult(values, results, *t)
+  results = np.where(table[..., 1] == 1, table[..., 0], np.nan)
+  t = [int(round(v)) for v in flat[table.size:]]
+  return SweepResult(values, {name: results[:, j] for j, name in enumerate(names)}, *t)

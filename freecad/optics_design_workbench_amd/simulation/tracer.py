@@ -176,6 +176,56 @@ class Tracer:
                                        C.byref(got)), 'odw_fetch_hits')
     return out[:int(got.value)]
 
+  def traceStreaming(self, jobs, seed, capacity, histogram=True, buffers=None):
+    """generator: trace every (first, n) of `jobs` and yield each job's hit rows on the host, the
+    copy of job k overlapping the trace of job k+1 (two device hit lists, a copy stream of its
+    own: odw_swap_hit_lists / odw_fetch_swapped_hits).  Rows come in append order (unordered
+    across rays).  The arrays yielded are views of two alternating host buffers: use one before
+    asking for the one after the next."""
+    self.reserveHits(capacity)
+    host = buffers or [np.empty(int(capacity), dtype=HIT_DTYPE) for _ in range(2)]
+    got = C.c_uint64(0)
+
+    def fetch(k):
+      buf = host[k % 2]
+      self._chk(self._lib.odw_fetch_swapped_hits(self._ctx, buf.ctypes.data_as(C.c_void_p), C.c_uint64(len(buf)),
+                                                 C.byref(got)), 'odw_fetch_swapped_hits')
+      return buf[:int(got.value)]
+    k = -1
+    for k, (first, n) in enumerate(jobs):
+      self.resetHits()
+      self.trace(first, n, seed, histogram=histogram)       # asynchronous, into the current list
+      if k > 0:
+        yield fetch(k - 1)                                  # the list put aside: job k-1
+      self._chk(self._lib.odw_swap_hit_lists(self._ctx), 'odw_swap_hit_lists')
+    if k >= 0:
+      yield fetch(k)
+
+  def deviceHits(self, group=None):
+    """the recorded rows as a `Hits`-like object that bins them where they are, in HBM
+    (`simulation.device_hits.DeviceHits`); valid until the next launch, reset or fetch"""
+    from .device_hits import DeviceHits
+    self.sync()
+    return DeviceHits(self, group)
+
+  def loadHits(self, hits, group=0):
+    """put recorded hits back into the device hit list (replacing its content) and return them as
+    `DeviceHits`: `hits` = HIT_DTYPE rows, or a hit dictionary / `Hits` as `RawFolder.loadHits`
+    returns it (points, directions, powers, isEntering; rows are numbered in their order)"""
+    if isinstance(hits, np.ndarray) and hits.dtype == HIT_DTYPE:
+      rows = np.ascontiguousarray(hits)
+    else:
+      d = getattr(hits, 'hits', hits)
+      n = len(d['points'])
+      rows = np.zeros(n, dtype=HIT_DTYPE)
+      rows['point'], rows['direction'] = d['points'], d['directions']
+      rows['power'] = d['powers'] if 'powers' in d else 1.0
+      ent = np.asarray(d['isEntering'] if 'isEntering' in d else np.ones(n), dtype=np.uint64)
+      rows['tag'] = (np.arange(n, dtype=np.uint64) | (np.uint64(int(group)) << np.uint64(48))
+                     | ((ent != 0).astype(np.uint64) << np.uint64(63)))
+    self._chk(self._lib.odw_load_hits(self._ctx, rows.ctypes.data_as(C.c_void_p), C.c_uint64(len(rows))), 'odw_load_hits')
+    return self.deviceHits()
+
   def resetSegments(self):
     self._chk(self._lib.odw_reset_segments(self._ctx), 'odw_reset_segments')
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define ODW_ABI_VERSION 4
+#define ODW_ABI_VERSION 5
 
 /* ---- return codes ------------------------------------------------------ */
 enum {
@@ -354,6 +354,18 @@ int odw_hit_count(odw_ctx* ctx, uint64_t* n);
 /* copies min(n_hits, capacity) rows, sorted by (ray index, bounce order)   */
 int odw_fetch_hits(odw_ctx* ctx, odw_hit* out, uint64_t capacity, uint64_t* n);
 int odw_fetch_histogram(odw_ctx* ctx, uint64_t* out, uint64_t n_bins);
+/* Overlapped row fetch for continuous runs that keep every hit (the reference
+ * buffers hits while the workers trace on and flushes them every few seconds,
+ * results_store.py:405-457): two hit lists.  odw_swap_hit_lists puts the list
+ * traced into so far aside and makes the other one current (allocated with
+ * the same room on first use; the caller recycles it with odw_reset_hits);
+ * odw_fetch_swapped_hits copies the rows of the list put aside to the host on
+ * a copy stream of its own -- it waits for the launches issued before the
+ * swap only, so a launch issued after it runs while the rows cross PCIe.
+ * Rows arrive in append order (unordered across rays; a ray's rows in bounce
+ * order); once lists are swapped appends are dense (no reserved blocks).    */
+int odw_swap_hit_lists(odw_ctx* ctx);
+int odw_fetch_swapped_hits(odw_ctx* ctx, odw_hit* out, uint64_t capacity, uint64_t* n);
 /* rows in the segment list and rows that did not fit into it               */
 int odw_segment_count(odw_ctx* ctx, uint64_t* n, uint64_t* dropped);
 /* copies the rows sorted by (ray index, ordinal); NULL out: count only      */
@@ -367,6 +379,40 @@ int odw_sample(odw_ctx* ctx, uint64_t first_ray, uint64_t n_rays, uint64_t seed,
  * origin and direction [n*3] of each ray of the uploaded source             */
 int odw_generate_rays(odw_ctx* ctx, uint64_t first_ray, uint64_t n_rays, uint64_t seed,
                       double* origins, double* directions);
+
+/* post-hoc detector binning on the rows in HBM --------------------------------
+ * Replaces the array work of Hits.histogram (jupyter_utils/hits.py:176-193):
+ * detectPlaneNormal's thinned sample (:96-113), planeProject3dPoints (:62-94),
+ * Histogram.__init__ (jupyter_utils/histogram.py:24-57: median origin,
+ * numpy.histogram2d of (X, Y) or of (arctan2(X, Y), hypot(X, Y))).  The plane
+ * search itself works on <= 300 rows and stays with the caller.  Call order:
+ * select -> gather (sample) -> project -> [range] -> bin; any launch, reset or
+ * fetch of the hit list ends the selection.                                  */
+/* put rows recorded earlier (a run folder's `*-hits.pkl` files,
+ * RawFolder.loadHits, freecad_document.py:1485-1504) back into the device hit
+ * list, replacing its content, so that they can be binned there             */
+int odw_load_hits(odw_ctx* ctx, const odw_hit* rows, uint64_t n);
+/* the rows of one recording group (-1: all) in (ray index, bounce) order;
+ * n_leaving: how many of them have isEntering == 0 (hits.py:108-111)        */
+int odw_hits_select(odw_ctx* ctx, int32_t group, uint64_t* n_rows, uint64_t* n_leaving);
+/* rows 0, stride, 2 stride, ... of the selection (entering_only: of its rows
+ * with isEntering != 0) = numpy's a[::stride]; NULL out: count only         */
+int odw_hits_gather(odw_ctx* ctx, int32_t entering_only, uint64_t stride, odw_hit* out,
+                    uint64_t capacity, uint64_t* n);
+/* X = p . ex, Y = p . ey for every selected row (key 0: points, 1: directions;
+ * ex, ey: unit vectors, [3] each); stats[8] = for X then Y: the two middle
+ * values of the sorted column (numpy.median = their mean), minimum, maximum */
+int odw_hits_project(odw_ctx* ctx, int32_t key, const double* ex, const double* ey, double* stats);
+/* range[4] = min, max of the first and of the second binned coordinate:
+ * cartesian (X - origin[0], Y - origin[1]); polar (arctan2 of those two,
+ * their hypot) -- what numpy takes as outer edges for integer bin counts    */
+int odw_hits_range(odw_ctx* ctx, int32_t polar, const double* origin, double* range);
+/* counts[(n_a-1)*(n_b-1)] (first coordinate major) with numpy.histogramdd's
+ * rule: bin = searchsorted(edges, v, 'right') - 1, the last edge closed      */
+int odw_hits_bin(odw_ctx* ctx, int32_t polar, const double* origin, const double* edges_a, int32_t n_a,
+                 const double* edges_b, int32_t n_b, uint64_t* counts);
+/* mean[3] and variance[3] (about the mean) of the selected rows' points     */
+int odw_hits_moments(odw_ctx* ctx, double* mean, double* var);
 
 /* device-side handles for collectives (RCCL reduce through torch)          */
 int odw_device_histogram(odw_ctx* ctx, void** dptr, uint64_t* n_bins);

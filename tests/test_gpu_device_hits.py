@@ -1,0 +1,108 @@
+"""Post-hoc detector binning on the rows in HBM (`DeviceHits`, csrc/odw_posthoc.hip) against
+(1) outputs of the reference's own Hits / Histogram classes (tests/golden/hist_cases.npz,
+fwhm_cases.npz) and (2) the host `Hits` on the rows of a real trace: same plane, same origin,
+same edges, same counts."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, project
+
+pytestmark = pytest.mark.gpu
+KINDS = {'cart30': dict(bins=30), 'polar3x50': dict(bins=(3, 50), binCoords='polar'),
+         'cartlin': dict(bins=[np.linspace(-2, 2, 41), np.linspace(-1, 1, 21)])}
+
+
+@pytest.fixture(scope='module')
+def tracer(native_lib):
+  from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
+  tr = Tracer(0)
+  yield tr
+  tr.close()
+
+
+def _same(H, G):
+  assert np.array_equal(H._planeNormal, G._planeNormal) and np.array_equal(H._xInPlaneVec, G._xInPlaneVec)
+  assert np.array_equal(H._origin, G._origin)
+  assert np.array_equal(H.binX, G.binX) and np.array_equal(H.binY, G.binY)
+  assert np.array_equal(H.hist, G.hist)
+  assert np.array_equal(np.asarray(H.binAreas), np.asarray(G.binAreas))
+
+
+@pytest.mark.parametrize('tag', ['A', 'B'])
+@pytest.mark.parametrize('kind', list(KINDS))
+def test_device_histogram_equals_reference_classes(tracer, tag, kind):
+  g = np.load(os.path.join(GOLDEN, 'hist_cases.npz'))
+  P, D = g[f'{tag}_points'], g[f'{tag}_directions']
+  dh = tracer.loadHits(dict(points=P, directions=D, powers=np.ones(len(P)), isEntering=np.ones(len(P), dtype=int)))
+  assert len(dh) == len(P)
+  H = dh.histogram(**KINDS[kind])
+  key = f'{tag}_{kind}'
+  assert np.array_equal(H._planeNormal, g[key + '_normal'])
+  assert np.array_equal(H._xInPlaneVec, g[key + '_xvec'])
+  # the projection is three products summed left to right here, a BLAS dot in numpy: the median can
+  # differ in its last bits, counts only if a hit sits within that of an edge
+  assert np.abs(H._origin - g[key + '_origin']).max() < 1e-13
+  assert np.allclose(H.binX, g[key + '_binX'], rtol=0, atol=1e-12) and np.allclose(H.binY, g[key + '_binY'], rtol=0, atol=1e-12)
+  assert np.array_equal(H.hist, g[key + '_hist'])
+  if kind.startswith('polar'):
+    assert np.allclose(H.byAzimuth()[2], g[key + '_az_dens'], rtol=1e-12)
+
+
+@pytest.mark.parametrize('tag', ['tight', 'wide', 'sparse'])
+def test_device_calc_fwhm_equals_reference(tracer, tag):
+  from freecad.optics_design_workbench_amd.simulation import sweep
+  g = np.load(os.path.join(GOLDEN, 'fwhm_cases.npz'))
+  P, D = g[tag + '_points'], g[tag + '_directions']
+  dh = tracer.loadHits(dict(points=P, directions=D, powers=np.ones(len(P)), isEntering=np.ones(len(P), dtype=int)))
+  H = dh.histogram(binCoords='polar', bins=[np.arange(0, 2 * np.pi, np.pi / 2), np.geomspace(1e-3, 5, 500)])
+  assert np.array_equal(H.hist, g[tag + '_hist'])
+  assert sweep.calcFwhm(dh) == pytest.approx(float(g[tag + '_fwhm']), rel=1e-12)
+
+
+def test_device_histogram_equals_host_hits_on_traced_rows(tracer):
+  """rows of a real launch (lensesAndMirrors, 1e6 rays; and GettingStarted with leaving rows of a
+  transparent detector mixed in): DeviceHits on the rows in HBM == Hits on the fetched rows"""
+  from freecad.optics_design_workbench_amd.jupyter_utils import Hits
+  from freecad.optics_design_workbench_amd.simulation import sweep
+  from freecad.optics_design_workbench_amd.simulation.tracer import hitsToDict
+  import copy
+  for name, record_all in (('lensesAndMirrors', False), ('GettingStarted', False), ('GettingStarted', True)):
+    pr = project(name)
+    sc = pr.scene
+    if record_all:
+      sc = copy.copy(sc)
+      sc.group_record = np.ones_like(sc.group_record)       # lens rows too: entering and leaving hits
+    n = 1_000_000
+    tracer.setScene(sc)
+    tracer.setSource(pr.source)
+    tracer.setLimits(pr.limits)
+    tracer.setDetector(None)
+    tracer.reserveHits(4 * n)
+    tracer.reset()
+    tracer.trace(0, n, 5)
+    tracer.sync()
+    rows = tracer.hits()
+    for group in ([None] if not record_all else [None, sc.group_index('OpticalLensGroup')]):
+      sel = rows if group is None else rows[((rows['tag'] >> np.uint64(48)) & np.uint64(0x7FFF)) == group]
+      host = Hits(dict(points=np.ascontiguousarray(sel['point']), directions=np.ascontiguousarray(sel['direction']),
+                       powers=np.ascontiguousarray(sel['power']), isEntering=(sel['tag'] >> np.uint64(63)).astype(np.int64)))
+      dh = tracer.deviceHits(group)
+      assert len(dh) == len(sel) > 0
+      pn, xv = dh.detectPlaneNormal()
+      hn, hx = host.detectPlaneNormal()
+      assert np.array_equal(pn, hn) and np.array_equal(xv, hx)
+      for kw in (dict(bins=30), dict(bins=(3, 50), binCoords='polar'), dict(bins=[40, np.linspace(-1, 1, 33)]),
+                 dict(radius=0.5, bins=64), dict(binCoords='polar', radius=2.0, bins=(4, 100)),
+                 dict(binCoords='polar', bins=[np.arange(0, 2 * np.pi, np.pi / 2), np.geomspace(1e-3, 5, 500)])):
+        H, G = dh.histogram(**kw), host.histogram(**kw)
+        assert np.abs(H._origin - G._origin).max() < 1e-12
+        assert np.allclose(H.binX, G.binX, rtol=0, atol=1e-11) and np.allclose(H.binY, G.binY, rtol=0, atol=1e-11)
+        assert H.hist.sum() == G.hist.sum()
+        assert np.abs(H.hist - G.hist).sum() <= 2             # a hit within an ulp of an edge may change sides
+      assert dh.rmsSpot() == pytest.approx(sweep.rmsSpot(host), rel=1e-9)
+      assert sweep.calcFwhm(dh) == pytest.approx(sweep.calcFwhm(host), rel=1e-6)
+      tracer.hits()                                          # a fetch ends the selection ...
+      with pytest.raises(Exception):
+        dh.histogram(bins=10)                                # ... and the object says so

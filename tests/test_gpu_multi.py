@@ -1,0 +1,142 @@
+"""The multi-GPU entry points on real hardware, as far as one GPU allows:
+
+* the RCCL device path of `parallel.reduceResults` -- torch tensors wrapped around the tracer's
+  HBM buffers through `__cuda_array_interface__`, `dist.reduce` over the `nccl` backend -- run by
+  ONE rank under torch.distributed.run in a child process (the worker fan-out it replaces:
+  simulation/processes/simulation_loop.py:386-396, 450-507);
+* `bench.py --gpus N`: starts its ranks itself, refuses to report fewer GPUs than asked for;
+* `bench.py --config c4 / c5` produce their lines (small sizes here; full sizes in test_gpu_scale.py).
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, project
+
+pytestmark = pytest.mark.gpu
+
+RCCL_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], 'tests'))
+import numpy as np, torch, torch.distributed as dist
+from conftest import project
+from freecad.optics_design_workbench_amd import scenes
+from freecad.optics_design_workbench_amd.simulation import parallel
+from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
+local = int(os.environ['LOCAL_RANK'])
+torch.cuda.set_device(local)
+dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+rank, world = dist.get_rank(), dist.get_world_size()
+pr = project('lensesAndMirrors')
+det = scenes.planeDetector(pr.scene, 'OpticalAbsorberGroup', nx=256, ny=256, toward=pr.source.xform[[3, 7, 11]])
+tr = Tracer(local)
+tr.setScene(pr.scene); tr.setSource(pr.source); tr.setLimits(pr.limits); tr.setDetector(det)
+tr.reserveHits(16)
+tr.reset()
+first, n = parallel.shardRange(1000, 300001, rank, world)
+tr.trace(first, n, 77, record_hits=False)
+parallel.reduceResults(tr, dist, torch)            # nccl = RCCL, on the tracer's own HBM buffers
+if rank == 0:
+  cnt = tr.counters()
+  np.savez(sys.argv[2], hist=tr.histogram(), cnt=np.array([cnt[k] for k in sorted(cnt)], dtype=np.int64),
+           backend=np.array(dist.get_backend()), world=np.array(world))
+# the int64 totals runSimulation exchanges per launch, and the sweep's table, on device tensors
+r = parallel.Ranks(dist, local)
+assert r.sum([3, 4]) == [3 * world, 4 * world]
+assert np.array_equal(r.sumFloats([0.5, 2.0]), np.array([0.5, 2.0]) * world)
+tr.close()
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def _port():
+  with socket.socket() as s:
+    s.bind(('127.0.0.1', 0))
+    return s.getsockname()[1]
+
+
+def test_rccl_reduce_on_device_buffers(native_lib, tmp_path):
+  from freecad.optics_design_workbench_amd import scenes
+  from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
+  script = tmp_path / 'rccl_worker.py'
+  script.write_text(RCCL_WORKER)
+  out = tmp_path / 'rank0.npz'
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=1',
+         '--master-addr', '127.0.0.1', '--master-port', str(_port()), str(script), ROOT, str(out)]
+  res = subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'), capture_output=True, text=True,
+                       timeout=900)
+  assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+  got = np.load(out)
+  assert str(got['backend']) == 'nccl' and int(got['world']) == 1
+  # the same job without torch.distributed
+  pr = project('lensesAndMirrors')
+  det = scenes.planeDetector(pr.scene, 'OpticalAbsorberGroup', nx=256, ny=256, toward=pr.source.xform[[3, 7, 11]])
+  with Tracer(0) as tr:
+    tr.setScene(pr.scene)
+    tr.setSource(pr.source)
+    tr.setLimits(pr.limits)
+    tr.setDetector(det)
+    tr.reserveHits(16)
+    tr.reset()
+    tr.trace(1000, 300001, 77, record_hits=False)
+    tr.sync()
+    cnt = tr.counters()
+    assert np.array_equal(got['hist'], tr.histogram())
+    assert [int(v) for v in got['cnt']] == [cnt[k] for k in sorted(cnt)]
+    assert cnt['traced_rays'] == 300001 and int(got['hist'].sum()) + cnt['hist_overflow'] == cnt['recorded_hits']
+
+
+def _bench(*argv, env=None, timeout=900):
+  e = dict(os.environ)
+  for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+    e.pop(k, None)
+  e.update(env or {})
+  return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + list(argv), env=e, capture_output=True,
+                        text=True, timeout=timeout)
+
+
+def _line(res):
+  assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+  return json.loads([l for l in res.stdout.splitlines() if l.startswith('{')][-1])
+
+
+def test_bench_refuses_more_gpus_than_present(native_lib):
+  import torch
+  n = torch.cuda.device_count() + 1
+  res = _bench('--gpus', str(n), '--steps', '1', '--warmup', '0', '--no-cpu-baseline')
+  assert res.returncode != 0 and 'device' in res.stderr
+  assert not [l for l in res.stdout.splitlines() if l.startswith('{')]      # no line with a smaller n_gpus
+
+
+def test_bench_under_a_launcher_with_one_rank_uses_rccl(native_lib):
+  """what the driver does for N > 1, with N = 1: torch.distributed.run, nccl process group, the
+  histogram + counters reduce inside the timed region"""
+  e = dict(os.environ)
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=1', '--master-addr',
+         '127.0.0.1', '--master-port', str(_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '2',
+         '--warmup', '1', '--rays-per-step', '4e6', '--no-cpu-baseline', '--no-end-to-end']
+  res = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=900)
+  out = _line(res)
+  assert out['n_gpus'] == 1 and out['config']['name'] == 'c3' and out['value'] > 1e8
+  # a launcher whose world size differs from --gpus is refused
+  cmd[cmd.index('--gpus') + 1] = '2'
+  res = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=900)
+  assert res.returncode != 0
+
+
+def test_bench_config_lines_c4_and_c5(native_lib):
+  out = _line(_bench('--config', 'c4', '--steps', '2', '--warmup', '1', '--rays-per-step', '4e6', '--no-cpu-baseline'))
+  assert out['config']['name'] == 'c4' and 'hugeArray' in out['metric'] and out['n_gpus'] == 1
+  assert 2.5 < out['config']['segments_per_ray'] < 3.2 and out['roofline']['kernel'].startswith('odw_trace_kernel<true')
+  assert 0 < out['roofline']['frac'] < 1
+  out = _line(_bench('--config', 'c5', '--radii', '6', '--rays-per-step', '2e5', '--no-cpu-baseline'))
+  spot = out['config']['spot_size']
+  assert out['config']['name'] == 'c5' and out['scaling'] == 'strong' and len(spot['fwhm_mm']) == 6
+  assert all(v is None or v > 0 for v in spot['fwhm_mm']) and any(v is not None for v in spot['fwhm_mm'])
+  assert all(v > 0 for v in spot['rms_spot_mm']) and 9 <= spot['best_radius_by_rms_mm'] <= 11
