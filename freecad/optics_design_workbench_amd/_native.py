@@ -14,12 +14,12 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(CSRC, 'libodw_trace.so')
-_SOURCES = ['odw_capi.hip', 'odw_kernels.hip', 'odw_posthoc.hip', 'odw_device.h']
+_SOURCES = ['odw_capi.hip', 'odw_kernels.hip', 'odw_grid.hip', 'odw_posthoc.hip', 'odw_device.h']
 _HEADER = os.path.normpath(os.path.join(_HERE, '..', '..', 'include', 'odw_trace.h'))
 
 ABI_VERSION = 5
 CNT_NAMES = ['traced_rays', 'recorded_hits', 'segments', 'escaped', 'died', 'capped',
-             'hist_overflow', 'hits_dropped']
+             'hist_overflow', 'hits_dropped', 'grating_in_medium']
 TRACE_RECORD_HITS, TRACE_HISTOGRAM, TRACE_RECORD_SEGMENTS = 1, 2, 4
 ERRORS = {1: 'invalid argument', 2: 'device error', 3: 'no scene', 4: 'capacity', 5: 'unsupported'}
 

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "odw_kernels.hip"
+#include "odw_grid.hip"
 
 using namespace odw;
 
@@ -55,6 +56,7 @@ struct odw_ctx {
 
   DevBuf prim_f64, prim_hdr, prim_i32, cond_i32, group_f64, group_i32, group_gdir, seq_mask;
   DevBuf bvh_nodes, bvh_prims, tri_nrm;
+  DevBuf grid_bounds, grid_cells, grid_items;   // rectilinear grid of big analytic scenes (odw_grid.hip)
   DevBuf phi_tab, t_tab, t_guide, phi_guide, d_source, d_det;
   DeviceSource h_source;
   DeviceDetector h_det;
@@ -381,6 +383,151 @@ struct BvhBuilder {
   }
 };
 
+
+// ---- rectilinear grid for big analytic scenes (odw_grid.hip) ---------------------------------
+// Planes per axis: one in the middle of every gap between the primitives' boxes (projected on the
+// axis) -- a Draft array gets one element per cell --, then slabs wider than twice the width an
+// even division into ~cbrt(n) cells per axis would give are cut evenly.  Cell lists (CSR): every
+// primitive whose box touches the cell.  The walk is exact whatever the planes are; they only
+// decide how many cells a ray crosses and how many primitives it tests per cell.
+constexpr int kGridMaxAxis = 128;             // cells per axis (8 bits each in the walk's cell word)
+constexpr uint32_t kGridMaxCellItems = 255;   // 8-bit count in the cell word
+constexpr size_t kGridLdsBudget = 144 * 1024; // of the CU's 160 KB, one block per CU
+
+int build_grid(odw_ctx* ctx, const std::vector<Box>& boxes, const std::vector<char>& dead) {
+  DeviceGrid& G = ctx->P.grid;
+  std::memset(&G, 0, sizeof G);
+  static const bool off = getenv("ODW_NO_GRID") != nullptr;
+  const int n = (int)boxes.size();
+  std::vector<int> live;
+  for (int p = 0; p < n; ++p)
+    if (!dead[p]) live.push_back(p);
+  if (off || live.empty()) return ODW_OK;
+  Box all;
+  all.reset();
+  for (int p : live) all.grow(boxes[p]);
+  double ext[3], vol = 1.0;
+  for (int a = 0; a < 3; ++a) { ext[a] = std::max(all.hi[a] - all.lo[a], 1e-9); vol *= ext[a]; }
+  const double per_len = std::cbrt((double)live.size() / vol);     // cells per unit length for ~1 primitive per cell
+  std::vector<double> planes[3];
+  for (int a = 0; a < 3; ++a) {
+    std::vector<std::pair<double, double>> iv;
+    for (int p : live) iv.emplace_back(boxes[p].lo[a], boxes[p].hi[a]);
+    std::sort(iv.begin(), iv.end());
+    const double pad = 1e-6 * (1.0 + ext[a]);
+    std::vector<double> b{all.lo[a] - pad};
+    double cover = iv[0].second;
+    for (size_t k = 1; k < iv.size(); ++k) {
+      if (iv[k].first > cover) b.push_back(0.5 * (cover + iv[k].first));
+      cover = std::max(cover, iv[k].second);
+    }
+    b.push_back(all.hi[a] + pad);
+    const double target = 1.0 / std::max(per_len, 1e-12);          // width of a cell of the even division
+    std::vector<double> cut{b[0]};
+    for (size_t k = 1; k < b.size(); ++k) {
+      const double wdt = b[k] - b[k - 1];
+      const int parts = wdt > 2.0 * target ? (int)std::min<double>(kGridMaxAxis, std::floor(wdt / target + 0.5)) : 1;
+      for (int j = 1; j <= parts; ++j) cut.push_back(j == parts ? b[k] : b[k - 1] + wdt * j / parts);
+    }
+    if ((int)cut.size() - 1 > kGridMaxAxis) {                     // too fine: even division
+      cut.clear();
+      for (int j = 0; j <= kGridMaxAxis; ++j) cut.push_back(b.front() + (b.back() - b.front()) * j / kGridMaxAxis);
+      cut.back() = b.back();
+    }
+    planes[a] = cut;
+  }
+  const int nx = (int)planes[0].size() - 1, ny = (int)planes[1].size() - 1, nz = (int)planes[2].size() - 1;
+  const size_t ncell = (size_t)nx * ny * nz;
+  if (ncell > (1u << 21)) return ODW_OK;
+  // cell ranges of every primitive (closed boxes: a box that ends on a plane is listed on both sides)
+  auto range = [&](int a, double lo, double hi, int& i0, int& i1) {
+    const std::vector<double>& b = planes[a];
+    const int m = (int)b.size() - 1;
+    i0 = (int)(std::upper_bound(b.begin(), b.end(), lo) - b.begin()) - 1;     // last plane <= lo
+    if (i0 > 0 && b[i0] == lo) --i0;
+    i1 = (int)(std::lower_bound(b.begin(), b.end(), hi) - b.begin()) - 1;     // slab whose upper plane >= hi
+    if (i1 + 1 < m && b[i1 + 1] == hi) ++i1;
+    i0 = std::max(0, std::min(m - 1, i0));
+    i1 = std::max(i0, std::min(m - 1, i1));
+  };
+  std::vector<uint32_t> count(ncell, 0);
+  std::vector<int> r(6 * (size_t)live.size());
+  for (size_t k = 0; k < live.size(); ++k) {
+    const Box& bx = boxes[live[k]];
+    int* q = &r[6 * k];
+    range(0, bx.lo[0], bx.hi[0], q[0], q[1]);
+    range(1, bx.lo[1], bx.hi[1], q[2], q[3]);
+    range(2, bx.lo[2], bx.hi[2], q[4], q[5]);
+    for (int z = q[4]; z <= q[5]; ++z)
+      for (int y = q[2]; y <= q[3]; ++y)
+        for (int x = q[0]; x <= q[1]; ++x) ++count[x + (size_t)nx * (y + (size_t)ny * z)];
+  }
+  size_t total = 0;
+  std::vector<uint32_t> first(ncell);
+  for (size_t c = 0; c < ncell; ++c) {
+    if (count[c] > kGridMaxCellItems) return ODW_OK;              // crowded beyond the cell word: BVH kernels
+    first[c] = (uint32_t)total;
+    total += count[c];
+  }
+  if (total >= (1u << 24)) return ODW_OK;
+  std::vector<uint32_t> item_prim(std::max<size_t>(total, 1)), fill(ncell, 0);
+  for (size_t k = 0; k < live.size(); ++k) {
+    const int* q = &r[6 * k];
+    for (int z = q[4]; z <= q[5]; ++z)
+      for (int y = q[2]; y <= q[3]; ++y)
+        for (int x = q[0]; x <= q[1]; ++x) {
+          const size_t c = x + (size_t)nx * (y + (size_t)ny * z);
+          item_prim[first[c] + fill[c]++] = (uint32_t)live[k];
+        }
+  }
+  std::vector<uint32_t> cells(ncell);
+  for (size_t c = 0; c < ncell; ++c) cells[c] = first[c] | (count[c] << 24);
+  bool spheres = true;
+  for (int p : live) {
+    const int32_t* pi = &ctx->h_prim_i32[4 * (size_t)p];
+    if (pi[0] != ODW_PRIM_SPHERE || ((pi[3] >> 24) & 0xff) != 0) { spheres = false; break; }
+  }
+  std::vector<double> bounds;
+  for (int a = 0; a < 3; ++a) bounds.insert(bounds.end(), planes[a].begin(), planes[a].end());
+  int rc;
+  if ((rc = upload(ctx, ctx->grid_bounds, bounds.data(), bounds.size() * sizeof(double)))) return rc;
+  if ((rc = upload(ctx, ctx->grid_cells, cells.data(), cells.size() * sizeof(uint32_t)))) return rc;
+  size_t item_bytes;
+  std::vector<double> recs;
+  if (spheres) {
+    // 48-byte records: centre (global; prim_f64 12..15 = R, cx, cy, cz as the flat kernel reads them),
+    // radius, {primitive, group | solid << 8}
+    recs.resize(std::max<size_t>(total, 1) * 6, 0.0);
+    for (size_t k = 0; k < total; ++k) {
+      const uint32_t p = item_prim[k];
+      const double* par = ctx->h_prim_f64.data() + 16 * (size_t)p + 12;
+      const int32_t* pi = &ctx->h_prim_i32[4 * (size_t)p];
+      double* o = &recs[6 * k];
+      o[0] = par[1]; o[1] = par[2]; o[2] = par[3]; o[3] = par[0];
+      const uint64_t bits = (uint64_t)p | ((uint64_t)(uint32_t)((pi[1] & 0xff) | ((pi[2] >> ODW_SOLID_SHIFT) << 8)) << 32);
+      std::memcpy(&o[4], &bits, sizeof bits);
+    }
+    item_bytes = recs.size() * sizeof(double);
+    if ((rc = upload(ctx, ctx->grid_items, recs.data(), item_bytes))) return rc;
+  } else {
+    item_prim.resize((item_prim.size() + 1) & ~(size_t)1, 0u);      // whole doubles (the LDS copy moves 8 bytes at a time)
+    item_bytes = item_prim.size() * sizeof(uint32_t);
+    if ((rc = upload(ctx, ctx->grid_items, item_prim.data(), item_bytes))) return rc;
+  }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));                   // host vectors die with this scope
+  const size_t fixed = bounds.size() * sizeof(double) + (ODW_GRID_WAVES * 16 + ODW_GRID_WAVES * 4) * sizeof(uint32_t);
+  const size_t staged = ((fixed + ncell * sizeof(uint32_t) + 15) & ~(size_t)15) + item_bytes;
+  G.bounds = (const double*)ctx->grid_bounds.p;
+  G.cells = (const uint32_t*)ctx->grid_cells.p;
+  G.items = ctx->grid_items.p;
+  G.nx = nx; G.ny = ny; G.nz = nz;
+  G.n_items = (int32_t)total;
+  G.spheres = spheres ? 1 : 0;
+  G.in_lds = staged + 16 <= kGridLdsBudget ? 1 : 0;
+  G.lds_bytes = (uint32_t)((G.in_lds ? staged : fixed) + 16);
+  return ODW_OK;
+}
+
 int build_bvh(odw_ctx* ctx) {
   const int n = ctx->P.scene.n_prims;
   ctx->P.scene.n_nodes = 0;
@@ -424,7 +571,12 @@ int build_bvh(odw_ctx* ctx) {
   static const int bvh_threshold = [] { const char* e = getenv("ODW_BVH_THRESHOLD"); return e ? atoi(e) : kBvhThreshold; }();
   bool has_triangles = false;
   for (int p = 0; p < n && !has_triangles; ++p) has_triangles = ctx->h_prim_i32[4 * p] == ODW_PRIM_TRIANGLE;
+  std::memset(&ctx->P.grid, 0, sizeof ctx->P.grid);
   if (n <= bvh_threshold && !has_triangles) return ODW_OK;   // triangles are only known to the BVH kernels
+  if (!has_triangles) {
+    int rc = build_grid(ctx, boxes, dead);
+    if (rc) return rc;
+  }
   // float32 traversal boxes: enlarge by what float rounding of the ray origin
   // and of the slab arithmetic can cost (see ray_box_f32 in odw_kernels.hip)
   for (int p = 0; p < n; ++p)
@@ -549,9 +701,13 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
   const uint64_t n_chunks = (n + ODW_CHUNK - 1) / ODW_CHUNK;
   const uint64_t cap = (uint64_t)ctx->n_cu * grid_mult;
   const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_chunks + 3) / 4, cap));
-  if (!P.scene.n_nodes && !ctx->swapping &&
-      ctx->hit_slots >= ctx->hit_capacity + ctx->hit_capacity / 8 + 64 + (uint64_t)grid * 4 * kHitBlock)
-    P.out.hit_block = kHitBlock;     // flat kernels only (see record_hit)
+  // big analytic scenes: grid kernel (no stochastic surfaces, no segment rows: those stay with the BVH kernels)
+  const bool use_grid = P.grid.nx > 0 && ctx->n_samplers == 0 && !(flags & ODW_TRACE_RECORD_SEGMENTS);
+  const uint64_t grid_blocks = std::max<uint64_t>(1, std::min<uint64_t>((n_chunks + ODW_GRID_WAVES - 1) / ODW_GRID_WAVES, (uint64_t)ctx->n_cu));
+  const uint64_t n_waves = use_grid ? grid_blocks * ODW_GRID_WAVES : (uint64_t)grid * 4;
+  if ((!P.scene.n_nodes || use_grid) && !ctx->swapping &&
+      ctx->hit_slots >= ctx->hit_capacity + ctx->hit_capacity / 8 + 64 + n_waves * kHitBlock)
+    P.out.hit_block = kHitBlock;     // flat and grid kernels only (see record_hit)
   HIPCHK(ctx, hipMemsetAsync(ctx->chunk_counter.p, 0, sizeof(uint64_t), ctx->stream));
   const size_t lds = P.scene.n_nodes ? (size_t)ODW_BVH_STACK * 256 * sizeof(int) : 0;
 
@@ -567,7 +723,23 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
     HIPCHK(ctx, hipEventRecord(ev.first, ctx->stream));
   }
   const bool stoch = ctx->n_samplers > 0;
-  if (flags & ODW_TRACE_RECORD_SEGMENTS) {
+  if (use_grid) {
+    const dim3 gb((unsigned)grid_blocks);
+    const size_t glds = P.grid.lds_bytes;
+#define ODW_GRID_LAUNCH(S, L)                                                                                  \
+    do {                                                                                                       \
+      static bool attr_set = false;                                                                            \
+      if (!attr_set) {                                                                                         \
+        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&odw_grid_kernel<S, L>),                 \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));              \
+        attr_set = true;                                                                                       \
+      }                                                                                                        \
+      hipLaunchKernelGGL((odw_grid_kernel<S, L>), gb, dim3(ODW_GRID_THREADS), glds, ctx->stream, P);           \
+    } while (0)
+    if (P.grid.spheres) { if (P.grid.in_lds) ODW_GRID_LAUNCH(true, true); else ODW_GRID_LAUNCH(true, false); }
+    else { if (P.grid.in_lds) ODW_GRID_LAUNCH(false, true); else ODW_GRID_LAUNCH(false, false); }
+#undef ODW_GRID_LAUNCH
+  } else if (flags & ODW_TRACE_RECORD_SEGMENTS) {
     if (P.scene.n_nodes) {
       if (stoch) hipLaunchKernelGGL((odw_trace_kernel<true, true, true>), dim3(grid), dim3(256), lds, ctx->stream, P);
       else hipLaunchKernelGGL((odw_trace_kernel<true, false, true>), dim3(grid), dim3(256), lds, ctx->stream, P);
@@ -667,6 +839,7 @@ void odw_destroy(odw_ctx* ctx) {
   for (auto& sb : ctx->surf_bufs) { release(sb.phi_tab); release(sb.t_tab); release(sb.t_guide); }
   release(ctx->d_samplers);
   release(ctx->d_group_sampler);
+  for (DevBuf* b : {&ctx->grid_bounds, &ctx->grid_cells, &ctx->grid_items}) release(*b);
   for (DevBuf* b : {&ctx->ph_sel_entering, &ctx->ph_flags, &ctx->ph_x, &ctx->ph_y, &ctx->ph_sorted, &ctx->ph_small,
                     &ctx->ph_part, &ctx->ph_edges, &ctx->ph_edges_b, &ctx->ph_counts})
     release(*b);

@@ -22,6 +22,7 @@
 namespace odw {
 
 #define ODW_TAG_UNUSED 0xFFFFFFFFFFFFFFFFull   // tag of a hit-list slot that was reserved but not written
+#define ODW_CNT_LDS 8        // counters 0..7 are gathered in LDS; rarer ones are added to the global array directly
 #define ODW_SOLID_SHIFT 16   // prim_i32 flags word: flags | facemask << 8 | solid id << 16
 
 struct d3 {
@@ -55,6 +56,22 @@ struct DeviceScene {
   int32_t n_prims, n_groups, n_nodes;
   int32_t seq_enabled, seq_len;
   uint64_t ignore_mask, all_mask;
+};
+
+// Rectilinear grid over the primitives of a big analytic scene (no facets): cell (i, j, k) spans
+// [bx[i], bx[i+1]] x [by[j], by[j+1]] x [bz[k], bz[k+1]]; the planes sit in the gaps between the
+// primitives' boxes where there are gaps (a Draft array of spheres gets one sphere per cell), wide
+// slabs are cut evenly.  A cell lists every primitive whose box (tolerance slack included) meets it.
+// Walked by a 3-D DDA: no stack, one cell per step.
+struct DeviceGrid {
+  const double* bounds;         // [nx+1 | ny+1 | nz+1]
+  const uint32_t* cells;        // [nx*ny*nz] first item | count << 24, x fastest
+  const void* items;            // spheres: 48-byte records (cx, cy, cz, R, {prim, group | solid << 8}, -)
+                                // else   : u32 primitive indices
+  int32_t nx, ny, nz, n_items;
+  int32_t spheres;              // every listed primitive is an untrimmed sphere
+  int32_t in_lds;               // cells + items are staged in LDS by every block
+  uint32_t lds_bytes;           // dynamic LDS of a block
 };
 
 struct DeviceSource {
@@ -124,6 +141,7 @@ struct DeviceOutputs {
 // out of the ray loop and keeps ~40 VGPRs occupied for the whole kernel.
 struct TraceParams {
   DeviceScene scene;
+  DeviceGrid grid;              // grid kernels only (nx = 0: none)
   DeviceLimits lim;
   const DeviceSource* source;
   const DeviceDetector* det;

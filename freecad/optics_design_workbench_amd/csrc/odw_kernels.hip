@@ -946,7 +946,9 @@ __device__ __noinline__ void next_hit_block(odw_hit* hits, uint64_t capacity, un
   }
 }
 
-template <bool BLOCKS>
+// cnt: the thread's (CS = 256: a column of the block's table, plain adds) or the wave's (CS = 1,
+// CA: ds_add) event counters
+template <bool BLOCKS, int CS = 256, bool CA = false>
 __device__ __forceinline__ void record_hit(const TraceParams& P, uint64_t ray, int group, d3 p, d3 d,
                                            double power, bool entering, uint32_t* cnt,
                                            volatile uint32_t* hit_state) {
@@ -986,8 +988,10 @@ __device__ __forceinline__ void record_hit(const TraceParams& P, uint64_t ray, i
       row[1] = make_double2(p.z, d.x);
       row[2] = make_double2(d.y, d.z);
       row[3] = make_double2(power, __longlong_as_double((long long)tag));
+    } else if (CA) {
+      atomicAdd(&cnt[ODW_CNT_HITS_DROPPED * CS], 1u);
     } else {
-      cnt[ODW_CNT_HITS_DROPPED * 256] += 1u;
+      cnt[ODW_CNT_HITS_DROPPED * CS] += 1u;
     }
   }
   if ((P.flags & ODW_TRACE_HISTOGRAM) && P.det_enabled) {
@@ -1001,8 +1005,10 @@ __device__ __forceinline__ void record_hit(const TraceParams& P, uint64_t ray, i
       const double fy = floor((y - det->y_lo) * det->y_scale);
       if (fx >= 0 && fx < det->nx_f && fy >= 0 && fy < det->ny_f)
         atomicAdd(P.out.hist + ((size_t)fx * (size_t)det->ny + (size_t)fy), 1ull);
+      else if (CA)
+        atomicAdd(&cnt[ODW_CNT_HIST_OVERFLOW * CS], 1u);
       else
-        cnt[ODW_CNT_HIST_OVERFLOW * 256] += 1u;
+        cnt[ODW_CNT_HIST_OVERFLOW * CS] += 1u;
     }
   }
 }
@@ -1071,9 +1077,9 @@ __global__ __launch_bounds__(256, BVH ? ODW_WAVES_PER_SIMD_BVH : ODW_WAVES_PER_S
   extern __shared__ int bvh_stack[];  // ODW_BVH_STACK x 256 ints (BVH variant only)
   // per-thread event counters live in LDS (one column per thread, ds_add_u32
   // at the event): eight fewer VGPRs across the whole ray loop
-  __shared__ uint32_t cnt_lds[ODW_CNT_COUNT * 256];
+  __shared__ uint32_t cnt_lds[ODW_CNT_LDS * 256];
 #pragma unroll
-  for (int k = 0; k < ODW_CNT_COUNT; ++k) cnt_lds[k * 256 + threadIdx.x] = 0;
+  for (int k = 0; k < ODW_CNT_LDS; ++k) cnt_lds[k * 256 + threadIdx.x] = 0;
 #define ODW_COUNT(k) (cnt_lds[(k) * 256 + threadIdx.x] += 1u)
   const DeviceScene& sc = P.scene;
   const DeviceLimits& lim = P.lim;
@@ -1232,7 +1238,12 @@ __global__ __launch_bounds__(256, BVH ? ODW_WAVES_PER_SIMD_BVH : ODW_WAVES_PER_S
             ++seq;
           }
         } else if (entering) {
-          if (medium >= 0) { ODW_COUNT(ODW_CNT_DIED); alive = false; }
+          if (medium >= 0) {
+            // the reference raises ValueError here (ray.py:234-237): counted, the host raises
+            atomicAdd(P.out.counters + ODW_CNT_GRATING_IN_MEDIUM, 1ull);
+            ODW_COUNT(ODW_CNT_DIED);
+            alive = false;
+          }
           medium = g;
           dir = line_grating(dir, 1.0, group_f64[4 * g], n, P.wavelength, order, lpm, gd, true);
         } else {
@@ -1266,7 +1277,7 @@ __global__ __launch_bounds__(256, BVH ? ODW_WAVES_PER_SIMD_BVH : ODW_WAVES_PER_S
   }
   // counters: wave reduction, one atomic per wave and counter
 #pragma unroll
-  for (int k = 0; k < ODW_CNT_COUNT; ++k) {
+  for (int k = 0; k < ODW_CNT_LDS; ++k) {
     const uint32_t s = wave_sum(cnt_lds[k * 256 + threadIdx.x]);
     if (__lane_id() == 0 && s) atomicAdd(P.out.counters + k, (unsigned long long)s);
   }

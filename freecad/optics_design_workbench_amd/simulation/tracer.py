@@ -191,6 +191,8 @@ class Tracer:
       self._chk(self._lib.odw_fetch_swapped_hits(self._ctx, buf.ctypes.data_as(C.c_void_p), C.c_uint64(len(buf)),
                                                  C.byref(got)), 'odw_fetch_swapped_hits')
       return buf[:int(got.value)]
+    # from the first swap on appends are dense (the rows of a list are copied as they lie)
+    self._chk(self._lib.odw_swap_hit_lists(self._ctx), 'odw_swap_hit_lists')
     k = -1
     for k, (first, n) in enumerate(jobs):
       self.resetHits()

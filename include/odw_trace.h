@@ -291,7 +291,12 @@ enum {
   ODW_CNT_CAPPED = 5,        /* numIntersections >= max, ray.py:96           */
   ODW_CNT_HIST_OVERFLOW = 6, /* recorded hits outside the detector window    */
   ODW_CNT_HITS_DROPPED = 7,  /* hit list capacity exceeded                   */
-  ODW_CNT_COUNT = 8
+  ODW_CNT_GRATING_IN_MEDIUM = 8, /* rays that entered a transmission grating
+                              * inside a medium: the reference raises
+                              * ValueError there (ray.py:234-237); the ray is
+                              * ended (also counted under DIED), the caller
+                              * turns a non-zero count into that exception    */
+  ODW_CNT_COUNT = 9
 };
 
 /* trace flags */

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, 'libodw_oracle.so')
 
 CNT_NAMES = ['traced_rays', 'recorded_hits', 'segments', 'escaped', 'died', 'capped',
-             'hist_overflow', 'hits_dropped']
+             'hist_overflow', 'hits_dropped', 'grating_in_medium']
 TRACE_RECORD_HITS, TRACE_HISTOGRAM = 1, 2
 
 HIT_DTYPE = np.dtype([('point', '<f8', 3), ('direction', '<f8', 3), ('power', '<f8'), ('tag', '<u8')])

@@ -843,7 +843,7 @@ static void trace_one(const odw_scene_desc* sc, const odw_limits* lim,
         if (entering) {
           /* the reference raises ValueError if medium is not None; the host
            * validates scenes for that, here the ray is simply stopped */
-          if (medium >= 0) { sk->cnt[ODW_CNT_DIED]++; break; }
+          if (medium >= 0) { sk->cnt[ODW_CNT_GRATING_IN_MEDIUM]++; sk->cnt[ODW_CNT_DIED]++; break; }   /* ValueError, ray.py:234-237 */
           medium = g;
           dir = line_grating(mul(dir, 1.0 / len(dir)), 1.0, sc->group_ior[g], n, wavelength,
                              sc->group_grating_order[g], sc->group_grating_lpm[g], gd, 1);

@@ -189,4 +189,4 @@ def test_c5_full_radius_sweep(tracer):
   k = int(np.argmin(rms))
   assert 10.0 < radii[k] < 10.6, radii[k]
   assert np.all(np.diff(rms[:k + 1]) < 0) and np.all(np.diff(rms[k:]) > 0)      # one valley
-  assert rms[k] < 0.2 * max(rms[0], rms[-1])
+  assert rms[k] < 0.25 * max(rms[0], rms[-1])

@@ -25,7 +25,8 @@ def test_oracle_reproduces_committed_vectors(oracle, scene):
   pr = project(scene)
   fn = oracle.trace_surface if hasattr(pr.source, 'face_prim') else oracle.trace
   r = fn(pr.scene, pr.source, pr.limits, first, n, seed)
-  assert [r['counters'][k] for k in oracle.CNT_NAMES] == list(g['counters'])
+  # (the vectors hold the eight counters of ABI 4; 'grating_in_medium', added later, stays zero)
+  assert [r['counters'][k] for k in oracle.CNT_NAMES[:8]] == list(g['counters']) and r['counters']['grating_in_medium'] == 0
   h = r['hits']
   assert np.array_equal(h['tag'], g['tag'])
   # same source, same compiler flags: bit for bit; another libm may differ in the last digits
