@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -56,7 +57,7 @@ struct odw_ctx {
 
   DevBuf prim_f64, prim_hdr, prim_i32, cond_i32, group_f64, group_i32, group_gdir, seq_mask;
   DevBuf bvh_nodes, bvh_prims, tri_nrm;
-  DevBuf grid_bounds, grid_cells, grid_items;   // rectilinear grid of big analytic scenes (odw_grid.hip)
+  DevBuf grid_bounds, grid_cells, grid_items, dbg;   // rectilinear grid of big analytic scenes (odw_grid.hip)
   DevBuf phi_tab, t_tab, t_guide, phi_guide, d_source, d_det;
   DeviceSource h_source;
   DeviceDetector h_det;
@@ -515,8 +516,13 @@ int build_grid(odw_ctx* ctx, const std::vector<Box>& boxes, const std::vector<ch
     if ((rc = upload(ctx, ctx->grid_items, item_prim.data(), item_bytes))) return rc;
   }
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));                   // host vectors die with this scope
-  const size_t fixed = bounds.size() * sizeof(double) + (ODW_GRID_WAVES * 16 + ODW_GRID_WAVES * 4) * sizeof(uint32_t);
-  const size_t staged = ((fixed + ncell * sizeof(uint32_t) + 15) & ~(size_t)15) + item_bytes;
+  // the kernel's LDS image (odw_grid_kernel, same arithmetic): planes | per-wave words | ray rings | cells | items
+  const size_t nbp = bounds.size();
+  const size_t word_off = 2 * nbp;
+  const size_t ring_off = (word_off + (size_t)ODW_GRID_WAVES * ODW_GRID_WAVE_WORDS + 1) / 2;
+  const size_t cell_off = 2 * (ring_off + (size_t)ODW_GRID_WAVES * ODW_GRID_RING_DOUBLES);
+  const size_t fixed = cell_off * sizeof(uint32_t);
+  const size_t staged = (((cell_off + ncell + 3) & ~(size_t)3) / 2) * sizeof(double) + item_bytes;
   G.bounds = (const double*)ctx->grid_bounds.p;
   G.cells = (const uint32_t*)ctx->grid_cells.p;
   G.items = ctx->grid_items.p;
@@ -681,6 +687,7 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
   P.ray_origins = ray_o;
   P.ray_dirs = ray_d;
   P.ray_powers = ray_p;
+  P.dbg = (unsigned long long*)ctx->dbg.p;
   P.out.hits = (odw_hit*)ctx->hits.p;
   P.out.hit_capacity = ctx->hit_slots;
   // block reservations need room for the unused slots they can leave behind: < 64 per block and the
@@ -807,6 +814,9 @@ int odw_create(int device, odw_ctx** out) {
   }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
+  if (getenv("ODW_GRID_STATS")) {               // diagnostic builds of the grid kernel report here (odw_destroy prints)
+    if (ensure(ctx, ctx->dbg, 16 * sizeof(uint64_t)) == ODW_OK) (void)hipMemset(ctx->dbg.p, 0, 16 * sizeof(uint64_t));
+  }
   int rc = ensure(ctx, ctx->counters, ODW_CNT_COUNT * sizeof(uint64_t));
   if (!rc) rc = ensure(ctx, ctx->hit_count, 2 * sizeof(uint64_t));
   if (!rc) rc = ensure(ctx, ctx->chunk_counter, sizeof(uint64_t));
@@ -824,6 +834,15 @@ void odw_destroy(odw_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->dbg.p) {
+    uint64_t v[16] = {0};
+    (void)hipMemcpy(v, ctx->dbg.p, sizeof v, hipMemcpyDeviceToHost);
+    const char* names[6] = {"A ring fills", "B segment setup", "C cell steps", "D all", "D resolve", "D interact"};
+    for (int k = 0; k < 6; ++k)
+      fprintf(stderr, "[odw grid stats] %-16s runs %12llu  lanes %14llu  (%.1f per run)\n", names[k], (unsigned long long)v[2 * k],
+              (unsigned long long)v[2 * k + 1], v[2 * k] ? (double)v[2 * k + 1] / (double)v[2 * k] : 0.0);
+    release(ctx->dbg);
+  }
   for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   for (auto& ev : ctx->free_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   DevBuf* all[] = {&ctx->prim_f64, &ctx->prim_hdr, &ctx->prim_i32, &ctx->cond_i32, &ctx->group_f64, &ctx->group_i32,

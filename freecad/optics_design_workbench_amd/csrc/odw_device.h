@@ -155,6 +155,7 @@ struct TraceParams {
   const double* ray_powers;
   uint64_t first_ray, n_rays, seed;
   uint32_t flags;
+  unsigned long long* dbg;      // diagnostic builds only (ODW_GRID_STATS): 16 words, or null
 };
 
 }  // namespace odw

@@ -6,39 +6,58 @@
 // of node visits, the lanes of a wave wait for the slowest (27 % of the issued lanes did work),
 // and its per-thread node stack (32 KB of LDS per block) capped the occupancy.  A grid walk needs
 // no stack; its state is a cell index and three plane distances.  With that little state the ray
-// loop can be turned inside out: every iteration, every lane that is walking takes one cell step
-// (uniform work: fetch the cell, test its primitives, advance); lanes whose walk has ended wait
-// until enough of them have gathered, then the (divergent, expensive) interaction code runs for
-// all of them at once and they start their next segment or take a new ray.
+// loop can be turned inside out -- three queues inside every wave:
+//   walk      every iteration, every walking lane takes one cell step: fetch the cell, a CHEAP test
+//             of its primitives (sphere: sign of the discriminant; others: bounding box), advance.
+//             Uniform work, all walking lanes together.
+//   resolve   a lane whose cheap test says "maybe" stops walking.  When enough lanes wait, the
+//   + interact  expensive, divergent code runs for all of them at once: exact roots and consider()
+//             for the cell's primitives, then either back to walking or the interaction with the
+//             surface (normal, Snell / mirror / grating, hit row) and the next segment's set-up.
+//   generate  new rays come from a per-wave ring in LDS that the WHOLE wave fills, 64 rays at a
+//             time (Philox, two table inversions, four sin/cos: ~600 instructions, now always at 64
+//             lanes); an idle lane pops its next ray from the ring.
+// Measured on hugeArray with one queue per segment (first version of this file): 1.79e10 VALU
+// wave-instructions per 1.25e8 rays -- generation at 21 lanes per run, the root / consider path at
+// ~9 lanes in nearly every cell step, interaction at 38.
 //
 // Same rules as nearest<>() of odw_kernels.hip (ray.py:290-452): every candidate goes through
 // consider(); the walk goes on while cells begin before nearest + 2 distTol.  Cells are visited in
 // the order the ray meets them, a primitive is listed in every cell its box (tolerance slack
 // included) touches, so every admissible candidate has been seen when the walk stops.
 //
-// Block = 1024 threads (16 waves, one block per CU, <= 128 VGPRs): bounds, cell table and --
-// for sphere scenes -- the primitive records live in LDS (hugeArray: 0.2 + 6 + 72 KB).
+// Block = 1024 threads (16 waves, one block per CU, <= 128 VGPRs): plane tables, cell table, -- for
+// sphere scenes -- the primitive records and the ray rings live in LDS (hugeArray: 0.2 + 6 + 72 + 48 KB).
 #include "odw_device.h"
 
 namespace odw {
 
 #ifndef ODW_GRID_STEP_MIN
-#define ODW_GRID_STEP_MIN 40     // keep stepping while at least this many lanes of the wave walk
-#endif
-#ifndef ODW_GRID_STEP_MAX
-#define ODW_GRID_STEP_MAX 6      // ... but look at the waiting lanes at least every so many steps
+#define ODW_GRID_STEP_MIN 24     // keep stepping while at least this many lanes of the wave walk (measured: 16-24 alike,
+#endif                           // 32: +6 %, 40: +25 %, 56: +90 % time on hugeArray)
+#ifndef ODW_GRID_REFILL_MIN
+#define ODW_GRID_REFILL_MIN 1    // idle lanes that make the wave pop new rays from its ring (measured: 1: 25.8 ms,
+                                 // 8: 39.8, 16: 41.5 per 1.25e8 hugeArray rays -- a pop costs ~30 instructions, a lane
+                                 // that waits for seven others idles through whole cell steps)
 #endif
 #define ODW_GRID_THREADS 1024
 #define ODW_GRID_WAVES (ODW_GRID_THREADS / 64)
+#define ODW_GRID_WAVE_WORDS 32   // per wave: event counters (0..7), diagnostics (8..27), hit-block state (28..31)
+#define ODW_GRID_RING 64         // rays per wave in the ring (one per lane and fill)
+#define ODW_GRID_RING_DOUBLES (ODW_GRID_RING * 6)
 
-struct GridView {
-  const double* bx; const double* by; const double* bz;   // LDS
-  const uint32_t* cells;
-  const void* items;
-  int nx, ny, nz;
-};
+// diagnostic build (-DODW_GRID_STATS): per phase, how often it ran and with how many lanes
+#ifdef ODW_GRID_STATS
+#define ODW_GSTAT(k, mask_)                                                                           \
+  do {                                                                                                \
+    const unsigned long long m_ = (mask_);                                                            \
+    if (m_ && (int)__lane_id() == __ffsll(m_) - 1) { wave_cnt[8 + 2 * (k)] += 1u; wave_cnt[9 + 2 * (k)] += (uint32_t)__popcll(m_); } \
+  } while (0)
+#else
+#define ODW_GSTAT(k, mask_) do {} while (0)
+#endif
 
-// index i with b[i] <= v < b[i+1], clamped to [0, n-1]   (b has n+1 entries)
+// index i with b[i] <= v < b[i+1], clamped to [0, n-1]   (b: n+1 planes in LDS)
 __device__ __forceinline__ int grid_slab(const double* b, int n, double v) {
   int lo = 0, hi = n;
   while (hi - lo > 1) {
@@ -46,58 +65,6 @@ __device__ __forceinline__ int grid_slab(const double* b, int n, double v) {
     if (v >= b[mid]) lo = mid; else hi = mid;
   }
   return lo;
-}
-
-struct Walk {
-  double tx, ty, tz;   // ray parameter at which the walk leaves the cell through each axis
-  d3 inv;
-  int cell;            // ix | iy << 8 | iz << 16
-};
-
-// start of a segment's walk: clip the ray to the grid, find the first cell.  false: misses the grid
-__device__ __forceinline__ bool walk_begin(const GridView& G, d3 o, d3 d, double tmax, Walk& w) {
-  w.inv = mk(frcp(d.x), frcp(d.y), frcp(d.z));
-  double t0 = 0.0, t1 = tmax;
-#define ODW_CLIP(O, D, INV, B, N)                                            \
-  if ((D) != 0) {                                                            \
-    const double a_ = ((B)[0] - (O)) * (INV), b_ = ((B)[N] - (O)) * (INV);   \
-    t0 = fmax(t0, fmin(a_, b_));                                             \
-    t1 = fmin(t1, fmax(a_, b_));                                             \
-  } else if ((O) < (B)[0] || (O) > (B)[N]) {                                 \
-    return false;                                                            \
-  }
-  ODW_CLIP(o.x, d.x, w.inv.x, G.bx, G.nx)
-  ODW_CLIP(o.y, d.y, w.inv.y, G.by, G.ny)
-  ODW_CLIP(o.z, d.z, w.inv.z, G.bz, G.nz)
-#undef ODW_CLIP
-  if (!(t0 <= t1)) return false;
-  const d3 p = o + d * t0;
-  const int ix = grid_slab(G.bx, G.nx, p.x), iy = grid_slab(G.by, G.ny, p.y), iz = grid_slab(G.bz, G.nz, p.z);
-  w.cell = ix | (iy << 8) | (iz << 16);
-  w.tx = d.x > 0 ? (G.bx[ix + 1] - o.x) * w.inv.x : (d.x < 0 ? (G.bx[ix] - o.x) * w.inv.x : INFINITY);
-  w.ty = d.y > 0 ? (G.by[iy + 1] - o.y) * w.inv.y : (d.y < 0 ? (G.by[iy] - o.y) * w.inv.y : INFINITY);
-  w.tz = d.z > 0 ? (G.bz[iz + 1] - o.z) * w.inv.z : (d.z < 0 ? (G.bz[iz] - o.z) * w.inv.z : INFINITY);
-  return true;
-}
-
-// leave the cell through the nearest plane.  false: left the grid
-__device__ __forceinline__ bool walk_advance(const GridView& G, d3 o, d3 d, Walk& w) {
-  int ix = w.cell & 0xff, iy = (w.cell >> 8) & 0xff, iz = w.cell >> 16;
-  if (w.tx <= w.ty && w.tx <= w.tz) {
-    ix += d.x > 0 ? 1 : -1;
-    if (ix < 0 || ix >= G.nx) return false;
-    w.tx = (G.bx[ix + (d.x > 0 ? 1 : 0)] - o.x) * w.inv.x;
-  } else if (w.ty <= w.tz) {
-    iy += d.y > 0 ? 1 : -1;
-    if (iy < 0 || iy >= G.ny) return false;
-    w.ty = (G.by[iy + (d.y > 0 ? 1 : 0)] - o.y) * w.inv.y;
-  } else {
-    iz += d.z > 0 ? 1 : -1;
-    if (iz < 0 || iz >= G.nz) return false;
-    w.tz = (G.bz[iz + (d.z > 0 ? 1 : 0)] - o.z) * w.inv.z;
-  }
-  w.cell = ix | (iy << 8) | (iz << 16);
-  return true;
 }
 
 // per-wave event counters in LDS: the interaction code runs under divergent control flow, so the
@@ -110,34 +77,33 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
   const DeviceScene& sc = P.scene;
   const DeviceLimits& lim = P.lim;
   const DeviceGrid& GD = P.grid;
-  // ---- LDS image: bounds | cells | items | per-wave counters | per-wave hit-block state ----
-  const int nb = GD.nx + GD.ny + GD.nz + 3;
-  const int ncell = GD.nx * GD.ny * GD.nz;
-  double* l_bounds = grid_lds;
-  uint32_t* l_words = reinterpret_cast<uint32_t*>(l_bounds + nb);
-  uint32_t* wave_cnt_all = l_words;                                   // [ODW_GRID_WAVES][16]
-  uint32_t* hit_state_all = wave_cnt_all + ODW_GRID_WAVES * 16;       // [ODW_GRID_WAVES][4]
-  uint32_t* l_cells = hit_state_all + ODW_GRID_WAVES * 4;
-  // items start on a 16-byte boundary
-  double* l_items = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(l_cells + (IN_LDS ? ncell : 0)) + 15) & ~(uintptr_t)15);
-  for (int k = threadIdx.x; k < nb; k += ODW_GRID_THREADS) l_bounds[k] = GD.bounds[k];
-  for (int k = threadIdx.x; k < ODW_GRID_WAVES * 16; k += ODW_GRID_THREADS) wave_cnt_all[k] = 0;
-  if (threadIdx.x < ODW_GRID_WAVES * 4) hit_state_all[threadIdx.x] = (threadIdx.x & 3) == 2 ? P.out.hit_block : 0u;
+  // ---- LDS image: planes | per-wave words | ray rings | cells | items ----
+  // (addressed by offsets from the one dynamic array: pointers that pass through integers or
+  //  through a struct lose their address space and turn every read into a flat load)
+  const int nx = GD.nx, ny = GD.ny, nz = GD.nz;
+  const int nb = nx + ny + nz + 3;
+  const int ncell = nx * ny * nz;
+  uint32_t* lds32 = reinterpret_cast<uint32_t*>(grid_lds);
+  const int word_off = 2 * nb;                                            // [ODW_GRID_WAVES][ODW_GRID_WAVE_WORDS] words
+  const int ring_off = (word_off + ODW_GRID_WAVES * ODW_GRID_WAVE_WORDS + 1) / 2;   // doubles: [ODW_GRID_WAVES][ring]
+  const int cell_off = 2 * (ring_off + ODW_GRID_WAVES * ODW_GRID_RING_DOUBLES);      // words: [ncell]
+  const int item_off = ((cell_off + (IN_LDS ? ncell : 0) + 3) & ~3) / 2;             // doubles, 16-byte aligned
+  for (int k = threadIdx.x; k < nb; k += ODW_GRID_THREADS) grid_lds[k] = GD.bounds[k];
+  for (int k = threadIdx.x; k < ODW_GRID_WAVES * ODW_GRID_WAVE_WORDS; k += ODW_GRID_THREADS)
+    lds32[word_off + k] = (k % ODW_GRID_WAVE_WORDS) == 30 ? P.out.hit_block : 0u;   // hit-block state: base lo, hi, used (full: none reserved yet), -
   if (IN_LDS) {
-    for (int k = threadIdx.x; k < ncell; k += ODW_GRID_THREADS) l_cells[k] = GD.cells[k];
+    for (int k = threadIdx.x; k < ncell; k += ODW_GRID_THREADS) lds32[cell_off + k] = GD.cells[k];
     const int n_words = SPHERES ? GD.n_items * 6 : (GD.n_items + 1) / 2;       // doubles
     const double* src = reinterpret_cast<const double*>(GD.items);
-    for (int k = threadIdx.x; k < n_words; k += ODW_GRID_THREADS) l_items[k] = src[k];
+    for (int k = threadIdx.x; k < n_words; k += ODW_GRID_THREADS) grid_lds[item_off + k] = src[k];
   }
   __syncthreads();
-  GridView G;
-  G.bx = l_bounds; G.by = l_bounds + GD.nx + 1; G.bz = l_bounds + GD.nx + GD.ny + 2;
-  G.nx = GD.nx; G.ny = GD.ny; G.nz = GD.nz;
-  G.cells = IN_LDS ? l_cells : GD.cells;
-  G.items = IN_LDS ? (const void*)l_items : GD.items;
+  const double* bx = grid_lds;                                   // the three plane tables, one after the other
+  const int by_off = nx + 1, bz_off = nx + ny + 2;
   const int wave = threadIdx.x >> 6;
-  uint32_t* wave_cnt = wave_cnt_all + wave * 16;
-  volatile uint32_t* hit_state = hit_state_all + wave * 4;
+  uint32_t* wave_cnt = lds32 + word_off + wave * ODW_GRID_WAVE_WORDS;
+  volatile uint32_t* hit_state = wave_cnt + 28;
+  double* ring = grid_lds + ring_off + wave * ODW_GRID_RING_DOUBLES;      // slot s: origin (3), direction (3)
 
   SceneView sv;
   sv.prim_f64 = as_const(sc.prim_f64);
@@ -150,10 +116,13 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
   cu64 seq_mask = as_const(sc.seq_mask);
 
   const uint32_t lane = __lane_id();
-  uint64_t next = 0, chunk_end = 0;                        // wave-uniform
-  // lane states: !alive (no ray) | fresh (ray or segment to set up) | walking | waiting for the
-  // interaction (alive && !fresh && !walking)
-  bool alive = false, fresh = false, walking = false;
+  uint64_t next = 0, chunk_end = 0;                        // wave-uniform: the wave's chunk of the launch
+  uint64_t ring_base = 0;                                  // wave-uniform: ray index of ring slot 0
+  uint32_t ring_n = 0;                                     // wave-uniform: rays left in the ring (slots 0 .. ring_n-1)
+  bool drained = false;                                    // wave-uniform: the launch has no rays left to hand out
+  // lane states: !alive (no ray) | fresh (segment to set up) | walking | pending (cheap test positive: resolve) |
+  // waiting for the interaction (alive && !fresh && !walking && !pending)
+  bool alive = false, fresh = false, walking = false, pending = false;
   uint64_t i = 0;
   // the ray's position, direction and medium live in the query record (one copy)
   Query q;
@@ -167,46 +136,102 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
   double power = 0;
   int seq = 0, nint = 0, skip = -1;
   uint64_t mask = 0;
-  bool drained = false;                                    // wave-uniform: the launch has no rays left to hand out
-  Walk w;
-  w.tx = w.ty = w.tz = INFINITY; w.inv = mk(0, 0, 0); w.cell = 0;
+  // the walk: ray parameter at which it leaves the cell through each axis, 1 / direction, the cell
+  // (ix | iy << 8 | iz << 16)
+  double tx = INFINITY, ty = INFINITY, tz = INFINITY, ivx = 0, ivy = 0, ivz = 0;
+  int cell = 0;
+
+  // leave the cell through the nearest plane (the axis by selects, the next plane by ONE read of the
+  // contiguous plane tables), or end the walk: beyond nearest + 2 distTol (ray.py:432, 440), or out of the grid
+#define ODW_WALK_ADVANCE()                                                                   \
+  do {                                                                                       \
+    const double t_exit_ = fmin(tx, fmin(ty, tz));                                           \
+    const double cut_ = fmin(q.tmax, q.any.t + 2.0 * q.tol);                                 \
+    if (!(t_exit_ <= cut_)) {                                                                \
+      walking = false;                                                                       \
+    } else {                                                                                 \
+      const bool ax_ = tx <= ty && tx <= tz;                                                 \
+      const bool ay_ = !ax_ && ty <= tz;                                                     \
+      const int shift_ = ax_ ? 0 : (ay_ ? 8 : 16);                                           \
+      const int n_ = ax_ ? nx : (ay_ ? ny : nz);                                             \
+      const double da_ = ax_ ? dir.x : (ay_ ? dir.y : dir.z);                                \
+      const double oa_ = ax_ ? point.x : (ay_ ? point.y : point.z);                          \
+      const double ia_ = ax_ ? ivx : (ay_ ? ivy : ivz);                                      \
+      const int base_ = ax_ ? 0 : (ay_ ? by_off : bz_off);                                   \
+      const int up_ = da_ > 0 ? 1 : 0;                                                       \
+      const int idx_ = ((cell >> shift_) & 0xff) + 2 * up_ - 1;                              \
+      if (idx_ < 0 || idx_ >= n_) {                                                          \
+        walking = false;                                                                     \
+      } else {                                                                               \
+        const double t_ = (bx[base_ + idx_ + up_] - oa_) * ia_;                              \
+        tx = ax_ ? t_ : tx;                                                                  \
+        ty = ay_ ? t_ : ty;                                                                  \
+        tz = (!ax_ && !ay_) ? t_ : tz;                                                       \
+        cell = (cell & ~(0xff << shift_)) | (idx_ << shift_);                                \
+        walking = true;                                                                      \
+      }                                                                                      \
+    }                                                                                        \
+  } while (0)
 
   for (;;) {
-    // ---- A: new rays for idle lanes (as in odw_trace_kernel) -------------------------------
+    // ---- A: new rays for idle lanes, from the wave's ring ------------------------------------------
     const uint64_t idle = __ballot(!alive);
-    if (idle == ~0ull && drained) break;                   // nothing live, nothing left
-    if (!drained && idle && (idle == ~0ull || __popcll(idle) >= ODW_REFILL_MIN)) {
-      if (next >= chunk_end) {
-        unsigned long long c = 0;
-        if (lane == (uint32_t)(__ffsll((unsigned long long)__ballot(1)) - 1)) c = atomicAdd(P.out.chunk_counter, 1ull);
-        const uint64_t chunk = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(c >> 32)) << 32) |
-                               __builtin_amdgcn_readfirstlane((uint32_t)c);
-        next = chunk * ODW_CHUNK;
-        if (next >= P.n_rays) { next = P.n_rays; drained = true; }
-        chunk_end = next + ODW_CHUNK < P.n_rays ? next + ODW_CHUNK : P.n_rays;
+    if (idle == ~0ull && drained && ring_n == 0) break;    // nothing live, nothing left
+    if (idle && !(drained && ring_n == 0) && (idle == ~0ull || __popcll(idle) >= ODW_GRID_REFILL_MIN)) {
+      if (ring_n == 0) {
+        // fill: the whole wave generates the next (up to) 64 rays of its chunk, one per lane
+        if (next >= chunk_end) {
+          // next chunk of the launch: one atomic per wave and chunk
+          unsigned long long c = 0;
+          if (lane == 0) c = atomicAdd(P.out.chunk_counter, 1ull);
+          const uint64_t chunk = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(c >> 32)) << 32) |
+                                 __builtin_amdgcn_readfirstlane((uint32_t)c);
+          next = chunk * ODW_CHUNK;
+          if (next >= P.n_rays) { next = P.n_rays; drained = true; }
+          chunk_end = next + ODW_CHUNK < P.n_rays ? next + ODW_CHUNK : P.n_rays;
+        }
+        const uint64_t avail = chunk_end - next;
+        const uint32_t fill = avail < ODW_GRID_RING ? (uint32_t)avail : (uint32_t)ODW_GRID_RING;
+        ODW_GSTAT(0, __ballot(lane < fill));
+        if (lane < fill) {
+          const uint64_t r = next + lane;
+          d3 o, d;
+          if (P.ray_origins) {
+            o = mk(P.ray_origins[3 * r], P.ray_origins[3 * r + 1], P.ray_origins[3 * r + 2]);
+            d = mk(P.ray_dirs[3 * r], P.ray_dirs[3 * r + 1], P.ray_dirs[3 * r + 2]);
+            d = d * (1.0 / sqrt(dot(d, d)));
+          } else {
+            const RayInit g = generate_ray(P.source, P.first_ray + r, P.seed);
+            o = g.point; d = g.dir;
+          }
+          double* slot = ring + 6 * lane;
+          slot[0] = o.x; slot[1] = o.y; slot[2] = o.z; slot[3] = d.x; slot[4] = d.y; slot[5] = d.z;
+        }
+        // (one wave: its LDS operations complete in program order; this only keeps the compiler from
+        //  moving the reads below above the writes)
+        __builtin_amdgcn_wave_barrier();
+        ring_base = next;
+        ring_n = fill;
+        next += fill;
       }
-      const uint64_t avail = next < chunk_end ? chunk_end - next : 0;
+      // pop: idle lanes take the top rays of the ring
       const uint32_t rank = __popcll(idle & ((1ull << lane) - 1ull));
       const uint32_t want = __popcll(idle);
-      const uint32_t take = want < avail ? want : (uint32_t)avail;
+      const uint32_t take = want < ring_n ? want : ring_n;
       if (!alive && rank < take) {
-        i = next + rank;
-        if (P.ray_origins) {
-          point = mk(P.ray_origins[3 * i], P.ray_origins[3 * i + 1], P.ray_origins[3 * i + 2]);
-          dir = mk(P.ray_dirs[3 * i], P.ray_dirs[3 * i + 1], P.ray_dirs[3 * i + 2]);
-          dir = dir * (1.0 / sqrt(dot(dir, dir)));
-          power = P.ray_powers ? P.ray_powers[i] : 1.0;
-        } else {
-          const RayInit r = generate_ray(P.source, P.first_ray + i, P.seed);
-          point = r.point; dir = r.dir; power = r.power;
-        }
+        const uint32_t s = ring_n - 1 - rank;
+        const double* slot = ring + 6 * s;
+        point = mk(slot[0], slot[1], slot[2]);
+        dir = mk(slot[3], slot[4], slot[5]);
+        i = ring_base + s;
+        power = P.ray_origins ? (P.ray_powers ? P.ray_powers[i] : 1.0) : as_const(P.source)->power;
         seq = 0; nint = 0; medium = -1; skip = -1;
-        alive = true; fresh = true; walking = false;
+        alive = true; fresh = true; walking = false; pending = false;
       }
-      next += take;
-      if (idle == ~0ull && drained) break;
+      ring_n -= take;
     }
     // ---- B: set up the next segment of fresh lanes ---------------------------------------------
+    ODW_GSTAT(1, __ballot(alive && fresh));
     if (alive && fresh) {
       fresh = false;
       if (nint >= lim.max_intersections) {
@@ -221,132 +246,235 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
         mask &= ~sc.ignore_mask;
         q.any.t = INFINITY; q.any.prim = 0x7fffffff; q.any.face = 0x7fffffff;
         q.oth = q.any;
-        walking = mask != 0ull && walk_begin(G, point, dir, q.tmax, w);
+        walking = false;
+        if (mask != 0ull) {
+          ivx = frcp(dir.x); ivy = frcp(dir.y); ivz = frcp(dir.z);
+          int ix, iy, iz;
+          bool in = true;
+          if (nint > 1) {
+            // A ray that goes on from a hit starts in the cell its walk stopped in: the walk ends in the
+            // cell whose exit lies beyond the hit (+ 2 distTol), so the hit point is in it or within the
+            // tolerance of it.  If it is a hair outside, the plane distance of that axis comes out
+            // negative (or the cell is entered at once) and the first advance corrects the index: at
+            // worst one cell is looked at in vain.
+            ix = cell & 0xff; iy = (cell >> 8) & 0xff; iz = cell >> 16;
+          } else {
+            // a new ray: clip it to the grid, find the first cell
+            double t0 = 0.0, t1 = q.tmax;
+#define ODW_CLIP(O, D, INV, LO, HI)                                          \
+            if ((D) != 0) {                                                  \
+              const double a_ = ((LO) - (O)) * (INV), b_ = ((HI) - (O)) * (INV); \
+              t0 = fmax(t0, fmin(a_, b_));                                   \
+              t1 = fmin(t1, fmax(a_, b_));                                   \
+            } else if ((O) < (LO) || (O) > (HI)) {                           \
+              in = false;                                                    \
+            }
+            ODW_CLIP(point.x, dir.x, ivx, bx[0], bx[nx])
+            ODW_CLIP(point.y, dir.y, ivy, bx[by_off], bx[by_off + ny])
+            ODW_CLIP(point.z, dir.z, ivz, bx[bz_off], bx[bz_off + nz])
+#undef ODW_CLIP
+            in = in && t0 <= t1;
+            const d3 p0 = point + dir * t0;
+            ix = grid_slab(bx, nx, p0.x); iy = grid_slab(bx + by_off, ny, p0.y); iz = grid_slab(bx + bz_off, nz, p0.z);
+          }
+          if (in) {
+            cell = ix | (iy << 8) | (iz << 16);
+            tx = dir.x > 0 ? (bx[ix + 1] - point.x) * ivx : (dir.x < 0 ? (bx[ix] - point.x) * ivx : INFINITY);
+            ty = dir.y > 0 ? (bx[by_off + iy + 1] - point.y) * ivy : (dir.y < 0 ? (bx[by_off + iy] - point.y) * ivy : INFINITY);
+            tz = dir.z > 0 ? (bx[bz_off + iz + 1] - point.z) * ivz : (dir.z < 0 ? (bx[bz_off + iz] - point.z) * ivz : INFINITY);
+            walking = true;
+          }
+        }
       }
     }
     // ---- C: cell steps, all walking lanes together -----------------------------------------------
     for (int it = 0;; ++it) {
       const uint64_t wb = __ballot(walking);
       if (wb == 0ull) break;
-      // stop stepping once few lanes walk (or after a few steps) if lanes wait: for their interaction,
-      // or -- enough of them -- for a new ray
-      if (it > 0 && (__popcll(wb) < ODW_GRID_STEP_MIN || it >= ODW_GRID_STEP_MAX) &&
-          (__ballot(alive && !walking) != 0ull || (!drained && __popcll(__ballot(!alive)) >= ODW_REFILL_MIN)))
+      // stop stepping once few lanes walk if lanes wait: for resolution / interaction, or -- enough of
+      // them -- for a new ray
+      if (it > 0 && __popcll(wb) < ODW_GRID_STEP_MIN &&
+          (__ballot(alive && !walking) != 0ull ||
+           (!(drained && ring_n == 0) && __popcll(__ballot(!alive)) >= ODW_GRID_REFILL_MIN)))
         break;
+      ODW_GSTAT(2, wb);
       if (walking) {
-        const int ix = w.cell & 0xff, iy = (w.cell >> 8) & 0xff, iz = w.cell >> 16;
-        const uint32_t word = G.cells[ix + G.nx * (iy + G.ny * iz)];
+        const int ix = cell & 0xff, iy = (cell >> 8) & 0xff, iz = cell >> 16;
+        const int ci = ix + nx * (iy + ny * iz);
+        uint32_t word;
+        if (IN_LDS) word = lds32[cell_off + ci]; else word = GD.cells[ci];
+        const uint32_t first = word & 0xffffffu, count = word >> 24;
+        bool maybe = false;
+        for (uint32_t k = 0; k < count; ++k) {
+          if (SPHERES) {
+            // cheap test: does the line meet the sphere (discriminant), not behind the ray
+            double2 r0, r1, r2;
+            if (IN_LDS) {
+              const double2* rec = reinterpret_cast<const double2*>(grid_lds + item_off) + 3 * (size_t)(first + k);
+              r0 = rec[0]; r1 = rec[1]; r2 = rec[2];
+            } else {
+              const double2* rec = reinterpret_cast<const double2*>(GD.items) + 3 * (size_t)(first + k);
+              r0 = rec[0]; r1 = rec[1]; r2 = rec[2];
+            }
+            const uint32_t gs = (uint32_t)((uint64_t)__double_as_longlong(r2.x) >> 32);
+            const d3 oc = point - mk(r0.x, r0.y, r1.x);
+            const double bh = dot(oc, dir), cc = dot(oc, oc) - r1.y * r1.y;
+            // (outside the sphere and moving away from its centre: both roots negative)
+            maybe |= ((mask >> (gs & 0xff)) & 1) && (int)(gs >> 8) != skip && bh * bh - cc >= 0 && (bh < 0 || cc < 0);
+          } else {
+            int p;
+            if (IN_LDS) p = (int)lds32[2 * item_off + first + k]; else p = (int)reinterpret_cast<const uint32_t*>(GD.items)[first + k];
+            // cheap test: the primitive's bounding box (tolerance slack included) against the ray up to the cut
+            cf64 hdr = sv.prim_hdr + 8 * (size_t)p;
+            ci32 hi = (ci32)(hdr + 6);
+            const d3 oi = mk(point.x * ivx, point.y * ivy, point.z * ivz);
+            maybe |= ((mask >> hi[1]) & 1) && (hi[2] >> ODW_SOLID_SHIFT) != skip &&
+                     ray_box(hdr, oi, mk(ivx, ivy, ivz), fmin(q.tmax, q.any.t + 2.0 * q.tol));
+          }
+        }
+        if (maybe) {
+          walking = false;                                 // resolve this cell's primitives in phase D
+          pending = true;
+        } else {
+          ODW_WALK_ADVANCE();
+        }
+      }
+    }
+    // ---- D: resolution and interaction of the lanes whose walk has stopped -----------------------------
+    ODW_GSTAT(3, __ballot(alive && !walking && !fresh));
+    if (alive && !walking && !fresh) {
+      if (pending) {
+        // the exact tests of the cell the walk stands in (every primitive listed there), then on or stop
+        pending = false;
+        ODW_GSTAT(4, __ballot(1));
+        const int ix = cell & 0xff, iy = (cell >> 8) & 0xff, iz = cell >> 16;
+        const int ci = ix + nx * (iy + ny * iz);
+        uint32_t word;
+        if (IN_LDS) word = lds32[cell_off + ci]; else word = GD.cells[ci];
         const uint32_t first = word & 0xffffffu, count = word >> 24;
         for (uint32_t k = 0; k < count; ++k) {
           if (SPHERES) {
-            const double2* rec = reinterpret_cast<const double2*>(reinterpret_cast<const double*>(G.items) + 6 * (size_t)(first + k));
-            const double2 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+            double2 r0, r1, r2;
+            if (IN_LDS) {
+              const double2* rec = reinterpret_cast<const double2*>(grid_lds + item_off) + 3 * (size_t)(first + k);
+              r0 = rec[0]; r1 = rec[1]; r2 = rec[2];
+            } else {
+              const double2* rec = reinterpret_cast<const double2*>(GD.items) + 3 * (size_t)(first + k);
+              r0 = rec[0]; r1 = rec[1]; r2 = rec[2];
+            }
             const uint64_t bits = (uint64_t)__double_as_longlong(r2.x);
             const int prim = (int)(uint32_t)bits, gs = (int)(uint32_t)(bits >> 32);
             const int g = gs & 0xff;
             if (((mask >> g) & 1) && (gs >> 8) != skip) {
               // a sphere needs no frame (as in intersect_prim): centre in global coordinates
-              const d3 oc = q.start - mk(r0.x, r0.y, r1.x);
+              const d3 oc = point - mk(r0.x, r0.y, r1.x);
               double ta, tb;
-              if (quad_roots_unit(dot(oc, q.dn), dot(oc, oc) - r1.y * r1.y, ta, tb) == 2) {
+              if (quad_roots_unit(dot(oc, dir), dot(oc, oc) - r1.y * r1.y, ta, tb) == 2) {
                 const double bt = ta > q.tol ? ta : (tb > q.tol ? tb : INFINITY);
                 consider(sv, q, bt, prim, 0, g, 0, 0);
               }
             }
           } else {
-            const int p = (int)reinterpret_cast<const uint32_t*>(G.items)[first + k];
+            int p;
+            if (IN_LDS) p = (int)lds32[2 * item_off + first + k]; else p = (int)reinterpret_cast<const uint32_t*>(GD.items)[first + k];
             ci32 pi = sv.prim_i32 + 4 * p;
             const int g = pi[1];
             if (((mask >> g) & 1) && (pi[2] >> ODW_SOLID_SHIFT) != skip) intersect_prim(sv, q, p, pi[0], g, pi[2], pi[3]);
           }
         }
-        // candidates beyond nearest + 2 distTol can never be selected (ray.py:432, 440): the walk
-        // ends when the cell it would enter next begins beyond that
-        const double t_exit = fmin(w.tx, fmin(w.ty, w.tz));
-        const double cut = fmin(q.tmax, q.any.t + 2.0 * q.tol);
-        if (!(t_exit <= cut) || !walk_advance(G, q.start, q.dn, w)) walking = false;
+        ODW_WALK_ADVANCE();
       }
-    }
-    // ---- D: interaction of the lanes whose walk has ended -------------------------------------------
-    if (alive && !walking && !fresh) {
-      if (q.any.prim == 0x7fffffff) {
-        ODW_GCOUNT(ODW_CNT_ESCAPED);
-        alive = false;
-      } else {
-        const bool use_oth = q.oth.prim != 0x7fffffff && q.oth.t < q.any.t + 2.0 * q.tol;
-        const double t_hit = use_oth ? q.oth.t : q.any.t;
-        const int face = use_oth ? q.oth.face : q.any.face;
-        const int prim = use_oth ? q.oth.prim : q.any.prim;
-        cf64 pf = sv.prim_f64 + (size_t)prim * 16;
-        ci32 pi = sv.prim_i32 + 4 * prim;
-        point = point + dir * t_hit;
-        if (medium >= 0) {                                  // ray.py:120-125 (assignment)
-          const double L = group_f64[4 * medium + 2];
-          if (L == 0) power = 0;
-          else if (L < INFINITY) power = exp(-t_hit / L);
-        }
-        d3 n = face_normal(pi[0], pf + 12, face, xf_point(pf, point));
-        if (pi[2] & ODW_FLAG_FLIP_NORMAL) n = n * -1.0;
-        n = xf_vec_t(pf, n);
-        const bool entering = dot(dir, n) < 0;
-        if (entering) n = n * -1.0;
-        const int g = pi[1];
-        const int gtype = group_i32[4 * g];
-        if (group_i32[4 * g + 1]) {
-          ODW_GCOUNT(ODW_CNT_RECORDED_HITS);
-          record_hit<true, 1, true>(P, P.first_ray + i, g, point, dir, power, entering, wave_cnt, hit_state);
-        }
-        if (gtype == ODW_OPT_MIRROR) {
-          dir = mirror(dir, n);
-          power *= group_f64[4 * g + 1];
-          ++seq;
-        } else if (gtype == ODW_OPT_LENS) {
-          const double n1 = (medium >= 0) ? group_f64[4 * medium] : 1.0;
-          double n2 = 1.0;
-          if (entering) { medium = g; n2 = group_f64[4 * g]; }
-          bool tir;
-          dir = snells_law(dir, n1, n2, n, tir);
-          if (!entering && !tir && medium == g) { medium = -1; ++seq; }
-        } else if (gtype == ODW_OPT_ABSORBER) {
-          power = 0;
-          ++seq;
-        } else if (gtype == ODW_OPT_VACUUM) {
-          ++seq;
-        } else {  // grating (ray.py:216-268)
-          const d3 gd = mk(group_gdir[3 * g], group_gdir[3 * g + 1], group_gdir[3 * g + 2]);
-          const double lpm = group_f64[4 * g + 3];
-          const int order = group_i32[4 * g + 3];
-          if (group_i32[4 * g + 2] == 0) {
-            if (entering) {
-              const double nn = (medium >= 0) ? group_f64[4 * medium] : 1.0;
-              dir = line_grating(dir, nn, nn, n, P.wavelength, order, lpm, gd, false);
-              ++seq;
-            }
-          } else if (entering) {
-            if (medium >= 0) {
-              atomicAdd(P.out.counters + ODW_CNT_GRATING_IN_MEDIUM, 1ull);     // a ValueError of the reference
-              ODW_GCOUNT(ODW_CNT_DIED);
-              alive = false;
-            }
-            medium = g;
-            dir = line_grating(dir, 1.0, group_f64[4 * g], n, P.wavelength, order, lpm, gd, true);
-          } else {
-            const double n1 = (medium >= 0) ? group_f64[4 * medium] : 1.0;
-            bool tir;
-            dir = snells_law(dir, n1, 1.0, n, tir);
-            if (!tir) { medium = -1; ++seq; }
+      if (!walking) {
+        ODW_GSTAT(5, __ballot(1));
+        if (q.any.prim == 0x7fffffff) {
+          ODW_GCOUNT(ODW_CNT_ESCAPED);
+          alive = false;
+        } else {
+          const bool use_oth = q.oth.prim != 0x7fffffff && q.oth.t < q.any.t + 2.0 * q.tol;
+          const double t_hit = use_oth ? q.oth.t : q.any.t;
+          const int face = use_oth ? q.oth.face : q.any.face;
+          const int prim = use_oth ? q.oth.prim : q.any.prim;
+          cf64 pf = sv.prim_f64 + (size_t)prim * 16;
+          ci32 pi = sv.prim_i32 + 4 * prim;
+          point = point + dir * t_hit;
+          if (medium >= 0) {                                  // ray.py:120-125 (assignment)
+            const double L = group_f64[4 * medium + 2];
+            if (L == 0) power = 0;
+            else if (L < INFINITY) power = exp(-t_hit / L);
           }
+          d3 n;
+          if (SPHERES) {
+            // a sphere's outward normal needs no frame either: (point - centre) / |.|, centre in global
+            // coordinates (prim_f64 row: 12 = R, 13..15 = centre, as in intersect_prim)
+            const d3 v = point - mk(pf[13], pf[14], pf[15]);
+            n = v * frsqrt(dot(v, v));
+            if (pi[2] & ODW_FLAG_FLIP_NORMAL) n = n * -1.0;
+          } else {
+            n = face_normal(pi[0], pf + 12, face, xf_point(pf, point));
+            if (pi[2] & ODW_FLAG_FLIP_NORMAL) n = n * -1.0;
+            n = xf_vec_t(pf, n);
+          }
+          const bool entering = dot(dir, n) < 0;
+          if (entering) n = n * -1.0;
+          const int g = pi[1];
+          const int gtype = group_i32[4 * g];
+          if (group_i32[4 * g + 1]) {
+            ODW_GCOUNT(ODW_CNT_RECORDED_HITS);
+            record_hit<true, 1, true>(P, P.first_ray + i, g, point, dir, power, entering, wave_cnt, hit_state);
+          }
+          if (gtype == ODW_OPT_MIRROR) {
+            dir = mirror(dir, n);
+            power *= group_f64[4 * g + 1];
+            ++seq;
+          } else if (gtype == ODW_OPT_LENS) {
+            const double n1 = (medium >= 0) ? group_f64[4 * medium] : 1.0;
+            double n2 = 1.0;
+            if (entering) { medium = g; n2 = group_f64[4 * g]; }
+            bool tir;
+            dir = snells_law(dir, n1, n2, n, tir);
+            if (!entering && !tir && medium == g) { medium = -1; ++seq; }
+          } else if (gtype == ODW_OPT_ABSORBER) {
+            power = 0;
+            ++seq;
+          } else if (gtype == ODW_OPT_VACUUM) {
+            ++seq;
+          } else {  // grating (ray.py:216-268)
+            const d3 gd = mk(group_gdir[3 * g], group_gdir[3 * g + 1], group_gdir[3 * g + 2]);
+            const double lpm = group_f64[4 * g + 3];
+            const int order = group_i32[4 * g + 3];
+            if (group_i32[4 * g + 2] == 0) {
+              if (entering) {
+                const double nn = (medium >= 0) ? group_f64[4 * medium] : 1.0;
+                dir = line_grating(dir, nn, nn, n, P.wavelength, order, lpm, gd, false);
+                ++seq;
+              }
+            } else if (entering) {
+              if (medium >= 0) {
+                atomicAdd(P.out.counters + ODW_CNT_GRATING_IN_MEDIUM, 1ull);     // a ValueError of the reference
+                ODW_GCOUNT(ODW_CNT_DIED);
+                alive = false;
+              }
+              medium = g;
+              dir = line_grating(dir, 1.0, group_f64[4 * g], n, P.wavelength, order, lpm, gd, true);
+            } else {
+              const double n1 = (medium >= 0) ? group_f64[4 * medium] : 1.0;
+              bool tir;
+              dir = snells_law(dir, n1, 1.0, n, tir);
+              if (!tir) { medium = -1; ++seq; }
+            }
+          }
+          skip = ((pi[2] & ODW_FLAG_CONVEX) && (entering ? -dot(dir, n) : dot(dir, n)) > 0) ? (pi[2] >> ODW_SOLID_SHIFT) : -1;
+          if (alive && power < lim.power_tol) { ODW_GCOUNT(ODW_CNT_DIED); alive = false; }
+          fresh = alive;
         }
-        skip = ((pi[2] & ODW_FLAG_CONVEX) && (entering ? -dot(dir, n) : dot(dir, n)) > 0) ? (pi[2] >> ODW_SOLID_SHIFT) : -1;
-        if (alive && power < lim.power_tol) { ODW_GCOUNT(ODW_CNT_DIED); alive = false; }
-        fresh = alive;
-      }
-      if (!alive) {
-        atomicAdd(&wave_cnt[ODW_CNT_SEGMENTS], (uint32_t)nint);
-        ODW_GCOUNT(ODW_CNT_TRACED_RAYS);
+        if (!alive) {
+          atomicAdd(&wave_cnt[ODW_CNT_SEGMENTS], (uint32_t)nint);
+          ODW_GCOUNT(ODW_CNT_TRACED_RAYS);
+        }
       }
     }
   }
+#undef ODW_WALK_ADVANCE
   // slots of the last block this wave never filled (as in odw_trace_kernel)
   const uint32_t hit_used = hit_state[2];
   const uint64_t hit_base = ((uint64_t)hit_state[1] << 32) | hit_state[0];
@@ -358,6 +486,9 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
     const uint64_t in_buf = at < P.out.hit_capacity ? (P.out.hit_capacity - at < left ? P.out.hit_capacity - at : left) : 0;
     if (__lane_id() == 0 && in_buf) atomicAdd(P.out.hit_count + 1, (unsigned long long)in_buf);
   }
+#ifdef ODW_GRID_STATS
+  if (lane < 12 && P.dbg) atomicAdd(P.dbg + lane, (unsigned long long)wave_cnt[8 + lane]);
+#endif
   if (lane < ODW_CNT_LDS) {
     const uint32_t s = wave_cnt[lane];
     if (s) atomicAdd(P.out.counters + lane, (unsigned long long)s);

@@ -1,15 +1,20 @@
 #!/usr/bin/env python3
 """Collect the round's profile evidence on the GPU box (run from the repo root):
 
-  python scripts/profile_round.py v8
+  python scripts/profile_round.py r02_c3 [--config c3|c4] [--no-bench]
 
-1. `python bench.py`                                         -> gpurun_out/<tag>_bench.json
-2. `rocprofv3 --kernel-trace --stats -- python3 bench.py`     -> <tag>_kernel_stats.csv
-3. `rocprofv3 --pmc <set> --kernel-trace -- python3 bench.py` -> <tag>_pmc.json, one run per counter set
-   (FETCH_SIZE and WRITE_SIZE alone, as MI355X_MICROARCH.md prescribes)
-rocprofv3 writes SQLite databases; the summaries are read from their views.
+1. `python bench.py --config C`                                      -> gpurun_out/<tag>_bench.json
+2. `rocprofv3 --kernel-trace --stats -- python3 bench.py --config C` -> <tag>_kernel_stats.csv
+3. `rocprofv3 --pmc <set> --kernel-trace -- python3 bench.py ...`    -> <tag>_pmc.json, one run per counter set
+   (FETCH_SIZE and WRITE_SIZE alone, as MI355X_MICROARCH.md prescribes; no trace domains besides
+   --kernel-trace next to --pmc)
+rocprofv3 writes SQLite databases; the summaries are read from their views.  Also writes
+gpurun_out/<tag>_pmc_current.json = the entry of profiles/pmc_current.json for this config
+(HBM bytes per launch with the gfx950 correction, VALU figures).
 """
+import argparse
 import glob
+import shutil
 import json
 import os
 import sqlite3
@@ -17,11 +22,18 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else 'vX'
+ap = argparse.ArgumentParser()
+ap.add_argument('tag')
+ap.add_argument('--config', default='c3')
+ap.add_argument('--no-bench', action='store_true')
+args = ap.parse_args()
+tag = args.tag
+KERNEL_LIKE = {'c3': '%odw_trace_kernel<false, false, false>%', 'c4': '%odw_grid_kernel%'}[args.config]
 out = os.path.join(ROOT, 'gpurun_out')
 os.makedirs(out, exist_ok=True)
 env = dict(os.environ, TMPDIR='/tmp')
-BENCH = ['python3', os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '1', '--no-cpu-baseline']
+BENCH = ['python3', os.path.join(ROOT, 'bench.py'), '--config', args.config, '--steps', '3', '--warmup', '1',
+         '--no-cpu-baseline', '--no-end-to-end']
 
 
 def run(cmd, log):
@@ -42,10 +54,12 @@ def tables(con):
 
 
 # 1. the bench line
-res = subprocess.run(['python3', os.path.join(ROOT, 'bench.py')], cwd=ROOT, env=env, capture_output=True, text=True, check=True)
-line = [l for l in res.stdout.splitlines() if l.startswith('{')][-1]
-open(os.path.join(out, f'{tag}_bench.json'), 'w').write(line + '\n')
-print(line[:200], flush=True)
+if not args.no_bench:
+  res = subprocess.run(['python3', os.path.join(ROOT, 'bench.py'), '--config', args.config], cwd=ROOT, env=env,
+                       capture_output=True, text=True, check=True)
+  line = [l for l in res.stdout.splitlines() if l.startswith('{')][-1]
+  open(os.path.join(out, f'{tag}_bench.json'), 'w').write(line + '\n')
+  print(line[:200], flush=True)
 
 # 2. kernel trace
 d = os.path.join(out, f'{tag}_trace')
@@ -59,14 +73,33 @@ with open(os.path.join(out, f'{tag}_kernel_stats.csv'), 'w') as f:
   for r in rows:
     f.write(','.join(str(x) for x in r) + '\n')
 print(open(os.path.join(out, f'{tag}_kernel_stats.csv')).read()[:600], flush=True)
+con.close()
+shutil.rmtree(d, ignore_errors=True)        # the raw databases are large; gpurun copies back <= 64 MiB
+kernel_ms = None
+if rows and cols:
+  ci = {c.lower(): k for k, c in enumerate(cols)}
+  for r in rows:
+    nm = str(r[ci.get('name', 0)])
+    if ('odw_grid_kernel' in nm) if args.config == 'c4' else ('odw_trace_kernel<false, false, false>' in nm):
+      for key in ('average', 'avg', 'averagens', 'average_ns'):
+        if key in ci:
+          kernel_ms = float(r[ci[key]]) / 1e3          # the view reports microseconds
+          break
 
 # 3. counters, one set per run
 sets = [['FETCH_SIZE'], ['WRITE_SIZE'], ['SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_SMEM', 'SQ_WAVE_CYCLES'],
-        ['SQ_BUSY_CYCLES', 'SQ_ACTIVE_INST_ANY', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY']]
+        ['SQ_BUSY_CYCLES', 'SQ_ACTIVE_INST_ANY', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY'],
+        ['SQ_ACTIVE_INST_VALU', 'SQ_THREAD_CYCLES_VALU', 'SQ_INSTS_LDS', 'SQ_ACTIVE_INST_LDS'],
+        ['SQ_INSTS_VALU_FMA_F64', 'SQ_INSTS_VALU_MUL_F64', 'SQ_INSTS_VALU_ADD_F64', 'SQ_INSTS_VALU_TRANS_F64'],
+        ['GRBM_GUI_ACTIVE', 'SQ_LDS_BANK_CONFLICT', 'SQ_LDS_IDX_ACTIVE', 'SQ_INSTS_VMEM']]
 avg = {}
 for k, cs in enumerate(sets):
   d = os.path.join(out, f'{tag}_pmc{k}')
-  run(['rocprofv3', '--pmc'] + cs + ['--kernel-trace', '-d', d, '--'] + BENCH, f'{tag}_pmc{k}.log')
+  try:
+    run(['rocprofv3', '--pmc'] + cs + ['--kernel-trace', '-d', d, '--'] + BENCH, f'{tag}_pmc{k}.log')
+  except subprocess.CalledProcessError as e:
+    print('counter set failed:', cs, e, flush=True)
+    continue
   con = db_of(d)
   view = [t for t in tables(con) if t.startswith('counters_collection')]
   cols = [c[1] for c in con.execute(f'pragma table_info({view[0]})')]
@@ -76,16 +109,39 @@ for k, cs in enumerate(sets):
   if not (kcol and ncol and vcol):
     raise SystemExit(f'unexpected columns in {view[0]}: {cols}')
   q = (f'select {ncol[0]}, avg({vcol[0]}), count(*) from {view[0]} '
-       f"where {kcol[0]} like '%odw_trace_kernel%' group by {ncol[0]}")
+       f"where {kcol[0]} like '{KERNEL_LIKE}' group by {ncol[0]}")
   for cname, value, count in con.execute(q):
     avg[cname] = value
     print(cname, value, f'({count} dispatches)', flush=True)
+  con.close()
+  shutil.rmtree(d, ignore_errors=True)
 fetch_raw = avg.get('FETCH_SIZE', 0.0) * 1024          # the counters are in KiB
 write = avg.get('WRITE_SIZE', 0.0) * 1024
-summary = dict(command='rocprofv3 --pmc <COUNTERS> --kernel-trace -- python3 bench.py --steps 3 --warmup 1 '
-                       '--no-cpu-baseline (one counter set per run)',
-               kernel='odw::odw_trace_kernel<false, false, false>', rays_per_launch=100000000,
+line = json.loads(open(os.path.join(out, f'{tag}_bench.json')).read()) if os.path.exists(os.path.join(out, f'{tag}_bench.json')) else {}
+n_per = line.get('config', {}).get('rays_per_step_per_gpu')
+summary = dict(command='rocprofv3 --pmc <COUNTERS> --kernel-trace -- ' + ' '.join(BENCH[:1] + ['bench.py'] + BENCH[2:]) +
+                       ' (one counter set per run)',
+               kernel=KERNEL_LIKE.strip('%'), rays_per_launch=n_per,
                counters_avg_per_dispatch=avg, fetch_bytes_raw=fetch_raw, fetch_bytes_corrected=2 * fetch_raw,
-               write_bytes=write, hbm_bytes_per_launch=2 * fetch_raw + write)
+               write_bytes=write, hbm_bytes_per_launch=2 * fetch_raw + write, kernel_ms_rocprof=kernel_ms)
 json.dump(summary, open(os.path.join(out, f'{tag}_pmc.json'), 'w'), indent=1)
-print(json.dumps(summary)[:400])
+ms = kernel_ms or line.get('roofline', {}).get('avg_kernel_ms')
+valu = None
+if 'SQ_INSTS_VALU' in avg and ms:
+  valu = dict(insts_per_launch=avg['SQ_INSTS_VALU'], salu_insts_per_launch=avg.get('SQ_INSTS_SALU'),
+              util=avg['SQ_INSTS_VALU'] * 4 / (1024 * ms * 1e-3 * 2.4e9),
+              definition='SQ_INSTS_VALU (wave-instructions) x 4 issue cycles / (1024 SIMDs x kernel time x 2.4 GHz)',
+              kernel_ms_profiled=ms, source=f'profiles/r02/{tag}_pmc.json, profiles/r02/{tag}_kernel_stats.csv')
+  if avg.get('SQ_THREAD_CYCLES_VALU') and avg.get('SQ_ACTIVE_INST_VALU'):
+    # lanes doing work per issued VALU instruction (64 = every lane)
+    valu['active_lanes_per_inst'] = avg['SQ_THREAD_CYCLES_VALU'] / (avg['SQ_ACTIVE_INST_VALU'] * 4) if avg['SQ_ACTIVE_INST_VALU'] else None
+  if avg.get('GRBM_GUI_ACTIVE') and avg.get('SQ_ACTIVE_INST_VALU'):
+    valu['valu_busy'] = avg['SQ_ACTIVE_INST_VALU'] * 4 / 1024 / (avg['GRBM_GUI_ACTIVE'] / 8)
+    valu['valu_busy_definition'] = 'SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs)'
+entry = dict(kernel=KERNEL_LIKE.strip('%'), rays_per_launch=n_per, fetch_bytes_corrected=2 * fetch_raw, write_bytes=write,
+             hbm_bytes_per_launch=2 * fetch_raw + write,
+             correction='FETCH_SIZE x2 (gfx950 under-count of wide reads, MI355X_MICROARCH.md HBM section; upper bound for '
+                        'this access mix), WRITE_SIZE as is; separate --pmc passes',
+             source=f'profiles/r02/{tag}_pmc.json', valu=valu)
+json.dump({args.config: entry}, open(os.path.join(out, f'{tag}_pmc_current.json'), 'w'), indent=1)
+print(json.dumps(entry)[:600])
