@@ -216,6 +216,7 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
                 tr.traceRays(o[sel], d[sel], pw[sel], first=base + lo + int(sel[0]), record_segments=record_rays)
           tr.sync()
           cnt = tr.counters()
+          Tracer.raiseForRayErrors(cnt)
           if not cnt['hits_dropped']:
             break
           if capacity >= worst:

@@ -129,6 +129,7 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
         tr.trace(0, int(rays), seed, histogram=False)
         tr.sync()
         cnt = tr.counters()
+        Tracer.raiseForRayErrors(cnt)
         if not cnt['hits_dropped']:
           break
         capacity = int(cnt['recorded_hits'] * 1.05) + 1024      # deterministic: trace again with room

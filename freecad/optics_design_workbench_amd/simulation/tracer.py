@@ -162,6 +162,15 @@ class Tracer:
                                            C.c_int32(len(out))), 'odw_fetch_counters')
     return {k: int(v) for k, v in zip(CNT_NAMES, out)}
 
+  @staticmethod
+  def raiseForRayErrors(cnt):
+    """exceptions the reference raises from inside Ray.traceRay, turned into counters by the kernels:
+    a ray that enters a transmission grating while inside a medium (ray.py:234-237)"""
+    if cnt.get('grating_in_medium'):
+      raise ValueError('ray entered grating while already being inside a medium, get rid of any overlapping '
+                       'lenses/transmission gratings in your project '
+                       f'({cnt["grating_in_medium"]} ray(s) of this launch)')
+
   def hitCount(self):
     n = C.c_uint64(0)
     self._chk(self._lib.odw_hit_count(self._ctx, C.byref(n)), 'odw_hit_count')
