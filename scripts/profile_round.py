@@ -134,7 +134,13 @@ if 'SQ_INSTS_VALU' in avg and ms:
               kernel_ms_profiled=ms, source=f'profiles/r02/{tag}_pmc.json, profiles/r02/{tag}_kernel_stats.csv')
   if avg.get('SQ_THREAD_CYCLES_VALU') and avg.get('SQ_ACTIVE_INST_VALU'):
     # lanes doing work per issued VALU instruction (64 = every lane)
-    valu['active_lanes_per_inst'] = avg['SQ_THREAD_CYCLES_VALU'] / (avg['SQ_ACTIVE_INST_VALU'] * 4) if avg['SQ_ACTIVE_INST_VALU'] else None
+    valu['active_lanes_per_inst'] = avg['SQ_THREAD_CYCLES_VALU'] / avg['SQ_ACTIVE_INST_VALU']
+    valu['active_lanes_definition'] = 'SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU (64 = every lane of every VALU instruction does work)'
+  f64 = [avg.get(k) for k in ('SQ_INSTS_VALU_FMA_F64', 'SQ_INSTS_VALU_MUL_F64', 'SQ_INSTS_VALU_ADD_F64', 'SQ_INSTS_VALU_TRANS_F64')]
+  if all(v is not None for v in f64):
+    valu['f64_arith_insts'] = sum(f64)
+  if avg.get('SQ_WAIT_ANY') and avg.get('SQ_WAVE_CYCLES'):
+    valu['wait_any_frac'] = avg['SQ_WAIT_ANY'] / avg['SQ_WAVE_CYCLES']
   if avg.get('GRBM_GUI_ACTIVE') and avg.get('SQ_ACTIVE_INST_VALU'):
     valu['valu_busy'] = avg['SQ_ACTIVE_INST_VALU'] * 4 / 1024 / (avg['GRBM_GUI_ACTIVE'] / 8)
     valu['valu_busy_definition'] = 'SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs)'

@@ -133,7 +133,7 @@ def test_bench_under_a_launcher_with_one_rank_uses_rccl(native_lib):
 def test_bench_config_lines_c4_and_c5(native_lib):
   out = _line(_bench('--config', 'c4', '--steps', '2', '--warmup', '1', '--rays-per-step', '4e6', '--no-cpu-baseline'))
   assert out['config']['name'] == 'c4' and 'hugeArray' in out['metric'] and out['n_gpus'] == 1
-  assert 2.5 < out['config']['segments_per_ray'] < 3.2 and out['roofline']['kernel'].startswith('odw_trace_kernel<true')
+  assert 2.5 < out['config']['segments_per_ray'] < 3.2 and out['roofline']['kernel'].startswith('odw_grid_kernel')
   assert 0 < out['roofline']['frac'] < 1
   out = _line(_bench('--config', 'c5', '--radii', '6', '--rays-per-step', '2e5', '--no-cpu-baseline'))
   spot = out['config']['spot_size']
