@@ -1,0 +1,279 @@
+"""The bake against a second reading of the geometry.
+
+Oracle and device are compared with each other on the SAME baked tables, so an error in the bake
+itself -- a wrong trimming condition, a missing face, a normal that should have been flipped --
+cannot show in those tests.  Here the baked faces are held against `csg_reference` (membership
+straight from the boolean features, no faces involved):
+  A  every sampled point of a baked face that its trimming conditions keep lies on the boundary
+     of its solid, with the baked outward normal pointing out of it -- and every point they
+     reject does not;
+  B  along random chords, every hit the oracle reports (all groups 'Vacuum' and recording: the ray
+     passes straight through everything) is a change of membership of a solid of that group, and
+     every change of membership found by sampling the chord is reported as a hit.
+BASELINE scenes (only MultiCommon booleans) plus hand-built Cut / Fuse / Common trees."""
+import copy
+import os
+
+import numpy as np
+import pytest
+
+from conftest import SCENES
+from csg_reference import groupSolids
+
+from freecad.optics_design_workbench_amd.freecad_elements import make
+from freecad.optics_design_workbench_amd.scene import Document, Placement, bake, geometry, open_fcstd
+from freecad.optics_design_workbench_amd.scene.placement import from_axis_angle
+
+BOX, SPHERE, CYLINDER, CONE, TORUS = range(5)
+EPS = 1e-5          # probe distance along the normal
+MARGIN = 1e-3       # samples this close to a trimming surface are not judged
+
+
+def sdist(kind, par, q):
+  """signed distance-like function of a primitive in its frame (the trimming test's measure)"""
+  if kind == BOX:
+    return np.maximum.reduce([-q[:, 0], q[:, 0] - par[0], -q[:, 1], q[:, 1] - par[1], -q[:, 2], q[:, 2] - par[2]])
+  if kind == SPHERE:
+    return np.linalg.norm(q, axis=1) - par[0]
+  rho = np.hypot(q[:, 0], q[:, 1])
+  if kind == CYLINDER:
+    return np.maximum.reduce([rho - par[0], -q[:, 2], q[:, 2] - par[1]])
+  if kind == CONE:
+    k = (par[1] - par[0]) / par[2]
+    return np.maximum.reduce([(rho - (par[0] + k * q[:, 2])) / np.sqrt(1 + k * k), -q[:, 2], q[:, 2] - par[2]])
+  return np.hypot(rho - par[0], q[:, 2]) - par[1]
+
+
+def sample_face(kind, par, face, n, rs):
+  """n points on face `face` of the untrimmed primitive + outward unit normals, in its frame"""
+  # (kept a hair away from the face's own rim: there the probes along the normal leave the solid sideways)
+  u, v = rs.random_sample(n), 1e-4 + (1 - 2e-4) * rs.random_sample(n)
+  if kind == BOX:
+    u = 1e-4 + (1 - 2e-4) * u
+    a, s = face >> 1, face & 1
+    b1, b2 = (a + 1) % 3, (a + 2) % 3
+    p = np.zeros((n, 3))
+    p[:, a] = par[a] * s
+    p[:, b1], p[:, b2] = par[b1] * u, par[b2] * v
+    nr = np.zeros((n, 3))
+    nr[:, a] = 1.0 if s else -1.0
+    return p, nr
+  phi = 2 * np.pi * u
+  if kind == SPHERE:
+    z = 2 * v - 1
+    r = np.sqrt(1 - z * z)
+    nr = np.stack([r * np.cos(phi), r * np.sin(phi), z], axis=1)
+    return nr * par[0], nr
+  if kind == TORUS:
+    th = 2 * np.pi * v
+    nr = np.stack([np.cos(th) * np.cos(phi), np.cos(th) * np.sin(phi), np.sin(th)], axis=1)
+    rho = par[0] + par[1] * np.cos(th)
+    return np.stack([rho * np.cos(phi), rho * np.sin(phi), par[1] * np.sin(th)], axis=1), nr
+  r1, r2, h = (par[0], par[0], par[1]) if kind == CYLINDER else (par[0], par[1], par[2])
+  if face == 0:
+    z = h * v
+    k = (r2 - r1) / h
+    r = r1 + k * z
+    nr = np.stack([np.cos(phi), np.sin(phi), np.full(n, -k)], axis=1) / np.sqrt(1 + k * k)
+    return np.stack([r * np.cos(phi), r * np.sin(phi), z], axis=1), nr
+  rr = (r1 if face == 1 else r2) * np.sqrt(v) * (1 - 1e-4)
+  nr = np.zeros((n, 3))
+  nr[:, 2] = -1.0 if face == 1 else 1.0
+  return np.stack([rr * np.cos(phi), rr * np.sin(phi), np.full(n, 0.0 if face == 1 else h)], axis=1), nr
+
+
+def solid_table(doc, scene):
+  """baked solid id -> csg_reference.Solid (both enumerate groups, members and array elements in
+  document order)"""
+  ref = groupSolids(doc)
+  table = {}
+  for gi, name in enumerate(scene.group_names):
+    ids = sorted(set(int(s) for s, g in zip(scene.prim_solid, scene.prim_group) if g == gi))
+    assert len(ids) == len(ref[name]), (name, len(ids), len(ref[name]))
+    for sid, solid in zip(ids, ref[name]):
+      table[sid] = solid
+  return table
+
+
+def check_faces(doc, scene, n_per_face, seed=1, prims=None):
+  rs = np.random.RandomState(seed)
+  solids = solid_table(doc, scene)
+  judged = kept = 0
+  for p in (range(scene.n_prims) if prims is None else prims):
+    kind, par = int(scene.prim_type[p]), scene.prim_params[p]
+    tw = scene.prim_to_world[p]
+    R, t = tw.m[:3, :3], tw.m[:3, 3]
+    flags = int(scene.prim_flags[p])
+    flip = -1.0 if flags & 1 else 1.0
+    solid = solids[int(scene.prim_solid[p])]
+    for f in range(geometry.N_FACES[kind]):
+      lp, ln = sample_face(kind, par, f, n_per_face, rs)
+      wp, wn = lp @ R.T + t, (ln @ R.T) * flip
+      # the baked verdict: face exists (mask) and every trimming condition holds
+      ok = np.full(n_per_face, bool((flags >> (8 + f)) & 1))
+      clear = np.ones(n_per_face, dtype=bool)
+      for c in range(scene.prim_cond_off[p], scene.prim_cond_off[p + 1]):
+        o, want_inside = int(scene.cond_prim[c]), bool(scene.cond_inside[c])
+        m = np.linalg.inv(scene.prim_to_world[o].m)
+        sd = sdist(int(scene.prim_type[o]), scene.prim_params[o], wp @ m[:3, :3].T + m[:3, 3])
+        ok &= (sd <= 0) if want_inside else (sd >= 0)
+        clear &= np.abs(sd) > MARGIN
+      # the independent verdict: membership of the solid changes across the point, inside lies
+      # against the baked outward normal
+      inner, outer = solid.inside(wp - EPS * wn), solid.inside(wp + EPS * wn)
+      boundary = inner & ~outer
+      wrong_way = ~inner & outer
+      assert not np.any(clear & ok & wrong_way), (solid.name, p, f, 'outward normal points into the solid')
+      bad = clear & (ok != boundary)
+      assert not bad.any(), (solid.name, p, f, int(bad.sum()), wp[bad][:3].tolist(), ok[bad][:3].tolist())
+      judged += int(clear.sum())
+      kept += int((clear & ok).sum())
+  return judged, kept
+
+
+def transitions(solid, o, d, t_max, n=4001):
+  """ray parameters at which membership of `solid` changes (coarse sampling + bisection)"""
+  t = np.linspace(0, t_max, n)
+  inside = solid.inside(o + t[:, None] * d)
+  out = []
+  for k in np.flatnonzero(inside[1:] != inside[:-1]):
+    lo, hi, a = t[k], t[k + 1], inside[k]
+    for _ in range(60):
+      mid = 0.5 * (lo + hi)
+      if solid.inside(o + mid * d)[0] == a:
+        lo = mid
+      else:
+        hi = mid
+    out.append(0.5 * (lo + hi))
+  return out
+
+
+def check_chords(doc, scene, lim, oracle, n_rays, seed=2, reach=None):
+  rs = np.random.RandomState(seed)
+  ref = groupSolids(doc)
+  sc = copy.copy(scene)
+  sc.group_type = np.full_like(scene.group_type, 4)              # Vacuum: straight through
+  sc.group_record = np.ones_like(scene.group_record)
+  sc.seq_enabled, sc.ignore_mask = 0, 0
+  sc.surface_samplers = []
+  lo = np.min([scene.prim_to_world[p] * np.zeros(3) for p in range(scene.n_prims)], axis=0) - 15
+  hi = np.max([scene.prim_to_world[p] * np.zeros(3) for p in range(scene.n_prims)], axis=0) + 15
+  centre, radius = (lo + hi) / 2, np.linalg.norm(hi - lo) / 2
+  d = rs.normal(size=(n_rays, 3))
+  d /= np.linalg.norm(d, axis=1)[:, None]
+  aim = centre + (rs.random_sample((n_rays, 3)) - 0.5) * (hi - lo) * 0.8
+  o = aim - d * radius * 1.5
+  t_max = 3.0 * radius
+  L = copy.copy(lim)
+  L.max_ray_length, L.max_intersections = t_max, 1000
+  r = oracle.trace_rays(sc, L, o, d, nthreads=0)
+  assert r['counters']['capped'] == 0
+  tags, pts = r['hits']['tag'], r['hits']['point']
+  ray = (tags & np.uint64(0xFFFFFFFFFFFF)).astype(np.int64)
+  grp = ((tags >> np.uint64(48)) & np.uint64(0x7FFF)).astype(np.int64)
+  checked = 0
+  for k in range(n_rays):
+    sel = ray == k
+    t_hit = np.linalg.norm(pts[sel] - o[k], axis=1)
+    for gi, name in enumerate(scene.group_names):
+      th = np.sort(t_hit[grp[sel] == gi])
+      # every reported hit is a change of membership of one of the group's solids ...
+      for t in th:
+        a, b = o[k] + (t - 1e-5) * d[k], o[k] + (t + 1e-5) * d[k]
+        assert any(s.inside(a)[0] != s.inside(b)[0] for s in ref[name]), (name, k, float(t))
+      # ... and every change found by sampling is reported (closer pairs than the sampling step
+      # escape the sampling, not the bake: they are only checked in the direction above)
+      if reach is not None and len(ref[name]) > reach:
+        continue
+      for s in ref[name]:
+        for t in transitions(s, o[k], d[k], t_max):
+          if len(th) == 0 or np.abs(th - t).min() > 1e-6:
+            # grazing chords: a pair of transitions closer than distTol is rightly one (or no) hit
+            near = [u for u in transitions(s, o[k], d[k], t_max, n=40001) if abs(u - t) < 1e-4 and u != t]
+            assert near, (s.name, k, float(t), th.tolist())
+          checked += 1
+  return checked
+
+
+def _doc(path):
+  doc = open_fcstd(os.path.join(SCENES, path + '.FCStd'))
+  src = bake.lightSources(doc)[0]
+  return doc, bake.bakeScene(doc, src), bake.bakeLimits(doc, src)
+
+
+@pytest.mark.parametrize('name', ['minimal', 'GettingStarted', 'lensesAndMirrors', 'lensesAndMirrorsSequential'])
+def test_baseline_scene_faces_and_chords(oracle, name):
+  doc, scene, lim = _doc(name)
+  judged, kept = check_faces(doc, scene, 100_000 // 4 if name != 'minimal' else 20_000)
+  assert kept > 0.2 * judged > 0
+  assert check_chords(doc, scene, lim, oracle, 300) > 100
+
+
+def test_huge_array_faces_and_chords(oracle):
+  doc, scene, lim = _doc('hugeArray')
+  assert scene.n_prims == 1500
+  judged, kept = check_faces(doc, scene, 400)
+  assert judged == kept == 1500 * 400                   # untrimmed spheres: every sample is boundary
+  # chords: hits -> membership for all 1500 spheres; membership -> hits for a sample of them
+  rs = np.random.RandomState(5)
+  sub = copy.copy(scene)
+  assert check_chords(doc, scene, lim, oracle, 40, reach=0) == 0
+  ref = groupSolids(doc)
+  pick = {g: [ref[g][i] for i in rs.choice(len(ref[g]), 6, replace=False)] for g in ref}
+  L = copy.copy(lim)
+  for g, solids in pick.items():
+    for s in solids:
+      # a chord aimed at the sphere's centre region must report its two crossings
+      c = np.array([[x, y, z] for x in np.linspace(-30, 30, 61) for y in (-23.0, 2.0, 22.0) for z in np.linspace(-2, 72, 38)])
+      inside = c[s.inside(c)]
+      if not len(inside):
+        continue
+      d = rs.normal(size=3)
+      d /= np.linalg.norm(d)
+      o = inside[0] - 200 * d
+      sc = copy.copy(scene)
+      sc.group_type = np.full_like(scene.group_type, 4)
+      sc.group_record = np.ones_like(scene.group_record)
+      L.max_ray_length, L.max_intersections = 400.0, 1000
+      r = oracle.trace_rays(sc, L, [o], [d], nthreads=0)
+      t_hit = np.linalg.norm(r['hits']['point'] - o, axis=1)
+      for t in transitions(s, o, d, 400.0, n=40001):
+        assert np.abs(t_hit - t).min() < 1e-6, (s.name, float(t))
+
+
+def _built(groups):
+  doc = Document()
+  for kind, elems, props in groups:
+    make.makeOpticalGroup(doc, kind, elems(doc), **props)
+  make.makeSimulationSettings(doc)
+  src = make.makePointSource(doc)
+  return doc, bake.bakeScene(doc, src), bake.bakeLimits(doc, src)
+
+
+def _rot(axis, deg, base=(0, 0, 0)):
+  pl = Placement(base=base)
+  return pl.withRotation(axis, np.radians(deg))
+
+
+def test_cut_fuse_common_trees(oracle):
+  """booleans the BASELINE scenes do not contain: Cut (flipped tool normals), Fuse (faces inside
+  the other operand vanish), nested Common / Cut, rotated operands, a torus tool"""
+  def plano_concave(d):
+    return [make.makeCut(d, make.makeCylinder(d, 'Cy', 6, 4), make.makeSphere(d, 'Sp', 8, placement=Placement(base=(0, 0, 10))), 'PC')]
+
+  def capsule(d):
+    return [make.makeFuse(d, [make.makeCylinder(d, 'Cy2', 3, 10, placement=_rot((1, 0, 0), 30, (20, 0, 0))),
+                              make.makeSphere(d, 'Sp2', 4, placement=Placement(base=(20, -2, 4)))], 'Cap')]
+
+  def notched(d):
+    inner = make.makeCommon(d, [make.makeBox(d, 'B3', 10, 10, 10, placement=Placement(base=(-30, -5, 0))),
+                                make.makeSphere(d, 'Sp3', 7, placement=Placement(base=(-25, 0, 5)))], 'In')
+    return [make.makeCut(d, inner, make.makeTorus(d, 'T3', 5, 1.5, placement=_rot((0, 1, 0), 20, (-25, 0, 5))), 'Notch')]
+
+  def cone_cut(d):
+    return [make.makeCut(d, make.makeCone(d, 'Co', 5, 2, 8, placement=Placement(base=(0, 25, 0))),
+                         make.makeBox(d, 'B4', 4, 20, 3, placement=_rot((0, 0, 1), 15, (-2, 18, 2))), 'CC')]
+  doc, scene, lim = _built([('Lens', plano_concave, {}), ('Mirror', capsule, {}), ('Lens', notched, dict(name='OpticalLensGroup2')), ('Absorber', cone_cut, {})])
+  judged, kept = check_faces(doc, scene, 20_000)
+  assert kept > 0.1 * judged > 0
+  assert check_chords(doc, scene, lim, oracle, 800) > 200
