@@ -161,7 +161,12 @@ def check_chords(doc, scene, lim, oracle, n_rays, seed=2, reach=None):
   centre, radius = (lo + hi) / 2, np.linalg.norm(hi - lo) / 2
   d = rs.normal(size=(n_rays, 3))
   d /= np.linalg.norm(d, axis=1)[:, None]
-  aim = centre + (rs.random_sample((n_rays, 3)) - 0.5) * (hi - lo) * 0.8
+  # aimed at the primitives (a chord through the scene's box rarely meets a 4 mm lens)
+  which = rs.randint(0, scene.n_prims, n_rays)
+  aim = np.empty((n_rays, 3))
+  for k, p in enumerate(which):
+    blo, bhi = geometry.local_bounds(int(scene.prim_type[p]), scene.prim_params[p])
+    aim[k] = scene.prim_to_world[p] * (blo + (bhi - blo) * (0.5 + 0.6 * (rs.random_sample(3) - 0.5)))
   o = aim - d * radius * 1.5
   t_max = 3.0 * radius
   L = copy.copy(lim)
