@@ -157,6 +157,11 @@ void local_bounds(int type, const double* par, double lo[3], double hi[3]) {
       lo[0] = lo[1] = -r; hi[0] = hi[1] = r; lo[2] = 0; hi[2] = par[2];
       break;
     }
+    case ODW_PRIM_PARABOLOID: {
+      const double r = 2.0 * std::sqrt(std::max(par[0] * par[1], 0.0));
+      lo[0] = lo[1] = -r; hi[0] = hi[1] = r; lo[2] = 0; hi[2] = par[1];
+      break;
+    }
     default: {
       const double r = par[0] + par[1];
       lo[0] = lo[1] = -r; hi[0] = hi[1] = r; lo[2] = -par[1]; hi[2] = par[1];
@@ -575,10 +580,14 @@ int build_bvh(odw_ctx* ctx) {
     ctx->P.scene.prim_hdr = (const double*)ctx->prim_hdr.p;
   }
   static const int bvh_threshold = [] { const char* e = getenv("ODW_BVH_THRESHOLD"); return e ? atoi(e) : kBvhThreshold; }();
-  bool has_triangles = false;
-  for (int p = 0; p < n && !has_triangles; ++p) has_triangles = ctx->h_prim_i32[4 * p] == ODW_PRIM_TRIANGLE;
+  bool has_triangles = false, has_paraboloids = false;
+  for (int p = 0; p < n; ++p) {
+    has_triangles |= ctx->h_prim_i32[4 * p] == ODW_PRIM_TRIANGLE;
+    has_paraboloids |= ctx->h_prim_i32[4 * p] == ODW_PRIM_PARABOLOID;
+  }
   std::memset(&ctx->P.grid, 0, sizeof ctx->P.grid);
-  if (n <= bvh_threshold && !has_triangles) return ODW_OK;   // triangles are only known to the BVH kernels
+  // (triangles are only known to the BVH kernels, paraboloids to the BVH and grid kernels)
+  if (n <= bvh_threshold && !has_triangles && !has_paraboloids) return ODW_OK;
   if (!has_triangles) {
     int rc = build_grid(ctx, boxes, dead);
     if (rc) return rc;
@@ -889,7 +898,7 @@ int odw_upload_scene(odw_ctx* ctx, const odw_scene_desc* s) {
   ctx->h_prim_i32.assign((size_t)n * 4, 0);
   for (int p = 0; p < n; ++p) {
     const int type = s->prim_type[p], group = s->prim_group[p];
-    if (type < ODW_PRIM_BOX || type > ODW_PRIM_TRIANGLE) return fail(ctx, ODW_ERR_UNSUPPORTED, "unknown primitive type");
+    if (type < ODW_PRIM_BOX || type > ODW_PRIM_PARABOLOID) return fail(ctx, ODW_ERR_UNSUPPORTED, "unknown primitive type");
     if (group < 0 || group >= s->n_groups) return fail(ctx, ODW_ERR_INVALID, "primitive group out of range");
     const int off = s->prim_cond_off[p], cnt = s->prim_cond_off[p + 1] - off;
     if (off < 0 || cnt < 0 || cnt > 255 || off + cnt > s->n_conds)
@@ -924,6 +933,11 @@ int odw_upload_scene(odw_ctx* ctx, const odw_scene_desc* s) {
         const double* m = &ctx->h_prim_f64[16 * (size_t)p];
         for (int k = 0; k < 3; ++k)
           ctx->h_prim_f64[16 * (size_t)p + 13 + k] = -(m[k] * m[3] + m[4 + k] * m[7] + m[8 + k] * m[11]);
+      }
+      if (type == ODW_PRIM_PARABOLOID) {
+        double* par = &ctx->h_prim_f64[16 * (size_t)p + 12];
+        if (!(par[0] > 0) || !(par[1] > 0)) return fail(ctx, ODW_ERR_INVALID, "paraboloid: focal length and height must be positive");
+        par[2] = 2.0 * std::sqrt(par[0] * par[1]);            // rim radius at z = H
       }
     }
     ctx->h_prim_i32[4 * p] = type;
@@ -1169,7 +1183,7 @@ int odw_upload_surface_source(odw_ctx* ctx, const odw_surface_source_desc* s) {
   std::vector<double> pf((size_t)n * 16);
   std::vector<int32_t> pi((size_t)n * 4);
   for (int p = 0; p < n; ++p) {
-    if (s->prim_type[p] < ODW_PRIM_BOX || s->prim_type[p] > ODW_PRIM_TRIANGLE)
+    if (s->prim_type[p] < ODW_PRIM_BOX || s->prim_type[p] > ODW_PRIM_PARABOLOID)
       return fail(ctx, ODW_ERR_UNSUPPORTED, "surface source: unknown primitive kind");
     const int off = s->prim_cond_off[p], cnt = s->prim_cond_off[p + 1] - off;
     if (s->prim_type[p] == ODW_PRIM_TRIANGLE && cnt != 0)
@@ -1188,7 +1202,7 @@ int odw_upload_surface_source(odw_ctx* ctx, const odw_surface_source_desc* s) {
       return fail(ctx, ODW_ERR_INVALID, "surface source: condition primitive out of range");
     cond[c] = s->cond_prim[c] | (s->cond_inside[c] ? (int32_t)0x80000000 : 0);
   }
-  static const int n_faces_of[6] = {6, 1, 3, 3, 1, 1};
+  static const int n_faces_of[7] = {6, 1, 3, 3, 1, 1, 0};     // (paraboloid faces do not emit: rejected below)
   std::vector<int32_t> fi((size_t)s->n_faces * 2);
   std::vector<double> fc((size_t)s->n_faces + 1, 0.0);
   double total = 0;

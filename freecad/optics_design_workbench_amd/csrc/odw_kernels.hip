@@ -226,8 +226,16 @@ __device__ __forceinline__ void make_ray(csource s, double t_or_r, double phi,
 }
 
 // ----------------------------------------------------------- primitives
-template <class PP>
+// PARAB: paraboloids are known to the BVH and grid kernels only (the flat kernel of the small
+// benchmark scenes is sensitive to every instruction in its loop: their branch cost it 1.1 %)
+template <bool PARAB, class PP>
 __device__ __forceinline__ double prim_sdist(int type, PP par, d3 p) {
+  if (PARAB && type == ODW_PRIM_PARABOLOID) {
+    // x^2 + y^2 - 4 f z over the length of its gradient: the distance to first order
+    const double r2 = p.x * p.x + p.y * p.y;
+    const double lat = (r2 - 4.0 * par[0] * p.z) * 0.5 * frsqrt(r2 + 4.0 * par[0] * par[0]);
+    return fmax(lat, p.z - par[1]);
+  }
   switch (type) {
     case ODW_PRIM_BOX: {
       const double dx = fmax(-p.x, p.x - par[0]);
@@ -311,6 +319,7 @@ struct SceneView {    // constant-address-space views of the scene tables
 // would replace a running minimum -- the trim by the other operands of a
 // boolean (cond list), then bookkeeping of the two running minima (nearest of
 // all / nearest whose group is not the current medium).
+template <bool PARAB = true>
 __device__ __forceinline__ void consider(const SceneView& sv, Query& q, double t, int p, int face,
                                          int group, int cond_off, int cond_cnt) {
   if (!(t > q.tol && t < q.tmax)) return;
@@ -323,7 +332,7 @@ __device__ __forceinline__ void consider(const SceneView& sv, Query& q, double t
       const int cw = sv.cond_i32[c];
       const int qp = cw & 0x7fffffff;
       cf64 pf = sv.prim_f64 + (size_t)qp * 16;
-      const double sd = prim_sdist(sv.prim_i32[4 * qp], pf + 12, xf_point(pf, gp));
+      const double sd = prim_sdist<PARAB>(sv.prim_i32[4 * qp], pf + 12, xf_point(pf, gp));
       if (cw < 0) { if (sd > q.tol) return; }     // must be inside
       else { if (sd < -q.tol) return; }           // must be outside
     }
@@ -362,6 +371,7 @@ __device__ __forceinline__ void cand_min2(Cands& c, double t, int f) {
 // natural face bounds with tolerance (ray.py:411-426).  The candidates are
 // collected first and judged by ONE copy of consider() (code size: the hot
 // loop must stay inside the instruction cache).
+template <bool PARAB = true>
 __device__ __forceinline__ void intersect_prim(const SceneView& sv, Query& q, int p, int type, int group,
                                                int flags, int cond_word) {
   cf64 pf = sv.prim_f64 + (size_t)p * 16;
@@ -454,17 +464,21 @@ __device__ __forceinline__ void intersect_prim(const SceneView& sv, Query& q, in
     }
 #undef ODW_BOX_FACE
     }
-  } else if (type == ODW_PRIM_CYLINDER || type == ODW_PRIM_CONE) {
-    const double R1 = par[0];
-    const double R2 = (type == ODW_PRIM_CYLINDER) ? par[0] : par[1];
-    const double H = (type == ODW_PRIM_CYLINDER) ? par[1] : par[2];
-    const double k = (type == ODW_PRIM_CYLINDER) ? 0.0 : (R2 - R1) / H;
+  } else if (type == ODW_PRIM_CYLINDER || type == ODW_PRIM_CONE || (PARAB && type == ODW_PRIM_PARABOLOID)) {
+    // one quadric template: cylinder / cone x^2 + y^2 = (R1 + k z)^2, paraboloid x^2 + y^2 = 4 f z
+    // (R1 = k = 0 and a term linear in z; its only cap is the one at z = H, face 2)
+    const bool parab = PARAB && type == ODW_PRIM_PARABOLOID;
+    const double R1 = parab ? 0.0 : par[0];
+    const double R2 = (type == ODW_PRIM_CYLINDER) ? par[0] : (parab ? par[2] : par[1]);
+    const double H = (type == ODW_PRIM_CONE) ? par[2] : par[1];
+    const double k = (type == ODW_PRIM_CONE) ? (R2 - R1) / H : 0.0;
+    const double f2 = parab ? 2.0 * par[0] : 0.0;
     if (fmask & 1) {
       const double rz = R1 + k * o.z;
       double t0 = INFINITY, t1 = INFINITY;
       const int nr = quad_roots(d.x * d.x + d.y * d.y - k * k * d.z * d.z,
-                                o.x * d.x + o.y * d.y - k * rz * d.z,
-                                o.x * o.x + o.y * o.y - rz * rz, t0, t1);
+                                o.x * d.x + o.y * d.y - k * rz * d.z - f2 * d.z,
+                                o.x * o.x + o.y * o.y - rz * rz - 2.0 * f2 * o.z, t0, t1);
       const double z0 = o.z + t0 * d.z, z1 = o.z + t1 * d.z;
       if (nr >= 1 && z0 >= -tol && z0 <= H + tol && (R1 + k * z0) >= -tol) c.t0 = t0;
       if (nr == 2 && z1 >= -tol && z1 <= H + tol && (R1 + k * z1) >= -tol) c.t1 = t1;
@@ -587,13 +601,13 @@ __device__ __forceinline__ void intersect_prim(const SceneView& sv, Query& q, in
     ODW_PICK(c.t2, c.f2)
     ODW_PICK(c.t3, c.f3)
 #undef ODW_PICK
-    consider(sv, q, bt, p, bf, group, 0, 0);
+    consider<PARAB>(sv, q, bt, p, bf, group, 0, 0);
   } else {
 #pragma unroll 1
     for (int k = 0; k < 4; ++k) {
       const double t = k == 0 ? c.t0 : (k == 1 ? c.t1 : (k == 2 ? c.t2 : c.t3));
       const int f = k == 0 ? c.f0 : (k == 1 ? c.f1 : (k == 2 ? c.f2 : c.f3));
-      consider(sv, q, t, p, f, group, cond_off, cond_cnt);
+      consider<PARAB>(sv, q, t, p, f, group, cond_off, cond_cnt);
     }
   }
 }
@@ -656,6 +670,7 @@ __device__ __forceinline__ d3 tri_normal(cf64 pf, const double* __restrict__ vn,
 }
 
 // outward normal of face `face` of primitive p at local point lp
+template <bool PARAB = true>
 __device__ __forceinline__ d3 face_normal(int type, cf64 par, int face, d3 lp) {
   if (type == ODW_PRIM_BOX) {
     const double s = (face & 1) ? 1.0 : -1.0;
@@ -663,12 +678,13 @@ __device__ __forceinline__ d3 face_normal(int type, cf64 par, int face, d3 lp) {
     return mk(a == 0 ? s : 0.0, a == 1 ? s : 0.0, a == 2 ? s : 0.0);
   }
   if (type == ODW_PRIM_SPHERE) return lp * frsqrt(dot(lp, lp));
-  if (type == ODW_PRIM_CYLINDER || type == ODW_PRIM_CONE) {
+  if (type == ODW_PRIM_CYLINDER || type == ODW_PRIM_CONE || (PARAB && type == ODW_PRIM_PARABOLOID)) {
     if (face == 1) return mk(0, 0, -1);
     if (face == 2) return mk(0, 0, 1);
     double k = 0;
     if (type == ODW_PRIM_CONE) k = (par[1] - par[0]) / par[2];
-    const d3 g = mk(lp.x, lp.y, -k * (par[0] + k * lp.z));
+    // gradient of x^2 + y^2 - (R1 + k z)^2, or of x^2 + y^2 - 4 f z
+    const d3 g = mk(lp.x, lp.y, (PARAB && type == ODW_PRIM_PARABOLOID) ? -2.0 * par[0] : -k * (par[0] + k * lp.z));
     return g * frsqrt(dot(g, g));
   }
   const double f = 1.0 - par[0] * frsqrt(lp.x * lp.x + lp.y * lp.y);
@@ -730,7 +746,7 @@ __device__ __forceinline__ int nearest(const DeviceScene& sc, const SceneView& s
       // selected (ray.py:432,440): shrink the search like the reference does
       const double cut = fmin(q.tmax, q.any.t + 2.0 * q.tol);
       if (!ray_box(hdr, oi, inv, cut)) continue;
-      intersect_prim(sv, q, p, type, g, flags, cond_word);
+      intersect_prim<false>(sv, q, p, type, g, flags, cond_word);
     }
   } else {
     // BVH traversal in float32 (culling only: leaves are intersected in
@@ -819,7 +835,7 @@ __device__ __forceinline__ int nearest(const DeviceScene& sc, const SceneView& s
         const int g = pi[1];
         if (((mask >> g) & 1) && (pi[2] >> ODW_SOLID_SHIFT) != skip_solid) {
           if (pi[0] == ODW_PRIM_TRIANGLE) intersect_tri(sv, q, p, g);
-          else intersect_prim(sv, q, p, pi[0], g, pi[2], pi[3]);
+          else intersect_prim<true>(sv, q, p, pi[0], g, pi[2], pi[3]);
         }
       }
     }
@@ -1190,7 +1206,7 @@ __global__ __launch_bounds__(256, BVH ? ODW_WAVES_PER_SIMD_BVH : ODW_WAVES_PER_S
         n = tri_normal(pf, sc.tri_nrm ? sc.tri_nrm + (size_t)prim * 9 : nullptr, point);
         if (pi[2] & ODW_FLAG_FLIP_NORMAL) n = n * -1.0;
       } else {
-        n = face_normal(pi[0], pf + 12, face, xf_point(pf, point));
+        n = face_normal<BVH>(pi[0], pf + 12, face, xf_point(pf, point));
         if (pi[2] & ODW_FLAG_FLIP_NORMAL) n = n * -1.0;
         n = xf_vec_t(pf, n);
       }
@@ -1416,7 +1432,7 @@ __global__ __launch_bounds__(256) void odw_emit_kernel(const DeviceEmitter E, ui
         const int cw = E.cond_i32[c];
         const int qp = cw & 0x7fffffff;
         const double* of = E.prim_f64 + (size_t)qp * 16;
-        const double sd = prim_sdist(E.prim_i32[4 * qp], of + 12, xf_point(of, gp));
+        const double sd = prim_sdist<true>(E.prim_i32[4 * qp], of + 12, xf_point(of, gp));
         if (cw < 0) { if (sd > E.dist_tol) ok = false; }
         else { if (sd < -E.dist_tol) ok = false; }
       }

@@ -66,6 +66,15 @@ def makeTorus(doc, name='Torus', radius1=10.0, radius2=2.0, **pl):
                        Angle1=-180.0, Angle2=180.0, Angle3=360.0, Placement=_placement(**pl))
 
 
+def makeParaboloid(doc, name='Paraboloid', focalLength=10.0, height=5.0, **pl):
+  """solid paraboloid of revolution x^2 + y^2 <= 4 f z, z <= height in its own frame (vertex at the
+  origin, axis +z): the blank of a parabolic mirror.  FreeCAD has no such primitive (there it is the
+  revolution of a parabola); this feature carries the two numbers the tracer needs"""
+  return doc.addObject('Part::FeaturePython', name, Proxy={'module': 'freecad.optics_design_workbench_amd.scene.geometry',
+                                                             'class': 'Paraboloid', 'state': {}},
+                       FocalLength=float(focalLength), Height=float(height), Placement=_placement(**pl))
+
+
 def makeCommon(doc, shapes, name='Common', **pl):
   return doc.addObject('Part::MultiCommon', name, Shapes=list(shapes), Placement=_placement(**pl))
 

@@ -57,6 +57,8 @@ class BakedSurfaceSource:
 
 def faceArea(kind, params, face):
   p = params
+  if kind == geometry.PARABOLOID:
+    raise geometry.UnsupportedGeometry('faces of a paraboloid as a surface source are not built')
   if kind == geometry.BOX:
     a = face >> 1
     return p[(a + 1) % 3] * p[(a + 2) % 3]

@@ -14,9 +14,12 @@ import numpy as np
 
 from .placement import Placement
 
-BOX, SPHERE, CYLINDER, CONE, TORUS, TRIANGLE = range(6)
-KIND_NAMES = ['box', 'sphere', 'cylinder', 'cone', 'torus', 'triangle']
-N_FACES = {BOX: 6, SPHERE: 1, CYLINDER: 3, CONE: 3, TORUS: 1, TRIANGLE: 1}
+BOX, SPHERE, CYLINDER, CONE, TORUS, TRIANGLE, PARABOLOID = range(7)
+KIND_NAMES = ['box', 'sphere', 'cylinder', 'cone', 'torus', 'triangle', 'paraboloid']
+# (paraboloid: face 0 = the surface of revolution, face 2 = the cap at z = H as on cylinders and
+#  cones; there is no face 1)
+N_FACES = {BOX: 6, SPHERE: 1, CYLINDER: 3, CONE: 3, TORUS: 1, TRIANGLE: 1, PARABOLOID: 3}
+PARABOLOID_FACES = 0b101
 
 
 class UnsupportedGeometry(ValueError):
@@ -61,6 +64,13 @@ def _primitive_of(obj):
     if not (_close(obj.Angle1, -180) and _close(obj.Angle2, 180) and _close(obj.Angle3, 360)):
       raise UnsupportedGeometry(f'{obj.Name}: partial tori need FreeCAD')
     return Node('prim', kind=TORUS, params=(obj.Radius1, obj.Radius2, 0.0, 0.0), source=obj.Name)
+  if t == 'Part::FeaturePython' and obj.ProxyClass == 'Paraboloid':
+    # solid paraboloid of revolution x^2 + y^2 <= 4 f z, z <= Height (freecad_elements.make.makeParaboloid;
+    # FreeCAD has no such primitive: there it is the revolution of a parabola about its axis)
+    f, h = float(obj.FocalLength), float(obj.Height)
+    if not (f > 0 and h > 0):
+      raise UnsupportedGeometry(f'{obj.Name}: paraboloid needs a positive focal length and height')
+    return Node('prim', kind=PARABOLOID, params=(f, h, 2.0 * np.sqrt(f * h), 0.0), source=obj.Name, facemask=PARABOLOID_FACES)
   return None
 
 
@@ -306,7 +316,7 @@ def is_convex(node):
   """True for solids a straight line meets in one interval: box, sphere,
   cylinder, cone and intersections (Common) of such"""
   if node.op == 'prim':
-    return node.kind in (BOX, SPHERE, CYLINDER, CONE)
+    return node.kind in (BOX, SPHERE, CYLINDER, CONE, PARABOLOID)
   if node.op == 'common':
     return all(is_convex(c) for c in node.children)
   return False
@@ -338,6 +348,9 @@ def local_bounds(kind, params):
   if kind == TORUS:
     r = p[0] + p[1]
     return np.array([-r, -r, -p[1]]), np.array([r, r, p[1]])
+  if kind == PARABOLOID:
+    r = 2.0 * np.sqrt(p[0] * p[1])
+    return np.array([-r, -r, 0.0]), np.array([r, r, p[1]])
   raise ValueError(kind)
 
 
@@ -348,6 +361,9 @@ def face_local_bounds(kind, params, face):
     a = face >> 1
     v = hi[a] if face & 1 else lo[a]
     lo[a] = hi[a] = v
+  elif kind == PARABOLOID and face == 2:
+    r = 2.0 * np.sqrt(params[0] * params[1])
+    lo = np.array([-r, -r, hi[2]]); hi = np.array([r, r, hi[2]])
   elif kind in (CYLINDER, CONE) and face in (1, 2):
     r = params[0] if (face == 1 or kind == CYLINDER) else params[1]
     z = lo[2] if face == 1 else hi[2]
@@ -444,6 +460,19 @@ def tessellate(kind, params, segments=48):
         dp = lambda U, V, r=r, z=z, s=s: st(r * V * np.cos(-s * two_pi * U), r * V * np.sin(-s * two_pi * U), z + 0 * V)
         dn = lambda U, V, s=s: st(0 * U, 0 * U, s + 0 * V)
         parts.append(_grid(n, max(1, n // 8), dp, dn))
+  elif kind == PARABOLOID:
+    f, h = params[0], params[1]
+    rim = 2.0 * np.sqrt(f * h)
+    # v = radius / rim (equal steps in radius: the chord error is even along the meridian)
+    pt = lambda U, V: st(rim * V * np.cos(two_pi * U), rim * V * np.sin(two_pi * U), (rim * V)**2 / (4 * f))
+    def nr(U, V):
+      g = st(rim * V * np.cos(two_pi * U), rim * V * np.sin(two_pi * U), -2.0 * f + 0 * V)
+      return g / np.linalg.norm(g, axis=-1, keepdims=True)
+    # (d/du) x (d/dv) must point outwards (away from the axis, downwards): u clockwise
+    lat = _grid(n, max(2, n // 4), lambda U, V: pt(-U, V), lambda U, V: nr(-U, V))
+    parts.append(lat)
+    dp = lambda U, V: st(rim * V * np.cos(-two_pi * U), rim * V * np.sin(-two_pi * U), h + 0 * V)
+    parts.append(_grid(n, max(1, n // 8), dp, lambda U, V: st(0 * U, 0 * U, 1.0 + 0 * V)))
   elif kind == BOX:
     L = np.array(params[:3], dtype=np.float64)
     for a in range(3):

@@ -42,6 +42,11 @@ enum {
 /*  CYLINDER axis +z, z in [0,H]          params = R, H, -, -               */
 /*  CONE     axis +z, z in [0,H]          params = R1(z=0), R2(z=H), H, -   */
 /*  TORUS    axis +z                      params = R1 (ring), R2 (tube)     */
+/*  PARABOLOID of revolution, axis +z, vertex at the origin: the solid       */
+/*           x^2 + y^2 <= 4 f z, z <= H (a parabolic mirror blank: `README.md`*/
+/*           "slotted parabolic mirrors"; FreeCAD builds it as the revolution */
+/*           of a parabola)        params = f (focal length), H, 2 sqrt(f H)  */
+/*           (= the rim radius, filled in by the library), -                 */
 /*  TRIANGLE one facet of a tessellated face (shapes whose surfaces are not */
 /*           quadrics: STEP imports, B-splines -- what FreeCAD's            */
 /*           `Shape.tessellate(tol)` returns).  No local frame: prim_xform  */
@@ -56,12 +61,13 @@ enum {
   ODW_PRIM_CYLINDER = 2,
   ODW_PRIM_CONE = 3,
   ODW_PRIM_TORUS = 4,
-  ODW_PRIM_TRIANGLE = 5
+  ODW_PRIM_TRIANGLE = 5,
+  ODW_PRIM_PARABOLOID = 6
 };
 
 /* face bit positions inside prim_flags >> ODW_FACEMASK_SHIFT               */
 /*  BOX: 0:-x 1:+x 2:-y 3:+y 4:-z 5:+z ; CYL/CONE: 0:lateral 1:z=0 2:z=H    */
-/*  SPHERE/TORUS/TRIANGLE: 0                                                */
+/*  SPHERE/TORUS/TRIANGLE: 0 ; PARABOLOID: 0:lateral 2:z=H (bit 1 unused)    */
 #define ODW_FLAG_FLIP_NORMAL 0x1 /* face normals point INTO the primitive   */
                                  /* (tool of a Part::Cut)                   */
 #define ODW_FLAG_CONVEX 0x2      /* the primitive's solid (prim_solid) is convex:*/

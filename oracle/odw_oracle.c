@@ -320,6 +320,12 @@ static double prim_sdist(int type, const double* par, v3 p) {
       double a = rho - par[0];
       return sqrt(a * a + p.z * p.z) - par[1];
     }
+    case ODW_PRIM_PARABOLOID: {
+      /* x^2 + y^2 - 4 f z over the length of its gradient: the distance to first order */
+      double r2 = p.x * p.x + p.y * p.y;
+      double lat = (r2 - 4.0 * par[0] * p.z) / (2.0 * sqrt(r2 + 4.0 * par[0] * par[0]));
+      return fmax(lat, p.z - par[1]);
+    }
   }
   return INFINITY;
 }
@@ -392,6 +398,30 @@ static int prim_candidates(int type, const double* par, int facemask, v3 o, v3 d
         double px = o.x + t * d.x, py = o.y + t * d.y;
         if (px * px + py * py > (rc + tol) * (rc + tol)) continue;
         out[n].t = t; out[n].n_local = V(0, 0, f == 1 ? -1.0 : 1.0); out[n].face = f; ++n;
+      }
+      break;
+    }
+    case ODW_PRIM_PARABOLOID: {
+      /* the solid x^2 + y^2 <= 4 f z, z <= H: lateral face 0, cap z = H face 2 (rim radius 2 sqrt(f H)) */
+      double f = par[0], H = par[1];
+      if (facemask & 1) {
+        double r[2];
+        int nr = quad_roots(d.x * d.x + d.y * d.y, o.x * d.x + o.y * d.y - 2.0 * f * d.z,
+                            o.x * o.x + o.y * o.y - 4.0 * f * o.z, r);
+        for (int i = 0; i < nr; ++i) {
+          v3 p = add(o, mul(d, r[i]));
+          if (p.z < -tol || p.z > H + tol) continue;
+          v3 g = V(p.x, p.y, -2.0 * f);
+          out[n].t = r[i]; out[n].n_local = mul(g, 1.0 / len(g)); out[n].face = 0; ++n;
+        }
+      }
+      if ((facemask & 4) && d.z != 0) {
+        double rc = 2.0 * sqrt(f * H);
+        double t = (H - o.z) / d.z;
+        double px = o.x + t * d.x, py = o.y + t * d.y;
+        if (px * px + py * py <= (rc + tol) * (rc + tol)) {
+          out[n].t = t; out[n].n_local = V(0, 0, 1.0); out[n].face = 2; ++n;
+        }
       }
       break;
     }

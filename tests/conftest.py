@@ -87,6 +87,28 @@ class _Backend:
     assert tr.counters()['hits_dropped'] == 0
     return tr.hits()
 
+  def traceRays(self, scene, lim, origins, dirs, wavelength=500.0):
+    """hit rows of explicit rays, all groups recording"""
+    import copy
+    import numpy as np
+    sc = copy.copy(scene)
+    sc.group_record = np.ones_like(scene.group_record)
+    if self.name == 'oracle':
+      from oracle import capi
+      capi.build()
+      return capi.trace_rays(sc, lim, origins, dirs, wavelength=wavelength, nthreads=0)['hits']
+    tr = self._tracers[0] if self._tracers else self.tracer()
+    tr.setScene(sc)
+    tr.setLimits(lim)
+    tr.setDetector(None)
+    tr.reserveHits(len(origins) * (lim.max_intersections + 1))
+    tr.reset()
+    tr.setWavelength(wavelength)
+    tr.traceRays(origins, dirs)
+    tr.sync()
+    assert tr.counters()['hits_dropped'] == 0
+    return tr.hits()
+
   def close(self):
     for t in self._tracers:
       t.close()

@@ -57,6 +57,9 @@ def _primitive(obj):
   if t == 'Part::Torus':
     R1, R2 = float(obj.Radius1), float(obj.Radius2)
     return lambda q: (np.hypot(q[:, 0], q[:, 1]) - R1)**2 + q[:, 2]**2 <= R2 * R2
+  if t == 'Part::FeaturePython' and obj.ProxyClass == 'Paraboloid':
+    f, H = float(obj.FocalLength), float(obj.Height)
+    return lambda q: (q[:, 0]**2 + q[:, 1]**2 <= 4 * f * q[:, 2]) & (q[:, 2] <= H)
   return None
 
 

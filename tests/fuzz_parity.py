@@ -4,7 +4,8 @@ optical types, overlaps), random rays aimed at them, device vs oracle on whole t
 (all groups record).  Prints one JSON line per scene that differs and a summary.
   python tests/fuzz_parity.py [scenes] [rays] [seed] [rich]
 (rich = 1: also tessellated solids, stochastic surfaces, gratings, absorbing media, sequential mode;
- 3: crowded scenes of 8-20 groups with the reference's distance tolerances; 2: both)
+ 3: crowded scenes of 8-20 groups with the reference's distance tolerances; 2: both;
+ 4: paraboloids among the primitives; 5: crowded with paraboloids)
 Differences are classified: `tags` (a different sequence of hits: a real disagreement unless the
 scene is chaotic -- many bounces between curved mirrors amplify rounding) and `coords` (same hits,
 coordinates apart by more than 1e-7 mm).
@@ -26,7 +27,8 @@ n_scenes = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 n_rays = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
 seed0 = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 rich = len(sys.argv) > 4 and sys.argv[4] in ('1', '2')
-crowded = len(sys.argv) > 4 and sys.argv[4] in ('2', '3')
+crowded = len(sys.argv) > 4 and sys.argv[4] in ('2', '3', '5')
+parab = len(sys.argv) > 4 and sys.argv[4] in ('4', '5')
 
 
 bad = dict(tags=0, coords=0)
@@ -35,7 +37,7 @@ with Tracer(0) as tr:
   for s in range(n_scenes):
     rs = np.random.RandomState(seed0 * 100003 + s)
     try:
-      sc, lim, targets = scene(rs, rich, crowded)
+      sc, lim, targets = scene(rs, rich, crowded, parab)
     except Exception as e:                         # nested disjunctions etc.: not a parity matter
       continue
     o, d = rays(rs, targets, n_rays)

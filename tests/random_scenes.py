@@ -12,10 +12,15 @@ def rquat(rs):
   return tuple(q / np.linalg.norm(q))
 
 
-def solid(doc, rs, k, centre):
-  kind = rs.choice(['box', 'sphere', 'cylinder', 'cone', 'torus'], p=[0.3, 0.3, 0.2, 0.1, 0.1])
+def solid(doc, rs, k, centre, paraboloids=False):
+  if paraboloids:
+    kind = rs.choice(['box', 'sphere', 'cylinder', 'cone', 'torus', 'paraboloid'], p=[0.2, 0.2, 0.15, 0.1, 0.05, 0.3])
+  else:
+    kind = rs.choice(['box', 'sphere', 'cylinder', 'cone', 'torus'], p=[0.3, 0.3, 0.2, 0.1, 0.1])
   pl = dict(base=tuple(centre + rs.normal(0, 1.0, 3)), quat=rquat(rs))
   s = rs.uniform(2, 6)
+  if kind == 'paraboloid':
+    return make.makeParaboloid(doc, f'P{k}', rs.uniform(0.5, 6), rs.uniform(2, 8), **pl)
   if kind == 'box':
     return make.makeBox(doc, f'B{k}', *(rs.uniform(2, 8, 3)), **pl)
   if kind == 'sphere':
@@ -27,11 +32,13 @@ def solid(doc, rs, k, centre):
   return make.makeTorus(doc, f'T{k}', s, s * rs.uniform(0.15, 0.4), **pl)
 
 
-def scene(rs, rich=False, crowded=False):
+def scene(rs, rich=False, crowded=False, paraboloids=False):
   """rich: also tessellated solids (triangle primitives, BVH kernels), stochastic surfaces,
   gratings, absorbing media, partly reflecting mirrors and sequential mode;
-  crowded: 8-20 groups (more than 16 primitives: BVH kernels on analytic primitives with
-  trimming conditions) and the distance tolerances the reference's documents use (1e-6 ... 1e-2)"""
+  crowded: 8-20 groups (more than 16 primitives: grid / BVH kernels on analytic primitives with
+  trimming conditions) and the distance tolerances the reference's documents use (1e-6 ... 1e-2);
+  paraboloids: solid paraboloids among the primitives (off by default: the other modes keep the
+  scenes their seeds have always produced)"""
   doc = Document()
   targets = []
   k = 0
@@ -39,14 +46,14 @@ def scene(rs, rich=False, crowded=False):
   for g in range(rs.randint(8, 21) if crowded else rs.randint(2, 6)):
     centre = rs.uniform(-18, 18, 3)
     targets.append(centre)
-    a = solid(doc, rs, k, centre); k += 1
+    a = solid(doc, rs, k, centre, paraboloids); k += 1
     r = rs.rand()
     if rich and r < 0.2:
       elem = make.makeTessellated(doc, a, int(rs.choice([6, 12, 20])), smooth=bool(rs.rand() < 0.6))
     elif r < 0.45:
       elem = a
     else:
-      b = solid(doc, rs, k, centre + rs.normal(0, 1.5, 3)); k += 1
+      b = solid(doc, rs, k, centre + rs.normal(0, 1.5, 3), paraboloids); k += 1
       elem = (make.makeCommon(doc, [a, b], f'X{k}') if r < 0.65 else
               make.makeCut(doc, a, b, f'X{k}') if r < 0.85 else make.makeFuse(doc, [a, b], f'X{k}'))
     kind = rs.choice(['Mirror', 'Lens', 'Absorber', 'Vacuum'], p=[0.3, 0.4, 0.15, 0.15])

@@ -24,7 +24,7 @@ from freecad.optics_design_workbench_amd.freecad_elements import make
 from freecad.optics_design_workbench_amd.scene import Document, Placement, bake, geometry, open_fcstd
 from freecad.optics_design_workbench_amd.scene.placement import from_axis_angle
 
-BOX, SPHERE, CYLINDER, CONE, TORUS = range(5)
+BOX, SPHERE, CYLINDER, CONE, TORUS, TRIANGLE, PARABOLOID = range(7)
 EPS = 1e-5          # probe distance along the normal
 MARGIN = 1e-3       # samples this close to a trimming surface are not judged
 
@@ -41,6 +41,8 @@ def sdist(kind, par, q):
   if kind == CONE:
     k = (par[1] - par[0]) / par[2]
     return np.maximum.reduce([(rho - (par[0] + k * q[:, 2])) / np.sqrt(1 + k * k), -q[:, 2], q[:, 2] - par[2]])
+  if kind == PARABOLOID:
+    return np.maximum((rho**2 - 4 * par[0] * q[:, 2]) / (2 * np.sqrt(rho**2 + 4 * par[0]**2)), q[:, 2] - par[1])
   return np.hypot(rho - par[0], q[:, 2]) - par[1]
 
 
@@ -69,6 +71,16 @@ def sample_face(kind, par, face, n, rs):
     nr = np.stack([np.cos(th) * np.cos(phi), np.cos(th) * np.sin(phi), np.sin(th)], axis=1)
     rho = par[0] + par[1] * np.cos(th)
     return np.stack([rho * np.cos(phi), rho * np.sin(phi), par[1] * np.sin(th)], axis=1), nr
+  if kind == PARABOLOID:
+    f, h = par[0], par[1]
+    if face == 2:
+      rr = 2 * np.sqrt(f * h) * np.sqrt(v) * (1 - 1e-4)
+      nr = np.zeros((n, 3))
+      nr[:, 2] = 1.0
+      return np.stack([rr * np.cos(phi), rr * np.sin(phi), np.full(n, h)], axis=1), nr
+    rr = 2 * np.sqrt(f * h) * np.sqrt(v)
+    g = np.stack([rr * np.cos(phi), rr * np.sin(phi), np.full(n, -2 * f)], axis=1)
+    return np.stack([rr * np.cos(phi), rr * np.sin(phi), rr**2 / (4 * f)], axis=1), g / np.linalg.norm(g, axis=1)[:, None]
   r1, r2, h = (par[0], par[0], par[1]) if kind == CYLINDER else (par[0], par[1], par[2])
   if face == 0:
     z = h * v
@@ -107,6 +119,8 @@ def check_faces(doc, scene, n_per_face, seed=1, prims=None):
     flip = -1.0 if flags & 1 else 1.0
     solid = solids[int(scene.prim_solid[p])]
     for f in range(geometry.N_FACES[kind]):
+      if kind == PARABOLOID and f == 1:
+        continue                      # (no such face: a paraboloid has its surface and the cap at z = H)
       lp, ln = sample_face(kind, par, f, n_per_face, rs)
       wp, wn = lp @ R.T + t, (ln @ R.T) * flip
       # the baked verdict: face exists (mask) and every trimming condition holds
@@ -278,7 +292,17 @@ def test_cut_fuse_common_trees(oracle):
   def cone_cut(d):
     return [make.makeCut(d, make.makeCone(d, 'Co', 5, 2, 8, placement=Placement(base=(0, 25, 0))),
                          make.makeBox(d, 'B4', 4, 20, 3, placement=_rot((0, 0, 1), 15, (-2, 18, 2))), 'CC')]
-  doc, scene, lim = _built([('Lens', plano_concave, {}), ('Mirror', capsule, {}), ('Lens', notched, dict(name='OpticalLensGroup2')), ('Absorber', cone_cut, {})])
+  def dish(d):
+    # a parabolic mirror: block with a paraboloid cavity (cut: the cavity's normals point into the tool)
+    return [make.makeCut(d, make.makeBox(d, 'Blk', 14, 14, 6, placement=Placement(base=(33, -7, -1))),
+                         make.makeParaboloid(d, 'Pb', 4.0, 8.0, placement=_rot((1, 0, 0), 10, (40, 0, 0.5))), 'Dish')]
+
+  def drop(d):
+    return [make.makeCommon(d, [make.makeParaboloid(d, 'Pb2', 2.0, 9.0, placement=_rot((0, 1, 0), 25, (0, -25, 0))),
+                                make.makeSphere(d, 'Sp5', 6, placement=Placement(base=(1, -25, 5)))], 'Drop')]
+  doc, scene, lim = _built([('Lens', plano_concave, {}), ('Mirror', capsule, {}), ('Lens', notched, dict(name='OpticalLensGroup2')),
+                            ('Absorber', cone_cut, {}), ('Mirror', dish, dict(name='OpticalMirrorGroup2')),
+                            ('Lens', drop, dict(name='OpticalLensGroup3'))])
   judged, kept = check_faces(doc, scene, 20_000)
   assert kept > 0.1 * judged > 0
   assert check_chords(doc, scene, lim, oracle, 800) > 200

@@ -54,6 +54,41 @@ def test_random_scenes_device_equals_oracle(native_lib, oracle, rich):
   assert scenes >= 30 and differing_rays <= 2, (scenes, differing_rays, total)
 
 
+@pytest.mark.parametrize('crowded', [False, True])
+def test_random_scenes_with_paraboloids(native_lib, oracle, crowded):
+  """solid paraboloids (ODW_PRIM_PARABOLOID) alone and in Common / Cut / Fuse with the other
+  primitives: flat kernel (few groups) and grid kernel (crowded), device vs oracle"""
+  from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
+  n = 5000
+  scenes = differing_rays = with_parab = 0
+  with Tracer(0) as tr:
+    for s in range(24):
+      rs = np.random.RandomState(19 * 100003 + s)
+      try:
+        sc, lim, targets = scene(rs, False, crowded, True)
+      except Exception:
+        continue
+      with_parab += int((np.asarray(sc.prim_type) == 6).any())
+      o, d = rays(rs, targets, n)
+      tr.setScene(sc); tr.setLimits(lim); tr.setDetector(None)
+      tr.reserveHits(n * (lim.max_intersections + 1))
+      tr.reset()
+      tr.traceRays(o, d)
+      tr.sync()
+      g = tr.hits()
+      r = oracle.trace_rays(sc, lim, o, d, nthreads=0)['hits']
+      scenes += 1
+      gr = (g['tag'] & np.uint64(0xFFFFFFFFFFFF)).astype(np.int64)
+      rr = (r['tag'] & np.uint64(0xFFFFFFFFFFFF)).astype(np.int64)
+      if len(g) != len(r) or not np.array_equal(g['tag'], r['tag']):
+        differing_rays += int((np.bincount(gr, minlength=n) != np.bincount(rr, minlength=n)).sum())
+        continue
+      first = np.r_[True, gr[1:] != gr[:-1]]
+      d1 = np.abs(g['point'][first] - r['point'][first]).max(axis=1)
+      assert d1.max() < 1e-9, (s, float(d1.max()))
+  assert scenes >= 18 and with_parab >= 12 and differing_rays <= 2, (scenes, with_parab, differing_rays)
+
+
 def test_trimmed_box_face_met_within_tolerance_of_an_edge(native_lib, oracle):
   """found by the long-form run (seed 102, crowded scene 3, ray 18561): inside a Fuse of a sphere and a
   box the ray leaves the box through a face the trim rejects (the point lies inside the sphere by more

@@ -173,6 +173,57 @@ def test_max_intersections_and_power_tol(oracle):
   assert r['counters']['died'] == 1 and r['counters']['segments'] == 20
 
 
+def test_parabolic_mirror_focuses_a_parallel_beam(backend):
+  """north star "analytic spheres / paraboloids"; README.md "slotted parabolic mirrors": rays
+  parallel to the axis of a paraboloid z = (x^2 + y^2) / 4f meet at its focus (0, 0, f) after one
+  reflection -- exactly, whatever their distance from the axis; and a ray through the focus
+  leaves parallel to the axis.  The mirror is a block with a paraboloid cavity (Part::Cut: the
+  cavity carries the tool's faces with flipped normals); an absorbing bead sits at the focus."""
+  f = 12.0
+  doc, sc, lim = build([
+      ('Mirror', lambda d: [make.makeCut(d, make.makeBox(d, 'Blk', 60, 60, 12, base=(-30, -30, -2)),
+                                         make.makeParaboloid(d, 'Pb', f, 20.0))], {}),
+      ('Absorber', lambda d: [make.makeSphere(d, 'Bead', 0.5, base=(0, 0, f))], {}),
+  ])
+  assert sc.prim_type.tolist().count(6) == 1
+  rs = np.random.RandomState(3)
+  n = 4000
+  xy = rs.uniform(-14, 14, (n, 2))
+  xy = xy[np.hypot(xy[:, 0], xy[:, 1]) > 1.0]                   # (rays that would hit the bead from above first)
+  xy = xy[np.hypot(xy[:, 0], xy[:, 1]) < 2 * np.sqrt(f * 10.0) - 0.5]     # inside the cavity's mouth at z = 10
+  o = np.column_stack([xy, np.full(len(xy), 40.0)])
+  d = np.tile([0.0, 0.0, -1.0], (len(xy), 1))
+  h = backend.traceRays(sc, lim, o, d)
+  ray = (h['tag'] & np.uint64(0xFFFFFFFFFFFF)).astype(np.int64)
+  grp = ((h['tag'] >> np.uint64(48)) & np.uint64(0x7FFF)).astype(np.int64)
+  mirror, bead = h[grp == 0], h[grp == 1]
+  assert len(mirror) == len(xy) and len(bead) == len(xy)        # every ray: one reflection, then the bead
+  # the reflection happens on the paraboloid ...
+  p = mirror['point']
+  assert np.abs(p[:, 2] - (p[:, 0]**2 + p[:, 1]**2) / (4 * f)).max() < 1e-9
+  # ... and the reflected ray runs through the focus: its direction at the bead points at (0, 0, f)
+  to_focus = np.array([0, 0, f]) - p
+  to_focus /= np.linalg.norm(to_focus, axis=1)[:, None]
+  assert np.abs(bead['direction'] - to_focus).max() < 1e-9
+  miss = np.linalg.norm(np.cross(bead['direction'], np.array([0, 0, f]) - bead['point']), axis=1)
+  assert miss.max() < 1e-9
+  # reversed: rays from the focus leave parallel to the axis
+  th = rs.uniform(np.radians(100), np.radians(170), 500)
+  ph = rs.uniform(0, 2 * np.pi, 500)
+  dd = np.column_stack([np.sin(th) * np.cos(ph), np.sin(th) * np.sin(ph), np.cos(th)])
+  sc2 = bake.bakeScene(doc, None)
+  sc2.ignore_mask = 1 << 1                                      # without the bead
+  h = backend.traceRays(sc2, lim, np.tile([0.0, 0.0, f], (500, 1)), dd)
+  first = h[np.r_[True, np.diff((h['tag'] & np.uint64(0xFFFFFFFFFFFF)).astype(np.int64)) != 0]]
+  out = first['direction'] - 2 * (first['direction'] * _parab_normal(first['point'], f)).sum(1)[:, None] * _parab_normal(first['point'], f)
+  assert np.abs(out - np.array([0, 0, 1.0])).max() < 1e-9
+
+
+def _parab_normal(p, f):
+  g = np.column_stack([p[:, 0], p[:, 1], np.full(len(p), -2 * f)])
+  return g / np.linalg.norm(g, axis=1)[:, None]
+
+
 def test_gaussian_spot_reference_acceptance(backend):
   """test/50-old-tests/run-simulations.py:123-174: exp(-theta^2/1e-4) on a
   plane at 100 mm: fitted sigma within 30 % of 100*sqrt(1e-4) = 1 mm, centre
