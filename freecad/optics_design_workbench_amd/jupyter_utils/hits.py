@@ -49,14 +49,19 @@ def _flattest_direction(cloud, angleTol):
   while True:
     cell = (phis[1] - phis[0], thetas[1] - thetas[0])
     P, T, normals = _sphere_dirs(phis, thetas)
-    # one matrix-vector product per candidate, as the reference evaluates them (hits.py:124-128):
-    # a single matrix-matrix product sums in another order, and the argmin over nearly equal
-    # extents then lands on a neighbouring cell now and then (1e-9 rad, a hit or two in a bin)
-    extent = np.empty(len(normals))
-    for j, nrm in enumerate(normals):
-      along = np.dot(cloud, nrm)
-      extent[j] = along.max() - along.min()
-    k = int(np.argmin(extent))
+    # The reference evaluates one matrix-vector product per candidate (hits.py:124-128) and takes the
+    # first minimum; one matrix-matrix product sums in another order, and the argmin over nearly
+    # equal extents then lands on a neighbouring cell now and then.  So: screen all candidates with
+    # the matrix-matrix product, then redo those within rounding of the smallest extent the
+    # reference's way -- same winner bit for bit, a fiftieth of the calls.
+    rough = normals @ cloud.T
+    rough = rough.max(axis=1) - rough.min(axis=1)
+    near = np.flatnonzero(rough <= rough.min() + 1e-12 * max(float(np.abs(cloud).max()), 1e-300))
+    exact = np.empty(len(near))
+    for j, c in enumerate(near):
+      along = np.dot(cloud, normals[c])
+      exact[j] = along.max() - along.min()
+    k = int(near[int(np.argmin(exact))])
     phis = np.linspace(P[k] - 1.1 * cell[0], P[k] + 1.1 * cell[0], 10)
     thetas = np.linspace(T[k] - 1.1 * cell[1], T[k] + 1.1 * cell[1], 10)
     if max(phis[1] - phis[0], thetas[1] - thetas[0]) < angleTol:
