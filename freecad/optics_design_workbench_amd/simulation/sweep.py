@@ -110,6 +110,7 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
   from .simulation_loop import bakeLightSource
   own = tracer is None
   tr = tracer or Tracer(device)
+  uploaded = {}
   table = np.zeros((len(values), len(names), 2))        # (result or 0, 1 = a number / 2 = nan)
   totals = np.zeros(3, dtype=np.int64)
   try:
@@ -118,9 +119,15 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
       scene = _bake.bakeScene(doc, src)
       bsrc = bakeLightSource(doc, src, seed)
       lim = _bake.bakeLimits(doc, src, **traceKwargs)
+      # (tables travel to the device only when they change: a sweep of one shape parameter uploads
+      #  the source's 1.6 MB of sampler tables once)
       tr.setScene(scene)
-      tr.setSource(bsrc)
-      tr.setLimits(lim)
+      if uploaded.get('source') is not bsrc:
+        tr.setSource(bsrc)
+        uploaded['source'] = bsrc
+      if uploaded.get('limits') != lim:
+        tr.setLimits(lim)
+        uploaded['limits'] = lim
       tr.setDetector(None)
       capacity = int(rays * 1.25) + 1024
       while True:
