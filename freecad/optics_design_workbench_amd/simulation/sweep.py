@@ -66,6 +66,15 @@ def shareOfRank(n_values, rank, world):
   return list(range(int(rank), int(n_values), int(world)))
 
 
+def _sourceKey(bsrc):
+  """what decides a source's device tables: the (cached) sampler tables by identity, the numbers by value"""
+  t = getattr(bsrc, 'tables', None)
+  if t is None:
+    return id(bsrc)
+  return (id(t), np.asarray(bsrc.xform, dtype=np.float64).tobytes(), float(bsrc.focal_length), float(bsrc.wavelength),
+          float(bsrc.power))
+
+
 class SweepResult:
   """values, one column of results per figure of merit (nan where a run produced none), and what
   the runs traced.  `results` is the first (or only) column."""
@@ -122,9 +131,10 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
       # (tables travel to the device only when they change: a sweep of one shape parameter uploads
       #  the source's 1.6 MB of sampler tables once)
       tr.setScene(scene)
-      if uploaded.get('source') is not bsrc:
+      key = _sourceKey(bsrc)
+      if uploaded.get('source') != key:
         tr.setSource(bsrc)
-        uploaded['source'] = bsrc
+        uploaded['source'] = key
       if uploaded.get('limits') != lim:
         tr.setLimits(lim)
         uploaded['limits'] = lim
