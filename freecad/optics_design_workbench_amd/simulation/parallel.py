@@ -74,7 +74,14 @@ class Ranks:
   def _tensor_device(self):
     import torch
     if self.dist.get_backend() == 'nccl':
-      return torch.device('cuda', self._device if self._device is not None else torch.cuda.current_device())
+      # RCCL wants the tensor on the device this rank's communicator was made for: the process'
+      # current device (set by the launcher code from LOCAL_RANK); a device given by the caller
+      # must be that one
+      cur = torch.cuda.current_device()
+      if self._device is not None and int(self._device) != cur and self.world > 1:
+        raise RuntimeError(f'rank {self.rank}: collectives on cuda:{cur} but the tracer works on cuda:{self._device}; '
+                           f'call torch.cuda.set_device(LOCAL_RANK) and create the Tracer on that device')
+      return torch.device('cuda', cur)
     return torch.device('cpu')
 
   def sum(self, values):

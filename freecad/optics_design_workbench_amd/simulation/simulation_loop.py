@@ -65,7 +65,8 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
   if pseudo:
     # the reference seeds numpy's global generator per worker (simulation_loop.py:813-820)
     np.random.seed(int(seed) % (1 << 32))
-  ranks = parallel.Ranks.detect(dist, device)
+  # (collectives run on the GPU the tracer works on: one process per GPU, each with its own device)
+  ranks = parallel.Ranks.detect(dist, getattr(tracer, 'device', device) if tracer is not None else device)
   if store is None:
     runFolder = None
     if resultsPath is not None and ranks.world > 1:

@@ -106,7 +106,8 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
                          on a thinned sample, projection, medians and binning on the device); False:
                          copy every row to the host first (what the reference does)
   """
-  ranks = parallel.Ranks.detect(dist, device)
+  # (collectives run on the GPU the tracer works on: one process per GPU, each with its own device)
+  ranks = parallel.Ranks.detect(dist, getattr(tracer, 'device', device) if tracer is not None else device)
   values = [float(v) for v in values]
   measures = dict(measure) if isinstance(measure, dict) else {'result': measure}
   names = list(measures)
