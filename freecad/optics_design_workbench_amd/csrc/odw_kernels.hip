@@ -904,9 +904,17 @@ __device__ __forceinline__ void surface_draw(const DeviceSurfaceSampler* sp, dou
   const DeviceSurfaceSampler S = *sp;
   int k = 0;
   if (S.axis != ODW_SURF_AXIS_NONE) {
+    // The reference compiles its tables at the hit's own value of the constant; here the two family
+    // members around it are mixed: member k0 + 1 with probability = the fractional position between
+    // the knots (a linear interpolation of the two distributions in the constant), decided by a
+    // uniform of its own.  At a knot the member is the reference's table bit for bit.
     const double c = S.axis == ODW_SURF_AXIS_THETA_IN ? theta_in : theta_refl;
-    k = (int)rint((c - S.lo) * S.inv_step);
-    k = max(0, min(S.n_family - 1, k));
+    const double kf = fmin(fmax((c - S.lo) * S.inv_step, 0.0), (double)(S.n_family - 1));
+    const int k0 = (int)floor(kf);
+    const double frac = kf - (double)k0;
+    uint32_t m0 = (uint32_t)ray, m1 = (uint32_t)(ray >> 32), m2 = ordinal, m3 = stream + 16u;
+    philox4x32_10(m0, m1, m2, m3, (uint32_t)seed, (uint32_t)(seed >> 32));
+    k = k0 + (u53(m0, m1) < frac ? 1 : 0);
   }
   TableView tv;
   tv.phi_tab = S.phi_tab + (size_t)k * (size_t)S.n_phi_knots * 2;

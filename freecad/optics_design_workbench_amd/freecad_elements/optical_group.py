@@ -13,8 +13,9 @@ Here the numeric-mode tables are built ahead of the launch:
   * no constant in the expression   -> one table set, exactly the reference's
   * one constant (`theta_in` or `theta_refl`; for mirrors `theta_refl =
     pi - theta_in`, so both may appear) -> a family of `n_family` table sets
-    at equidistant values of the constant; the device uses the nearest member.
-    At the family's knots the tables are the reference's, bit for bit.
+    at equidistant values of the constant; the device mixes the two members around the
+    hit's constant (member k0 + 1 with probability = the fractional position between the
+    knots).  At the family's knots the tables are the reference's, bit for bit.
 Densities that only consist of `DiracDelta(theta)` [* `DiracDelta(phi)`] as
 ray *modification* (the default the reference's GUI writes into new groups)
 leave the direction unchanged (theta = 0: both rotations are identities) and
@@ -51,12 +52,16 @@ class BakedSurfaceSampler:
   def n_family(self):
     return int(self.phi_cdf.shape[0])
 
-  def member(self, c):
-    """index of the family member used for the constant value c (device rule)"""
-    if self.axis == AXIS_NONE:
+  def member(self, c, u=0.5):
+    """index of the family member used for the constant value c (device rule): of the two members
+    around c the upper one with probability = the fractional position between the knots, decided by
+    the uniform u (the device draws it from Philox counter word 3 = 17 + kind)"""
+    if self.axis == AXIS_NONE or self.n_family < 2:
       return 0
-    k = int(np.rint((c - self.lo) * (self.n_family - 1) / (self.hi - self.lo)))
-    return max(0, min(self.n_family - 1, k))
+    kf = (c - self.lo) * ((self.n_family - 1) / (self.hi - self.lo))
+    kf = min(max(kf, 0.0), float(self.n_family - 1))
+    k0 = int(np.floor(kf))
+    return k0 + (1 if u < kf - k0 else 0)
 
   def constant(self, k):
     if self.n_family == 1:

@@ -160,8 +160,10 @@ typedef struct odw_source_desc {
  * the constants theta_in, phi_in = 0, theta_refl, phi_refl = 0
  * (optical_group.py:212-269, 305-307); here the numeric-mode tables
  * (random_number_generator.py:337-464) are tabulated ahead of the launch for
- * a family of n_family equidistant values of ONE constant (family_axis); the
- * member nearest to the hit's constant is sampled exactly like a source.
+ * a family of n_family equidistant values of ONE constant (family_axis); of
+ * the two members around the hit's constant, member k0 + 1 is taken with
+ * probability = the fractional position between the knots (a uniform of its
+ * own: counter word 3 = 17 + kind), and sampled exactly like a source.
  *   kind PRIMARY: Reflected- (mirror) / RefractedProbabilityDensity (lens):
  *     out = Rot(normal, phi) * Rot(normal x dirIn, theta) * normal
  *   kind MODIFY : RayModificationProbabilityDensity, applied afterwards:

@@ -703,12 +703,21 @@ static void surface_draw(const odw_surface_sampler_desc* S, double theta_in, dou
                          uint64_t ray, uint64_t seed, uint32_t ordinal, uint32_t stream,
                          double* theta, double* phi) {
   int k = 0;
-  if (S->family_axis != ODW_SURF_AXIS_NONE) {
+  if (S->family_axis != ODW_SURF_AXIS_NONE && S->n_family > 1) {
     double c = S->family_axis == ODW_SURF_AXIS_THETA_IN ? theta_in : theta_refl;
     double inv_step = (double)(S->n_family - 1) / (S->family_hi - S->family_lo);
-    k = (int)rint((c - S->family_lo) * inv_step);
-    if (k < 0) k = 0;
-    if (k > S->n_family - 1) k = S->n_family - 1;
+    /* the two members around the hit's constant are mixed: member k0 + 1 with probability = the
+     * fractional position between the knots, decided by a uniform of its own (stream + 16) */
+    double kf = (c - S->family_lo) * inv_step;
+    if (kf < 0) kf = 0;
+    if (kf > (double)(S->n_family - 1)) kf = (double)(S->n_family - 1);
+    int k0 = (int)floor(kf);
+    double frac = kf - (double)k0;
+    uint32_t mctr[4] = {(uint32_t)ray, (uint32_t)(ray >> 32), ordinal, stream + 16u};
+    uint32_t mkey[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t mw[4];
+    odw_oracle_philox(mctr, mkey, mw);
+    k = k0 + (u53(mw[0], mw[1]) < frac ? 1 : 0);
   }
   odw_source_desc t;
   memset(&t, 0, sizeof t);

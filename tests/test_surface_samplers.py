@@ -129,7 +129,8 @@ def _reference_scatter(oracle, samplers, ray, seed, ordinal, din, ideal, n):
   out = ideal
   for s in sorted(samplers, key=lambda s: s.kind):
     c = theta_in if s.axis == optical_group.AXIS_THETA_IN else theta_refl
-    k = s.member(c)
+    m = oracle.philox([ray & 0xFFFFFFFF, ray >> 32, ordinal, 17 + s.kind], [seed & 0xFFFFFFFF, seed >> 32])
+    k = s.member(c, _u53(m[0], m[1]))
     w = oracle.philox([ray & 0xFFFFFFFF, ray >> 32, ordinal, 1 + s.kind], [seed & 0xFFFFFFFF, seed >> 32])
     t = SamplerTables(s.t_edges, s.t_cdf[k], s.phi_edges, s.phi_cdf[k])
     th, ph = t.draw(np.array([_u53(w[0], w[1])]), np.array([_u53(w[2], w[3])]))
@@ -233,3 +234,33 @@ def test_specular_lobe_follows_incidence(oracle):
   oracle.set_surface_samplers(None)
   # lobe sigma 0.007 rad + nearest-member error <= pi/256/2
   assert worst < 5 * 0.00707 + np.pi / 512 + 1e-3
+
+
+def test_family_members_are_mixed_between_knots(oracle):
+  """between two knots of the family the device does not jump to the nearer member: it takes the
+  upper one with probability = the fractional position, so that the scattered distribution moves
+  continuously with the hit's constant (the reference compiles at the exact value).  Coarse family
+  of 3 members, constants at 0 %, 30 %, 70 % and 100 % between knots 0 and 1: the mean polar angle
+  of the scattered rays is the same mix of the two members' means."""
+  g = _group('Mirror', ReflectedProbabilityDensity='exp(-(theta-theta_refl)**2/0.002)',
+             PowerThetaDomain='pi/2, pi', PowerPhiDomain='0, 2*pi')
+  (s,) = optical_group.surfaceSamplers(g, 3, n_family=3)
+  assert s.axis == optical_group.AXIS_THETA_REFL and s.n_family == 3
+  oracle.set_surface_samplers([s])
+  try:
+    means = {}
+    for frac in (0.0, 0.3, 0.7, 1.0):
+      theta_refl = s.constant(0) + frac * (s.constant(1) - s.constant(0))
+      # mirror: theta_refl = pi - theta_in  ->  incidence angle; n along the travel direction
+      ti = np.pi - theta_refl
+      n = np.array([0.0, 0.0, 1.0])
+      din = np.array([np.sin(ti), 0.0, np.cos(ti)])
+      ideal = din - 2 * n * (din @ n)
+      th = [np.arccos(np.clip(oracle.scatter(3, 10_000 + i, 77, 1, din, ideal, n) @ n, -1, 1)) for i in range(6000)]
+      means[frac] = float(np.mean(th))
+    lo, hi = means[0.0], means[1.0]
+    assert abs(hi - lo) > 0.2                                   # the two members differ clearly
+    for frac in (0.3, 0.7):
+      assert means[frac] == pytest.approx(lo + frac * (hi - lo), abs=4 * 0.5 * abs(hi - lo) / np.sqrt(6000) + 3e-3)
+  finally:
+    oracle.set_surface_samplers(None)
