@@ -248,7 +248,7 @@ def run_trace_config(args, cfg_name, cfg, rank, local_rank, world, dist, torch):
 def end_to_end(tr, n_per, steps):
   """PCIe-inclusive rate, reported beside `value` (never as it): every step's hit rows cross to
   host memory, the copy of step k overlapping the trace of step k+1 (two row buffers, a copy
-  stream of its own, page-locked destination: `Tracer.traceStreaming`)"""
+  stream of its own: `Tracer.traceStreaming`)"""
   if not hasattr(tr, 'traceStreaming'):
     return None
   from freecad.optics_design_workbench_amd.simulation import parallel
@@ -260,7 +260,7 @@ def end_to_end(tr, n_per, steps):
     rows += len(chunk)
   dt = time.perf_counter() - t0
   return dict(rays_per_s=n_per * steps / dt, rows=rows, seconds=dt, gb_per_s=rows * 64 / dt / 1e9,
-              note='hit rows of every step copied to page-locked host memory (unordered), copy of step k '
+              note='hit rows of every step copied to host memory (append order), copy of step k '
                    'overlapped with the trace of step k+1')
 
 

@@ -1540,6 +1540,17 @@ int odw_swap_hit_lists(odw_ctx* ctx) {
   return ODW_OK;
 }
 
+int odw_release_swapped_hits(odw_ctx* ctx) {
+  if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_release_swapped_hits: null ctx");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (ctx->copy_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  release(ctx->alt_hits);
+  ctx->alt_capacity = ctx->alt_slots = 0;
+  ctx->swapping = false;           // launches reserve hit-list blocks again
+  return ODW_OK;
+}
+
 int odw_fetch_swapped_hits(odw_ctx* ctx, odw_hit* out, uint64_t capacity, uint64_t* n) {
   if (!ctx || !n) return fail(ctx, ODW_ERR_INVALID, "odw_fetch_swapped_hits: bad argument");
   if (!ctx->swapping || !ctx->copy_stream) return fail(ctx, ODW_ERR_INVALID, "odw_fetch_swapped_hits: odw_swap_hit_lists first");

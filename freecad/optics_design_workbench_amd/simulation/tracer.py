@@ -202,15 +202,19 @@ class Tracer:
       return buf[:int(got.value)]
     # from the first swap on appends are dense (the rows of a list are copied as they lie)
     self._chk(self._lib.odw_swap_hit_lists(self._ctx), 'odw_swap_hit_lists')
-    k = -1
-    for k, (first, n) in enumerate(jobs):
-      self.resetHits()
-      self.trace(first, n, seed, histogram=histogram)       # asynchronous, into the current list
-      if k > 0:
-        yield fetch(k - 1)                                  # the list put aside: job k-1
-      self._chk(self._lib.odw_swap_hit_lists(self._ctx), 'odw_swap_hit_lists')
-    if k >= 0:
-      yield fetch(k)
+    try:
+      k = -1
+      for k, (first, n) in enumerate(jobs):
+        self.resetHits()
+        self.trace(first, n, seed, histogram=histogram)       # asynchronous, into the current list
+        if k > 0:
+          yield fetch(k - 1)                                  # the list put aside: job k-1
+        self._chk(self._lib.odw_swap_hit_lists(self._ctx), 'odw_swap_hit_lists')
+      if k >= 0:
+        yield fetch(k)
+    finally:
+      # back to one list: later launches reserve hit-list blocks per wave again
+      self._chk(self._lib.odw_release_swapped_hits(self._ctx), 'odw_release_swapped_hits')
 
   def deviceHits(self, group=None):
     """the recorded rows as a `Hits`-like object that bins them where they are, in HBM

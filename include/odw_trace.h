@@ -379,6 +379,9 @@ int odw_fetch_histogram(odw_ctx* ctx, uint64_t* out, uint64_t n_bins);
  * order); once lists are swapped appends are dense (no reserved blocks).    */
 int odw_swap_hit_lists(odw_ctx* ctx);
 int odw_fetch_swapped_hits(odw_ctx* ctx, odw_hit* out, uint64_t capacity, uint64_t* n);
+/* end of a streamed run: frees the list put aside; later launches reserve
+ * hit-list blocks per wave again (the current list and its rows stay)        */
+int odw_release_swapped_hits(odw_ctx* ctx);
 /* rows in the segment list and rows that did not fit into it               */
 int odw_segment_count(odw_ctx* ctx, uint64_t* n, uint64_t* dropped);
 /* copies the rows sorted by (ray index, ordinal); NULL out: count only      */
