@@ -1540,6 +1540,20 @@ int odw_swap_hit_lists(odw_ctx* ctx) {
   return ODW_OK;
 }
 
+int odw_host_alloc(odw_ctx* ctx, uint64_t bytes, void** out) {
+  if (!ctx || !out || bytes == 0) return fail(ctx, ODW_ERR_INVALID, "odw_host_alloc: bad argument");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  *out = nullptr;
+  HIPCHK(ctx, hipHostMalloc(out, bytes, hipHostMallocDefault));
+  return ODW_OK;
+}
+
+int odw_host_free(odw_ctx* ctx, void* p) {
+  if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_host_free: null ctx");
+  if (p) HIPCHK(ctx, hipHostFree(p));
+  return ODW_OK;
+}
+
 int odw_release_swapped_hits(odw_ctx* ctx) {
   if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_release_swapped_hits: null ctx");
   HIPCHK(ctx, hipSetDevice(ctx->device));

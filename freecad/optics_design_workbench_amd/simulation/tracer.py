@@ -36,6 +36,9 @@ class Tracer:
   # -- lifecycle ------------------------------------------------------------
   def close(self):
     if self._ctx:
+      for p in getattr(self, '_pinned', []):
+        self._lib.odw_host_free(self._ctx, p)
+      self._pinned = []
       self._lib.odw_destroy(self._ctx)
       self._ctx = C.c_void_p()
 
@@ -185,6 +188,17 @@ class Tracer:
                                        C.byref(got)), 'odw_fetch_hits')
     return out[:int(got.value)]
 
+  def hostRows(self, n):
+    """page-locked array of n hit rows (destination of row fetches: copied into directly by the
+    copy engine); freed with the tracer"""
+    p = C.c_void_p()
+    nbytes = int(n) * HIT_DTYPE.itemsize
+    self._chk(self._lib.odw_host_alloc(self._ctx, C.c_uint64(nbytes), C.byref(p)), 'odw_host_alloc')
+    self._pinned = getattr(self, '_pinned', [])
+    self._pinned.append(p)
+    buf = (C.c_char * nbytes).from_address(p.value)
+    return np.frombuffer(buf, dtype=HIT_DTYPE)
+
   def traceStreaming(self, jobs, seed, capacity, histogram=True, buffers=None):
     """generator: trace every (first, n) of `jobs` and yield each job's hit rows on the host, the
     copy of job k overlapping the trace of job k+1 (two device hit lists, a copy stream of its
@@ -192,7 +206,7 @@ class Tracer:
     across rays).  The arrays yielded are views of two alternating host buffers: use one before
     asking for the one after the next."""
     self.reserveHits(capacity)
-    host = buffers or [np.empty(int(capacity), dtype=HIT_DTYPE) for _ in range(2)]
+    host = buffers or [self.hostRows(capacity) for _ in range(2)]
     got = C.c_uint64(0)
 
     def fetch(k):

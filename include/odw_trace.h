@@ -382,6 +382,10 @@ int odw_fetch_swapped_hits(odw_ctx* ctx, odw_hit* out, uint64_t capacity, uint64
 /* end of a streamed run: frees the list put aside; later launches reserve
  * hit-list blocks per wave again (the current list and its rows stay)        */
 int odw_release_swapped_hits(odw_ctx* ctx);
+/* page-locked host memory for the destination of row fetches (the copy engine
+ * writes it directly: no staging through the runtime's own pinned buffers)  */
+int odw_host_alloc(odw_ctx* ctx, uint64_t bytes, void** out);
+int odw_host_free(odw_ctx* ctx, void* p);
 /* rows in the segment list and rows that did not fit into it               */
 int odw_segment_count(odw_ctx* ctx, uint64_t* n, uint64_t* dropped);
 /* copies the rows sorted by (ray index, ordinal); NULL out: count only      */
