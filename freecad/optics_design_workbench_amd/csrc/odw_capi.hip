@@ -54,6 +54,7 @@ struct odw_ctx {
   std::vector<int32_t> h_cond;            // prim | inside << 31
   bool have_scene = false, have_source = false, have_limits = false;
   bool bvh_dirty = true;
+  bool lean = false;                       // no grating group, no finite absorption length: LEAN kernels
 
   DevBuf prim_f64, prim_hdr, prim_i32, cond_i32, group_f64, group_i32, group_gdir, seq_mask;
   DevBuf bvh_nodes, bvh_prims, tri_nrm;
@@ -768,6 +769,7 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
     else hipLaunchKernelGGL((odw_trace_kernel<true, false, false>), dim3(grid), dim3(256), lds, ctx->stream, P);
   } else {
     if (stoch) hipLaunchKernelGGL((odw_trace_kernel<false, true, false>), dim3(grid), dim3(256), 0, ctx->stream, P);
+    else if (ctx->lean) hipLaunchKernelGGL((odw_trace_kernel<false, false, false, true>), dim3(grid), dim3(256), 0, ctx->stream, P);
     else hipLaunchKernelGGL((odw_trace_kernel<false, false, false>), dim3(grid), dim3(256), 0, ctx->stream, P);
   }
   HIPCHK(ctx, hipGetLastError());

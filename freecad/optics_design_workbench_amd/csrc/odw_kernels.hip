@@ -1099,7 +1099,9 @@ template <> struct HitBlockState<false> {
 #ifndef ODW_WAVES_PER_SIMD_BVH
 #define ODW_WAVES_PER_SIMD_BVH 4
 #endif
-template <bool BVH, bool STOCH, bool SEG>
+// LEAN: the scene has no grating group and no finite absorption length (the host checks): their code
+// -- line_grating's chain of IEEE divisions and square roots, exp() -- is left out of the binary
+template <bool BVH, bool STOCH, bool SEG, bool LEAN = false>
 __global__ __launch_bounds__(256, BVH ? ODW_WAVES_PER_SIMD_BVH : ODW_WAVES_PER_SIMD) void odw_trace_kernel(const TraceParams P) {
   extern __shared__ int bvh_stack[];  // ODW_BVH_STACK x 256 ints (BVH variant only)
   // per-thread event counters live in LDS (one column per thread, ds_add_u32
@@ -1206,7 +1208,7 @@ __global__ __launch_bounds__(256, BVH ? ODW_WAVES_PER_SIMD_BVH : ODW_WAVES_PER_S
       ci32 pi = sv.prim_i32 + 4 * prim;
       point = point + dir * t_hit;
       // absorption along the traversed medium (ray.py:120-125, assignment)
-      if (medium >= 0) {
+      if (!LEAN && medium >= 0) {
         const double L = group_f64[4 * medium + 2];
         if (L == 0) power = 0;
         else if (L < INFINITY) power = exp(-t_hit / L);
@@ -1252,7 +1254,7 @@ __global__ __launch_bounds__(256, BVH ? ODW_WAVES_PER_SIMD_BVH : ODW_WAVES_PER_S
       } else if (gtype == ODW_OPT_ABSORBER) {
         power = 0;
         ++seq;
-      } else if (gtype == ODW_OPT_VACUUM) {
+      } else if (LEAN || gtype == ODW_OPT_VACUUM) {
         ++seq;
       } else {  // grating (ray.py:216-268)
         const d3 gd = mk(group_gdir[3 * g], group_gdir[3 * g + 1], group_gdir[3 * g + 2]);
