@@ -44,14 +44,14 @@ RAY_STATE_BYTES = 64    # S, read + written once per segment
 HIT_BYTES = 64          # H, one row per recorded hit
 
 CONFIGS = {
-    'c3': dict(scene='lensesAndMirrors', rays=1e8, steps=5, warmup=1, kernel='odw_trace_kernel<false, false, false>',
+    'c3': dict(scene='lensesAndMirrors', rays=1e8, steps=5, warmup=1, kernel='odw_trace_kernel<false, false, false, true>',
                workload='benchmark/lensesAndMirrors.FCStd, %.0e Monte-Carlo rays per step per GPU (BASELINE configs[2]), '
                         'Gaussian point source sigma=1e-2, Philox4x32-10 seed 0x0D15EA5E'),
     'c4': dict(scene='hugeArray', rays=1.25e8, steps=3, warmup=1, kernel='odw_grid_kernel<true, true>',
                workload='benchmark/hugeArray.FCStd (1500 spheres, grid kernel), %.3e Monte-Carlo rays per step per GPU = '
                         'the 1/8 share of 1e9 (BASELINE configs[3]), Gaussian point source sigma=0.2, one RCCL '
                         'histogram reduce'),
-    'c5': dict(scene='GettingStarted', rays=1e7, steps=1, warmup=0, kernel='odw_trace_kernel<false, false, false>',
+    'c5': dict(scene='GettingStarted', rays=1e7, steps=1, warmup=0, kernel='odw_trace_kernel<false, false, false, true>',
                workload='examples/1-getting-started/GettingStarted.FCStd, spherical-lens radius sweep: 64 radii '
                         'linspace(9, 11, 64) x %.0e Monte-Carlo rays each per step (BASELINE configs[4]), spot size = '
                         'calcFwhm of optimize-spotsize.ipynb per radius'),

@@ -28,7 +28,7 @@ ap.add_argument('--config', default='c3')
 ap.add_argument('--no-bench', action='store_true')
 args = ap.parse_args()
 tag = args.tag
-KERNEL_LIKE = {'c3': '%odw_trace_kernel<false, false, false>%', 'c4': '%odw_grid_kernel%'}[args.config]
+KERNEL_LIKE = {'c3': '%odw_trace_kernel<false, false, false%', 'c4': '%odw_grid_kernel%'}[args.config]
 out = os.path.join(ROOT, 'gpurun_out')
 os.makedirs(out, exist_ok=True)
 env = dict(os.environ, TMPDIR='/tmp')
@@ -80,7 +80,7 @@ if rows and cols:
   ci = {c.lower(): k for k, c in enumerate(cols)}
   for r in rows:
     nm = str(r[ci.get('name', 0)])
-    if ('odw_grid_kernel' in nm) if args.config == 'c4' else ('odw_trace_kernel<false, false, false>' in nm):
+    if ('odw_grid_kernel' in nm) if args.config == 'c4' else ('odw_trace_kernel<false, false, false' in nm):
       for key in ('average', 'avg', 'averagens', 'average_ns'):
         if key in ci:
           kernel_ms = float(r[ci[key]]) / 1e3          # the view reports microseconds
