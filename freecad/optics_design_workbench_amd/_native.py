@@ -17,10 +17,12 @@ LIB_PATH = os.path.join(CSRC, 'libodw_trace.so')
 _SOURCES = ['odw_capi.hip', 'odw_kernels.hip', 'odw_grid.hip', 'odw_posthoc.hip', 'odw_device.h']
 _HEADER = os.path.normpath(os.path.join(_HERE, '..', '..', 'include', 'odw_trace.h'))
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 CNT_NAMES = ['traced_rays', 'recorded_hits', 'segments', 'escaped', 'died', 'capped',
              'hist_overflow', 'hits_dropped', 'grating_in_medium']
 TRACE_RECORD_HITS, TRACE_HISTOGRAM, TRACE_RECORD_SEGMENTS = 1, 2, 4
+COMPILE_OFF, COMPILE_STRUCTURE, COMPILE_VALUES = 0, 1, 2
+COMPILE_MODES = {None: 0, False: 0, 'off': 0, 0: 0, 'structure': 1, 1: 1, True: 1, 'values': 2, 2: 2}
 ERRORS = {1: 'invalid argument', 2: 'device error', 3: 'no scene', 4: 'capacity', 5: 'unsupported'}
 
 HIT_DTYPE = np.dtype([('point', '<f8', 3), ('direction', '<f8', 3), ('power', '<f8'), ('tag', '<u8')])
@@ -32,7 +34,8 @@ SYMBOLS = ['odw_abi_version', 'odw_create', 'odw_destroy', 'odw_last_error', 'od
            'odw_trace_rays', 'odw_sync', 'odw_reset_results', 'odw_reset_hits', 'odw_fetch_counters', 'odw_hit_count',
            'odw_fetch_hits', 'odw_fetch_histogram', 'odw_segment_count', 'odw_fetch_segments', 'odw_reset_segments', 'odw_sample', 'odw_device_histogram',
            'odw_device_counters', 'odw_stream', 'odw_timing_enable', 'odw_timing_read',
-           'odw_swap_hit_lists', 'odw_fetch_swapped_hits', 'odw_release_swapped_hits', 'odw_host_alloc', 'odw_host_free', 'odw_load_hits', 'odw_hits_select', 'odw_hits_gather', 'odw_hits_project', 'odw_hits_range', 'odw_hits_bin', 'odw_hits_moments']
+           'odw_swap_hit_lists', 'odw_fetch_swapped_hits', 'odw_release_swapped_hits', 'odw_host_alloc', 'odw_host_free', 'odw_load_hits', 'odw_hits_select', 'odw_hits_gather', 'odw_hits_project', 'odw_hits_range', 'odw_hits_bin', 'odw_hits_moments',
+           'odw_compile_scene', 'odw_compiled_info', 'odw_compile_check']
 
 _pd = C.POINTER(C.c_double)
 _pi = C.POINTER(C.c_int32)
@@ -186,6 +189,23 @@ def scene_desc(sc):
       raise ValueError('tri_edges needs one entry per primitive')
     d.tri_edges = keep['tri_edges'].ctypes.data_as(_pi)
   return d, keep
+
+
+def compile_check(scene, limits, mode='structure', arch=None):
+  """Host only (no GPU): the header of constants the library writes for `scene` and the size of the
+  code object hiprtc builds from it for `arch` (default gfx950).  Raises NativeError when the scene
+  is outside the flat kernel's domain or the compilation fails."""
+  d, keep = scene_desc(scene)
+  lim = LimitsDesc(float(limits.max_ray_length), int(limits.max_intersections), float(limits.dist_tol),
+                   float(limits.power_tol))
+  buf = C.create_string_buffer(1 << 20)
+  size = C.c_uint64(0)
+  f = lib().odw_compile_check
+  f.argtypes = [C.POINTER(SceneDesc), C.POINTER(LimitsDesc), C.c_int32, C.c_char_p, C.c_char_p, C.c_uint64,
+                C.POINTER(C.c_uint64)]
+  rc = f(C.byref(d), C.byref(lim), COMPILE_MODES[mode], arch.encode() if arch else None, buf, len(buf), C.byref(size))
+  check(None, rc, 'odw_compile_check')
+  return buf.value.decode(), int(size.value)
 
 
 def source_desc(src):

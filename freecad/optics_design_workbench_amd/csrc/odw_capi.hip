@@ -52,6 +52,18 @@ struct odw_ctx {
   std::vector<double> h_prim_f64;
   std::vector<int32_t> h_prim_i32;
   std::vector<int32_t> h_cond;            // prim | inside << 31
+  std::vector<double> h_prim_hdr;         // 64-byte headers (boxes + the four integers), built with the BVH
+  std::vector<char> h_dead;               // primitives no ray can meet (no face, or an empty box)
+  std::vector<double> h_group_f64, h_group_gdir;
+  std::vector<int32_t> h_group_i32;
+  std::vector<uint64_t> h_seq;
+  // scene-compiled flat kernel (odw_spec.hip)
+  int compile_mode = 0;                    // ODW_COMPILE_*: sticky, applies to every scene uploaded later too
+  bool spec_dirty = true;                  // scene / limits changed since the last binding attempt
+  hipFunction_t spec_fn = nullptr;         // bound kernel (owned by the process-wide cache), or null
+  bool spec_lean = false;
+  double spec_seconds = 0;                 // compile time of the bound kernel (0: it came from a cache)
+  int spec_cache_hit = 0;                  // 0 compiled now, 1 process cache, 2 disk cache
   bool have_scene = false, have_source = false, have_limits = false;
   bool bvh_dirty = true;
   bool lean = false;                       // no grating group, no finite absorption length: LEAN kernels
@@ -540,21 +552,21 @@ int build_grid(odw_ctx* ctx, const std::vector<Box>& boxes, const std::vector<ch
   return ODW_OK;
 }
 
-int build_bvh(odw_ctx* ctx) {
+// the primitives' boxes and 64-byte headers (host only: ctx->h_prim_hdr, ctx->h_dead)
+void compute_boxes(odw_ctx* ctx, std::vector<Box>& boxes, std::vector<char>& dead) {
   const int n = ctx->P.scene.n_prims;
-  ctx->P.scene.n_nodes = 0;
-  ctx->bvh_dirty = false;
   // boxes contain every point the tolerance rules may accept
   const double slack = 2.0 * (ctx->have_limits ? ctx->P.lim.dist_tol : 1e-2);
-  std::vector<Box> boxes(n);
-  std::vector<double> flat((size_t)std::max(1, n) * 8, 0.0);   // 64-byte headers
+  boxes.assign(n, Box());
+  std::vector<double>& flat = ctx->h_prim_hdr;
+  flat.assign((size_t)std::max(1, n) * 8, 0.0);   // 64-byte headers
   for (int p = 0; p < n; ++p)
     boxes[p] = world_box(ctx->h_prim_f64.data() + 16 * (size_t)p, ctx->h_prim_i32[4 * p], slack);
   // A face that exists only inside other primitives (operands of a Common, the base of a Cut for
   // its tool) lies in their boxes too: the box of a lens cap is the lens, not the sphere.
   // Primitives without faces (pure operands) and faces that cannot exist get a box no ray meets.
   std::vector<Box> full = boxes;
-  std::vector<char> dead(n, 0);
+  dead.assign(n, 0);
   for (int p = 0; p < n; ++p) {
     const int cw = ctx->h_prim_i32[4 * p + 3], off = cw & 0xffffff, cnt = (cw >> 24) & 0xff;
     for (int c = off; c < off + cnt && c < (int)ctx->h_cond.size(); ++c) {
@@ -574,6 +586,18 @@ int build_bvh(odw_ctx* ctx) {
     for (int a = 0; a < 3; ++a) { h[a] = boxes[p].lo[a]; h[3 + a] = boxes[p].hi[a]; }
     std::memcpy(h + 6, &ctx->h_prim_i32[4 * (size_t)p], 4 * sizeof(int32_t));
   }
+  ctx->h_dead = dead;
+}
+
+int build_bvh(odw_ctx* ctx) {
+  const int n = ctx->P.scene.n_prims;
+  ctx->P.scene.n_nodes = 0;
+  ctx->bvh_dirty = false;
+  ctx->spec_dirty = true;
+  std::vector<Box> boxes;
+  std::vector<char> dead;
+  compute_boxes(ctx, boxes, dead);
+  const std::vector<double>& flat = ctx->h_prim_hdr;
   {
     int rc = upload(ctx, ctx->prim_hdr, flat.data(), flat.size() * sizeof(double));
     if (rc) return rc;
@@ -667,6 +691,10 @@ __global__ void hit_gather_kernel(const odw_hit* __restrict__ hits, const uint32
   }
 }
 
+}  // namespace
+#include "odw_spec.hip"
+namespace {
+
 int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32_t flags,
                  const double* ray_o, const double* ray_d, const double* ray_p) {
   const bool explicit_rays = ray_o != nullptr;
@@ -676,6 +704,10 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
   ctx->ph_valid = false;           // the hit list is about to change
   if (ctx->bvh_dirty) {
     int rc = build_bvh(ctx);
+    if (rc) return rc;
+  }
+  if (ctx->spec_dirty) {
+    int rc = spec_bind(ctx);
     if (rc) return rc;
   }
   if ((flags & ODW_TRACE_RECORD_HITS) && ctx->hit_capacity == 0)
@@ -769,6 +801,7 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
     else hipLaunchKernelGGL((odw_trace_kernel<true, false, false>), dim3(grid), dim3(256), lds, ctx->stream, P);
   } else {
     if (stoch) hipLaunchKernelGGL((odw_trace_kernel<false, true, false>), dim3(grid), dim3(256), 0, ctx->stream, P);
+    else if (ctx->spec_fn && ctx->spec_lean == ctx->lean) { int rc = spec_launch(ctx, grid); if (rc) return rc; }
     else if (ctx->lean) hipLaunchKernelGGL((odw_trace_kernel<false, false, false, true>), dim3(grid), dim3(256), 0, ctx->stream, P);
     else hipLaunchKernelGGL((odw_trace_kernel<false, false, false>), dim3(grid), dim3(256), 0, ctx->stream, P);
   }
@@ -881,7 +914,8 @@ void odw_destroy(odw_ctx* ctx) {
   delete ctx;
 }
 
-int odw_upload_scene(odw_ctx* ctx, const odw_scene_desc* s) {
+// host half of odw_upload_scene: validation and the host copies of every table (no device call)
+static int scene_host_tables(odw_ctx* ctx, const odw_scene_desc* s) {
   if (!ctx || !s) return fail(ctx, ODW_ERR_INVALID, "odw_upload_scene: null argument");
   if (s->n_prims < 0 || s->n_groups < 0 || s->n_groups > ODW_MAX_GROUPS || s->seq_len < 0 ||
       s->seq_len > ODW_MAX_SEQUENCE || s->n_conds < 0 || s->n_conds >= (1 << 24))
@@ -892,7 +926,6 @@ int odw_upload_scene(odw_ctx* ctx, const odw_scene_desc* s) {
       (s->n_groups > 0 && (!s->group_type || !s->group_ior || !s->group_refl || !s->group_abslen || !s->group_record)) ||
       (s->seq_len > 0 && !s->seq_mask))
     return fail(ctx, ODW_ERR_INVALID, "odw_upload_scene: null table pointer");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
   const int n = s->n_prims;
   int max_solid = 0;
   for (int p = 0; p < n && s->prim_solid; ++p) max_solid = std::max(max_solid, s->prim_solid[p]);
@@ -961,6 +994,9 @@ int odw_upload_scene(odw_ctx* ctx, const odw_scene_desc* s) {
   ctx->h_cond = cond;
   std::vector<double> gf(ODW_MAX_GROUPS * 4, 0.0), gd(ODW_MAX_GROUPS * 3, 0.0);
   std::vector<int32_t> gi(ODW_MAX_GROUPS * 4, 0);
+  ctx->lean = getenv("ODW_NO_LEAN") == nullptr;
+  for (int g = 0; g < s->n_groups; ++g)
+    if (s->group_type[g] == ODW_OPT_GRATING || !(s->group_abslen[g] == INFINITY)) ctx->lean = false;
   for (int g = 0; g < s->n_groups; ++g) {
     if (s->group_type[g] < ODW_OPT_MIRROR || s->group_type[g] > ODW_OPT_VACUUM)
       return fail(ctx, ODW_ERR_INVALID, "unknown optical type");
@@ -976,7 +1012,30 @@ int odw_upload_scene(odw_ctx* ctx, const odw_scene_desc* s) {
   }
   std::vector<uint64_t> seq((size_t)std::max(1, s->seq_len), 0);
   for (int i = 0; i < s->seq_len; ++i) seq[i] = s->seq_mask[i];
-  int rc;
+  ctx->h_group_f64 = gf;
+  ctx->h_group_i32 = gi;
+  ctx->h_group_gdir = gd;
+  ctx->h_seq = seq;
+  DeviceScene& d = ctx->P.scene;
+  d.n_prims = n;
+  d.n_groups = s->n_groups;
+  d.n_nodes = 0;
+  d.seq_enabled = s->seq_enabled ? 1 : 0;
+  d.seq_len = s->seq_len;
+  d.all_mask = (s->n_groups >= 64) ? ~0ull : ((1ull << s->n_groups) - 1ull);
+  d.ignore_mask = s->ignore_mask;
+  return ODW_OK;
+}
+
+int odw_upload_scene(odw_ctx* ctx, const odw_scene_desc* s) {
+  int rc = scene_host_tables(ctx, s);
+  if (rc) return rc;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const int n = s->n_prims;
+  const std::vector<int32_t>& cond = ctx->h_cond;
+  const std::vector<double>&gf = ctx->h_group_f64, &gd = ctx->h_group_gdir;
+  const std::vector<int32_t>& gi = ctx->h_group_i32;
+  const std::vector<uint64_t>& seq = ctx->h_seq;
   if ((rc = upload(ctx, ctx->prim_f64, ctx->h_prim_f64.data(), ctx->h_prim_f64.size() * sizeof(double)))) return rc;
   if ((rc = upload(ctx, ctx->prim_i32, ctx->h_prim_i32.data(), ctx->h_prim_i32.size() * sizeof(int32_t)))) return rc;
   if ((rc = upload(ctx, ctx->cond_i32, cond.data(), cond.size() * sizeof(int32_t)))) return rc;
@@ -997,16 +1056,62 @@ int odw_upload_scene(odw_ctx* ctx, const odw_scene_desc* s) {
   d.group_i32 = (const int32_t*)ctx->group_i32.p;
   d.group_gdir = (const double*)ctx->group_gdir.p;
   d.seq_mask = (const uint64_t*)ctx->seq_mask.p;
-  d.n_prims = n;
-  d.n_groups = s->n_groups;
-  d.n_nodes = 0;
-  d.seq_enabled = s->seq_enabled ? 1 : 0;
-  d.seq_len = s->seq_len;
-  d.all_mask = (s->n_groups >= 64) ? ~0ull : ((1ull << s->n_groups) - 1ull);
-  d.ignore_mask = s->ignore_mask;
   ctx->have_scene = true;
   ctx->bvh_dirty = true;
+  ctx->spec_dirty = true;
+  ctx->spec_fn = nullptr;
   ctx->n_samplers = 0;   // surface samplers belong to the previous scene's groups
+  return ODW_OK;
+}
+
+int odw_compile_scene(odw_ctx* ctx, int32_t mode) {
+  if (!ctx || mode < ODW_COMPILE_OFF || mode > ODW_COMPILE_VALUES) return fail(ctx, ODW_ERR_INVALID, "odw_compile_scene: bad argument");
+  ctx->compile_mode = mode;
+  ctx->spec_dirty = true;
+  ctx->spec_fn = nullptr;
+  if (mode == ODW_COMPILE_OFF || !ctx->have_scene || !ctx->have_limits) return ODW_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (ctx->bvh_dirty) {
+    int rc = build_bvh(ctx);
+    if (rc) return rc;
+  }
+  return spec_bind(ctx);
+}
+
+int odw_compiled_info(odw_ctx* ctx, int32_t* bound, double* compile_seconds, int32_t* cache_hit) {
+  if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_compiled_info: null context");
+  if (bound) *bound = (ctx->spec_fn && !ctx->spec_dirty && !ctx->bvh_dirty) ? ctx->compile_mode : 0;
+  if (compile_seconds) *compile_seconds = ctx->spec_seconds;
+  if (cache_hit) *cache_hit = ctx->spec_cache_hit;
+  return ODW_OK;
+}
+
+int odw_compile_check(const odw_scene_desc* scene, const odw_limits* limits, int32_t mode, const char* arch,
+                      char* header_out, uint64_t header_capacity, uint64_t* code_bytes) {
+  if (!scene || !limits || mode < ODW_COMPILE_STRUCTURE || mode > ODW_COMPILE_VALUES)
+    return fail(nullptr, ODW_ERR_INVALID, "odw_compile_check: bad argument");
+  odw_ctx tmp;                     // host tables only: no device, no stream
+  std::memset(&tmp.P, 0, sizeof tmp.P);
+  int rc = scene_host_tables(&tmp, scene);
+  if (rc) return rc;
+  tmp.P.lim.dist_tol = limits->dist_tol;
+  tmp.have_limits = true;
+  std::vector<Box> boxes;
+  std::vector<char> dead;
+  compute_boxes(&tmp, boxes, dead);
+  const std::string why = spec_ineligible(&tmp);
+  if (!why.empty()) return fail(nullptr, ODW_ERR_UNSUPPORTED, "odw_compile_check: " + why);
+  const std::string text = spec_text(&tmp, mode);
+  if (header_out && header_capacity) {
+    const size_t k = std::min<size_t>(text.size(), (size_t)header_capacity - 1);
+    std::memcpy(header_out, text.data(), k);
+    header_out[k] = 0;
+  }
+  std::vector<char> code;
+  std::string err;
+  if (!spec_compile(text, mode == ODW_COMPILE_VALUES, arch && *arch ? arch : "gfx950", code, err))
+    return fail(nullptr, ODW_ERR_DEVICE, err);
+  if (code_bytes) *code_bytes = code.size();
   return ODW_OK;
 }
 
@@ -1294,7 +1399,7 @@ int odw_set_limits(odw_ctx* ctx, const odw_limits* l) {
   if (!ctx || !l) return fail(ctx, ODW_ERR_INVALID, "odw_set_limits: null argument");
   if (!(l->dist_tol > 0) || l->max_intersections < 0 || !(l->max_ray_length > 0))
     return fail(ctx, ODW_ERR_INVALID, "odw_set_limits: values out of range");
-  if (!ctx->have_limits || ctx->P.lim.dist_tol != l->dist_tol) ctx->bvh_dirty = true;
+  if (!ctx->have_limits || ctx->P.lim.dist_tol != l->dist_tol) ctx->bvh_dirty = true;   // (the boxes carry the tolerance; a compiled scene is bound again after the rebuild)
   ctx->P.lim.max_ray_length = l->max_ray_length;
   ctx->P.lim.max_intersections = l->max_intersections;
   ctx->P.lim.dist_tol = l->dist_tol;

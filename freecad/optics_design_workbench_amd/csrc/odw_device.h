@@ -14,10 +14,28 @@
 // indices, so hipcc emits scalar (s_load) loads: the scene costs SGPRs, not
 // VGPRs, and no LDS staging is needed for the small benchmark scenes.
 #pragma once
+#ifndef __HIPCC_RTC__      // (hiprtc brings the HIP runtime declarations and the fixed-width integers itself)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#else
+typedef signed char int8_t;
+typedef unsigned char uint8_t;
+typedef signed int int32_t;
+typedef unsigned int uint32_t;
+typedef signed long int64_t;
+typedef unsigned long uint64_t;
+typedef unsigned long uintptr_t;
+#endif
 
+#ifdef __HIPCC_RTC__        // (compiled at run time from the sources embedded in the library: flat names)
+#include "odw_trace.h"
+#else
 #include "../../../include/odw_trace.h"
+#endif
+
+#ifndef INFINITY          // (runtime compilation: no <math.h>)
+#define INFINITY (__builtin_inff())
+#endif
 
 namespace odw {
 

@@ -106,14 +106,14 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
   double* ring = grid_lds + ring_off + wave * ODW_GRID_RING_DOUBLES;      // slot s: origin (3), direction (3)
 
   SceneView sv;
-  sv.prim_f64 = as_const(sc.prim_f64);
-  sv.prim_hdr = as_const(sc.prim_hdr);
-  sv.prim_i32 = as_const(sc.prim_i32);
-  sv.cond_i32 = as_const(sc.cond_i32);
-  cf64 group_f64 = as_const(sc.group_f64);
-  ci32 group_i32 = as_const(sc.group_i32);
-  cf64 group_gdir = as_const(sc.group_gdir);
-  cu64 seq_mask = as_const(sc.seq_mask);
+  sv.prim_f64 = as_scene(sc.prim_f64);
+  sv.prim_hdr = as_scene(sc.prim_hdr);
+  sv.prim_i32 = as_scene(sc.prim_i32);
+  sv.cond_i32 = as_scene(sc.cond_i32);
+  cf64 group_f64 = as_scene(sc.group_f64);
+  ci32 group_i32 = as_scene(sc.group_i32);
+  cf64 group_gdir = as_scene(sc.group_gdir);
+  cu64 seq_mask = as_scene(sc.seq_mask);
 
   const uint32_t lane = __lane_id();
   uint64_t next = 0, chunk_end = 0;                        // wave-uniform: the wave's chunk of the launch
@@ -184,8 +184,8 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
           // next chunk of the launch: one atomic per wave and chunk
           unsigned long long c = 0;
           if (lane == 0) c = atomicAdd(P.out.chunk_counter, 1ull);
-          const uint64_t chunk = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(c >> 32)) << 32) |
-                                 __builtin_amdgcn_readfirstlane((uint32_t)c);
+          const uint64_t chunk = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(c >> 32)) << 32) |
+                                 (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)c);
           next = chunk * ODW_CHUNK;
           if (next >= P.n_rays) { next = P.n_rays; drained = true; }
           chunk_end = next + ODW_CHUNK < P.n_rays ? next + ODW_CHUNK : P.n_rays;

@@ -29,12 +29,23 @@ namespace odw {
 // primitive.  (Plain global pointers inside a by-value struct are not
 // provably unclobbered, and hipcc falls back to per-lane global_load.)
 #define ODW_CONST __attribute__((address_space(4)))
-typedef const double ODW_CONST* cf64;
-typedef const int32_t ODW_CONST* ci32;
-typedef const uint64_t ODW_CONST* cu64;
+// (a scene compiled with its values, odw_spec.hip, reads its tables from constant arrays of the
+// translation unit itself: plain pointers, every read with a constant index folds to a literal)
+#ifdef ODW_SPEC_VALUES
+#define ODW_SCENE_AS
+#else
+#define ODW_SCENE_AS ODW_CONST
+#endif
+typedef const double ODW_SCENE_AS* cf64;
+typedef const int32_t ODW_SCENE_AS* ci32;
+typedef const uint64_t ODW_SCENE_AS* cu64;
 template <class T>
 __device__ __forceinline__ const T ODW_CONST* as_const(const T* p) {
   return (const T ODW_CONST*)(uintptr_t)p;
+}
+template <class T>
+__device__ __forceinline__ const T ODW_SCENE_AS* as_scene(const T* p) {
+  return (const T ODW_SCENE_AS*)(uintptr_t)p;
 }
 // a uniform pointer the optimiser cannot see through: loads behind it stay
 // where they are written instead of being hoisted out of the ray loop
@@ -179,6 +190,63 @@ template <class P>
 __device__ __forceinline__ d3 xf_vec_t(P m, d3 v) {  // R^T v
   return mk(m[0] * v.x + m[4] * v.y + m[8] * v.z, m[1] * v.x + m[5] * v.y + m[9] * v.z,
             m[2] * v.x + m[6] * v.y + m[10] * v.z);
+}
+
+// ---- scene-compiled kernels (odw_spec.h) -----------------------------------
+// A SPEC class carries the STRUCTURE of one baked scene as compile-time constants: primitive types,
+// groups, flags, trimming lists, which entries of every global->local frame are exactly zero.  The
+// primitive loop of the flat kernel is then unrolled over it: type dispatch, face masks and condition
+// lists fold away, frame products skip their zero terms, and every table read has a constant offset
+// (no dependent scalar loads, no scalar branches).  All float64 VALUES (frames, parameters, boxes,
+// optical constants) are still read from the tables, so one compiled kernel serves every scene of the
+// same structure (a radius sweep compiles once).  NoSpec = the generic kernels.
+struct NoSpec {
+  static constexpr bool enabled = false, values = false;
+  static constexpr int N = 0;
+  static constexpr unsigned long long xf(int) { return 0xfffull; }
+  static constexpr int type(int) { return 0; }
+  static constexpr int cond(int) { return 0; }
+};
+// Frame products of a compiled scene.  XF = the pattern of a primitive's 12 frame entries: bits 0-11
+// entry != 0, bits 12-23 entry == +1, bits 24-35 entry == -1.  A term whose coefficient is exactly zero
+// is left out, a coefficient of +-1 becomes an addition / subtraction; the order of the remaining
+// operations is the generic one (second product first, then the first and third by fma, then the
+// translation), so the results are those of xf_point / xf_vec / xf_vec_t bit for bit (apart from the
+// sign of a zero).
+template <unsigned long long XF, int IA, int IB, int IC, int IT, class P>
+__device__ __forceinline__ double xf_comb(P m, double a, double b, double c) {
+  double acc = 0.0;
+  bool have = false;
+#define ODW_XF_TERM(I, V)                                                                            \
+  if constexpr (((XF >> (I)) & 1ull) != 0) {                                                         \
+    if constexpr (((XF >> (12 + (I))) & 1ull) != 0) acc = have ? acc + (V) : (V);                    \
+    else if constexpr (((XF >> (24 + (I))) & 1ull) != 0) acc = have ? acc - (V) : -(V);              \
+    else acc = have ? fma(m[I], (V), acc) : m[I] * (V);                                              \
+    have = true;                                                                                     \
+  }
+  ODW_XF_TERM(IB, b)
+  ODW_XF_TERM(IA, a)
+  ODW_XF_TERM(IC, c)
+#undef ODW_XF_TERM
+  if constexpr (IT >= 0) {
+    if constexpr (((XF >> (IT < 0 ? 0 : IT)) & 1ull) != 0) acc = have ? m[IT < 0 ? 0 : IT] + acc : m[IT < 0 ? 0 : IT];
+  }
+  return acc;
+}
+template <unsigned long long XF, class P>
+__device__ __forceinline__ d3 xf_point_nz(P m, d3 p) {
+  return mk(xf_comb<XF, 0, 1, 2, 3>(m, p.x, p.y, p.z), xf_comb<XF, 4, 5, 6, 7>(m, p.x, p.y, p.z),
+            xf_comb<XF, 8, 9, 10, 11>(m, p.x, p.y, p.z));
+}
+template <unsigned long long XF, class P>
+__device__ __forceinline__ d3 xf_vec_nz(P m, d3 v) {
+  return mk(xf_comb<XF, 0, 1, 2, -1>(m, v.x, v.y, v.z), xf_comb<XF, 4, 5, 6, -1>(m, v.x, v.y, v.z),
+            xf_comb<XF, 8, 9, 10, -1>(m, v.x, v.y, v.z));
+}
+template <unsigned long long XF, class P>
+__device__ __forceinline__ d3 xf_vec_t_nz(P m, d3 v) {  // R^T v
+  return mk(xf_comb<XF, 0, 4, 8, -1>(m, v.x, v.y, v.z), xf_comb<XF, 1, 5, 9, -1>(m, v.x, v.y, v.z),
+            xf_comb<XF, 2, 6, 10, -1>(m, v.x, v.y, v.z));
 }
 
 // sin and cos for |x| <~ 64 (source angles are domain-limited): one Cody-Waite
@@ -341,6 +409,35 @@ __device__ __forceinline__ void consider(const SceneView& sv, Query& q, double t
   if (cand_oth) { q.oth.t = t; q.oth.prim = p; q.oth.face = face; }
 }
 
+// the same for primitive PI of a compiled scene: group and trimming list are constants, the list is
+// unrolled, every operand's frame product skips its zero terms
+template <bool PARAB, class SPEC, int C, int END>
+__device__ __forceinline__ bool trim_ok(const SceneView& sv, const Query& q, d3 gp) {
+  if constexpr (C >= END) {
+    return true;
+  } else {
+    constexpr int cw = SPEC::cond(C);
+    constexpr int qp = cw & 0x7fffffff;
+    cf64 pf = sv.prim_f64 + (size_t)qp * 16;
+    const double sd = prim_sdist<PARAB>(SPEC::type(qp), pf + 12, xf_point_nz<SPEC::xf(qp)>(pf, gp));
+    if (cw < 0) { if (sd > q.tol) return false; }     // must be inside
+    else { if (sd < -q.tol) return false; }           // must be outside
+    return trim_ok<PARAB, SPEC, C + 1, END>(sv, q, gp);
+  }
+}
+template <bool PARAB, class SPEC, int PI>
+__device__ __forceinline__ void consider_spec(const SceneView& sv, Query& q, double t, int face) {
+  if (!(t > q.tol && t < q.tmax)) return;
+  const bool cand_any = better(t, PI, face, q.any);
+  const bool cand_oth = (SPEC::group(PI) != q.medium) && better(t, PI, face, q.oth);
+  if (!cand_any && !cand_oth) return;
+  if constexpr (SPEC::cond_cnt(PI) > 0) {
+    if (!trim_ok<PARAB, SPEC, SPEC::cond_off(PI), SPEC::cond_off(PI) + SPEC::cond_cnt(PI)>(sv, q, q.start + q.dn * t)) return;
+  }
+  if (cand_any) { q.any.t = t; q.any.prim = PI; q.any.face = face; }
+  if (cand_oth) { q.oth.t = t; q.oth.prim = PI; q.oth.face = face; }
+}
+
 // up to four candidate (t, face) pairs of one primitive, kept in registers
 struct Cands {
   double t0, t1, t2, t3;
@@ -371,7 +468,9 @@ __device__ __forceinline__ void cand_min2(Cands& c, double t, int f) {
 // natural face bounds with tolerance (ray.py:411-426).  The candidates are
 // collected first and judged by ONE copy of consider() (code size: the hot
 // loop must stay inside the instruction cache).
-template <bool PARAB = true>
+// SPEC / PI: primitive PI of a compiled scene -- the caller passes its constants as p, type, group,
+// flags, cond_word, so everything that depends on them folds
+template <bool PARAB = true, class SPEC = NoSpec, int PI = 0>
 __device__ __forceinline__ void intersect_prim(const SceneView& sv, Query& q, int p, int type, int group,
                                                int flags, int cond_word) {
   cf64 pf = sv.prim_f64 + (size_t)p * 16;
@@ -393,8 +492,14 @@ __device__ __forceinline__ void intersect_prim(const SceneView& sv, Query& q, in
       }
     }
   } else {
-  const d3 o = xf_point(pf, q.start);
-  const d3 d = xf_vec(pf, q.dn);
+  d3 o, d;
+  if constexpr (SPEC::enabled) {
+    o = xf_point_nz<SPEC::xf(PI)>(pf, q.start);
+    d = xf_vec_nz<SPEC::xf(PI)>(pf, q.dn);
+  } else {
+    o = xf_point(pf, q.start);
+    d = xf_vec(pf, q.dn);
+  }
   if (type == ODW_PRIM_BOX) {
     // Slab form of the six plane tests.  Per axis the ray meets the low/high
     // plane at tn <= tf; a face hit is valid when the other two coordinates lie
@@ -601,7 +706,16 @@ __device__ __forceinline__ void intersect_prim(const SceneView& sv, Query& q, in
     ODW_PICK(c.t2, c.f2)
     ODW_PICK(c.t3, c.f3)
 #undef ODW_PICK
-    consider<PARAB>(sv, q, bt, p, bf, group, 0, 0);
+    if constexpr (SPEC::enabled) consider_spec<PARAB, SPEC, PI>(sv, q, bt, bf);
+    else consider<PARAB>(sv, q, bt, p, bf, group, 0, 0);
+  } else if constexpr (SPEC::enabled) {
+    // (a sphere has two candidates; the trimming code exists once per candidate slot)
+    consider_spec<PARAB, SPEC, PI>(sv, q, c.t0, c.f0);
+    consider_spec<PARAB, SPEC, PI>(sv, q, c.t1, c.f1);
+    if constexpr (SPEC::type(PI) != ODW_PRIM_SPHERE) {
+      consider_spec<PARAB, SPEC, PI>(sv, q, c.t2, c.f2);
+      consider_spec<PARAB, SPEC, PI>(sv, q, c.t3, c.f3);
+    }
   } else {
 #pragma unroll 1
     for (int k = 0; k < 4; ++k) {
@@ -714,7 +828,28 @@ __device__ __forceinline__ bool ray_box(P bx, d3 oi, d3 inv, double tmax) {
 //            primitive culled by its bounding box first -- the analogue of the
 //            reference's shell/face BoundBox culls (ray.py:353-398);
 // BVH=true : stack traversal, node stack in LDS (one column per thread).
-template <bool BVH>
+// one primitive of a compiled scene (flat loop unrolled over SPEC)
+template <class SPEC, int PI>
+__device__ __forceinline__ void spec_prim(const SceneView& sv, Query& q, d3 oi, d3 inv, int skip_solid, uint64_t mask) {
+  constexpr int flags = SPEC::flags(PI);
+  // relevant groups: a constant without sequential mode (ignored groups' primitives leave no code),
+  // the ray's own mask with it
+  if constexpr (!SPEC::dead(PI) && (SPEC::seq() || ((SPEC::umask() >> SPEC::group(PI)) & 1) != 0)) {
+    if ((!SPEC::seq() || ((mask >> SPEC::group(PI)) & 1)) && (flags >> ODW_SOLID_SHIFT) != skip_solid) {
+      const double cut = fmin(q.tmax, q.any.t + 2.0 * q.tol);
+      if (ray_box(sv.prim_hdr + 8 * PI, oi, inv, cut))
+        intersect_prim<false, SPEC, PI>(sv, q, PI, SPEC::type(PI), SPEC::group(PI), flags, SPEC::cond_word(PI));
+    }
+  }
+}
+template <class T, T... I> struct IndexList {};      // (std::integer_sequence without <utility>: runtime compilation has no libstdc++)
+template <class SPEC, int... PI>
+__device__ __forceinline__ void spec_prims(const SceneView& sv, Query& q, d3 oi, d3 inv, int skip_solid, uint64_t mask,
+                                           IndexList<int, PI...>) {
+  (spec_prim<SPEC, PI>(sv, q, oi, inv, skip_solid, mask), ...);
+}
+
+template <bool BVH, class SPEC = NoSpec>
 __device__ __forceinline__ int nearest(const DeviceScene& sc, const SceneView& sv,
                                        const DeviceLimits& lim, d3 start, d3 dn, int medium,
                                        uint64_t mask, double& t_hit, int& face,
@@ -726,7 +861,9 @@ __device__ __forceinline__ int nearest(const DeviceScene& sc, const SceneView& s
   q.oth = q.any;
   const d3 inv = mk(frcp(dn.x), frcp(dn.y), frcp(dn.z));
   const d3 oi = mk(start.x * inv.x, start.y * inv.y, start.z * inv.z);
-  if (!BVH) {
+  if constexpr (SPEC::enabled) {
+    spec_prims<SPEC>(sv, q, oi, inv, skip_solid, mask, __make_integer_seq<IndexList, int, SPEC::N>{});
+  } else if (!BVH) {
     // without sequential mode the set of relevant groups is the same for
     // every ray: the test is scalar and skips a primitive for the whole wave
     const bool per_lane_mask = sc.seq_enabled != 0;
@@ -762,7 +899,7 @@ __device__ __forceinline__ int nearest(const DeviceScene& sc, const SceneView& s
     typedef float vf4 __attribute__((ext_vector_type(4)));
     typedef int vi4 __attribute__((ext_vector_type(4)));
     cf32 nodes = (cf32)(uintptr_t)sc.bvh_nodes;
-    ci32 bvh_prims = as_const(sc.bvh_prims);
+    ci32 bvh_prims = as_scene(sc.bvh_prims);
     const float ofx = (float)start.x, ofy = (float)start.y, ofz = (float)start.z;
     const float ivx = (float)inv.x, ivy = (float)inv.y, ivz = (float)inv.z;
     int sp = 0;
@@ -972,10 +1109,45 @@ __device__ __noinline__ void next_hit_block(odw_hit* hits, uint64_t capacity, un
 
 // cnt: the thread's (CS = 256: a column of the block's table, plain adds) or the wave's (CS = 1,
 // CA: ds_add) event counters
-template <bool BLOCKS, int CS = 256, bool CA = false>
-__device__ __forceinline__ void record_hit(const TraceParams& P, uint64_t ray, int group, d3 p, d3 d,
+// Detector histogram: the counts are u64 in HBM, and a global atomic executes at the memory side
+// (every add one uncached request; adds to the same few lines queue there).  A focused beam puts most
+// of its hits into a few thousand bins -- 1e8 such adds cap a launch at ~6.5e9 rays/s (measured) --, so
+// the flat kernels keep a WINDOW of ODW_HIST_WIN x ODW_HIST_WIN bins of the histogram per block in LDS
+// (u32 counts, ds_add): the first recorded hit of the block centres it, hits inside it cost an LDS
+// add, hits outside still go to HBM, and every block adds its window to the histogram once, when it
+// ends.  Integer sums: the histogram is the same whichever way a hit was counted.
+// win: [0] 0 = no window yet, ~0 = being opened, else first bin in x + 1; [1] first bin in y;
+//      [4 ...] counts (x major)
+#ifndef ODW_HIST_WIN
+#define ODW_HIST_WIN 88
+#endif
+// the block's first recorded hit opens the window around its bin (once per block and launch: out of line)
+__device__ __forceinline__ void hist_window_open(uint32_t* win, int ix, int iy, int nx, int ny) {
+  if (atomicCAS(win, 0u, ~0u) == 0u) {
+    volatile uint32_t* vw = win;
+    vw[1] = (uint32_t)max(0, min(iy - ODW_HIST_WIN / 2, ny - ODW_HIST_WIN));
+    vw[0] = (uint32_t)max(0, min(ix - ODW_HIST_WIN / 2, nx - ODW_HIST_WIN)) + 1u;
+  }
+}
+// true: the hit was counted in the window
+__device__ __forceinline__ bool hist_window_add(uint32_t* win, int ix, int iy, int nx, int ny) {
+  volatile uint32_t* vw = win;
+  uint32_t x1 = vw[0];
+  if (x1 == 0u) {
+    hist_window_open(win, ix, iy, nx, ny);
+    x1 = vw[0];
+  }
+  if (x1 == 0u || x1 == ~0u) return false;     // another wave is opening it: this hit goes to HBM
+  const uint32_t dx = (uint32_t)ix - (x1 - 1u), dy = (uint32_t)iy - vw[1];
+  if (dx >= (uint32_t)ODW_HIST_WIN || dy >= (uint32_t)ODW_HIST_WIN) return false;
+  atomicAdd(win + 4 + dx * ODW_HIST_WIN + dy, 1u);
+  return true;
+}
+// PT: TraceParams, or TraceParams in the constant address space (the kernel's argument segment)
+template <bool BLOCKS, int CS = 256, bool CA = false, class PT>
+__device__ __forceinline__ void record_hit(const PT& P, uint64_t ray, int group, d3 p, d3 d,
                                            double power, bool entering, uint32_t* cnt,
-                                           volatile uint32_t* hit_state) {
+                                           volatile uint32_t* hit_state, uint32_t* win = nullptr) {
   if (P.flags & ODW_TRACE_RECORD_HITS) {
     const uint64_t active = __ballot(1);
     const int lane = __lane_id();
@@ -1030,14 +1202,31 @@ __device__ __forceinline__ void record_hit(const TraceParams& P, uint64_t ray, i
       const double y = dot(r, mk(det->ey[0], det->ey[1], det->ey[2]));
       const double fx = floor((x - det->x_lo) * det->x_scale);
       const double fy = floor((y - det->y_lo) * det->y_scale);
-      if (fx >= 0 && fx < det->nx_f && fy >= 0 && fy < det->ny_f)
-        atomicAdd(P.out.hist + ((size_t)fx * (size_t)det->ny + (size_t)fy), 1ull);
-      else if (CA)
+      if (fx >= 0 && fx < det->nx_f && fy >= 0 && fy < det->ny_f) {
+        const int ix = (int)fx, iy = (int)fy;
+        if (!(win && hist_window_add(win, ix, iy, det->nx, det->ny)))
+          atomicAdd(P.out.hist + ((size_t)ix * (size_t)det->ny + (size_t)iy), 1ull);
+      } else if (CA)
         atomicAdd(&cnt[ODW_CNT_HIST_OVERFLOW * CS], 1u);
       else
         cnt[ODW_CNT_HIST_OVERFLOW * CS] += 1u;
     }
   }
+}
+
+// K5 of the flat kernels, out of line: a ray records once or twice in its life, and inlined into the
+// recording branches this code decides the register allocation of the whole ray loop (30 more spilled
+// VGPRs with the histogram window, measured).  kargs: the kernel's argument segment (TraceParams is
+// the kernels' only argument; the pointer is taken in the kernel, a callee cannot ask for it).
+typedef const TraceParams ODW_CONST* ckargs;
+__device__ __noinline__ void record_hit_flat(ckargs kargs, uint64_t ray, int group, d3 p, d3 d, double power,
+                                             bool entering, uint32_t* cnt, uint32_t* hit_state, uint32_t* win) {
+  // (arguments arrive in vector registers: the pointer is wave-uniform, say so -- scalar loads again)
+  const uint64_t a = (uint64_t)(uintptr_t)kargs;
+  // (the builtin returns int: without the casts the low word is sign-extended over the high one)
+  const uint64_t u = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(a >> 32)) << 32) |
+                     (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)a);
+  record_hit<true>(*(ckargs)(uintptr_t)u, ray, group, p, d, power, entering, cnt, hit_state, win);
 }
 
 // RecordRays (generic_source.py:78-118): one row per segment Ray.traceRay yields.  Only a
@@ -1075,10 +1264,109 @@ __device__ __noinline__ RayInit generate_ray(const DeviceSource* sp, uint64_t ra
   return r;
 }
 
+// K3 for one hit, the part that depends on the optical group: recording, mirror / Snell / absorb /
+// vacuum / grating, medium and sequence state (ray.py:91-281).  The generic kernels pass the group's
+// words as read from the tables; a compiled scene passes constants and the branches fold.
+// n: surface normal along the travel direction; cnt: the thread's column of event counters.
+template <bool BVH, bool STOCH, bool LEAN>
+__device__ __forceinline__ void interact(const TraceParams& P, cf64 group_f64, ci32 group_i32, cf64 group_gdir, int g,
+                                         int gtype, bool record, d3 n, bool entering, uint64_t ray, int nint,
+                                         uint32_t* cnt, uint32_t* hit_state, uint32_t* win, d3 point, d3& dir, double& power,
+                                         int& medium, int& seq, bool& alive) {
+  if (record) {
+    cnt[ODW_CNT_RECORDED_HITS * 256] += 1u;
+    // (block reservations and the histogram window only in the flat kernels: in the BVH kernels
+    // their state costs more registers / LDS than the atomics cost time)
+    if (BVH) record_hit<false>(P, ray, g, point, dir, power, entering, cnt, hit_state);
+    else record_hit_flat((ckargs)__builtin_amdgcn_kernarg_segment_ptr(), ray, g, point, dir, power, entering, cnt,
+                         hit_state, win);   // (interact is inlined into the kernel: the pointer is the kernel's)
+  }
+  if (gtype == ODW_OPT_MIRROR) {
+    const d3 ideal = mirror(dir, n);
+    if (STOCH) dir = scatter(P.samplers, P.group_sampler[2 * g], P.group_sampler[2 * g + 1], ray, P.seed, (uint32_t)nint,
+                             dir, ideal, n);
+    else dir = ideal;
+    power *= group_f64[4 * g + 1];
+    ++seq;
+  } else if (gtype == ODW_OPT_LENS) {
+    const double n1 = (medium >= 0) ? group_f64[4 * medium] : 1.0;
+    double n2 = 1.0;
+    if (entering) { medium = g; n2 = group_f64[4 * g]; }
+    bool tir;
+    const d3 ideal = snells_law(dir, n1, n2, n, tir);
+    if (STOCH) dir = scatter(P.samplers, P.group_sampler[2 * g], P.group_sampler[2 * g + 1], ray, P.seed, (uint32_t)nint,
+                             dir, ideal, n);
+    else dir = ideal;
+    if (!entering && !tir && medium == g) { medium = -1; ++seq; }
+  } else if (gtype == ODW_OPT_ABSORBER) {
+    power = 0;
+    ++seq;
+  } else if (LEAN || gtype == ODW_OPT_VACUUM) {
+    ++seq;
+  } else {  // grating (ray.py:216-268)
+    const d3 gd = mk(group_gdir[3 * g], group_gdir[3 * g + 1], group_gdir[3 * g + 2]);
+    const double lpm = group_f64[4 * g + 3];
+    const int order = group_i32[4 * g + 3];
+    if (group_i32[4 * g + 2] == 0) {
+      if (entering) {
+        const double nn = (medium >= 0) ? group_f64[4 * medium] : 1.0;
+        dir = line_grating(dir, nn, nn, n, P.wavelength, order, lpm, gd, false);
+        ++seq;
+      }
+    } else if (entering) {
+      if (medium >= 0) {
+        // the reference raises ValueError here (ray.py:234-237): counted, the host raises
+        atomicAdd(P.out.counters + ODW_CNT_GRATING_IN_MEDIUM, 1ull);
+        cnt[ODW_CNT_DIED * 256] += 1u;
+        alive = false;
+      }
+      medium = g;
+      dir = line_grating(dir, 1.0, group_f64[4 * g], n, P.wavelength, order, lpm, gd, true);
+    } else {
+      const double n1 = (medium >= 0) ? group_f64[4 * medium] : 1.0;
+      bool tir;
+      dir = snells_law(dir, n1, 1.0, n, tir);
+      if (!tir) { medium = -1; ++seq; }
+    }
+  }
+}
+
+// the hit is on primitive PI of a compiled scene: its type, frame pattern, flags, group and the group's
+// optical type / recording switch are constants
+template <bool LEAN, class SPEC, int PI>
+__device__ __forceinline__ void spec_hit(const TraceParams& P, const SceneView& sv, cf64 group_f64, ci32 group_i32,
+                                         cf64 group_gdir, int face, uint64_t ray, int nint, uint32_t* cnt,
+                                         uint32_t* hit_state, uint32_t* win, d3 point, d3& dir, double& power, int& medium, int& seq,
+                                         int& skip, bool& alive) {
+  constexpr int flags = SPEC::flags(PI), g = SPEC::group(PI);
+  cf64 pf = sv.prim_f64 + (size_t)PI * 16;
+  d3 n = face_normal<false>(SPEC::type(PI), pf + 12, face, xf_point_nz<SPEC::xf(PI)>(pf, point));
+  if constexpr ((flags & ODW_FLAG_FLIP_NORMAL) != 0) n = n * -1.0;
+  n = xf_vec_t_nz<SPEC::xf(PI)>(pf, n);
+  const bool entering = dot(dir, n) < 0;
+  if (entering) n = n * -1.0;
+  interact<false, false, LEAN>(P, group_f64, group_i32, group_gdir, g, SPEC::gtype(g), SPEC::record(g), n, entering, ray,
+                               nint, cnt, hit_state, win, point, dir, power, medium, seq, alive);
+  if constexpr ((flags & ODW_FLAG_CONVEX) != 0)
+    skip = ((entering ? -dot(dir, n) : dot(dir, n)) > 0) ? (flags >> ODW_SOLID_SHIFT) : -1;
+  else
+    skip = -1;
+}
+template <bool LEAN, class SPEC, int... PI>
+__device__ __forceinline__ void spec_hits(const TraceParams& P, const SceneView& sv, cf64 group_f64, ci32 group_i32,
+                                          cf64 group_gdir, int prim, int face, uint64_t ray, int nint, uint32_t* cnt,
+                                          uint32_t* hit_state, uint32_t* win, d3 point, d3& dir, double& power, int& medium, int& seq,
+                                          int& skip, bool& alive, IndexList<int, PI...>) {
+  (void)((prim == PI ? (spec_hit<LEAN, SPEC, PI>(P, sv, group_f64, group_i32, group_gdir, face, ray, nint, cnt, hit_state, win,
+                                                  point, dir, power, medium, seq, skip, alive), true)
+                     : false) || ...);
+}
+
 // LDS of the hit-list block reservations: exists only where it is used
+// (+ the block's histogram window, see record_hit: header at word 16, counts from word 20)
 template <bool ON> struct HitBlockState {
   __device__ static __forceinline__ uint32_t* lds() {
-    __shared__ uint32_t state[4 * 4];
+    __shared__ uint32_t state[4 * 4 + 4 + ODW_HIST_WIN * ODW_HIST_WIN];
     return state;
   }
 };
@@ -1101,8 +1389,8 @@ template <> struct HitBlockState<false> {
 #endif
 // LEAN: the scene has no grating group and no finite absorption length (the host checks): their code
 // -- line_grating's chain of IEEE divisions and square roots, exp() -- is left out of the binary
-template <bool BVH, bool STOCH, bool SEG, bool LEAN = false>
-__global__ __launch_bounds__(256, BVH ? ODW_WAVES_PER_SIMD_BVH : ODW_WAVES_PER_SIMD) void odw_trace_kernel(const TraceParams P) {
+template <bool BVH, bool STOCH, bool SEG, bool LEAN = false, class SPEC = NoSpec>
+__device__ __forceinline__ void trace_body(const TraceParams& P) {
   extern __shared__ int bvh_stack[];  // ODW_BVH_STACK x 256 ints (BVH variant only)
   // per-thread event counters live in LDS (one column per thread, ds_add_u32
   // at the event): eight fewer VGPRs across the whole ray loop
@@ -1113,14 +1401,21 @@ __global__ __launch_bounds__(256, BVH ? ODW_WAVES_PER_SIMD_BVH : ODW_WAVES_PER_S
   const DeviceScene& sc = P.scene;
   const DeviceLimits& lim = P.lim;
   SceneView sv;
-  sv.prim_f64 = as_const(sc.prim_f64);
-  sv.prim_hdr = as_const(sc.prim_hdr);
-  sv.prim_i32 = as_const(sc.prim_i32);
-  sv.cond_i32 = as_const(sc.cond_i32);
-  cf64 group_f64 = as_const(sc.group_f64);
-  ci32 group_i32 = as_const(sc.group_i32);
-  cf64 group_gdir = as_const(sc.group_gdir);
-  cu64 seq_mask = as_const(sc.seq_mask);
+  sv.prim_f64 = as_scene(sc.prim_f64);
+  sv.prim_hdr = as_scene(sc.prim_hdr);
+  sv.prim_i32 = as_scene(sc.prim_i32);
+  sv.cond_i32 = as_scene(sc.cond_i32);
+  cf64 group_f64 = as_scene(sc.group_f64);
+  ci32 group_i32 = as_scene(sc.group_i32);
+  cf64 group_gdir = as_scene(sc.group_gdir);
+  cu64 seq_mask = as_scene(sc.seq_mask);
+  if constexpr (SPEC::values) {       // the compiled scene's own constant tables
+    sv.prim_f64 = SPEC::prim_f64();
+    sv.prim_hdr = SPEC::prim_hdr();
+    group_f64 = SPEC::group_f64();
+    group_i32 = SPEC::group_i32();
+    group_gdir = SPEC::group_gdir();
+  }
   // Persistent waves with ray regeneration.  Rays are handed out in chunks of
   // ODW_CHUNK consecutive indices, taken from a launch-wide atomic counter.  A
   // lane whose ray has terminated takes the next index of its wave's chunk
@@ -1140,8 +1435,10 @@ __global__ __launch_bounds__(256, BVH ? ODW_WAVES_PER_SIMD_BVH : ODW_WAVES_PER_S
   // (flat kernels only: the BVH kernels' node stacks + counters fill the 160 KB of a CU exactly at
   //  4 blocks -- 64 more bytes would cost a quarter of the occupancy)
   uint32_t* hit_lds = HitBlockState<!BVH>::lds();
+  uint32_t* hist_win = BVH ? nullptr : hit_lds + 16;
   if (!BVH) {
     if (threadIdx.x < 16) hit_lds[threadIdx.x] = (threadIdx.x & 3) == 2 ? P.out.hit_block : 0u;
+    for (int k = threadIdx.x; k < 4 + ODW_HIST_WIN * ODW_HIST_WIN; k += 256) hist_win[k] = 0u;
     __syncthreads();
   }
   for (;;) {
@@ -1154,8 +1451,8 @@ __global__ __launch_bounds__(256, BVH ? ODW_WAVES_PER_SIMD_BVH : ODW_WAVES_PER_S
         // hand-out keeps every CU busy until the very end of the launch)
         unsigned long long c = 0;
         if (lane == (uint32_t)(__ffsll((unsigned long long)__ballot(1)) - 1)) c = atomicAdd(P.out.chunk_counter, 1ull);
-        const uint64_t chunk = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(c >> 32)) << 32) |
-                               __builtin_amdgcn_readfirstlane((uint32_t)c);
+        const uint64_t chunk = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(c >> 32)) << 32) |
+                               (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)c);
         next = chunk * ODW_CHUNK;
         if (next > P.n_rays) next = P.n_rays;
         chunk_end = next + ODW_CHUNK < P.n_rays ? next + ODW_CHUNK : P.n_rays;
@@ -1195,7 +1492,7 @@ __global__ __launch_bounds__(256, BVH ? ODW_WAVES_PER_SIMD_BVH : ODW_WAVES_PER_S
       mask &= ~sc.ignore_mask;
       double t_hit;
       int face;
-      const int prim = nearest<BVH>(sc, sv, lim, point, dir, medium, mask, t_hit, face,
+      const int prim = nearest<BVH, SPEC>(sc, sv, lim, point, dir, medium, mask, t_hit, face,
                                     bvh_stack + threadIdx.x, skip);
       if (SEG)   // (p1, p2), power at p1, medium of the segment (ray.py:104-117)
         record_segment(P.out.segs, P.out.seg_capacity, P.out.seg_count, P.first_ray + i, nint - 1, medium, point,
@@ -1204,8 +1501,6 @@ __global__ __launch_bounds__(256, BVH ? ODW_WAVES_PER_SIMD_BVH : ODW_WAVES_PER_S
         ODW_COUNT(ODW_CNT_ESCAPED);
         alive = false;
       } else {
-      cf64 pf = sv.prim_f64 + (size_t)prim * 16;
-      ci32 pi = sv.prim_i32 + 4 * prim;
       point = point + dir * t_hit;
       // absorption along the traversed medium (ray.py:120-125, assignment)
       if (!LEAN && medium >= 0) {
@@ -1213,6 +1508,14 @@ __global__ __launch_bounds__(256, BVH ? ODW_WAVES_PER_SIMD_BVH : ODW_WAVES_PER_S
         if (L == 0) power = 0;
         else if (L < INFINITY) power = exp(-t_hit / L);
       }
+      uint32_t* cnt = cnt_lds + threadIdx.x;
+      uint32_t* hit_state = hit_lds + (threadIdx.x >> 6) * 4;
+      if constexpr (SPEC::enabled) {
+        spec_hits<LEAN, SPEC>(P, sv, group_f64, group_i32, group_gdir, prim, face, P.first_ray + i, nint, cnt, hit_state,
+                              hist_win, point, dir, power, medium, seq, skip, alive, __make_integer_seq<IndexList, int, SPEC::N>{});
+      } else {
+      cf64 pf = sv.prim_f64 + (size_t)prim * 16;
+      ci32 pi = sv.prim_i32 + 4 * prim;
       // getNormal (ray.py:455-480): outward normal -> along the travel direction
       d3 n;
       if (BVH && pi[0] == ODW_PRIM_TRIANGLE) {
@@ -1226,64 +1529,11 @@ __global__ __launch_bounds__(256, BVH ? ODW_WAVES_PER_SIMD_BVH : ODW_WAVES_PER_S
       const bool entering = dot(dir, n) < 0;
       if (entering) n = n * -1.0;
       const int g = pi[1];
-      const int gtype = group_i32[4 * g];
-      if (group_i32[4 * g + 1]) {
-        ODW_COUNT(ODW_CNT_RECORDED_HITS);
-        // (block reservations only in the flat kernels: in the BVH kernels their state costs more
-        // registers than the atomics cost time)
-        record_hit<!BVH>(P, P.first_ray + i, g, point, dir, power, entering, cnt_lds + threadIdx.x,
-                         hit_lds + (threadIdx.x >> 6) * 4);
-      }
-      if (gtype == ODW_OPT_MIRROR) {
-        const d3 ideal = mirror(dir, n);
-        if (STOCH) dir = scatter(P.samplers, P.group_sampler[2 * g], P.group_sampler[2 * g + 1], P.first_ray + i,
-                                 P.seed, (uint32_t)nint, dir, ideal, n);
-        else dir = ideal;
-        power *= group_f64[4 * g + 1];
-        ++seq;
-      } else if (gtype == ODW_OPT_LENS) {
-        const double n1 = (medium >= 0) ? group_f64[4 * medium] : 1.0;
-        double n2 = 1.0;
-        if (entering) { medium = g; n2 = group_f64[4 * g]; }
-        bool tir;
-        const d3 ideal = snells_law(dir, n1, n2, n, tir);
-        if (STOCH) dir = scatter(P.samplers, P.group_sampler[2 * g], P.group_sampler[2 * g + 1], P.first_ray + i,
-                                 P.seed, (uint32_t)nint, dir, ideal, n);
-        else dir = ideal;
-        if (!entering && !tir && medium == g) { medium = -1; ++seq; }
-      } else if (gtype == ODW_OPT_ABSORBER) {
-        power = 0;
-        ++seq;
-      } else if (LEAN || gtype == ODW_OPT_VACUUM) {
-        ++seq;
-      } else {  // grating (ray.py:216-268)
-        const d3 gd = mk(group_gdir[3 * g], group_gdir[3 * g + 1], group_gdir[3 * g + 2]);
-        const double lpm = group_f64[4 * g + 3];
-        const int order = group_i32[4 * g + 3];
-        if (group_i32[4 * g + 2] == 0) {
-          if (entering) {
-            const double nn = (medium >= 0) ? group_f64[4 * medium] : 1.0;
-            dir = line_grating(dir, nn, nn, n, P.wavelength, order, lpm, gd, false);
-            ++seq;
-          }
-        } else if (entering) {
-          if (medium >= 0) {
-            // the reference raises ValueError here (ray.py:234-237): counted, the host raises
-            atomicAdd(P.out.counters + ODW_CNT_GRATING_IN_MEDIUM, 1ull);
-            ODW_COUNT(ODW_CNT_DIED);
-            alive = false;
-          }
-          medium = g;
-          dir = line_grating(dir, 1.0, group_f64[4 * g], n, P.wavelength, order, lpm, gd, true);
-        } else {
-          const double n1 = (medium >= 0) ? group_f64[4 * medium] : 1.0;
-          bool tir;
-          dir = snells_law(dir, n1, 1.0, n, tir);
-          if (!tir) { medium = -1; ++seq; }
-        }
-      }
+      interact<BVH, STOCH, LEAN>(P, group_f64, group_i32, group_gdir, g, group_i32[4 * g], group_i32[4 * g + 1] != 0, n,
+                                 entering, P.first_ray + i, nint, cnt, hit_state, hist_win, point, dir, power, medium, seq, alive);
       // outward normal of the solid = n against the travel direction when entering
       skip = ((pi[2] & ODW_FLAG_CONVEX) && (entering ? -dot(dir, n) : dot(dir, n)) > 0) ? (pi[2] >> ODW_SOLID_SHIFT) : -1;
+      }
       if (alive && power < lim.power_tol) { ODW_COUNT(ODW_CNT_DIED); alive = false; }
       }
       }
@@ -1304,6 +1554,20 @@ __global__ __launch_bounds__(256, BVH ? ODW_WAVES_PER_SIMD_BVH : ODW_WAVES_PER_S
     const uint64_t in_buf = at < P.out.hit_capacity ? (P.out.hit_capacity - at < left ? P.out.hit_capacity - at : left) : 0;
     if (__lane_id() == 0 && in_buf) atomicAdd(P.out.hit_count + 1, (unsigned long long)in_buf);
   }
+  // the block's histogram window joins the histogram (every wave of the block has finished its rays)
+  if (!BVH) {
+    __syncthreads();
+    if (hist_win[0] != 0u) {
+      cdetector det = as_const(opaque(P.det));
+      const uint32_t x0 = hist_win[0] - 1u, y0 = hist_win[1];
+      const uint32_t nx = (uint32_t)det->nx, ny = (uint32_t)det->ny;
+      for (int k = threadIdx.x; k < ODW_HIST_WIN * ODW_HIST_WIN; k += 256) {
+        const uint32_t c = hist_win[4 + k];
+        const uint32_t x = x0 + (uint32_t)k / ODW_HIST_WIN, y = y0 + (uint32_t)k % ODW_HIST_WIN;
+        if (c && x < nx && y < ny) atomicAdd(P.out.hist + ((size_t)x * ny + y), (unsigned long long)c);
+      }
+    }
+  }
   // counters: wave reduction, one atomic per wave and counter
 #pragma unroll
   for (int k = 0; k < ODW_CNT_LDS; ++k) {
@@ -1311,6 +1575,23 @@ __global__ __launch_bounds__(256, BVH ? ODW_WAVES_PER_SIMD_BVH : ODW_WAVES_PER_S
     if (__lane_id() == 0 && s) atomicAdd(P.out.counters + k, (unsigned long long)s);
   }
 }
+
+template <bool BVH, bool STOCH, bool SEG, bool LEAN = false>
+__global__ __launch_bounds__(256, BVH ? ODW_WAVES_PER_SIMD_BVH : ODW_WAVES_PER_SIMD) void odw_trace_kernel(const TraceParams P) {
+  trace_body<BVH, STOCH, SEG, LEAN>(P);
+}
+
+#ifdef ODW_SPEC_HEADER
+// the scene-compiled flat kernel: ODW_SPEC_HEADER defines `struct Spec` (written by the host library
+// from the uploaded scene, odw_capi.hip: spec_source) and ODW_SPEC_LEAN
+#include ODW_SPEC_HEADER
+#ifndef ODW_SPEC_WAVES
+#define ODW_SPEC_WAVES 4
+#endif
+extern "C" __global__ __launch_bounds__(256, ODW_SPEC_WAVES) void odw_spec_kernel(const TraceParams P) {
+  trace_body<false, false, false, ODW_SPEC_LEAN, Spec>(P);
+}
+#endif
 
 // sampler only: theta-or-radius and phi per ray (diagnostics / parity tests)
 __global__ __launch_bounds__(256) void odw_sample_kernel(const DeviceSource* sp, uint64_t first,

@@ -1,0 +1,324 @@
+// odw_spec.hip -- scene-compiled flat kernels, host side.
+//
+// The reference prepares a scene once per run and reuses the result for every ray
+// (simulation/raytracing_cache.py:92-111: cachedShape / cachedFaces / cachedBoundBox ..., cleared by
+// cacheClear :36).  The counterpart here goes one step further: for a scene the flat kernel would
+// trace (<= 16 analytic primitives), the library writes the scene's STRUCTURE -- primitive types,
+// groups, flags, trimming lists, zero / +-1 pattern of every frame, optical type and recording switch
+// of every group -- as a C++ header of compile-time constants, compiles odw_kernels.hip's ray loop
+// against it with hiprtc (1.5 - 2 s), and launches that kernel instead of the generic one: the
+// primitive loop is unrolled, type dispatch and face masks fold away, frame products skip their zero
+// terms, table reads have constant offsets (odw_kernels.hip: SPEC).  Two levels:
+//   ODW_COMPILE_STRUCTURE  float64 values still come from the tables: one kernel serves every scene
+//                          of the same structure (a parameter sweep compiles once);
+//   ODW_COMPILE_VALUES     the values (frames, parameters, boxes, optical constants) are literals of
+//                          the kernel as well: no table reads at all in the primitive loop; a kernel
+//                          per scene -- for long runs on a fixed scene.
+// Kernels are cached per process (key = the header text) and on disk (ODW_KERNEL_CACHE, default
+// ~/.cache/odw_trace).  Results: the same arithmetic in the same order as the generic kernel.
+// hiprtc is loaded on first use (dlopen); the kernel sources are embedded in this library.
+#include <dlfcn.h>
+#include <hip/hiprtc.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <map>
+#include <mutex>
+
+#if !defined(__HIP_DEVICE_COMPILE__)
+// the sources the run-time compiler needs, byte for byte as this library was built from
+__asm__(
+    ".pushsection .rodata\n"
+    ".global odw_src_kernels\nodw_src_kernels:\n.incbin \"odw_kernels.hip\"\n.byte 0\n"
+    ".global odw_src_device\nodw_src_device:\n.incbin \"odw_device.h\"\n.byte 0\n"
+    ".global odw_src_trace\nodw_src_trace:\n.incbin \"../../../include/odw_trace.h\"\n.byte 0\n"
+    ".popsection\n");
+#endif
+extern "C" const char odw_src_kernels[], odw_src_device[], odw_src_trace[];
+
+namespace {
+
+constexpr int kSpecMaxPrims = 16;
+
+struct Hiprtc {
+  void* lib = nullptr;
+  decltype(&hiprtcCreateProgram) create = nullptr;
+  decltype(&hiprtcCompileProgram) compile = nullptr;
+  decltype(&hiprtcGetProgramLogSize) log_size = nullptr;
+  decltype(&hiprtcGetProgramLog) log = nullptr;
+  decltype(&hiprtcGetCodeSize) code_size = nullptr;
+  decltype(&hiprtcGetCode) code = nullptr;
+  decltype(&hiprtcDestroyProgram) destroy = nullptr;
+  std::string error;
+};
+
+Hiprtc& hiprtc() {
+  static Hiprtc h;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const char* name : {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"}) {
+      h.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (h.lib) break;
+    }
+    if (!h.lib) { h.error = std::string("hiprtc not available: ") + dlerror(); return; }
+#define ODW_RTC_SYM(field, sym)                                             \
+    h.field = reinterpret_cast<decltype(h.field)>(dlsym(h.lib, #sym));      \
+    if (!h.field) h.error = "hiprtc: missing symbol " #sym;
+    ODW_RTC_SYM(create, hiprtcCreateProgram)
+    ODW_RTC_SYM(compile, hiprtcCompileProgram)
+    ODW_RTC_SYM(log_size, hiprtcGetProgramLogSize)
+    ODW_RTC_SYM(log, hiprtcGetProgramLog)
+    ODW_RTC_SYM(code_size, hiprtcGetCodeSize)
+    ODW_RTC_SYM(code, hiprtcGetCode)
+    ODW_RTC_SYM(destroy, hiprtcDestroyProgram)
+#undef ODW_RTC_SYM
+  });
+  return h;
+}
+
+// ---- the header ------------------------------------------------------------------------------
+std::string f64_literal(double v) {
+  if (std::isnan(v)) return "__builtin_nan(\"\")";
+  if (std::isinf(v)) return v > 0 ? "__builtin_huge_val()" : "(-__builtin_huge_val())";
+  char buf[64];
+  snprintf(buf, sizeof buf, "%a", v);       // hexadecimal: exact
+  return buf;
+}
+
+template <class T, class F>
+std::string table(const char* type, const char* name, int n, const T* v, F fmt) {
+  std::string s = std::string("  static constexpr ") + type + " " + name + "(int i) { constexpr " + type + " T[] = {";
+  for (int i = 0; i < std::max(1, n); ++i) s += (i ? ", " : "") + (i < n ? fmt(v[i]) : std::string("0"));
+  return s + "}; return T[i]; }\n";
+}
+
+// why the scene cannot be compiled, or empty
+std::string spec_ineligible(const odw_ctx* ctx) {
+  const int n = ctx->P.scene.n_prims;
+  if (n < 1) return "no primitives";
+  if (n > kSpecMaxPrims) return "more primitives than the flat kernel takes";
+  for (int p = 0; p < n; ++p) {
+    const int t = ctx->h_prim_i32[4 * p];
+    if (t == ODW_PRIM_TRIANGLE || t == ODW_PRIM_PARABOLOID) return "facets / paraboloids belong to the BVH and grid kernels";
+  }
+  if (ctx->h_prim_hdr.size() < (size_t)n * 8 || ctx->h_dead.size() < (size_t)n) return "boxes not built";
+  return "";
+}
+
+// `struct Spec` of the uploaded scene (tables of scene_host_tables / compute_boxes).  The text is the
+// cache key: equal text = equal kernel.
+std::string spec_text(const odw_ctx* ctx, int mode) {
+  const int n = ctx->P.scene.n_prims, ng = ctx->P.scene.n_groups;
+  const bool values = mode == ODW_COMPILE_VALUES;
+  std::vector<int> type(n), group(n), flags(n), condw(n), dead(n);
+  std::vector<unsigned long long> xf(n);
+  for (int p = 0; p < n; ++p) {
+    type[p] = ctx->h_prim_i32[4 * p];
+    group[p] = ctx->h_prim_i32[4 * p + 1];
+    flags[p] = ctx->h_prim_i32[4 * p + 2];
+    condw[p] = ctx->h_prim_i32[4 * p + 3];
+    const int facemask = (flags[p] >> ODW_FACEMASK_SHIFT) & 0xff;
+    // (an empty box is a matter of values: structural kernels keep such a primitive, its box culls it)
+    dead[p] = values ? (int)ctx->h_dead[p] : (facemask == 0);
+    const double* m = &ctx->h_prim_f64[16 * (size_t)p];
+    unsigned long long w = 0;
+    for (int i = 0; i < 12; ++i) {
+      if (m[i] != 0.0) w |= 1ull << i;
+      if (i % 4 != 3 && m[i] == 1.0) w |= 1ull << (12 + i);
+      if (i % 4 != 3 && m[i] == -1.0) w |= 1ull << (24 + i);
+    }
+    xf[p] = w;
+  }
+  std::vector<int> gtype(std::max(1, ng)), grec(std::max(1, ng));
+  for (int g = 0; g < ng; ++g) { gtype[g] = ctx->h_group_i32[4 * g]; grec[g] = ctx->h_group_i32[4 * g + 1]; }
+  auto fi = [](int v) { return std::to_string(v); };
+  auto fu = [](unsigned long long v) { char b[32]; snprintf(b, sizeof b, "0x%llxull", v); return std::string(b); };
+  std::string s;
+  if (values) {
+    auto arr = [&](const char* name, const std::vector<double>& v, size_t count) {
+      s += std::string("constexpr double ") + name + "[] = {";
+      for (size_t i = 0; i < std::max<size_t>(1, count); ++i) s += (i ? ", " : "") + (i < count ? f64_literal(v[i]) : std::string("0"));
+      s += "};\n";
+    };
+    s += "namespace odw {\n";
+    arr("kSpecPrimF64", ctx->h_prim_f64, (size_t)n * 16);
+    // (the four integers at the end of a 64-byte header are constants of the structure here)
+    std::vector<double> hdr(ctx->h_prim_hdr);
+    for (int p = 0; p < n; ++p) hdr[8 * (size_t)p + 6] = hdr[8 * (size_t)p + 7] = 0.0;
+    arr("kSpecPrimHdr", hdr, (size_t)n * 8);
+    arr("kSpecGroupF64", ctx->h_group_f64, (size_t)ng * 4);
+    arr("kSpecGroupGdir", ctx->h_group_gdir, (size_t)ng * 3);
+    s += "constexpr int kSpecGroupI32[] = {";
+    for (int i = 0; i < std::max(1, ng * 4); ++i) s += (i ? ", " : "") + std::to_string(i < ng * 4 ? ctx->h_group_i32[i] : 0);
+    s += "};\n}\n";
+  }
+  s += "struct Spec {\n  static constexpr bool enabled = true;\n";
+  s += std::string("  static constexpr bool values = ") + (values ? "true" : "false") + ";\n";
+  s += "  static constexpr int N = " + std::to_string(n) + ";\n";
+  s += table("int", "type", n, type.data(), fi) + table("int", "group", n, group.data(), fi) +
+       table("int", "flags", n, flags.data(), fi) + table("int", "cond_word", n, condw.data(), fi) +
+       table("bool", "dead", n, dead.data(), fi) +
+       table("int", "cond", (int)ctx->h_cond.size(), ctx->h_cond.data(), fi) +
+       table("unsigned long long", "xf", n, xf.data(), fu) + table("int", "gtype", ng, gtype.data(), fi) +
+       table("bool", "record", ng, grec.data(), fi);
+  s += "  static constexpr int cond_off(int i) { return cond_word(i) & 0xffffff; }\n"
+       "  static constexpr int cond_cnt(int i) { return (cond_word(i) >> 24) & 0xff; }\n";
+  s += "  static constexpr unsigned long long umask() { return " + fu(ctx->P.scene.all_mask & ~ctx->P.scene.ignore_mask) + "; }\n";
+  s += std::string("  static constexpr bool seq() { return ") + (ctx->P.scene.seq_enabled ? "true" : "false") + "; }\n";
+  if (values)
+    s += "  static __device__ __forceinline__ const double* prim_f64() { return odw::kSpecPrimF64; }\n"
+         "  static __device__ __forceinline__ const double* prim_hdr() { return odw::kSpecPrimHdr; }\n"
+         "  static __device__ __forceinline__ const double* group_f64() { return odw::kSpecGroupF64; }\n"
+         "  static __device__ __forceinline__ const double* group_gdir() { return odw::kSpecGroupGdir; }\n"
+         "  static __device__ __forceinline__ const int* group_i32() { return odw::kSpecGroupI32; }\n";
+  s += "};\n";
+  s += std::string("#define ODW_SPEC_LEAN ") + (ctx->lean ? "true" : "false") + "\n";
+  return s;
+}
+
+// ---- compile ---------------------------------------------------------------------------------
+uint64_t fnv1a(const std::string& s, uint64_t h = 1469598103934665603ull) {
+  for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
+  return h;
+}
+
+std::string cache_dir() {
+  const char* e = getenv("ODW_KERNEL_CACHE");
+  if (e) return *e ? e : "";                      // empty: no disk cache
+  const char* x = getenv("XDG_CACHE_HOME");
+  if (x && *x) return std::string(x) + "/odw_trace";
+  const char* h = getenv("HOME");
+  return h && *h ? std::string(h) + "/.cache/odw_trace" : "";
+}
+
+void mkdirs(const std::string& path) {
+  for (size_t i = 1; i <= path.size(); ++i)
+    if (i == path.size() || path[i] == '/') (void)mkdir(path.substr(0, i).c_str(), 0755);
+}
+
+// header text -> code object for `arch`; error text in `err`
+bool spec_compile(const std::string& text, bool values, const std::string& arch, std::vector<char>& code, std::string& err) {
+  Hiprtc& rtc = hiprtc();
+  if (!rtc.error.empty()) { err = rtc.error; return false; }
+  const char* headers[] = {odw_src_kernels, odw_src_device, odw_src_trace, text.c_str()};
+  const char* names[] = {"odw_kernels.hip", "odw_device.h", "odw_trace.h", "odw_spec.h"};
+  hiprtcProgram prog = nullptr;
+  if (rtc.create(&prog, "#include \"odw_kernels.hip\"\n", "odw_spec_kernel.hip", 4, headers, names) != HIPRTC_SUCCESS) {
+    err = "hiprtcCreateProgram failed";
+    return false;
+  }
+  const std::string a = "--offload-arch=" + arch;
+  std::vector<const char*> opts = {a.c_str(), "-std=c++17", "-O3", "-DODW_SPEC_HEADER=\"odw_spec.h\""};
+  if (values) opts.push_back("-DODW_SPEC_VALUES=1");
+  // experiments: ODW_SPEC_OPTS = further compiler options, separated by blanks (part of the cache key)
+  std::vector<std::string> extra;
+  if (const char* e = getenv("ODW_SPEC_OPTS")) {
+    std::string w;
+    for (const char* c = e;; ++c) {
+      if (*c == ' ' || *c == 0) { if (!w.empty()) extra.push_back(w); w.clear(); if (!*c) break; }
+      else w += *c;
+    }
+  }
+  for (const std::string& x : extra) opts.push_back(x.c_str());
+  const hiprtcResult r = rtc.compile(prog, (int)opts.size(), opts.data());
+  if (r != HIPRTC_SUCCESS) {
+    size_t ls = 0;
+    rtc.log_size(prog, &ls);
+    std::string log(ls, '\0');
+    if (ls) rtc.log(prog, &log[0]);
+    err = "hiprtc: compilation of the scene kernel failed:\n" + log.substr(0, 4000);
+    rtc.destroy(&prog);
+    return false;
+  }
+  size_t cs = 0;
+  rtc.code_size(prog, &cs);
+  code.resize(cs);
+  if (cs) rtc.code(prog, code.data());
+  rtc.destroy(&prog);
+  if (!cs) { err = "hiprtc returned no code"; return false; }
+  return true;
+}
+
+struct SpecKernel {
+  hipModule_t mod = nullptr;
+  hipFunction_t fn = nullptr;
+};
+std::mutex g_spec_mu;
+std::map<std::string, SpecKernel> g_spec_cache;     // (device, arch, header text) -> loaded kernel; lives as long as the process
+
+// binds ctx->spec_fn for the uploaded scene (or leaves it null: the generic kernels run)
+int spec_bind(odw_ctx* ctx) {
+  ctx->spec_dirty = false;
+  ctx->spec_fn = nullptr;
+  ctx->spec_seconds = 0;
+  ctx->spec_cache_hit = 0;
+  if (ctx->compile_mode == ODW_COMPILE_OFF || !ctx->have_scene) return ODW_OK;
+  if (!spec_ineligible(ctx).empty() || ctx->P.scene.n_nodes || ctx->P.grid.nx > 0) return ODW_OK;
+  hipDeviceProp_t prop;
+  HIPCHK(ctx, hipGetDeviceProperties(&prop, ctx->device));
+  const std::string arch = prop.gcnArchName;
+  const bool values = ctx->compile_mode == ODW_COMPILE_VALUES;
+  const std::string text = spec_text(ctx, ctx->compile_mode);
+  const char* xo = getenv("ODW_SPEC_OPTS");
+  const std::string key = std::to_string(ctx->device) + "|" + arch + "|" + (xo ? xo : "") + "|" + text;
+  std::lock_guard<std::mutex> lock(g_spec_mu);
+  auto it = g_spec_cache.find(key);
+  if (it == g_spec_cache.end()) {
+    std::vector<char> code;
+    // disk cache: named after the header, the sources and the target
+    std::string file;
+    const std::string dir = cache_dir();
+    if (!dir.empty()) {
+      uint64_t h = fnv1a(arch + "|" + (xo ? xo : "") + "|" + text);
+      h = fnv1a(odw_src_kernels, h);
+      h = fnv1a(odw_src_device, h);
+      h = fnv1a(odw_src_trace, h);
+      char name[40];
+      snprintf(name, sizeof name, "/%016llx.hsaco", (unsigned long long)h);
+      file = dir + name;
+      if (FILE* f = fopen(file.c_str(), "rb")) {
+        fseek(f, 0, SEEK_END);
+        const long sz = ftell(f);
+        fseek(f, 0, SEEK_SET);
+        if (sz > 0) { code.resize((size_t)sz); if (fread(code.data(), 1, (size_t)sz, f) != (size_t)sz) code.clear(); }
+        fclose(f);
+        if (!code.empty()) ctx->spec_cache_hit = 2;
+      }
+    }
+    if (code.empty()) {
+      const auto t0 = std::chrono::steady_clock::now();
+      std::string err;
+      if (!spec_compile(text, values, arch, code, err)) return fail(ctx, ODW_ERR_DEVICE, err);
+      ctx->spec_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (!file.empty()) {
+        mkdirs(dir);
+        const std::string tmp = file + "." + std::to_string((long)getpid());
+        if (FILE* f = fopen(tmp.c_str(), "wb")) {
+          const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
+          fclose(f);
+          if (!ok || rename(tmp.c_str(), file.c_str()) != 0) (void)unlink(tmp.c_str());
+        }
+      }
+    }
+    SpecKernel k;
+    HIPCHK(ctx, hipModuleLoadData(&k.mod, code.data()));
+    HIPCHK(ctx, hipModuleGetFunction(&k.fn, k.mod, "odw_spec_kernel"));
+    it = g_spec_cache.emplace(key, k).first;
+  } else {
+    ctx->spec_cache_hit = 1;
+  }
+  ctx->spec_fn = it->second.fn;
+  ctx->spec_lean = ctx->lean;
+  return ODW_OK;
+}
+
+int spec_launch(odw_ctx* ctx, unsigned grid) {
+  TraceParams P = ctx->P;
+  size_t size = sizeof P;
+  void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &P, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+  HIPCHK(ctx, hipModuleLaunchKernel(ctx->spec_fn, grid, 1, 1, 256, 1, 1, 0, ctx->stream, nullptr, config));
+  return ODW_OK;
+}
+
+}  // namespace

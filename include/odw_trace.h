@@ -17,13 +17,15 @@
 #ifndef ODW_TRACE_H
 #define ODW_TRACE_H
 
+#ifndef __HIPCC_RTC__
 #include <stdint.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define ODW_ABI_VERSION 5
+#define ODW_ABI_VERSION 6
 
 /* ---- return codes ------------------------------------------------------ */
 enum {
@@ -433,6 +435,39 @@ int odw_hits_bin(odw_ctx* ctx, int32_t polar, const double* origin, const double
                  const double* edges_b, int32_t n_b, uint64_t* counts);
 /* mean[3] and variance[3] (about the mean) of the selected rows' points     */
 int odw_hits_moments(odw_ctx* ctx, double* mean, double* var);
+
+/* scene-compiled kernels -------------------------------------------------------
+ * The reference prepares a scene once per run and reuses it for every ray
+ * (simulation/raytracing_cache.py:92-111 cachedShape / cachedFaces /
+ * cachedBoundBox ..., cacheClear :36).  Here, for a scene of <= 16 analytic
+ * primitives the library can compile the ray loop against the scene itself
+ * (hiprtc, ~2 s, cached per process and on disk): primitive loop unrolled,
+ * type dispatch / face masks / trimming lists / optical types folded.
+ *   ODW_COMPILE_STRUCTURE  values are still read from the uploaded tables: one
+ *                          kernel per scene STRUCTURE (parameter sweeps reuse it)
+ *   ODW_COMPILE_VALUES     frames, parameters, boxes, optical constants are
+ *                          literals of the kernel too: one kernel per scene
+ * The mode is sticky: it applies to the uploaded scene (bound at once if scene
+ * and limits are there, else at the next launch) and to every scene uploaded
+ * later.  Scenes outside the flat kernel's domain (facets, paraboloids, > 16
+ * primitives, stochastic surfaces, segment rows) keep the generic kernels --
+ * that is not an error.  Results are those of the generic kernel.
+ * ODW_KERNEL_CACHE: directory of the disk cache (default ~/.cache/odw_trace,
+ * empty string: none).                                                       */
+#define ODW_COMPILE_OFF 0
+#define ODW_COMPILE_STRUCTURE 1
+#define ODW_COMPILE_VALUES 2
+int odw_compile_scene(odw_ctx* ctx, int32_t mode);
+/* bound: the mode of the kernel the next eligible launch runs (0: generic);
+ * compile_seconds: of the bound kernel (0 if it came from a cache);
+ * cache_hit: 0 compiled now, 1 process cache, 2 disk cache                   */
+int odw_compiled_info(odw_ctx* ctx, int32_t* bound, double* compile_seconds, int32_t* cache_hit);
+/* no device needed: writes the scene's header (NUL-terminated, truncated to
+ * header_capacity) and compiles the kernel for `arch` (NULL: "gfx950");
+ * code_bytes = size of the code object.  ODW_ERR_UNSUPPORTED: the scene is
+ * outside the flat kernel's domain.                                          */
+int odw_compile_check(const odw_scene_desc* scene, const odw_limits* limits, int32_t mode, const char* arch,
+                      char* header_out, uint64_t header_capacity, uint64_t* code_bytes);
 
 /* device-side handles for collectives (RCCL reduce through torch)          */
 int odw_device_histogram(odw_ctx* ctx, void** dptr, uint64_t* n_bins);

@@ -26,9 +26,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument('tag')
 ap.add_argument('--config', default='c3')
 ap.add_argument('--no-bench', action='store_true')
+ap.add_argument('--kernel', default=None, help='substring of the kernel name the counters are taken from')
 args = ap.parse_args()
 tag = args.tag
-KERNEL_LIKE = {'c3': '%odw_trace_kernel<false, false, false%', 'c4': '%odw_grid_kernel%'}[args.config]
+KERNEL_NAME = args.kernel or {'c3': 'odw_trace_kernel<false, false, false', 'c4': 'odw_grid_kernel'}[args.config]
+KERNEL_LIKE = '%' + KERNEL_NAME + '%'
 out = os.path.join(ROOT, 'gpurun_out')
 os.makedirs(out, exist_ok=True)
 env = dict(os.environ, TMPDIR='/tmp')
@@ -80,7 +82,7 @@ if rows and cols:
   ci = {c.lower(): k for k, c in enumerate(cols)}
   for r in rows:
     nm = str(r[ci.get('name', 0)])
-    if ('odw_grid_kernel' in nm) if args.config == 'c4' else ('odw_trace_kernel<false, false, false' in nm):
+    if KERNEL_NAME in nm:
       for key in ('average', 'avg', 'averagens', 'average_ns'):
         if key in ci:
           kernel_ms = float(r[ci[key]]) / 1e3          # the view reports microseconds
