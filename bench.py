@@ -44,7 +44,7 @@ RAY_STATE_BYTES = 64    # S, read + written once per segment
 HIT_BYTES = 64          # H, one row per recorded hit
 
 CONFIGS = {
-    'c3': dict(scene='lensesAndMirrors', rays=1e8, steps=5, warmup=1, kernel='odw_trace_kernel<false, false, false, true>',
+    'c3': dict(scene='lensesAndMirrors', rays=1e8, steps=20, warmup=3, kernel='odw_trace_kernel<false, false, false, true>',
                workload='benchmark/lensesAndMirrors.FCStd, %.0e Monte-Carlo rays per step per GPU (BASELINE configs[2]), '
                         'Gaussian point source sigma=1e-2, Philox4x32-10 seed 0x0D15EA5E'),
     'c4': dict(scene='hugeArray', rays=1.25e8, steps=3, warmup=1, kernel='odw_grid_kernel<true, true>',
@@ -125,7 +125,7 @@ def spawn_ranks(args, argv):
   return subprocess.call(cmd, env=dict(os.environ, MASTER_ADDR='127.0.0.1'))
 
 
-def pmc_figures(cfg_name, n_per, record_hits):
+def pmc_figures(cfg_name, n_per, record_hits, kernel):
   """HBM traffic and VALU figures of the dominant kernel from the committed rocprofv3 PMC passes of
   this same command (profiles/pmc_current.json: FETCH_SIZE / WRITE_SIZE / SQ_* in separate --pmc
   runs, gfx950 correction applied).  PMC cannot be collected from inside the process, so the
@@ -137,6 +137,8 @@ def pmc_figures(cfg_name, n_per, record_hits):
     allcfg = json.load(f)
   tj = allcfg.get(cfg_name)
   if not tj or tj.get('rays_per_launch') != n_per or not record_hits:
+    return None
+  if tj.get('kernel') and not kernel.startswith(tj['kernel']):     # profiled on another kernel (e.g. --compile off)
     return None
   return tj
 
@@ -162,6 +164,9 @@ def run_trace_config(args, cfg_name, cfg, rank, local_rank, world, dist, torch):
   tr.setSource(proj.source)
   tr.setLimits(proj.limits)
   tr.setDetector(det)
+  # scene-compiled kernel (odw_compile_scene): part of the scene's preparation, like its upload -- done
+  # before the clock starts; hugeArray (grid kernel) is outside its domain and keeps the generic kernel
+  compiled = tr.compileScene(args.compile)
   record_hits = not args.no_hits
   if record_hits:
     # c3: <= 1 recorded hit per ray; c4: 0.16 per ray (3 absorber layers of 15); reused every step
@@ -214,7 +219,8 @@ def run_trace_config(args, cfg_name, cfg, rank, local_rank, world, dist, torch):
     bytes_per_ray = kbar * 2 * RAY_STATE_BYTES + hbar * HIT_BYTES
     avg_kernel_s = kernel_ms / 1e3 / max(1, launches)
     achieved = bytes_per_ray * n_per / avg_kernel_s / 1e9
-    pmc = pmc_figures(cfg_name, n_per, record_hits)
+    kernel_name = 'odw_spec_kernel' if compiled['mode'] else cfg['kernel']
+    pmc = pmc_figures(cfg_name, n_per, record_hits, kernel_name)
     traffic = traffic_bytes = valu = None
     if pmc:
       traffic_bytes = pmc['hbm_bytes_per_launch']
@@ -229,12 +235,15 @@ def run_trace_config(args, cfg_name, cfg, rank, local_rank, world, dist, torch):
         'config': {'workload': cfg['workload'] % n_per, 'name': cfg_name,
                    'rays_per_step_per_gpu': n_per, 'segments_per_ray': kbar, 'hits_per_ray': hbar,
                    'record_hit_rows': record_hits, 'histogram': '1024x1024 u64',
+                   'scene_compiled': {'mode': {0: 'off', 1: 'structure'}[compiled['mode']],
+                                      'compile_seconds': compiled['seconds'], 'cache': compiled['cache'],
+                                      'note': 'hiprtc compile of the ray loop against the scene, before the timed region'},
                    'parallelism': f'ray-index sharding x{world}, one RCCL reduce'},
         'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                      'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_bytes_per_launch': traffic_bytes,
                      'algorithmic_bytes_per_launch': bytes_per_ray * n_per,
                      'traffic_source': pmc.get('source') if pmc else None,
-                     'kernel': cfg['kernel'], 'avg_kernel_ms': avg_kernel_s * 1e3,
+                     'kernel': kernel_name, 'avg_kernel_ms': avg_kernel_s * 1e3,
                      'algorithmic_bytes_per_ray': bytes_per_ray, 'valu': valu},
     }
     if world == 1 and record_hits and cfg_name == 'c3' and not args.no_end_to_end:
@@ -285,6 +294,7 @@ def run_sweep_config(args, cfg, rank, local_rank, world, dist, torch):
   def setRadius(d, r):
     d.Sphere.Radius = float(r)
   tr = Tracer(local_rank)
+  tr.compileScene(args.compile)      # sticky: every radius has the same structure -> one kernel for the sweep
 
   def barrier():
     tr.sync()
@@ -362,6 +372,8 @@ def main():
   ap.add_argument('--rays-per-step', type=float, default=None,
                   help='rays per step per GPU (c5: per radius); default: the BASELINE size of the config')
   ap.add_argument('--radii', type=int, default=N_RADII, help='c5: number of radii of the sweep')
+  ap.add_argument('--compile', choices=['off', 'structure'], default='structure',
+                  help='scene-compiled kernels (odw_compile_scene); scenes outside their domain (c4) run the generic ones')
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-end-to-end', action='store_true')
   ap.add_argument('--no-hits', action='store_true', help='histogram only (diagnostic, not the metric)')

@@ -21,8 +21,8 @@ ABI_VERSION = 6
 CNT_NAMES = ['traced_rays', 'recorded_hits', 'segments', 'escaped', 'died', 'capped',
              'hist_overflow', 'hits_dropped', 'grating_in_medium']
 TRACE_RECORD_HITS, TRACE_HISTOGRAM, TRACE_RECORD_SEGMENTS = 1, 2, 4
-COMPILE_OFF, COMPILE_STRUCTURE, COMPILE_VALUES = 0, 1, 2
-COMPILE_MODES = {None: 0, False: 0, 'off': 0, 0: 0, 'structure': 1, 1: 1, True: 1, 'values': 2, 2: 2}
+COMPILE_OFF, COMPILE_STRUCTURE = 0, 1
+COMPILE_MODES = {None: 0, False: 0, 'off': 0, 0: 0, 'structure': 1, 1: 1, True: 1}
 ERRORS = {1: 'invalid argument', 2: 'device error', 3: 'no scene', 4: 'capacity', 5: 'unsupported'}
 
 HIT_DTYPE = np.dtype([('point', '<f8', 3), ('direction', '<f8', 3), ('power', '<f8'), ('tag', '<u8')])
@@ -108,7 +108,9 @@ def build(force=False, verbose=False):
   """compile csrc/ for gfx950 into csrc/libodw_trace.so"""
   if not force and not needs_build():
     return LIB_PATH
-  cmd = [hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
+  # -ffp-contract=on: products and sums are fused where one expression says so, never across statements
+  # -- the generic kernels and the scene-compiled ones (odw_spec.hip, same flag) then round alike
+  cmd = [hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=on', '-fPIC', '-shared',
          '-o', LIB_PATH + '.tmp', os.path.join(CSRC, 'odw_capi.hip')]
   if verbose:
     cmd.insert(1, '-Rpass-analysis=kernel-resource-usage')

@@ -1065,7 +1065,7 @@ int odw_upload_scene(odw_ctx* ctx, const odw_scene_desc* s) {
 }
 
 int odw_compile_scene(odw_ctx* ctx, int32_t mode) {
-  if (!ctx || mode < ODW_COMPILE_OFF || mode > ODW_COMPILE_VALUES) return fail(ctx, ODW_ERR_INVALID, "odw_compile_scene: bad argument");
+  if (!ctx || mode < ODW_COMPILE_OFF || mode > ODW_COMPILE_STRUCTURE) return fail(ctx, ODW_ERR_INVALID, "odw_compile_scene: bad argument");
   ctx->compile_mode = mode;
   ctx->spec_dirty = true;
   ctx->spec_fn = nullptr;
@@ -1088,7 +1088,7 @@ int odw_compiled_info(odw_ctx* ctx, int32_t* bound, double* compile_seconds, int
 
 int odw_compile_check(const odw_scene_desc* scene, const odw_limits* limits, int32_t mode, const char* arch,
                       char* header_out, uint64_t header_capacity, uint64_t* code_bytes) {
-  if (!scene || !limits || mode < ODW_COMPILE_STRUCTURE || mode > ODW_COMPILE_VALUES)
+  if (!scene || !limits || mode != ODW_COMPILE_STRUCTURE)
     return fail(nullptr, ODW_ERR_INVALID, "odw_compile_check: bad argument");
   odw_ctx tmp;                     // host tables only: no device, no stream
   std::memset(&tmp.P, 0, sizeof tmp.P);
@@ -1101,7 +1101,7 @@ int odw_compile_check(const odw_scene_desc* scene, const odw_limits* limits, int
   compute_boxes(&tmp, boxes, dead);
   const std::string why = spec_ineligible(&tmp);
   if (!why.empty()) return fail(nullptr, ODW_ERR_UNSUPPORTED, "odw_compile_check: " + why);
-  const std::string text = spec_text(&tmp, mode);
+  const std::string text = spec_text(&tmp);
   if (header_out && header_capacity) {
     const size_t k = std::min<size_t>(text.size(), (size_t)header_capacity - 1);
     std::memcpy(header_out, text.data(), k);
@@ -1109,7 +1109,7 @@ int odw_compile_check(const odw_scene_desc* scene, const odw_limits* limits, int
   }
   std::vector<char> code;
   std::string err;
-  if (!spec_compile(text, mode == ODW_COMPILE_VALUES, arch && *arch ? arch : "gfx950", code, err))
+  if (!spec_compile(text, arch && *arch ? arch : "gfx950", code, err))
     return fail(nullptr, ODW_ERR_DEVICE, err);
   if (code_bytes) *code_bytes = code.size();
   return ODW_OK;

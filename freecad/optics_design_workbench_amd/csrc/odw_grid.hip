@@ -106,14 +106,14 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
   double* ring = grid_lds + ring_off + wave * ODW_GRID_RING_DOUBLES;      // slot s: origin (3), direction (3)
 
   SceneView sv;
-  sv.prim_f64 = as_scene(sc.prim_f64);
-  sv.prim_hdr = as_scene(sc.prim_hdr);
-  sv.prim_i32 = as_scene(sc.prim_i32);
-  sv.cond_i32 = as_scene(sc.cond_i32);
-  cf64 group_f64 = as_scene(sc.group_f64);
-  ci32 group_i32 = as_scene(sc.group_i32);
-  cf64 group_gdir = as_scene(sc.group_gdir);
-  cu64 seq_mask = as_scene(sc.seq_mask);
+  sv.prim_f64 = as_const(sc.prim_f64);
+  sv.prim_hdr = as_const(sc.prim_hdr);
+  sv.prim_i32 = as_const(sc.prim_i32);
+  sv.cond_i32 = as_const(sc.cond_i32);
+  cf64 group_f64 = as_const(sc.group_f64);
+  ci32 group_i32 = as_const(sc.group_i32);
+  cf64 group_gdir = as_const(sc.group_gdir);
+  cu64 seq_mask = as_const(sc.seq_mask);
 
   const uint32_t lane = __lane_id();
   uint64_t next = 0, chunk_end = 0;                        // wave-uniform: the wave's chunk of the launch

@@ -29,23 +29,12 @@ namespace odw {
 // primitive.  (Plain global pointers inside a by-value struct are not
 // provably unclobbered, and hipcc falls back to per-lane global_load.)
 #define ODW_CONST __attribute__((address_space(4)))
-// (a scene compiled with its values, odw_spec.hip, reads its tables from constant arrays of the
-// translation unit itself: plain pointers, every read with a constant index folds to a literal)
-#ifdef ODW_SPEC_VALUES
-#define ODW_SCENE_AS
-#else
-#define ODW_SCENE_AS ODW_CONST
-#endif
-typedef const double ODW_SCENE_AS* cf64;
-typedef const int32_t ODW_SCENE_AS* ci32;
-typedef const uint64_t ODW_SCENE_AS* cu64;
+typedef const double ODW_CONST* cf64;
+typedef const int32_t ODW_CONST* ci32;
+typedef const uint64_t ODW_CONST* cu64;
 template <class T>
 __device__ __forceinline__ const T ODW_CONST* as_const(const T* p) {
   return (const T ODW_CONST*)(uintptr_t)p;
-}
-template <class T>
-__device__ __forceinline__ const T ODW_SCENE_AS* as_scene(const T* p) {
-  return (const T ODW_SCENE_AS*)(uintptr_t)p;
 }
 // a uniform pointer the optimiser cannot see through: loads behind it stay
 // where they are written instead of being hoisted out of the ray loop
@@ -201,7 +190,7 @@ __device__ __forceinline__ d3 xf_vec_t(P m, d3 v) {  // R^T v
 // optical constants) are still read from the tables, so one compiled kernel serves every scene of the
 // same structure (a radius sweep compiles once).  NoSpec = the generic kernels.
 struct NoSpec {
-  static constexpr bool enabled = false, values = false;
+  static constexpr bool enabled = false;
   static constexpr int N = 0;
   static constexpr unsigned long long xf(int) { return 0xfffull; }
   static constexpr int type(int) { return 0; }
@@ -899,7 +888,7 @@ __device__ __forceinline__ int nearest(const DeviceScene& sc, const SceneView& s
     typedef float vf4 __attribute__((ext_vector_type(4)));
     typedef int vi4 __attribute__((ext_vector_type(4)));
     cf32 nodes = (cf32)(uintptr_t)sc.bvh_nodes;
-    ci32 bvh_prims = as_scene(sc.bvh_prims);
+    ci32 bvh_prims = as_const(sc.bvh_prims);
     const float ofx = (float)start.x, ofy = (float)start.y, ofz = (float)start.z;
     const float ivx = (float)inv.x, ivy = (float)inv.y, ivz = (float)inv.z;
     int sp = 0;
@@ -1401,21 +1390,14 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
   const DeviceScene& sc = P.scene;
   const DeviceLimits& lim = P.lim;
   SceneView sv;
-  sv.prim_f64 = as_scene(sc.prim_f64);
-  sv.prim_hdr = as_scene(sc.prim_hdr);
-  sv.prim_i32 = as_scene(sc.prim_i32);
-  sv.cond_i32 = as_scene(sc.cond_i32);
-  cf64 group_f64 = as_scene(sc.group_f64);
-  ci32 group_i32 = as_scene(sc.group_i32);
-  cf64 group_gdir = as_scene(sc.group_gdir);
-  cu64 seq_mask = as_scene(sc.seq_mask);
-  if constexpr (SPEC::values) {       // the compiled scene's own constant tables
-    sv.prim_f64 = SPEC::prim_f64();
-    sv.prim_hdr = SPEC::prim_hdr();
-    group_f64 = SPEC::group_f64();
-    group_i32 = SPEC::group_i32();
-    group_gdir = SPEC::group_gdir();
-  }
+  sv.prim_f64 = as_const(sc.prim_f64);
+  sv.prim_hdr = as_const(sc.prim_hdr);
+  sv.prim_i32 = as_const(sc.prim_i32);
+  sv.cond_i32 = as_const(sc.cond_i32);
+  cf64 group_f64 = as_const(sc.group_f64);
+  ci32 group_i32 = as_const(sc.group_i32);
+  cf64 group_gdir = as_const(sc.group_gdir);
+  cu64 seq_mask = as_const(sc.seq_mask);
   // Persistent waves with ray regeneration.  Rays are handed out in chunks of
   // ODW_CHUNK consecutive indices, taken from a launch-wide atomic counter.  A
   // lane whose ray has terminated takes the next index of its wave's chunk

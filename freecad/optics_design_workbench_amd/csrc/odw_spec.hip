@@ -8,14 +8,14 @@
 // of every group -- as a C++ header of compile-time constants, compiles odw_kernels.hip's ray loop
 // against it with hiprtc (1.5 - 2 s), and launches that kernel instead of the generic one: the
 // primitive loop is unrolled, type dispatch and face masks fold away, frame products skip their zero
-// terms, table reads have constant offsets (odw_kernels.hip: SPEC).  Two levels:
-//   ODW_COMPILE_STRUCTURE  float64 values still come from the tables: one kernel serves every scene
-//                          of the same structure (a parameter sweep compiles once);
-//   ODW_COMPILE_VALUES     the values (frames, parameters, boxes, optical constants) are literals of
-//                          the kernel as well: no table reads at all in the primitive loop; a kernel
-//                          per scene -- for long runs on a fixed scene.
+// terms, table reads have constant offsets (odw_kernels.hip: SPEC).  All float64 VALUES (frames,
+// parameters, boxes, optical constants) are still read from the uploaded tables, so one kernel serves
+// every scene of the same structure: a parameter sweep compiles once.  (Values as literals of the
+// kernel were tried as a second level: 13.1 against 12.2 ms per 1e8 C3 rays -- the constants crowd the
+// scalar registers, 56 spilled -- and rounding no longer matched the generic kernel; not kept.)
 // Kernels are cached per process (key = the header text) and on disk (ODW_KERNEL_CACHE, default
-// ~/.cache/odw_trace).  Results: the same arithmetic in the same order as the generic kernel.
+// ~/.cache/odw_trace).  Results: the generic kernel's, bit for bit (same arithmetic in the same
+// order; both are compiled with -ffp-contract=on).
 // hiprtc is loaded on first use (dlopen); the kernel sources are embedded in this library.
 #include <dlfcn.h>
 #include <hip/hiprtc.h>
@@ -108,9 +108,8 @@ std::string spec_ineligible(const odw_ctx* ctx) {
 
 // `struct Spec` of the uploaded scene (tables of scene_host_tables / compute_boxes).  The text is the
 // cache key: equal text = equal kernel.
-std::string spec_text(const odw_ctx* ctx, int mode) {
+std::string spec_text(const odw_ctx* ctx) {
   const int n = ctx->P.scene.n_prims, ng = ctx->P.scene.n_groups;
-  const bool values = mode == ODW_COMPILE_VALUES;
   std::vector<int> type(n), group(n), flags(n), condw(n), dead(n);
   std::vector<unsigned long long> xf(n);
   for (int p = 0; p < n; ++p) {
@@ -119,8 +118,8 @@ std::string spec_text(const odw_ctx* ctx, int mode) {
     flags[p] = ctx->h_prim_i32[4 * p + 2];
     condw[p] = ctx->h_prim_i32[4 * p + 3];
     const int facemask = (flags[p] >> ODW_FACEMASK_SHIFT) & 0xff;
-    // (an empty box is a matter of values: structural kernels keep such a primitive, its box culls it)
-    dead[p] = values ? (int)ctx->h_dead[p] : (facemask == 0);
+    // (an empty box is a matter of values: such a primitive stays, its box culls it)
+    dead[p] = facemask == 0;
     const double* m = &ctx->h_prim_f64[16 * (size_t)p];
     unsigned long long w = 0;
     for (int i = 0; i < 12; ++i) {
@@ -135,26 +134,7 @@ std::string spec_text(const odw_ctx* ctx, int mode) {
   auto fi = [](int v) { return std::to_string(v); };
   auto fu = [](unsigned long long v) { char b[32]; snprintf(b, sizeof b, "0x%llxull", v); return std::string(b); };
   std::string s;
-  if (values) {
-    auto arr = [&](const char* name, const std::vector<double>& v, size_t count) {
-      s += std::string("constexpr double ") + name + "[] = {";
-      for (size_t i = 0; i < std::max<size_t>(1, count); ++i) s += (i ? ", " : "") + (i < count ? f64_literal(v[i]) : std::string("0"));
-      s += "};\n";
-    };
-    s += "namespace odw {\n";
-    arr("kSpecPrimF64", ctx->h_prim_f64, (size_t)n * 16);
-    // (the four integers at the end of a 64-byte header are constants of the structure here)
-    std::vector<double> hdr(ctx->h_prim_hdr);
-    for (int p = 0; p < n; ++p) hdr[8 * (size_t)p + 6] = hdr[8 * (size_t)p + 7] = 0.0;
-    arr("kSpecPrimHdr", hdr, (size_t)n * 8);
-    arr("kSpecGroupF64", ctx->h_group_f64, (size_t)ng * 4);
-    arr("kSpecGroupGdir", ctx->h_group_gdir, (size_t)ng * 3);
-    s += "constexpr int kSpecGroupI32[] = {";
-    for (int i = 0; i < std::max(1, ng * 4); ++i) s += (i ? ", " : "") + std::to_string(i < ng * 4 ? ctx->h_group_i32[i] : 0);
-    s += "};\n}\n";
-  }
   s += "struct Spec {\n  static constexpr bool enabled = true;\n";
-  s += std::string("  static constexpr bool values = ") + (values ? "true" : "false") + ";\n";
   s += "  static constexpr int N = " + std::to_string(n) + ";\n";
   s += table("int", "type", n, type.data(), fi) + table("int", "group", n, group.data(), fi) +
        table("int", "flags", n, flags.data(), fi) + table("int", "cond_word", n, condw.data(), fi) +
@@ -166,12 +146,6 @@ std::string spec_text(const odw_ctx* ctx, int mode) {
        "  static constexpr int cond_cnt(int i) { return (cond_word(i) >> 24) & 0xff; }\n";
   s += "  static constexpr unsigned long long umask() { return " + fu(ctx->P.scene.all_mask & ~ctx->P.scene.ignore_mask) + "; }\n";
   s += std::string("  static constexpr bool seq() { return ") + (ctx->P.scene.seq_enabled ? "true" : "false") + "; }\n";
-  if (values)
-    s += "  static __device__ __forceinline__ const double* prim_f64() { return odw::kSpecPrimF64; }\n"
-         "  static __device__ __forceinline__ const double* prim_hdr() { return odw::kSpecPrimHdr; }\n"
-         "  static __device__ __forceinline__ const double* group_f64() { return odw::kSpecGroupF64; }\n"
-         "  static __device__ __forceinline__ const double* group_gdir() { return odw::kSpecGroupGdir; }\n"
-         "  static __device__ __forceinline__ const int* group_i32() { return odw::kSpecGroupI32; }\n";
   s += "};\n";
   s += std::string("#define ODW_SPEC_LEAN ") + (ctx->lean ? "true" : "false") + "\n";
   return s;
@@ -198,7 +172,7 @@ void mkdirs(const std::string& path) {
 }
 
 // header text -> code object for `arch`; error text in `err`
-bool spec_compile(const std::string& text, bool values, const std::string& arch, std::vector<char>& code, std::string& err) {
+bool spec_compile(const std::string& text, const std::string& arch, std::vector<char>& code, std::string& err) {
   Hiprtc& rtc = hiprtc();
   if (!rtc.error.empty()) { err = rtc.error; return false; }
   const char* headers[] = {odw_src_kernels, odw_src_device, odw_src_trace, text.c_str()};
@@ -209,8 +183,7 @@ bool spec_compile(const std::string& text, bool values, const std::string& arch,
     return false;
   }
   const std::string a = "--offload-arch=" + arch;
-  std::vector<const char*> opts = {a.c_str(), "-std=c++17", "-O3", "-DODW_SPEC_HEADER=\"odw_spec.h\""};
-  if (values) opts.push_back("-DODW_SPEC_VALUES=1");
+  std::vector<const char*> opts = {a.c_str(), "-std=c++17", "-O3", "-ffp-contract=on", "-DODW_SPEC_HEADER=\"odw_spec.h\""};
   // experiments: ODW_SPEC_OPTS = further compiler options, separated by blanks (part of the cache key)
   std::vector<std::string> extra;
   if (const char* e = getenv("ODW_SPEC_OPTS")) {
@@ -258,8 +231,7 @@ int spec_bind(odw_ctx* ctx) {
   hipDeviceProp_t prop;
   HIPCHK(ctx, hipGetDeviceProperties(&prop, ctx->device));
   const std::string arch = prop.gcnArchName;
-  const bool values = ctx->compile_mode == ODW_COMPILE_VALUES;
-  const std::string text = spec_text(ctx, ctx->compile_mode);
+  const std::string text = spec_text(ctx);
   const char* xo = getenv("ODW_SPEC_OPTS");
   const std::string key = std::to_string(ctx->device) + "|" + arch + "|" + (xo ? xo : "") + "|" + text;
   std::lock_guard<std::mutex> lock(g_spec_mu);
@@ -289,7 +261,7 @@ int spec_bind(odw_ctx* ctx) {
     if (code.empty()) {
       const auto t0 = std::chrono::steady_clock::now();
       std::string err;
-      if (!spec_compile(text, values, arch, code, err)) return fail(ctx, ODW_ERR_DEVICE, err);
+      if (!spec_compile(text, arch, code, err)) return fail(ctx, ODW_ERR_DEVICE, err);
       ctx->spec_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
       if (!file.empty()) {
         mkdirs(dir);

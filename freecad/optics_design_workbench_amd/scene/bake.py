@@ -370,8 +370,8 @@ def bakeScene(doc, source=None, surfaceFamily=None):
       prim_flags=np.concatenate([np.array([(1 if p.flip else 0) | (2 if getattr(p, 'convex', False) else 0) | (p.facemask << 8)
                                            for p in prims], dtype=np.int32),
                                  np.full(n_tri, 1 << 8, dtype=np.int32)]),
-      prim_xform=np.concatenate([np.array([p.to_world.inverse().rows12() for p in prims],
-                                          dtype=np.float64).reshape(n, 12), tri_xform]),
+      prim_xform=np.concatenate([_snapFrames(np.array([p.to_world.inverse().rows12() for p in prims],
+                                                      dtype=np.float64).reshape(n, 12)), tri_xform]),
       prim_params=np.concatenate([np.array([p.params for p in prims], dtype=np.float64).reshape(n, 4),
                                   np.zeros((n_tri, 4))]),
       prim_cond_off=np.array(cond_off, dtype=np.int32),
@@ -395,6 +395,24 @@ def bakeScene(doc, source=None, surfaceFamily=None):
       prim_to_world=[p.to_world for p in prims] + [None] * n_tri,
       surface_samplers=surface_samplers,
   )
+
+
+def _snapFrames(rows):
+  """Rotation entries of the global -> local frames that differ from 0 or +-1 by rounding of the
+  placement chain only (|.| < 1e-15: cos 90 deg = 6e-17, products of such) are set to the exact value.
+  The frame stays orthonormal to the last bit or two; an exact 0 / +-1 is a term the scene-compiled
+  kernels leave out (odw_kernels.hip: xf_comb) and costs the generic ones nothing."""
+  rows = np.array(rows, dtype=np.float64).reshape(-1, 12)
+  import os
+  if os.environ.get('ODW_NO_SNAP'):
+    return rows
+  rot = [0, 1, 2, 4, 5, 6, 8, 9, 10]
+  r = rows[:, rot]
+  r[np.abs(r) < 1e-15] = 0.0
+  r[np.abs(r - 1.0) < 1e-15] = 1.0
+  r[np.abs(r + 1.0) < 1e-15] = -1.0
+  rows[:, rot] = r
+  return rows
 
 
 def bakeLimits(doc, source=None, maxRayLength=None, maxIntersections=None, powerTol=1e-6,

@@ -32,7 +32,7 @@ class Tracer:
     _native.check(None, self._lib.odw_create(self.device, C.byref(self._ctx)), 'odw_create')
     self._det = None
     self._keep = {}
-    # ODW_COMPILE=structure|values: every tracer of the process compiles its scenes (test campaigns)
+    # ODW_COMPILE=structure: every tracer of the process compiles its scenes (test campaigns)
     import os
     if os.environ.get('ODW_COMPILE'):
       self.compileScene(os.environ['ODW_COMPILE'])
@@ -71,17 +71,17 @@ class Tracer:
 
   def compileScene(self, mode='structure'):
     """Scene-compiled kernels (odw_compile_scene): 'structure' -- the ray loop compiled against the
-    scene's structure (one kernel per structure: parameter sweeps reuse it), 'values' -- against its
-    values as well (one kernel per scene: long runs), 'off' / None -- the generic kernels.  Sticky:
-    applies to the uploaded scene and to every scene set later.  Same results as the generic
-    kernels; scenes outside the flat kernel's domain keep them silently.  Returns compiledInfo()."""
+    scene's structure (one kernel per structure: parameter sweeps reuse it), 'off' / None -- the
+    generic kernels.  Sticky: applies to the uploaded scene and to every scene set later.  The results
+    are those of the generic kernels bit for bit; scenes outside the flat kernel's domain keep them
+    silently.  Returns compiledInfo()."""
     f = self._lib.odw_compile_scene
     f.argtypes = [C.c_void_p, C.c_int32]
     self._chk(f(self._ctx, _native.COMPILE_MODES[mode]), 'odw_compile_scene')
     return self.compiledInfo()
 
   def compiledInfo(self):
-    """dict(mode: 0 generic / 1 structure / 2 values -- of the kernel the next eligible launch runs,
+    """dict(mode: 0 generic / 1 structure -- of the kernel the next eligible launch runs,
     seconds: compile time of it (0 from a cache), cache: 0 compiled now / 1 process / 2 disk)"""
     f = self._lib.odw_compiled_info
     f.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int32)]

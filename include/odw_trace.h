@@ -443,20 +443,18 @@ int odw_hits_moments(odw_ctx* ctx, double* mean, double* var);
  * primitives the library can compile the ray loop against the scene itself
  * (hiprtc, ~2 s, cached per process and on disk): primitive loop unrolled,
  * type dispatch / face masks / trimming lists / optical types folded.
- *   ODW_COMPILE_STRUCTURE  values are still read from the uploaded tables: one
- *                          kernel per scene STRUCTURE (parameter sweeps reuse it)
- *   ODW_COMPILE_VALUES     frames, parameters, boxes, optical constants are
- *                          literals of the kernel too: one kernel per scene
+ * Float64 values (frames, parameters, boxes, optical constants) are still read
+ * from the uploaded tables: one kernel per scene STRUCTURE, parameter sweeps
+ * reuse it.
  * The mode is sticky: it applies to the uploaded scene (bound at once if scene
  * and limits are there, else at the next launch) and to every scene uploaded
  * later.  Scenes outside the flat kernel's domain (facets, paraboloids, > 16
  * primitives, stochastic surfaces, segment rows) keep the generic kernels --
- * that is not an error.  Results are those of the generic kernel.
+ * that is not an error.  Results are those of the generic kernel, bit for bit.
  * ODW_KERNEL_CACHE: directory of the disk cache (default ~/.cache/odw_trace,
  * empty string: none).                                                       */
 #define ODW_COMPILE_OFF 0
 #define ODW_COMPILE_STRUCTURE 1
-#define ODW_COMPILE_VALUES 2
 int odw_compile_scene(odw_ctx* ctx, int32_t mode);
 /* bound: the mode of the kernel the next eligible launch runs (0: generic);
  * compile_seconds: of the bound kernel (0 if it came from a cache);

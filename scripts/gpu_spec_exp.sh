@@ -9,6 +9,5 @@ d = json.loads(open('gpurun_out/spec_exp.log').read().strip().splitlines()[-1])
 print('%.4g rays/s' % d['value'], '%.3f ms' % d['roofline']['avg_kernel_ms'], d['config']['segments_per_ray'], d['config']['hits_per_ray'], flush=True)
 PY
 }
-echo "generic"; ODW_COMPILE= run "$@" &&
-echo "structure" && ODW_COMPILE=structure run "$@" &&
-echo "values" && ODW_COMPILE=values run "$@"
+echo "generic"; run --compile off "$@" &&
+echo "structure" && run --compile structure "$@"

@@ -1,0 +1,150 @@
+"""Scene-compiled kernels on the device (odw_compile_scene): the same rays through the generic flat
+kernel and through the kernel compiled against the scene -- same counters, same hit rows, same
+histogram; cache behaviour; scenes outside the flat kernel's domain keep the generic kernels.
+(The whole -m gpu suite also passes with ODW_COMPILE=structure, i.e. with every tracer compiling
+its scenes: device-vs-oracle parity, randomised scenes and the acceptance tests included.)"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import SCENES, project
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x0D15EA5E
+
+
+def run(tr, proj, n, det=None, first=0):
+  tr.setScene(proj.scene)
+  tr.setSource(proj.source)
+  tr.setLimits(proj.limits)
+  tr.setDetector(det)
+  tr.reserveHits(max(16, 4 * n))
+  tr.reset()
+  tr.trace(first, n, SEED)
+  tr.sync()
+  return dict(counters=tr.counters(), hits=tr.hits(), hist=tr.histogram() if det is not None else None,
+              info=tr.compiledInfo())
+
+
+def same(a, b):
+  assert a['counters'] == b['counters']
+  assert np.array_equal(a['hits']['tag'], b['hits']['tag'])
+  # the same arithmetic in the same order: the rows are equal bit for bit
+  for col in ('point', 'direction', 'power'):
+    assert np.array_equal(a['hits'][col], b['hits'][col]), col
+  if a['hist'] is not None:
+    assert np.array_equal(a['hist'], b['hist'])
+
+
+@pytest.fixture()
+def tracers(native_lib):
+  from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
+  made = []
+
+  def make(mode):
+    tr = Tracer(0)
+    tr.compileScene(mode)
+    made.append(tr)
+    return tr
+  yield make
+  for tr in made:
+    tr.close()
+
+
+@pytest.mark.parametrize('scene,group', [('minimal', 'OpticalAbsorberGroup'), ('lensesAndMirrors', 'OpticalAbsorberGroup'),
+                                         ('lensesAndMirrorsSequential', 'OpticalAbsorberGroup'), ('GettingStarted', None),
+                                         ('grating', None), ('playground', None), ('mirror', None)])
+def test_compiled_kernel_equals_generic(tracers, scene, group, mode='structure'):
+  from freecad.optics_design_workbench_amd import scenes
+  proj = project(scene)
+  det = None
+  if group is not None:
+    det = scenes.planeDetector(proj.scene, group, nx=128, ny=128, toward=proj.source.xform[[3, 7, 11]])
+  n = 200000
+  ref = run(tracers('off'), proj, n, det)
+  got = run(tracers(mode), proj, n, det)
+  assert ref['info']['mode'] == 0
+  assert got['info']['mode'] == 1
+  assert ref['counters']['traced_rays'] == n
+  same(got, ref)
+
+
+def test_all_groups_recording_and_explicit_rays(tracers):
+  """every branch of the compiled interaction records; explicit initial conditions take the same kernel"""
+  import copy
+  proj = project('lensesAndMirrors')
+  sc = copy.copy(proj.scene)
+  sc.group_record = np.ones_like(sc.group_record)
+  rng = np.random.default_rng(5)
+  n = 100000
+  o = np.tile(np.asarray(proj.source.xform, dtype=float).reshape(12)[[3, 7, 11]], (n, 1)) + rng.normal(0, 0.2, (n, 3))
+  d = rng.normal(0, 0.02, (n, 3)) + np.array([0.0, 0.0, 1.0])
+  out = []
+  for mode in ('off', 'structure'):
+    tr = tracers(mode)
+    tr.setScene(sc)
+    tr.setLimits(proj.limits)
+    tr.setDetector(None)
+    tr.reserveHits(16 * n)
+    tr.reset()
+    tr.traceRays(o, d)
+    tr.sync()
+    out.append(dict(counters=tr.counters(), hits=tr.hits(), hist=None))
+  assert out[0]['counters']['recorded_hits'] > 2 * n
+  same(out[1], out[0])
+
+
+def test_one_kernel_for_a_parameter_sweep_and_process_cache(tracers):
+  from freecad.optics_design_workbench_amd import scenes
+  from freecad.optics_design_workbench_amd.scene import open_fcstd
+  doc = open_fcstd(os.path.join(SCENES, 'GettingStarted.FCStd'))
+  tr, ref = tracers('structure'), tracers('off')
+  infos = []
+  for r in (9.0, 9.7, 10.27, 11.0):
+    doc.Sphere.Radius = r
+    proj = scenes.bakeProject(doc)
+    got = run(tr, proj, 50000)
+    same(got, run(ref, proj, 50000))
+    infos.append(got['info'])
+  assert all(i['mode'] == 1 for i in infos)
+  # the first radius compiled (or found the kernel in a cache); the others reuse the loaded kernel
+  assert all(i['cache'] == 1 and i['seconds'] == 0 for i in infos[1:])
+  # another context of the process finds it too
+  other = run(tracers('structure'), proj, 1000)
+  assert other['info']['mode'] == 1 and other['info']['cache'] == 1
+
+
+def test_scenes_outside_the_domain_keep_the_generic_kernels(tracers):
+  proj = project('hugeArray')
+  tr = tracers('structure')
+  got = run(tr, proj, 20000)
+  assert got['info']['mode'] == 0                 # grid kernel
+  assert got['counters']['traced_rays'] == 20000
+  # and back to a small scene: bound again
+  small = run(tr, project('minimal'), 20000)
+  assert small['info']['mode'] == 1
+
+
+def test_histogram_window_edges(tracers):
+  """the per-block LDS window of the histogram: histograms smaller than the window, a window clipped
+  at the border, hits outside it -- always the bins of the plain count"""
+  from freecad.optics_design_workbench_amd import scenes
+  proj = project('lensesAndMirrors')
+  n = 300000
+  for nx, ny, half in ((16, 8, 10.0), (1024, 1024, 10.0), (2048, 64, 0.3), (200, 3000, 0.05)):
+    det = scenes.planeDetector(proj.scene, 'OpticalAbsorberGroup', nx=nx, ny=ny, toward=proj.source.xform[[3, 7, 11]])
+    det = dict(det, x_lo=-half, x_hi=half, y_lo=-half * 0.7, y_hi=half * 1.3)      # off-centre, partly cutting the spot
+    got = run(tracers('structure'), proj, n, det)
+    hist = got['hist'].reshape(nx, ny)
+    # reference binning of the recorded rows on the host, with the kernel's arithmetic
+    p = got['hits']['point'] - np.asarray(det['origin'])
+    x, y = p @ np.asarray(det['ex']), p @ np.asarray(det['ey'])
+    fx = np.floor((x - det['x_lo']) * (nx / (det['x_hi'] - det['x_lo'])))
+    fy = np.floor((y - det['y_lo']) * (ny / (det['y_hi'] - det['y_lo'])))
+    ok = (fx >= 0) & (fx < nx) & (fy >= 0) & (fy < ny)
+    want = np.zeros((nx, ny), dtype=np.uint64)
+    np.add.at(want, (fx[ok].astype(int), fy[ok].astype(int)), 1)
+    assert got['counters']['hist_overflow'] == int((~ok).sum())
+    assert np.array_equal(hist, want)
