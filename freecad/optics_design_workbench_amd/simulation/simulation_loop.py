@@ -34,9 +34,12 @@ def _limit(settings, key, default):
     return np.inf
 
 
+COMPILE_FROM_RAYS = 1e9     # a compile (<= 2 s) is worth ~1.5e10 traced rays at the rates of C3; see `compileScene`
+
+
 def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPath=None, store=None,
                   raysPerLaunch=1 << 22, endIf=None, tracer=None, pseudoIterationsPerLaunch=64,
-                  dist=None, **traceKwargs):
+                  dist=None, compileScene='auto', **traceKwargs):
   """trace `doc` until its simulation settings' end criteria are met.
 
   action       'true' (continuous Monte-Carlo) | 'singletrue' (one iteration)
@@ -54,6 +57,11 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
                hit files into the shared run folder, the end criteria see the
                job's totals (`parallel.Ranks`); picked up automatically under a
                launcher (WORLD_SIZE > 1)
+  compileScene 'auto': a continuous run whose end criteria allow >= 1e9 rays (or leave it to
+               endIf) compiles the ray loop against the scene (Tracer.compileScene: 0.5 - 2 s
+               once per scene structure, cached on disk) -- the results are those of the generic
+               kernels bit for bit, only faster; 'structure' / 'off': always / never.  Applies to
+               the tracer this call creates; a tracer passed in keeps its own setting.
   traceKwargs  maxRayLength, maxIntersections, powerTol, distTol (ray.py:36-38)
   -> SimulationResults
   """
@@ -91,6 +99,11 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
   enabled = enabledHitMetadata(settings)
   own = tracer is None
   tr = tracer or Tracer(device)
+  if own:
+    # rays the end criteria ask for, at most (a hit takes at least one ray)
+    wanted = min(store.endAfterRays, store.endAfterIterations * rpi * len(sources), store.endAfterHits) if continuous else 0
+    if compileScene == 'structure' or (compileScene == 'auto' and continuous and wanted >= COMPILE_FROM_RAYS):
+      tr.compileScene('structure')
   master = ranks.rank == 0
   if master:
     store.setStatus('simulation-is-done', False)

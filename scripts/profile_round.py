@@ -4,7 +4,7 @@
   python scripts/profile_round.py r02_c3 [--config c3|c4] [--no-bench]
 
 1. `python bench.py --config C`                                      -> gpurun_out/<tag>_bench.json
-2. `rocprofv3 --kernel-trace --stats -- python3 bench.py --config C` -> <tag>_kernel_stats.csv
+2. `rocprofv3 --kernel-trace --stats -- python3 bench.py --config C --steps 16 --warmup 4` -> <tag>_kernel_stats.csv
 3. `rocprofv3 --pmc <set> --kernel-trace -- python3 bench.py ...`    -> <tag>_pmc.json, one run per counter set
    (FETCH_SIZE and WRITE_SIZE alone, as MI355X_MICROARCH.md prescribes; no trace domains besides
    --kernel-trace next to --pmc)
@@ -29,7 +29,7 @@ ap.add_argument('--no-bench', action='store_true')
 ap.add_argument('--kernel', default=None, help='substring of the kernel name the counters are taken from')
 args = ap.parse_args()
 tag = args.tag
-KERNEL_NAME = args.kernel or {'c3': 'odw_trace_kernel<false, false, false', 'c4': 'odw_grid_kernel'}[args.config]
+KERNEL_NAME = args.kernel or {'c3': 'odw_spec_kernel', 'c4': 'odw_grid_kernel'}[args.config]
 KERNEL_LIKE = '%' + KERNEL_NAME + '%'
 out = os.path.join(ROOT, 'gpurun_out')
 os.makedirs(out, exist_ok=True)
@@ -65,7 +65,12 @@ if not args.no_bench:
 
 # 2. kernel trace
 d = os.path.join(out, f'{tag}_trace')
-run(['rocprofv3', '--kernel-trace', '--stats', '-d', d, '--'] + BENCH, f'{tag}_trace.log')
+# (more launches than the counter passes: the first two or three launches of a process run 5 - 15 %
+#  slower -- clocks, first touch -- and the average should be the steady state bench.py reports)
+TRACE_BENCH = [x for x in BENCH]
+TRACE_BENCH[TRACE_BENCH.index('--steps') + 1] = '16'
+TRACE_BENCH[TRACE_BENCH.index('--warmup') + 1] = '4'
+run(['rocprofv3', '--kernel-trace', '--stats', '-d', d, '--'] + TRACE_BENCH, f'{tag}_trace.log')
 con = db_of(d)
 name = [t for t in tables(con) if t.startswith('top_kernels')]
 rows = con.execute(f'select * from {name[0]}').fetchall() if name else []
