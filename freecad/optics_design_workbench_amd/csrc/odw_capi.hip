@@ -61,7 +61,7 @@ struct odw_ctx {
   int compile_mode = 0;                    // ODW_COMPILE_*: sticky, applies to every scene uploaded later too
   bool spec_dirty = true;                  // scene / limits changed since the last binding attempt
   hipFunction_t spec_fn = nullptr;         // bound kernel (owned by the process-wide cache), or null
-  bool spec_lean = false;
+  bool spec_lean = false, spec_stoch = false;
   double spec_seconds = 0;                 // compile time of the bound kernel (0: it came from a cache)
   int spec_cache_hit = 0;                  // 0 compiled now, 1 process cache, 2 disk cache
   bool have_scene = false, have_source = false, have_limits = false;
@@ -800,8 +800,8 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
     if (stoch) hipLaunchKernelGGL((odw_trace_kernel<true, true, false>), dim3(grid), dim3(256), lds, ctx->stream, P);
     else hipLaunchKernelGGL((odw_trace_kernel<true, false, false>), dim3(grid), dim3(256), lds, ctx->stream, P);
   } else {
-    if (stoch) hipLaunchKernelGGL((odw_trace_kernel<false, true, false>), dim3(grid), dim3(256), 0, ctx->stream, P);
-    else if (ctx->spec_fn && ctx->spec_lean == ctx->lean) { int rc = spec_launch(ctx, grid); if (rc) return rc; }
+    if (ctx->spec_fn && ctx->spec_lean == ctx->lean && ctx->spec_stoch == stoch) { int rc = spec_launch(ctx, grid); if (rc) return rc; }
+    else if (stoch) hipLaunchKernelGGL((odw_trace_kernel<false, true, false>), dim3(grid), dim3(256), 0, ctx->stream, P);
     else if (ctx->lean) hipLaunchKernelGGL((odw_trace_kernel<false, false, false, true>), dim3(grid), dim3(256), 0, ctx->stream, P);
     else hipLaunchKernelGGL((odw_trace_kernel<false, false, false>), dim3(grid), dim3(256), 0, ctx->stream, P);
   }
@@ -1121,6 +1121,7 @@ int odw_upload_surface_samplers(odw_ctx* ctx, const odw_surface_sampler_desc* sa
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // a running launch may still read the old tables
   ctx->n_samplers = 0;
+  ctx->spec_dirty = true;                           // (a compiled scene: the kernel variant with / without scatter())
   if (n == 0) return ODW_OK;
   std::vector<int32_t> gs(ODW_MAX_GROUPS * 2, -1);
   std::vector<DeviceSurfaceSampler> ds((size_t)n);

@@ -1322,7 +1322,7 @@ __device__ __forceinline__ void interact(const TraceParams& P, cf64 group_f64, c
 
 // the hit is on primitive PI of a compiled scene: its type, frame pattern, flags, group and the group's
 // optical type / recording switch are constants
-template <bool LEAN, class SPEC, int PI>
+template <bool STOCH, bool LEAN, class SPEC, int PI>
 __device__ __forceinline__ void spec_hit(const TraceParams& P, const SceneView& sv, cf64 group_f64, ci32 group_i32,
                                          cf64 group_gdir, int face, uint64_t ray, int nint, uint32_t* cnt,
                                          uint32_t* hit_state, uint32_t* win, d3 point, d3& dir, double& power, int& medium, int& seq,
@@ -1334,19 +1334,19 @@ __device__ __forceinline__ void spec_hit(const TraceParams& P, const SceneView& 
   n = xf_vec_t_nz<SPEC::xf(PI)>(pf, n);
   const bool entering = dot(dir, n) < 0;
   if (entering) n = n * -1.0;
-  interact<false, false, LEAN>(P, group_f64, group_i32, group_gdir, g, SPEC::gtype(g), SPEC::record(g), n, entering, ray,
+  interact<false, STOCH, LEAN>(P, group_f64, group_i32, group_gdir, g, SPEC::gtype(g), SPEC::record(g), n, entering, ray,
                                nint, cnt, hit_state, win, point, dir, power, medium, seq, alive);
   if constexpr ((flags & ODW_FLAG_CONVEX) != 0)
     skip = ((entering ? -dot(dir, n) : dot(dir, n)) > 0) ? (flags >> ODW_SOLID_SHIFT) : -1;
   else
     skip = -1;
 }
-template <bool LEAN, class SPEC, int... PI>
+template <bool STOCH, bool LEAN, class SPEC, int... PI>
 __device__ __forceinline__ void spec_hits(const TraceParams& P, const SceneView& sv, cf64 group_f64, ci32 group_i32,
                                           cf64 group_gdir, int prim, int face, uint64_t ray, int nint, uint32_t* cnt,
                                           uint32_t* hit_state, uint32_t* win, d3 point, d3& dir, double& power, int& medium, int& seq,
                                           int& skip, bool& alive, IndexList<int, PI...>) {
-  (void)((prim == PI ? (spec_hit<LEAN, SPEC, PI>(P, sv, group_f64, group_i32, group_gdir, face, ray, nint, cnt, hit_state, win,
+  (void)((prim == PI ? (spec_hit<STOCH, LEAN, SPEC, PI>(P, sv, group_f64, group_i32, group_gdir, face, ray, nint, cnt, hit_state, win,
                                                   point, dir, power, medium, seq, skip, alive), true)
                      : false) || ...);
 }
@@ -1493,7 +1493,7 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
       uint32_t* cnt = cnt_lds + threadIdx.x;
       uint32_t* hit_state = hit_lds + (threadIdx.x >> 6) * 4;
       if constexpr (SPEC::enabled) {
-        spec_hits<LEAN, SPEC>(P, sv, group_f64, group_i32, group_gdir, prim, face, P.first_ray + i, nint, cnt, hit_state,
+        spec_hits<STOCH, LEAN, SPEC>(P, sv, group_f64, group_i32, group_gdir, prim, face, P.first_ray + i, nint, cnt, hit_state,
                               hist_win, point, dir, power, medium, seq, skip, alive, __make_integer_seq<IndexList, int, SPEC::N>{});
       } else {
       cf64 pf = sv.prim_f64 + (size_t)prim * 16;
@@ -1565,13 +1565,16 @@ __global__ __launch_bounds__(256, BVH ? ODW_WAVES_PER_SIMD_BVH : ODW_WAVES_PER_S
 
 #ifdef ODW_SPEC_HEADER
 // the scene-compiled flat kernel: ODW_SPEC_HEADER defines `struct Spec` (written by the host library
-// from the uploaded scene, odw_capi.hip: spec_source) and ODW_SPEC_LEAN
+// from the uploaded scene, odw_spec.hip: spec_text), ODW_SPEC_LEAN and ODW_SPEC_STOCH
 #include ODW_SPEC_HEADER
 #ifndef ODW_SPEC_WAVES
 #define ODW_SPEC_WAVES 4
 #endif
+#ifndef ODW_SPEC_STOCH
+#define ODW_SPEC_STOCH false
+#endif
 extern "C" __global__ __launch_bounds__(256, ODW_SPEC_WAVES) void odw_spec_kernel(const TraceParams P) {
-  trace_body<false, false, false, ODW_SPEC_LEAN, Spec>(P);
+  trace_body<false, ODW_SPEC_STOCH, false, ODW_SPEC_LEAN, Spec>(P);
 }
 #endif
 

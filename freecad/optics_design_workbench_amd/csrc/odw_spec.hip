@@ -148,6 +148,8 @@ std::string spec_text(const odw_ctx* ctx) {
   s += std::string("  static constexpr bool seq() { return ") + (ctx->P.scene.seq_enabled ? "true" : "false") + "; }\n";
   s += "};\n";
   s += std::string("#define ODW_SPEC_LEAN ") + (ctx->lean ? "true" : "false") + "\n";
+  // stochastic surfaces: the kernel variant with scatter() (the sampler tables themselves are run-time data)
+  s += std::string("#define ODW_SPEC_STOCH ") + (ctx->n_samplers > 0 ? "true" : "false") + "\n";
   return s;
 }
 
@@ -282,6 +284,7 @@ int spec_bind(odw_ctx* ctx) {
   }
   ctx->spec_fn = it->second.fn;
   ctx->spec_lean = ctx->lean;
+  ctx->spec_stoch = ctx->n_samplers > 0;
   return ODW_OK;
 }
 

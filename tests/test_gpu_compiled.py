@@ -55,7 +55,7 @@ def tracers(native_lib):
 
 @pytest.mark.parametrize('scene,group', [('minimal', 'OpticalAbsorberGroup'), ('lensesAndMirrors', 'OpticalAbsorberGroup'),
                                          ('lensesAndMirrorsSequential', 'OpticalAbsorberGroup'), ('GettingStarted', None),
-                                         ('grating', None), ('playground', None), ('mirror', None)])
+                                         ('grating', None), ('playground', None), ('mirror', None), ('mirror-diffuse', None)])
 def test_compiled_kernel_equals_generic(tracers, scene, group, mode='structure'):
   from freecad.optics_design_workbench_amd import scenes
   proj = project(scene)
