@@ -77,8 +77,11 @@ __device__ __forceinline__ void philox4x32_10(uint32_t& c0, uint32_t& c1, uint32
                                               uint32_t& c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
-    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    // (one 32 x 32 -> 64 bit multiply per product: v_mad_u64_u32, instead of a high and a low one --
+    //  integer multiplies issue at a quarter of the rate)
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
     const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
     c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
     k0 += 0x9E3779B9u;
@@ -274,12 +277,14 @@ __device__ __forceinline__ void make_ray(csource s, double t_or_r, double phi,
     ldir = mk(0, 0, 1);
     lorg = mk(t_or_r * cp, -t_or_r * sp, 0.0);
   }
-  const d3 ln = ldir * (1.0 / sqrt(dot(ldir, ldir)));
+  // (both vectors are unit vectors up to rounding already: the two normalisations of the reference move them
+  //  by an ulp or two, frsqrt -- <= 2 ulp -- does the same without the IEEE square root and division)
+  const d3 ln = ldir * frsqrt(dot(ldir, ldir));
   const d3 p1 = xf_point(s->m, lorg);
   const d3 p2 = xf_point(s->m, lorg + ln);
   const d3 d = p2 - p1;
   origin = p1;
-  dir = d * (1.0 / sqrt(dot(d, d)));
+  dir = d * frsqrt(dot(d, d));
 }
 
 // ----------------------------------------------------------- primitives
@@ -818,16 +823,33 @@ __device__ __forceinline__ bool ray_box(P bx, d3 oi, d3 inv, double tmax) {
 //            reference's shell/face BoundBox culls (ray.py:353-398);
 // BVH=true : stack traversal, node stack in LDS (one column per thread).
 // one primitive of a compiled scene (flat loop unrolled over SPEC)
+// boxhit: the outcome of the box test of every primitive so far.  Operands of a Common that must lie inside
+// each other (a lens = sphere in cylinder, cylinder in sphere) carry the SAME box -- each one's own box cut by
+// the other's -- which shows in the structure: equal sets {primitive} + {primitives it must be inside}
+// (SPEC::box_of = the first primitive with that set).  The later ones reuse the first one's outcome (taken
+// with a cut at least as wide: conservative).
 template <class SPEC, int PI>
-__device__ __forceinline__ void spec_prim(const SceneView& sv, Query& q, d3 oi, d3 inv, int skip_solid, uint64_t mask) {
+__device__ __forceinline__ void spec_prim(const SceneView& sv, Query& q, d3 oi, d3 inv, int skip_solid, uint64_t mask,
+                                          bool* boxhit) {
   constexpr int flags = SPEC::flags(PI);
   // relevant groups: a constant without sequential mode (ignored groups' primitives leave no code),
   // the ray's own mask with it
   if constexpr (!SPEC::dead(PI) && (SPEC::seq() || ((SPEC::umask() >> SPEC::group(PI)) & 1) != 0)) {
     if ((!SPEC::seq() || ((mask >> SPEC::group(PI)) & 1)) && (flags >> ODW_SOLID_SHIFT) != skip_solid) {
-      const double cut = fmin(q.tmax, q.any.t + 2.0 * q.tol);
-      if (ray_box(sv.prim_hdr + 8 * PI, oi, inv, cut))
+      bool in_box;
+      if constexpr (SPEC::box_of(PI) != PI) {
+        in_box = boxhit[SPEC::box_of(PI)];
+      } else {
+        const double cut = fmin(q.tmax, q.any.t + 2.0 * q.tol);
+        in_box = ray_box(sv.prim_hdr + 8 * PI, oi, inv, cut);
+      }
+      boxhit[PI] = in_box;
+      if (in_box)
         intersect_prim<false, SPEC, PI>(sv, q, PI, SPEC::type(PI), SPEC::group(PI), flags, SPEC::cond_word(PI));
+    } else if constexpr (SPEC::box_of(PI) == PI) {
+      // (skipped for this lane -- not relevant, or the convex solid just left --, but a later primitive may
+      //  ask for this box: its own test then)
+      boxhit[PI] = SPEC::box_shared(PI) ? ray_box(sv.prim_hdr + 8 * PI, oi, inv, fmin(q.tmax, q.any.t + 2.0 * q.tol)) : false;
     }
   }
 }
@@ -835,7 +857,8 @@ template <class T, T... I> struct IndexList {};      // (std::integer_sequence w
 template <class SPEC, int... PI>
 __device__ __forceinline__ void spec_prims(const SceneView& sv, Query& q, d3 oi, d3 inv, int skip_solid, uint64_t mask,
                                            IndexList<int, PI...>) {
-  (spec_prim<SPEC, PI>(sv, q, oi, inv, skip_solid, mask), ...);
+  bool boxhit[sizeof...(PI)] = {};
+  (spec_prim<SPEC, PI>(sv, q, oi, inv, skip_solid, mask, boxhit), ...);
 }
 
 template <bool BVH, class SPEC = NoSpec>

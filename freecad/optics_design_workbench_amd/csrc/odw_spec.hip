@@ -129,6 +129,27 @@ std::string spec_text(const odw_ctx* ctx) {
     }
     xf[p] = w;
   }
+  // primitives with the same box: equal sets {p} + {q : p must lie inside q} (compute_boxes cuts p's box by
+  // the boxes of those q).  box_of = the first such primitive, box_shared = another one refers to it.
+  std::vector<int> box_of(n), box_shared(n, 0);
+  {
+    std::vector<std::vector<int>> inside(n);
+    for (int p = 0; p < n; ++p) {
+      inside[p].push_back(p);
+      const int off = condw[p] & 0xffffff, cnt = (condw[p] >> 24) & 0xff;
+      for (int c = off; c < off + cnt && c < (int)ctx->h_cond.size(); ++c)
+        if (ctx->h_cond[c] < 0) inside[p].push_back(ctx->h_cond[c] & 0x7fffffff);
+      std::sort(inside[p].begin(), inside[p].end());
+      inside[p].erase(std::unique(inside[p].begin(), inside[p].end()), inside[p].end());
+    }
+    for (int p = 0; p < n; ++p) {
+      box_of[p] = p;
+      // (the sets are equal, but compute_boxes cuts with the operands' FULL boxes only: p's box is
+      //  box(p) ^ box(q1) ^ ..., the same expression for both when the sets agree)
+      for (int q = 0; q < p; ++q)
+        if (!dead[q] && !dead[p] && group[q] == group[p] && inside[q] == inside[p]) { box_of[p] = q; box_shared[q] = 1; break; }
+    }
+  }
   std::vector<int> gtype(std::max(1, ng)), grec(std::max(1, ng));
   for (int g = 0; g < ng; ++g) { gtype[g] = ctx->h_group_i32[4 * g]; grec[g] = ctx->h_group_i32[4 * g + 1]; }
   auto fi = [](int v) { return std::to_string(v); };
@@ -138,7 +159,8 @@ std::string spec_text(const odw_ctx* ctx) {
   s += "  static constexpr int N = " + std::to_string(n) + ";\n";
   s += table("int", "type", n, type.data(), fi) + table("int", "group", n, group.data(), fi) +
        table("int", "flags", n, flags.data(), fi) + table("int", "cond_word", n, condw.data(), fi) +
-       table("bool", "dead", n, dead.data(), fi) +
+       table("bool", "dead", n, dead.data(), fi) + table("int", "box_of", n, box_of.data(), fi) +
+       table("bool", "box_shared", n, box_shared.data(), fi) +
        table("int", "cond", (int)ctx->h_cond.size(), ctx->h_cond.data(), fi) +
        table("unsigned long long", "xf", n, xf.data(), fu) + table("int", "gtype", ng, gtype.data(), fi) +
        table("bool", "record", ng, grec.data(), fi);
