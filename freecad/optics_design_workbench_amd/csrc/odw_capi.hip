@@ -707,8 +707,9 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
     if (rc) return rc;
   }
   if (ctx->spec_dirty) {
-    int rc = spec_bind(ctx);
-    if (rc) return rc;
+    // a scene kernel that cannot be built (no hiprtc on this machine, a compiler error) is not a reason to
+    // stop tracing: the generic kernels run, odw_compile_scene / odw_last_error tell why
+    if (spec_bind(ctx) != ODW_OK) ctx->spec_fn = nullptr;
   }
   if ((flags & ODW_TRACE_RECORD_HITS) && ctx->hit_capacity == 0)
     return fail(ctx, ODW_ERR_CAPACITY, "ODW_TRACE_RECORD_HITS without odw_reserve_hits");

@@ -451,6 +451,9 @@ int odw_hits_moments(odw_ctx* ctx, double* mean, double* var);
  * later.  Scenes outside the flat kernel's domain (facets, paraboloids, > 16
  * primitives, stochastic surfaces, segment rows) keep the generic kernels --
  * that is not an error.  Results are those of the generic kernel, bit for bit.
+ * If the kernel cannot be built (hiprtc missing, a compiler error) the call
+ * returns ODW_ERR_DEVICE with the reason in odw_last_error; launches go on
+ * with the generic kernels.
  * ODW_KERNEL_CACHE: directory of the disk cache (default ~/.cache/odw_trace,
  * empty string: none).                                                       */
 #define ODW_COMPILE_OFF 0

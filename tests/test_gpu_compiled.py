@@ -148,3 +148,20 @@ def test_histogram_window_edges(tracers):
     np.add.at(want, (fx[ok].astype(int), fy[ok].astype(int)), 1)
     assert got['counters']['hist_overflow'] == int((~ok).sum())
     assert np.array_equal(hist, want)
+
+
+def test_a_kernel_that_cannot_be_built_leaves_the_generic_kernels(tracers, monkeypatch):
+  """compiler trouble (here: a broken option) is reported by compileScene and does not stop the tracing"""
+  from freecad.optics_design_workbench_amd import _native
+  proj = project('lensesAndMirrors')
+  ref = run(tracers('off'), proj, 50000)
+  monkeypatch.setenv('ODW_SPEC_OPTS', '-DODW_SPEC_WAVES=oops')
+  tr = tracers('off')
+  tr.setScene(proj.scene)
+  tr.setSource(proj.source)
+  tr.setLimits(proj.limits)
+  with pytest.raises(_native.NativeError, match='hiprtc'):
+    tr.compileScene('structure')
+  got = run(tr, proj, 50000)          # (setScene again: the bind fails again, silently this time)
+  assert got['info']['mode'] == 0
+  same(got, ref)
