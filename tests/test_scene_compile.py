@@ -82,3 +82,27 @@ def test_frames_are_snapped_to_exact_zeros_and_ones():
     assert not ((np.abs(np.abs(m) - 1) < 1e-12) & (np.abs(m) != 1)).any()
     r = m.reshape(-1, 3, 3)
     assert np.abs(r @ r.transpose(0, 2, 1) - np.eye(3)).max() < 1e-14
+
+
+def test_random_structures_compile(native_lib):
+  """random scenes of the parity fuzzers (boxes, spheres, cylinders, cones, tori; Common / Cut / Fuse; random
+  optical types): every structure the flat kernel takes compiles for gfx950 (the launches are -m gpu:
+  tests/test_gpu_fuzz.py, tests/fuzz_parity.py with ODW_COMPILE=structure)"""
+  from freecad.optics_design_workbench_amd import _native
+  from random_scenes import scene
+  done = 0
+  for s in range(40):
+    rs = np.random.RandomState(4200 + s)
+    try:
+      sc, lim, targets = scene(rs, rich=(s % 3 == 2))
+    except Exception:
+      continue
+    if len(sc.prim_type) > 16 or any(int(t) >= 5 for t in sc.prim_type):
+      continue                                   # BVH / grid kernels
+    header, code_bytes = _native.compile_check(sc, lim, 'structure')
+    assert code_bytes > 10000
+    assert f'static constexpr int N = {len(sc.prim_type)};' in header
+    done += 1
+    if done == 12:
+      break
+  assert done >= 8
