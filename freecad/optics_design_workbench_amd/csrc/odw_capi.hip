@@ -752,10 +752,13 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
   const uint64_t cap = (uint64_t)ctx->n_cu * grid_mult;
   const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_chunks + 3) / 4, cap));
   // big analytic scenes: grid kernel (no stochastic surfaces, no segment rows: those stay with the BVH kernels)
-  const bool use_grid = P.grid.nx > 0 && ctx->n_samplers == 0 && !(flags & ODW_TRACE_RECORD_SEGMENTS);
+  // a scene compiled against its structure (odw_spec.hip): its own kernel, whatever else was built for it
+  const bool use_spec = ctx->spec_fn && ctx->spec_lean == ctx->lean && ctx->spec_stoch == (ctx->n_samplers > 0) &&
+                        !(flags & ODW_TRACE_RECORD_SEGMENTS);
+  const bool use_grid = !use_spec && P.grid.nx > 0 && ctx->n_samplers == 0 && !(flags & ODW_TRACE_RECORD_SEGMENTS);
   const uint64_t grid_blocks = std::max<uint64_t>(1, std::min<uint64_t>((n_chunks + ODW_GRID_WAVES - 1) / ODW_GRID_WAVES, (uint64_t)ctx->n_cu));
   const uint64_t n_waves = use_grid ? grid_blocks * ODW_GRID_WAVES : (uint64_t)grid * 4;
-  if ((!P.scene.n_nodes || use_grid) && !ctx->swapping &&
+  if ((!P.scene.n_nodes || use_grid || use_spec) && !ctx->swapping &&
       ctx->hit_slots >= ctx->hit_capacity + ctx->hit_capacity / 8 + 64 + n_waves * kHitBlock)
     P.out.hit_block = kHitBlock;     // flat and grid kernels only (see record_hit)
   HIPCHK(ctx, hipMemsetAsync(ctx->chunk_counter.p, 0, sizeof(uint64_t), ctx->stream));
@@ -773,7 +776,10 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
     HIPCHK(ctx, hipEventRecord(ev.first, ctx->stream));
   }
   const bool stoch = ctx->n_samplers > 0;
-  if (use_grid) {
+  if (use_spec) {
+    int rc = spec_launch(ctx, grid);
+    if (rc) return rc;
+  } else if (use_grid) {
     const dim3 gb((unsigned)grid_blocks);
     const size_t glds = P.grid.lds_bytes;
 #define ODW_GRID_LAUNCH(S, L)                                                                                  \
@@ -801,8 +807,7 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
     if (stoch) hipLaunchKernelGGL((odw_trace_kernel<true, true, false>), dim3(grid), dim3(256), lds, ctx->stream, P);
     else hipLaunchKernelGGL((odw_trace_kernel<true, false, false>), dim3(grid), dim3(256), lds, ctx->stream, P);
   } else {
-    if (ctx->spec_fn && ctx->spec_lean == ctx->lean && ctx->spec_stoch == stoch) { int rc = spec_launch(ctx, grid); if (rc) return rc; }
-    else if (stoch) hipLaunchKernelGGL((odw_trace_kernel<false, true, false>), dim3(grid), dim3(256), 0, ctx->stream, P);
+    if (stoch) hipLaunchKernelGGL((odw_trace_kernel<false, true, false>), dim3(grid), dim3(256), 0, ctx->stream, P);
     else if (ctx->lean) hipLaunchKernelGGL((odw_trace_kernel<false, false, false, true>), dim3(grid), dim3(256), 0, ctx->stream, P);
     else hipLaunchKernelGGL((odw_trace_kernel<false, false, false>), dim3(grid), dim3(256), 0, ctx->stream, P);
   }

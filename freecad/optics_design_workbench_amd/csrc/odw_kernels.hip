@@ -845,7 +845,7 @@ __device__ __forceinline__ void spec_prim(const SceneView& sv, Query& q, d3 oi, 
       }
       boxhit[PI] = in_box;
       if (in_box)
-        intersect_prim<false, SPEC, PI>(sv, q, PI, SPEC::type(PI), SPEC::group(PI), flags, SPEC::cond_word(PI));
+        intersect_prim<SPEC::parab(), SPEC, PI>(sv, q, PI, SPEC::type(PI), SPEC::group(PI), flags, SPEC::cond_word(PI));
     } else if constexpr (SPEC::box_of(PI) == PI) {
       // (skipped for this lane -- not relevant, or the convex solid just left --, but a later primitive may
       //  ask for this box: its own test then)
@@ -1352,7 +1352,7 @@ __device__ __forceinline__ void spec_hit(const TraceParams& P, const SceneView& 
                                          int& skip, bool& alive) {
   constexpr int flags = SPEC::flags(PI), g = SPEC::group(PI);
   cf64 pf = sv.prim_f64 + (size_t)PI * 16;
-  d3 n = face_normal<false>(SPEC::type(PI), pf + 12, face, xf_point_nz<SPEC::xf(PI)>(pf, point));
+  d3 n = face_normal<SPEC::parab()>(SPEC::type(PI), pf + 12, face, xf_point_nz<SPEC::xf(PI)>(pf, point));
   if constexpr ((flags & ODW_FLAG_FLIP_NORMAL) != 0) n = n * -1.0;
   n = xf_vec_t_nz<SPEC::xf(PI)>(pf, n);
   const bool entering = dot(dir, n) < 0;

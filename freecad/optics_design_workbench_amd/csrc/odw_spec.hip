@@ -6,7 +6,7 @@
 // trace (<= 16 analytic primitives), the library writes the scene's STRUCTURE -- primitive types,
 // groups, flags, trimming lists, zero / +-1 pattern of every frame, optical type and recording switch
 // of every group -- as a C++ header of compile-time constants, compiles odw_kernels.hip's ray loop
-// against it with hiprtc (1.5 - 2 s), and launches that kernel instead of the generic one: the
+// against it with hiprtc (0.5 - 2 s), and launches that kernel instead of the generic one: the
 // primitive loop is unrolled, type dispatch and face masks fold away, frame products skip their zero
 // terms, table reads have constant offsets (odw_kernels.hip: SPEC).  All float64 VALUES (frames,
 // parameters, boxes, optical constants) are still read from the uploaded tables, so one kernel serves
@@ -78,14 +78,6 @@ Hiprtc& hiprtc() {
 }
 
 // ---- the header ------------------------------------------------------------------------------
-std::string f64_literal(double v) {
-  if (std::isnan(v)) return "__builtin_nan(\"\")";
-  if (std::isinf(v)) return v > 0 ? "__builtin_huge_val()" : "(-__builtin_huge_val())";
-  char buf[64];
-  snprintf(buf, sizeof buf, "%a", v);       // hexadecimal: exact
-  return buf;
-}
-
 template <class T, class F>
 std::string table(const char* type, const char* name, int n, const T* v, F fmt) {
   std::string s = std::string("  static constexpr ") + type + " " + name + "(int i) { constexpr " + type + " T[] = {";
@@ -100,7 +92,7 @@ std::string spec_ineligible(const odw_ctx* ctx) {
   if (n > kSpecMaxPrims) return "more primitives than the flat kernel takes";
   for (int p = 0; p < n; ++p) {
     const int t = ctx->h_prim_i32[4 * p];
-    if (t == ODW_PRIM_TRIANGLE || t == ODW_PRIM_PARABOLOID) return "facets / paraboloids belong to the BVH and grid kernels";
+    if (t == ODW_PRIM_TRIANGLE) return "facets belong to the BVH kernels";
   }
   if (ctx->h_prim_hdr.size() < (size_t)n * 8 || ctx->h_dead.size() < (size_t)n) return "boxes not built";
   return "";
@@ -164,6 +156,11 @@ std::string spec_text(const odw_ctx* ctx) {
        table("int", "cond", (int)ctx->h_cond.size(), ctx->h_cond.data(), fi) +
        table("unsigned long long", "xf", n, xf.data(), fu) + table("int", "gtype", ng, gtype.data(), fi) +
        table("bool", "record", ng, grec.data(), fi);
+  // (paraboloids: the generic flat kernel leaves their code out -- it costs every scene 1 % -- and hands such
+  //  documents to the grid kernel; a compiled kernel carries it exactly when the scene has one)
+  bool parab = false;
+  for (int p = 0; p < n; ++p) parab |= type[p] == ODW_PRIM_PARABOLOID;
+  s += std::string("  static constexpr bool parab() { return ") + (parab ? "true" : "false") + "; }\n";
   s += "  static constexpr int cond_off(int i) { return cond_word(i) & 0xffffff; }\n"
        "  static constexpr int cond_cnt(int i) { return (cond_word(i) >> 24) & 0xff; }\n";
   s += "  static constexpr unsigned long long umask() { return " + fu(ctx->P.scene.all_mask & ~ctx->P.scene.ignore_mask) + "; }\n";
@@ -251,7 +248,7 @@ int spec_bind(odw_ctx* ctx) {
   ctx->spec_seconds = 0;
   ctx->spec_cache_hit = 0;
   if (ctx->compile_mode == ODW_COMPILE_OFF || !ctx->have_scene) return ODW_OK;
-  if (!spec_ineligible(ctx).empty() || ctx->P.scene.n_nodes || ctx->P.grid.nx > 0) return ODW_OK;
+  if (!spec_ineligible(ctx).empty()) return ODW_OK;
   hipDeviceProp_t prop;
   HIPCHK(ctx, hipGetDeviceProperties(&prop, ctx->device));
   const std::string arch = prop.gcnArchName;

@@ -165,3 +165,28 @@ def test_a_kernel_that_cannot_be_built_leaves_the_generic_kernels(tracers, monke
   got = run(tr, proj, 50000)          # (setScene again: the bind fails again, silently this time)
   assert got['info']['mode'] == 0
   same(got, ref)
+
+
+def test_small_paraboloid_scene_takes_the_compiled_kernel(tracers):
+  """the generic flat kernel carries no paraboloid code (such documents go to the grid kernel); a compiled
+  kernel has it exactly when the scene does: rays reflected off a parabolic mirror onto a screen, both routes"""
+  from freecad.optics_design_workbench_amd.freecad_elements import make, point_source
+  from freecad.optics_design_workbench_amd.scene import Document, bake
+  import types
+  doc = Document()
+  f = 20.0
+  pb = make.makeParaboloid(doc, 'P', f, 10.0, base=(0, 0, 50))
+  make.makeMirror(doc, [pb], RecordHits=True)
+  make.makeAbsorber(doc, [make.makeBox(doc, 'A', 200, 200, 1, base=(-100, -100, -30))], RecordHits=True)
+  make.makeSimulationSettings(doc)
+  src = make.makePointSource(doc, PowerDensity='exp(-theta**2/0.3**2)')
+  proj = types.SimpleNamespace(scene=bake.bakeScene(doc, src), limits=bake.bakeLimits(doc, src),
+                               source=point_source.bakeSource(doc, src))
+  n = 100000
+  ref = run(tracers('off'), proj, n)
+  got = run(tracers('structure'), proj, n)
+  assert ref['info']['mode'] == 0 and got['info']['mode'] == 1
+  assert got['counters'] == ref['counters'] and ref['counters']['recorded_hits'] > n
+  assert np.array_equal(got['hits']['tag'], ref['hits']['tag'])
+  assert np.abs(got['hits']['point'] - ref['hits']['point']).max() < 1e-9
+  assert np.abs(got['hits']['direction'] - ref['hits']['direction']).max() < 1e-9
