@@ -403,9 +403,6 @@ def _snapFrames(rows):
   The frame stays orthonormal to the last bit or two; an exact 0 / +-1 is a term the scene-compiled
   kernels leave out (odw_kernels.hip: xf_comb) and costs the generic ones nothing."""
   rows = np.array(rows, dtype=np.float64).reshape(-1, 12)
-  import os
-  if os.environ.get('ODW_NO_SNAP'):
-    return rows
   rot = [0, 1, 2, 4, 5, 6, 8, 9, 10]
   r = rows[:, rot]
   r[np.abs(r) < 1e-15] = 0.0
