@@ -29,7 +29,13 @@ constexpr uint32_t kHitBlock = 512;            // hit-list slots a wave reserves
 constexpr uint64_t kHitBlockMinRows = 1ull << 22;
 constexpr int kPhiGuide = 1 << 8;        // azimuth table of a source (~1e2 knots)
 constexpr int kSurfaceGuide = 1 << 10;  // per row of a surface sampler (tables of ~1e3 knots)
-constexpr int kBvhThreshold = 16;  // brute force (scalar loads) below this many primitives
+// Analytic scenes of up to this many primitives take the flat kernels (brute force over the primitives, scalar
+// loads, one box test each).  Measured against the grid kernel's generic variant, which such scenes took above 16
+// primitives until round 2: lens trains of 19 / 25 / 37 / 61 primitives 1.63e9 / 1.10e9 / 6.1e8 / 2.75e8 rays/s flat
+// against 6.4e8 / 5.1e8 / 3.5e8 / 1.95e8 on the grid; random crowded scenes of 19 - 30 primitives 2 - 3.6 x faster
+// (scripts/bench_lens_train.py, scripts/bench_crowded.py).  ODW_BVH_THRESHOLD (read when a context is created)
+// overrides it: the tests keep the grid kernel's generic variant covered with 16.
+constexpr int kBvhThreshold = 64;
 const int kBvhLeaf = [] { const char* e = getenv("ODW_BVH_LEAF"); const int v = e ? atoi(e) : 0; return v > 0 && v < 200 ? v : 8; }();   // largest leaf the SAH may form (measured: 8 >= 4 > 2 > 1 on meshes)
 constexpr int kBvhSweepMax = 2048;       // nodes with more primitives use binned SAH
 
@@ -66,6 +72,7 @@ struct odw_ctx {
   int spec_cache_hit = 0;                  // 0 compiled now, 1 process cache, 2 disk cache
   bool have_scene = false, have_source = false, have_limits = false;
   bool bvh_dirty = true;
+  int flat_limit = kBvhThreshold;          // most primitives the flat kernels take (ODW_BVH_THRESHOLD at odw_create)
   bool lean = false;                       // no grating group, no finite absorption length: LEAN kernels
 
   DevBuf prim_f64, prim_hdr, prim_i32, cond_i32, group_f64, group_i32, group_gdir, seq_mask;
@@ -604,7 +611,7 @@ int build_bvh(odw_ctx* ctx) {
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->P.scene.prim_hdr = (const double*)ctx->prim_hdr.p;
   }
-  static const int bvh_threshold = [] { const char* e = getenv("ODW_BVH_THRESHOLD"); return e ? atoi(e) : kBvhThreshold; }();
+  const int bvh_threshold = ctx->flat_limit;
   bool has_triangles = false, has_paraboloids = false;
   for (int p = 0; p < n; ++p) {
     has_triangles |= ctx->h_prim_i32[4 * p] == ODW_PRIM_TRIANGLE;
@@ -851,6 +858,7 @@ int odw_create(int device, odw_ctx** out) {
   odw_ctx* ctx = new (std::nothrow) odw_ctx();
   if (!ctx) return fail(nullptr, ODW_ERR_DEVICE, "out of host memory");
   ctx->device = device;
+  if (const char* e = getenv("ODW_BVH_THRESHOLD")) ctx->flat_limit = atoi(e);
   std::memset(&ctx->P, 0, sizeof ctx->P);
   ctx->P.wavelength = 500.0;
   std::memset(&ctx->det_desc, 0, sizeof ctx->det_desc);

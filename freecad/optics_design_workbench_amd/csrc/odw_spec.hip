@@ -3,7 +3,7 @@
 // The reference prepares a scene once per run and reuses the result for every ray
 // (simulation/raytracing_cache.py:92-111: cachedShape / cachedFaces / cachedBoundBox ..., cleared by
 // cacheClear :36).  The counterpart here goes one step further: for a scene the flat kernel would
-// trace (<= 16 analytic primitives), the library writes the scene's STRUCTURE -- primitive types,
+// trace (<= 64 analytic primitives), the library writes the scene's STRUCTURE -- primitive types,
 // groups, flags, trimming lists, zero / +-1 pattern of every frame, optical type and recording switch
 // of every group -- as a C++ header of compile-time constants, compiles odw_kernels.hip's ray loop
 // against it with hiprtc (0.5 - 2 s), and launches that kernel instead of the generic one: the
@@ -39,7 +39,17 @@ extern "C" const char odw_src_kernels[], odw_src_device[], odw_src_trace[];
 
 namespace {
 
-constexpr int kSpecMaxPrims = 16;
+// primitives a compiled kernel is unrolled over at most (ODW_SPEC_MAX_PRIMS: experiments).  A lens train of 61
+// primitives compiles in 17 s to 212 KB of code and still runs 2.6 x the generic flat kernel's rate (19
+// primitives: 4.6 s, 91 KB, 2.1 x; scripts/bench_lens_train.py).
+// (a plain function: a second initialiser lambda of this shape in the same translation unit ran the first
+//  one's body -- kBvhLeaf's, odw_capi.hip -- with this compiler)
+int spec_max_prims() {
+  const char* e = getenv("ODW_SPEC_MAX_PRIMS");
+  const int v = e ? atoi(e) : 0;
+  return v > 0 ? v : 64;
+}
+const int kSpecMaxPrims = spec_max_prims();
 
 struct Hiprtc {
   void* lib = nullptr;
@@ -89,7 +99,7 @@ std::string table(const char* type, const char* name, int n, const T* v, F fmt) 
 std::string spec_ineligible(const odw_ctx* ctx) {
   const int n = ctx->P.scene.n_prims;
   if (n < 1) return "no primitives";
-  if (n > kSpecMaxPrims) return "more primitives than the flat kernel takes";
+  if (n > kSpecMaxPrims) return "more primitives (" + std::to_string(n) + ") than a compiled kernel takes (" + std::to_string(kSpecMaxPrims) + ")";
   for (int p = 0; p < n; ++p) {
     const int t = ctx->h_prim_i32[4 * p];
     if (t == ODW_PRIM_TRIANGLE) return "facets belong to the BVH kernels";

@@ -34,7 +34,7 @@ def _limit(settings, key, default):
     return np.inf
 
 
-COMPILE_FROM_RAYS = 1e9     # a compile (<= 2 s) is worth ~1.5e10 traced rays at the rates of C3; see `compileScene`
+COMPILE_FROM_RAYS = 1e9     # a compile (0.5 - 2 s up to 16 primitives) pays from ~1e9 traced rays; see `compileScene`
 
 
 def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPath=None, store=None,
@@ -102,8 +102,13 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
   if own:
     # rays the end criteria ask for, at most (a hit takes at least one ray)
     wanted = min(store.endAfterRays, store.endAfterIterations * rpi * len(sources), store.endAfterHits) if continuous else 0
-    if compileScene == 'structure' or (compileScene == 'auto' and continuous and wanted >= COMPILE_FROM_RAYS):
+    if compileScene == 'structure':
       tr.compileScene('structure')
+  else:
+    wanted = 0
+  # ('auto' is decided when the first scene is uploaded: bigger scenes compile longer -- 61 primitives: 17 s --,
+  #  the bar rises with the square of the primitive count)
+  auto_compile = own and compileScene == 'auto' and continuous
   master = ranks.rank == 0
   if master:
     store.setStatus('simulation-is-done', False)
@@ -186,6 +191,9 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
         if uploaded.get('scene') is not scene:
           tr.setScene(scene)
           uploaded['scene'] = scene
+          if auto_compile and wanted >= COMPILE_FROM_RAYS * (max(16, len(scene.prim_type)) / 16.0)**2:
+            tr.compileScene('structure')
+            auto_compile = False
         if uploaded.get('limits') is not lim:
           tr.setLimits(lim)
           uploaded['limits'] = lim

@@ -439,7 +439,7 @@ int odw_hits_moments(odw_ctx* ctx, double* mean, double* var);
 /* scene-compiled kernels -------------------------------------------------------
  * The reference prepares a scene once per run and reuses it for every ray
  * (simulation/raytracing_cache.py:92-111 cachedShape / cachedFaces /
- * cachedBoundBox ..., cacheClear :36).  Here, for a scene of <= 16 analytic
+ * cachedBoundBox ..., cacheClear :36).  Here, for a scene of <= 64 analytic
  * primitives the library can compile the ray loop against the scene itself
  * (hiprtc, ~2 s, cached per process and on disk): primitive loop unrolled,
  * type dispatch / face masks / trimming lists / optical types folded.
@@ -448,8 +448,8 @@ int odw_hits_moments(odw_ctx* ctx, double* mean, double* var);
  * reuse it.
  * The mode is sticky: it applies to the uploaded scene (bound at once if scene
  * and limits are there, else at the next launch) and to every scene uploaded
- * later.  Scenes outside the flat kernel's domain (facets, paraboloids, > 16
- * primitives, stochastic surfaces, segment rows) keep the generic kernels --
+ * later.  Scenes outside the domain (facets, > 64 primitives) and launches
+ * that record segment rows keep the generic kernels --
  * that is not an error.  Results are those of the generic kernel, bit for bit.
  * If the kernel cannot be built (hiprtc missing, a compiler error) the call
  * returns ODW_ERR_DEVICE with the reason in odw_last_error; launches go on

@@ -111,3 +111,41 @@ def test_trimmed_box_face_met_within_tolerance_of_an_edge(native_lib, oracle):
   ray = (r['tag'] & np.uint64(0xFFFFFFFFFFFF)).astype(np.int64)
   assert (ray == 61).sum() == 5                       # the ray in question: five recorded hits
   assert np.abs(g['point'] - r['point']).max() < 1e-7
+
+
+@pytest.mark.parametrize('flat_limit', [None, '16'])
+def test_crowded_scenes_on_the_flat_and_on_the_grid_kernels(native_lib, oracle, monkeypatch, flat_limit):
+  """scenes of 17 - 64 analytic primitives take the flat kernels (brute force: faster than the grid kernel's generic
+  variant there, scripts/bench_crowded.py); with ODW_BVH_THRESHOLD=16 at odw_create they take the grid kernel as
+  before round 2 -- its generic variant stays covered.  Device vs oracle on whole trajectories, both routes."""
+  from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
+  if flat_limit is not None:
+    monkeypatch.setenv('ODW_BVH_THRESHOLD', flat_limit)
+  n = 5000
+  scenes = differing_rays = big = 0
+  with Tracer(0) as tr:
+    for s in range(16):
+      rs = np.random.RandomState(23 * 100003 + s)
+      try:
+        sc, lim, targets = scene(rs, False, True)
+      except Exception:
+        continue
+      big += int(16 < len(sc.prim_type) <= 64)
+      o, d = rays(rs, targets, n)
+      tr.setScene(sc); tr.setLimits(lim); tr.setDetector(None)
+      tr.reserveHits(n * (lim.max_intersections + 1))
+      tr.reset()
+      tr.traceRays(o, d)
+      tr.sync()
+      g = tr.hits()
+      r = oracle.trace_rays(sc, lim, o, d, nthreads=0)['hits']
+      scenes += 1
+      gr = (g['tag'] & np.uint64(0xFFFFFFFFFFFF)).astype(np.int64)
+      rr = (r['tag'] & np.uint64(0xFFFFFFFFFFFF)).astype(np.int64)
+      if len(g) != len(r) or not np.array_equal(g['tag'], r['tag']):
+        differing_rays += int((np.bincount(gr, minlength=n) != np.bincount(rr, minlength=n)).sum())
+        continue
+      first = np.r_[True, gr[1:] != gr[:-1]]
+      d1 = np.abs(g['point'][first] - r['point'][first]).max(axis=1)
+      assert d1.max() < 1e-9, (s, float(d1.max()))
+  assert scenes >= 12 and big >= 8 and differing_rays <= 2, (scenes, big, differing_rays)
