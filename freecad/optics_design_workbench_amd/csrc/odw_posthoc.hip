@@ -53,6 +53,21 @@ __global__ void ph_gather_strided_kernel(const odw_hit* __restrict__ hits, const
   }
 }
 
+// the selected rows as columns: points [m][3], directions [m][3], powers [m], isEntering [m] (int64), ray index [m]
+// (int64) -- the arrays the reference pickles per (source, object) (results_store.py:405-457)
+__global__ void ph_columns_kernel(const odw_hit* __restrict__ hits, const uint32_t* __restrict__ sel, uint64_t m,
+                                  double* __restrict__ points, double* __restrict__ dirs, double* __restrict__ powers,
+                                  long long* __restrict__ entering, long long* __restrict__ ray) {
+  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  const odw_hit h = hits[sel[j]];
+  if (points) { points[3 * j] = h.point[0]; points[3 * j + 1] = h.point[1]; points[3 * j + 2] = h.point[2]; }
+  if (dirs) { dirs[3 * j] = h.direction[0]; dirs[3 * j + 1] = h.direction[1]; dirs[3 * j + 2] = h.direction[2]; }
+  if (powers) powers[j] = h.power;
+  if (entering) entering[j] = ODW_HIT_ENTERING(h.tag) ? 1 : 0;
+  if (ray) ray[j] = (long long)ODW_HIT_RAY(h.tag);
+}
+
 // numpy.dot(points, axis): three products, summed left to right, no contraction
 __global__ void ph_project_kernel(const odw_hit* __restrict__ hits, const uint32_t* __restrict__ sel, uint64_t m, int key,
                                   double ex0, double ex1, double ex2, double ey0, double ey1, double ey2,
@@ -270,6 +285,37 @@ int odw_hits_select(odw_ctx* ctx, int32_t group, uint64_t* n_rows, uint64_t* n_l
   }
   ctx->ph_group = group;
   ctx->ph_valid = true;
+  return ODW_OK;
+}
+
+int odw_hits_columns(odw_ctx* ctx, double* points, double* directions, double* powers, int64_t* is_entering,
+                     int64_t* ray_index, uint64_t capacity, uint64_t* n) {
+  if (!ctx || !n) return fail(ctx, ODW_ERR_INVALID, "odw_hits_columns: bad argument");
+  int rc = ph_need_selection(ctx, "odw_hits_columns");
+  if (rc) return rc;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const uint64_t m = ctx->ph_n;
+  *n = m;
+  if (m == 0 || !(points || directions || powers || is_entering || ray_index)) return ODW_OK;
+  if (m > capacity) return fail(ctx, ODW_ERR_CAPACITY, "odw_hits_columns: output arrays too small");
+  // staging: 9 doubles per row (3 + 3 + 1 + 1 + 1), one buffer
+  if ((rc = ensure(ctx, ctx->sorted_rows, m * 9 * sizeof(double)))) return rc;
+  double* base = (double*)ctx->sorted_rows.p;
+  double* d_points = points ? base : nullptr;
+  double* d_dirs = directions ? base + 3 * m : nullptr;
+  double* d_powers = powers ? base + 6 * m : nullptr;
+  long long* d_ent = is_entering ? (long long*)(base + 7 * m) : nullptr;
+  long long* d_ray = ray_index ? (long long*)(base + 8 * m) : nullptr;
+  hipLaunchKernelGGL(ph_columns_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream,
+                     (const odw_hit*)ctx->hits.p, (const uint32_t*)ctx->sort_vals[1].p, m, d_points, d_dirs, d_powers, d_ent,
+                     d_ray);
+  HIPCHK(ctx, hipGetLastError());
+  if (points) HIPCHK(ctx, hipMemcpyAsync(points, d_points, m * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (directions) HIPCHK(ctx, hipMemcpyAsync(directions, d_dirs, m * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (powers) HIPCHK(ctx, hipMemcpyAsync(powers, d_powers, m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (is_entering) HIPCHK(ctx, hipMemcpyAsync(is_entering, d_ent, m * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+  if (ray_index) HIPCHK(ctx, hipMemcpyAsync(ray_index, d_ray, m * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return ODW_OK;
 }
 

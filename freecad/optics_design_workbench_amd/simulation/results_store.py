@@ -14,6 +14,7 @@ import fnmatch
 import glob
 import os
 import pickle
+import queue
 import threading
 import time
 import uuid
@@ -177,11 +178,48 @@ class SimulationResults:
     return f'{self.totalTracedRays / dt:.1e} rays/s, {self.totalRecordedHits / dt:.1e} recorded hits/s'
 
   # -- output ----------------------------------------------------------------
-  def flush(self):
+  # -- writing in the background ---------------------------------------------------------------
+  # Pickling 4e6 hits (290 MB) takes ~85 ms, a launch that produces them 1 ms: the run loop hands the files of
+  # a flush to a writer thread (at most two flushes in flight) and goes on tracing; everything that reads the
+  # folder, and the end of the run, waits for it (`drain`).  Protocol 5: numpy arrays go into the file without
+  # the intermediate bytes copy of the default protocol; `pickle.load` of the reference reads them all the same.
+  def _writer_put(self, path, obj):
+    if getattr(self, '_writer', None) is None:
+      self._writeQueue = queue.Queue(maxsize=2)
+      self._writeError = None
+
+      def work():
+        while True:
+          item = self._writeQueue.get()
+          try:
+            if item is None:
+              return
+            if self._writeError is None:
+              with open(item[0], 'wb') as f:
+                pickle.dump(item[1], f, protocol=pickle.HIGHEST_PROTOCOL)
+          except BaseException as e:                 # reported by drain()
+            self._writeError = e
+          finally:
+            self._writeQueue.task_done()
+      self._writer = threading.Thread(target=work, name='odw-hit-writer', daemon=True)
+      self._writer.start()
+    self._writeQueue.put((path, obj))
+
+  def drain(self):
+    """wait until every file handed to the writer thread is on disk; raises what the writer met"""
+    if getattr(self, '_writer', None) is not None:
+      self._writeQueue.join()
+      if self._writeError is not None:
+        e, self._writeError = self._writeError, None
+        raise e
+
+  def flush(self, wait=True):
     """write buffered hits as `*-hits.pkl` and empty the buffers (results_store.py:405-457).
     With a results folder nothing stays in host memory after the write (the reference clears its
     lists, :455-457; `hits()` reads the run folder back); without one the batches are kept as a
-    list of chunks and merged lazily by `hits()`"""
+    list of chunks and merged lazily by `hits()`.  wait=False (the run loop): the files are written by
+    the writer thread while the next launch runs; `drain()` -- called by everything that reads them --
+    waits for them."""
     ms = max(int(time.time() * 1e3), getattr(self, '_lastStampMs', 0) + 1)   # one file name per flush
     self._lastStampMs = ms
     stamp = f'{ms}-pid{os.getpid()}-thread{threading.get_ident()}'
@@ -195,8 +233,7 @@ class SimulationResults:
         folder = os.path.join(self.runFolderPath(), f'source-{sourceLabel}', f'object-{objLabel}')
         os.makedirs(folder, exist_ok=True)
         path = os.path.join(folder, f'{stamp}-hits.pkl')
-        with open(path, 'wb') as f:
-          pickle.dump(merged, f)
+        self._writer_put(path, merged)
         self._hitFiles.setdefault(key, []).append(path)
       if self.keepInMemory:
         self._flushed.setdefault(key, []).append(merged)
@@ -207,12 +244,13 @@ class SimulationResults:
         folder = os.path.join(self.runFolderPath(), f'source-{key[1]}')
         os.makedirs(folder, exist_ok=True)
         path = os.path.join(folder, f'{stamp}-rays.pkl')
-        with open(path, 'wb') as f:
-          pickle.dump(rays, f)
+        self._writer_put(path, rays)
         self._rayFiles.setdefault(key, []).append(path)
       if self.keepInMemory:
         self._flushedRays.setdefault(key, []).extend(rays)
     self._rays = {}
+    if wait:
+      self.drain()
 
   @staticmethod
   def _matches(rel, pattern):

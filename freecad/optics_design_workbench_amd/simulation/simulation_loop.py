@@ -248,7 +248,10 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
           hits_per_ray[src.Name] = max(cnt['recorded_hits'] / m, 0.25)
         first[src.Name] = base + n
         before = store.totalRecordedHits
-        _store_hits(store, tr.hits(), scene, src, per_ray, index_base, enabled)
+        if hasattr(tr, 'hitColumns'):
+          _store_hit_columns(store, tr, scene, src, per_ray, index_base, enabled)
+        else:                                   # (test doubles without the columnar fetch)
+          _store_hits(store, tr.hits(), scene, src, per_ray, index_base, enabled)
         mine = store.totalRecordedHits - before
         if record_rays:
           _, dropped = tr.segmentCount()
@@ -259,18 +262,25 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
         store.totalRecordedHits += everyone - mine         # every rank sees the job's totals
         store.incrementRayCount(n)
         store.incrementIterationCount(iters)
-      store.flush()
+      store.flush(wait=False)                 # the writer thread pickles while the next launch runs
       if master:
         store.dumpProgress()
       stop = ended or not continuous or store.reachedEnd()
       if not stop and endIf is not None:
+        store.drain()                           # the callback reads the run folder
         (votes,) = ranks.sum([1 if endIf(store) else 0])
         stop = votes > 0
       if stop:
         break
+    store.drain()
     ranks.barrier()
     failed = False
   finally:
+    if failed:
+      try:
+        store.drain()
+      except Exception:
+        pass
     # any exception cancels the run (simulation_loop.py:715-723)
     if master or failed:
       store.setStatus('simulation-is-canceled', failed)
@@ -347,6 +357,21 @@ class _DeviceInitialConditions:
     if key == 'initWavelength':
       return np.full(self._n, self._src.wavelength)
     raise KeyError(key)
+
+
+def _store_hit_columns(store, tr, scene, src, per_ray, base, enabled):
+  """the launch's rows into the store, one recording group at a time, as the device hands them over: already
+  split into the arrays of the reference's hit dictionary (Tracer.hitColumns) -- the host copies nothing"""
+  keys = [k for k in enabled if k in per_ray]
+  columns = {k: per_ray[k] for k in keys}
+  for g in np.nonzero(np.asarray(scene.group_record))[0]:
+    cols = tr.hitColumns(int(g))
+    if cols is None:
+      continue
+    ray = cols['rayIndex'] - int(base)
+    extra = {k: np.asarray(v)[ray] for k, v in columns.items()}
+    store.addRayHits(src.Name, src._props.get('Label', src.Name), scene.group_names[g], scene.group_labels[g],
+                     cols['points'], cols['directions'], cols['powers'], cols['isEntering'], **extra)
 
 
 def _store_hits(store, rows, scene, src, per_ray, base, enabled):

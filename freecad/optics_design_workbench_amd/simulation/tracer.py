@@ -254,6 +254,27 @@ class Tracer:
       # back to one list: later launches reserve hit-list blocks per wave again
       self._chk(self._lib.odw_release_swapped_hits(self._ctx), 'odw_release_swapped_hits')
 
+  def hitColumns(self, group):
+    """the recorded rows of one group as the arrays the reference pickles per (source, object)
+    (results_store.py:405-457): dict(points (n, 3), directions (n, 3), powers (n), isEntering (n) int64,
+    rayIndex (n) int64), in (ray index, bounce) order -- selected and split into columns on the device
+    (odw_hits_select + odw_hits_columns), so the host only receives them; None if the group has no row"""
+    n, leaving = C.c_uint64(0), C.c_uint64(0)
+    self._chk(self._lib.odw_hits_select(self._ctx, C.c_int32(int(group)), C.byref(n), C.byref(leaving)), 'odw_hits_select')
+    m = int(n.value)
+    if m == 0:
+      return None
+    out = dict(points=np.empty((m, 3)), directions=np.empty((m, 3)), powers=np.empty(m),
+               isEntering=np.empty(m, dtype=np.int64), rayIndex=np.empty(m, dtype=np.int64))
+    f = self._lib.odw_hits_columns
+    f.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_uint64, C.POINTER(C.c_uint64)]
+    got = C.c_uint64(0)
+    self._chk(f(self._ctx, *(out[k].ctypes.data_as(C.c_void_p) for k in ('points', 'directions', 'powers', 'isEntering',
+                                                                          'rayIndex')), C.c_uint64(m), C.byref(got)),
+              'odw_hits_columns')
+    assert int(got.value) == m
+    return out
+
   def deviceHits(self, group=None):
     """the recorded rows as a `Hits`-like object that bins them where they are, in HBM
     (`simulation.device_hits.DeviceHits`); valid until the next launch, reset or fetch"""

@@ -421,6 +421,13 @@ int odw_hits_select(odw_ctx* ctx, int32_t group, uint64_t* n_rows, uint64_t* n_l
  * with isEntering != 0) = numpy's a[::stride]; NULL out: count only         */
 int odw_hits_gather(odw_ctx* ctx, int32_t entering_only, uint64_t stride, odw_hit* out,
                     uint64_t capacity, uint64_t* n);
+/* the selection as the arrays the reference pickles per (source, object)
+ * (results_store.py:405-457: points, directions, powers, isEntering; the ray
+ * index for per-ray metadata) -- gathered on the device, in (ray, bounce)
+ * order; any pointer may be NULL (that column is skipped); *n = rows of the
+ * selection                                                                 */
+int odw_hits_columns(odw_ctx* ctx, double* points, double* directions, double* powers, int64_t* is_entering,
+                     int64_t* ray_index, uint64_t capacity, uint64_t* n);
 /* X = p . ex, Y = p . ey for every selected row (key 0: points, 1: directions;
  * ex, ey: unit vectors, [3] each); stats[8] = for X then Y: the two middle
  * values of the sorted column (numpy.median = their mean), minimum, maximum */
