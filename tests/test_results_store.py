@@ -326,3 +326,36 @@ def test_recorded_rays_and_surface_fans_through_the_document_api(native_lib):
     f.OpticalSimulationSettings.EndAfterRays = '2e4'
     assert 80 < f.runSimulation('fans').loadProgress()['totalTracedRays'] < 160
     assert f.runSimulation('true').loadProgress()['totalTracedRays'] > 2e4
+
+
+def test_flushes_written_in_the_background(tmp_path):
+  """flush(wait=False) -- the run loop's -- hands the files to the writer thread; drain() waits for them, and
+  whatever the writer met is raised there"""
+  from freecad.optics_design_workbench_amd.simulation import results_store as rs
+  res = rs.resultsFolderPath(str(tmp_path / 'proj.FCStd'))
+  store = rs.SimulationResults('true', resultsPath=res)
+  for k in range(5):
+    _fill(store, 2000, k)
+    store.flush(wait=False)
+  store.drain()
+  folder = os.path.join(store.runFolderPath(), 'source-src', 'object-OpticalAbsorberGroup')
+  files = sorted(os.listdir(folder))
+  assert len(files) == 5
+  total = 0
+  for f in files:
+    d = pickle.load(open(os.path.join(folder, f), 'rb'))          # plain pickle.load, as the reference reads them
+    assert d['points'].shape == (2000, 3)
+    total += len(d['powers'])
+  assert total == 10000 and len(rs.latestRawFolder(res).loadHits('*')) == 10000
+  # an error of the writer surfaces at the next drain
+  _fill(store, 10, 9)
+  import shutil
+  shutil.rmtree(store.runFolderPath())
+  real_makedirs = os.makedirs
+  try:
+    os.makedirs = lambda *a, **k: None                          # the folder is gone: open() fails in the writer
+    store.flush(wait=False)
+  finally:
+    os.makedirs = real_makedirs
+  with pytest.raises(OSError):
+    store.drain()
