@@ -68,6 +68,11 @@ struct odw_ctx {
   bool spec_dirty = true;                  // scene / limits changed since the last binding attempt
   hipFunction_t spec_fn = nullptr;         // bound kernel (owned by the process-wide cache), or null
   bool spec_lean = false, spec_stoch = false;
+  // ODW_COMPILE_AUTO: the scene's kernel is not there yet (not hot enough, or being compiled)
+  bool spec_pending = false;
+  std::string spec_key;
+  uint64_t spec_rays = 0;                  // rays traced with the uploaded scene on generic kernels
+  uint64_t spec_hot_rays = 50000000;       // ... after which its compilation starts (ODW_SPEC_HOT_RAYS at odw_create)
   double spec_seconds = 0;                 // compile time of the bound kernel (0: it came from a cache)
   int spec_cache_hit = 0;                  // 0 compiled now, 1 process cache, 2 disk cache
   bool have_scene = false, have_source = false, have_limits = false;
@@ -823,6 +828,7 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
     HIPCHK(ctx, hipEventRecord(ev.second, ctx->stream));
     ctx->events.push_back(ev);
   }
+  if (!use_spec) spec_note_launch(ctx, n);
   return ODW_OK;
 }
 
@@ -859,6 +865,7 @@ int odw_create(int device, odw_ctx** out) {
   if (!ctx) return fail(nullptr, ODW_ERR_DEVICE, "out of host memory");
   ctx->device = device;
   if (const char* e = getenv("ODW_BVH_THRESHOLD")) ctx->flat_limit = atoi(e);
+  if (const char* e = getenv("ODW_SPEC_HOT_RAYS")) ctx->spec_hot_rays = (uint64_t)atof(e);
   std::memset(&ctx->P, 0, sizeof ctx->P);
   ctx->P.wavelength = 500.0;
   std::memset(&ctx->det_desc, 0, sizeof ctx->det_desc);
@@ -1074,12 +1081,13 @@ int odw_upload_scene(odw_ctx* ctx, const odw_scene_desc* s) {
   ctx->bvh_dirty = true;
   ctx->spec_dirty = true;
   ctx->spec_fn = nullptr;
+  ctx->spec_rays = 0;
   ctx->n_samplers = 0;   // surface samplers belong to the previous scene's groups
   return ODW_OK;
 }
 
 int odw_compile_scene(odw_ctx* ctx, int32_t mode) {
-  if (!ctx || mode < ODW_COMPILE_OFF || mode > ODW_COMPILE_STRUCTURE) return fail(ctx, ODW_ERR_INVALID, "odw_compile_scene: bad argument");
+  if (!ctx || mode < ODW_COMPILE_OFF || mode > ODW_COMPILE_AUTO) return fail(ctx, ODW_ERR_INVALID, "odw_compile_scene: bad argument");
   ctx->compile_mode = mode;
   ctx->spec_dirty = true;
   ctx->spec_fn = nullptr;

@@ -22,9 +22,12 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <chrono>
 #include <map>
+#include <memory>
 #include <mutex>
+#include <thread>
 
 #if !defined(__HIP_DEVICE_COMPILE__)
 // the sources the run-time compiler needs, byte for byte as this library was built from
@@ -248,15 +251,86 @@ struct SpecKernel {
   hipModule_t mod = nullptr;
   hipFunction_t fn = nullptr;
 };
-std::mutex g_spec_mu;
-std::map<std::string, SpecKernel> g_spec_cache;     // (device, arch, header text) -> loaded kernel; lives as long as the process
+// a compilation under way (ODW_COMPILE_AUTO): run by a thread of its own, picked up by the launch that finds it done
+struct SpecJob {
+  std::atomic<bool> done{false};
+  bool ok = false;
+  std::vector<char> code;
+  std::string err;
+  double seconds = 0;
+};
+// process-wide state, never destroyed (a compile thread may outlive main(): nothing of it is torn down under it)
+struct SpecGlobal {
+  std::mutex mu;
+  std::map<std::string, SpecKernel> cache;                 // (device, arch, options, header text) -> loaded kernel
+  std::map<std::string, std::shared_ptr<SpecJob>> jobs;    // (arch, options, header text) -> compilation under way / finished
+  std::atomic<int> running{0};
+};
+SpecGlobal& spec_global() {
+  static SpecGlobal* g = new SpecGlobal();
+  return *g;
+}
 
-// binds ctx->spec_fn for the uploaded scene (or leaves it null: the generic kernels run)
+std::string spec_cache_file(const std::string& arch, const std::string& opts, const std::string& text) {
+  const std::string dir = cache_dir();
+  if (dir.empty()) return "";
+  uint64_t h = fnv1a(arch + "|" + opts + "|" + text);
+  h = fnv1a(odw_src_kernels, h);
+  h = fnv1a(odw_src_device, h);
+  h = fnv1a(odw_src_trace, h);
+  char name[40];
+  snprintf(name, sizeof name, "/%016llx.hsaco", (unsigned long long)h);
+  return dir + name;
+}
+
+// code object of the header: from the disk cache, or compiled now (and put there); hit = 2 if it came from the disk
+bool spec_code(const std::string& text, const std::string& arch, std::vector<char>& code, std::string& err, int& hit,
+               double& seconds) {
+  const char* xo = getenv("ODW_SPEC_OPTS");
+  const std::string file = spec_cache_file(arch, xo ? xo : "", text);
+  hit = 0;
+  seconds = 0;
+  if (!file.empty()) {
+    if (FILE* f = fopen(file.c_str(), "rb")) {
+      fseek(f, 0, SEEK_END);
+      const long sz = ftell(f);
+      fseek(f, 0, SEEK_SET);
+      if (sz > 0) { code.resize((size_t)sz); if (fread(code.data(), 1, (size_t)sz, f) != (size_t)sz) code.clear(); }
+      fclose(f);
+      if (!code.empty()) { hit = 2; return true; }
+    }
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  if (!spec_compile(text, arch, code, err)) return false;
+  seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (!file.empty()) {
+    mkdirs(cache_dir());
+    const std::string tmp = file + "." + std::to_string((long)getpid());
+    if (FILE* f = fopen(tmp.c_str(), "wb")) {
+      const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
+      fclose(f);
+      if (!ok || rename(tmp.c_str(), file.c_str()) != 0) (void)unlink(tmp.c_str());
+    }
+  }
+  return true;
+}
+
+// at exit: wait for compilations under way (they use hiprtc, whose own state goes away after this handler)
+void spec_wait_at_exit() {
+  for (int k = 0; k < 3000 && spec_global().running.load() > 0; ++k) usleep(10000);
+}
+
+// Binds ctx->spec_fn for the uploaded scene, or leaves it null (the generic kernels run).
+// ODW_COMPILE_STRUCTURE: compiles now if no cache has the kernel.
+// ODW_COMPILE_AUTO: never waits -- a kernel already loaded (or on disk) is bound at once; otherwise the scene has to
+// earn its compilation: once ctx->spec_hot_rays rays were traced with it on the generic kernel, a thread compiles,
+// and the first launch after it has finished binds the result (the rows are the same either way, bit for bit).
 int spec_bind(odw_ctx* ctx) {
   ctx->spec_dirty = false;
   ctx->spec_fn = nullptr;
   ctx->spec_seconds = 0;
   ctx->spec_cache_hit = 0;
+  ctx->spec_pending = false;
   if (ctx->compile_mode == ODW_COMPILE_OFF || !ctx->have_scene) return ODW_OK;
   if (!spec_ineligible(ctx).empty()) return ODW_OK;
   hipDeviceProp_t prop;
@@ -264,50 +338,64 @@ int spec_bind(odw_ctx* ctx) {
   const std::string arch = prop.gcnArchName;
   const std::string text = spec_text(ctx);
   const char* xo = getenv("ODW_SPEC_OPTS");
-  const std::string key = std::to_string(ctx->device) + "|" + arch + "|" + (xo ? xo : "") + "|" + text;
-  std::lock_guard<std::mutex> lock(g_spec_mu);
-  auto it = g_spec_cache.find(key);
-  if (it == g_spec_cache.end()) {
+  const std::string jkey = arch + "|" + (xo ? xo : "") + "|" + text;
+  const std::string key = std::to_string(ctx->device) + "|" + jkey;
+  SpecGlobal& G = spec_global();
+  std::unique_lock<std::mutex> lock(G.mu);
+  auto it = G.cache.find(key);
+  if (it == G.cache.end()) {
     std::vector<char> code;
-    // disk cache: named after the header, the sources and the target
-    std::string file;
-    const std::string dir = cache_dir();
-    if (!dir.empty()) {
-      uint64_t h = fnv1a(arch + "|" + (xo ? xo : "") + "|" + text);
-      h = fnv1a(odw_src_kernels, h);
-      h = fnv1a(odw_src_device, h);
-      h = fnv1a(odw_src_trace, h);
-      char name[40];
-      snprintf(name, sizeof name, "/%016llx.hsaco", (unsigned long long)h);
-      file = dir + name;
-      if (FILE* f = fopen(file.c_str(), "rb")) {
-        fseek(f, 0, SEEK_END);
-        const long sz = ftell(f);
-        fseek(f, 0, SEEK_SET);
-        if (sz > 0) { code.resize((size_t)sz); if (fread(code.data(), 1, (size_t)sz, f) != (size_t)sz) code.clear(); }
-        fclose(f);
-        if (!code.empty()) ctx->spec_cache_hit = 2;
+    std::string err;
+    if (ctx->compile_mode == ODW_COMPILE_AUTO) {
+      auto jt = G.jobs.find(jkey);
+      if (jt == G.jobs.end()) {
+        // on disk already?  (a file read, no compilation: done here)
+        const std::string file = spec_cache_file(arch, xo ? xo : "", text);
+        FILE* f = file.empty() ? nullptr : fopen(file.c_str(), "rb");
+        if (f) {
+          fclose(f);
+        } else {
+          // not hot yet, or hot: start the thread
+          ctx->spec_pending = true;
+          ctx->spec_key = jkey;
+          if (ctx->spec_rays < ctx->spec_hot_rays) return ODW_OK;
+          auto job = std::make_shared<SpecJob>();
+          G.jobs[jkey] = job;
+          static std::once_flag once;
+          std::call_once(once, [] { (void)hiprtc(); atexit(spec_wait_at_exit); });
+          G.running.fetch_add(1);
+          std::thread([job, text, arch] {
+            int hit;
+            job->ok = spec_code(text, arch, job->code, job->err, hit, job->seconds);
+            job->done.store(true);
+            spec_global().running.fetch_sub(1);
+          }).detach();
+          return ODW_OK;
+        }
+      } else if (!jt->second->done.load()) {
+        ctx->spec_pending = true;
+        ctx->spec_key = jkey;
+        return ODW_OK;                                      // still compiling: generic kernels meanwhile
+      } else {
+        std::shared_ptr<SpecJob> job = jt->second;
+        if (!job->ok) return fail(ctx, ODW_ERR_DEVICE, job->err);   // (stays in the map: not tried again)
+        code = job->code;
+        ctx->spec_seconds = job->seconds;
       }
     }
     if (code.empty()) {
-      const auto t0 = std::chrono::steady_clock::now();
-      std::string err;
-      if (!spec_compile(text, arch, code, err)) return fail(ctx, ODW_ERR_DEVICE, err);
-      ctx->spec_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-      if (!file.empty()) {
-        mkdirs(dir);
-        const std::string tmp = file + "." + std::to_string((long)getpid());
-        if (FILE* f = fopen(tmp.c_str(), "wb")) {
-          const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
-          fclose(f);
-          if (!ok || rename(tmp.c_str(), file.c_str()) != 0) (void)unlink(tmp.c_str());
-        }
-      }
+      lock.unlock();                                        // (a compilation of seconds: other contexts go on)
+      const bool ok = spec_code(text, arch, code, err, ctx->spec_cache_hit, ctx->spec_seconds);
+      lock.lock();
+      if (!ok) return fail(ctx, ODW_ERR_DEVICE, err);
+      it = G.cache.find(key);                               // (another context may have loaded it meanwhile)
     }
-    SpecKernel k;
-    HIPCHK(ctx, hipModuleLoadData(&k.mod, code.data()));
-    HIPCHK(ctx, hipModuleGetFunction(&k.fn, k.mod, "odw_spec_kernel"));
-    it = g_spec_cache.emplace(key, k).first;
+    if (it == G.cache.end()) {
+      SpecKernel k;
+      HIPCHK(ctx, hipModuleLoadData(&k.mod, code.data()));
+      HIPCHK(ctx, hipModuleGetFunction(&k.fn, k.mod, "odw_spec_kernel"));
+      it = G.cache.emplace(key, k).first;
+    }
   } else {
     ctx->spec_cache_hit = 1;
   }
@@ -315,6 +403,19 @@ int spec_bind(odw_ctx* ctx) {
   ctx->spec_lean = ctx->lean;
   ctx->spec_stoch = ctx->n_samplers > 0;
   return ODW_OK;
+}
+
+// ODW_COMPILE_AUTO, called by every launch that runs a generic flat kernel: counts the scene's rays and looks whether
+// its compilation should start / has finished (then the next launch binds it)
+void spec_note_launch(odw_ctx* ctx, uint64_t n_rays) {
+  if (ctx->compile_mode != ODW_COMPILE_AUTO || !ctx->spec_pending) return;
+  ctx->spec_rays += n_rays;
+  if (ctx->spec_rays < ctx->spec_hot_rays) return;
+  SpecGlobal& G = spec_global();
+  std::lock_guard<std::mutex> lock(G.mu);
+  auto jt = G.jobs.find(ctx->spec_key);
+  // hot and no compilation yet: the next launch starts it; compilation finished: the next launch binds its result
+  if (jt == G.jobs.end() || jt->second->done.load()) ctx->spec_dirty = true;
 }
 
 int spec_launch(odw_ctx* ctx, unsigned grid) {

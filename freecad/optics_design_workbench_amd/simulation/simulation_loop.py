@@ -34,9 +34,6 @@ def _limit(settings, key, default):
     return np.inf
 
 
-COMPILE_FROM_RAYS = 1e9     # a compile (0.5 - 2 s up to 16 primitives) pays from ~1e9 traced rays; see `compileScene`
-
-
 def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPath=None, store=None,
                   raysPerLaunch=1 << 22, endIf=None, tracer=None, pseudoIterationsPerLaunch=64,
                   dist=None, compileScene='auto', **traceKwargs):
@@ -57,10 +54,10 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
                hit files into the shared run folder, the end criteria see the
                job's totals (`parallel.Ranks`); picked up automatically under a
                launcher (WORLD_SIZE > 1)
-  compileScene 'auto': a continuous run whose end criteria allow >= 1e9 rays (or leave it to
-               endIf) compiles the ray loop against the scene (Tracer.compileScene: 0.5 - 2 s
-               once per scene structure, cached on disk) -- the results are those of the generic
-               kernels bit for bit, only faster; 'structure' / 'off': always / never.  Applies to
+  compileScene 'auto': a continuous run lets the library compile the ray loop against the scene in the
+               background once the scene has traced 5e7 rays, and switches over when the kernel is ready
+               (Tracer.compileScene('auto'): nothing waits, the results are those of the generic kernels
+               bit for bit); 'structure': compile before the first launch; 'off': never.  Applies to
                the tracer this call creates; a tracer passed in keeps its own setting.
   traceKwargs  maxRayLength, maxIntersections, powerTol, distTol (ray.py:36-38)
   -> SimulationResults
@@ -99,16 +96,8 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
   enabled = enabledHitMetadata(settings)
   own = tracer is None
   tr = tracer or Tracer(device)
-  if own:
-    # rays the end criteria ask for, at most (a hit takes at least one ray)
-    wanted = min(store.endAfterRays, store.endAfterIterations * rpi * len(sources), store.endAfterHits) if continuous else 0
-    if compileScene == 'structure':
-      tr.compileScene('structure')
-  else:
-    wanted = 0
-  # ('auto' is decided when the first scene is uploaded: bigger scenes compile longer -- 61 primitives: 17 s --,
-  #  the bar rises with the square of the primitive count)
-  auto_compile = own and compileScene == 'auto' and continuous
+  if own and compileScene in ('auto', 'structure') and (continuous or compileScene == 'structure'):
+    tr.compileScene(compileScene)
   master = ranks.rank == 0
   if master:
     store.setStatus('simulation-is-done', False)
@@ -191,9 +180,6 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
         if uploaded.get('scene') is not scene:
           tr.setScene(scene)
           uploaded['scene'] = scene
-          if auto_compile and wanted >= COMPILE_FROM_RAYS * (max(16, len(scene.prim_type)) / 16.0)**2:
-            tr.compileScene('structure')
-            auto_compile = False
         if uploaded.get('limits') is not lim:
           tr.setLimits(lim)
           uploaded['limits'] = lim

@@ -464,7 +464,11 @@ int odw_hits_moments(odw_ctx* ctx, double* mean, double* var);
  * ODW_KERNEL_CACHE: directory of the disk cache (default ~/.cache/odw_trace,
  * empty string: none).                                                       */
 #define ODW_COMPILE_OFF 0
-#define ODW_COMPILE_STRUCTURE 1
+#define ODW_COMPILE_STRUCTURE 1   /* compile when the scene is bound (the call / the next launch waits)      */
+#define ODW_COMPILE_AUTO 2        /* never wait: a kernel from a cache is bound at once; otherwise the scene
+                                   * is traced by the generic kernels, a thread compiles once 5e7 rays
+                                   * (ODW_SPEC_HOT_RAYS) were traced with it, and the launch after it has
+                                   * finished takes the compiled kernel -- same rows bit for bit           */
 int odw_compile_scene(odw_ctx* ctx, int32_t mode);
 /* bound: the mode of the kernel the next eligible launch runs (0: generic);
  * compile_seconds: of the bound kernel (0 if it came from a cache);

@@ -217,3 +217,44 @@ def test_compiled_kernels_beyond_sixteen_primitives(tracers):
   assert ref['info']['mode'] == 0 and got['info']['mode'] == 1
   assert ref['counters']['segments'] > 16 * 100000
   same(got, ref)
+
+
+def test_auto_mode_compiles_in_the_background_and_switches_over(native_lib, monkeypatch, tmp_path):
+  """ODW_COMPILE_AUTO: the first launches run the generic kernel, the scene earns its compilation by the rays it
+  traces (ODW_SPEC_HOT_RAYS), a thread compiles, a later launch takes the compiled kernel -- rows identical
+  throughout; with the kernel in a cache it is bound at once"""
+  import time
+  from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
+  monkeypatch.setenv('ODW_KERNEL_CACHE', str(tmp_path / 'kernels'))      # an empty disk cache: a real compilation
+  monkeypatch.setenv('ODW_SPEC_HOT_RAYS', '150000')
+  monkeypatch.setenv('ODW_SPEC_OPTS', '-DODW_TEST_AUTO_MODE=1')          # (a key no other test has loaded)
+  proj = project('GettingStarted')
+  n = 100000
+  with Tracer(0) as ref_tr:
+    ref = run(ref_tr, proj, n)
+  with Tracer(0) as tr:
+    assert tr.compileScene('auto')['mode'] == 0
+    modes = []
+    t0 = time.time()
+    while time.time() - t0 < 60:
+      got = run_again(tr, proj, n) if modes else run(tr, proj, n)
+      same(got, ref)
+      modes.append(got['info']['mode'])
+      if modes[-1] == 2:
+        break
+      time.sleep(0.05)
+    assert modes[0] == 0 and modes[1] == 0        # below the threshold, then compiling
+    assert modes[-1] == 2, modes                  # switched over
+    same(run_again(tr, proj, n), ref)
+  with Tracer(0) as tr2:                          # the kernel is loaded: bound at once
+    tr2.setScene(proj.scene); tr2.setSource(proj.source); tr2.setLimits(proj.limits)
+    assert tr2.compileScene('auto')['mode'] == 2
+    assert tr2.compiledInfo()['cache'] == 1
+
+
+def run_again(tr, proj, n, first=0):
+  """another launch of the same rays without uploading the scene again"""
+  tr.reset()
+  tr.trace(first, n, SEED)
+  tr.sync()
+  return dict(counters=tr.counters(), hits=tr.hits(), hist=None, info=tr.compiledInfo())
