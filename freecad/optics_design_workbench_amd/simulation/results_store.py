@@ -205,10 +205,15 @@ class SimulationResults:
       self._writer.start()
     self._writeQueue.put((path, obj))
 
-  def drain(self):
-    """wait until every file handed to the writer thread is on disk; raises what the writer met"""
+  def drain(self, stop=False):
+    """wait until every file handed to the writer thread is on disk; raises what the writer met.
+    stop: the thread ends as well (the end of a run; a later flush starts a new one)"""
     if getattr(self, '_writer', None) is not None:
       self._writeQueue.join()
+      if stop:
+        self._writeQueue.put(None)
+        self._writer.join()
+        self._writer = None
       if self._writeError is not None:
         e, self._writeError = self._writeError, None
         raise e

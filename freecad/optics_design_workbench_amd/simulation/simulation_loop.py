@@ -258,13 +258,13 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
         stop = votes > 0
       if stop:
         break
-    store.drain()
+    store.drain(stop=True)
     ranks.barrier()
     failed = False
   finally:
     if failed:
       try:
-        store.drain()
+        store.drain(stop=True)
       except Exception:
         pass
     # any exception cancels the run (simulation_loop.py:715-723)

@@ -359,3 +359,20 @@ def test_flushes_written_in_the_background(tmp_path):
     os.makedirs = real_makedirs
   with pytest.raises(OSError):
     store.drain()
+
+
+def test_writer_thread_ends_with_the_run(tmp_path):
+  import threading
+  from freecad.optics_design_workbench_amd.simulation import results_store as rs
+  res = rs.resultsFolderPath(str(tmp_path / 'proj.FCStd'))
+  before = threading.active_count()
+  store = rs.SimulationResults('true', resultsPath=res)
+  _fill(store, 100, 0)
+  store.flush(wait=False)
+  store.drain(stop=True)
+  assert threading.active_count() == before
+  _fill(store, 100, 1)                 # a later flush starts a new writer
+  store.flush()
+  store.drain(stop=True)
+  assert threading.active_count() == before
+  assert len(rs.latestRawFolder(res).loadHits('*')) == 200
