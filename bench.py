@@ -298,8 +298,16 @@ def run_sweep_config(args, cfg, rank, local_rank, world, dist, torch):
   def setRadius(d, r):
     d.Sphere.Radius = float(r)
   tr = Tracer(local_rank)
-  tr.compileScene(args.compile)      # sticky: every radius has the same structure -> one kernel for the sweep
-                                     # (no scene yet: nothing is built here; a failure later leaves the generic kernels)
+  # one compiled kernel serves the whole sweep (every radius has the same structure); it is built here, before
+  # the clock starts, from the scene of the first radius (sticky mode: the other radii find it in the cache)
+  setRadius(doc, radii[0])
+  first = scenes.bakeProject(doc)
+  tr.setScene(first.scene)
+  tr.setLimits(first.limits)
+  try:
+    tr.compileScene(args.compile)
+  except Exception:
+    pass                               # (no hiprtc / compiler trouble: the generic kernels run)
 
   def barrier():
     tr.sync()
