@@ -448,7 +448,8 @@ int odw_hits_moments(odw_ctx* ctx, double* mean, double* var);
  * (simulation/raytracing_cache.py:92-111 cachedShape / cachedFaces /
  * cachedBoundBox ..., cacheClear :36).  Here, for a scene of <= 64 analytic
  * primitives the library can compile the ray loop against the scene itself
- * (hiprtc, ~2 s, cached per process and on disk): primitive loop unrolled,
+ * (hiprtc: 0.5 - 2 s up to 16 primitives, 17 s for 61; cached per process and
+ * on disk): primitive loop unrolled,
  * type dispatch / face masks / trimming lists / optical types folded.
  * Float64 values (frames, parameters, boxes, optical constants) are still read
  * from the uploaded tables: one kernel per scene STRUCTURE, parameter sweeps
