@@ -28,7 +28,7 @@ def scene(k):
 
 
 n = 20_000_000
-for k in (1, 3, 5, 6, 8, 12, 20):
+for k in ((1, 3, 5, 6, 8, 12, 20) if len(sys.argv) < 2 else [int(a) for a in sys.argv[1:]]):
   sc, lim, src = scene(k)
   out = dict(lenses=k, prims=len(sc.prim_type))
   for mode in ('off', 'structure'):
