@@ -71,8 +71,8 @@ struct odw_ctx {
   // ODW_COMPILE_AUTO: the scene's kernel is not there yet (not hot enough, or being compiled)
   bool spec_pending = false;
   std::string spec_key;
-  uint64_t spec_rays = 0;                  // rays traced with the uploaded scene on generic kernels
-  uint64_t spec_hot_rays = 50000000;       // ... after which its compilation starts (ODW_SPEC_HOT_RAYS at odw_create)
+  uint64_t spec_hot_rays = 50000000;       // rays traced with a structure on generic kernels (process-wide count) after
+                                           // which its compilation starts (ODW_SPEC_HOT_RAYS at odw_create)
   double spec_seconds = 0;                 // compile time of the bound kernel (0: it came from a cache)
   int spec_cache_hit = 0;                  // 0 compiled now, 1 process cache, 2 disk cache
   bool have_scene = false, have_source = false, have_limits = false;
@@ -1081,7 +1081,6 @@ int odw_upload_scene(odw_ctx* ctx, const odw_scene_desc* s) {
   ctx->bvh_dirty = true;
   ctx->spec_dirty = true;
   ctx->spec_fn = nullptr;
-  ctx->spec_rays = 0;
   ctx->n_samplers = 0;   // surface samplers belong to the previous scene's groups
   return ODW_OK;
 }

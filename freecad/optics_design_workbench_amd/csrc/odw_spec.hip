@@ -264,6 +264,9 @@ struct SpecGlobal {
   std::mutex mu;
   std::map<std::string, SpecKernel> cache;                 // (device, arch, options, header text) -> loaded kernel
   std::map<std::string, std::shared_ptr<SpecJob>> jobs;    // (arch, options, header text) -> compilation under way / finished
+  std::map<std::string, uint64_t> rays;                    // the same key -> rays traced with that structure on generic
+                                                           // kernels, by all contexts of the process (many short runs
+                                                           // of one project make it hot like one long run)
   std::atomic<int> running{0};
 };
 SpecGlobal& spec_global() {
@@ -323,7 +326,8 @@ void spec_wait_at_exit() {
 // Binds ctx->spec_fn for the uploaded scene, or leaves it null (the generic kernels run).
 // ODW_COMPILE_STRUCTURE: compiles now if no cache has the kernel.
 // ODW_COMPILE_AUTO: never waits -- a kernel already loaded (or on disk) is bound at once; otherwise the scene has to
-// earn its compilation: once ctx->spec_hot_rays rays were traced with it on the generic kernel, a thread compiles,
+// earn its compilation: once ctx->spec_hot_rays rays were traced with its structure on generic kernels (by all
+// contexts of the process together), a thread compiles,
 // and the first launch after it has finished binds the result (the rows are the same either way, bit for bit).
 int spec_bind(odw_ctx* ctx) {
   ctx->spec_dirty = false;
@@ -358,7 +362,7 @@ int spec_bind(odw_ctx* ctx) {
           // not hot yet, or hot: start the thread
           ctx->spec_pending = true;
           ctx->spec_key = jkey;
-          if (ctx->spec_rays < ctx->spec_hot_rays) return ODW_OK;
+          if (G.rays[jkey] < ctx->spec_hot_rays) return ODW_OK;
           auto job = std::make_shared<SpecJob>();
           G.jobs[jkey] = job;
           static std::once_flag once;
@@ -409,10 +413,11 @@ int spec_bind(odw_ctx* ctx) {
 // its compilation should start / has finished (then the next launch binds it)
 void spec_note_launch(odw_ctx* ctx, uint64_t n_rays) {
   if (ctx->compile_mode != ODW_COMPILE_AUTO || !ctx->spec_pending) return;
-  ctx->spec_rays += n_rays;
-  if (ctx->spec_rays < ctx->spec_hot_rays) return;
   SpecGlobal& G = spec_global();
   std::lock_guard<std::mutex> lock(G.mu);
+  uint64_t& rays = G.rays[ctx->spec_key];
+  rays += n_rays;
+  if (rays < ctx->spec_hot_rays) return;
   auto jt = G.jobs.find(ctx->spec_key);
   // hot and no compilation yet: the next launch starts it; compilation finished: the next launch binds its result
   if (jt == G.jobs.end() || jt->second->done.load()) ctx->spec_dirty = true;
