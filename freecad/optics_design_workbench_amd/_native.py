@@ -21,6 +21,7 @@ ABI_VERSION = 6
 CNT_NAMES = ['traced_rays', 'recorded_hits', 'segments', 'escaped', 'died', 'capped',
              'hist_overflow', 'hits_dropped', 'grating_in_medium']
 TRACE_RECORD_HITS, TRACE_HISTOGRAM, TRACE_RECORD_SEGMENTS = 1, 2, 4
+FLAG_FLIP_NORMAL, FLAG_CONVEX = 1, 2      # ODW_FLAG_* of prim_flags (include/odw_trace.h)
 COMPILE_OFF, COMPILE_STRUCTURE, COMPILE_AUTO = 0, 1, 2
 COMPILE_MODES = {None: 0, False: 0, 'off': 0, 0: 0, 'structure': 1, 1: 1, True: 1, 'auto': 2, 2: 2}
 ERRORS = {1: 'invalid argument', 2: 'device error', 3: 'no scene', 4: 'capacity', 5: 'unsupported'}

@@ -351,6 +351,29 @@ def threads():
   return int(lib().odw_oracle_threads())
 
 
+def set_strict(on):
+  """reference-strict findNearestIntersection (odw_oracle.c, nearest_strict): the reference's own
+  candidate order, maxRayLength shrink and selection, no convex-solid skip; returns the old mode"""
+  old = bool(lib().odw_oracle_get_strict())
+  lib().odw_oracle_set_strict(C.c_int(1 if on else 0))
+  return old
+
+
+class strict:
+  """with capi.strict(): ... -- the oracle in reference-strict mode inside the block"""
+
+  def __init__(self, on=True):
+    self.on = on
+
+  def __enter__(self):
+    self.old = set_strict(self.on)
+    return self
+
+  def __exit__(self, *exc):
+    set_strict(self.old)
+    return False
+
+
 def surface_source_desc(src):
   """odw_surface_source_desc for a freecad_elements.surface_source.BakedSurfaceSource"""
   keep = dict(prim_type=_arr(src.prim_type, np.int32), prim_flags=_arr(src.prim_flags, np.int32),

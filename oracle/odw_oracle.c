@@ -625,6 +625,331 @@ static nearest_hit nearest_skipping(const odw_scene_desc* sc, const odw_limits* 
 }
 
 /* ------------------------------------------------------------------ */
+/* REFERENCE-STRICT findNearestIntersection (ray.py:328-452).          */
+/*                                                                     */
+/* nearest_skipping() above is the rule the device implements: order-  */
+/* independent (two running minima) and with the convex-solid skip.    */
+/* This second restatement keeps the reference's own control flow so   */
+/* that the two can be compared ray for ray (tests/test_oracle_strict) */
+/*   - no convex-solid skip: every shell of every relevant group is a  */
+/*     candidate of every segment (ray.py:328-364);                    */
+/*   - shells sorted by the distance of their (distTol-enlarged)       */
+/*     bounding box from the start (stable, ray.py:367), skipped when  */
+/*     that distance is no longer < maxRayLength or the line misses    */
+/*     the box (ray.py:372-374);                                       */
+/*   - faces of a shell sorted the same way (ray.py:383-404), each     */
+/*     intersected as an infinite line with the untrimmed surface      */
+/*     (ray.py:411); a point is kept iff it is further than distTol    */
+/*     from the start, within distTol of the FINITE line of the length */
+/*     maxRayLength had when the shell was entered (ray.py:377,425)    */
+/*     and within distTol of the trimmed face (ray.py:426);            */
+/*   - every kept point shrinks maxRayLength to its distance +         */
+/*     5*distTol (ray.py:432);                                         */
+/*   - selection: keep points closer than min + 2*distTol, stable sort */
+/*     by distance, first one whose group is not the current medium,   */
+/*     else the first (ray.py:438-452).                                */
+/* What it cannot restate (no OpenCASCADE): bounding boxes are those   */
+/* of the primitives in GLOBAL axes (the reference's are the shell's   */
+/* and face's in the group's local axes) -- boxes only order and cull  */
+/* candidates, they never decide whether a point is valid --, and      */
+/* "within distTol of the trimmed face" stays the conjunction of       */
+/* signed-distance tests of the default mode (DESIGN.md section 3,     */
+/* note 1).                                                            */
+/* ------------------------------------------------------------------ */
+static int g_strict = 0;
+int odw_oracle_set_strict(int on) { g_strict = on != 0; return ODW_OK; }
+int odw_oracle_get_strict(void) { return g_strict; }
+
+typedef struct { double lo[3], hi[3]; } aabb;
+
+static void aabb_empty(aabb* b) {
+  for (int a = 0; a < 3; ++a) { b->lo[a] = INFINITY; b->hi[a] = -INFINITY; }
+}
+static void aabb_add_point(aabb* b, v3 p) {
+  const double c[3] = {p.x, p.y, p.z};
+  for (int a = 0; a < 3; ++a) { if (c[a] < b->lo[a]) b->lo[a] = c[a]; if (c[a] > b->hi[a]) b->hi[a] = c[a]; }
+}
+static void aabb_merge(aabb* b, const aabb* o) {
+  for (int a = 0; a < 3; ++a) { if (o->lo[a] < b->lo[a]) b->lo[a] = o->lo[a]; if (o->hi[a] > b->hi[a]) b->hi[a] = o->hi[a]; }
+}
+/* BoundBox.isInside / closestPoint distance (ray.py:353-357): 0 inside */
+static double aabb_dist(const aabb* b, v3 p) {
+  const double c[3] = {p.x, p.y, p.z};
+  double s = 0;
+  for (int a = 0; a < 3; ++a) {
+    double d = 0;
+    if (c[a] < b->lo[a]) d = b->lo[a] - c[a]; else if (c[a] > b->hi[a]) d = c[a] - b->hi[a];
+    s += d * d;
+  }
+  return sqrt(s);
+}
+/* BoundBox.intersect(base, dir): the infinite line meets the box (slab test) */
+static int aabb_line(const aabb* b, v3 o, v3 d) {
+  const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+  double t0 = -INFINITY, t1 = INFINITY;
+  for (int a = 0; a < 3; ++a) {
+    if (dd[a] == 0) { if (oo[a] < b->lo[a] || oo[a] > b->hi[a]) return 0; continue; }
+    double ta = (b->lo[a] - oo[a]) / dd[a], tb = (b->hi[a] - oo[a]) / dd[a];
+    if (ta > tb) { double t = ta; ta = tb; tb = t; }
+    if (ta > t0) t0 = ta;
+    if (tb < t1) t1 = tb;
+  }
+  return t0 <= t1;
+}
+
+/* box of one primitive in global axes, enlarged by tol (cachedBoundBox(..., enlarge=distTol)) */
+static void prim_aabb(const odw_scene_desc* sc, int p, double tol, aabb* out) {
+  const double* M = sc->prim_xform + 12 * (size_t)p;
+  const double* par = sc->prim_params + 4 * (size_t)p;
+  aabb_empty(out);
+  if (sc->prim_type[p] == ODW_PRIM_TRIANGLE) {
+    for (int k = 0; k < 3; ++k) aabb_add_point(out, V(M[3 * k], M[3 * k + 1], M[3 * k + 2]));
+  } else {
+    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    switch (sc->prim_type[p]) {
+      case ODW_PRIM_BOX: hi[0] = par[0]; hi[1] = par[1]; hi[2] = par[2]; break;
+      case ODW_PRIM_SPHERE: for (int a = 0; a < 3; ++a) { lo[a] = -par[0]; hi[a] = par[0]; } break;
+      case ODW_PRIM_CYLINDER: lo[0] = lo[1] = -par[0]; hi[0] = hi[1] = par[0]; hi[2] = par[1]; break;
+      case ODW_PRIM_CONE: { double r = fmax(par[0], par[1]); lo[0] = lo[1] = -r; hi[0] = hi[1] = r; hi[2] = par[2]; break; }
+      case ODW_PRIM_TORUS: { double r = par[0] + par[1]; lo[0] = lo[1] = -r; hi[0] = hi[1] = r; lo[2] = -par[1]; hi[2] = par[1]; break; }
+      case ODW_PRIM_PARABOLOID: { double r = 2.0 * sqrt(par[0] * par[1]); lo[0] = lo[1] = -r; hi[0] = hi[1] = r; hi[2] = par[1]; break; }
+    }
+    for (int k = 0; k < 8; ++k)
+      aabb_add_point(out, xf_point_inv(M, V((k & 1) ? hi[0] : lo[0], (k & 2) ? hi[1] : lo[1], (k & 4) ? hi[2] : lo[2])));
+  }
+  for (int a = 0; a < 3; ++a) { out->lo[a] -= tol; out->hi[a] += tol; }
+}
+
+/* the static part of the candidate search, built once per scene (raytracing_cache.py:92-111):
+ * shells in group order then shell order, their faces' primitives, all boxes */
+typedef struct { int group, solid, first, count; aabb box; } shell_rec;
+typedef struct {
+  const odw_scene_desc* sc; const double* xform; int n_prims; double tol;
+  int n_shells; shell_rec* shells; int* prims; aabb* prim_box;
+} strict_cache;
+static strict_cache g_sc = {0};
+
+static void strict_cache_build(const odw_scene_desc* sc, double tol) {
+  free(g_sc.shells); free(g_sc.prims); free(g_sc.prim_box);
+  memset(&g_sc, 0, sizeof g_sc);
+  g_sc.sc = sc; g_sc.xform = sc->prim_xform; g_sc.n_prims = sc->n_prims; g_sc.tol = tol;
+  g_sc.prim_box = (aabb*)malloc((size_t)(sc->n_prims ? sc->n_prims : 1) * sizeof(aabb));
+  g_sc.prims = (int*)malloc((size_t)(sc->n_prims ? sc->n_prims : 1) * sizeof(int));
+  g_sc.shells = (shell_rec*)malloc((size_t)(sc->n_prims ? sc->n_prims : 1) * sizeof(shell_rec));
+  int* shell_of = (int*)malloc((size_t)(sc->n_prims ? sc->n_prims : 1) * sizeof(int));
+  int n_sh = 0;
+  for (int g = 0; g < sc->n_groups; ++g) {
+    int first_of_group = n_sh;
+    for (int p = 0; p < sc->n_prims; ++p) {
+      if (sc->prim_group[p] != g) continue;
+      shell_of[p] = -1;
+      int facemask = sc->prim_type[p] == ODW_PRIM_TRIANGLE ? 1 : (sc->prim_flags[p] >> ODW_FACEMASK_SHIFT) & 0xff;
+      if (!facemask) continue;                       /* an operand without a face of its own */
+      prim_aabb(sc, p, tol, &g_sc.prim_box[p]);
+      int solid = sc->prim_solid ? sc->prim_solid[p] : p;
+      int k;
+      for (k = n_sh - 1; k >= first_of_group; --k) if (g_sc.shells[k].solid == solid) break;
+      if (k < first_of_group) {
+        k = n_sh++;
+        g_sc.shells[k].group = g; g_sc.shells[k].solid = solid; g_sc.shells[k].count = 0;
+        g_sc.shells[k].box = g_sc.prim_box[p];
+      } else {
+        aabb_merge(&g_sc.shells[k].box, &g_sc.prim_box[p]);
+      }
+      shell_of[p] = k;
+      g_sc.shells[k].count++;
+    }
+  }
+  int at = 0;
+  for (int k = 0; k < n_sh; ++k) { g_sc.shells[k].first = at; at += g_sc.shells[k].count; g_sc.shells[k].count = 0; }
+  for (int g = 0; g < sc->n_groups; ++g)
+    for (int p = 0; p < sc->n_prims; ++p)
+      if (sc->prim_group[p] == g && shell_of[p] >= 0) {
+        shell_rec* r = &g_sc.shells[shell_of[p]];
+        g_sc.prims[r->first + r->count++] = p;
+      }
+  g_sc.n_shells = n_sh;
+  free(shell_of);
+}
+
+/* called once per trace call, outside the parallel region */
+static void strict_prepare(const odw_scene_desc* sc, double tol) {
+  strict_cache_build(sc, tol);
+}
+
+typedef struct { int shell; double bb_dist; } shell_cand;
+typedef struct { int prim, face; double bb_dist; } face_cand;
+
+static int n_faces_of(int type) {
+  switch (type) {
+    case ODW_PRIM_BOX: return 6;
+    case ODW_PRIM_CYLINDER: case ODW_PRIM_CONE: case ODW_PRIM_PARABOLOID: return 3;
+    default: return 1;
+  }
+}
+
+static nearest_hit nearest_strict(const odw_scene_desc* sc, const odw_limits* lim, v3 start,
+                                  v3 dir, int medium, int seq_idx) {
+  const double tol = lim->dist_tol;
+  double max_len = lim->max_ray_length;
+  uint64_t mask = relevant_mask(sc, seq_idx);
+  v3 dn = mul(dir, 1.0 / len(dir));
+  nearest_hit none;
+  memset(&none, 0, sizeof none);
+  none.dist = INFINITY;
+  /* (the shell tables were built by strict_prepare() before any thread got here) */
+
+  /* (1) shells of the relevant groups, in group order then shell order (ray.py:328-364) */
+  shell_cand* sh = (shell_cand*)malloc((size_t)(g_sc.n_shells ? g_sc.n_shells : 1) * sizeof(shell_cand));
+  int n_sh = 0;
+  for (int k = 0; k < g_sc.n_shells; ++k) {
+    if (!((mask >> g_sc.shells[k].group) & 1)) continue;
+    double bd = aabb_dist(&g_sc.shells[k].box, start);
+    if (!isfinite(max_len) || bd < max_len) { sh[n_sh].shell = k; sh[n_sh].bb_dist = bd; ++n_sh; }
+  }
+  /* (2) stable sort by bounding-box distance (ray.py:367) */
+  for (int i = 1; i < n_sh; ++i) {
+    shell_cand c = sh[i];
+    int j = i - 1;
+    while (j >= 0 && sh[j].bb_dist > c.bb_dist) { sh[j + 1] = sh[j]; --j; }
+    sh[j + 1] = c;
+  }
+
+  int cap_hit = 16, n_hit = 0;
+  nearest_hit* hits = (nearest_hit*)malloc((size_t)cap_hit * sizeof(nearest_hit));
+  int cap_fc = 64;
+  face_cand* fc = (face_cand*)malloc((size_t)cap_fc * sizeof(face_cand));
+
+  for (int k = 0; k < n_sh; ++k) {
+    const shell_rec* S = &g_sc.shells[sh[k].shell];
+    /* (3) ray.py:372-374 */
+    if (!(sh[k].bb_dist < max_len) || !aabb_line(&S->box, start, dn)) continue;
+    const double line_len = max_len;   /* Part.makeLine(lstart, lstart + dir * maxRayLength), ray.py:377 */
+    int n_fc = 0;
+    for (int m = 0; m < S->count; ++m) {
+      int p = g_sc.prims[S->first + m];
+      int facemask = sc->prim_type[p] == ODW_PRIM_TRIANGLE ? 1 : (sc->prim_flags[p] >> ODW_FACEMASK_SHIFT) & 0xff;
+      const aabb* pb = &g_sc.prim_box[p];
+      double fd = aabb_dist(pb, start);
+      if (!(fd < max_len) || !aabb_line(pb, start, dn)) continue;        /* ray.py:397-398 */
+      for (int f = 0; f < n_faces_of(sc->prim_type[p]); ++f) {
+        if (!((facemask >> f) & 1)) continue;
+        if (n_fc == cap_fc) { cap_fc *= 2; fc = (face_cand*)realloc(fc, (size_t)cap_fc * sizeof(face_cand)); }
+        fc[n_fc].prim = p; fc[n_fc].face = f; fc[n_fc].bb_dist = fd; ++n_fc;
+      }
+    }
+    for (int i = 1; i < n_fc; ++i) {                                      /* ray.py:404 */
+      face_cand c = fc[i];
+      int j = i - 1;
+      while (j >= 0 && fc[j].bb_dist > c.bb_dist) { fc[j + 1] = fc[j]; --j; }
+      fc[j + 1] = c;
+    }
+    for (int i = 0; i < n_fc; ++i) {
+      if (!(fc[i].bb_dist < max_len)) continue;                            /* ray.py:410 */
+      int p = fc[i].prim, g = sc->prim_group[p];
+      const double* M = sc->prim_xform + 12 * (size_t)p;
+      int flags = sc->prim_flags[p];
+      if (sc->prim_type[p] == ODW_PRIM_TRIANGLE) {
+        /* one facet: same arithmetic as the default mode, finite-line test with line_len */
+        v3 v0 = V(M[0], M[1], M[2]);
+        v3 e1 = sub(V(M[3], M[4], M[5]), v0), e2 = sub(V(M[6], M[7], M[8]), v0);
+        v3 nn = cross(e1, e2);
+        double a2 = len(nn);
+        v3 pv = cross(dn, e2);
+        double det = dot(e1, pv);
+        if (det == 0) continue;
+        v3 tv = sub(start, v0);
+        double u = dot(tv, pv) / det;
+        v3 qv = cross(tv, e1);
+        double v = dot(dn, qv) / det;
+        int fe = sc->tri_edges ? sc->tri_edges[p] : 7;
+        double a0 = (fe & 1) ? tol * (len(e2) / a2) : 1e-9;
+        double a1 = (fe & 2) ? tol * (len(e1) / a2) : 1e-9;
+        double a2e = (fe & 4) ? tol * (len(sub(e2, e1)) / a2) : 1e-9;
+        if (u < -a0 || v < -a1 || u + v > 1.0 + a2e) continue;
+        if ((u < 0 && (fe & 1)) || (v < 0 && (fe & 2)) || (u + v > 1.0 && (fe & 4))) {
+          v3 w = add(mul(e1, u), mul(e2, v));
+          double best = seg_dist2(w, e1);
+          double other = seg_dist2(w, e2);
+          if (other < best) best = other;
+          other = seg_dist2(sub(w, e1), sub(e2, e1));
+          if (other < best) best = other;
+          if (best > tol * tol) continue;
+        }
+        double t = dot(e2, qv) / det;
+        if (!(t > tol) || !(t < line_len + tol)) continue;
+        v3 gp = add(start, mul(dn, t));
+        v3 ng = mul(nn, 1.0 / a2);
+        if (sc->tri_normals) {
+          const double* vn = sc->tri_normals + 9 * (size_t)p;
+          v3 tg = sub(gp, v0);
+          double inv = 1.0 / dot(nn, nn);
+          double bu = dot(cross(tg, e2), nn) * inv, bv = dot(cross(e1, tg), nn) * inv, bw = 1.0 - bu - bv;
+          v3 ni = V(bw * vn[0] + bu * vn[3] + bv * vn[6], bw * vn[1] + bu * vn[4] + bv * vn[7],
+                    bw * vn[2] + bu * vn[5] + bv * vn[8]);
+          if (dot(ni, ni) > 0) ng = mul(ni, 1.0 / len(ni));
+        }
+        if (flags & ODW_FLAG_FLIP_NORMAL) ng = mul(ng, -1.0);
+        if (n_hit == cap_hit) { cap_hit *= 2; hits = (nearest_hit*)realloc(hits, (size_t)cap_hit * sizeof(nearest_hit)); }
+        nearest_hit* h = &hits[n_hit++];
+        h->found = 1; h->prim = p; h->face = 0; h->group = g; h->dist = t; h->point = gp; h->normal = ng;
+        max_len = t + 5 * tol;                                             /* ray.py:432 */
+        continue;
+      }
+      v3 lstart = xf_point(M, start);
+      v3 ldir = sub(xf_point(M, add(start, dn)), lstart);                  /* ray.py:348-349 */
+      cand cs[8];
+      int nc = prim_candidates(sc->prim_type[p], sc->prim_params + 4 * (size_t)p, 1 << fc[i].face,
+                               lstart, ldir, tol, cs);
+      for (int c = 0; c < nc; ++c) {
+        double t = cs[c].t;
+        v3 lp = add(lstart, mul(ldir, t));
+        double dist = len(sub(lp, lstart));
+        /* (vec-lstart).Length > distTol and vert.distToShape(line) < distTol: the point lies on the
+         * infinite line, so its distance from the finite one is how far it is beyond either end */
+        if (!(dist > tol)) continue;
+        double beyond = t < 0 ? dist : (dist > line_len ? dist - line_len : 0.0);
+        if (!(beyond < tol)) continue;
+        v3 gp = xf_point_inv(M, lp);
+        int ok = 1;
+        for (int q = sc->prim_cond_off[p]; q < sc->prim_cond_off[p + 1] && ok; ++q) {
+          int qp = sc->cond_prim[q];
+          v3 pt = xf_point(sc->prim_xform + 12 * (size_t)qp, gp);
+          double sd = prim_sdist(sc->prim_type[qp], sc->prim_params + 4 * (size_t)qp, pt);
+          if (sc->cond_inside[q]) { if (sd > tol) ok = 0; }
+          else { if (sd < -tol) ok = 0; }
+        }
+        if (!ok) continue;
+        v3 nl = cs[c].n_local;
+        if (flags & ODW_FLAG_FLIP_NORMAL) nl = mul(nl, -1.0);
+        v3 ng = sub(xf_point_inv(M, add(lp, nl)), gp);
+        if (n_hit == cap_hit) { cap_hit *= 2; hits = (nearest_hit*)realloc(hits, (size_t)cap_hit * sizeof(nearest_hit)); }
+        nearest_hit* h = &hits[n_hit++];
+        h->found = 1; h->prim = p; h->face = cs[c].face; h->group = g; h->dist = dist; h->point = gp; h->normal = ng;
+        max_len = dist + 5 * tol;                                          /* ray.py:432 */
+      }
+    }
+  }
+  free(sh); free(fc);
+  if (!n_hit) { free(hits); return none; }
+  /* ray.py:438-452 */
+  double min_dist = INFINITY;
+  for (int i = 0; i < n_hit; ++i) if (hits[i].dist < min_dist) min_dist = hits[i].dist;
+  int n_near = 0;
+  for (int i = 0; i < n_hit; ++i) if (hits[i].dist < min_dist + 2 * tol) hits[n_near++] = hits[i];
+  for (int i = 1; i < n_near; ++i) {            /* sorted(): stable */
+    nearest_hit c = hits[i];
+    int j = i - 1;
+    while (j >= 0 && hits[j].dist > c.dist) { hits[j + 1] = hits[j]; --j; }
+    hits[j + 1] = c;
+  }
+  nearest_hit res = hits[0];
+  for (int i = 0; i < n_near; ++i) if (hits[i].group != medium) { res = hits[i]; break; }
+  free(hits);
+  return res;
+}
+
+/* ------------------------------------------------------------------ */
 /* mirror / snellsLaw / lineGrating (ray.py:482-539)                   */
 /* ------------------------------------------------------------------ */
 static v3 mirror(v3 ray, v3 n) {
@@ -824,7 +1149,8 @@ static void trace_one(const odw_scene_desc* sc, const odw_limits* lim,
     if (nint >= lim->max_intersections) { sk->cnt[ODW_CNT_CAPPED]++; break; }
     nint++;
     sk->cnt[ODW_CNT_SEGMENTS]++;
-    nearest_hit h = nearest_skipping(sc, lim, point, dir, medium, seq, skip_solid);
+    nearest_hit h = g_strict ? nearest_strict(sc, lim, point, dir, medium, seq)
+                             : nearest_skipping(sc, lim, point, dir, medium, seq, skip_solid);
     if (flags & ODW_TRACE_RECORD_SEGMENTS)
       record_segment(sk, ray, nint - 1, medium, point,
                      h.found ? h.point : add(point, mul(dir, lim->max_ray_length / len(dir))), power);
@@ -940,6 +1266,7 @@ static int run(const odw_scene_desc* sc, const odw_source_desc* src, const odw_l
   uint64_t total[ODW_CNT_COUNT] = {0};
   int max_hits_per_ray = lim->max_intersections > 0 ? lim->max_intersections : 1;
   (void)nthreads;
+  if (g_strict) strict_prepare(sc, lim->dist_tol);
 #ifdef _OPENMP
   if (nthreads > 0) omp_set_num_threads(nthreads);
 #pragma omp parallel
@@ -1224,8 +1551,10 @@ int odw_oracle_surface_rays(const odw_surface_source_desc* s, uint64_t first, ui
 int odw_oracle_nearest(const odw_scene_desc* sc, const odw_limits* lim, const double* start,
                        const double* dir, int medium, int seq_idx, int* prim, int* face,
                        int* group, double* dist, double* point, double* normal) {
-  nearest_hit h = nearest(sc, lim, V(start[0], start[1], start[2]), V(dir[0], dir[1], dir[2]),
-                          medium, seq_idx);
+  if (g_strict) strict_prepare(sc, lim->dist_tol);
+  nearest_hit h = g_strict ? nearest_strict(sc, lim, V(start[0], start[1], start[2]), V(dir[0], dir[1], dir[2]), medium, seq_idx)
+                           : nearest(sc, lim, V(start[0], start[1], start[2]), V(dir[0], dir[1], dir[2]),
+                                     medium, seq_idx);
   if (!h.found) return 0;
   *prim = h.prim; *face = h.face; *group = h.group; *dist = h.dist;
   point[0] = h.point.x; point[1] = h.point.y; point[2] = h.point.z;

@@ -11,15 +11,19 @@ from random_scenes import rays, scene
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize('compile', ['off', 'structure'])
 @pytest.mark.parametrize('rich', [False, True])
-def test_random_scenes_device_equals_oracle(native_lib, oracle, rich):
+def test_random_scenes_device_equals_oracle(native_lib, oracle, rich, compile):
   """rich: also tessellated solids (BVH kernels), stochastic surfaces, gratings, absorbing media,
-  partly reflecting mirrors, sequential mode"""
+  partly reflecting mirrors, sequential mode.  compile = structure: every scene the flat kernel traces gets
+  its own scene-compiled kernel (one hiprtc compilation per random structure) -- the kernel family bench.py
+  times, against the oracle directly"""
   from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
   n = 5000
-  scenes = differing_rays = total = 0
+  scenes = differing_rays = total = compiled = 0
   with Tracer(0) as tr:
-    for s in range(40):
+    tr.compileScene(compile)
+    for s in range(40 if compile == 'off' else 16):
       rs = np.random.RandomState(7 * 100003 + s)
       try:
         sc, lim, targets = scene(rs, rich)
@@ -32,6 +36,7 @@ def test_random_scenes_device_equals_oracle(native_lib, oracle, rich):
       tr.setSurfaceSeed(s + 17)
       tr.traceRays(o, d)
       tr.sync()
+      compiled += tr.compiledInfo()['mode'] == 1
       g = tr.hits()
       r = oracle.trace_rays(sc, lim, o, d, nthreads=0, surface_seed=s + 17)['hits']
       scenes += 1
@@ -51,7 +56,11 @@ def test_random_scenes_device_equals_oracle(native_lib, oracle, rich):
       start = np.maximum.accumulate(np.where(first, np.arange(len(gr)), 0))
       early = np.arange(len(gr)) - start < 4
       assert dev[early].max() < 1e-7, (s, float(dev[early].max()))
-  assert scenes >= 30 and differing_rays <= 2, (scenes, differing_rays, total)
+  assert scenes >= (30 if compile == 'off' else 12) and differing_rays <= 2, (scenes, differing_rays, total)
+  if compile == 'structure':
+    assert compiled >= (scenes if not rich else 4), (compiled, scenes)      # (rich: tessellated scenes keep the BVH kernels)
+  else:
+    assert compiled == 0
 
 
 @pytest.mark.parametrize('crowded', [False, True])

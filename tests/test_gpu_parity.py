@@ -15,10 +15,14 @@ SEED = 0x0D15EA5E
 TOL = 1e-9
 
 
-@pytest.fixture(scope='module')
-def tracer(native_lib):
+# every test of this module runs on the generic kernels and on the scene-compiled ones (odw_spec_kernel,
+# the kernel bench.py times): scenes outside a compiled kernel's domain (hugeArray: grid kernel) keep theirs
+@pytest.fixture(scope='module', params=['off', 'structure'])
+def tracer(native_lib, request):
   from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
   tr = Tracer(0)
+  tr.compileScene(request.param)
+  tr.compileMode = request.param
   yield tr
   tr.close()
 
@@ -63,9 +67,47 @@ def test_scene_parity(tracer, oracle, scene, group, n):
   if group is not None:
     det = scenes.planeDetector(proj.scene, group, nx=128, ny=128, toward=proj.source.xform[[3, 7, 11]])
   gpu = run_gpu(tracer, proj, 0, n, SEED, det)
+  # the kernel that ran is the one the parameter names
+  assert tracer.compiledInfo()['mode'] == (1 if tracer.compileMode == 'structure' else 0)
   ref = oracle.trace(proj.scene, proj.source, proj.limits, 0, n, SEED, det=det, nthreads=0)
   assert ref['counters']['traced_rays'] == n
   compare(gpu, ref)
+
+
+@pytest.mark.parametrize('scene', ['lens-overlap', 'playground', 'lensesAndMirrors', 'GettingStarted'])
+def test_reference_strict_device_equals_strict_oracle(native_lib, oracle, tracer, scene):
+  """Tracer(referenceStrict=True) uploads the scene without ODW_FLAG_CONVEX (no convex-solid skip) and is
+  compared with the oracle's reference-strict findNearestIntersection (ray.py:328-452 in the reference's own
+  order, oracle/odw_oracle.c nearest_strict) on whole trajectories.  lens-overlap and playground
+  (DistanceTolerance 1e-2) are the two reference scenes in which the skip changes rays
+  (tests/test_oracle_strict.py): here the device follows the strict oracle through every one of them."""
+  import copy
+  from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
+  proj = project(scene)
+  sc = copy.copy(proj.scene)
+  sc.group_record = np.ones_like(sc.group_record)
+  n = 200000
+  cap = n * 12
+  with Tracer(0, referenceStrict=True) as tr:
+    tr.compileScene(tracer.compileMode)
+    tr.setScene(sc); tr.setSource(proj.source); tr.setLimits(proj.limits); tr.setDetector(None)
+    tr.reserveHits(cap)
+    tr.reset()
+    tr.trace(0, n, SEED)
+    tr.sync()
+    assert tr.compiledInfo()['mode'] == (1 if tracer.compileMode == 'structure' else 0)
+    g, gc = tr.hits(), tr.counters()
+  with oracle.strict():
+    ref = oracle.trace(sc, proj.source, proj.limits, 0, n, SEED, nthreads=0, hit_capacity=cap)
+  default = oracle.trace(sc, proj.source, proj.limits, 0, n, SEED, nthreads=0, hit_capacity=cap)
+  assert gc == ref['counters'] and gc['hits_dropped'] == 0
+  assert np.array_equal(g['tag'], ref['hits']['tag'])
+  if scene in ('lens-overlap', 'playground'):     # ... and these rows are not the default mode's
+    assert ref['counters'] != default['counters']
+  # first hits to 1e-9 mm (later ones carry rounding amplified by curved surfaces, see test_gpu_parity_geometry)
+  ray = (g['tag'] & np.uint64(0xFFFFFFFFFFFF)).astype(np.int64)
+  first = np.r_[True, ray[1:] != ray[:-1]]
+  assert np.abs(g['point'][first] - ref['hits']['point'][first]).max() < TOL
 
 
 def test_huge_array_parity(tracer, oracle):
