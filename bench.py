@@ -40,6 +40,8 @@ os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 SCENES = os.path.join(ROOT, 'tests', 'golden', 'scenes')
 SEED = 0x0D15EA5E
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # 256 CUs x 4 SIMDs x 16 f64 FMA lanes x 2 flop x 2.4 GHz
+SIMDS, CLOCK_GHZ = 1024, 2.4     # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, 2400 MHz max clock
 RAY_STATE_BYTES = 64    # S, read + written once per segment
 HIT_BYTES = 64          # H, one row per recorded hit
 
@@ -108,20 +110,18 @@ def cpu_baseline(proj, det, seconds=12.0):
 
 
 def spawn_ranks(args, argv):
-  """--gpus N > 1 without a launcher: start the N ranks as a child process.  Nothing in this
-  process has touched the GPU yet (torch.cuda.device_count() only counts), and this process is
-  never replaced by another program: it waits for the child and exits with its code."""
-  import socket
+  """--gpus N > 1 without a launcher: start the N ranks as a CHILD process.  Counting the devices may
+  initialise the HIP runtime in this process (torch.cuda.device_count() calls hipGetDeviceCount); that is
+  harmless here because this process is never replaced by another program and runs no kernel: it starts
+  the launcher as a child, waits for it and exits with its code.  The rendezvous port is the launcher's to
+  pick (--standalone on 127.0.0.1: no bind-then-close race)."""
   import torch
   have = torch.cuda.device_count()
   if have < args.gpus:
     sys.stderr.write(f'bench.py: --gpus {args.gpus} asked for, {have} device(s) present\n')
     return 2
-  with socket.socket() as s:
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
-         '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + argv
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--standalone', '--local-addr', '127.0.0.1', '--nnodes=1',
+         f'--nproc-per-node={args.gpus}', os.path.abspath(__file__)] + argv
   return subprocess.call(cmd, env=dict(os.environ, MASTER_ADDR='127.0.0.1'))
 
 
@@ -141,6 +141,44 @@ def pmc_figures(cfg_name, n_per, record_hits, kernel):
   if tj.get('kernel') and not kernel.startswith(tj['kernel']):     # profiled on another kernel (e.g. --compile off)
     return None
   return tj
+
+
+def roofline_block(kernel_name, avg_kernel_s, rays_per_launch, bytes_per_ray, pmc, note=None):
+  """The bound of these kernels is VECTOR-INSTRUCTION ISSUE, not HBM: rays live in registers from generation to
+  termination, the only HBM traffic is the hit rows.  frac = wave64 VALU instructions per second (SQ_INSTS_VALU of
+  the committed rocprofv3 pass of this same command / the kernel time measured live with HIP events) / the peak
+  issue rate FOR THE KERNEL'S OWN INSTRUCTION MIX (per-class costs measured by scripts/valu_peak.hip at the
+  kernels' occupancy, profiles/r03/valu_peak.json).  Beside it: float64 flop/s against the 78.6 TF vector peak,
+  the counters' HBM bytes against 8 TB/s, and SURVEY 8(d)'s wavefront-formulation figure (what the same work would
+  move if ray state lived in HBM between bounces) -- kept for comparability, never as `frac`."""
+  alg = bytes_per_ray * rays_per_launch
+  r = {'bound': 'valu_issue', 'achieved': None, 'peak': None, 'unit': 'G wave64 VALU instructions/s', 'frac': None,
+       'traffic': None, 'kernel': kernel_name, 'avg_kernel_ms': avg_kernel_s * 1e3,
+       'wavefront_equivalent_frac': alg / avg_kernel_s / 1e9 / HBM_PEAK_GBS,
+       'wavefront_equivalent_note': 'SURVEY 8(d): (2 x 64 B ray state per segment + 64 B per hit row) x rays / kernel time / 8 TB/s; '
+                                    'a register-resident megakernel never moves the ray state: not a bound',
+       'algorithmic_bytes_per_ray': bytes_per_ray, 'algorithmic_bytes_per_launch': alg}
+  if note:
+    r['note'] = note
+  v = pmc.get('valu') if pmc else None
+  if pmc:
+    r['traffic'] = pmc['hbm_bytes_per_launch'] / avg_kernel_s / 1e9            # GB/s, PMC bytes per launch / live kernel time
+    r['traffic_bytes_per_launch'] = pmc['hbm_bytes_per_launch']
+    r['hbm_counter_frac'] = r['traffic'] / HBM_PEAK_GBS
+    r['traffic_source'] = pmc.get('source')
+  if v and v.get('cyc_per_inst_calibrated'):
+    r['achieved'] = v['insts_per_launch'] / avg_kernel_s / 1e9
+    r['peak'] = SIMDS * CLOCK_GHZ / v['cyc_per_inst_calibrated']
+    r['frac'] = r['achieved'] / r['peak']
+    r['valu'] = {k: v[k] for k in ('insts_per_launch', 'salu_insts_per_launch', 'cyc_per_inst_calibrated', 'insts_by_class',
+                                   'class_cycles', 'unclassified_split', 'active_lanes_per_inst', 'wait_any_frac',
+                                   'lds_bank_conflict_frac', 'kernel_ms_profiled', 'source', 'definition') if k in v}
+    r['valu']['calibration'] = 'profiles/r03/valu_peak.json'
+    if v.get('fp64_flop_per_launch'):
+      r['fp64_flops_frac'] = v['fp64_flop_per_launch'] / avg_kernel_s / 1e12 / FP64_VECTOR_PEAK_TFLOPS
+  else:
+    r['note'] = ((note + '; ') if note else '') + 'no committed counter pass for this workload: instruction counts unknown, frac not computed'
+  return r
 
 
 def run_trace_config(args, cfg_name, cfg, rank, local_rank, world, dist, torch):
@@ -221,14 +259,8 @@ def run_trace_config(args, cfg_name, cfg, rank, local_rank, world, dist, torch):
     hbar = cnt['recorded_hits'] / cnt['traced_rays']
     bytes_per_ray = kbar * 2 * RAY_STATE_BYTES + hbar * HIT_BYTES
     avg_kernel_s = kernel_ms / 1e3 / max(1, launches)
-    achieved = bytes_per_ray * n_per / avg_kernel_s / 1e9
     kernel_name = 'odw_spec_kernel' if compiled['mode'] else cfg['kernel']
     pmc = pmc_figures(cfg_name, n_per, record_hits, kernel_name)
-    traffic = traffic_bytes = valu = None
-    if pmc:
-      traffic_bytes = pmc['hbm_bytes_per_launch']
-      traffic = traffic_bytes / avg_kernel_s / 1e9       # same unit as `achieved`
-      valu = pmc.get('valu')
     out = {
         'metric': 'Monte-Carlo rays/sec (whole node), lensesAndMirrors.FCStd' if cfg_name == 'c3'
                   else f'Monte-Carlo rays/sec (whole node), {cfg["scene"]}.FCStd',
@@ -243,12 +275,7 @@ def run_trace_config(args, cfg_name, cfg, rank, local_rank, world, dist, torch):
                                       'note': 'hiprtc compile of the ray loop against the scene, before the timed region',
                                       **({'error': compiled['error']} if 'error' in compiled else {})},
                    'parallelism': f'ray-index sharding x{world}, one RCCL reduce'},
-        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_bytes_per_launch': traffic_bytes,
-                     'algorithmic_bytes_per_launch': bytes_per_ray * n_per,
-                     'traffic_source': pmc.get('source') if pmc else None,
-                     'kernel': kernel_name, 'avg_kernel_ms': avg_kernel_s * 1e3,
-                     'algorithmic_bytes_per_ray': bytes_per_ray, 'valu': valu},
+        'roofline': roofline_block(kernel_name, avg_kernel_s, n_per, bytes_per_ray, pmc),
     }
     if world == 1 and record_hits and cfg_name == 'c3' and not args.no_end_to_end:
       out['end_to_end'] = end_to_end(tr, n_per, max(2, args.steps))
@@ -305,9 +332,9 @@ def run_sweep_config(args, cfg, rank, local_rank, world, dist, torch):
   tr.setScene(first.scene)
   tr.setLimits(first.limits)
   try:
-    tr.compileScene(args.compile)
-  except Exception:
-    pass                               # (no hiprtc / compiler trouble: the generic kernels run)
+    compiled = tr.compileScene(args.compile)
+  except Exception as e:               # no hiprtc / compiler trouble: the generic kernels run, the line says so
+    compiled = dict(mode=0, seconds=0.0, cache=0, error=str(e)[:300])
 
   def barrier():
     tr.sync()
@@ -343,7 +370,9 @@ def run_sweep_config(args, cfg, rank, local_rank, world, dist, torch):
     hbar = res.recordedHits / res.tracedRays
     bytes_per_ray = kbar * 2 * RAY_STATE_BYTES + hbar * HIT_BYTES
     avg_kernel_s = kernel_ms / 1e3 / max(1, launches)
-    achieved = bytes_per_ray * n_per / avg_kernel_s / 1e9
+    info = tr.compiledInfo()             # the kernel the last radius ran
+    kernel_name = 'odw_spec_kernel' if info['mode'] == 1 else cfg['kernel']
+    pmc = pmc_figures('c5', n_per, True, kernel_name)
     best_r, best_f = res.best('fwhm') if np.isfinite(res.columns['fwhm']).any() else (float('nan'), float('nan'))
     rms_r, rms_v = res.best('rms')
     out = {
@@ -353,6 +382,10 @@ def run_sweep_config(args, cfg, rank, local_rank, world, dist, torch):
         'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'config': {'workload': cfg['workload'] % n_per, 'name': 'c5', 'radii': len(radii),
                    'rays_per_radius': n_per, 'segments_per_ray': kbar, 'hits_per_ray': hbar,
+                   'scene_compiled': {'mode': {0: 'off', 1: 'structure', 2: 'auto'}[info['mode']],
+                                      'compile_seconds': compiled.get('seconds', 0.0), 'cache': compiled.get('cache', 0),
+                                      'note': 'one kernel for the whole sweep (every radius has the same structure), compiled before the timed region',
+                                      **({'error': compiled['error']} if 'error' in compiled else {})},
                    'parallelism': f'radii dealt out over {world} rank(s), one RCCL all-reduce of the table',
                    'spot_size': {'kind': 'calcFwhm (optimize-spotsize.ipynb cell 8)', 'radii': radii.tolist(),
                                  'fwhm_mm': [None if np.isnan(v) else float(v) for v in res.columns['fwhm']],
@@ -362,12 +395,9 @@ def run_sweep_config(args, cfg, rank, local_rank, world, dist, torch):
                                               'flat near the focus; the rms spot radius below stays defined',
                                  'rms_spot_mm': [float(v) for v in res.columns['rms']],
                                  'best_radius_by_rms_mm': rms_r, 'best_rms_spot_mm': rms_v}},
-        'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
-                     'algorithmic_bytes_per_launch': bytes_per_ray * n_per, 'kernel': cfg['kernel'],
-                     'avg_kernel_ms': avg_kernel_s * 1e3, 'algorithmic_bytes_per_ray': bytes_per_ray,
-                     'note': 'launches of rank 0; a launch = one radius; per step the host also re-bakes the scene and '
-                             'searches the detector plane per radius (host-bound at 1e7 rays per radius)'},
+        'roofline': roofline_block(kernel_name, avg_kernel_s, n_per, bytes_per_ray, pmc,
+                                   note='launches of rank 0; a launch = one radius; per step the host also re-bakes the scene and '
+                                        'searches the detector plane per radius'),
     }
     if world == 1 and not args.no_cpu_baseline:
       proj = scenes.bakeProject(doc)
@@ -390,6 +420,8 @@ def main():
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-end-to-end', action='store_true')
   ap.add_argument('--no-hits', action='store_true', help='histogram only (diagnostic, not the metric)')
+  ap.add_argument('--no-extra', action='store_true',
+                  help='c3 only: leave out the c4 (3 steps) and c5 (1 sweep) lines nested under "extra_configs"')
   args = ap.parse_args()
   cfg = CONFIGS[args.config]
   if args.steps is None:
@@ -423,6 +455,30 @@ def main():
     out = run_sweep_config(args, cfg, rank, local_rank, world, dist, torch)
   else:
     out = run_trace_config(args, args.config, cfg, rank, local_rank, world, dist, torch)
+  if args.config == 'c3' and not args.no_extra and not args.no_hits and not args.rays_per_step:
+    # the other two GPU configs of BASELINE.json in the same driver-timed record: c4 (hugeArray, 3 steps) and
+    # c5 (the radius sweep, 1 sweep after 1 untimed one), each measured exactly like its own `--config` line
+    import copy
+    extra = {}
+    for name, steps, warmup in (('c4', 3, 1), ('c5', 1, 1)):
+      sub = copy.copy(args)
+      sub.config, sub.steps, sub.warmup = name, steps, warmup
+      sub.no_cpu_baseline = sub.no_end_to_end = True
+      try:
+        if name == 'c5':
+          line = run_sweep_config(sub, CONFIGS[name], rank, local_rank, world, dist, torch)
+        else:
+          line = run_trace_config(sub, name, CONFIGS[name], rank, local_rank, world, dist, torch)
+      except Exception as e:            # (a failing extra must not take the headline line with it; it is reported)
+        line = {'error': f'{type(e).__name__}: {e}'[:500]}
+        if dist is not None:
+          raise
+      if rank == 0:
+        if name == 'c5' and 'config' in line:          # (the per-radius table belongs to the c5 line of its own)
+          line['config'].get('spot_size', {}).pop('radii', None)
+        extra[name] = line
+    if rank == 0:
+      out['extra_configs'] = extra
   if rank == 0:
     print(json.dumps(out), flush=True)
   if dist is not None:

@@ -796,11 +796,13 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
     const size_t glds = P.grid.lds_bytes;
 #define ODW_GRID_LAUNCH(S, L)                                                                                  \
     do {                                                                                                       \
-      static bool attr_set = false;                                                                            \
-      if (!attr_set) {                                                                                         \
+      /* (once per device and instantiation: a second context on another GPU of the process needs its own) */  \
+      static uint64_t attr_set = 0;                                                                            \
+      const uint64_t dev_bit = 1ull << (ctx->device & 63);                                                     \
+      if (!(attr_set & dev_bit)) {                                                                             \
         HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&odw_grid_kernel<S, L>),                 \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));              \
-        attr_set = true;                                                                                       \
+        attr_set |= dev_bit;                                                                                   \
       }                                                                                                        \
       hipLaunchKernelGGL((odw_grid_kernel<S, L>), gb, dim3(ODW_GRID_THREADS), glds, ctx->stream, P);           \
     } while (0)

@@ -63,7 +63,9 @@ struct Hiprtc {
   decltype(&hiprtcGetCodeSize) code_size = nullptr;
   decltype(&hiprtcGetCode) code = nullptr;
   decltype(&hiprtcDestroyProgram) destroy = nullptr;
+  decltype(&hiprtcVersion) version = nullptr;
   std::string error;
+  std::string version_text;       // "major.minor" of the loaded hiprtc (part of the disk-cache key)
 };
 
 Hiprtc& hiprtc() {
@@ -85,7 +87,12 @@ Hiprtc& hiprtc() {
     ODW_RTC_SYM(code_size, hiprtcGetCodeSize)
     ODW_RTC_SYM(code, hiprtcGetCode)
     ODW_RTC_SYM(destroy, hiprtcDestroyProgram)
+    ODW_RTC_SYM(version, hiprtcVersion)
 #undef ODW_RTC_SYM
+    if (h.version) {
+      int major = 0, minor = 0;
+      if (h.version(&major, &minor) == HIPRTC_SUCCESS) h.version_text = std::to_string(major) + "." + std::to_string(minor);
+    }
   });
   return h;
 }
@@ -277,7 +284,11 @@ SpecGlobal& spec_global() {
 std::string spec_cache_file(const std::string& arch, const std::string& opts, const std::string& text) {
   const std::string dir = cache_dir();
   if (dir.empty()) return "";
+  // (the compiler is part of the key: a process that imported torch first compiles with torch's bundled hiprtc, of
+  //  another ROCm release -- scripts/torch_rtc_check.py --, and code objects of two compilers must not share a file;
+  //  HIP_VERSION = the hipcc that built this library and its generic kernels)
   uint64_t h = fnv1a(arch + "|" + opts + "|" + text);
+  h = fnv1a("|rtc " + hiprtc().version_text + "|hip " + std::to_string((long)HIP_VERSION), h);
   h = fnv1a(odw_src_kernels, h);
   h = fnv1a(odw_src_device, h);
   h = fnv1a(odw_src_trace, h);
@@ -308,7 +319,8 @@ bool spec_code(const std::string& text, const std::string& arch, std::vector<cha
   seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (!file.empty()) {
     mkdirs(cache_dir());
-    const std::string tmp = file + "." + std::to_string((long)getpid());
+    static std::atomic<unsigned> serial{0};               // (two contexts of one process may compile the same key)
+    const std::string tmp = file + "." + std::to_string((long)getpid()) + "." + std::to_string(serial.fetch_add(1));
     if (FILE* f = fopen(tmp.c_str(), "wb")) {
       const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
       fclose(f);
@@ -396,9 +408,25 @@ int spec_bind(odw_ctx* ctx) {
     }
     if (it == G.cache.end()) {
       SpecKernel k;
-      HIPCHK(ctx, hipModuleLoadData(&k.mod, code.data()));
-      HIPCHK(ctx, hipModuleGetFunction(&k.fn, k.mod, "odw_spec_kernel"));
-      it = G.cache.emplace(key, k).first;
+      hipError_t le = hipModuleLoadData(&k.mod, code.data());
+      if (le == hipSuccess) le = hipModuleGetFunction(&k.fn, k.mod, "odw_spec_kernel");
+      if (le != hipSuccess && ctx->spec_cache_hit == 2) {
+        // a file of the disk cache that does not load (truncated, damaged): drop it and compile once
+        (void)hipGetLastError();
+        if (k.mod) { (void)hipModuleUnload(k.mod); k.mod = nullptr; }
+        const std::string file = spec_cache_file(arch, xo ? xo : "", text);
+        if (!file.empty()) (void)unlink(file.c_str());
+        code.clear();
+        lock.unlock();
+        const bool ok = spec_code(text, arch, code, err, ctx->spec_cache_hit, ctx->spec_seconds);
+        lock.lock();
+        if (!ok) return fail(ctx, ODW_ERR_DEVICE, err);
+        le = hipModuleLoadData(&k.mod, code.data());
+        if (le == hipSuccess) le = hipModuleGetFunction(&k.fn, k.mod, "odw_spec_kernel");
+      }
+      HIPCHK(ctx, le);
+      it = G.cache.find(key);
+      if (it == G.cache.end()) it = G.cache.emplace(key, k).first;
     }
   } else {
     ctx->spec_cache_hit = 1;

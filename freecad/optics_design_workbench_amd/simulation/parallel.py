@@ -58,6 +58,14 @@ class Ranks:
     self.rank = dist.get_rank() if dist is not None else 0
     self.world = dist.get_world_size() if dist is not None else 1
     self._device = device
+    # RCCL runs a collective on the device of its tensors, and a rank's communicator belongs to one
+    # device.  The tracer's device is that device: settled HERE, before any GPU work and on every rank
+    # alike -- a check inside the first collective would fail on some ranks only (rank 0's device 0 is
+    # always "current") and leave the others waiting in all_reduce until the watchdog ends the job.
+    if dist is not None and self.world > 1 and device is not None and dist.get_backend() == 'nccl':
+      import torch
+      if torch.cuda.current_device() != int(device):
+        torch.cuda.set_device(int(device))
 
   @classmethod
   def detect(cls, dist=None, device=None):
@@ -74,14 +82,8 @@ class Ranks:
   def _tensor_device(self):
     import torch
     if self.dist.get_backend() == 'nccl':
-      # RCCL wants the tensor on the device this rank's communicator was made for: the process'
-      # current device (set by the launcher code from LOCAL_RANK); a device given by the caller
-      # must be that one
-      cur = torch.cuda.current_device()
-      if self._device is not None and int(self._device) != cur and self.world > 1:
-        raise RuntimeError(f'rank {self.rank}: collectives on cuda:{cur} but the tracer works on cuda:{self._device}; '
-                           f'call torch.cuda.set_device(LOCAL_RANK) and create the Tracer on that device')
-      return torch.device('cuda', cur)
+      # the tracer's device (made current in __init__), else the process' current device
+      return torch.device('cuda', int(self._device) if self._device is not None else torch.cuda.current_device())
     return torch.device('cpu')
 
   def sum(self, values):

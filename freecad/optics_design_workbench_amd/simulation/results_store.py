@@ -195,15 +195,27 @@ class SimulationResults:
             if item is None:
               return
             if self._writeError is None:
-              with open(item[0], 'wb') as f:
+              # (written under a temporary name: a reader of the folder -- loadHits of a concurrent
+              #  notebook, an endIf callback -- never meets half a pickle)
+              tmp = item[0] + '.tmp'
+              with open(tmp, 'wb') as f:
                 pickle.dump(item[1], f, protocol=pickle.HIGHEST_PROTOCOL)
-          except BaseException as e:                 # reported by drain()
+              os.replace(tmp, item[0])
+          except BaseException as e:                 # raised by the next flush() / drain()
             self._writeError = e
           finally:
             self._writeQueue.task_done()
       self._writer = threading.Thread(target=work, name='odw-hit-writer', daemon=True)
       self._writer.start()
+    self._raiseWriteError()
     self._writeQueue.put((path, obj))
+
+  def _raiseWriteError(self):
+    """a failed write (disk full, permissions) ends the run at the next flush, not at its end: the files after
+    it would be skipped, and the counters would report hits that are not on disk"""
+    if getattr(self, '_writeError', None) is not None:
+      e, self._writeError = self._writeError, None
+      raise e
 
   def drain(self, stop=False):
     """wait until every file handed to the writer thread is on disk; raises what the writer met.
@@ -214,9 +226,7 @@ class SimulationResults:
         self._writeQueue.put(None)
         self._writer.join()
         self._writer = None
-      if self._writeError is not None:
-        e, self._writeError = self._writeError, None
-        raise e
+      self._raiseWriteError()
 
   def flush(self, wait=True):
     """write buffered hits as `*-hits.pkl` and empty the buffers (results_store.py:405-457).

@@ -39,12 +39,13 @@ def calcFwhm(hits):
   for phi, dens in zip(phis, hists):
     if max(dens) > 0:
       a, b = np.polyfit(np.log(r[dens > 0])[:10], np.log(dens[dens > 0])[:10], deg=1)
+      # (outside the try, as in the notebook: an azimuth bin without a radial bin above 10 -- max() of an
+      #  empty selection -- raises ValueError to the caller; with the notebook's own 1e3 rays that happens)
+      rFit = np.geomspace(min(r), max(r[dens > 10][:10]), 100)
+      fitDens = np.exp(a * np.log(rFit) + b)
       try:
-        # (inside the try: with no bin above 10 hits the notebook's max() of an empty list raises
-        # the ValueError its except clause swallows as well)
-        rFit = np.geomspace(min(r), max(r[dens > 10][:10]), 100)
-        fitDens = np.exp(a * np.log(rFit) + b)
         fwhmList.append(min(rFit[fitDens <= max(dens) / 2]))
+      # the notebook ignores the cases where the FWHM is ill defined (the fit never falls to half the peak)
       except ValueError:
         pass
   return np.mean(fwhmList) if len(fwhmList) else np.nan

@@ -29,13 +29,13 @@ ap.add_argument('--no-bench', action='store_true')
 ap.add_argument('--kernel', default=None, help='substring of the kernel name the counters are taken from')
 args = ap.parse_args()
 tag = args.tag
-KERNEL_NAME = args.kernel or {'c3': 'odw_spec_kernel', 'c4': 'odw_grid_kernel'}[args.config]
+KERNEL_NAME = args.kernel or {'c3': 'odw_spec_kernel', 'c4': 'odw_grid_kernel', 'c5': 'odw_spec_kernel'}[args.config]
 KERNEL_LIKE = '%' + KERNEL_NAME + '%'
 out = os.path.join(ROOT, 'gpurun_out')
 os.makedirs(out, exist_ok=True)
 env = dict(os.environ, TMPDIR='/tmp')
-BENCH = ['python3', os.path.join(ROOT, 'bench.py'), '--config', args.config, '--steps', '3', '--warmup', '1',
-         '--no-cpu-baseline', '--no-end-to-end']
+BENCH = ['python3', os.path.join(ROOT, 'bench.py'), '--config', args.config, '--steps', '1' if args.config == 'c5' else '3', '--warmup', '1',
+         '--no-cpu-baseline', '--no-end-to-end', '--no-extra']
 
 
 def run(cmd, log):
@@ -57,7 +57,7 @@ def tables(con):
 
 # 1. the bench line
 if not args.no_bench:
-  res = subprocess.run(['python3', os.path.join(ROOT, 'bench.py'), '--config', args.config], cwd=ROOT, env=env,
+  res = subprocess.run(['python3', os.path.join(ROOT, 'bench.py'), '--config', args.config, '--no-extra'], cwd=ROOT, env=env,
                        capture_output=True, text=True, check=True)
   line = [l for l in res.stdout.splitlines() if l.startswith('{')][-1]
   open(os.path.join(out, f'{tag}_bench.json'), 'w').write(line + '\n')
@@ -68,8 +68,9 @@ d = os.path.join(out, f'{tag}_trace')
 # (more launches than the counter passes: the first two or three launches of a process run 5 - 15 %
 #  slower -- clocks, first touch -- and the average should be the steady state bench.py reports)
 TRACE_BENCH = [x for x in BENCH]
-TRACE_BENCH[TRACE_BENCH.index('--steps') + 1] = '16'
-TRACE_BENCH[TRACE_BENCH.index('--warmup') + 1] = '4'
+if args.config != 'c5':
+  TRACE_BENCH[TRACE_BENCH.index('--steps') + 1] = '16'
+  TRACE_BENCH[TRACE_BENCH.index('--warmup') + 1] = '4'
 run(['rocprofv3', '--kernel-trace', '--stats', '-d', d, '--'] + TRACE_BENCH, f'{tag}_trace.log')
 con = db_of(d)
 name = [t for t in tables(con) if t.startswith('top_kernels')]
@@ -98,6 +99,8 @@ sets = [['FETCH_SIZE'], ['WRITE_SIZE'], ['SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_I
         ['SQ_BUSY_CYCLES', 'SQ_ACTIVE_INST_ANY', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY'],
         ['SQ_ACTIVE_INST_VALU', 'SQ_THREAD_CYCLES_VALU', 'SQ_INSTS_LDS', 'SQ_ACTIVE_INST_LDS'],
         ['SQ_INSTS_VALU_FMA_F64', 'SQ_INSTS_VALU_MUL_F64', 'SQ_INSTS_VALU_ADD_F64', 'SQ_INSTS_VALU_TRANS_F64'],
+        ['SQ_INSTS_VALU_INT32', 'SQ_INSTS_VALU_INT64', 'SQ_INSTS_VALU_CVT', 'SQ_INSTS_VALU_FMA_F32', 'SQ_INSTS_VALU_ADD_F32',
+         'SQ_INSTS_VALU_MUL_F32'],
         ['GRBM_GUI_ACTIVE', 'SQ_LDS_BANK_CONFLICT', 'SQ_LDS_IDX_ACTIVE', 'SQ_INSTS_VMEM']]
 avg = {}
 for k, cs in enumerate(sets):
@@ -125,7 +128,7 @@ for k, cs in enumerate(sets):
 fetch_raw = avg.get('FETCH_SIZE', 0.0) * 1024          # the counters are in KiB
 write = avg.get('WRITE_SIZE', 0.0) * 1024
 line = json.loads(open(os.path.join(out, f'{tag}_bench.json')).read()) if os.path.exists(os.path.join(out, f'{tag}_bench.json')) else {}
-n_per = line.get('config', {}).get('rays_per_step_per_gpu')
+n_per = line.get('config', {}).get('rays_per_step_per_gpu') or line.get('config', {}).get('rays_per_radius')
 summary = dict(command='rocprofv3 --pmc <COUNTERS> --kernel-trace -- ' + ' '.join(BENCH[:1] + ['bench.py'] + BENCH[2:]) +
                        ' (one counter set per run)',
                kernel=KERNEL_LIKE.strip('%'), rays_per_launch=n_per,
@@ -133,12 +136,11 @@ summary = dict(command='rocprofv3 --pmc <COUNTERS> --kernel-trace -- ' + ' '.joi
                write_bytes=write, hbm_bytes_per_launch=2 * fetch_raw + write, kernel_ms_rocprof=kernel_ms)
 json.dump(summary, open(os.path.join(out, f'{tag}_pmc.json'), 'w'), indent=1)
 ms = kernel_ms or line.get('roofline', {}).get('avg_kernel_ms')
+ROUND = os.environ.get('ODW_PROFILE_ROUND', 'r03')
 valu = None
 if 'SQ_INSTS_VALU' in avg and ms:
   valu = dict(insts_per_launch=avg['SQ_INSTS_VALU'], salu_insts_per_launch=avg.get('SQ_INSTS_SALU'),
-              util=avg['SQ_INSTS_VALU'] * 4 / (1024 * ms * 1e-3 * 2.4e9),
-              definition='SQ_INSTS_VALU (wave-instructions) x 4 issue cycles / (1024 SIMDs x kernel time x 2.4 GHz)',
-              kernel_ms_profiled=ms, source=f'profiles/r02/{tag}_pmc.json, profiles/r02/{tag}_kernel_stats.csv')
+              kernel_ms_profiled=ms, source=f'profiles/{ROUND}/{tag}_pmc.json, profiles/{ROUND}/{tag}_kernel_stats.csv')
   if avg.get('SQ_THREAD_CYCLES_VALU') and avg.get('SQ_ACTIVE_INST_VALU'):
     # lanes doing work per issued VALU instruction (64 = every lane)
     valu['active_lanes_per_inst'] = avg['SQ_THREAD_CYCLES_VALU'] / avg['SQ_ACTIVE_INST_VALU']
@@ -146,15 +148,53 @@ if 'SQ_INSTS_VALU' in avg and ms:
   f64 = [avg.get(k) for k in ('SQ_INSTS_VALU_FMA_F64', 'SQ_INSTS_VALU_MUL_F64', 'SQ_INSTS_VALU_ADD_F64', 'SQ_INSTS_VALU_TRANS_F64')]
   if all(v is not None for v in f64):
     valu['f64_arith_insts'] = sum(f64)
+    # flop per launch: an FMA counts 2, 64 lanes x the active-lane share
+    lanes = valu.get('active_lanes_per_inst', 64.0)
+    valu['fp64_flop_per_launch'] = (2 * f64[0] + f64[1] + f64[2] + f64[3]) * lanes
   if avg.get('SQ_WAIT_ANY') and avg.get('SQ_WAVE_CYCLES'):
     valu['wait_any_frac'] = avg['SQ_WAIT_ANY'] / avg['SQ_WAVE_CYCLES']
-  if avg.get('GRBM_GUI_ACTIVE') and avg.get('SQ_ACTIVE_INST_VALU'):
-    valu['valu_busy'] = avg['SQ_ACTIVE_INST_VALU'] * 4 / 1024 / (avg['GRBM_GUI_ACTIVE'] / 8)
-    valu['valu_busy_definition'] = 'SQ_ACTIVE_INST_VALU x 4 / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs)'
+  if avg.get('SQ_LDS_BANK_CONFLICT') is not None and avg.get('SQ_LDS_IDX_ACTIVE'):
+    valu['lds_bank_conflict_frac'] = avg['SQ_LDS_BANK_CONFLICT'] / avg['SQ_LDS_IDX_ACTIVE']
+  # the calibrated issue floor (profiles/r03/valu_peak.json): dynamic counts by class where the hardware
+  # classifies (f64 fma / mul / add / transcendental, int32, int64, cvt), the rest split like the static
+  # census of the kernel (compares, v_cndmask, moves, min / max)
+  peak_path = os.path.join(ROOT, 'profiles', 'r03', 'valu_peak.json')
+  census_path = os.path.join(ROOT, 'profiles', 'r03', f'{args.config}_census.json')
+  if os.path.exists(peak_path) and all(v is not None for v in f64):
+    cyc = json.load(open(peak_path))['class_cycles']
+    dyn = dict(f64_fma=f64[0], f64_mul=f64[1], f64_add=f64[2], f64_trans=f64[3],
+               int32=avg.get('SQ_INSTS_VALU_INT32', 0.0), mov_b64=avg.get('SQ_INSTS_VALU_INT64', 0.0),
+               cvt=avg.get('SQ_INSTS_VALU_CVT', 0.0),
+               f32=sum(avg.get(k, 0.0) for k in ('SQ_INSTS_VALU_FMA_F32', 'SQ_INSTS_VALU_ADD_F32', 'SQ_INSTS_VALU_MUL_F32')))
+    rest = avg['SQ_INSTS_VALU'] - sum(dyn.values())
+    split = dict(cmp=0.35, cndmask=0.2, f64_minmax=0.08, mov_b32=0.25, mov_b64=0.12)      # (no census: a typical flat kernel)
+    if os.path.exists(census_path):
+      st = json.load(open(census_path))['valu_by_class']
+      keys = ('cmp', 'cndmask', 'f64_minmax', 'mov_b32', 'mov_b64', 'f64_other')
+      # (int64 / mov_b64 of the census: whatever the INT64 counter has not already taken)
+      tot = sum(st.get(k, 0) for k in keys)
+      split = {k: st.get(k, 0) / tot for k in keys}
+    by_class = dict(dyn)
+    for k, f in split.items():
+      by_class[k] = by_class.get(k, 0.0) + rest * f
+    cost = dict(f64_fma=cyc['f64_fma'], f64_mul=cyc['f64_mul'], f64_add=cyc['f64_add'], f64_trans=cyc['f64_trans'],
+                f64_minmax=cyc['f64_minmax'], f64_other=cyc['f64_fma'], cmp=cyc['cmp'], cndmask=cyc['cndmask'],
+                mov_b32=cyc['mov_b32'], mov_b64=cyc['mov_b64'], int32=cyc['int32'], cvt=cyc['f64_fma'], f32=cyc['f32_fma'])
+    floor = sum(by_class[k] * cost[k] for k in by_class)
+    valu['insts_by_class'] = by_class
+    valu['class_cycles'] = cost
+    valu['unclassified_split'] = dict(split, source=(f'static census profiles/r03/{args.config}_census.json' if os.path.exists(census_path)
+                                                      else 'assumed'))
+    valu['issue_cycles_per_launch'] = floor
+    valu['cyc_per_inst_calibrated'] = floor / avg['SQ_INSTS_VALU']
+    valu['definition'] = ('calibrated issue floor: sum over instruction classes of (wave-instructions per launch x cycles one SIMD '
+                          'spends per instruction of that class at 4 waves per SIMD, profiles/r03/valu_peak.json); peak rate for this '
+                          'mix = 1024 SIMDs x 2.4 GHz / cyc_per_inst_calibrated')
+    valu['frac_profiled'] = floor / (1024 * ms * 1e-3 * 2.4e9)
 entry = dict(kernel=KERNEL_LIKE.strip('%'), rays_per_launch=n_per, fetch_bytes_corrected=2 * fetch_raw, write_bytes=write,
              hbm_bytes_per_launch=2 * fetch_raw + write,
              correction='FETCH_SIZE x2 (gfx950 under-count of wide reads, MI355X_MICROARCH.md HBM section; upper bound for '
                         'this access mix), WRITE_SIZE as is; separate --pmc passes',
-             source=f'profiles/r02/{tag}_pmc.json', valu=valu)
+             source=f'profiles/{ROUND}/{tag}_pmc.json', valu=valu)
 json.dump({args.config: entry}, open(os.path.join(out, f'{tag}_pmc_current.json'), 'w'), indent=1)
 print(json.dumps(entry)[:600])

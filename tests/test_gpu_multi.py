@@ -61,19 +61,30 @@ def _port():
     return s.getsockname()[1]
 
 
-def test_rccl_reduce_on_device_buffers(native_lib, tmp_path):
+def _devices():
+  import torch
+  return torch.cuda.device_count()
+
+
+# The tests marked `two_ranks` arm themselves on a box with two or more GPUs (the driver's 8-GPU node): RCCL
+# between two devices over xGMI, with the results of the one-rank job as the reference, bit for bit.
+two_ranks = pytest.mark.skipif(_devices() < 2, reason='needs two GPUs (RCCL between devices); one present')
+
+
+@pytest.mark.parametrize('ranks', [1, pytest.param(2, marks=two_ranks)])
+def test_rccl_reduce_on_device_buffers(native_lib, tmp_path, ranks):
   from freecad.optics_design_workbench_amd import scenes
   from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
   script = tmp_path / 'rccl_worker.py'
   script.write_text(RCCL_WORKER)
   out = tmp_path / 'rank0.npz'
-  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=1',
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={ranks}',
          '--master-addr', '127.0.0.1', '--master-port', str(_port()), str(script), ROOT, str(out)]
   res = subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'), capture_output=True, text=True,
                        timeout=900)
   assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
   got = np.load(out)
-  assert str(got['backend']) == 'nccl' and int(got['world']) == 1
+  assert str(got['backend']) == 'nccl' and int(got['world']) == ranks
   # the same job without torch.distributed
   pr = project('lensesAndMirrors')
   det = scenes.planeDetector(pr.scene, 'OpticalAbsorberGroup', nx=256, ny=256, toward=pr.source.xform[[3, 7, 11]])
@@ -134,9 +145,89 @@ def test_bench_config_lines_c4_and_c5(native_lib):
   out = _line(_bench('--config', 'c4', '--steps', '2', '--warmup', '1', '--rays-per-step', '4e6', '--no-cpu-baseline'))
   assert out['config']['name'] == 'c4' and 'hugeArray' in out['metric'] and out['n_gpus'] == 1
   assert 2.5 < out['config']['segments_per_ray'] < 3.2 and out['roofline']['kernel'].startswith('odw_grid_kernel')
-  assert 0 < out['roofline']['frac'] < 1
+  # (a reduced workload has no committed counter pass: the instruction-issue fraction is not computed for it)
+  assert out['roofline']['bound'] == 'valu_issue' and out['roofline']['frac'] is None
+  assert 0 < out['roofline']['wavefront_equivalent_frac'] < 1
   out = _line(_bench('--config', 'c5', '--radii', '6', '--rays-per-step', '2e5', '--no-cpu-baseline'))
   spot = out['config']['spot_size']
   assert out['config']['name'] == 'c5' and out['scaling'] == 'strong' and len(spot['fwhm_mm']) == 6
   assert all(v is None or v > 0 for v in spot['fwhm_mm']) and any(v is not None for v in spot['fwhm_mm'])
   assert all(v > 0 for v in spot['rms_spot_mm']) and 9 <= spot['best_radius_by_rms_mm'] <= 11
+
+
+@two_ranks
+def test_bench_on_two_gpus_reports_two_gpus(native_lib):
+  """`bench.py --gpus 2` (starts its two ranks itself): n_gpus 2, twice the rays, counters and histogram of the whole
+  job on rank 0 (asserted inside bench.py); c4 alike; c5: the 2-rank table equals the 1-rank table bit for bit"""
+  small = ['--steps', '2', '--warmup', '1', '--rays-per-step', '4e6', '--no-cpu-baseline', '--no-end-to-end']
+  one = _line(_bench('--gpus', '1', *small))
+  two = _line(_bench('--gpus', '2', *small))
+  assert two['n_gpus'] == 2 and one['n_gpus'] == 1 and two['config']['parallelism'].startswith('ray-index sharding x2')
+  assert two['config']['segments_per_ray'] == pytest.approx(one['config']['segments_per_ray'], rel=1e-3)
+  assert two['value'] > 1.2 * one['value'] * 0.5          # (no scaling claim here: the driver measures that)
+  c4 = _line(_bench('--gpus', '2', '--config', 'c4', *small[:6], '--no-cpu-baseline'))
+  assert c4['n_gpus'] == 2 and c4['config']['name'] == 'c4'
+  args = ['--config', 'c5', '--radii', '6', '--rays-per-step', '2e5', '--no-cpu-baseline']
+  t1 = _line(_bench('--gpus', '1', *args))['config']['spot_size']
+  t2 = _line(_bench('--gpus', '2', *args))
+  assert t2['n_gpus'] == 2 and t2['scaling'] == 'strong'
+  assert t2['config']['spot_size']['fwhm_mm'] == t1['fwhm_mm']
+  assert t2['config']['spot_size']['rms_spot_mm'] == t1['rms_spot_mm']
+
+
+RUN_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], 'tests'))
+import numpy as np, torch, torch.distributed as dist
+from freecad.optics_design_workbench_amd.scene import open_fcstd
+from freecad.optics_design_workbench_amd.simulation import runSimulation, resultsFolderPath
+local = int(os.environ['LOCAL_RANK'])
+# (deliberately no torch.cuda.set_device: runSimulation(device=LOCAL_RANK) alone must put every collective on
+#  the tracer's device -- parallel.Ranks settles that before any GPU work, on every rank alike)
+dist.init_process_group('nccl')
+doc = open_fcstd(sys.argv[2])
+st = doc.OpticalSimulationSettings
+st.EndAfterRays, st.EndAfterHits = 'inf', '150000'
+st.StoreHitInitPhi = True
+store = runSimulation(doc, 'true', seed=42, resultsPath=resultsFolderPath(sys.argv[2]), raysPerLaunch=70000, device=local)
+assert store.totalRecordedHits > 150000, store.totalRecordedHits     # the job's total, on every rank
+loc = len(store.hits())
+total = torch.tensor([loc], device=torch.device('cuda', local)); dist.all_reduce(total)
+assert int(total) == store.totalRecordedHits and 0 < loc < store.totalRecordedHits
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+@two_ranks
+def test_two_rank_run_simulation_on_two_gpus(native_lib, tmp_path):
+  """runSimulation under a 2-rank launcher on two GPUs (simulation_loop.py:386-396, 450-507: the workers of the
+  reference): launches sharded by ray index, both ranks write into ONE run folder, three int64 totals per launch
+  all-reduced over RCCL; the merged folder holds the single-process rows, row for row"""
+  import shutil
+  from conftest import SCENES
+  from freecad.optics_design_workbench_amd.scene import open_fcstd
+  from freecad.optics_design_workbench_amd.simulation import rawFolders, resultsFolderPath, runSimulation
+  path = str(tmp_path / 'GettingStarted.FCStd')
+  shutil.copy(os.path.join(SCENES, 'GettingStarted.FCStd'), path)
+  script = tmp_path / 'run_worker.py'
+  script.write_text(RUN_WORKER)
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
+         '--master-addr', '127.0.0.1', '--master-port', str(_port()), str(script), ROOT, path]
+  res = subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'), capture_output=True, text=True, timeout=900)
+  assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
+  folders = rawFolders(resultsFolderPath(path))
+  assert len(folders) == 1
+  merged = folders[0].loadHits('*').hits
+  doc = open_fcstd(path)
+  st = doc.OpticalSimulationSettings
+  st.EndAfterRays, st.EndAfterHits = 'inf', '150000'
+  st.StoreHitInitPhi = True
+  single = runSimulation(doc, 'true', seed=42, raysPerLaunch=70000, device=0).hits().hits
+
+  def rows(h):
+    a = np.concatenate([h['points'], h['directions'], h['powers'][:, None], h['initPhi'][:, None]], axis=1)
+    return a[np.lexsort(a.T[::-1])]
+
+  assert len(merged['points']) == len(single['points']) > 150000
+  assert np.array_equal(rows(merged), rows(single))

@@ -376,3 +376,34 @@ def test_writer_thread_ends_with_the_run(tmp_path):
   store.drain(stop=True)
   assert threading.active_count() == before
   assert len(rs.latestRawFolder(res).loadHits('*')) == 200
+
+
+def test_a_failed_write_ends_the_run_at_the_next_flush(tmp_path, monkeypatch):
+  """the writer thread meets an error (disk full, permissions): the flush after it raises -- the run loop's
+  `flush(wait=False)` included --, not only the drain at the end of the run; no half-written file is left
+  under a name readers look for"""
+  from freecad.optics_design_workbench_amd.simulation import results_store as rs
+  res = rs.resultsFolderPath(str(tmp_path / 'proj.FCStd'))
+  store = rs.SimulationResults('true', resultsPath=res)
+  real_dump = pickle.dump
+  state = dict(fail=True)
+
+  def dump(obj, f, **kw):
+    if state['fail'] and getattr(f, 'name', '').endswith('-hits.pkl.tmp'):
+      f.write(b'half a pickle')
+      raise OSError(28, 'No space left on device')
+    return real_dump(obj, f, **kw)
+  monkeypatch.setattr(rs.pickle, 'dump', dump)
+  _fill(store, 10, 0)
+  store.flush(wait=False)                      # handed to the writer, which fails
+  store._writeQueue.join()
+  _fill(store, 10, 1)
+  with pytest.raises(OSError):
+    store.flush(wait=False)                    # the run loop learns of it here
+  folder = os.path.join(store.runFolderPath(), 'source-src', 'object-OpticalAbsorberGroup')
+  assert not [f for f in os.listdir(folder) if f.endswith('-hits.pkl')]
+  state['fail'] = False
+  _fill(store, 10, 2)
+  store.flush()
+  store.drain(stop=True)
+  assert len([f for f in os.listdir(folder) if f.endswith('-hits.pkl')]) == 1

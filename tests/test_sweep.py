@@ -40,6 +40,24 @@ def test_calc_fwhm_of_nothing_is_nan():
   assert np.isnan(sweep.calcFwhm(h)) or sweep.calcFwhm(h) > 0
 
 
+def test_calc_fwhm_raises_where_the_notebook_raises():
+  """cell 8 computes rFit = geomspace(min(r), max(r[dens > 10][:10]), 100) BEFORE its try: an azimuth bin that
+  received hits but holds no radial bin above 10 counts makes max() of an empty selection raise ValueError --
+  to the caller, not into the except clause (which only covers the half-maximum search)"""
+  rs = np.random.RandomState(5)
+  n = 41
+  # a thin ring (densities are counts per bin AREA: only the wide outer bins stay below 10 per mm^2 with a hit
+  # in them) around one central hit that fixes the median origin
+  rad, ang = rs.uniform(3.0, 4.8, n - 1), np.linspace(0, 2 * np.pi, n - 1, endpoint=False)
+  yz = np.concatenate([np.stack([rad * np.cos(ang), rad * np.sin(ang)], axis=1), [[0.0, 0.0]]])
+  P = np.concatenate([np.full((n, 1), -41.0), yz], axis=1)
+  h = Hits(dict(points=P, directions=np.tile([-1.0, 0, 0], (n, 1)), powers=np.ones(n), isEntering=np.ones(n, dtype=int)))
+  H = h.histogram(binCoords='polar', bins=[np.arange(0, 2 * np.pi, np.pi / 2), np.geomspace(1e-3, 5, 500)])
+  assert 0 < H.hist.max() <= 10
+  with pytest.raises(ValueError):
+    sweep.calcFwhm(h)
+
+
 def test_share_of_rank_is_a_partition():
   for n in (0, 1, 7, 64):
     for world in (1, 2, 3, 8):
