@@ -92,7 +92,9 @@ struct odw_ctx {
   DevBuf ray_o, ray_d, ray_p, samp_t, samp_phi;
   DevBuf sort_keys[2], sort_vals[2], sort_tmp, sorted_rows;
   // post-hoc binning of the rows in HBM (odw_posthoc.hip): the selection = sort_vals[1][0 .. ph_n)
-  DevBuf ph_sel_entering, ph_flags, ph_x, ph_y, ph_sorted, ph_small, ph_part, ph_edges, ph_edges_b, ph_counts;
+  DevBuf ph_sel_entering, ph_flags, ph_x, ph_y, ph_sorted, ph_small, ph_part, ph_edges, ph_edges_b, ph_counts, ph_sel_hist;
+  uint64_t alt_hit_ray_end = 0;    // the same for the list odw_swap_hit_lists has put aside
+  uint64_t hit_ray_end = 0;        // ray indices of the rows in the hit list lie below this (0: list empty; 1 << 48: unknown)
   uint64_t ph_n = 0, ph_n_entering = 0;
   int ph_group = -1;
   bool ph_valid = false, ph_projected = false, ph_entering_built = false;
@@ -671,12 +673,12 @@ int build_bvh(odw_ctx* ctx) {
 }
 
 // ---- device-side ordering of the hit list (odw_fetch_hits) -----------------
-__global__ void hit_keys_kernel(const odw_hit* __restrict__ hits, uint64_t n, uint64_t* __restrict__ keys,
+__global__ void hit_keys_kernel(const odw_hit* __restrict__ hits, uint64_t n, uint64_t sentinel, uint64_t* __restrict__ keys,
                                 uint32_t* __restrict__ vals) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
     const uint64_t tag = hits[i].tag;
-    keys[i] = tag == ODW_TAG_UNUSED ? (1ull << 48) : ODW_HIT_RAY(tag);   // unused slots sort behind every ray
+    keys[i] = tag == ODW_TAG_UNUSED ? sentinel : ODW_HIT_RAY(tag);   // unused slots sort behind every ray
     vals[i] = (uint32_t)i;
   }
 }
@@ -714,6 +716,7 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
   if (!explicit_rays && !ctx->have_source) return fail(ctx, ODW_ERR_NO_SCENE, "source not uploaded");
   if (n == 0) return ODW_OK;
   ctx->ph_valid = false;           // the hit list is about to change
+  ctx->hit_ray_end = std::max<uint64_t>(ctx->hit_ray_end, std::min<uint64_t>(first + n, 1ull << 48));
   if (ctx->bvh_dirty) {
     int rc = build_bvh(ctx);
     if (rc) return rc;
@@ -927,7 +930,7 @@ void odw_destroy(odw_ctx* ctx) {
   release(ctx->d_group_sampler);
   for (DevBuf* b : {&ctx->grid_bounds, &ctx->grid_cells, &ctx->grid_items}) release(*b);
   for (DevBuf* b : {&ctx->ph_sel_entering, &ctx->ph_flags, &ctx->ph_x, &ctx->ph_y, &ctx->ph_sorted, &ctx->ph_small,
-                    &ctx->ph_part, &ctx->ph_edges, &ctx->ph_edges_b, &ctx->ph_counts})
+                    &ctx->ph_part, &ctx->ph_edges, &ctx->ph_edges_b, &ctx->ph_counts, &ctx->ph_sel_hist})
     release(*b);
   release(ctx->alt_hits);
   release(ctx->alt_hit_count);
@@ -1550,6 +1553,7 @@ int odw_reset_results(odw_ctx* ctx) {
   if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_reset_results: null ctx");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   ctx->ph_valid = false;
+  ctx->hit_ray_end = 0;
   HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, ODW_CNT_COUNT * sizeof(uint64_t), ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(ctx->hit_count.p, 0, 2 * sizeof(uint64_t), ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(ctx->seg_count.p, 0, sizeof(uint64_t), ctx->stream));
@@ -1567,6 +1571,7 @@ int odw_reset_segments(odw_ctx* ctx) {
 int odw_reset_hits(odw_ctx* ctx) {
   if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_reset_hits: null ctx");
   ctx->ph_valid = false;
+  ctx->hit_ray_end = 0;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipMemsetAsync(ctx->hit_count.p, 0, 2 * sizeof(uint64_t), ctx->stream));
   return ODW_OK;
@@ -1625,15 +1630,18 @@ int odw_fetch_hits(odw_ctx* ctx, odw_hit* out, uint64_t capacity, uint64_t* n) {
     uint32_t* v_in = (uint32_t*)ctx->sort_vals[0].p;
     uint32_t* v_out = (uint32_t*)ctx->sort_vals[1].p;
     const unsigned blocks = (unsigned)((used + 255) / 256);
+    // (only the bits ray indices of this list can have, + 1 for the sentinel: see odw_hits_select)
+    int bits = 48;
+    if (ctx->hit_ray_end && ctx->hit_ray_end < (1ull << 48)) { bits = 1; while ((1ull << bits) < ctx->hit_ray_end) ++bits; }
     hipLaunchKernelGGL(hit_keys_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const odw_hit*)ctx->hits.p,
-                       used, k_in, v_in);
+                       used, 1ull << bits, k_in, v_in);
     HIPCHK(ctx, hipGetLastError());
     size_t tmp_bytes = 0;
-    HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k_in, k_out, v_in, v_out, (int)used, 0, 49,
+    HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k_in, k_out, v_in, v_out, (int)used, 0, bits + 1,
                                                    ctx->stream));
     if ((rc = ensure(ctx, ctx->sort_tmp, tmp_bytes))) return rc;
     HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(ctx->sort_tmp.p, tmp_bytes, k_in, k_out, v_in, v_out, (int)used,
-                                                   0, 49, ctx->stream));
+                                                   0, bits + 1, ctx->stream));
     const unsigned gblocks = (unsigned)((have * 4 + 255) / 256);
     hipLaunchKernelGGL(hit_gather_kernel, dim3(gblocks), dim3(256), 0, ctx->stream, (const odw_hit*)ctx->hits.p,
                        v_out, have, (odw_hit*)ctx->sorted_rows.p);
@@ -1667,6 +1675,7 @@ int odw_swap_hit_lists(odw_ctx* ctx) {
   std::swap(ctx->hit_count, ctx->alt_hit_count);
   std::swap(ctx->hit_capacity, ctx->alt_capacity);
   std::swap(ctx->hit_slots, ctx->alt_slots);
+  std::swap(ctx->hit_ray_end, ctx->alt_hit_ray_end);
   ctx->swapping = true;
   return ODW_OK;
 }

@@ -18,21 +18,31 @@ namespace {
 constexpr int kPhLdsBins = 8192;
 constexpr int kPhLdsEdges = 2048;
 
-__global__ void ph_keys_kernel(const odw_hit* __restrict__ hits, uint64_t n, int group, uint64_t* __restrict__ keys,
-                               uint32_t* __restrict__ vals, unsigned long long* __restrict__ counts) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  bool sel = false, leaving = false;
-  if (i < n) {
+// key = ray index of a selected row, `sentinel` (above every ray index of the list) for everything else;
+// counts[0] += selected rows, counts[1] += those that leave.  Grid-stride, one pair of atomics per block: one
+// pair per wave serialised 3e5 memory-side atomics of a 1e7-row list on two addresses (1.9 ms; now 0.1).
+__global__ __launch_bounds__(256) void ph_keys_kernel(const odw_hit* __restrict__ hits, uint64_t n, int group, uint64_t sentinel,
+                                                      uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                      unsigned long long* __restrict__ counts) {
+  uint32_t n_sel = 0, n_leave = 0;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const uint64_t tag = hits[i].tag;
-    sel = tag != ODW_TAG_UNUSED && (group < 0 || (int)ODW_HIT_GROUP(tag) == group);
-    leaving = sel && !ODW_HIT_ENTERING(tag);
-    keys[i] = sel ? ODW_HIT_RAY(tag) : (1ull << 48);     // everything else sorts behind every ray
+    const bool sel = tag != ODW_TAG_UNUSED && (group < 0 || (int)ODW_HIT_GROUP(tag) == group);
+    n_sel += sel ? 1u : 0u;
+    n_leave += (sel && !ODW_HIT_ENTERING(tag)) ? 1u : 0u;
+    keys[i] = sel ? ODW_HIT_RAY(tag) : sentinel;         // everything else sorts behind every ray
     vals[i] = (uint32_t)i;
   }
-  const unsigned long long bs = __ballot(sel), bl = __ballot(leaving);
-  if ((threadIdx.x & 63) == 0) {
-    if (bs) atomicAdd(counts, (unsigned long long)__popcll(bs));
-    if (bl) atomicAdd(counts + 1, (unsigned long long)__popcll(bl));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { n_sel += __shfl_xor(n_sel, off); n_leave += __shfl_xor(n_leave, off); }
+  __shared__ uint32_t s[4][2];
+  if ((threadIdx.x & 63) == 0) { s[threadIdx.x >> 6][0] = n_sel; s[threadIdx.x >> 6][1] = n_leave; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t a = s[0][0] + s[1][0] + s[2][0] + s[3][0], b = s[0][1] + s[1][1] + s[2][1] + s[3][1];
+    if (a) atomicAdd(counts, (unsigned long long)a);
+    if (b) atomicAdd(counts + 1, (unsigned long long)b);
   }
 }
 
@@ -68,17 +78,121 @@ __global__ void ph_columns_kernel(const odw_hit* __restrict__ hits, const uint32
   if (ray) ray[j] = (long long)ODW_HIT_RAY(h.tag);
 }
 
-// numpy.dot(points, axis): three products, summed left to right, no contraction
-__global__ void ph_project_kernel(const odw_hit* __restrict__ hits, const uint32_t* __restrict__ sel, uint64_t m, int key,
-                                  double ex0, double ex1, double ex2, double ey0, double ey1, double ey2,
-                                  double* __restrict__ X, double* __restrict__ Y) {
+// numpy.dot(points, axis): three products, summed left to right, no contraction; per block the extrema of
+// both coordinates (part[4 b ..]: min X, max X, min Y, max Y)
+__global__ __launch_bounds__(256) void ph_project_kernel(const odw_hit* __restrict__ hits, const uint32_t* __restrict__ sel,
+                                                         uint64_t m, int key, double ex0, double ex1, double ex2, double ey0,
+                                                         double ey1, double ey2, double* __restrict__ X,
+                                                         double* __restrict__ Y, double* __restrict__ part) {
 #pragma clang fp contract(off)
-  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j < m) {
+  double lo_x = INFINITY, hi_x = -INFINITY, lo_y = INFINITY, hi_y = -INFINITY;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
     const double* p = key ? hits[sel[j]].direction : hits[sel[j]].point;
     const double a = p[0], b = p[1], c = p[2];
-    X[j] = a * ex0 + b * ex1 + c * ex2;
-    Y[j] = a * ey0 + b * ey1 + c * ey2;
+    const double x = a * ex0 + b * ex1 + c * ex2, y = a * ey0 + b * ey1 + c * ey2;
+    X[j] = x;
+    Y[j] = y;
+    lo_x = fmin(lo_x, x); hi_x = fmax(hi_x, x);
+    lo_y = fmin(lo_y, y); hi_y = fmax(hi_y, y);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    lo_x = fmin(lo_x, __shfl_xor(lo_x, off)); hi_x = fmax(hi_x, __shfl_xor(hi_x, off));
+    lo_y = fmin(lo_y, __shfl_xor(lo_y, off)); hi_y = fmax(hi_y, __shfl_xor(hi_y, off));
+  }
+  __shared__ double s[4][4];
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { s[w][0] = lo_x; s[w][1] = hi_x; s[w][2] = lo_y; s[w][3] = hi_y; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 4; ++k) {
+      s[0][0] = fmin(s[0][0], s[k][0]); s[0][1] = fmax(s[0][1], s[k][1]);
+      s[0][2] = fmin(s[0][2], s[k][2]); s[0][3] = fmax(s[0][3], s[k][3]);
+    }
+    for (int k = 0; k < 4; ++k) part[4 * blockIdx.x + k] = s[0][k];
+  }
+}
+
+// Medians by selection instead of two full radix sorts (numpy.median needs the one or two middle elements only):
+// a histogram of kPhSelBins equal bins over [lo, hi] per coordinate -> the host finds the bins that hold the middle
+// ranks -> a second histogram of the elements of those bins, kPhSelBins times finer -> the elements of the fine
+// bins that hold the ranks are collected and the host picks the ranks among them.  The bin of a value is a
+// monotone function of it, so every element of a lower bin is <= every element of a higher one: exact.
+// Counting happens in LDS (a focused spot piles 1e7 values into a few hundred bins: global atomics on them
+// took 1.8 ms), every block writes its counts to a slice of its own, a second kernel adds the slices.
+constexpr int kPhSelBins = 4096;
+constexpr int kPhSelBlocks = 512;
+struct PhSel {
+  double lo[2], sc[2];        // coarse bins of X, Y
+  uint32_t c_lo[2], c_hi[2];  // pass 2 / collect: only elements whose coarse bin lies in [c_lo, c_hi]
+  double flo[2], fsc[2];      // fine bins of those elements
+  uint32_t f0[2], f1[2];      // collect: fine bins wanted
+  int fine;                   // 0: first pass
+};
+__device__ __forceinline__ uint32_t ph_sel_bin(double v, double lo, double scale) {
+  const double f = (v - lo) * scale;                       // (NaN: bin 0 -- NaN coordinates do not occur in hit rows)
+  return f >= (double)(kPhSelBins - 1) ? (uint32_t)(kPhSelBins - 1) : (f > 0 ? (uint32_t)f : 0u);
+}
+__global__ __launch_bounds__(512) void ph_sel_hist_kernel(const double* __restrict__ X, const double* __restrict__ Y, uint64_t m,
+                                                          const PhSel P, uint32_t* __restrict__ slices) {
+  __shared__ uint32_t h[2 * kPhSelBins];
+  for (int k = threadIdx.x; k < 2 * kPhSelBins; k += blockDim.x) h[k] = 0;
+  __syncthreads();
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
+    const double v[2] = {X[j], Y[j]};
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const uint32_t c = ph_sel_bin(v[a], P.lo[a], P.sc[a]);
+      if (!P.fine) atomicAdd(&h[a * kPhSelBins + c], 1u);
+      else if (c >= P.c_lo[a] && c <= P.c_hi[a]) atomicAdd(&h[a * kPhSelBins + ph_sel_bin(v[a], P.flo[a], P.fsc[a])], 1u);
+    }
+  }
+  __syncthreads();
+  uint32_t* out = slices + (size_t)blockIdx.x * 2 * kPhSelBins;
+  for (int k = threadIdx.x; k < 2 * kPhSelBins; k += blockDim.x) out[k] = h[k];
+}
+__global__ __launch_bounds__(256) void ph_sel_sum_kernel(const uint32_t* __restrict__ slices, int n_slices, uint32_t* __restrict__ hist) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < 2 * kPhSelBins) {
+    uint32_t s = 0;
+    for (int b = 0; b < n_slices; ++b) s += slices[(size_t)b * 2 * kPhSelBins + k];
+    hist[k] = s;
+  }
+}
+// elements of X / Y whose coarse bin lies in [c_lo, c_hi] and whose fine bin is f0 or f1, appended to out
+// (X: from 0, Y: from off_y); one atomic per wave and coordinate
+__global__ __launch_bounds__(256) void ph_sel_collect_kernel(const double* __restrict__ X, const double* __restrict__ Y, uint64_t m,
+                                                             const PhSel P, double* __restrict__ out, uint64_t off_y,
+                                                             unsigned long long* __restrict__ n_out) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint64_t rounds = (m + stride - 1) / stride;
+  const int lane = __lane_id();
+  for (uint64_t r = 0; r < rounds; ++r) {
+    const uint64_t j = r * stride + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const double v[2] = {j < m ? X[j] : 0.0, j < m ? Y[j] : 0.0};
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      bool want = false;
+      if (j < m) {
+        const uint32_t c = ph_sel_bin(v[a], P.lo[a], P.sc[a]);
+        if (c >= P.c_lo[a] && c <= P.c_hi[a]) {
+          const uint32_t f = ph_sel_bin(v[a], P.flo[a], P.fsc[a]);
+          want = f == P.f0[a] || f == P.f1[a];
+        }
+      }
+      const unsigned long long b = __ballot(want);
+      if (b) {
+        // (every lane of the wave is here -- the loop bounds are wave-uniform --: lane 0 reserves, readfirstlane
+        //  reads lane 0)
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(n_out + a, (unsigned long long)__popcll(b));
+        base = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) |
+               (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)base);
+        if (want) out[(a ? off_y : 0) + base + __popcll(b & ((1ull << lane) - 1ull))] = v[a];
+      }
+    }
   }
 }
 
@@ -211,7 +325,7 @@ int ph_need_projection(odw_ctx* ctx, const char* who) {
   return ODW_OK;
 }
 
-// sorted copy of v[0..m) -> the two middle values and the extrema
+// sorted copy of v[0..m) -> the two middle values and the extrema (the fallback of ph_select_stats)
 int ph_sorted_stats(odw_ctx* ctx, const double* v, uint64_t m, double out[4]) {
   int rc;
   if ((rc = ensure(ctx, ctx->ph_sorted, m * sizeof(double)))) return rc;
@@ -228,6 +342,109 @@ int ph_sorted_stats(odw_ctx* ctx, const double* v, uint64_t m, double out[4]) {
   return ODW_OK;
 }
 
+// The two middle elements (numpy.median) of X and of Y, given their extrema: two histogram passes, the elements of
+// the fine bins that hold the middle ranks, the ranks among them.  stats = {x mid lo, x mid hi, min x, max x, y ...}.
+// A coordinate whose fine bins still hold more than kPhSelMax elements (a cloud piled up on one value) takes the sort.
+constexpr uint64_t kPhSelMax = 1u << 21;
+// bins that hold ranks k_lo <= k_hi in a histogram: bin[2], elements below each
+static bool ph_rank_bins(const uint32_t* h, uint64_t k_lo, uint64_t k_hi, uint32_t bin[2], uint64_t below[2]) {
+  uint64_t run = 0;
+  int found = 0;
+  for (int b = 0; b < kPhSelBins && found < 2; ++b) {
+    const uint64_t next = run + h[b];
+    while (found < 2 && (found == 0 ? k_lo : k_hi) < next) { bin[found] = (uint32_t)b; below[found] = run; ++found; }
+    run = next;
+  }
+  return found == 2;
+}
+int ph_select_stats(odw_ctx* ctx, uint64_t m, const double ext[4], double stats[8]) {
+  int rc;
+  const double* X = (const double*)ctx->ph_x.p;
+  const double* Y = (const double*)ctx->ph_y.p;
+  stats[2] = ext[0]; stats[3] = ext[1]; stats[6] = ext[2]; stats[7] = ext[3];
+  const uint64_t k_lo = (m - 1) / 2, k_hi = m / 2;
+  PhSel P;
+  std::memset(&P, 0, sizeof P);
+  double width[2];
+  for (int a = 0; a < 2; ++a) {
+    P.lo[a] = ext[2 * a];
+    width[a] = ext[2 * a + 1] - ext[2 * a];
+    P.sc[a] = (width[a] > 0 && width[a] < INFINITY) ? (double)kPhSelBins / width[a] : 0.0;
+  }
+  const size_t slice_bytes = (size_t)kPhSelBlocks * 2 * kPhSelBins * sizeof(uint32_t);
+  const size_t hist_bytes = 2 * (size_t)kPhSelBins * sizeof(uint32_t);
+  if ((rc = ensure(ctx, ctx->ph_sel_hist, slice_bytes + hist_bytes + 64))) return rc;
+  uint32_t* slices = (uint32_t*)ctx->ph_sel_hist.p;
+  uint32_t* d_hist = (uint32_t*)((char*)ctx->ph_sel_hist.p + slice_bytes);
+  unsigned long long* d_count = (unsigned long long*)((char*)ctx->ph_sel_hist.p + slice_bytes + hist_bytes);
+  const unsigned hgrid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((m + 511) / 512, (uint64_t)kPhSelBlocks));
+  std::vector<uint32_t> hist(2 * (size_t)kPhSelBins);
+  auto histogram = [&]() -> int {
+    hipLaunchKernelGGL(ph_sel_hist_kernel, dim3(hgrid), dim3(512), 0, ctx->stream, X, Y, m, P, slices);
+    hipLaunchKernelGGL(ph_sel_sum_kernel, dim3((2 * kPhSelBins + 255) / 256), dim3(256), 0, ctx->stream, (const uint32_t*)slices,
+                       (int)hgrid, d_hist);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(hist.data(), d_hist, hist_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return ODW_OK;
+  };
+  if ((rc = histogram())) return rc;
+  uint32_t cbin[2][2], fbin[2][2];
+  uint64_t cbelow[2][2], fbelow[2][2], take[2] = {0, 0};
+  bool by_sort[2] = {false, false};
+  for (int a = 0; a < 2; ++a) {
+    if (!ph_rank_bins(hist.data() + (size_t)a * kPhSelBins, k_lo, k_hi, cbin[a], cbelow[a]))
+      return fail(ctx, ODW_ERR_DEVICE, "odw_hits_project: histogram of the projection does not add up");
+    P.c_lo[a] = cbin[a][0]; P.c_hi[a] = cbin[a][1];
+    // fine bins over the value range of the coarse bins [c_lo, c_hi]
+    const double w = width[a] / (double)kPhSelBins;
+    P.flo[a] = P.lo[a] + (double)P.c_lo[a] * w;
+    const double fw = (double)(P.c_hi[a] - P.c_lo[a] + 1) * w;
+    P.fsc[a] = (fw > 0 && fw < INFINITY) ? (double)kPhSelBins / fw : 0.0;
+  }
+  P.fine = 1;
+  if ((rc = histogram())) return rc;
+  for (int a = 0; a < 2; ++a) {
+    // ranks among the elements of the coarse bins [c_lo, c_hi]: everything below c_lo lies below
+    if (!ph_rank_bins(hist.data() + (size_t)a * kPhSelBins, k_lo - cbelow[a][0], k_hi - cbelow[a][0], fbin[a], fbelow[a]))
+      return fail(ctx, ODW_ERR_DEVICE, "odw_hits_project: second histogram of the projection does not add up");
+    P.f0[a] = fbin[a][0]; P.f1[a] = fbin[a][1];
+    const uint32_t* h = hist.data() + (size_t)a * kPhSelBins;
+    take[a] = h[fbin[a][0]] + (fbin[a][1] != fbin[a][0] ? h[fbin[a][1]] : 0u);
+    by_sort[a] = take[a] > kPhSelMax;
+    if (by_sort[a]) { P.c_lo[a] = 1; P.c_hi[a] = 0; }       // (collects nothing)
+  }
+  const uint64_t off_y = by_sort[0] ? 0 : take[0];
+  const uint64_t n_out = (by_sort[0] ? 0 : take[0]) + (by_sort[1] ? 0 : take[1]);
+  std::vector<double> cand(n_out);
+  if (n_out) {
+    if ((rc = ensure(ctx, ctx->ph_sorted, n_out * sizeof(double)))) return rc;
+    HIPCHK(ctx, hipMemsetAsync(d_count, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((m + 255) / 256, (uint64_t)ctx->n_cu * 8));
+    hipLaunchKernelGGL(ph_sel_collect_kernel, dim3(grid), dim3(256), 0, ctx->stream, X, Y, m, P, (double*)ctx->ph_sorted.p, off_y,
+                       d_count);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(cand.data(), ctx->ph_sorted.p, n_out * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  for (int a = 0; a < 2; ++a) {
+    if (by_sort[a]) {
+      double four[4];
+      if ((rc = ph_sorted_stats(ctx, a ? Y : X, m, four))) return rc;
+      stats[4 * a] = four[0]; stats[4 * a + 1] = four[1];
+      continue;
+    }
+    double* c = cand.data() + (a ? off_y : 0);
+    std::sort(c, c + take[a]);
+    // the collected elements are those of fine bin f0 (and, if different, f1), in value order after the sort
+    const uint64_t r_lo = k_lo - cbelow[a][0], r_hi = k_hi - cbelow[a][0];
+    const uint64_t n0 = hist[(size_t)a * kPhSelBins + fbin[a][0]];
+    stats[4 * a] = c[r_lo - fbelow[a][0]];
+    stats[4 * a + 1] = fbin[a][1] == fbin[a][0] ? c[r_hi - fbelow[a][0]] : c[n0 + (r_hi - fbelow[a][1])];
+  }
+  return ODW_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -237,6 +454,7 @@ int odw_load_hits(odw_ctx* ctx, const odw_hit* rows, uint64_t n) {
   int rc = odw_reserve_hits(ctx, std::max<uint64_t>(n, 16));
   if (rc) return rc;
   ctx->ph_valid = false;
+  ctx->hit_ray_end = 1ull << 48;     // rows of unknown origin: every bit of the ray index counts
   if (n) HIPCHK(ctx, hipMemcpyAsync(ctx->hits.p, rows, n * sizeof(odw_hit), hipMemcpyHostToDevice, ctx->stream));
   const uint64_t count[2] = {n, 0};
   HIPCHK(ctx, hipMemcpyAsync(ctx->hit_count.p, count, sizeof count, hipMemcpyHostToDevice, ctx->stream));
@@ -265,15 +483,21 @@ int odw_hits_select(odw_ctx* ctx, int32_t group, uint64_t* n_rows, uint64_t* n_l
     uint64_t* k_out = (uint64_t*)ctx->sort_keys[1].p;
     uint32_t* v_in = (uint32_t*)ctx->sort_vals[0].p;
     uint32_t* v_out = (uint32_t*)ctx->sort_vals[1].p;
-    hipLaunchKernelGGL(ph_keys_kernel, dim3((unsigned)((used + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (const odw_hit*)ctx->hits.p, used, (int)group, k_in, v_in, (unsigned long long*)ctx->ph_small.p);
+    // ray indices of the list lie below hit_ray_end (launch_trace keeps it): the sort needs their bits only, plus
+    // one for the sentinel of the rows that are not selected (1e7 rays: 25 bits = 4 passes instead of 7)
+    int bits = 48;
+    if (ctx->hit_ray_end && ctx->hit_ray_end < (1ull << 48)) { bits = 1; while ((1ull << bits) < ctx->hit_ray_end) ++bits; }
+    const uint64_t sentinel = 1ull << bits;
+    const unsigned kgrid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((used + 255) / 256, (uint64_t)ctx->n_cu * 8));
+    hipLaunchKernelGGL(ph_keys_kernel, dim3(kgrid), dim3(256), 0, ctx->stream, (const odw_hit*)ctx->hits.p, used, (int)group,
+                       sentinel, k_in, v_in, (unsigned long long*)ctx->ph_small.p);
     HIPCHK(ctx, hipGetLastError());
     size_t tmp_bytes = 0;
-    HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k_in, k_out, v_in, v_out, (int)used, 0, 49,
+    HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k_in, k_out, v_in, v_out, (int)used, 0, bits + 1,
                                                    ctx->stream));
     if ((rc = ensure(ctx, ctx->sort_tmp, tmp_bytes))) return rc;
     HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(ctx->sort_tmp.p, tmp_bytes, k_in, k_out, v_in, v_out, (int)used, 0,
-                                                   49, ctx->stream));
+                                                   bits + 1, ctx->stream));
     uint64_t c[2] = {0, 0};
     HIPCHK(ctx, hipMemcpyAsync(c, ctx->ph_small.p, sizeof c, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -326,7 +550,9 @@ int odw_hits_gather(odw_ctx* ctx, int32_t entering_only, uint64_t stride, odw_hi
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const uint32_t* sel = (const uint32_t*)ctx->sort_vals[1].p;
   uint64_t m = ctx->ph_n;
-  if (entering_only) {
+  if (entering_only && ctx->ph_n_entering == ctx->ph_n) {
+    // (every selected row enters -- an absorbing detector: the list is the selection itself)
+  } else if (entering_only) {
     // rows with isEntering != 0, still in (ray, bounce) order: flags + stream compaction
     if (!ctx->ph_entering_built && m) {
       if ((rc = ensure(ctx, ctx->ph_flags, m))) return rc;
@@ -370,12 +596,21 @@ int odw_hits_project(odw_ctx* ctx, int32_t key, const double* ex, const double* 
   if (m == 0) return fail(ctx, ODW_ERR_INVALID, "odw_hits_project: no rows selected");
   if ((rc = ensure(ctx, ctx->ph_x, m * sizeof(double)))) return rc;
   if ((rc = ensure(ctx, ctx->ph_y, m * sizeof(double)))) return rc;
-  hipLaunchKernelGGL(ph_project_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream,
-                     (const odw_hit*)ctx->hits.p, (const uint32_t*)ctx->sort_vals[1].p, m, (int)key, ex[0], ex[1], ex[2],
-                     ey[0], ey[1], ey[2], (double*)ctx->ph_x.p, (double*)ctx->ph_y.p);
+  const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((m + 255) / 256, (uint64_t)ctx->n_cu * 8));
+  if ((rc = ensure(ctx, ctx->ph_part, (size_t)grid * 4 * sizeof(double)))) return rc;
+  hipLaunchKernelGGL(ph_project_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const odw_hit*)ctx->hits.p,
+                     (const uint32_t*)ctx->sort_vals[1].p, m, (int)key, ex[0], ex[1], ex[2], ey[0], ey[1], ey[2],
+                     (double*)ctx->ph_x.p, (double*)ctx->ph_y.p, (double*)ctx->ph_part.p);
   HIPCHK(ctx, hipGetLastError());
-  if ((rc = ph_sorted_stats(ctx, (const double*)ctx->ph_x.p, m, stats))) return rc;
-  if ((rc = ph_sorted_stats(ctx, (const double*)ctx->ph_y.p, m, stats + 4))) return rc;
+  std::vector<double> part((size_t)grid * 4);
+  HIPCHK(ctx, hipMemcpyAsync(part.data(), ctx->ph_part.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  double ext[4] = {INFINITY, -INFINITY, INFINITY, -INFINITY};
+  for (unsigned b = 0; b < grid; ++b) {
+    ext[0] = std::fmin(ext[0], part[4 * b]); ext[1] = std::fmax(ext[1], part[4 * b + 1]);
+    ext[2] = std::fmin(ext[2], part[4 * b + 2]); ext[3] = std::fmax(ext[3], part[4 * b + 3]);
+  }
+  if ((rc = ph_select_stats(ctx, m, ext, stats))) return rc;
   ctx->ph_projected = true;
   return ODW_OK;
 }

@@ -46,6 +46,7 @@ def _flattest_direction(cloud, angleTol):
   (a plane has two normals), then 10 x 10 grids 1.1 cells around the best one until the cells are
   smaller than angleTol"""
   phis, thetas = np.linspace(0, np.pi, 30), np.linspace(-np.pi / 2, np.pi / 2, 30)
+  cloud_t = np.ascontiguousarray(np.asarray(cloud, dtype=np.float64).T)
   while True:
     cell = (phis[1] - phis[0], thetas[1] - thetas[0])
     P, T, normals = _sphere_dirs(phis, thetas)
@@ -54,8 +55,10 @@ def _flattest_direction(cloud, angleTol):
     # equal extents then lands on a neighbouring cell now and then.  So: screen all candidates with
     # one vectorised pass, then redo those within rounding of the smallest extent the
     # reference's way -- same winner bit for bit, a fiftieth of the calls.
-    # (element-wise, not BLAS: a threaded matrix product of this size spends its time waking threads)
-    rough = normals[:, 0, None] * cloud[:, 0] + normals[:, 1, None] * cloud[:, 1] + normals[:, 2, None] * cloud[:, 2]
+    # (the screen only has to be right to ~1e-13 of the cloud's size -- the margin below --, so one
+    #  matrix product does: 0.5 ms for the 900 candidates of the first grid against 2.9 ms element-wise;
+    #  64 x 8 ms of plane search were the larger half of a 64-radius sweep)
+    rough = normals @ cloud_t
     rough = rough.max(axis=1) - rough.min(axis=1)
     near = np.flatnonzero(rough <= rough.min() + 1e-12 * max(float(np.abs(cloud).max()), 1e-300))
     exact = np.empty(len(near))

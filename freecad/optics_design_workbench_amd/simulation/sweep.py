@@ -94,7 +94,7 @@ class SweepResult:
 
 
 def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAULT_SEED, device=0,
-                   dist=None, tracer=None, source=None, deviceHits=True, **traceKwargs):
+                   dist=None, tracer=None, source=None, deviceHits=True, pipeline=True, **traceKwargs):
   """run `rays` true-random rays for every entry of `values` and return a SweepResult.
 
   setValue(doc, value)   applies one parameter value (e.g. `doc.Sphere.Radius = value`)
@@ -106,6 +106,8 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
   deviceHits             measure on the hit rows where they are, in HBM (`DeviceHits`: plane search
                          on a thinned sample, projection, medians and binning on the device); False:
                          copy every row to the host first (what the reference does)
+  pipeline               with deviceHits on a device tracer: a second context on the same GPU, so that
+                         value k + 1 is baked and traced while value k is measured (same results)
   """
   # (collectives run on the GPU the tracer works on: one process per GPU, each with its own device)
   ranks = parallel.Ranks.detect(dist, getattr(tracer, 'device', device) if tracer is not None else device)
@@ -121,50 +123,86 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
   from .simulation_loop import bakeLightSource
   own = tracer is None
   tr = tracer or Tracer(device)
-  uploaded = {}
+  # Two contexts on the same GPU take turns: while a worker thread measures the rows of value k on one of them
+  # (selection, the plane search on the host, projection, binning -- GPU work and host work in alternation),
+  # the main thread bakes and traces value k + 1 on the other.  Each context has its own stream and hit list;
+  # the compiled kernel is shared through the process cache.  Only for device tracers measured in HBM.
+  lanes = [tr]
+  if pipeline and deviceHits and isinstance(tr, Tracer) and len(mine) > 1:
+    second = Tracer(tr.device, referenceStrict=tr.referenceStrict)
+    try:
+      second.compileScene({0: 'off', 1: 'structure', 2: 'auto'}[tr.compileMode()])
+    except Exception:
+      pass
+    lanes.append(second)
+  uploaded = [dict() for _ in lanes]
   table = np.zeros((len(values), len(names), 2))        # (result or 0, 1 = a number / 2 = nan)
   totals = np.zeros(3, dtype=np.int64)
+  pool = None
+  if len(lanes) > 1:
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=len(lanes), thread_name_prefix='odw-sweep-measure')
+  pending = [None] * len(lanes)
+
+  def measureInto(t, scene, k):
+    if deviceHits and hasattr(t, 'deviceHits'):
+      hits = t.deviceHits()
+    else:
+      merged = {}
+      for d in hitsToDict(t.hits(), scene, src.Name).values():
+        for key, v in d.items():
+          updateResultEntry(merged, key, v)
+      hits = Hits(merged)
+    for j, name in enumerate(names):
+      m = float(measures[name](hits)) if len(hits) else np.nan
+      table[k, j] = (0.0, 2.0) if np.isnan(m) else (m, 1.0)
+
   try:
-    for k in mine:
+    for turn, k in enumerate(mine):
+      lane = turn % len(lanes)
+      t, up = lanes[lane], uploaded[lane]
+      if pending[lane] is not None:
+        pending[lane].result()          # the rows of this context are free again (and its errors surface here)
+        pending[lane] = None
       setValue(doc, values[k])
       scene = _bake.bakeScene(doc, src)
       bsrc = bakeLightSource(doc, src, seed)
       lim = _bake.bakeLimits(doc, src, **traceKwargs)
       # (tables travel to the device only when they change: a sweep of one shape parameter uploads
       #  the source's 1.6 MB of sampler tables once)
-      tr.setScene(scene)
+      t.setScene(scene)
       key = _sourceKey(bsrc)
-      if uploaded.get('source') != key:
-        tr.setSource(bsrc)
-        uploaded['source'] = key
-      if uploaded.get('limits') != lim:
-        tr.setLimits(lim)
-        uploaded['limits'] = lim
-      tr.setDetector(None)
+      if up.get('source') != key:
+        t.setSource(bsrc)
+        up['source'] = key
+      if up.get('limits') != lim:
+        t.setLimits(lim)
+        up['limits'] = lim
+      t.setDetector(None)
       capacity = int(rays * 1.25) + 1024
       while True:
-        tr.reserveHits(capacity)
-        tr.reset()
-        tr.trace(0, int(rays), seed, histogram=False)
-        tr.sync()
-        cnt = tr.counters()
+        t.reserveHits(capacity)
+        t.reset()
+        t.trace(0, int(rays), seed, histogram=False)
+        t.sync()
+        cnt = t.counters()
         Tracer.raiseForRayErrors(cnt)
         if not cnt['hits_dropped']:
           break
         capacity = int(cnt['recorded_hits'] * 1.05) + 1024      # deterministic: trace again with room
       totals += (cnt['traced_rays'], cnt['recorded_hits'], cnt['segments'])
-      if deviceHits and hasattr(tr, 'deviceHits'):
-        hits = tr.deviceHits()
+      if pool is not None:
+        pending[lane] = pool.submit(measureInto, t, scene, k)
       else:
-        merged = {}
-        for d in hitsToDict(tr.hits(), scene, src.Name).values():
-          for key, v in d.items():
-            updateResultEntry(merged, key, v)
-        hits = Hits(merged)
-      for j, name in enumerate(names):
-        m = float(measures[name](hits)) if len(hits) else np.nan
-        table[k, j] = (0.0, 2.0) if np.isnan(m) else (m, 1.0)
+        measureInto(t, scene, k)
+    for f in pending:
+      if f is not None:
+        f.result()
   finally:
+    if pool is not None:
+      pool.shutdown(wait=True)
+    for extra in lanes[1:]:
+      extra.close()
     if own:
       tr.close()
   flat = ranks.sumFloats(np.concatenate([table.ravel(), totals.astype(np.float64)]))

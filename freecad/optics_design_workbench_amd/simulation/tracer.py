@@ -96,7 +96,12 @@ class Tracer:
     f = self._lib.odw_compile_scene
     f.argtypes = [C.c_void_p, C.c_int32]
     self._chk(f(self._ctx, _native.COMPILE_MODES[mode]), 'odw_compile_scene')
+    self._compileMode = _native.COMPILE_MODES[mode]
     return self.compiledInfo()
+
+  def compileMode(self):
+    """the sticky mode compileScene last set: 0 off, 1 structure, 2 auto"""
+    return getattr(self, '_compileMode', 0)
 
   def compiledInfo(self):
     """dict(mode: 0 generic (in 'auto' mode: not compiled yet) / 1 structure / 2 auto -- of the kernel the next eligible launch runs,
