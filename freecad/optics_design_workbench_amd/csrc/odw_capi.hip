@@ -89,7 +89,7 @@ struct odw_ctx {
   DevBuf hits, hit_count, hist, counters, chunk_counter;
   DevBuf segs, seg_count;                  // RecordRays segment list
   uint64_t seg_capacity = 0;
-  DevBuf ray_o, ray_d, ray_p, samp_t, samp_phi;
+  DevBuf ray_o, ray_d, ray_p, ray_aos, samp_t, samp_phi;
   DevBuf sort_keys[2], sort_vals[2], sort_tmp, sorted_rows;
   // post-hoc binning of the rows in HBM (odw_posthoc.hip): the selection = sort_vals[1][0 .. ph_n)
   DevBuf ph_sel_entering, ph_flags, ph_x, ph_y, ph_sorted, ph_small, ph_part, ph_edges, ph_edges_b, ph_counts, ph_sel_hist;
@@ -745,6 +745,7 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
   P.ray_origins = ray_o;
   P.ray_dirs = ray_d;
   P.ray_powers = ray_p;
+  P.ray_stride = n;
   P.dbg = (unsigned long long*)ctx->dbg.p;
   P.out.hits = (odw_hit*)ctx->hits.p;
   P.out.hit_capacity = ctx->hit_slots;
@@ -839,13 +840,15 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
 
 constexpr uint64_t kEmitChunk = 1ull << 24;
 
-int emit_rays(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed) {
+// component_major: 3 x n for the trace kernels; else n x 3 (odw_generate_rays hands that to the caller)
+int emit_rays(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, bool component_major = true) {
   int rc;
   if ((rc = ensure(ctx, ctx->em_o, std::min<uint64_t>(n, kEmitChunk) * 3 * sizeof(double)))) return rc;
   if ((rc = ensure(ctx, ctx->em_d, std::min<uint64_t>(n, kEmitChunk) * 3 * sizeof(double)))) return rc;
   const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n + 255) / 256, (uint64_t)ctx->n_cu * 16));
   hipLaunchKernelGGL(odw_emit_kernel, dim3(grid), dim3(256), 0, ctx->stream, ctx->h_emitter, first, n, seed,
-                     (double*)ctx->em_o.p, (double*)ctx->em_d.p);
+                     (double*)ctx->em_o.p, (double*)ctx->em_d.p, component_major ? n : (uint64_t)1,
+                     component_major ? (uint64_t)1 : (uint64_t)3);
   HIPCHK(ctx, hipGetLastError());
   return ODW_OK;
 }
@@ -918,7 +921,7 @@ void odw_destroy(odw_ctx* ctx) {
   DevBuf* all[] = {&ctx->prim_f64, &ctx->prim_hdr, &ctx->prim_i32, &ctx->cond_i32, &ctx->group_f64, &ctx->group_i32,
                    &ctx->group_gdir, &ctx->seq_mask, &ctx->bvh_nodes, &ctx->bvh_prims,
                    &ctx->phi_tab, &ctx->t_tab, &ctx->t_guide, &ctx->d_source, &ctx->d_det, &ctx->hits, &ctx->hit_count, &ctx->chunk_counter, &ctx->hist,
-                   &ctx->counters, &ctx->ray_o, &ctx->ray_d, &ctx->ray_p, &ctx->samp_t, &ctx->samp_phi,
+                   &ctx->counters, &ctx->ray_o, &ctx->ray_d, &ctx->ray_p, &ctx->ray_aos, &ctx->samp_t, &ctx->samp_phi,
                    &ctx->sort_keys[0], &ctx->sort_keys[1], &ctx->sort_vals[0], &ctx->sort_vals[1],
                    &ctx->sort_tmp, &ctx->sorted_rows, &ctx->segs, &ctx->seg_count};
   for (DevBuf* b : all) release(*b);
@@ -1406,7 +1409,7 @@ int odw_generate_rays(odw_ctx* ctx, uint64_t first_ray, uint64_t n_rays, uint64_
     const uint64_t m = std::min<uint64_t>(kEmitChunk, n_rays - off);
     int rc;
     if (ctx->emitter_active) {
-      if ((rc = emit_rays(ctx, first_ray + off, m, seed))) return rc;
+      if ((rc = emit_rays(ctx, first_ray + off, m, seed, false))) return rc;
     } else {
       if ((rc = ensure(ctx, ctx->em_o, m * 3 * sizeof(double)))) return rc;
       if ((rc = ensure(ctx, ctx->em_d, m * 3 * sizeof(double)))) return rc;
@@ -1530,8 +1533,20 @@ int odw_trace_rays(odw_ctx* ctx, uint64_t first_ray, uint64_t n_rays, const doub
   // the previous launch may still read the staging buffers
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   int rc;
-  if ((rc = upload(ctx, ctx->ray_o, origins, n_rays * 3 * sizeof(double)))) return rc;
-  if ((rc = upload(ctx, ctx->ray_d, directions, n_rays * 3 * sizeof(double)))) return rc;
+  // the caller's n x 3 arrays are staged as they are, then turned component-major on the device (the kernels'
+  // lanes read consecutive rays: unit-stride loads instead of 24-byte strides)
+  if ((rc = ensure(ctx, ctx->ray_aos, n_rays * 6 * sizeof(double)))) return rc;
+  if ((rc = ensure(ctx, ctx->ray_o, n_rays * 3 * sizeof(double)))) return rc;
+  if ((rc = ensure(ctx, ctx->ray_d, n_rays * 3 * sizeof(double)))) return rc;
+  double* aos = (double*)ctx->ray_aos.p;
+  HIPCHK(ctx, hipMemcpyAsync(aos, origins, n_rays * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(aos + 3 * n_rays, directions, n_rays * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  {
+    const unsigned tgrid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((3 * n_rays + 255) / 256, (uint64_t)ctx->n_cu * 16));
+    hipLaunchKernelGGL(odw_rays_to_components_kernel, dim3(tgrid), dim3(256), 0, ctx->stream, (const double*)aos,
+                       (const double*)(aos + 3 * n_rays), n_rays, (double*)ctx->ray_o.p, (double*)ctx->ray_d.p);
+    HIPCHK(ctx, hipGetLastError());
+  }
   if (powers) {
     if ((rc = upload(ctx, ctx->ray_p, powers, n_rays * sizeof(double)))) return rc;
   }
@@ -1689,7 +1704,7 @@ int odw_host_alloc(odw_ctx* ctx, uint64_t bytes, void** out) {
 }
 
 int odw_host_free(odw_ctx* ctx, void* p) {
-  if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_host_free: null ctx");
+  // (ctx may be null: page-locked arrays handed to the caller can outlive the context that allocated them)
   if (p) HIPCHK(ctx, hipHostFree(p));
   return ODW_OK;
 }

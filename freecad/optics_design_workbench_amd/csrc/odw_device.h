@@ -168,9 +168,10 @@ struct TraceParams {
   const DeviceSurfaceSampler* samplers;   // stochastic surfaces (STOCH kernels only)
   const int32_t* group_sampler;           // [64*2] sampler index of (group, kind) or -1
   DeviceOutputs out;
-  const double* ray_origins;    // explicit initial conditions (or null)
-  const double* ray_dirs;
-  const double* ray_powers;
+  const double* ray_origins;    // explicit initial conditions (or null), component-major: x of every ray, then
+  const double* ray_dirs;       //   y, then z (component c of ray i at [c * ray_stride + i]): a wave that takes
+  const double* ray_powers;     //   consecutive rays reads consecutive doubles
+  uint64_t ray_stride;          // rays of the launch
   uint64_t first_ray, n_rays, seed;
   uint32_t flags;
   unsigned long long* dbg;      // diagnostic builds only (ODW_GRID_STATS): 16 words, or null

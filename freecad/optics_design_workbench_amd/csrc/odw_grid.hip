@@ -197,8 +197,8 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
           const uint64_t r = next + lane;
           d3 o, d;
           if (P.ray_origins) {
-            o = mk(P.ray_origins[3 * r], P.ray_origins[3 * r + 1], P.ray_origins[3 * r + 2]);
-            d = mk(P.ray_dirs[3 * r], P.ray_dirs[3 * r + 1], P.ray_dirs[3 * r + 2]);
+            o = mk(P.ray_origins[r], P.ray_origins[P.ray_stride + r], P.ray_origins[2 * P.ray_stride + r]);
+            d = mk(P.ray_dirs[r], P.ray_dirs[P.ray_stride + r], P.ray_dirs[2 * P.ray_stride + r]);
             d = d * (1.0 / sqrt(dot(d, d)));
           } else {
             const RayInit g = generate_ray(P.source, P.first_ray + r, P.seed);

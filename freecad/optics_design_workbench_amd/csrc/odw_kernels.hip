@@ -1469,8 +1469,9 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
       if (!alive && rank < take) {
         i = next + rank;
         if (P.ray_origins) {
-          point = mk(P.ray_origins[3 * i], P.ray_origins[3 * i + 1], P.ray_origins[3 * i + 2]);
-          dir = mk(P.ray_dirs[3 * i], P.ray_dirs[3 * i + 1], P.ray_dirs[3 * i + 2]);
+          // (component-major staging: the lanes of a wave take consecutive rays, so these are coalesced loads)
+          point = mk(P.ray_origins[i], P.ray_origins[P.ray_stride + i], P.ray_origins[2 * P.ray_stride + i]);
+          dir = mk(P.ray_dirs[i], P.ray_dirs[P.ray_stride + i], P.ray_dirs[2 * P.ray_stride + i]);
           dir = dir * (1.0 / sqrt(dot(dir, dir)));
           power = P.ray_powers ? P.ray_powers[i] : 1.0;
         } else {
@@ -1685,8 +1686,11 @@ __device__ __forceinline__ double face_point(int type, const double* par, int fa
   return 1.0;
 }
 
+// cs / rs: stride of a component / of a ray in the output (3 x n component-major for the trace kernels: cs = n,
+// rs = 1; n x 3 for odw_generate_rays: cs = 1, rs = 3)
 __global__ __launch_bounds__(256) void odw_emit_kernel(const DeviceEmitter E, uint64_t first, uint64_t n, uint64_t seed,
-                                                       double* __restrict__ origins, double* __restrict__ dirs) {
+                                                       double* __restrict__ origins, double* __restrict__ dirs, uint64_t cs,
+                                                       uint64_t rs) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const uint64_t ray = first + i;
@@ -1750,8 +1754,20 @@ __global__ __launch_bounds__(256) void odw_emit_kernel(const DeviceEmitter E, ui
     const double phi = 6.283185307179586 * u_phi;
     d3 d = rotate(gn, phi, rotate(gt, theta, gn));
     d = d * (1.0 / sqrt(dot(d, d)));
-    origins[3 * i] = gp.x; origins[3 * i + 1] = gp.y; origins[3 * i + 2] = gp.z;
-    dirs[3 * i] = d.x; dirs[3 * i + 1] = d.y; dirs[3 * i + 2] = d.z;
+    origins[i * rs] = gp.x; origins[cs + i * rs] = gp.y; origins[2 * cs + i * rs] = gp.z;
+    dirs[i * rs] = d.x; dirs[cs + i * rs] = d.y; dirs[2 * cs + i * rs] = d.z;
+  }
+}
+
+// n x 3 (the caller's layout) -> 3 x n (the trace kernels'), both arrays in one pass
+__global__ __launch_bounds__(256) void odw_rays_to_components_kernel(const double* __restrict__ o_in, const double* __restrict__ d_in,
+                                                                     uint64_t n, double* __restrict__ o_out,
+                                                                     double* __restrict__ d_out) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < 3 * n; i += stride) {
+    const uint64_t ray = i / 3, c = i - 3 * ray;           // (reads are contiguous, writes three interleaved streams)
+    o_out[c * n + ray] = o_in[i];
+    d_out[c * n + ray] = d_in[i];
   }
 }
 

@@ -387,6 +387,7 @@ int odw_release_swapped_hits(odw_ctx* ctx);
 /* page-locked host memory for the destination of row fetches (the copy engine
  * writes it directly: no staging through the runtime's own pinned buffers)  */
 int odw_host_alloc(odw_ctx* ctx, uint64_t bytes, void** out);
+/* ctx may be NULL: arrays handed to the caller (hit columns of a run kept in memory) outlive their context */
 int odw_host_free(odw_ctx* ctx, void* p);
 /* rows in the segment list and rows that did not fit into it               */
 int odw_segment_count(odw_ctx* ctx, uint64_t* n, uint64_t* dropped);
