@@ -596,6 +596,40 @@ void compute_boxes(odw_ctx* ctx, std::vector<Box>& boxes, std::vector<char>& dea
               boxes[p].lo[2] > boxes[p].hi[2];
     if (dead[p])
       for (int a = 0; a < 3; ++a) boxes[p].lo[a] = boxes[p].hi[a] = 1e30;
+  }
+  // ODW_FLAG_ISOLATED (odw_device.h): solids whose box keeps clear of every other solid's
+  {
+    std::map<int, Box> solid_box;
+    for (int p = 0; p < n; ++p) {
+      ctx->h_prim_i32[4 * p + 2] &= ~ODW_FLAG_ISOLATED;
+      if (dead[p]) continue;
+      const int sid = ctx->h_prim_i32[4 * p + 2] >> ODW_SOLID_SHIFT;
+      auto it = solid_box.find(sid);
+      if (it == solid_box.end()) { solid_box[sid] = boxes[p]; continue; }
+      for (int a = 0; a < 3; ++a) {
+        it->second.lo[a] = std::min(it->second.lo[a], boxes[p].lo[a]);
+        it->second.hi[a] = std::max(it->second.hi[a], boxes[p].hi[a]);
+      }
+    }
+    const double gap = 2.0 * slack;                             // 4 distTol
+    static const bool enabled = !(getenv("ODW_ISOLATED") && getenv("ODW_ISOLATED")[0] == '0');   // (A/B runs)
+    if (enabled && solid_box.size() <= 64 && solid_box.count(0x7fff) == 0)  // (0x7fff: solid ids that did not fit the word)
+      for (int p = 0; p < n; ++p) {
+        if (dead[p]) continue;
+        const int sid = ctx->h_prim_i32[4 * p + 2] >> ODW_SOLID_SHIFT;
+        const Box& mine = solid_box[sid];
+        bool alone = true;
+        for (const auto& other : solid_box) {
+          if (other.first == sid) continue;
+          bool apart = false;
+          for (int a = 0; a < 3; ++a)
+            apart |= mine.lo[a] - other.second.hi[a] > gap || other.second.lo[a] - mine.hi[a] > gap;
+          if (!apart) { alone = false; break; }
+        }
+        if (alone) ctx->h_prim_i32[4 * p + 2] |= ODW_FLAG_ISOLATED;
+      }
+  }
+  for (int p = 0; p < n; ++p) {
     double* h = flat.data() + 8 * (size_t)p;
     for (int a = 0; a < 3; ++a) { h[a] = boxes[p].lo[a]; h[3 + a] = boxes[p].hi[a]; }
     std::memcpy(h + 6, &ctx->h_prim_i32[4 * (size_t)p], 4 * sizeof(int32_t));
@@ -614,6 +648,8 @@ int build_bvh(odw_ctx* ctx) {
   const std::vector<double>& flat = ctx->h_prim_hdr;
   {
     int rc = upload(ctx, ctx->prim_hdr, flat.data(), flat.size() * sizeof(double));
+    // (compute_boxes has set ODW_FLAG_ISOLATED in the flag words)
+    if (!rc && n > 0) rc = upload(ctx, ctx->prim_i32, ctx->h_prim_i32.data(), ctx->h_prim_i32.size() * sizeof(int32_t));
     if (rc) return rc;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->P.scene.prim_hdr = (const double*)ctx->prim_hdr.p;
@@ -1010,7 +1046,7 @@ static int scene_host_tables(odw_ctx* ctx, const odw_scene_desc* s) {
     // convex-solid shortcut, nothing else
     const int solid = s->prim_solid ? s->prim_solid[p] : 0;
     const bool fits = s->prim_solid && solid >= 0 && solid < 0x7fff && max_solid < 0x7fff;
-    ctx->h_prim_i32[4 * p + 2] = ((s->prim_flags[p] & 0xffff) & (fits ? ~0 : ~ODW_FLAG_CONVEX)) | ((fits ? solid : 0x7fff) << ODW_SOLID_SHIFT);
+    ctx->h_prim_i32[4 * p + 2] = ((s->prim_flags[p] & 0xffff & ~ODW_FLAG_ISOLATED) & (fits ? ~0 : ~ODW_FLAG_CONVEX)) | ((fits ? solid : 0x7fff) << ODW_SOLID_SHIFT);
     ctx->h_prim_i32[4 * p + 3] = off | (cnt << 24);
   }
   std::vector<int32_t> cond((size_t)std::max(1, s->n_conds), 0);

@@ -42,6 +42,12 @@ namespace odw {
 #define ODW_TAG_UNUSED 0xFFFFFFFFFFFFFFFFull   // tag of a hit-list slot that was reserved but not written
 #define ODW_CNT_LDS 8        // counters 0..7 are gathered in LDS; rarer ones are added to the global array directly
 #define ODW_SOLID_SHIFT 16   // prim_i32 flags word: flags | facemask << 8 | solid id << 16
+// set by the library (compute_boxes): the box of the primitive's solid, tolerance slack included, keeps more than
+// 4 distTol away from the box of every other solid.  A ray that has just ENTERED such a solid meets the solid
+// itself before anything else (a straight line that has left a box does not come back, and every hit the
+// tolerance rules accept lies in its solid's box): the next segment tests this solid's primitives only, and
+// falls back to all of them in the one case that finds nothing (a hit within distTol beyond an edge).
+#define ODW_FLAG_ISOLATED 0x4
 
 struct d3 {
   double x, y, z;

@@ -143,6 +143,8 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
 
   // leave the cell through the nearest plane (the axis by selects, the next plane by ONE read of the
   // contiguous plane tables), or end the walk: beyond nearest + 2 distTol (ray.py:432, 440), or out of the grid
+  // (tried in round 3: three predicated blocks, one per axis, each with its own operands instead of the selects --
+  //  46 fewer v_cndmask in the binary, but three LDS reads in a row under divergent masks: 25.6 against 24.3 ms)
 #define ODW_WALK_ADVANCE()                                                                   \
   do {                                                                                       \
     const double t_exit_ = fmin(tx, fmin(ty, tz));                                           \

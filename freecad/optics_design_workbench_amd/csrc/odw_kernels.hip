@@ -198,6 +198,7 @@ struct NoSpec {
   static constexpr unsigned long long xf(int) { return 0xfffull; }
   static constexpr int type(int) { return 0; }
   static constexpr int cond(int) { return 0; }
+  static constexpr bool isolated() { return true; }
 };
 // Frame products of a compiled scene.  XF = the pattern of a primitive's 12 frame entries: bits 0-11
 // entry != 0, bits 12-23 entry == +1, bits 24-35 entry == -1.  A term whose coefficient is exactly zero
@@ -829,13 +830,16 @@ __device__ __forceinline__ bool ray_box(P bx, d3 oi, d3 inv, double tmax) {
 // (SPEC::box_of = the first primitive with that set).  The later ones reuse the first one's outcome (taken
 // with a cut at least as wide: conservative).
 template <class SPEC, int PI>
-__device__ __forceinline__ void spec_prim(const SceneView& sv, Query& q, d3 oi, d3 inv, int skip_solid, uint64_t mask,
-                                          bool* boxhit) {
+__device__ __forceinline__ void spec_prim(const SceneView& sv, Query& q, d3 oi, d3 inv, int skip_solid, int only_solid,
+                                          uint64_t mask, bool* boxhit) {
   constexpr int flags = SPEC::flags(PI);
   // relevant groups: a constant without sequential mode (ignored groups' primitives leave no code),
   // the ray's own mask with it
   if constexpr (!SPEC::dead(PI) && (SPEC::seq() || ((SPEC::umask() >> SPEC::group(PI)) & 1) != 0)) {
-    if ((!SPEC::seq() || ((mask >> SPEC::group(PI)) & 1)) && (flags >> ODW_SOLID_SHIFT) != skip_solid) {
+    // (only_solid: the isolated solid the ray has just entered, ODW_FLAG_ISOLATED -- a scene without such solids
+    //  never sets it, and the test folds away)
+    if ((!SPEC::seq() || ((mask >> SPEC::group(PI)) & 1)) && (flags >> ODW_SOLID_SHIFT) != skip_solid &&
+        (!SPEC::isolated() || only_solid < 0 || (flags >> ODW_SOLID_SHIFT) == only_solid)) {
       bool in_box;
       if constexpr (SPEC::box_of(PI) != PI) {
         in_box = boxhit[SPEC::box_of(PI)];
@@ -855,17 +859,17 @@ __device__ __forceinline__ void spec_prim(const SceneView& sv, Query& q, d3 oi, 
 }
 template <class T, T... I> struct IndexList {};      // (std::integer_sequence without <utility>: runtime compilation has no libstdc++)
 template <class SPEC, int... PI>
-__device__ __forceinline__ void spec_prims(const SceneView& sv, Query& q, d3 oi, d3 inv, int skip_solid, uint64_t mask,
-                                           IndexList<int, PI...>) {
+__device__ __forceinline__ void spec_prims(const SceneView& sv, Query& q, d3 oi, d3 inv, int skip_solid, int only_solid,
+                                           uint64_t mask, IndexList<int, PI...>) {
   bool boxhit[sizeof...(PI)] = {};
-  (spec_prim<SPEC, PI>(sv, q, oi, inv, skip_solid, mask, boxhit), ...);
+  (spec_prim<SPEC, PI>(sv, q, oi, inv, skip_solid, only_solid, mask, boxhit), ...);
 }
 
 template <bool BVH, class SPEC = NoSpec>
 __device__ __forceinline__ int nearest(const DeviceScene& sc, const SceneView& sv,
                                        const DeviceLimits& lim, d3 start, d3 dn, int medium,
                                        uint64_t mask, double& t_hit, int& face,
-                                       int* __restrict__ stack, int skip_solid) {
+                                       int* __restrict__ stack, int skip_solid, int only_solid = -1) {
   Query q;
   q.start = start; q.dn = dn; q.tol = lim.dist_tol; q.tmax = lim.max_ray_length + lim.dist_tol;
   q.medium = medium;
@@ -874,7 +878,7 @@ __device__ __forceinline__ int nearest(const DeviceScene& sc, const SceneView& s
   const d3 inv = mk(frcp(dn.x), frcp(dn.y), frcp(dn.z));
   const d3 oi = mk(start.x * inv.x, start.y * inv.y, start.z * inv.z);
   if constexpr (SPEC::enabled) {
-    spec_prims<SPEC>(sv, q, oi, inv, skip_solid, mask, __make_integer_seq<IndexList, int, SPEC::N>{});
+    spec_prims<SPEC>(sv, q, oi, inv, skip_solid, only_solid, mask, __make_integer_seq<IndexList, int, SPEC::N>{});
   } else if (!BVH) {
     // without sequential mode the set of relevant groups is the same for
     // every ray: the test is scalar and skips a primitive for the whole wave
@@ -889,8 +893,10 @@ __device__ __forceinline__ int nearest(const DeviceScene& sc, const SceneView& s
       } else {
         if (!((umask >> g) & 1)) continue;
       }
-      // a ray that has just left a convex solid cannot meet it again
+      // a ray that has just left a convex solid cannot meet it again; one that has just entered an isolated
+      // solid meets that solid first (ODW_FLAG_ISOLATED)
       if ((flags >> ODW_SOLID_SHIFT) == skip_solid) continue;
+      if (only_solid >= 0 && (flags >> ODW_SOLID_SHIFT) != only_solid) continue;
       // candidates farther than the nearest hit + 2*distTol can never be
       // selected (ray.py:432,440): shrink the search like the reference does
       const double cut = fmin(q.tmax, q.any.t + 2.0 * q.tol);
@@ -1349,7 +1355,7 @@ template <bool STOCH, bool LEAN, class SPEC, int PI>
 __device__ __forceinline__ void spec_hit(const TraceParams& P, const SceneView& sv, cf64 group_f64, ci32 group_i32,
                                          cf64 group_gdir, int face, uint64_t ray, int nint, uint32_t* cnt,
                                          uint32_t* hit_state, uint32_t* win, d3 point, d3& dir, double& power, int& medium, int& seq,
-                                         int& skip, bool& alive) {
+                                         int& skip, int& only, bool& alive) {
   constexpr int flags = SPEC::flags(PI), g = SPEC::group(PI);
   cf64 pf = sv.prim_f64 + (size_t)PI * 16;
   d3 n = face_normal<SPEC::parab()>(SPEC::type(PI), pf + 12, face, xf_point_nz<SPEC::xf(PI)>(pf, point));
@@ -1359,18 +1365,20 @@ __device__ __forceinline__ void spec_hit(const TraceParams& P, const SceneView& 
   if (entering) n = n * -1.0;
   interact<false, STOCH, LEAN>(P, group_f64, group_i32, group_gdir, g, SPEC::gtype(g), SPEC::record(g), n, entering, ray,
                                nint, cnt, hit_state, win, point, dir, power, medium, seq, alive);
-  if constexpr ((flags & ODW_FLAG_CONVEX) != 0)
-    skip = ((entering ? -dot(dir, n) : dot(dir, n)) > 0) ? (flags >> ODW_SOLID_SHIFT) : -1;
-  else
-    skip = -1;
+  // n points along the incoming travel direction: out of the solid when leaving it, into it when entering
+  const double out = entering ? -dot(dir, n) : dot(dir, n);
+  if constexpr ((flags & ODW_FLAG_CONVEX) != 0) skip = out > 0 ? (flags >> ODW_SOLID_SHIFT) : -1;
+  else skip = -1;
+  if constexpr ((flags & ODW_FLAG_ISOLATED) != 0) only = out < 0 ? (flags >> ODW_SOLID_SHIFT) : -1;
+  else only = -1;
 }
 template <bool STOCH, bool LEAN, class SPEC, int... PI>
 __device__ __forceinline__ void spec_hits(const TraceParams& P, const SceneView& sv, cf64 group_f64, ci32 group_i32,
                                           cf64 group_gdir, int prim, int face, uint64_t ray, int nint, uint32_t* cnt,
                                           uint32_t* hit_state, uint32_t* win, d3 point, d3& dir, double& power, int& medium, int& seq,
-                                          int& skip, bool& alive, IndexList<int, PI...>) {
+                                          int& skip, int& only, bool& alive, IndexList<int, PI...>) {
   (void)((prim == PI ? (spec_hit<STOCH, LEAN, SPEC, PI>(P, sv, group_f64, group_i32, group_gdir, face, ray, nint, cnt, hit_state, win,
-                                                  point, dir, power, medium, seq, skip, alive), true)
+                                                  point, dir, power, medium, seq, skip, only, alive), true)
                      : false) || ...);
 }
 
@@ -1436,6 +1444,7 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
   double power = 0;
   int seq = 0, nint = 0, medium = -1;
   int skip = -1;     // solid the ray has just left, if that solid is convex (it cannot be met again)
+  int only = -1;     // solid the ray has just entered, if that solid is isolated (it is met before anything else)
   // per wave: block of hit-list slots (base lo, base hi) and how many are taken (full: none reserved yet)
   // (flat kernels only: the BVH kernels' node stacks + counters fill the 160 KB of a CU exactly at
   //  4 blocks -- 64 more bytes would cost a quarter of the occupancy)
@@ -1481,7 +1490,7 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
         // `dir` stays a unit vector: mirror() preserves length, snells_law() and
         // line_grating() return unit vectors for unit input; the reference
         // renormalises every segment (ray.py:377), a no-op up to rounding
-        seq = 0; nint = 0; medium = -1; skip = -1;
+        seq = 0; nint = 0; medium = -1; skip = -1; only = -1;
         alive = true;
       }
       next += take;
@@ -1499,7 +1508,15 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
       double t_hit;
       int face;
       const int prim = nearest<BVH, SPEC>(sc, sv, lim, point, dir, medium, mask, t_hit, face,
-                                    bvh_stack + threadIdx.x, skip);
+                                          bvh_stack + threadIdx.x, skip, BVH ? -1 : only);
+      // A ray that has entered an isolated solid within distTol beyond one of its edges can pass it by: then, and
+      // only then, the solid's own primitives yield nothing -- the segment is done again with every primitive, in
+      // the next trip of the loop (no second copy of the search, no state kept across one)
+      if (!BVH && prim < 0 && only >= 0) {
+        only = -1;
+        --nint;
+        continue;
+      }
       if (SEG)   // (p1, p2), power at p1, medium of the segment (ray.py:104-117)
         record_segment(P.out.segs, P.out.seg_capacity, P.out.seg_count, P.first_ray + i, nint - 1, medium, point,
                        point + dir * (prim < 0 ? lim.max_ray_length : t_hit), power);
@@ -1518,7 +1535,7 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
       uint32_t* hit_state = hit_lds + (threadIdx.x >> 6) * 4;
       if constexpr (SPEC::enabled) {
         spec_hits<STOCH, LEAN, SPEC>(P, sv, group_f64, group_i32, group_gdir, prim, face, P.first_ray + i, nint, cnt, hit_state,
-                              hist_win, point, dir, power, medium, seq, skip, alive, __make_integer_seq<IndexList, int, SPEC::N>{});
+                              hist_win, point, dir, power, medium, seq, skip, only, alive, __make_integer_seq<IndexList, int, SPEC::N>{});
       } else {
       cf64 pf = sv.prim_f64 + (size_t)prim * 16;
       ci32 pi = sv.prim_i32 + 4 * prim;
@@ -1538,7 +1555,9 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
       interact<BVH, STOCH, LEAN>(P, group_f64, group_i32, group_gdir, g, group_i32[4 * g], group_i32[4 * g + 1] != 0, n,
                                  entering, P.first_ray + i, nint, cnt, hit_state, hist_win, point, dir, power, medium, seq, alive);
       // outward normal of the solid = n against the travel direction when entering
-      skip = ((pi[2] & ODW_FLAG_CONVEX) && (entering ? -dot(dir, n) : dot(dir, n)) > 0) ? (pi[2] >> ODW_SOLID_SHIFT) : -1;
+      const double out = entering ? -dot(dir, n) : dot(dir, n);
+      skip = ((pi[2] & ODW_FLAG_CONVEX) && out > 0) ? (pi[2] >> ODW_SOLID_SHIFT) : -1;
+      only = (!BVH && (pi[2] & ODW_FLAG_ISOLATED) && out < 0) ? (pi[2] >> ODW_SOLID_SHIFT) : -1;
       }
       if (alive && power < lim.power_tol) { ODW_COUNT(ODW_CNT_DIED); alive = false; }
       }

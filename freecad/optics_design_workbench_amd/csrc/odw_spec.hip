@@ -127,7 +127,7 @@ std::string spec_text(const odw_ctx* ctx) {
   for (int p = 0; p < n; ++p) {
     type[p] = ctx->h_prim_i32[4 * p];
     group[p] = ctx->h_prim_i32[4 * p + 1];
-    flags[p] = ctx->h_prim_i32[4 * p + 2];
+    flags[p] = ctx->h_prim_i32[4 * p + 2] & ~ODW_FLAG_ISOLATED;
     condw[p] = ctx->h_prim_i32[4 * p + 3];
     const int facemask = (flags[p] >> ODW_FACEMASK_SHIFT) & 0xff;
     // (an empty box is a matter of values: such a primitive stays, its box culls it)
@@ -181,6 +181,11 @@ std::string spec_text(const odw_ctx* ctx) {
   bool parab = false;
   for (int p = 0; p < n; ++p) parab |= type[p] == ODW_PRIM_PARABOLOID;
   s += std::string("  static constexpr bool parab() { return ") + (parab ? "true" : "false") + "; }\n";
+  // ODW_FLAG_ISOLATED (a ray that has entered an isolated solid tests that solid only) is left to the generic
+  // flat kernel, which gains 3 % on lensesAndMirrors from it: in a compiled kernel a skipped box test saves less
+  // than the extra predicate on every primitive costs (11.85 against 11.30 ms, 8 spilled SGPRs).  The rule
+  // never changes a result, so the two kernels still produce the same rows.
+  s += "  static constexpr bool isolated() { return false; }\n";
   s += "  static constexpr int cond_off(int i) { return cond_word(i) & 0xffffff; }\n"
        "  static constexpr int cond_cnt(int i) { return (cond_word(i) >> 24) & 0xff; }\n";
   s += "  static constexpr unsigned long long umask() { return " + fu(ctx->P.scene.all_mask & ~ctx->P.scene.ignore_mask) + "; }\n";
