@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(CSRC, 'libodw_trace.so')
 _SOURCES = ['odw_capi.hip', 'odw_kernels.hip', 'odw_grid.hip', 'odw_posthoc.hip', 'odw_spec.hip', 'odw_device.h']
 _HEADER = os.path.normpath(os.path.join(_HERE, '..', '..', 'include', 'odw_trace.h'))
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 CNT_NAMES = ['traced_rays', 'recorded_hits', 'segments', 'escaped', 'died', 'capped',
              'hist_overflow', 'hits_dropped', 'grating_in_medium']
 TRACE_RECORD_HITS, TRACE_HISTOGRAM, TRACE_RECORD_SEGMENTS = 1, 2, 4
@@ -64,7 +64,8 @@ class SurfaceSamplerDesc(C.Structure):
   _fields_ = [('group', C.c_int32), ('kind', C.c_int32), ('family_axis', C.c_int32), ('n_family', C.c_int32),
               ('family_lo', C.c_double), ('family_hi', C.c_double), ('n_phi_knots', C.c_int32),
               ('phi_edges', _pd), ('phi_cdf', _pd), ('n_t_knots', C.c_int32), ('n_t_rows', C.c_int32),
-              ('t_edges', _pd), ('t_cdf', _pd)]
+              ('t_edges', _pd), ('t_cdf', _pd), ('mu', C.c_double), ('n_atoms', C.c_int32),
+              ('atom_mass', _pd), ('atom_theta', _pd), ('atom_phi', _pd)]
 
 
 class SurfaceSourceDesc(C.Structure):
@@ -238,6 +239,13 @@ def surface_sampler_descs(samplers):
     d.n_phi_knots, d.n_t_knots, d.n_t_rows = len(phi_edges), len(t_edges), int(t_cdf.shape[-2])
     for name, a in (('phi_edges', phi_edges), ('phi_cdf', phi_cdf), ('t_edges', t_edges), ('t_cdf', t_cdf)):
       setattr(d, name, a.ctypes.data_as(_pd))
+    d.mu = float(getattr(s, 'mu', 0.0))
+    d.n_atoms = int(getattr(s, 'n_atoms', 0) or 0)
+    if d.n_atoms:
+      for name in ('atom_mass', 'atom_theta', 'atom_phi'):
+        a = _arr(getattr(s, name), np.float64)
+        keep.append(a)
+        setattr(d, name, a.ctypes.data_as(_pd))
   return arr, len(samplers), keep
 
 

@@ -99,7 +99,7 @@ struct odw_ctx {
   int ph_group = -1;
   bool ph_valid = false, ph_projected = false, ph_entering_built = false;
   // stochastic surfaces: one table set per sampler, descriptor block, (group, kind) -> index
-  struct SurfaceBufs { DevBuf phi_tab, t_tab, t_guide; };
+  struct SurfaceBufs { DevBuf phi_tab, t_tab, t_guide, atom_mass; };
   std::vector<SurfaceBufs> surf_bufs;
   DevBuf d_samplers, d_group_sampler;
   int n_samplers = 0;
@@ -1195,7 +1195,13 @@ int odw_upload_surface_samplers(odw_ctx* ctx, const odw_surface_sampler_desc* sa
     const odw_surface_sampler_desc& s = samplers[i];
     if (s.group < 0 || s.group >= ctx->P.scene.n_groups || s.kind < ODW_SURF_PRIMARY || s.kind > ODW_SURF_MODIFY)
       return fail(ctx, ODW_ERR_INVALID, "surface sampler: group/kind out of range");
-    if (gs[2 * s.group + s.kind] >= 0) return fail(ctx, ODW_ERR_INVALID, "surface sampler: duplicate (group, kind)");
+    // several samplers of one (group, kind): told apart by mu (a chain: group_sampler -> first, DeviceSurfaceSampler::next)
+    for (int j = gs[2 * s.group + s.kind]; j >= 0; j = ds[(size_t)j].next)
+      if (ds[(size_t)j].mu == s.mu) return fail(ctx, ODW_ERR_INVALID, "surface sampler: duplicate (group, kind, mu)");
+    if (s.n_atoms < 0 || s.n_atoms > ODW_SURF_MAX_ATOMS || (s.n_atoms && (!s.atom_mass || !s.atom_theta || !s.atom_phi)))
+      return fail(ctx, ODW_ERR_INVALID, "surface sampler: atoms");
+    for (int k = 0; k < s.n_family * s.n_atoms; ++k)
+      if (!(s.atom_mass[k] >= 0.0 && s.atom_mass[k] <= 1.0)) return fail(ctx, ODW_ERR_INVALID, "surface sampler: atom probability outside [0, 1]");
     if (s.n_family < 1 || s.family_axis < ODW_SURF_AXIS_NONE || s.family_axis > ODW_SURF_AXIS_THETA_REFL ||
         (s.family_axis == ODW_SURF_AXIS_NONE && s.n_family != 1) ||
         (s.n_family > 1 && !(s.family_hi > s.family_lo)))
@@ -1252,6 +1258,19 @@ int odw_upload_surface_samplers(odw_ctx* ctx, const odw_surface_sampler_desc* sa
     d.n_family = s.n_family;
     d.lo = s.family_lo;
     d.inv_step = s.n_family > 1 ? (double)(s.n_family - 1) / (s.family_hi - s.family_lo) : 0.0;
+    d.mu = s.mu;
+    d.n_atoms = s.n_atoms;
+    d.atom_mass = nullptr;
+    std::memset(d.atom_theta, 0, sizeof d.atom_theta);
+    std::memset(d.atom_phi, 0, sizeof d.atom_phi);
+    if (s.n_atoms) {
+      if ((rc = upload(ctx, sb.atom_mass, s.atom_mass, (size_t)s.n_family * (size_t)s.n_atoms * sizeof(double)))) return rc;
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      d.atom_mass = (const double*)sb.atom_mass.p;
+      for (int j = 0; j < s.n_atoms; ++j)
+        for (int c = 0; c < 3; ++c) { d.atom_theta[j][c] = s.atom_theta[3 * j + c]; d.atom_phi[j][c] = s.atom_phi[3 * j + c]; }
+    }
+    d.next = gs[2 * s.group + s.kind];       // (the chain runs from the last one uploaded to the first)
     gs[2 * s.group + s.kind] = i;
   }
   int rc;

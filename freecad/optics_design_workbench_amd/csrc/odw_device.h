@@ -118,6 +118,11 @@ struct DeviceSurfaceSampler {
   int32_t n_phi_knots, n_t_knots, n_t_rows, n_guide;
   int32_t axis, n_family;
   double lo, inv_step;          // member = rint((c - lo) * inv_step), clamped
+  double mu;                    // n1 / n2 this sampler is for (-1: total reflection, 0: every hit)
+  int32_t next;                 // the next sampler of the same (group, kind), or -1
+  int32_t n_atoms;              // discrete events (odw_surface_sampler_desc)
+  const double* atom_mass;      // [n_family][n_atoms]
+  double atom_theta[ODW_SURF_MAX_ATOMS][3], atom_phi[ODW_SURF_MAX_ATOMS][3];
 };
 
 // surface source (odw_surface_source_desc)

@@ -1071,21 +1071,54 @@ __device__ __forceinline__ void surface_draw(const DeviceSurfaceSampler* sp, dou
     philox4x32_10(m0, m1, m2, m3, (uint32_t)seed, (uint32_t)(seed >> 32));
     k = k0 + (u53(m0, m1) < frac ? 1 : 0);
   }
+  uint32_t c0 = (uint32_t)ray, c1 = (uint32_t)(ray >> 32), c2 = ordinal, c3 = stream;
+  philox4x32_10(c0, c1, c2, c3, (uint32_t)seed, (uint32_t)(seed >> 32));
+  double u_phi = u53(c0, c1);
+  const double u_t = u53(c2, c3);
+  if (S.n_atoms) {
+    // discrete events (DiracDelta terms): atom j owns [sum of the masses before it, + its own) of u_phi; what is
+    // left of the unit interval goes on as the tables' u_phi
+    double acc = 0.0;
+    for (int j = 0; j < S.n_atoms; ++j) {
+      const double pj = S.atom_mass[(size_t)k * (size_t)S.n_atoms + j];
+      if (u_phi < acc + pj) {
+        theta = S.atom_theta[j][0] + S.atom_theta[j][1] * theta_in + S.atom_theta[j][2] * theta_refl;
+        phi = S.atom_phi[j][0] != 0.0 ? S.atom_phi[j][1] + (u_phi - acc) / pj * (S.atom_phi[j][2] - S.atom_phi[j][1]) : S.atom_phi[j][1];
+        return;
+      }
+      acc += pj;
+    }
+    u_phi = fmin((u_phi - acc) / (1.0 - acc), 0.99999999999999989);
+  }
   TableView tv;
   tv.phi_tab = S.phi_tab + (size_t)k * (size_t)S.n_phi_knots * 2;
   tv.t_tab = S.t_tab + (size_t)k * (size_t)S.n_t_rows * (size_t)S.n_t_knots * 2;
   tv.t_guide = S.t_guide + (size_t)k * (size_t)S.n_t_rows * (size_t)(S.n_guide + 1);
   tv.n_phi_knots = S.n_phi_knots; tv.n_t_knots = S.n_t_knots; tv.n_t_rows = S.n_t_rows; tv.n_guide = S.n_guide;
   tv.phi_guide = nullptr; tv.n_phi_guide = 0;
-  uint32_t c0 = (uint32_t)ray, c1 = (uint32_t)(ray >> 32), c2 = ordinal, c3 = stream;
-  philox4x32_10(c0, c1, c2, c3, (uint32_t)seed, (uint32_t)(seed >> 32));
-  sample_tables(tv, u53(c0, c1), u53(c2, c3), theta, phi);
+  sample_tables(tv, u_phi, u_t, theta, phi);
+}
+
+// the sampler of a (group, kind) chain that serves a hit with n1 / n2 = mu (mu <= 0: total reflection): the one
+// whose own mu is nearest in log mu; samplers with mu = 0 serve every hit
+__device__ __forceinline__ int pick_sampler(const DeviceSurfaceSampler* samplers, int first, double mu) {
+  int best = first;
+  double dist = INFINITY;
+  for (int j = first; j >= 0; j = samplers[j].next) {
+    const double m = samplers[j].mu;
+    if (m == 0.0) return j;
+    const double d = (m < 0 || mu <= 0) ? ((m < 0) == (mu <= 0) ? 0.0 : INFINITY) : fabs(log(m / mu));
+    if (d < dist) { dist = d; best = j; }
+  }
+  return best;
 }
 
 // OpticalGroupProxy.applyStochasticRayCorrections (optical_group.py:279-323)
+// mu: n1 / n2 of a lens hit, <= 0 for total reflection; anything for mirrors
 __device__ __noinline__ d3 scatter(const DeviceSurfaceSampler* samplers, int s_primary, int s_modify,
-                                   uint64_t ray, uint64_t seed, uint32_t ordinal, d3 din, d3 ideal, d3 n) {
+                                   uint64_t ray, uint64_t seed, uint32_t ordinal, d3 din, d3 ideal, d3 n, double mu) {
   if (s_primary < 0 && s_modify < 0) return ideal;
+  if (s_primary >= 0 && samplers[s_primary].next >= 0) s_primary = pick_sampler(samplers, s_primary, mu);
   const double nl = sqrt(dot(n, n));
   const double theta_in = acos_clamped(dot(din, n) / nl);
   const double theta_refl = acos_clamped(dot(ideal, n) / (sqrt(dot(ideal, ideal)) * nl));
@@ -1302,7 +1335,7 @@ __device__ __forceinline__ void interact(const TraceParams& P, cf64 group_f64, c
   if (gtype == ODW_OPT_MIRROR) {
     const d3 ideal = mirror(dir, n);
     if (STOCH) dir = scatter(P.samplers, P.group_sampler[2 * g], P.group_sampler[2 * g + 1], ray, P.seed, (uint32_t)nint,
-                             dir, ideal, n);
+                             dir, ideal, n, 1.0);
     else dir = ideal;
     power *= group_f64[4 * g + 1];
     ++seq;
@@ -1313,7 +1346,7 @@ __device__ __forceinline__ void interact(const TraceParams& P, cf64 group_f64, c
     bool tir;
     const d3 ideal = snells_law(dir, n1, n2, n, tir);
     if (STOCH) dir = scatter(P.samplers, P.group_sampler[2 * g], P.group_sampler[2 * g + 1], ray, P.seed, (uint32_t)nint,
-                             dir, ideal, n);
+                             dir, ideal, n, tir ? -1.0 : n1 / n2);
     else dir = ideal;
     if (!entering && !tir && medium == g) { medium = -1; ++seq; }
   } else if (gtype == ODW_OPT_ABSORBER) {

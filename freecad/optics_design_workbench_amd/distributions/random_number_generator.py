@@ -155,6 +155,9 @@ class VectorRandomVariable:
       c = np.concatenate([[0.0], np.cumsum(p)])
       cdf0 = (c / c[-1])[None, :]
     cdf1 = np.concatenate([[0.0], np.cumsum(marg)])
+    # integral of the density over its domain (mid-point rule, like the tables): what a discrete event's
+    # weight is compared with (freecad_elements/optical_group.py)
+    self._mass = float(cdf1[-1]) * float(e0[1] - e0[0]) * float(e1[1] - e1[0])
     cdf1 = cdf1 / cdf1[-1]
     self._tables = SamplerTables(e0, cdf0, e1, cdf1)
     self._order = order
@@ -165,6 +168,12 @@ class VectorRandomVariable:
     if self._tables is None:
       self.compile()
     return self._tables
+
+  def mass(self):
+    """integral of the (unnormalised) density over the domain, for the constants last compiled with"""
+    if self._tables is None:
+      self.compile()
+    return self._mass
 
   def draw(self, N=None, constants=None):
     """host draw with numpy's global RNG, consuming uniforms in the

@@ -275,8 +275,12 @@ def bakeScene(doc, source=None, surfaceFamily=None):
   # stochastic surfaces (optical_group.py:212-323): tables per (group, kind)
   from ..freecad_elements import optical_group as _og
   surface_samplers = []
+  # (groups a ray can be inside of: their refractive indices decide which n1 / n2 a lens hit can have)
+  media = {gi: float(g._props.get('RefractiveIndex', 1.0)) for gi, g in enumerate(groups)
+           if g._props.get('OpticalType', 'Mirror') == 'Lens'
+           or (g._props.get('OpticalType') == 'Grating' and str(g._props.get('GratingType', '')).lower().startswith('trans'))}
   for gi, g in enumerate(groups):
-    surface_samplers += _og.surfaceSamplers(g, gi, n_family=surfaceFamily or _og.DEFAULT_FAMILY)
+    surface_samplers += _og.surfaceSamplers(g, gi, n_family=surfaceFamily or _og.DEFAULT_FAMILY, media=media)
   prims = []
   prim_group, prim_solid = [], []
   meshes = []                    # (group, solid id, world vertices, triangles, world normals or None, source)

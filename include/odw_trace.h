@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ODW_ABI_VERSION 6
+#define ODW_ABI_VERSION 7
 
 /* ---- return codes ------------------------------------------------------ */
 enum {
@@ -172,9 +172,19 @@ typedef struct odw_source_desc {
  *     out = Rot(out, phi) * Rot(out x dirIn, theta) * out
  * (Rot(axis, angle) = FreeCAD Rotation; a zero axis is the identity.)
  * Uniforms: Philox4x32-10, key = seed, counter = (ray_lo, ray_hi,
- * intersection ordinal 1.., 1 + kind); words (0,1) -> u_phi, (2,3) -> u_theta. */
+ * intersection ordinal 1.., 1 + kind); words (0,1) -> u_phi, (2,3) -> u_theta.
+ * mu: several samplers may serve one (group, ODW_SURF_PRIMARY) of a LENS whose density names both theta_in
+ *   and theta_refl -- the two are tied by Snell's law, theta_refl = asin(mu sin theta_in), mu = n1 / n2 of the
+ *   hit (ray.py:171-199) --: one family over theta_in per value of mu; the hit takes the sampler whose mu is
+ *   its own (nearest in log mu); mu = -1 serves total reflection (theta_refl = pi - theta_in), mu = 0 every hit.
+ * Atoms: DiracDelta terms of the density (the reference's analytic mode with discrete events,
+ *   random_number_generator.py:204-320): with probability atom_mass[member][j] the draw is
+ *   theta = a0 + a1 theta_in + a2 theta_refl, phi = b (rule 0) or uniform over [lo, hi] (rule 1); else the
+ *   tables.  Decided by u_phi: atom j owns [sum of the masses before it, + its own); what is left of the
+ *   unit interval is stretched back to [0, 1) and goes on as u_phi of the tables (or as the uniform of rule 1). */
 enum { ODW_SURF_PRIMARY = 0, ODW_SURF_MODIFY = 1 };
 enum { ODW_SURF_AXIS_NONE = 0, ODW_SURF_AXIS_THETA_IN = 1, ODW_SURF_AXIS_THETA_REFL = 2 };
+#define ODW_SURF_MAX_ATOMS 4
 typedef struct odw_surface_sampler_desc {
   int32_t group;           /* index into the group tables (Mirror or Lens)    */
   int32_t kind;            /* ODW_SURF_PRIMARY / ODW_SURF_MODIFY              */
@@ -189,6 +199,12 @@ typedef struct odw_surface_sampler_desc {
   int32_t n_t_rows;        /* n_phi_knots-1, or 1 if the density is phi-free  */
   const double* t_edges;   /* [n_t_knots]                                     */
   const double* t_cdf;     /* [n_family*n_t_rows*n_t_knots]                   */
+  double mu;               /* > 0: n1 / n2 this sampler is for; -1: total     */
+                           /* reflection on a lens; 0: every hit              */
+  int32_t n_atoms;         /* <= ODW_SURF_MAX_ATOMS discrete events, or 0     */
+  const double* atom_mass; /* [n_family*n_atoms] probability per member       */
+  const double* atom_theta;/* [n_atoms*3] a0, a1 (x theta_in), a2 (x theta_refl) */
+  const double* atom_phi;  /* [n_atoms*3] rule (0 fixed, 1 uniform), lo, hi   */
 } odw_surface_sampler_desc;
 
 /* Surface source = SurfaceSourceProxy._generateRays(mode='true')

@@ -67,7 +67,8 @@ class SurfaceSamplerDesc(C.Structure):
   _fields_ = [('group', C.c_int32), ('kind', C.c_int32), ('family_axis', C.c_int32), ('n_family', C.c_int32),
               ('family_lo', C.c_double), ('family_hi', C.c_double), ('n_phi_knots', C.c_int32),
               ('phi_edges', _pd), ('phi_cdf', _pd), ('n_t_knots', C.c_int32), ('n_t_rows', C.c_int32),
-              ('t_edges', _pd), ('t_cdf', _pd)]
+              ('t_edges', _pd), ('t_cdf', _pd), ('mu', C.c_double), ('n_atoms', C.c_int32),
+              ('atom_mass', _pd), ('atom_theta', _pd), ('atom_phi', _pd)]
 
 
 def build(force=False):
@@ -197,14 +198,20 @@ def set_surface_samplers(samplers, explicit_ray_seed=0):
     d.family_lo, d.family_hi = float(s.lo), float(s.hi)
     d.n_phi_knots, d.n_t_knots, d.n_t_rows = len(phi_edges), len(t_edges), int(t_cdf.shape[-2])
     d.phi_edges, d.phi_cdf, d.t_edges, d.t_cdf = (_p(a, _pd) for a in (phi_edges, phi_cdf, t_edges, t_cdf))
+    d.mu = float(getattr(s, 'mu', 0.0))
+    d.n_atoms = int(getattr(s, 'n_atoms', 0) or 0)
+    if d.n_atoms:
+      am, at, ap = (_arr(getattr(s, n), np.float64) for n in ('atom_mass', 'atom_theta', 'atom_phi'))
+      keep += [am, at, ap]
+      d.atom_mass, d.atom_theta, d.atom_phi = _p(am, _pd), _p(at, _pd), _p(ap, _pd)
   _surface_keep = keep
   lib().odw_oracle_set_surface_samplers(arr, C.c_int32(len(samplers)), C.c_uint64(int(explicit_ray_seed)))
 
 
-def scatter(group, ray, seed, ordinal, din, ideal, normal):
+def scatter(group, ray, seed, ordinal, din, ideal, normal, mu=0.0):
   a, b, c = ((C.c_double * 3)(*v) for v in (din, ideal, normal))
   out = (C.c_double * 3)()
-  lib().odw_oracle_scatter(C.c_int(group), C.c_uint64(ray), C.c_uint64(seed), C.c_uint32(ordinal), a, b, c, out)
+  lib().odw_oracle_scatter(C.c_int(group), C.c_uint64(ray), C.c_uint64(seed), C.c_uint32(ordinal), a, b, c, C.c_double(mu), out)
   return np.array(out[:])
 
 

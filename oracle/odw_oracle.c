@@ -1006,10 +1006,19 @@ int odw_oracle_set_surface_samplers(const odw_surface_sampler_desc* s, int32_t n
   return ODW_OK;
 }
 
-static const odw_surface_sampler_desc* find_sampler(int group, int kind) {
-  for (int i = 0; i < g_n_samplers; ++i)
-    if (g_samplers[i].group == group && g_samplers[i].kind == kind) return &g_samplers[i];
-  return NULL;
+/* the sampler of (group, kind) that serves a hit with n1 / n2 = mu (mu <= 0: total reflection): mu = 0
+ * samplers serve every hit, else the one nearest in log mu (include/odw_trace.h)                          */
+static const odw_surface_sampler_desc* find_sampler(int group, int kind, double mu) {
+  const odw_surface_sampler_desc* best = NULL;
+  double dist = INFINITY;
+  for (int i = 0; i < g_n_samplers; ++i) {
+    const odw_surface_sampler_desc* S = &g_samplers[i];
+    if (S->group != group || S->kind != kind) continue;
+    if (S->mu == 0.0) return S;
+    double d = (S->mu < 0 || mu <= 0) ? (((S->mu < 0) == (mu <= 0)) ? 0.0 : INFINITY) : fabs(log(S->mu / mu));
+    if (!best || d < dist) { dist = d; best = S; }
+  }
+  return best;
 }
 
 /* FreeCAD Rotation(axis, angle) * v (Base::Rotation::setValue normalises the
@@ -1044,6 +1053,27 @@ static void surface_draw(const odw_surface_sampler_desc* S, double theta_in, dou
     odw_oracle_philox(mctr, mkey, mw);
     k = k0 + (u53(mw[0], mw[1]) < frac ? 1 : 0);
   }
+  uint32_t ctr[4] = {(uint32_t)ray, (uint32_t)(ray >> 32), ordinal, stream};
+  uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  uint32_t w[4];
+  odw_oracle_philox(ctr, key, w);
+  double u_phi = u53(w[0], w[1]), u_t = u53(w[2], w[3]);
+  if (S->n_atoms) {
+    /* discrete events: atom j owns [sum of the masses before it, + its own) of u_phi */
+    double acc = 0.0;
+    for (int j = 0; j < S->n_atoms; ++j) {
+      double pj = S->atom_mass[(size_t)k * (size_t)S->n_atoms + j];
+      if (u_phi < acc + pj) {
+        const double* a = S->atom_theta + 3 * j;
+        const double* b = S->atom_phi + 3 * j;
+        *theta = a[0] + a[1] * theta_in + a[2] * theta_refl;
+        *phi = b[0] != 0.0 ? b[1] + (u_phi - acc) / pj * (b[2] - b[1]) : b[1];
+        return;
+      }
+      acc += pj;
+    }
+    u_phi = fmin((u_phi - acc) / (1.0 - acc), 0.99999999999999989);
+  }
   odw_source_desc t;
   memset(&t, 0, sizeof t);
   t.n_phi_knots = S->n_phi_knots;
@@ -1053,16 +1083,12 @@ static void surface_draw(const odw_surface_sampler_desc* S, double theta_in, dou
   t.n_t_rows = S->n_t_rows;
   t.t_edges = S->t_edges;
   t.t_cdf = S->t_cdf + (size_t)k * (size_t)S->n_t_rows * (size_t)S->n_t_knots;
-  uint32_t ctr[4] = {(uint32_t)ray, (uint32_t)(ray >> 32), ordinal, stream};
-  uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
-  uint32_t w[4];
-  odw_oracle_philox(ctr, key, w);
-  sample_one(&t, u53(w[0], w[1]), u53(w[2], w[3]), theta, phi);
+  sample_one(&t, u_phi, u_t, theta, phi);
 }
 
-static v3 scatter(int group, uint64_t ray, uint64_t seed, uint32_t ordinal, v3 din, v3 ideal, v3 n) {
-  const odw_surface_sampler_desc* prim = find_sampler(group, ODW_SURF_PRIMARY);
-  const odw_surface_sampler_desc* modi = find_sampler(group, ODW_SURF_MODIFY);
+static v3 scatter(int group, uint64_t ray, uint64_t seed, uint32_t ordinal, v3 din, v3 ideal, v3 n, double mu) {
+  const odw_surface_sampler_desc* prim = find_sampler(group, ODW_SURF_PRIMARY, mu);
+  const odw_surface_sampler_desc* modi = find_sampler(group, ODW_SURF_MODIFY, mu);
   if (!prim && !modi) return ideal;
   double nl = len(n);
   double theta_in = acos_clamped(dot(din, n) / nl);
@@ -1082,9 +1108,9 @@ static v3 scatter(int group, uint64_t ray, uint64_t seed, uint32_t ordinal, v3 d
 
 /* one applyStochasticRayCorrections call with explicit vectors (unit tests) */
 int odw_oracle_scatter(int group, uint64_t ray, uint64_t seed, uint32_t ordinal, const double* din,
-                       const double* ideal, const double* normal, double* out) {
+                       const double* ideal, const double* normal, double mu, double* out) {
   v3 r = scatter(group, ray, seed, ordinal, V(din[0], din[1], din[2]), V(ideal[0], ideal[1], ideal[2]),
-                 V(normal[0], normal[1], normal[2]));
+                 V(normal[0], normal[1], normal[2]), mu);
   out[0] = r.x; out[1] = r.y; out[2] = r.z;
   return ODW_OK;
 }
@@ -1177,7 +1203,7 @@ static void trace_one(const odw_scene_desc* sc, const odw_limits* lim,
     int type = sc->group_type[g];
     if (type == ODW_OPT_MIRROR) {
       v3 din = mul(dir, 1.0 / len(dir));
-      dir = scatter(g, ray, seed, (uint32_t)nint, din, mirror(dir, n), n);
+      dir = scatter(g, ray, seed, (uint32_t)nint, din, mirror(dir, n), n, 1.0);
       power *= sc->group_refl[g];
       seq++;
     } else if (type == ODW_OPT_LENS) {
@@ -1192,7 +1218,8 @@ static void trace_one(const odw_scene_desc* sc, const odw_limits* lim,
       }
       int tir;
       v3 din = mul(dir, 1.0 / len(dir));
-      dir = scatter(g, ray, seed, (uint32_t)nint, din, snells_law(din, n1, n2, n, &tir), n);
+      v3 ideal = snells_law(din, n1, n2, n, &tir);
+      dir = scatter(g, ray, seed, (uint32_t)nint, din, ideal, n, tir ? -1.0 : n1 / n2);
       if (!entering && !tir && medium == g) { medium = -1; seq++; }
     } else if (type == ODW_OPT_GRATING) {
       v3 gd = V(sc->group_grating_dir[3 * g], sc->group_grating_dir[3 * g + 1],

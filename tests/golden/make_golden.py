@@ -381,6 +381,40 @@ def make_surface(rng):
   np.savez_compressed(os.path.join(OUT, 'surface_samplers.npz'), **out)
 
 
+# densities with DiracDelta terms: the reference's analytic mode with discrete events
+# (random_number_generator.py:204-320).  Its draws consume the uniforms in another order than the device's
+# sampler, so what is pinned is the distribution: samples of the reference for constants on family knots.
+ATOM_CASES = [
+  # (name, density, theta domain, phi domain, theta_in) -- mirror: theta_refl = pi - theta_in.  (Continuum parts the
+  # reference's symbolic inversion finishes within its two-second deadline: it gives up on abs(), Gaussians ...)
+  ('ring_plus_lobe', 'DiracDelta(theta-theta_in) + cos(theta)', (0, np.pi / 2), (0, 2 * np.pi), 40 * (np.pi / 2) / 128),
+  ('ring_only', 'DiracDelta(theta-theta_in)', (0, np.pi / 2), (0, 2 * np.pi), 16 * (np.pi / 2) / 128),
+  ('two_rings', '0.25*DiracDelta(theta-theta_in) + 0.5*DiracDelta(theta-0.2) + cos(theta)', (0, np.pi / 2), (0, 2 * np.pi),
+   100 * (np.pi / 2) / 128),
+]
+
+
+def make_surface_atoms(rng):
+  N = 6000
+  out = {}
+  for name, dens, tdom, pdom, c in ATOM_CASES:
+    vrv = rng.VectorRandomVariable(probabilityDensity='(' + dens + ')', variableOrder=('theta', 'phi'),
+                                   variableDomains=dict(theta=tdom, phi=pdom))
+    vrv.compile(theta_in=c, phi_in=0, theta_refl=np.pi - c, phi_refl=0)
+    assert vrv.mode() == 'analytic', vrv.mode()
+    np.random.seed(29)
+    th, ph = vrv.draw(N=N)
+    out[name + '_density'] = np.array(dens)
+    out[name + '_theta_domain'] = np.array(tdom)
+    out[name + '_phi_domain'] = np.array(pdom)
+    out[name + '_theta_in'] = np.array(c)
+    out[name + '_theta'] = np.asarray(th, dtype=np.float64)
+    out[name + '_phi'] = np.asarray(ph, dtype=np.float64)
+    vals, counts = np.unique(np.round(np.asarray(th, dtype=np.float64), 9), return_counts=True)
+    print('atoms', name, {float(v): int(k) for v, k in zip(vals, counts) if k > 50})
+  np.savez_compressed(os.path.join(OUT, 'surface_atoms.npz'), **out)
+
+
 # VectorRandomVariable.drawPseudo (random_number_generator.py:562-682) as the
 # sources call it (point_source.py:670): N = RaysPerIteration
 PSEUDO_CASES = [
@@ -503,6 +537,7 @@ if __name__ == '__main__':
   make_hist(hits)
   make_fan_rays(io, rng, pbd)
   make_surface(rng)
+  make_surface_atoms(rng)
   make_pseudo(rng)
   make_fan_math(hits)
   make_scalar(rng)

@@ -260,6 +260,42 @@ def test_stochastic_surfaces(tracer, oracle):
   tracer.setSurfaceSeed(0)
 
 
+def test_stochastic_atoms_and_snell_families(tracer, oracle):
+  """densities with DiracDelta terms (discrete events beside a continuum: a partly specular, partly diffuse mirror; a
+  cone of fixed opening angle) and a lens density that names theta_in AND theta_refl (one table family per n1 / n2,
+  picked by the hit): device == oracle on whole trajectories"""
+  sc, lim = build([
+      ('Mirror', lambda d: [make.makeBox(d, 'M1', 30, 30, 1, base=(-15, -15, 20))],
+       dict(ReflectedProbabilityDensity='3*DiracDelta(theta-theta_refl)*DiracDelta(phi-phi_refl) + abs(cos(theta))*(1+0.3*cos(phi))',
+            PowerThetaDomain='pi/2, pi', PowerPhiDomain='0, 2*pi')),
+      ('Lens', lambda d: [make.makeSphere(d, 'L1', 6, base=(0, 0, -15))],
+       dict(RefractiveIndex=1.5, RefractedProbabilityDensity='exp(-((theta-theta_refl)/(0.05+0.1*theta_in))**2)',
+            PowerThetaDomain='0, pi', PowerPhiDomain='-0.3, 0.3')),
+      ('Mirror', lambda d: [make.makeBox(d, 'M2', 30, 1, 30, base=(-15, 25, -15))],
+       dict(name='OpticalMirrorGroup2', ReflectedProbabilityDensity='DiracDelta(theta-theta_refl) + 0.2*DiracDelta(theta-2.9)',
+            PowerThetaDomain='pi/2, pi', PowerPhiDomain='0, 2*pi')),
+      ('Absorber', lambda d: [make.makeBox(d, 'Wall', 400, 400, 1, base=(-200, -200, -60))], {}),
+  ], settings=dict(MaxIntersections=12))
+  kinds = [(s.group, s.kind, s.n_atoms, s.mu) for s in sc.surface_samplers]
+  assert kinds[0] == (0, 0, 1, 0.0) and kinds[-1] == (2, 0, 2, 0.0)
+  assert sorted(k[3] for k in kinds if k[0] == 1) == [-1.0, 1 / 1.5, 1.0, 1.5]      # vacuum and the lens itself as media
+  o, d = aimed_rays(20000, [[0, 0, 20], [0, 0, -15], [0, 25, 0]], 3.0, 17, radius=45.0)
+  tracer.setSurfaceSeed(99)
+  tracer.setScene(sc)
+  tracer.setLimits(lim)
+  tracer.setDetector(None)
+  tracer.reserveHits(len(o) * (lim.max_intersections + 1))
+  tracer.reset()
+  tracer.traceRays(o, d)
+  tracer.sync()
+  g, gc = tracer.hits(), tracer.counters()
+  ref = oracle.trace_rays(sc, lim, o, d, surface_seed=99, nthreads=8)
+  r, rc = ref['hits'], ref['counters']
+  assert rc['recorded_hits'] > 30000
+  assert_same_short_paths(g, gc, r, rc, len(o), max_len=12)
+  tracer.setSurfaceSeed(0)
+
+
 def test_stochastic_mirror_seeded_launch(tracer, oracle):
   """odw_trace (in-kernel generation) with a diffuse mirror: surface draws are
   keyed by the launch seed; counters, tags and histogram bins identical"""

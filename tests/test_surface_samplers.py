@@ -75,11 +75,16 @@ def test_dirac_modification_is_identity_and_others_are_rejected():
   g = _group('Absorber', RayModificationProbabilityDensity='DiracDelta(theta-1)')
   assert optical_group.surfaceSamplers(g, 0) == []
   # the ideal direction with certainty = an ideal surface
-  for dens in ('DiracDelta(theta-theta_refl) * DiracDelta(phi-phi_refl)', 'DiracDelta(theta-theta_refl)'):
-    assert optical_group.surfaceSamplers(_group('Mirror', ReflectedProbabilityDensity=dens), 0) == []
-    assert optical_group.surfaceSamplers(_group('Lens', RefractedProbabilityDensity=dens), 0) == []
-  with pytest.raises(NotImplementedError):
-    optical_group.surfaceSamplers(_group('Mirror', ReflectedProbabilityDensity='DiracDelta(theta-theta_in)'), 0)
+  dens = 'DiracDelta(theta-theta_refl) * DiracDelta(phi-phi_refl)'
+  assert optical_group.surfaceSamplers(_group('Mirror', ReflectedProbabilityDensity=dens), 0) == []
+  assert optical_group.surfaceSamplers(_group('Lens', RefractedProbabilityDensity=dens), 0) == []
+  # ... but without the second factor phi is uniform over its domain (the reference's analytic mode: a cone
+  # around the normal): a discrete event, see test_dirac_terms_become_atoms
+  assert len(optical_group.surfaceSamplers(_group('Mirror', ReflectedProbabilityDensity='DiracDelta(theta-theta_refl)'), 0)) == 1
+  for dens in ('DiracDelta(theta**2-theta_in)', 'DiracDelta(phi-1)*cos(theta)', 'cos(DiracDelta(theta))',
+               'DiracDelta(theta-theta_in)*cos(phi)', 'DiracDelta(theta-theta_in**2)'):
+    with pytest.raises(NotImplementedError):
+      optical_group.surfaceSamplers(_group('Mirror', ReflectedProbabilityDensity=dens), 0)
   with pytest.raises(ValueError):     # modification draws have no constants (optical_group.py:317)
     optical_group.surfaceSamplers(_group('Mirror', RayModificationProbabilityDensity='exp(-(theta-theta_in)**2)'), 0)
   with pytest.raises(ValueError):
@@ -262,5 +267,99 @@ def test_family_members_are_mixed_between_knots(oracle):
     assert abs(hi - lo) > 0.2                                   # the two members differ clearly
     for frac in (0.3, 0.7):
       assert means[frac] == pytest.approx(lo + frac * (hi - lo), abs=4 * 0.5 * abs(hi - lo) / np.sqrt(6000) + 3e-3)
+  finally:
+    oracle.set_surface_samplers(None)
+
+
+# --- discrete events (DiracDelta terms) and lens densities with both constants ----------------------
+@pytest.fixture(scope='module')
+def atoms_golden():
+  return np.load(os.path.join(GOLDEN, 'surface_atoms.npz'))
+
+
+def _scattered(oracle, sampler_list, theta_in, n=6000, mu=1.0, seed=5):
+  """(theta, phi) of n oracle draws for a hit at theta_in on group 0 (mirror: theta_refl = pi - theta_in): recovered
+  from the outgoing directions out = Rot(normal, phi) Rot(normal x dirIn, theta) normal with normal = z"""
+  nrm = np.array([0.0, 0.0, 1.0])
+  din = np.array([np.sin(theta_in), 0.0, np.cos(theta_in)])
+  ideal = din - 2 * nrm * din.dot(nrm)
+  oracle.set_surface_samplers(sampler_list, explicit_ray_seed=seed)
+  th, ph = np.empty(n), np.empty(n)
+  for r in range(n):
+    o = oracle.scatter(0, r, seed, 1, din, ideal, nrm, mu=mu)
+    th[r] = np.arccos(np.clip(o[2], -1, 1))
+    # Rot(z, phi) Rot(z x din, theta) z: azimuth of the tilted normal = phi + azimuth(z x din) - pi/2 ... = phi here
+    ph[r] = np.arctan2(o[1], o[0]) % (2 * np.pi)
+  oracle.set_surface_samplers(None)
+  return th, ph
+
+
+@pytest.mark.parametrize('name', ['ring_plus_lobe', 'ring_only', 'two_rings'])
+def test_dirac_terms_become_atoms(oracle, atoms_golden, name):
+  """densities with DiracDelta terms against samples of the reference's analytic mode (surface_atoms.npz): the share
+  of every discrete event and the distribution of the continuum"""
+  import scipy.stats
+  g = atoms_golden
+  dens, c = str(g[name + '_density']), float(g[name + '_theta_in'])
+  grp = _group('Mirror', ReflectedProbabilityDensity=dens, PowerThetaDomain='%.17g, %.17g' % tuple(g[name + '_theta_domain']),
+               PowerPhiDomain='%.17g, %.17g' % tuple(g[name + '_phi_domain']))
+  ss = optical_group.surfaceSamplers(grp, 0)
+  assert len(ss) == 1 and ss[0].n_atoms >= 1
+  s = ss[0]
+  ref_t, ref_p = g[name + '_theta'], g[name + '_phi']
+  th, ph = _scattered(oracle, ss, c, n=len(ref_t))
+  # discrete events: theta values that occur more than 50 times
+  vals, counts = np.unique(np.round(ref_t, 9), return_counts=True)
+  k = s.member(c)
+  assert abs(s.constant(k) - c) < 1e-12
+  at_atom = np.zeros(len(th), dtype=bool)
+  found = 0
+  for v, cnt in zip(vals, counts):
+    if cnt <= 50:
+      continue
+    mine = np.isclose(th, v, atol=1e-9)
+    p_ref = cnt / len(ref_t)
+    sigma = np.sqrt(p_ref * (1 - p_ref) / len(ref_t)) * np.sqrt(2)
+    assert abs(mine.mean() - p_ref) < 4.5 * sigma + 1e-12, (name, v, mine.mean(), p_ref)
+    at_atom |= mine
+    found += 1
+  assert found == s.n_atoms
+  assert abs(s.atom_mass[k].sum() - at_atom.mean()) < 0.03
+  # the continuum (what is not on an atom) and the azimuth: same distributions
+  ref_cont = ref_t[~np.isin(np.round(ref_t, 9), [v for v, cnt in zip(vals, counts) if cnt > 50])]
+  if len(ref_cont) > 200:
+    assert scipy.stats.ks_2samp(th[~at_atom], ref_cont).pvalue > 1e-3
+  assert scipy.stats.ks_2samp(ph, ref_p % (2 * np.pi)).pvalue > 1e-3
+
+
+def test_lens_density_with_both_constants_gets_one_family_per_mu(oracle):
+  """RefractedProbabilityDensity naming theta_in AND theta_refl: the two are tied by Snell's law through mu = n1 / n2
+  of the hit; one family over theta_in per value mu can take (entering from vacuum or another medium, leaving, total
+  reflection), picked by the hit's own mu.  Checked on the oracle: a lobe around theta_refl whose width grows
+  with theta_in lands on Snell's angle for every mu."""
+  dens = 'exp(-((theta-theta_refl)/(0.1+0.1*theta_in))**2)'
+  grp = _group('Lens', RefractedProbabilityDensity=dens, PowerThetaDomain='0, pi', RefractiveIndex=1.5)
+  ss = optical_group.surfaceSamplers(grp, 0, media={0: 1.5, 3: 1.2})
+  mus = sorted(s.mu for s in ss)
+  assert mus[0] == optical_group.MU_TOTAL_REFLECTION and len(ss) == len(set(mus)) >= 5
+  for want in (1 / 1.5, 1.5, 1.2 / 1.5, 1.2, 1.0):
+    assert min(abs(m - want) for m in mus) < 1e-12
+  assert all(s.axis == optical_group.AXIS_THETA_IN and s.n_family == optical_group.SNELL_FAMILY for s in ss)
+  nrm = np.array([0.0, 0.0, 1.0])
+  oracle.set_surface_samplers(ss, explicit_ray_seed=3)
+  try:
+    for mu, theta_in in ((1 / 1.5, 0.6), (1.5, 0.3), (1.2 / 1.5, 1.0), (-1.0, 0.9)):
+      din = np.array([np.sin(theta_in), 0.0, np.cos(theta_in)])
+      if mu < 0:
+        ideal, expect = din - 2 * nrm * din.dot(nrm), np.pi - theta_in
+      else:
+        expect = np.arcsin(mu * np.sin(theta_in))
+        ideal = np.array([np.sin(expect), 0.0, np.cos(expect)])
+      th = np.array([np.arccos(np.clip(oracle.scatter(0, r, 3, 1, din, ideal, nrm, mu=mu)[2], -1, 1)) for r in range(1500)])
+      # (between family knots two members are mixed: lobes narrower than the knots' spacing in theta_refl, 0.04 here,
+      #  would come out double-peaked -- the approximation DESIGN.md states for every table family)
+      width = (0.1 + 0.1 * theta_in) / np.sqrt(2)
+      assert abs(th.mean() - expect) < 5 * width / np.sqrt(len(th)) + 3e-3, (mu, th.mean(), expect)
+      assert 0.85 * width < th.std() < 1.15 * width, (mu, th.std(), width)
   finally:
     oracle.set_surface_samplers(None)
