@@ -225,6 +225,70 @@ class Revolved(Geometry):
     return ang(abs(self.r) + abs(self.extra)), ang(self.extra)
 
 
+class Parabola(Geometry):
+  """gp_Parab / gp_Parab2d: vertex c, axis of symmetry dx, focal length f: c + t^2 / (4 f) dx + t dy"""
+  kind = 'parabola'
+
+  def __init__(self, c, dx, dy, focal):
+    self.c, self.dx, self.dy, self.f = np.asarray(c, float), np.asarray(dx, float), np.asarray(dy, float), float(focal)
+
+  def eval(self, t):
+    t = np.asarray(t, float)[:, None]
+    return self.c + t * t / (4.0 * self.f) * self.dx + t * self.dy
+
+
+class Paraboloid(Geometry):
+  """Geom_SurfaceOfRevolution of a parabola about its own axis of symmetry: S(u, v) = the point C(v) of the
+  parabola turned by u about the axis (OpenCASCADE's parametrisation of a surface of revolution):
+  p + v^2 / (4 f) n + v (cos u dx + sin u dy), p = vertex, n = axis towards the open side, dx = the parabola's
+  own transverse direction, dy = axis x dx (axis = the direction of revolution, +n or -n)"""
+  kind = 'paraboloid'
+
+  def __init__(self, p, n, dx, dy, focal):
+    self.p, self.n, self.dx, self.dy = (np.asarray(a, float) for a in (p, n, dx, dy))
+    self.f = float(focal)
+
+  def _frame(self, u):
+    u = np.asarray(u, float)[:, None]
+    return np.cos(u) * self.dx + np.sin(u) * self.dy
+
+  def eval(self, u, v):
+    e, v = self._frame(u), np.asarray(v, float)[:, None]
+    return self.p + v * v / (4.0 * self.f) * self.n + v * e
+
+  def d1(self, u, v):
+    u = np.asarray(u, float)[:, None]
+    v = np.asarray(v, float)[:, None]
+    e = np.cos(u) * self.dx + np.sin(u) * self.dy
+    t = -np.sin(u) * self.dx + np.cos(u) * self.dy
+    return v * t, v / (2.0 * self.f) * self.n + e
+
+  def normal(self, u, v):
+    """dS/du x dS/dv normalised; at the vertex (v = 0) the limit: -+ the axis"""
+    e, v = self._frame(u), np.asarray(v, float)[:, None]
+    hand = np.sign(np.dot(np.cross(self.dx, self.dy), self.n)) or 1.0
+    # t x (v / 2f n + e) with t = de/du:  (t x n) v / 2f + t x e = hand (e v / 2f - n)
+    nrm = hand * (e * v / (2.0 * self.f) - self.n) * np.where(v < 0, -1.0, 1.0)
+    return nrm / np.linalg.norm(nrm, axis=1, keepdims=True)
+
+  def invert(self, x, hint):
+    d = np.asarray(x, float) - self.p
+    ex, ey = d @ self.dx, d @ self.dy
+    rho = np.hypot(ex, ey)
+    neg = hint[:, 1] < 0
+    u = np.arctan2(ey, ex) + np.where(neg, np.pi, 0.0)
+    u = hint[:, 0] + (u - hint[:, 0] + np.pi) % (2 * np.pi) - np.pi
+    u = np.where(rho > 1e-9 * max(abs(self.f), 1.0), u, hint[:, 0])
+    return np.stack([u, np.where(neg, -rho, rho)], axis=1)
+
+  def steps_range(self, tol, lo, hi):
+    """(du, dv) that keep the chord error below tol on lo <= (u, v) <= hi"""
+    # (half the tolerance for the parallels, half for the meridians: the sags of a cell's two directions add up)
+    rmax = max(abs(lo[1]), abs(hi[1]), 1e-12)
+    du = 2.0 * np.arccos(max(-1.0, 1.0 - min(0.5 * tol / rmax, 1.0)))
+    return du, 4.0 * np.sqrt(0.5 * tol * abs(self.f))       # curvature of the meridian <= 1 / (2 f)
+
+
 class BSplineSurface(Geometry):
   kind = 'bspline-surface'
 
@@ -435,12 +499,18 @@ class Payload:
       r1 = self._float()
       r2 = self._float() if t == 3 else r1
       return Conic(c, dx, dy, r1, r2, 'circle' if t == 2 else 'ellipse')
+    if t == 4:                               # parabola: vertex, [normal of its plane,] axis of symmetry, transverse, focal
+      c = self._floats(dim)
+      if dim == 3:
+        self._floats(3)
+      dx, dy = self._floats(dim), self._floats(dim)
+      return Parabola(c, dx, dy, self._float())
     if t == 7:
       return self._read_bspline_curve(dim)
     if t == 8:
       self._floats(2)
       return TrimmedCurve(self._read_curve(dim))
-    raise BRepError(f'{dim}-D curve kind {t} (parabola / hyperbola / Bezier / offset) is not read')
+    raise BRepError(f'{dim}-D curve kind {t} (hyperbola / Bezier / offset) is not read')
 
   def _read_surface(self):
     t = self._int()
@@ -467,10 +537,26 @@ class Payload:
       for i in range(nvk):
         vk[i], vm[i] = self._float(), self._int()
       return BSplineSurface(udeg, vdeg, poles, weights, uk, um, vk, vm, uper, vper)
+    if t == 7:
+      # surface of revolution: point and direction of the axis, then the basis curve.  Read when it is a
+      # paraboloid -- a parabola turned about its own axis of symmetry (parabolic mirrors, README "slotted
+      # parabolic mirrors") --, which the tracer knows as an analytic primitive
+      a, d = self._floats(3), self._floats(3)
+      c = self._read_curve(3)
+      basis = c.basis if isinstance(c, TrimmedCurve) else c
+      if basis.kind != 'parabola':
+        raise BRepError(f'surface of revolution of a {basis.kind} is not read (only of a parabola about its axis)')
+      d = d / np.linalg.norm(d)
+      n = basis.dx / np.linalg.norm(basis.dx)
+      off = basis.c - a
+      if abs(abs(n @ d) - 1.0) > 1e-9 or np.linalg.norm(off - (off @ d) * d) > 1e-9 * max(1.0, abs(basis.f)):
+        raise BRepError('surface of revolution of a parabola about another line than its axis is not read')
+      dx = basis.dy / np.linalg.norm(basis.dy)
+      return Paraboloid(basis.c, n, dx, np.cross(d, dx), basis.f)
     if t == 10:
       self._floats(4)
       return TrimmedSurface(self._read_surface())
-    raise BRepError(f'surface kind {t} (extrusion / revolution / Bezier / offset) is not read')
+    raise BRepError(f'surface kind {t} (extrusion / Bezier / offset) is not read')
 
   def _read_sub(self):
     t = self._next()

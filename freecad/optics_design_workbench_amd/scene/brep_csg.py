@@ -27,6 +27,7 @@ from . import brep_mesh
 from .placement import Placement
 
 BOX, SPHERE, CYLINDER, CONE, TORUS = range(5)
+PARABOLOID = 6
 
 
 def _frame(origin, z, x=None):
@@ -63,6 +64,8 @@ class _Surface:
       return rho - self.r
     if self.kind == 'cone':
       return (rho - (self.r + z * np.tan(self.extra))) * np.cos(self.extra)
+    if self.kind == 'paraboloid':                          # rho^2 = 4 f z, r = f: distance to first order
+      return (rho * rho - 4.0 * self.r * z) / (2.0 * np.sqrt(rho * rho + 4.0 * self.r * self.r))
     return np.hypot(rho - self.r, z) - self.extra          # torus
 
   def grad(self, x, h=1e-6):
@@ -72,10 +75,13 @@ class _Surface:
 
 def _surface_of(s, loc):
   """brep surface + its location -> _Surface in shape coordinates (None: not a quadric / torus)"""
-  if s.kind not in ('plane', 'sphere', 'cylinder', 'cone', 'torus'):
+  if s.kind not in ('plane', 'sphere', 'cylinder', 'cone', 'torus', 'paraboloid'):
     return None
   R = loc[:3, :3]
   p = R @ s.p + loc[:3, 3]
+  if s.kind == 'paraboloid':
+    axis = R @ s.n
+    return _Surface('paraboloid', p, axis / np.linalg.norm(axis), R @ s.dx, abs(s.f))
   if s.kind == 'plane':
     n = R @ np.cross(s.dx, s.dy)
     return _Surface('plane', p, n / np.linalg.norm(n), R @ s.dx)
@@ -168,6 +174,11 @@ def recognise(payload, mesh, tol=1e-6, samples=48):
         vs = -np.pi / 2 + np.pi * (np.arange(n_s) + 0.5) / n_s
       elif surf.kind == 'torus':
         vs = us.copy()
+      elif surf.kind == 'paraboloid':
+        # v = distance from the axis: as far as the box reaches
+        d = local - surf.p
+        rmax = np.linalg.norm(d - (d @ surf.n)[:, None] * surf.n, axis=1).max()
+        vs = rmax * (np.arange(n_s) + 0.5) / n_s
       else:
         z = (local - surf.p) @ surf.n
         z = z / np.cos(surf.extra) if surf.kind == 'cone' else z
@@ -218,6 +229,11 @@ def _primitive(s, sg, centre, size, far):
     return Node('prim', placement=Placement(base=s.p), kind=SPHERE, params=(s.r, 0.0, 0.0, 0.0))
   if s.kind == 'torus':
     return Node('prim', placement=_frame(s.p, s.axis, s.xdir), kind=TORUS, params=(s.r, s.extra, 0.0, 0.0))
+  if s.kind == 'paraboloid':
+    # x^2 + y^2 <= 4 f z up to a height beyond the solid (its cap is masked out: faces bit 0 only)
+    h = max((centre - s.p) @ s.axis, 0.0) + far
+    return Node('prim', placement=_frame(s.p, s.axis, s.xdir), kind=PARABOLOID, params=(s.r, h, 2.0 * np.sqrt(s.r * h), 0.0),
+                facemask=1)
   if s.kind == 'plane':
     # one face of a box that extends `far` to the material side: the face z = far of a box whose
     # local z runs along the outward normal (f < 0 is behind the plane; sg < 0 turns it round)

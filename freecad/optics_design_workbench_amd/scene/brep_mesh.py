@@ -145,7 +145,7 @@ class _Mesher:
       pc_idx = rep[1] if (rev and rep[1] is not None) else rep[0]
       pc = self.P.curves2d[pc_idx - 1]
       uv = pc.eval(rep[4] + sp * (rep[5] - rep[4]))
-      if isinstance(surf, brep.Revolved) and np.isfinite(xyz).all():
+      if isinstance(surf, (brep.Revolved, brep.Paraboloid)) and np.isfinite(xyz).all():
         # quadrics and tori: the parameters of the 3-D points themselves (stored p-curves of
         # imports are approximations: a rim circle wobbles about its v = const line, and the
         # triangulation fills the bulges with facets that stand across the surface); the
@@ -183,6 +183,8 @@ class _Mesher:
           n *= 2
         steps.append((hi[axis] - lo[axis]) / n)
       return steps[0], steps[1]
+    if surf.kind == 'paraboloid':
+      return surf.steps_range(self.tol, lo, hi)
     du, dv = surf.steps(self.tol)
     if du is None:       # cone: the largest radius of the face's v range
       rmax = max(abs(surf.r + lo[1] * np.sin(surf.extra)), abs(surf.r + hi[1] * np.sin(surf.extra)), 1e-9)
@@ -405,7 +407,7 @@ def _conforming_delaunay(loops, interior, scale, segs=None, requests=None):
   return p, tri
 
 
-def tessellate(payload, deflection=1e-3, max_grid=256, keep_root_location=True):
+def tessellate(payload, deflection=1e-3, max_grid=1024, keep_root_location=True):
   """-> ShapeMesh of every face of the payload (explorer order = FreeCAD's Face1, Face2, ...).
   deflection: largest distance between a facet and the surface (mm);
   keep_root_location=False leaves out the location stored with the root shape (FreeCAD keeps the

@@ -128,8 +128,14 @@ def test_face_order_is_the_explorer_order():
 
 def test_unsupported_payloads_fail_loudly():
   text = payload('nested-structure', 'Sphere.Shape.brp').decode()
-  with pytest.raises(brep.BRepError, match='surface kind 7'):
-    brep.load(text.replace('Surfaces 1\n4 ', 'Surfaces 1\n7 '))
+  with pytest.raises(brep.BRepError, match='surface kind 6'):       # linear extrusion: not read
+    brep.load(text.replace('Surfaces 1\n4 ', 'Surfaces 1\n6 '))
+  # a surface of revolution is read when its basis is a parabola about its own axis, and only then
+  from brep_fixtures import paraboloid_solid
+  with pytest.raises(brep.BRepError, match='revolution'):
+    brep.load(paraboloid_solid().replace('Surfaces 2\n7 0 0 0 0 0 1 \n4 ', 'Surfaces 2\n7 0 0 0 0 0 1 \n1 '))
+  with pytest.raises(brep.BRepError, match='revolution'):
+    brep.load(paraboloid_solid().replace('Surfaces 2\n7 0 0 0 0 0 1 ', 'Surfaces 2\n7 0 0 0 1 0 0 '))
   doc = Document()
   ghost = doc.addObject('Part::Feature', 'Ghost')
   make.makeMirror(doc, [ghost])
@@ -156,7 +162,36 @@ def _shape(tree):
     ('imported-stepfile-as-surface-source', 'Part__Feature001.Shape.brp', None),    # B-spline surfaces
 ])
 def test_solids_of_quadric_half_spaces_are_recognised(scene, member, expected):
-  P = brep.load(payload(scene, member))
+  _check_recognition(brep.load(payload(scene, member)), expected)
+
+
+@pytest.mark.parametrize('fixture,expected', [
+    ('paraboloid_solid', 'common(paraboloid, box, box)'),
+    ('parabolic_dish', 'cut(common(cylinder, box, box), paraboloid)'),
+])
+def test_surfaces_of_revolution_of_a_parabola_are_recognised(fixture, expected):
+  """Part::Revolution of a parabola about its axis (GeomTools surface kind 7 over curve kind 4): the blank of a
+  parabolic mirror (README.md "slotted parabolic mirrors").  Read, meshed to a closed surface of the right area,
+  recognised as the analytic paraboloid."""
+  import brep_fixtures
+  f, h = 2.5, 4.0
+  P = brep.load(getattr(brep_fixtures, fixture)(f, h))
+  m = brep_mesh.tessellate(P, deflection=1e-3, keep_root_location=False)
+  assert m.faces[0].kind == 'paraboloid'
+  t = m.vertices[m.triangles[m.faces[0].first:m.faces[0].first + m.faces[0].count]]
+  area = 0.5 * np.linalg.norm(np.cross(t[:, 1] - t[:, 0], t[:, 2] - t[:, 0]), axis=1).sum()
+  r = 2 * np.sqrt(f * h)
+  exact = np.pi * r / (6 * h * h) * ((r * r + 4 * h * h)**1.5 - r**3)      # lateral area of a paraboloid of revolution
+  assert abs(area / exact - 1) < 1e-3
+  # closed: every edge belongs to two facets, once in each direction
+  e = np.concatenate([m.triangles[:, [0, 1]], m.triangles[:, [1, 2]], m.triangles[:, [2, 0]]])
+  pos = np.round(m.vertices, 9)
+  key = lambda a, b: [tuple(pos[i]) + tuple(pos[j]) for i, j in zip(a, b)]
+  assert sorted(key(e[:, 0], e[:, 1])) == sorted(key(e[:, 1], e[:, 0]))
+  _check_recognition(P, expected)
+
+
+def _check_recognition(P, expected):
   m = brep_mesh.tessellate(P, deflection=1e-3, keep_root_location=False)
   r = brep_csg.recognise(P, m)
   # (the last box of a Common is the shape's bounding box, an operand without faces: the
@@ -177,6 +212,8 @@ def test_solids_of_quadric_half_spaces_are_recognised(scene, member, expected):
         i = ((local >= lo) & (local <= hi)).all(axis=1)
       elif fp.kind == geometry.SPHERE:
         i = np.linalg.norm(local, axis=1) <= fp.params[0]
+      elif fp.kind == geometry.PARABOLOID:
+        i = (local[:, 0]**2 + local[:, 1]**2 <= 4 * fp.params[0] * local[:, 2]) & (local[:, 2] <= fp.params[1])
       else:
         i = (np.hypot(local[:, 0], local[:, 1]) <= fp.params[0]) & (local[:, 2] >= 0) & (local[:, 2] <= fp.params[1])
       ok &= (i != fp.flip)             # tools of a Cut count from outside

@@ -219,6 +219,51 @@ def test_parabolic_mirror_focuses_a_parallel_beam(backend):
   assert np.abs(out - np.array([0, 0, 1.0])).max() < 1e-9
 
 
+@pytest.mark.parametrize('exact', [True, False])
+def test_parabolic_mirror_from_a_stored_brep_shape(backend, exact):
+  """the same mirror as a shape WITHOUT a parametric recipe (what a STEP import or a Part::Revolution leaves in the
+  file): a cylinder blank with a paraboloid cavity, stored as BRep text (tests/brep_fixtures.py).  Recognised as
+  Cut(cylinder, paraboloid): the reflections lie on the paraboloid to 1e-9 and run through the focus; as facets
+  (deflection 1e-3 mm): the same picture to the facet error."""
+  from brep_fixtures import parabolic_dish
+  from freecad.optics_design_workbench_amd.scene import geometry
+  from freecad.optics_design_workbench_amd.scene.fcstd import BRepPayload
+  f, h = 12.0, 10.0
+  old = geometry.BREP_EXACT
+  geometry.BREP_EXACT = exact
+  try:
+    doc, sc, lim = build([
+        ('Mirror', lambda d: [d.addObject('Part::Feature', 'Dish',
+                                          Shape=BRepPayload('Dish.Shape.brp', parabolic_dish(f, h, 2.0).encode()))], {}),
+        ('Absorber', lambda d: [make.makeSphere(d, 'Bead', 0.5, base=(0, 0, f))], {}),
+    ])
+  finally:
+    geometry.BREP_EXACT = old
+  assert (sc.prim_type == 6).sum() == (1 if exact else 0) and ((sc.prim_type == 5).sum() > 1000) == (not exact)
+  rs = np.random.RandomState(5)
+  xy = rs.uniform(-22, 22, (3000, 2))
+  rho = np.hypot(xy[:, 0], xy[:, 1])
+  xy = xy[(rho > 1.0) & (rho < 2 * np.sqrt(f * h) - 0.5)]
+  o = np.column_stack([xy, np.full(len(xy), 40.0)])
+  d = np.tile([0.0, 0.0, -1.0], (len(xy), 1))
+  hits = backend.traceRays(sc, lim, o, d)
+  grp = ((hits['tag'] >> np.uint64(48)) & np.uint64(0x7FFF)).astype(np.int64)
+  mirror, bead = hits[grp == 0], hits[grp == 1]
+  tol = 1e-9 if exact else 1.5e-3           # (deflection 1e-3 along the normal, up to 1.35e-3 along z at the rim)
+  assert len(mirror) == len(xy)
+  p = mirror['point']
+  assert np.abs(p[:, 2] - (p[:, 0]**2 + p[:, 1]**2) / (4 * f)).max() < tol
+  if exact:
+    assert len(bead) == len(xy)
+    miss = np.linalg.norm(np.cross(bead['direction'], np.array([0, 0, f]) - bead['point']), axis=1)
+    assert miss.max() < 1e-9
+  else:
+    # smooth vertex normals: the reflected rays pass the focus within the facet error of the normal (~1e-3 rad)
+    assert len(bead) > 0.99 * len(xy)
+    miss = np.linalg.norm(np.cross(bead['direction'], np.array([0, 0, f]) - bead['point']), axis=1)
+    assert miss.max() < 0.1
+
+
 def _parab_normal(p, f):
   g = np.column_stack([p[:, 0], p[:, 1], np.full(len(p), -2 * f)])
   return g / np.linalg.norm(g, axis=1)[:, None]
