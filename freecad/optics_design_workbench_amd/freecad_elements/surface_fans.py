@@ -10,8 +10,9 @@ much of the range the face fills, the effective lengths of the two parameter
 lines and whether the area element is uniform along one parameter, and then thin
 out the rows where parameter lines crowd (poles of a sphere).  `FaceView` offers
 the same four facilities for the faces this build knows: faces of stored BRep
-shapes (scene/brep.py: surface + trimming wires) and the faces of the untrimmed
-parametric primitives in OpenCASCADE's parametrisations.  The grid logic is
+shapes (scene/brep.py: surface + trimming wires), the faces of the untrimmed
+parametric primitives in OpenCASCADE's parametrisations, and the faces of boolean
+results over such primitives (each operand's faces, trimmed by the other operands).  The grid logic is
 restated on top of it; rays are handed to the tracer as explicit initial
 conditions (`odw_trace_rays`).
 """
@@ -34,9 +35,8 @@ class FaceView:
 
 
 # ------------------------------------------------------------------ faces of primitives
-def _primitive_faces(kind, params, to_world, names, dist_tol):
-  """FaceViews of an untrimmed primitive in OpenCASCADE's parametrisations; names: 'Face<k>' or all"""
-  from . import surface_source
+def _primitive_face_table(kind, params, to_world, dist_tol):
+  """{face bit position: FaceView} of an untrimmed primitive in OpenCASCADE's parametrisations"""
   R, t = to_world.m[:3, :3], to_world.m[:3, 3]
   world = lambda p: R @ np.asarray(p, float) + t
   wdir = lambda d: R @ np.asarray(d, float)
@@ -92,8 +92,31 @@ def _primitive_faces(kind, params, to_world, names, dist_tol):
                             lambda u, v, x, rr=rr: np.hypot(u, v) <= rr + dist_tol,
                             lambda u, v, s=s: wdir([0.0, 0.0, s]),
                             lambda u, v: (wdir([1.0, 0.0, 0.0]), wdir([0.0, 1.0, 0.0])))
+  elif kind == geometry.PARABOLOID:
+    # surface of revolution of the parabola (v, 0, v^2 / 4f) about z: u = angle, v = distance from the axis
+    f, h = p[0], p[1]
+    rr = 2.0 * np.sqrt(f * h)
+    faces[0] = FaceView(
+        (0.0, two_pi, 0.0, rr), np.pi * rr / (6 * h * h) * ((rr * rr + 4 * h * h)**1.5 - rr**3),
+        lambda u, v: world([v * np.cos(u), v * np.sin(u), v * v / (4 * f)]), lambda u, v, x: True,
+        lambda u, v: wdir(np.array([v * np.cos(u), v * np.sin(u), -2 * f]) / np.sqrt(v * v + 4 * f * f)),
+        lambda u, v: (wdir([-v * np.sin(u), v * np.cos(u), 0.0]), wdir([np.cos(u), np.sin(u), v / (2 * f)])))
+    faces[2] = FaceView((-rr, rr, -rr, rr), np.pi * rr * rr, lambda u, v: world([u, v, h]),
+                        lambda u, v, x: np.hypot(u, v) <= rr + dist_tol, lambda u, v: wdir([0.0, 0.0, 1.0]),
+                        lambda u, v: (wdir([1.0, 0.0, 0.0]), wdir([0.0, 1.0, 0.0])))
   else:
     raise geometry.UnsupportedGeometry(f'no fan grid for primitive kind {kind}')
+  return faces
+
+
+def _primitive_faces(kind, params, to_world, names, dist_tol):
+  """FaceViews of an untrimmed primitive; names: 'Face<k>' or all"""
+  from . import surface_source
+  faces = _primitive_face_table(kind, params, to_world, dist_tol)
+  if kind == geometry.PARABOLOID:
+    if names:
+      raise geometry.UnsupportedGeometry('faces of a paraboloid are not selected by name')
+    return [faces[0], faces[2]]
   if names:
     return [faces[surface_source._faceIndex(kind, params, n)] for n in names]
   # whole body: OpenCASCADE's face order (surface_source._faceIndex)
@@ -104,6 +127,131 @@ def _primitive_faces(kind, params, to_world, names, dist_tol):
     except geometry.UnsupportedGeometry:
       return out
     k += 1
+
+
+# ------------------------------------------------------------------ faces of boolean results
+def _inside_primitive(fp, x, tol):
+  """is the point inside the (closed) primitive, or within tol of its boundary"""
+  m = fp.to_world.m
+  q = (np.asarray(x, float) - m[:3, 3]) @ m[:3, :3]
+  p, k = fp.params, fp.kind
+  if k == geometry.BOX:
+    return bool(np.all(q >= -tol) and np.all(q <= np.array(p[:3]) + tol))
+  if k == geometry.SPHERE:
+    return bool(np.linalg.norm(q) <= p[0] + tol)
+  rho = np.hypot(q[0], q[1])
+  if k == geometry.CYLINDER:
+    return bool(rho <= p[0] + tol and -tol <= q[2] <= p[1] + tol)
+  if k == geometry.CONE:
+    z = min(max(q[2], 0.0), p[2])
+    return bool(-tol <= q[2] <= p[2] + tol and rho <= p[0] + (p[1] - p[0]) * z / p[2] + tol * np.hypot(1.0, (p[1] - p[0]) / p[2]))
+  if k == geometry.TORUS:
+    return bool(np.hypot(rho - p[0], q[2]) <= p[1] + tol)
+  if k == geometry.PARABOLOID:
+    return bool(q[2] <= p[1] + tol and rho * rho <= 4 * p[0] * q[2] + tol * np.sqrt(rho * rho + 4 * p[0] * p[0]) * 2)
+  raise geometry.UnsupportedGeometry(f'no containment test for primitive kind {k}')
+
+
+def _strictly_inside_primitive(fp, x, tol):
+  m = fp.to_world.m
+  q = (np.asarray(x, float) - m[:3, 3]) @ m[:3, :3]
+  p, k = fp.params, fp.kind
+  if k == geometry.BOX:
+    return bool(np.all(q > tol) and np.all(q < np.array(p[:3]) - tol))
+  if k == geometry.SPHERE:
+    return bool(np.linalg.norm(q) < p[0] - tol)
+  rho = np.hypot(q[0], q[1])
+  if k == geometry.CYLINDER:
+    return bool(rho < p[0] - tol and tol < q[2] < p[1] - tol)
+  if k == geometry.CONE:
+    return bool(tol < q[2] < p[2] - tol and rho < p[0] + (p[1] - p[0]) * q[2] / p[2] - tol * np.hypot(1.0, (p[1] - p[0]) / p[2]))
+  if k == geometry.TORUS:
+    return bool(np.hypot(rho - p[0], q[2]) < p[1] - tol)
+  if k == geometry.PARABOLOID:
+    return bool(q[2] < p[1] - tol and rho * rho < 4 * p[0] * q[2] - tol * np.sqrt(rho * rho + 4 * p[0] * p[0]) * 2)
+  raise geometry.UnsupportedGeometry(f'no containment test for primitive kind {k}')
+
+
+_TRIM_SCAN = 96       # samples per parameter when the trimmed extent of a face is looked for
+
+
+def _boolean_faces(tree, container, dist_tol):
+  """FaceViews of the result of Cut / Fuse / Common over primitives: every face of every operand that keeps a part
+  of itself in the result, trimmed by the other operands.  OpenCASCADE hands the reference such a result as faces
+  with the trimmed `ParameterRange` and an `isInside` that knows the trimming wires; here the trimming is the
+  conjunction of the operands' half-space conditions (geometry.flatten, the same conditions the tracer trims
+  with), the parameter range is the extent of the part that survives (scanned, then each bound refined by
+  bisection) and the area the sum of the area elements over the scan.  One view per operand face: OpenCASCADE
+  splits a face whose remainder is not connected, the grid recipe then runs per piece -- here it runs once over
+  their common extent.  Order: operands depth-first, faces in the primitive's own order."""
+  out = []
+  for fp in geometry.flatten(tree, container):
+    table = _primitive_face_table(fp.kind, fp.params, fp.to_world, dist_tol)
+    for f in sorted(table):
+      if not (fp.facemask >> f) & 1:
+        continue
+      view = table[f]
+
+      def valid(u, v, x, view=view, conds=fp.conds):
+        if not view.valid(u, v, x):
+          return False
+        for other, inside in conds:
+          # (a point of the face that lies ON the other operand's boundary belongs to the result's edge)
+          if inside and not _inside_primitive(other, x, dist_tol):
+            return False
+          if not inside and _strictly_inside_primitive(other, x, dist_tol):
+            return False
+        return True
+      u0, u1, v0, v1 = view.range
+      found = True
+      for _ in range(4):
+        # scan; where the surviving part fills less than half of the window in a direction, look again closer
+        us, vs = np.linspace(u0, u1, _TRIM_SCAN + 1), np.linspace(v0, v1, _TRIM_SCAN + 1)
+        ok = np.array([[valid(u, v, view.value(u, v)) for v in vs] for u in us])
+        if not ok.any():
+          found = False
+          break
+        iu, iv = np.nonzero(ok.any(axis=1))[0], np.nonzero(ok.any(axis=0))[0]
+        if max(iu[-1] - iu[0], 1) * 2 > _TRIM_SCAN and max(iv[-1] - iv[0], 1) * 2 > _TRIM_SCAN:
+          break
+        u0, u1 = us[max(iu[0] - 1, 0)], us[min(iu[-1] + 1, _TRIM_SCAN)]
+        v0, v1 = vs[max(iv[0] - 1, 0)], vs[min(iv[-1] + 1, _TRIM_SCAN)]
+      if not found:
+        continue
+
+      def any_on(axis, c):
+        if axis == 0:
+          return any(valid(c, v, view.value(c, v)) for v in vs)
+        return any(valid(u, c, view.value(u, c)) for u in us)
+
+      def refine(axis, grid, k_in, k_out):
+        """between sample k_in (part of the result somewhere along it) and its neighbour k_out (none)"""
+        if not 0 <= k_out < len(grid):
+          return grid[k_in]
+        a, b = grid[k_in], grid[k_out]
+        for _ in range(24):
+          c = 0.5 * (a + b)
+          if any_on(axis, c):
+            a = c
+          else:
+            b = c
+        return a
+      rng = (refine(0, us, iu[0], iu[0] - 1), refine(0, us, iu[-1], iu[-1] + 1),
+             refine(1, vs, iv[0], iv[0] - 1), refine(1, vs, iv[-1], iv[-1] + 1))
+      # area of what survives: area elements at the cell centres of the last scan
+      uc, vc = 0.5 * (us[1:] + us[:-1]), 0.5 * (vs[1:] + vs[:-1])
+      area = 0.0
+      for u in uc:
+        for v in vc:
+          if valid(u, v, view.value(u, v)):
+            du, dv = view.derivatives(u, v)
+            area += float(np.linalg.norm(np.cross(du, dv)))
+      area *= (us[1] - us[0]) * (vs[1] - vs[0])
+      if area <= 0:
+        continue
+      normal = (lambda u, v, view=view: -np.asarray(view.normal(u, v))) if fp.flip else view.normal
+      out.append(FaceView(rng, area, view.value, valid, normal, view.derivatives))
+  return out
 
 
 # ------------------------------------------------------------------ faces of stored shapes
@@ -173,9 +321,15 @@ def facesOf(doc, source):
           out.extend(_primitive_faces(tree.kind, tree.params, pl, names, tol))
         elif tree.op == 'mesh' and len(tree.mesh) > 4:
           out.extend(_brep_faces(tree.mesh[4], tree.source, pl, names, tol))
+        elif tree.op in ('cut', 'fuse', 'common'):
+          if names:
+            raise geometry.UnsupportedGeometry(
+                f'{source.Name}: faces {names} of the boolean result {part.Name} are numbered by OpenCASCADE; '
+                f'select the whole body or faces of primitive solids')
+          out.extend(_boolean_faces(tree, container, tol))
         else:
           raise NotImplementedError(
-              f'{source.Name}: fan grids are built on faces of primitives and of stored shapes; '
+              f'{source.Name}: fan grids are built on faces of primitives, boolean results and stored shapes; '
               f'{tree.source or part.Name} is a {tree.op}')
   return out
 

@@ -320,6 +320,74 @@ def test_fan_grid_is_roughly_equidistant_on_curved_and_trimmed_faces():
   assert 0.35 < side.mean() < 0.75          # (the rows on the two rims are not counted)
 
 
+def test_fan_grid_on_the_faces_of_boolean_results():
+  """a lens made by Part::Common of two spheres and a cylinder; a mirror blank made by Part::Cut of a cylinder by
+  a paraboloid.  Each operand face that keeps a part of itself in the result is a face of the result, trimmed by
+  the other operands: the same faces (areas, trimmed parameter extent) as the stored shape of the same lens in
+  test/80 (edmund-optics-lens.FCStd, read by scene/brep.py -- an independent route), the grid points lie on the
+  solid's boundary, the rays leave it along the outward normal."""
+  from scipy.spatial import cKDTree
+  from conftest import SCENES
+  from freecad.optics_design_workbench_amd.freecad_elements import surface_fans
+  from freecad.optics_design_workbench_amd.scene import open_fcstd
+  doc = Document()
+  make.makeSimulationSettings(doc)
+  R1, R2, rim = 58.81, 50.72, 12.5
+  crown = make.makeCommon(doc, [make.makeSphere(doc, 'S1', R1, base=(0, 0, R1)), make.makeSphere(doc, 'S2', R2, base=(0, 0, 5 - R2)),
+                                make.makeCylinder(doc, 'C1', rim, 20, base=(0, 0, -5))], 'Crown')
+  faces = surface_fans.facesOf(doc, _source(doc, [(crown, [])]))
+  stored = open_fcstd(os.path.join(SCENES, 'edmund-optics-lens.FCStd'))
+  twin = surface_fans.facesOf(stored, _source(stored, [(stored.getObject('Part__Feature'), [])]))
+  assert len(faces) == len(twin) == 3
+  for a, b in zip(faces, twin):
+    assert abs(a.area / b.area - 1) < 0.01
+  # the spheres' caps end where the stored faces end: polar distance of the rim (the stored spheres have their axis
+  # across the lens, the Part::Spheres along it)
+  assert abs((faces[0].range[3] + np.pi / 2) - np.arcsin(rim / R1)) < 1e-6 and faces[0].range[2] == -np.pi / 2
+  assert abs((np.pi / 2 - faces[1].range[2]) - np.arcsin(rim / R2)) < 1e-6
+  assert abs(twin[0].range[3] - np.arcsin(rim / R1)) < 1e-6
+  # the cylinder keeps the band between the two rims
+  z1, z2 = R1 - np.sqrt(R1**2 - rim**2), 5 - (R2 - np.sqrt(R2**2 - rim**2))
+  # (to the distance tolerance 1e-6: a point that close to an operand's boundary counts as on it)
+  assert abs(faces[2].range[2] - (z1 + 5)) < 3e-6 and abs(faces[2].range[3] - (z2 + 5)) < 3e-6
+
+  o, d = _fan_points(doc, [(crown, [])], 300)
+  assert 250 < len(o) < 600
+  rho = np.hypot(o[:, 0], o[:, 1])
+  front = np.abs(np.linalg.norm(o - [0, 0, R1], axis=1) - R1) < 1e-9
+  back = np.abs(np.linalg.norm(o - [0, 0, 5 - R2], axis=1) - R2) < 1e-9
+  side = np.abs(rho - rim) < 1e-9
+  assert np.all(front | back | side) and front.sum() > 80 and back.sum() > 80 and side.sum() > 20
+  assert rho.max() <= rim + 1e-6 and o[:, 2].min() >= -1e-9 and o[:, 2].max() <= 5 + 1e-9
+  only = lambda m, others: m & ~others
+  assert np.abs(d[only(front, side)] - (o[only(front, side)] - [0, 0, R1]) / R1).max() < 1e-9
+  assert np.abs(d[only(back, side)] - (o[only(back, side)] - [0, 0, 5 - R2]) / R2).max() < 1e-9
+  uniq = np.unique(o[front].round(9), axis=0)
+  nn = cKDTree(uniq).query(uniq, k=2)[0][:, 1]
+  assert nn.max() < 3.5 * np.median(nn)
+
+  # Cut: the cavity is the tool's face, turned inside out
+  f, h = 12.0, 10.0
+  r = 2 * np.sqrt(f * h)                      # the cavity's mouth in the blank's top, z = h
+  dish = make.makeCut(doc, make.makeCylinder(doc, 'Blank', r + 2, h + 2, base=(0, 0, -2)),
+                      make.makeParaboloid(doc, 'Pb', f, h + 1), 'Dish')
+  views = surface_fans.facesOf(doc, _source(doc, [(dish, [])]))
+  # lateral face, bottom, the ring the cavity leaves of the top, the cavity (the tool's cap is outside the blank)
+  assert len(views) == 4
+  cavity = np.pi * r / (6 * h * h) * ((r * r + 4 * h * h)**1.5 - r**3)
+  want = (2 * np.pi * (r + 2) * (h + 2), np.pi * (r + 2)**2, np.pi * ((r + 2)**2 - r * r), cavity)
+  assert [abs(v.area / a - 1) < 0.02 for v, a in zip(views, want)] == [True] * 4
+  assert abs(views[3].range[3] - r) < 1e-5 and views[3].range[2] == 0.0
+  o, d = _fan_points(doc, [(dish, [])], 400)
+  on_cavity = (np.abs(o[:, 2] - (o[:, 0]**2 + o[:, 1]**2) / (4 * f)) < 1e-9) & (np.hypot(o[:, 0], o[:, 1]) < r - 1e-6)
+  assert on_cavity.sum() > 60
+  g = np.column_stack([-o[:, 0], -o[:, 1], np.full(len(o), 2 * f)])
+  g /= np.linalg.norm(g, axis=1)[:, None]
+  assert np.abs(d[on_cavity] - g[on_cavity]).max() < 1e-9          # into the cavity: towards the axis and upwards
+  with pytest.raises(geometry.UnsupportedGeometry, match='numbered by OpenCASCADE'):
+    _fan_points(doc, [(dish, ['Face1'])], 100)
+
+
 def test_fan_mode_of_the_reference_scenes(oracle):
   """test/21-simulation-modes (Face5 of a box above a ball lens) and test/80 (two faces of an
   imported aspheric lens): `runSimulation('fans')` traces the normal rays"""
