@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(CSRC, 'libodw_trace.so')
-_SOURCES = ['odw_capi.hip', 'odw_kernels.hip', 'odw_grid.hip', 'odw_posthoc.hip', 'odw_spec.hip', 'odw_device.h']
+_SOURCES = ['odw_capi.hip', 'odw_kernels.hip', 'odw_grid.hip', 'odw_mesh.hip', 'odw_posthoc.hip', 'odw_spec.hip', 'odw_device.h']
 _HEADER = os.path.normpath(os.path.join(_HERE, '..', '..', 'include', 'odw_trace.h'))
 
 ABI_VERSION = 7

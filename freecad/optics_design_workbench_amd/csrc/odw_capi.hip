@@ -8,6 +8,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -19,6 +20,7 @@
 
 #include "odw_kernels.hip"
 #include "odw_grid.hip"
+#include "odw_mesh.hip"
 
 using namespace odw;
 
@@ -82,6 +84,7 @@ struct odw_ctx {
 
   DevBuf prim_f64, prim_hdr, prim_i32, cond_i32, group_f64, group_i32, group_gdir, seq_mask;
   DevBuf bvh_nodes, bvh_prims, tri_nrm;
+  DevBuf bvh_leaf, bvh_wide;                         // leaf records and eight-wide tree of the mesh kernel (odw_mesh.hip)
   DevBuf grid_bounds, grid_cells, grid_items, dbg;   // rectilinear grid of big analytic scenes (odw_grid.hip)
   DevBuf phi_tab, t_tab, t_guide, phi_guide, d_source, d_det;
   DeviceSource h_source;
@@ -417,6 +420,182 @@ struct BvhBuilder {
 };
 
 
+// ---- eight-wide tree of the mesh kernel (odw_mesh.hip) --------------------------------------
+// The binary tree above, collapsed: a wide node takes up to eight descendants of a binary node (the one with the
+// largest box is opened next; one whose subtree is too high for the levels that remain goes first -- that bounds
+// the depth, and with one stack entry per level the traversal stack, at kWideMaxDepth + 1).  The children's boxes
+// are stored as 8-bit offsets from the node's corner in units of a power of two per axis (rounded outward);
+// children sit in the slot whose sign pattern (x, y, z: away from / towards the corner) fits the direction from
+// the node's centre to theirs best, so that `slot XOR ray octant` orders them roughly front to back without a
+// sort.  Inner children are consecutive nodes (slot order), the facets of leaf children consecutive leaf
+// records (slot order, <= 15 per leaf).
+// Node = 32 words (128 bytes, 20 used):
+//   0..2 corner (float)            3  exponent bytes x | y << 8 | z << 16 (biased: scale = 2^(e - 127))
+//   4    first inner child         5  first leaf record
+//   6    inner slots | leaf slots << 8          7  facets per leaf slot (4 bits each)
+//   8..13 near corner offsets: x of slots 0-3, x of 4-7, y, y, z, z     14..19 far corner offsets, the same way
+constexpr int kWideWords = 32;
+constexpr int kWideMaxDepth = 11;
+
+struct WideBvh {
+  struct Ref { int32_t child, count; float lo[3], hi[3]; };     // count > 0: leaf of `count` primitives from order[child]
+  const std::vector<BvhNode>& bn;
+  const std::vector<int>& order;
+  std::vector<int> height;
+  std::vector<uint32_t> nodes;
+  std::vector<int> leaf_prim;                 // primitive of every leaf record
+  std::vector<float> leaf_center;             // 3 per record: the centre its group is expressed around
+  int depth = 0;
+  bool ok = true;
+
+  WideBvh(const std::vector<BvhNode>& n, const std::vector<int>& o) : bn(n), order(o), height(n.size(), -1) {}
+
+  static bool far_box(const float* lo) { return lo[0] >= 3.0e38f; }        // the child a wrapper root does not have
+  static Ref ref0(const BvhNode& nd) { Ref r{nd.child0, nd.count0, {nd.lo0[0], nd.lo0[1], nd.lo0[2]}, {nd.hi0[0], nd.hi0[1], nd.hi0[2]}}; return r; }
+  static Ref ref1(const BvhNode& nd) { Ref r{nd.child1, nd.count1, {nd.lo1[0], nd.lo1[1], nd.lo1[2]}, {nd.hi1[0], nd.hi1[1], nd.hi1[2]}}; return r; }
+
+  int node_height(int n) {
+    if (height[n] >= 0) return height[n];
+    const BvhNode& nd = bn[n];
+    int h = 0;
+    if (nd.count0 == 0 && !far_box(nd.lo0)) h = std::max(h, node_height(nd.child0));
+    if (nd.count1 == 0 && !far_box(nd.lo1)) h = std::max(h, node_height(nd.child1));
+    return height[n] = h + 1;
+  }
+  static double area(const Ref& r) {
+    const double ex = (double)r.hi[0] - r.lo[0], ey = (double)r.hi[1] - r.lo[1], ez = (double)r.hi[2] - r.lo[2];
+    return 2.0 * (ex * ey + ey * ez + ez * ex);
+  }
+
+  void build() {
+    if (bn.empty()) { ok = false; return; }
+    if (node_height(0) > 3 * (kWideMaxDepth + 1)) { ok = false; return; }
+    nodes.assign(kWideWords, 0u);
+    fill(0, 0, 0);
+  }
+
+  void fill(size_t index, int n, int d) {
+    depth = std::max(depth, d);
+    if (d > kWideMaxDepth) { ok = false; return; }
+    std::vector<Ref> cand;
+    for (const Ref& r : {ref0(bn[n]), ref1(bn[n])})
+      if (!far_box(r.lo)) cand.push_back(r);
+    const int allowed = 3 * (kWideMaxDepth - d);             // binary height a child's subtree may have
+    while (cand.size() < 8) {
+      int pick = -1;
+      int tallest = allowed;
+      for (size_t k = 0; k < cand.size(); ++k)
+        if (cand[k].count == 0 && node_height(cand[k].child) > tallest) { tallest = node_height(cand[k].child); pick = (int)k; }
+      if (pick < 0) {
+        double best = -1.0;
+        for (size_t k = 0; k < cand.size(); ++k)
+          if (cand[k].count == 0 && area(cand[k]) > best) { best = area(cand[k]); pick = (int)k; }
+      }
+      if (pick < 0) break;                                     // leaves only
+      const BvhNode& nd = bn[cand[pick].child];
+      cand[pick] = ref0(nd);
+      cand.push_back(ref1(nd));
+    }
+    // the node's box and the slots
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (const Ref& r : cand)
+      for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], r.lo[a]); hi[a] = std::max(hi[a], r.hi[a]); }
+    int slot_of[8], cand_in[8];
+    for (int k = 0; k < 8; ++k) { slot_of[k] = -1; cand_in[k] = -1; }
+    {
+      struct Pair { double cost; int c, s; };
+      std::vector<Pair> pairs;
+      for (size_t c = 0; c < cand.size(); ++c)
+        for (int sl = 0; sl < 8; ++sl) {
+          double cost = 0.0;
+          for (int a = 0; a < 3; ++a) {
+            const double v = 0.5 * ((double)cand[c].lo[a] + cand[c].hi[a]) - 0.5 * ((double)lo[a] + hi[a]);
+            cost += ((sl >> a) & 1) ? v : -v;
+          }
+          pairs.push_back({cost, (int)c, sl});
+        }
+      std::stable_sort(pairs.begin(), pairs.end(), [](const Pair& x, const Pair& y) { return x.cost > y.cost; });
+      for (const Pair& pr : pairs)
+        if (slot_of[pr.c] < 0 && cand_in[pr.s] < 0) { slot_of[pr.c] = pr.s; cand_in[pr.s] = pr.c; }
+    }
+    uint32_t w[kWideWords] = {0};
+    uint32_t ebyte[3];
+    double scale[3];
+    for (int a = 0; a < 3; ++a) {
+      std::memcpy(&w[a], &lo[a], 4);
+      const double ext = (double)hi[a] - (double)lo[a];
+      int e = -100;
+      if (ext > 0) {
+        int ex2;
+        std::frexp(ext / 255.0, &ex2);                        // ext / 255 = m 2^ex2, 0.5 <= m < 1: 2^ex2 >= ext / 255
+        e = ex2;
+      }
+      e = std::max(-126, std::min(127, e));
+      while (std::ldexp(255.0, e) < ext && e < 127) ++e;
+      ebyte[a] = (uint32_t)(e + 127);
+      scale[a] = std::ldexp(1.0, e);
+    }
+    w[3] = ebyte[0] | (ebyte[1] << 8) | (ebyte[2] << 16);
+    uint32_t imask = 0, lmask = 0, counts = 0;
+    const uint32_t child_base = (uint32_t)(nodes.size() / kWideWords);
+    const uint32_t leaf_base = (uint32_t)leaf_prim.size();
+    int n_inner = 0;
+    float glo[3] = {INFINITY, INFINITY, INFINITY}, ghi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int sl = 0; sl < 8; ++sl) {
+      const int c = cand_in[sl];
+      if (c < 0) continue;
+      const Ref& r = cand[c];
+      if (r.count == 0) { imask |= 1u << sl; ++n_inner; }
+      else {
+        if (r.count > 15) { ok = false; return; }
+        lmask |= 1u << sl;
+        counts |= (uint32_t)r.count << (4 * sl);
+        for (int a = 0; a < 3; ++a) { glo[a] = std::min(glo[a], r.lo[a]); ghi[a] = std::max(ghi[a], r.hi[a]); }
+      }
+      for (int a = 0; a < 3; ++a) {
+        const double ql = std::floor(((double)r.lo[a] - (double)lo[a]) / scale[a]);
+        const double qh = std::ceil(((double)r.hi[a] - (double)lo[a]) / scale[a]);
+        const uint32_t bl = (uint32_t)std::max(0.0, std::min(255.0, ql)), bh = (uint32_t)std::max(0.0, std::min(255.0, qh));
+        if (qh > 255.0) { ok = false; return; }                // (cannot happen: 255 scale >= extent)
+        w[8 + 2 * a + (sl >> 2)] |= bl << (8 * (sl & 3));
+        w[14 + 2 * a + (sl >> 2)] |= bh << (8 * (sl & 3));
+      }
+    }
+    {
+      int total = 0;
+      for (int sl = 0; sl < 8; ++sl) total += (int)((counts >> (4 * sl)) & 15u);
+      if (total > 64) { ok = false; return; }                  // (the kernel's candidate mask)
+    }
+    w[4] = child_base;
+    w[5] = leaf_base;
+    w[6] = imask | (lmask << 8);
+    w[7] = counts;
+    std::memcpy(&nodes[index * kWideWords], w, sizeof w);
+    // leaf records of this node, slot order
+    const float gc[3] = {0.5f * glo[0] + 0.5f * ghi[0], 0.5f * glo[1] + 0.5f * ghi[1], 0.5f * glo[2] + 0.5f * ghi[2]};
+    for (int sl = 0; sl < 8; ++sl) {
+      const int c = cand_in[sl];
+      if (c < 0 || cand[c].count == 0) continue;
+      for (int k = 0; k < cand[c].count; ++k) {
+        leaf_prim.push_back(order[(size_t)cand[c].child + k]);
+        leaf_center.insert(leaf_center.end(), gc, gc + 3);
+      }
+    }
+    // inner children: consecutive nodes, slot order
+    nodes.resize(nodes.size() + (size_t)n_inner * kWideWords, 0u);
+    int rank = 0;
+    for (int sl = 0; sl < 8; ++sl) {
+      const int c = cand_in[sl];
+      if (c < 0 || cand[c].count != 0) continue;
+      const int child = cand[c].child;
+      fill((size_t)child_base + rank, child, d + 1);
+      if (!ok) return;
+      ++rank;
+    }
+  }
+};
+
+
 // ---- rectilinear grid for big analytic scenes (odw_grid.hip) ---------------------------------
 // Planes per axis: one in the middle of every gap between the primitives' boxes (projected on the
 // axis) -- a Draft array gets one element per cell --, then slabs wider than twice the width an
@@ -661,6 +840,8 @@ int build_bvh(odw_ctx* ctx) {
     has_paraboloids |= ctx->h_prim_i32[4 * p] == ODW_PRIM_PARABOLOID;
   }
   std::memset(&ctx->P.grid, 0, sizeof ctx->P.grid);
+  ctx->P.scene.bvh_leaf = nullptr;
+  ctx->P.scene.bvh_wide = nullptr;
   // (triangles are only known to the BVH kernels, paraboloids to the BVH and grid kernels)
   if (n <= bvh_threshold && !has_triangles && !has_paraboloids) return ODW_OK;
   if (!has_triangles) {
@@ -701,9 +882,65 @@ int build_bvh(odw_ctx* ctx) {
   int rc;
   if ((rc = upload(ctx, ctx->bvh_nodes, b.nodes.data(), b.nodes.size() * sizeof(BvhNode)))) return rc;
   if ((rc = upload(ctx, ctx->bvh_prims, b.order.data(), b.order.size() * sizeof(int)))) return rc;
+  // the mesh kernel's eight-wide tree and leaf records (odw_mesh.hip: ODW_LEAF_WORDS): the facet relative to the centre
+  // of the leaf group of its node, in float32, with the bounds the conservative filter needs
+  ctx->P.scene.bvh_leaf = nullptr;
+  ctx->P.scene.bvh_wide = nullptr;
+  std::vector<float> recs;
+  // (read at every build: A/B runs and the test that holds the two kernels against each other)
+  const bool mesh_kernel = !(getenv("ODW_MESH_KERNEL") && getenv("ODW_MESH_KERNEL")[0] == '0');
+  WideBvh wide(b.nodes, b.order);
+  if (has_triangles && mesh_kernel) {
+    wide.build();
+    if (wide.ok) {
+      recs.assign(std::max<size_t>(wide.leaf_prim.size(), 1) * ODW_LEAF_WORDS, 0.0f);
+      for (size_t j = 0; j < wide.leaf_prim.size(); ++j) {
+        const int p = wide.leaf_prim[j];
+        float* r = &recs[j * ODW_LEAF_WORDS];
+        const float* c = &wide.leaf_center[3 * j];
+        const double* pf = ctx->h_prim_f64.data() + 16 * (size_t)p;
+        const int32_t* pi = &ctx->h_prim_i32[4 * (size_t)p];
+        uint32_t gs = (uint32_t)(pi[1] & 0xff) | ((uint32_t)((pi[2] >> ODW_SOLID_SHIFT) & 0x7fff) << 8);
+        float smax = 0.0f, err = 0.0f;
+        if (pi[0] == ODW_PRIM_TRIANGLE) {
+          double l1[2] = {0.0, 0.0};
+          float e1[3], e2[3];
+          for (int a = 0; a < 3; ++a) {
+            r[a] = (float)(pf[a] - (double)c[a]);
+            e1[a] = (float)pf[3 + a];
+            e2[a] = (float)pf[6 + a];
+            l1[0] += std::fabs(pf[3 + a]);
+            l1[1] += std::fabs(pf[6 + a]);
+          }
+          r[3] = e1[0]; r[4] = e1[1]; r[5] = e1[2]; r[6] = e2[0]; r[7] = e2[1]; r[8] = e2[2];
+          smax = round_up(std::max(0.0, std::max(pf[12], std::max(pf[13], pf[14]))));
+          err = round_up(4e-6 * std::max(l1[0], l1[1]));
+        } else {
+          gs |= 0x80000000u;
+        }
+        std::memcpy(&r[9], &gs, 4);
+        r[10] = smax;
+        r[11] = err;
+        std::memcpy(&r[12], &p, 4);
+        r[13] = c[0]; r[14] = c[1]; r[15] = c[2];
+      }
+      if ((rc = upload(ctx, ctx->bvh_leaf, recs.data(), recs.size() * sizeof(float)))) return rc;
+      if ((rc = upload(ctx, ctx->bvh_wide, wide.nodes.data(), wide.nodes.size() * sizeof(uint32_t)))) return rc;
+      for (int a = 0; a < 3; ++a) {       // node 0 as the kernel decodes it: corner + 255 units of its scale
+        float corner, unit;
+        const uint32_t eb = ((wide.nodes[3] >> (8 * a)) & 0xffu) << 23;
+        std::memcpy(&corner, &wide.nodes[a], 4);
+        std::memcpy(&unit, &eb, 4);
+        ctx->P.scene.wide_lo[a] = (double)corner;
+        ctx->P.scene.wide_hi[a] = (double)corner + 255.0 * (double)unit;
+      }
+    }
+  }
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host vectors die with this scope
   ctx->P.scene.bvh_nodes = (const float*)ctx->bvh_nodes.p;
   ctx->P.scene.bvh_prims = (const int32_t*)ctx->bvh_prims.p;
+  ctx->P.scene.bvh_leaf = recs.empty() ? nullptr : (const float*)ctx->bvh_leaf.p;
+  ctx->P.scene.bvh_wide = recs.empty() ? nullptr : (const uint32_t*)ctx->bvh_wide.p;
   ctx->P.scene.n_nodes = (int)b.nodes.size();
   return ODW_OK;
 }
@@ -809,10 +1046,13 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
                         !(flags & ODW_TRACE_RECORD_SEGMENTS);
   const bool use_grid = !use_spec && P.grid.nx > 0 && ctx->n_samplers == 0 && !(flags & ODW_TRACE_RECORD_SEGMENTS);
   const uint64_t grid_blocks = std::max<uint64_t>(1, std::min<uint64_t>((n_chunks + ODW_GRID_WAVES - 1) / ODW_GRID_WAVES, (uint64_t)ctx->n_cu));
+  // scenes with facets: the mesh kernel (same exclusions)
+  const bool use_mesh = !use_spec && !use_grid && P.scene.n_nodes && P.scene.bvh_leaf && ctx->n_samplers == 0 &&
+                        !(flags & ODW_TRACE_RECORD_SEGMENTS);
   const uint64_t n_waves = use_grid ? grid_blocks * ODW_GRID_WAVES : (uint64_t)grid * 4;
-  if ((!P.scene.n_nodes || use_grid || use_spec) && !ctx->swapping &&
+  if ((!P.scene.n_nodes || use_grid || use_spec || use_mesh) && !ctx->swapping &&
       ctx->hit_slots >= ctx->hit_capacity + ctx->hit_capacity / 8 + 64 + n_waves * kHitBlock)
-    P.out.hit_block = kHitBlock;     // flat and grid kernels only (see record_hit)
+    P.out.hit_block = kHitBlock;     // flat, grid and mesh kernels only (see record_hit)
   HIPCHK(ctx, hipMemsetAsync(ctx->chunk_counter.p, 0, sizeof(uint64_t), ctx->stream));
   const size_t lds = P.scene.n_nodes ? (size_t)ODW_BVH_STACK * 256 * sizeof(int) : 0;
 
@@ -849,6 +1089,10 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
     if (P.grid.spheres) { if (P.grid.in_lds) ODW_GRID_LAUNCH(true, true); else ODW_GRID_LAUNCH(true, false); }
     else { if (P.grid.in_lds) ODW_GRID_LAUNCH(false, true); else ODW_GRID_LAUNCH(false, false); }
 #undef ODW_GRID_LAUNCH
+  } else if (use_mesh) {
+    const size_t mlds = (size_t)ODW_MESH_STACK * ODW_MESH_THREADS * 2 * sizeof(int) +
+                        (size_t)ODW_MESH_BLOCK_WAVES * (ODW_MESH_WAVE_WORDS * sizeof(uint32_t) + ODW_MESH_RING_DOUBLES * sizeof(double));
+    hipLaunchKernelGGL(odw_mesh_kernel, dim3(grid), dim3(ODW_MESH_THREADS), mlds, ctx->stream, P);
   } else if (flags & ODW_TRACE_RECORD_SEGMENTS) {
     if (P.scene.n_nodes) {
       if (stoch) hipLaunchKernelGGL((odw_trace_kernel<true, true, true>), dim3(grid), dim3(256), lds, ctx->stream, P);
@@ -924,7 +1168,7 @@ int odw_create(int device, odw_ctx** out) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->n_cu = prop.multiProcessorCount;
   if (getenv("ODW_GRID_STATS")) {               // diagnostic builds of the grid kernel report here (odw_destroy prints)
-    if (ensure(ctx, ctx->dbg, 16 * sizeof(uint64_t)) == ODW_OK) (void)hipMemset(ctx->dbg.p, 0, 16 * sizeof(uint64_t));
+    if (ensure(ctx, ctx->dbg, 32 * sizeof(uint64_t)) == ODW_OK) (void)hipMemset(ctx->dbg.p, 0, 32 * sizeof(uint64_t));
   }
   int rc = ensure(ctx, ctx->counters, ODW_CNT_COUNT * sizeof(uint64_t));
   if (!rc) rc = ensure(ctx, ctx->hit_count, 2 * sizeof(uint64_t));
@@ -944,18 +1188,25 @@ void odw_destroy(odw_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->dbg.p) {
-    uint64_t v[16] = {0};
+    uint64_t v[32] = {0};
     (void)hipMemcpy(v, ctx->dbg.p, sizeof v, hipMemcpyDeviceToHost);
     const char* names[6] = {"A ring fills", "B segment setup", "C cell steps", "D all", "D resolve", "D interact"};
     for (int k = 0; k < 6; ++k)
       fprintf(stderr, "[odw grid stats] %-16s runs %12llu  lanes %14llu  (%.1f per run)\n", names[k], (unsigned long long)v[2 * k],
               (unsigned long long)v[2 * k + 1], v[2 * k] ? (double)v[2 * k + 1] / (double)v[2 * k] : 0.0);
+    // (mesh kernel, ODW_MESH_STATS: clock ticks of s_memtime every wave spent in each phase, waits included)
+    uint64_t total = 0;
+    for (int k = 16; k < 24; ++k) total += v[k];
+    const char* phases[8] = {"A refill", "B setup", "C walk", "D leaves", "-", "D interact", "-", "-"};
+    if (total)
+      for (int k = 0; k < 6; ++k)
+        fprintf(stderr, "[odw mesh time] %-16s %14llu ticks  %5.1f %%\n", phases[k], (unsigned long long)v[16 + k], 100.0 * (double)v[16 + k] / (double)total);
     release(ctx->dbg);
   }
   for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   for (auto& ev : ctx->free_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   DevBuf* all[] = {&ctx->prim_f64, &ctx->prim_hdr, &ctx->prim_i32, &ctx->cond_i32, &ctx->group_f64, &ctx->group_i32,
-                   &ctx->group_gdir, &ctx->seq_mask, &ctx->bvh_nodes, &ctx->bvh_prims,
+                   &ctx->group_gdir, &ctx->seq_mask, &ctx->bvh_nodes, &ctx->bvh_prims, &ctx->bvh_leaf, &ctx->bvh_wide,
                    &ctx->phi_tab, &ctx->t_tab, &ctx->t_guide, &ctx->d_source, &ctx->d_det, &ctx->hits, &ctx->hit_count, &ctx->chunk_counter, &ctx->hist,
                    &ctx->counters, &ctx->ray_o, &ctx->ray_d, &ctx->ray_p, &ctx->ray_aos, &ctx->samp_t, &ctx->samp_phi,
                    &ctx->sort_keys[0], &ctx->sort_keys[1], &ctx->sort_vals[0], &ctx->sort_vals[1],

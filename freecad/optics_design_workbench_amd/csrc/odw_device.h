@@ -76,6 +76,9 @@ struct DeviceScene {
   // (lo0 hi0 lo1 hi1, 12 floats) + child0, child1, count0, count1 (count > 0: leaf)
   const float* bvh_nodes;       // [n_nodes*16]
   const int32_t* bvh_prims;     // leaf primitive order
+  const float* bvh_leaf;        // 64-byte leaf records of the mesh kernel (odw_mesh.hip), or null
+  const uint32_t* bvh_wide;     // its eight-wide tree: 128-byte nodes (odw_capi.hip: WideBvh)
+  double wide_lo[3], wide_hi[3];   // the box of that tree's root (rays start their float32 walk where they enter it)
   const double* tri_nrm;        // [n_prims*9] vertex normals of TRIANGLE primitives, or null (facet normals)
   int32_t n_prims, n_groups, n_nodes;
   int32_t seq_enabled, seq_len;

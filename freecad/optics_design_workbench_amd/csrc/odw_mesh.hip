@@ -1,0 +1,511 @@
+// odw_mesh.hip -- trace kernel for scenes with facets (tessellated shapes, STL, BRep faces that are not quadrics):
+// an eight-wide tree with quantised child boxes (odw_capi.hip: WideBvh) walked by a per-lane state machine whose
+// loop iteration is ONE NODE or ONE GROUP OF LEAVES, not one segment -- the construction of odw_grid.hip carried
+// over to a tree.
+//
+// Why (ball lens as 6.5e4 / 1e6 facets, profiles/r03/r03f_mesh*_pmc.json): in odw_trace_kernel<true, ...> every
+// lane of a wave finishes its traversal before any lane goes on -- 17 of 64 lanes did work per issued VALU
+// instruction, 72 % of the wave cycles waited on a chain of ~40 dependent node fetches per segment --, and every
+// facet of every leaf met went through the float64 Moeller-Trumbore test with its 128-byte record.  Here:
+//   walk      every iteration, every walking lane visits one node: one 80-byte fetch holds the boxes of eight
+//             children (8-bit offsets from the node's corner, a power-of-two scale per axis), tested in float32 with
+//             the slack of the binary kernels; the children that are hit travel as ONE stack entry (first child,
+//             slot bits), visited in the order `slot XOR ray octant` -- front to back without a sort.  A third of
+//             the dependent fetches of the binary tree, a stack of 12 entries instead of 32.
+//   leaves    a lane that hits leaf children stops walking.  When few lanes still walk, the waiting lanes test their
+//             facets together: a float32 filter first (64-byte leaf records: the facet relative to the centre of
+//             its group, the ray moved to the point next to that centre -- all magnitudes are those of the group,
+//             the test is conservative with bounds that scale with it); only the facets that pass -- one or two per
+//             leaf -- take the float64 test of odw_kernels.hip (intersect_tri: tolerance rim, face-outline rule), so
+//             the hit itself is the number the binary kernels and the oracle compute.  Analytic primitives listed in
+//             a leaf (a screen behind the mesh) skip the filter.
+//   interact  lanes whose stack is empty: nearest-hit selection, normal (interpolated for facets), Snell / mirror
+//             / grating, hit row, next segment -- or a new ray from the wave's ring (filled 64 rays at a time).
+// No stochastic surfaces and no segment rows here: those launches keep odw_trace_kernel<true, ...>.
+// Same rules as nearest<>() (ray.py:290-452): every candidate goes through consider(), subtrees are culled
+// against nearest + 2 distTol.
+#include "odw_device.h"
+
+namespace odw {
+
+#ifndef ODW_MESH_STEP_MIN
+#define ODW_MESH_STEP_MIN 16     // keep walking while at least this many lanes of the wave walk (and others wait)
+#endif
+#ifndef ODW_MESH_WAVES
+#define ODW_MESH_WAVES 3         // waves per SIMD the register allocation aims at (LDS per block: stacks 24 KB + rings 12 KB)
+#endif
+#define ODW_MESH_THREADS 256
+#define ODW_MESH_BLOCK_WAVES (ODW_MESH_THREADS / 64)
+#define ODW_MESH_WAVE_WORDS 32   // per wave: event counters (0..7), diagnostics (8..27), hit-block state (28..31)
+#define ODW_MESH_RING 64
+#define ODW_MESH_RING_DOUBLES (ODW_MESH_RING * 6)
+#define ODW_MESH_STACK 12        // entries (two words each) per lane: one per level of the wide tree (kWideMaxDepth + 1)
+#define ODW_WIDE_WORDS 32        // words per node (odw_capi.hip: kWideWords)
+
+// leaf record (64 bytes): words 0..2 v0 - centre of its group, 3..5 e1, 6..8 e2 (float32), 9 group | solid << 8 |
+// (not a facet) << 31, 10 largest barycentric slack per unit of tolerance, 11 error scale: 4e-6 x max(|e1|_1,
+// |e2|_1), 12 primitive, 13..15 the centre (the same in every record of a node's leaves)
+#define ODW_LEAF_WORDS 16
+
+#ifdef ODW_MESH_STATS
+#define ODW_MSTAT(k, mask_)                                                                           \
+  do {                                                                                                \
+    const unsigned long long m_ = (mask_);                                                            \
+    if (m_ && (int)__lane_id() == __ffsll(m_) - 1) { wave_cnt[8 + 2 * (k)] += 1u; wave_cnt[9 + 2 * (k)] += (uint32_t)__popcll(m_); } \
+  } while (0)
+// time per phase: s_memtime ticks between marks, kept per wave (uniform), added up at the end
+#define ODW_MTIME(k) do { const uint64_t t_ = __builtin_readcyclecounter(); phase_t[(k)] += t_ - t_mark; t_mark = t_; } while (0)
+#else
+#define ODW_MSTAT(k, mask_) do {} while (0)
+#define ODW_MTIME(k) do {} while (0)
+#endif
+#define ODW_MCOUNT(k) atomicAdd(&wave_cnt[(k)], 1u)
+
+__global__ __launch_bounds__(ODW_MESH_THREADS, ODW_MESH_WAVES) void odw_mesh_kernel(const TraceParams P) {
+  extern __shared__ double mesh_lds[];
+  const DeviceScene& sc = P.scene;
+  const DeviceLimits& lim = P.lim;
+  // ---- LDS image: node stacks [ODW_MESH_STACK][256] x 2 words | per-wave words | ray rings ----
+  uint2* stack = reinterpret_cast<uint2*>(mesh_lds) + threadIdx.x;
+  uint32_t* lds32 = reinterpret_cast<uint32_t*>(mesh_lds);
+  const int word_off = 2 * ODW_MESH_STACK * ODW_MESH_THREADS;
+  const int ring_off = (word_off + ODW_MESH_BLOCK_WAVES * ODW_MESH_WAVE_WORDS) / 2;     // doubles
+  for (int k = threadIdx.x; k < ODW_MESH_BLOCK_WAVES * ODW_MESH_WAVE_WORDS; k += ODW_MESH_THREADS)
+    lds32[word_off + k] = (k % ODW_MESH_WAVE_WORDS) == 30 ? P.out.hit_block : 0u;        // hit-block state: base lo, hi, used, -
+  __syncthreads();
+  const int wave = threadIdx.x >> 6;
+  uint32_t* wave_cnt = lds32 + word_off + wave * ODW_MESH_WAVE_WORDS;
+  volatile uint32_t* hit_state = wave_cnt + 28;
+  double* ring = mesh_lds + ring_off + wave * ODW_MESH_RING_DOUBLES;
+
+  SceneView sv;
+  sv.prim_f64 = as_const(sc.prim_f64);
+  sv.prim_hdr = as_const(sc.prim_hdr);
+  sv.prim_i32 = as_const(sc.prim_i32);
+  sv.cond_i32 = as_const(sc.cond_i32);
+  cf64 group_f64 = as_const(sc.group_f64);
+  ci32 group_i32 = as_const(sc.group_i32);
+  cf64 group_gdir = as_const(sc.group_gdir);
+  cu64 seq_mask = as_const(sc.seq_mask);
+  typedef const float ODW_CONST* cf32;
+  typedef const uint32_t ODW_CONST* cu32;
+  typedef float vf4 __attribute__((ext_vector_type(4)));
+  typedef uint32_t vu4 __attribute__((ext_vector_type(4)));
+  cu32 nodes = (cu32)(uintptr_t)sc.bvh_wide;
+  cf32 leaves = (cf32)(uintptr_t)sc.bvh_leaf;
+  const uint32_t lane = __lane_id();
+  uint64_t next = 0, chunk_end = 0;                        // wave-uniform: the wave's chunk of the launch
+  uint64_t ring_base = 0;
+  uint32_t ring_n = 0;
+  bool drained = false;
+  // lane states: !alive | fresh (segment to set up) | walking (cur = node) | pending (leaf children to test) |
+  // done with the tree (alive && !fresh && !walking && !pending): interaction
+  bool alive = false, fresh = false, walking = false, pending = false;
+  uint64_t i = 0;
+  Query q;
+  q.tol = lim.dist_tol; q.tmax = lim.max_ray_length + lim.dist_tol;
+  q.start = mk(0, 0, 0); q.dn = mk(0, 0, 1); q.medium = -1;
+  q.any.t = INFINITY; q.any.prim = 0x7fffffff; q.any.face = 0x7fffffff;
+  q.oth = q.any;
+  d3& point = q.start;
+  d3& dir = q.dn;
+  int& medium = q.medium;
+  double power = 0;
+  int seq = 0, nint = 0, skip = -1;
+  uint64_t mask = 0;
+  // the walk: float32 ray (origin moved along the ray by tsh, 1 / direction, octant: bit a = direction a > 0),
+  // cut-off (relative to the moved origin), node, stack height; the leaf children that wait for their test
+  float ofx = 0, ofy = 0, ofz = 0, ivx = 0, ivy = 0, ivz = 0, cutf = 0, tsh = 0;
+  uint32_t oct = 0;
+  int cur = -1, sp = 0;
+  uint32_t lbase = 0, lcounts = 0, lhits = 0;
+  const float tolf = (float)lim.dist_tol * 1.000001f;
+
+  // which of the hit children comes first: the set bit whose slot XOR octant is largest
+#define ODW_MESH_FIRST(hits_, slot_)                                                         \
+  do {                                                                                       \
+    uint32_t m_ = (hits_);                                                                   \
+    m_ = (oct & 1u) ? (((m_ & 0x55u) << 1) | ((m_ & 0xAAu) >> 1)) : m_;                      \
+    m_ = (oct & 2u) ? (((m_ & 0x33u) << 2) | ((m_ & 0xCCu) >> 2)) : m_;                      \
+    m_ = (oct & 4u) ? (((m_ & 0x0Fu) << 4) | ((m_ & 0xF0u) >> 4)) : m_;                      \
+    (slot_) = (uint32_t)(31 - __clz((int)m_)) ^ oct;                                         \
+  } while (0)
+  // the walk goes on with the next child of the group on top of the stack (first inner child, inner slots << 8 |
+  // slots still to visit), or the traversal is over
+#define ODW_MESH_POP()                                                                       \
+  do {                                                                                       \
+    pending = false;                                                                         \
+    if (sp > 0) {                                                                            \
+      const uint2 e_ = stack[(sp - 1) * ODW_MESH_THREADS];                                   \
+      uint32_t sl_;                                                                          \
+      ODW_MESH_FIRST(e_.y & 0xffu, sl_);                                                     \
+      const uint32_t rest_ = (e_.y & 0xffu) & ~(1u << sl_);                                  \
+      if (rest_) stack[(sp - 1) * ODW_MESH_THREADS] = make_uint2(e_.x, (e_.y & ~0xffu) | rest_); \
+      else --sp;                                                                             \
+      cur = (int)(e_.x + (uint32_t)__popc((e_.y >> 8) & ((1u << sl_) - 1u)));                \
+      walking = true;                                                                        \
+    } else {                                                                                 \
+      cur = -1;                                                                              \
+      walking = false;                                                                       \
+    }                                                                                        \
+  } while (0)
+
+#ifdef ODW_MESH_STATS
+  uint64_t phase_t[6] = {0, 0, 0, 0, 0, 0};
+  uint64_t t_mark = __builtin_readcyclecounter();
+#endif
+  for (;;) {
+    // ---- A: new rays for idle lanes, from the wave's ring ------------------------------------------
+    const uint64_t idle = __ballot(!alive);
+    if (idle == ~0ull && drained && ring_n == 0) break;    // nothing live, nothing left
+    if (idle && !(drained && ring_n == 0)) {
+      if (ring_n == 0) {
+        if (next >= chunk_end) {
+          unsigned long long c = 0;
+          if (lane == 0) c = atomicAdd(P.out.chunk_counter, 1ull);
+          const uint64_t chunk = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(c >> 32)) << 32) |
+                                 (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)c);
+          next = chunk * ODW_CHUNK;
+          if (next >= P.n_rays) { next = P.n_rays; drained = true; }
+          chunk_end = next + ODW_CHUNK < P.n_rays ? next + ODW_CHUNK : P.n_rays;
+        }
+        const uint64_t avail = chunk_end - next;
+        const uint32_t fill = avail < ODW_MESH_RING ? (uint32_t)avail : (uint32_t)ODW_MESH_RING;
+        ODW_MSTAT(0, __ballot(lane < fill));
+        if (lane < fill) {
+          const uint64_t r = next + lane;
+          d3 o, d;
+          if (P.ray_origins) {
+            o = mk(P.ray_origins[r], P.ray_origins[P.ray_stride + r], P.ray_origins[2 * P.ray_stride + r]);
+            d = mk(P.ray_dirs[r], P.ray_dirs[P.ray_stride + r], P.ray_dirs[2 * P.ray_stride + r]);
+            d = d * (1.0 / sqrt(dot(d, d)));
+          } else {
+            const RayInit g = generate_ray(P.source, P.first_ray + r, P.seed);
+            o = g.point; d = g.dir;
+          }
+          double* slot = ring + 6 * lane;
+          slot[0] = o.x; slot[1] = o.y; slot[2] = o.z; slot[3] = d.x; slot[4] = d.y; slot[5] = d.z;
+        }
+        __builtin_amdgcn_wave_barrier();
+        ring_base = next;
+        ring_n = fill;
+        next += fill;
+      }
+      const uint32_t rank = __popcll(idle & ((1ull << lane) - 1ull));
+      const uint32_t want = __popcll(idle);
+      const uint32_t take = want < ring_n ? want : ring_n;
+      if (!alive && rank < take) {
+        const uint32_t s = ring_n - 1 - rank;
+        const double* slot = ring + 6 * s;
+        point = mk(slot[0], slot[1], slot[2]);
+        dir = mk(slot[3], slot[4], slot[5]);
+        i = ring_base + s;
+        power = P.ray_origins ? (P.ray_powers ? P.ray_powers[i] : 1.0) : as_const(P.source)->power;
+        seq = 0; nint = 0; medium = -1; skip = -1;
+        alive = true; fresh = true; walking = false; pending = false;
+      }
+      ring_n -= take;
+    }
+    ODW_MTIME(0);
+    // ---- B: set up the next segment of fresh lanes ---------------------------------------------
+    ODW_MSTAT(1, __ballot(alive && fresh));
+    if (alive && fresh) {
+      fresh = false;
+      if (nint >= lim.max_intersections) {
+        ODW_MCOUNT(ODW_CNT_CAPPED);
+        atomicAdd(&wave_cnt[ODW_CNT_SEGMENTS], (uint32_t)nint);
+        ODW_MCOUNT(ODW_CNT_TRACED_RAYS);
+        alive = false;
+      } else {
+        ++nint;
+        mask = sc.all_mask;
+        if (sc.seq_enabled) mask = (seq < sc.seq_len) ? seq_mask[seq] : 0ull;
+        mask &= ~sc.ignore_mask;
+        q.any.t = INFINITY; q.any.prim = 0x7fffffff; q.any.face = 0x7fffffff;
+        q.oth = q.any;
+        walking = false; pending = false;
+        if (mask != 0ull) {
+          // where the ray enters the tree's box (float64): the float32 walk starts there, with the origin
+          // as near to the geometry as it gets; a ray that misses the box has no candidates
+          const d3 inv = mk(frcp(dir.x), frcp(dir.y), frcp(dir.z));
+          double t0 = 0.0, t1 = q.tmax;
+          {
+            const double a0 = (sc.wide_lo[0] - point.x) * inv.x, a1 = (sc.wide_hi[0] - point.x) * inv.x;
+            const double b0 = (sc.wide_lo[1] - point.y) * inv.y, b1 = (sc.wide_hi[1] - point.y) * inv.y;
+            const double c0 = (sc.wide_lo[2] - point.z) * inv.z, c1 = (sc.wide_hi[2] - point.z) * inv.z;
+            t0 = fmax(t0, fmax(fmin(a0, a1), fmax(fmin(b0, b1), fmin(c0, c1))));
+            t1 = fmin(t1, fmin(fmax(a0, a1), fmin(fmax(b0, b1), fmax(c0, c1))));
+          }
+          if (t0 <= t1 * (1.0 + 1e-9) + 1e-6) {
+            // (rounded down: the moved origin is a point of the ray before the box, exactly)
+            tsh = t0 > 2e-3 ? (float)(t0 - 1e-3) * 0.999999f : 0.0f;
+            const d3 o = point + dir * (double)tsh;
+            ofx = (float)o.x; ofy = (float)o.y; ofz = (float)o.z;
+            ivx = (float)inv.x; ivy = (float)inv.y; ivz = (float)inv.z;
+            oct = (dir.x > 0 ? 1u : 0u) | (dir.y > 0 ? 2u : 0u) | (dir.z > 0 ? 4u : 0u);
+            cutf = (float)(q.tmax - (double)tsh) * 1.00001f + 1e-3f;
+            cur = 0; sp = 0;
+            walking = true;
+          }
+        }
+      }
+    }
+    ODW_MTIME(1);
+    // ---- C: node steps, all walking lanes together -------------------------------------------------
+    for (int it = 0;; ++it) {
+      const uint64_t wb = __ballot(walking);
+      if (wb == 0ull) break;
+      if (it > 0 && __popcll(wb) < ODW_MESH_STEP_MIN &&
+          (__ballot(alive && !walking) != 0ull || (!(drained && ring_n == 0) && __ballot(!alive) != 0ull)))
+        break;
+      ODW_MSTAT(2, wb);
+      if (walking) {
+        cu32 nd = nodes + (size_t)cur * ODW_WIDE_WORDS;
+        const vu4 h0 = *reinterpret_cast<const vu4 ODW_CONST*>(nd);          // corner, exponents
+        const vu4 h1 = *reinterpret_cast<const vu4 ODW_CONST*>(nd + 4);      // first inner child, first leaf record, slots, counts
+        const vu4 qa = *reinterpret_cast<const vu4 ODW_CONST*>(nd + 8);      // near corner: x x y y
+        const vu4 qb = *reinterpret_cast<const vu4 ODW_CONST*>(nd + 12);     // near z z | far x x
+        const vu4 qc = *reinterpret_cast<const vu4 ODW_CONST*>(nd + 16);     // far y y z z
+        // t of plane q on axis a: q * (scale_a / d_a) + (corner_a - o_a) / d_a
+        const float ax = __uint_as_float((h0.w & 0xffu) << 23) * ivx, bx = (__uint_as_float(h0.x) - ofx) * ivx;
+        const float ay = __uint_as_float(((h0.w >> 8) & 0xffu) << 23) * ivy, by = (__uint_as_float(h0.y) - ofy) * ivy;
+        const float az = __uint_as_float(((h0.w >> 16) & 0xffu) << 23) * ivz, bz = (__uint_as_float(h0.z) - ofz) * ivz;
+        // per axis: the planes the ray meets first / last
+        const uint32_t nx0 = ivx < 0 ? qb.z : qa.x, nx1 = ivx < 0 ? qb.w : qa.y, fx0 = ivx < 0 ? qa.x : qb.z, fx1 = ivx < 0 ? qa.y : qb.w;
+        const uint32_t ny0 = ivy < 0 ? qc.x : qa.z, ny1 = ivy < 0 ? qc.y : qa.w, fy0 = ivy < 0 ? qa.z : qc.x, fy1 = ivy < 0 ? qa.w : qc.y;
+        const uint32_t nz0 = ivz < 0 ? qc.z : qb.x, nz1 = ivz < 0 ? qc.w : qb.y, fz0 = ivz < 0 ? qb.x : qc.z, fz1 = ivz < 0 ? qb.y : qc.w;
+        uint32_t hits = 0;
+#define ODW_MESH_SLOT(S, NX, NY, NZ, FX, FY, FZ, SH)                                                          \
+        {                                                                                                     \
+          const float tnx = fmaf((float)(((NX) >> (SH)) & 0xffu), ax, bx), tfx = fmaf((float)(((FX) >> (SH)) & 0xffu), ax, bx); \
+          const float tny = fmaf((float)(((NY) >> (SH)) & 0xffu), ay, by), tfy = fmaf((float)(((FY) >> (SH)) & 0xffu), ay, by); \
+          const float tnz = fmaf((float)(((NZ) >> (SH)) & 0xffu), az, bz), tfz = fmaf((float)(((FZ) >> (SH)) & 0xffu), az, bz); \
+          const float tn = fmaxf(fmaxf(tnx, tny), tnz), tf = fminf(fminf(tfx, tfy), tfz);                     \
+          /* conservative acceptance: relative 1e-5 + absolute 1e-3 mm on t (as in nearest<true>) */         \
+          const bool h_ = tf * 1.00001f + 1e-3f >= fmaxf(tn, 0.f) * 0.99999f - 1e-3f && tn * 0.99999f - 1e-3f < cutf; \
+          hits |= h_ ? (1u << (S)) : 0u;                                                                      \
+        }
+        ODW_MESH_SLOT(0, nx0, ny0, nz0, fx0, fy0, fz0, 0)
+        ODW_MESH_SLOT(1, nx0, ny0, nz0, fx0, fy0, fz0, 8)
+        ODW_MESH_SLOT(2, nx0, ny0, nz0, fx0, fy0, fz0, 16)
+        ODW_MESH_SLOT(3, nx0, ny0, nz0, fx0, fy0, fz0, 24)
+        ODW_MESH_SLOT(4, nx1, ny1, nz1, fx1, fy1, fz1, 0)
+        ODW_MESH_SLOT(5, nx1, ny1, nz1, fx1, fy1, fz1, 8)
+        ODW_MESH_SLOT(6, nx1, ny1, nz1, fx1, fy1, fz1, 16)
+        ODW_MESH_SLOT(7, nx1, ny1, nz1, fx1, fy1, fz1, 24)
+#undef ODW_MESH_SLOT
+        const uint32_t imask = h1.z & 0xffu, lmask = (h1.z >> 8) & 0xffu;
+        const uint32_t ih = hits & imask, lh = hits & lmask;
+        if (lh) {
+          // leaves first (their hits cull the inner children): the lane waits for phase D
+          lbase = h1.y; lcounts = h1.w; lhits = lh;
+          if (ih) { stack[sp * ODW_MESH_THREADS] = make_uint2(h1.x, (imask << 8) | ih); ++sp; }
+          walking = false;
+          pending = true;
+        } else if (ih) {
+          uint32_t sl;
+          ODW_MESH_FIRST(ih, sl);
+          const uint32_t rest = ih & ~(1u << sl);
+          if (rest) { stack[sp * ODW_MESH_THREADS] = make_uint2(h1.x, (imask << 8) | rest); ++sp; }
+          cur = (int)(h1.x + (uint32_t)__popc(imask & ((1u << sl) - 1u)));
+        } else {
+          ODW_MESH_POP();
+        }
+      }
+    }
+    ODW_MTIME(2);
+    // ---- D: leaves, then the interaction of the lanes whose traversal is over ------------------------
+    ODW_MSTAT(3, __ballot(alive && pending));
+    if (alive && pending) {
+      // the ray, moved to the point next to the centre of this node's leaves and taken relative to it (float64, then
+      // rounded: magnitudes of the size of the group)
+      const vf4 hq = *reinterpret_cast<const vf4 ODW_CONST*>(leaves + (size_t)lbase * ODW_LEAF_WORDS + 12);
+      const d3 oc = point - mk((double)hq.y, (double)hq.z, (double)hq.w);
+      const double tc = -dot(oc, dir);
+      const d3 orel = oc + dir * tc;
+      const float ox = (float)orel.x, oy = (float)orel.y, oz = (float)orel.z;
+      const float dx = (float)dir.x, dy = (float)dir.y, dz = (float)dir.z;
+      // the records of the leaf children that were hit, as bits relative to the node's first record (<= 64 per node):
+      // a leaf's records follow those of the leaf slots below it (sum of their 4-bit counts)
+      uint64_t cand = 0;
+      for (uint32_t todo = lhits; todo; todo &= todo - 1u) {
+        const uint32_t sl = (uint32_t)__ffs((int)todo) - 1u;
+        const uint32_t cnt = (lcounts >> (4u * sl)) & 15u;
+        const uint32_t below = lcounts & ((1u << (4u * sl)) - 1u);
+        const uint32_t pairs = (below & 0x0f0f0f0fu) + ((below >> 4) & 0x0f0f0f0fu);
+        cand |= ((1ull << cnt) - 1ull) << ((pairs * 0x01010101u) >> 24);
+      }
+      cf32 rec0 = leaves + (size_t)lbase * ODW_LEAF_WORDS;
+      const auto filter = [&](vf4 w0, vf4 w1, vf4 w2) -> bool {
+        const uint32_t gs = __float_as_uint(w2.y);             // w0: v0x v0y v0z e1x, w1: e1y e1z e2x e2y, w2: e2z gs smax err
+        const bool relevant = ((mask >> (gs & 0xff)) & 1) && (int)((gs >> 8) & 0x7fff) != skip;
+        if (!relevant || (gs >> 31)) return relevant;
+        const float e1x = w0.w, e1y = w1.x, e1z = w1.y, e2x = w1.z, e2y = w1.w, e2z = w2.x;
+        const float pvx = dy * e2z - dz * e2y, pvy = dz * e2x - dx * e2z, pvz = dx * e2y - dy * e2x;
+        const float det = e1x * pvx + e1y * pvy + e1z * pvz;
+        const float tvx = ox - w0.x, tvy = oy - w0.y, tvz = oz - w0.z;
+        const float qvx = tvy * e1z - tvz * e1y, qvy = tvz * e1x - tvx * e1z, qvz = tvx * e1y - tvy * e1x;
+        float U = tvx * pvx + tvy * pvy + tvz * pvz;
+        float V = dx * qvx + dy * qvy + dz * qvz;
+        const float ad = fabsf(det);
+        U = det < 0 ? -U : U;
+        V = det < 0 ? -V : V;
+        // bounds: barycentric slack of the tolerance rules (intersect_tri) + rounding of this arithmetic
+        const float m = tolf * w2.z + 1e-6f;
+        const float ea = (fabsf(tvx) + fabsf(tvy) + fabsf(tvz)) * w2.w + m * ad;
+        return U >= -ea && V >= -ea && U + V <= ad + 2.0f * ea;
+      };
+      uint64_t pass = 0;
+      while (cand) {
+        // four records per trip: twelve loads in flight before the first is used (the trip is a round trip to the
+        // cache: fewer, fuller trips)
+        int kk[4];
+        bool on[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          on[j] = cand != 0ull;
+          kk[j] = on[j] ? __ffsll((unsigned long long)cand) - 1 : kk[0];
+          cand &= cand - 1ull;                                // (0 stays 0)
+        }
+        vf4 w[4][3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          cf32 r = rec0 + (size_t)kk[j] * ODW_LEAF_WORDS;
+          w[j][0] = *reinterpret_cast<const vf4 ODW_CONST*>(r);
+          w[j][1] = *reinterpret_cast<const vf4 ODW_CONST*>(r + 4);
+          w[j][2] = *reinterpret_cast<const vf4 ODW_CONST*>(r + 8);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          pass |= (on[j] && filter(w[j][0], w[j][1], w[j][2])) ? (1ull << kk[j]) : 0ull;
+      }
+      ODW_MSTAT(4, __ballot(pass != 0ull));
+      while (pass) {
+        const int k = __ffsll((unsigned long long)pass) - 1;
+        pass &= pass - 1ull;
+        cf32 rec = rec0 + (size_t)k * ODW_LEAF_WORDS;
+        const int p = (int)__float_as_uint(rec[12]);
+        const uint32_t gs = __float_as_uint(rec[9]);
+        if (gs >> 31) {
+          ci32 pi = sv.prim_i32 + 4 * p;
+          intersect_prim<true>(sv, q, p, pi[0], pi[1], pi[2], pi[3]);
+        } else {
+          intersect_tri(sv, q, p, (int)(gs & 0xff));
+        }
+      }
+      cutf = (float)(fmin(q.tmax, q.any.t + 2.0 * q.tol) - (double)tsh) * 1.00001f + 1e-3f;
+      ODW_MESH_POP();
+    }
+    ODW_MTIME(3);
+    ODW_MSTAT(5, __ballot(alive && !walking && !pending && !fresh));
+    if (alive && !walking && !pending && !fresh) {
+      if (q.any.prim == 0x7fffffff) {
+        ODW_MCOUNT(ODW_CNT_ESCAPED);
+        alive = false;
+      } else {
+        const bool use_oth = q.oth.prim != 0x7fffffff && q.oth.t < q.any.t + 2.0 * q.tol;
+        const double t_hit = use_oth ? q.oth.t : q.any.t;
+        const int face = use_oth ? q.oth.face : q.any.face;
+        const int prim = use_oth ? q.oth.prim : q.any.prim;
+        cf64 pf = sv.prim_f64 + (size_t)prim * 16;
+        ci32 pi = sv.prim_i32 + 4 * prim;
+        point = point + dir * t_hit;
+        if (medium >= 0) {                                  // ray.py:120-125 (assignment)
+          const double L = group_f64[4 * medium + 2];
+          if (L == 0) power = 0;
+          else if (L < INFINITY) power = exp(-t_hit / L);
+        }
+        d3 n;
+        if (pi[0] == ODW_PRIM_TRIANGLE) {
+          n = tri_normal(pf, sc.tri_nrm ? sc.tri_nrm + (size_t)prim * 9 : nullptr, point);
+          if (pi[2] & ODW_FLAG_FLIP_NORMAL) n = n * -1.0;
+        } else {
+          n = face_normal<true>(pi[0], pf + 12, face, xf_point(pf, point));
+          if (pi[2] & ODW_FLAG_FLIP_NORMAL) n = n * -1.0;
+          n = xf_vec_t(pf, n);
+        }
+        const bool entering = dot(dir, n) < 0;
+        if (entering) n = n * -1.0;
+        const int g = pi[1];
+        const int gtype = group_i32[4 * g];
+        if (group_i32[4 * g + 1]) {
+          ODW_MCOUNT(ODW_CNT_RECORDED_HITS);
+          record_hit<true, 1, true>(P, P.first_ray + i, g, point, dir, power, entering, wave_cnt, hit_state);
+        }
+        if (gtype == ODW_OPT_MIRROR) {
+          dir = mirror(dir, n);
+          power *= group_f64[4 * g + 1];
+          ++seq;
+        } else if (gtype == ODW_OPT_LENS) {
+          const double n1 = (medium >= 0) ? group_f64[4 * medium] : 1.0;
+          double n2 = 1.0;
+          if (entering) { medium = g; n2 = group_f64[4 * g]; }
+          bool tir;
+          dir = snells_law(dir, n1, n2, n, tir);
+          if (!entering && !tir && medium == g) { medium = -1; ++seq; }
+        } else if (gtype == ODW_OPT_ABSORBER) {
+          power = 0;
+          ++seq;
+        } else if (gtype == ODW_OPT_VACUUM) {
+          ++seq;
+        } else {  // grating (ray.py:216-268)
+          const d3 gd = mk(group_gdir[3 * g], group_gdir[3 * g + 1], group_gdir[3 * g + 2]);
+          const double lpm = group_f64[4 * g + 3];
+          const int order = group_i32[4 * g + 3];
+          if (group_i32[4 * g + 2] == 0) {
+            if (entering) {
+              const double nn = (medium >= 0) ? group_f64[4 * medium] : 1.0;
+              dir = line_grating(dir, nn, nn, n, P.wavelength, order, lpm, gd, false);
+              ++seq;
+            }
+          } else if (entering) {
+            if (medium >= 0) {
+              atomicAdd(P.out.counters + ODW_CNT_GRATING_IN_MEDIUM, 1ull);     // a ValueError of the reference
+              ODW_MCOUNT(ODW_CNT_DIED);
+              alive = false;
+            }
+            medium = g;
+            dir = line_grating(dir, 1.0, group_f64[4 * g], n, P.wavelength, order, lpm, gd, true);
+          } else {
+            const double n1 = (medium >= 0) ? group_f64[4 * medium] : 1.0;
+            bool tir;
+            dir = snells_law(dir, n1, 1.0, n, tir);
+            if (!tir) { medium = -1; ++seq; }
+          }
+        }
+        skip = ((pi[2] & ODW_FLAG_CONVEX) && (entering ? -dot(dir, n) : dot(dir, n)) > 0) ? (pi[2] >> ODW_SOLID_SHIFT) : -1;
+        if (alive && power < lim.power_tol) { ODW_MCOUNT(ODW_CNT_DIED); alive = false; }
+        fresh = alive;
+      }
+      if (!alive) {
+        atomicAdd(&wave_cnt[ODW_CNT_SEGMENTS], (uint32_t)nint);
+        ODW_MCOUNT(ODW_CNT_TRACED_RAYS);
+      }
+    }
+    ODW_MTIME(5);
+  }
+#undef ODW_MESH_POP
+#undef ODW_MESH_FIRST
+  // slots of the last block this wave never filled (as in odw_trace_kernel)
+  const uint32_t hit_used = hit_state[2];
+  const uint64_t hit_base = ((uint64_t)hit_state[1] << 32) | hit_state[0];
+  if (P.out.hit_block && hit_used < P.out.hit_block) {
+    const uint32_t left = P.out.hit_block - hit_used;
+    for (uint32_t k = __lane_id(); k < left; k += 64)
+      if (hit_base + hit_used + k < P.out.hit_capacity) P.out.hits[hit_base + hit_used + k].tag = ODW_TAG_UNUSED;
+    const uint64_t at = hit_base + hit_used;
+    const uint64_t in_buf = at < P.out.hit_capacity ? (P.out.hit_capacity - at < left ? P.out.hit_capacity - at : left) : 0;
+    if (__lane_id() == 0 && in_buf) atomicAdd(P.out.hit_count + 1, (unsigned long long)in_buf);
+  }
+#ifdef ODW_MESH_STATS
+  if (lane < 12 && P.dbg) atomicAdd(P.dbg + lane, (unsigned long long)wave_cnt[8 + lane]);
+  if (lane == 0 && P.dbg)
+    for (int k = 0; k < 6; ++k) atomicAdd(P.dbg + 16 + k, (unsigned long long)phase_t[k]);
+#endif
+  if (lane < ODW_CNT_LDS) {
+    const uint32_t s = wave_cnt[lane];
+    if (s) atomicAdd(P.out.counters + lane, (unsigned long long)s);
+  }
+}
+
+}  // namespace odw

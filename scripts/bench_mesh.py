@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
-"""Throughput of the triangle path: a ball lens as analytic sphere and as
-tessellations of growing size (interpolated normals), 1e7 rays each.
-  python scripts/bench_mesh.py
+"""Throughput of the triangle path (BVH kernels): a ball lens as analytic sphere and as tessellations of
+growing size (interpolated normals), behind a Gaussian point source; and the same with a wide beam that
+fills the ball (incoherent rays).
+  python scripts/bench_mesh.py [--segments 0 64 256 1024] [--rays 1e7] [--steps 3] [--warmup 1] [--sigma 0.05]
+One JSON line per case: rays/s from HIP events around the launches (Tracer.timingRead), segments and hits per ray.
 """
+import argparse
 import json
 import os
 import sys
@@ -16,20 +19,28 @@ from freecad.optics_design_workbench_amd.freecad_elements import make, point_sou
 from freecad.optics_design_workbench_amd.scene import Document, bake
 from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
 
+ap = argparse.ArgumentParser()
+ap.add_argument('--segments', type=int, nargs='*', default=[0, 64, 256, 1024], help='0: the analytic sphere')
+ap.add_argument('--rays', type=float, default=1e7)
+ap.add_argument('--steps', type=int, default=3)
+ap.add_argument('--warmup', type=int, default=1)
+ap.add_argument('--sigma', type=float, default=0.05, help='width of the beam (rad); the ball subtends 0.17 rad')
+args = ap.parse_args()
+
 
 def scene(segments):
   doc = Document()
   sp = make.makeSphere(doc, 'S', 5, base=(0, 0, 30))
-  make.makeLens(doc, [sp] if segments is None else [make.makeTessellated(doc, sp, segments)], RefractiveIndex=1.5)
+  make.makeLens(doc, [sp] if not segments else [make.makeTessellated(doc, sp, segments)], RefractiveIndex=1.5)
   make.makeAbsorber(doc, [make.makeBox(doc, 'A', 100, 100, 1, base=(-50, -50, 60))])
   make.makeSimulationSettings(doc)
-  src = make.makePointSource(doc, PowerDensity='exp(-theta**2/0.05**2)')
+  src = make.makePointSource(doc, PowerDensity=f'exp(-theta**2/{args.sigma}**2)')
   return bake.bakeScene(doc, src), bake.bakeLimits(doc, src), point_source.bakeSource(doc, src)
 
 
 tr = Tracer(0)
-n = 10_000_000
-for seg in (None, 64, 256, 1024):
+n = int(args.rays)
+for seg in args.segments:
   t0 = time.perf_counter()
   sc, lim, src = scene(seg)
   t1 = time.perf_counter()
@@ -39,11 +50,19 @@ for seg in (None, 64, 256, 1024):
   tr.trace(1 << 40, 1000, 1)          # includes the BVH build
   tr.sync()
   t2 = time.perf_counter()
-  tr.reset()
-  tr.trace(0, n, 1)
+  for w in range(args.warmup):
+    tr.reset()
+    tr.trace((1 << 41) + w * n, n, 1)
   tr.sync()
-  t3 = time.perf_counter()
+  tr.timingEnable(True)
+  tr.timingRead()
+  for s in range(args.steps):
+    tr.reset()
+    tr.trace(s * n, n, 1)
+  tr.sync()
+  ms, launches = tr.timingRead()
+  tr.timingEnable(False)
   c = tr.counters()
-  print(json.dumps(dict(case='analytic sphere' if seg is None else f'{sc.n_prims - 1} facets', bake_s=round(t1 - t0, 3),
-                        upload_and_bvh_s=round(t2 - t1, 3), rays_per_s=n / (t3 - t2),
+  print(json.dumps(dict(case='analytic sphere' if not seg else f'{sc.n_prims - 1} facets', sigma=args.sigma, bake_s=round(t1 - t0, 3),
+                        upload_and_bvh_s=round(t2 - t1, 3), kernel_ms=ms / max(launches, 1), rays_per_s=n * launches / (ms * 1e-3),
                         segments_per_ray=c['segments'] / n, hits_per_ray=c['recorded_hits'] / n)), flush=True)

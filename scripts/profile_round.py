@@ -27,8 +27,13 @@ ap.add_argument('tag')
 ap.add_argument('--config', default='c3')
 ap.add_argument('--no-bench', action='store_true')
 ap.add_argument('--kernel', default=None, help='substring of the kernel name the counters are taken from')
+ap.add_argument('--script', default=None, help='profile `python3 <script> <script-args>` instead of bench.py (needs --kernel)')
+ap.add_argument('--script-args', default='')
+ap.add_argument('--rays', type=float, default=None, help='with --script: rays per launch')
 args = ap.parse_args()
 tag = args.tag
+if args.script:
+  args.no_bench = True
 KERNEL_NAME = args.kernel or {'c3': 'odw_spec_kernel', 'c4': 'odw_grid_kernel', 'c5': 'odw_spec_kernel'}[args.config]
 KERNEL_LIKE = '%' + KERNEL_NAME + '%'
 out = os.path.join(ROOT, 'gpurun_out')
@@ -36,6 +41,9 @@ os.makedirs(out, exist_ok=True)
 env = dict(os.environ, TMPDIR='/tmp')
 BENCH = ['python3', os.path.join(ROOT, 'bench.py'), '--config', args.config, '--steps', '1' if args.config == 'c5' else '3', '--warmup', '1',
          '--no-cpu-baseline', '--no-end-to-end', '--no-extra']
+if args.script:
+  import shlex
+  BENCH = ['python3', os.path.join(ROOT, args.script)] + shlex.split(args.script_args)
 
 
 def run(cmd, log):
@@ -68,7 +76,7 @@ d = os.path.join(out, f'{tag}_trace')
 # (more launches than the counter passes: the first two or three launches of a process run 5 - 15 %
 #  slower -- clocks, first touch -- and the average should be the steady state bench.py reports)
 TRACE_BENCH = [x for x in BENCH]
-if args.config != 'c5':
+if args.config != 'c5' and not args.script:
   TRACE_BENCH[TRACE_BENCH.index('--steps') + 1] = '16'
   TRACE_BENCH[TRACE_BENCH.index('--warmup') + 1] = '4'
 run(['rocprofv3', '--kernel-trace', '--stats', '-d', d, '--'] + TRACE_BENCH, f'{tag}_trace.log')
@@ -128,7 +136,7 @@ for k, cs in enumerate(sets):
 fetch_raw = avg.get('FETCH_SIZE', 0.0) * 1024          # the counters are in KiB
 write = avg.get('WRITE_SIZE', 0.0) * 1024
 line = json.loads(open(os.path.join(out, f'{tag}_bench.json')).read()) if os.path.exists(os.path.join(out, f'{tag}_bench.json')) else {}
-n_per = line.get('config', {}).get('rays_per_step_per_gpu') or line.get('config', {}).get('rays_per_radius')
+n_per = line.get('config', {}).get('rays_per_step_per_gpu') or line.get('config', {}).get('rays_per_radius') or args.rays
 summary = dict(command='rocprofv3 --pmc <COUNTERS> --kernel-trace -- ' + ' '.join(BENCH[:1] + ['bench.py'] + BENCH[2:]) +
                        ' (one counter set per run)',
                kernel=KERNEL_LIKE.strip('%'), rays_per_launch=n_per,
@@ -196,5 +204,5 @@ entry = dict(kernel=KERNEL_LIKE.strip('%'), rays_per_launch=n_per, fetch_bytes_c
              correction='FETCH_SIZE x2 (gfx950 under-count of wide reads, MI355X_MICROARCH.md HBM section; upper bound for '
                         'this access mix), WRITE_SIZE as is; separate --pmc passes',
              source=f'profiles/{ROUND}/{tag}_pmc.json', valu=valu)
-json.dump({args.config: entry}, open(os.path.join(out, f'{tag}_pmc_current.json'), 'w'), indent=1)
+json.dump({(args.config if not args.script else tag): entry}, open(os.path.join(out, f'{tag}_pmc_current.json'), 'w'), indent=1)
 print(json.dumps(entry)[:600])

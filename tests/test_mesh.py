@@ -158,6 +158,39 @@ def test_device_equals_oracle_on_meshes(tracer, oracle):
 
 
 @pytest.mark.gpu
+def test_mesh_kernel_equals_bvh_kernel(native_lib, monkeypatch):
+  """launches without stochastic surfaces and segment rows take odw_mesh_kernel (node / leaf state machine, float32
+  leaf filter in front of the float64 facet test); ODW_MESH_KERNEL=0 keeps odw_trace_kernel<true, ...>.  The filter
+  only discards facets the float64 test would discard: the same rows, bit for bit, on the mixed scene (facets +
+  analytic primitives in one tree, distTol 1e-6) and on a ball of 6.5e4 facets with distTol 1e-2 (wide rims)."""
+  from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
+  cases = [(_mixed_scene(), 30000)]
+  _, sc, lim, src = _lens_scene(256)
+  cases.append(((sc, lim, src), 200000))
+  doc2, sc2, lim2, src2 = _lens_scene(64)
+  import copy
+  lim2 = copy.copy(lim2)
+  lim2.dist_tol = 1e-2
+  cases.append(((sc2, lim2, src2), 100000))
+  for (sc, lim, src), n in cases:
+    rows = {}
+    for mode in ('1', '0'):
+      monkeypatch.setenv('ODW_MESH_KERNEL', mode)
+      with Tracer(0) as tr:
+        tr.setScene(sc); tr.setSource(src); tr.setLimits(lim); tr.setDetector(None)
+        tr.reserveHits(n * 8)
+        tr.reset()
+        tr.trace(0, n, 11, histogram=False)
+        tr.sync()
+        rows[mode] = (tr.counters(), tr.hits())
+    assert rows['1'][0] == rows['0'][0] and rows['1'][0]['recorded_hits'] > n // 2
+    a, b = rows['1'][1], rows['0'][1]
+    assert np.array_equal(a['tag'], b['tag'])
+    assert np.array_equal(a['point'], b['point']) and np.array_equal(a['direction'], b['direction'])
+    assert np.array_equal(a['power'], b['power'])
+
+
+@pytest.mark.gpu
 def test_large_mesh_matches_analytic_statistics(tracer):
   """2e5 facets (BVH with binned SAH): the ball-lens spot of the tessellated
   lens equals the analytic one within the facet error, all rays accounted for"""
