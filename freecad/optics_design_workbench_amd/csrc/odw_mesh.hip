@@ -29,7 +29,8 @@
 namespace odw {
 
 #ifndef ODW_MESH_STEP_MIN
-#define ODW_MESH_STEP_MIN 16     // keep walking while at least this many lanes of the wave walk (and others wait)
+#define ODW_MESH_STEP_MIN 8      // keep walking while at least this many lanes of the wave walk and others wait
+                                 // (1e6 facets: 8: 26.1 ms, 16: 27.0, 28: 29.8 per 1e7 rays)
 #endif
 #ifndef ODW_MESH_WAVES
 #define ODW_MESH_WAVES 3         // waves per SIMD the register allocation aims at (LDS per block: stacks 24 KB + rings 12 KB)
@@ -337,9 +338,9 @@ __global__ __launch_bounds__(ODW_MESH_THREADS, ODW_MESH_WAVES) void odw_mesh_ker
       }
       cf32 rec0 = leaves + (size_t)lbase * ODW_LEAF_WORDS;
       const auto filter = [&](vf4 w0, vf4 w1, vf4 w2) -> bool {
-        const uint32_t gs = __float_as_uint(w2.y);             // w0: v0x v0y v0z e1x, w1: e1y e1z e2x e2y, w2: e2z gs smax err
-        const bool relevant = ((mask >> (gs & 0xff)) & 1) && (int)((gs >> 8) & 0x7fff) != skip;
-        if (!relevant || (gs >> 31)) return relevant;
+        // w0: v0x v0y v0z e1x, w1: e1y e1z e2x e2y, w2: e2z gs smax err.  Geometry only: whether the facet's group is
+        // relevant and its solid not the one just left is asked of the few that pass
+        if (__float_as_uint(w2.y) >> 31) return true;
         const float e1x = w0.w, e1y = w1.x, e1z = w1.y, e2x = w1.z, e2y = w1.w, e2z = w2.x;
         const float pvx = dy * e2z - dz * e2y, pvy = dz * e2x - dx * e2z, pvz = dx * e2y - dy * e2x;
         const float det = e1x * pvx + e1y * pvy + e1z * pvz;
@@ -353,6 +354,8 @@ __global__ __launch_bounds__(ODW_MESH_THREADS, ODW_MESH_WAVES) void odw_mesh_ker
         // bounds: barycentric slack of the tolerance rules (intersect_tri) + rounding of this arithmetic
         const float m = tolf * w2.z + 1e-6f;
         const float ea = (fabsf(tvx) + fabsf(tvy) + fabsf(tvz)) * w2.w + m * ad;
+        // (tried: the distance as a third condition, t in (tol, nearest + 2 tol) -- 8 % slower: few facets fail on it
+        //  alone, all pay for it)
         return U >= -ea && V >= -ea && U + V <= ad + 2.0f * ea;
       };
       uint64_t pass = 0;
@@ -386,6 +389,7 @@ __global__ __launch_bounds__(ODW_MESH_THREADS, ODW_MESH_WAVES) void odw_mesh_ker
         cf32 rec = rec0 + (size_t)k * ODW_LEAF_WORDS;
         const int p = (int)__float_as_uint(rec[12]);
         const uint32_t gs = __float_as_uint(rec[9]);
+        if (!(((mask >> (gs & 0xff)) & 1) && (int)((gs >> 8) & 0x7fff) != skip)) continue;
         if (gs >> 31) {
           ci32 pi = sv.prim_i32 + 4 * p;
           intersect_prim<true>(sv, q, p, pi[0], pi[1], pi[2], pi[3]);
@@ -398,6 +402,7 @@ __global__ __launch_bounds__(ODW_MESH_THREADS, ODW_MESH_WAVES) void odw_mesh_ker
     }
     ODW_MTIME(3);
     ODW_MSTAT(5, __ballot(alive && !walking && !pending && !fresh));
+    // (tried: waiting until 16 / 32 lanes are done with the tree before the interaction runs -- no difference)
     if (alive && !walking && !pending && !fresh) {
       if (q.any.prim == 0x7fffffff) {
         ODW_MCOUNT(ODW_CNT_ESCAPED);

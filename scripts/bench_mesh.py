@@ -24,6 +24,7 @@ ap.add_argument('--segments', type=int, nargs='*', default=[0, 64, 256, 1024], h
 ap.add_argument('--rays', type=float, default=1e7)
 ap.add_argument('--steps', type=int, default=3)
 ap.add_argument('--warmup', type=int, default=1)
+ap.add_argument('--plain', action='store_true', help='no small first launch (profiles: every dispatch is a full one)')
 ap.add_argument('--sigma', type=float, default=0.05, help='width of the beam (rad); the ball subtends 0.17 rad')
 args = ap.parse_args()
 
@@ -47,8 +48,9 @@ for seg in args.segments:
   tr.setScene(sc); tr.setSource(src); tr.setLimits(lim); tr.setDetector(None)
   tr.reserveHits(n + 1024)
   tr.reset()
-  tr.trace(1 << 40, 1000, 1)          # includes the BVH build
-  tr.sync()
+  if not args.plain:
+    tr.trace(1 << 40, 1000, 1)          # includes the BVH build
+    tr.sync()
   t2 = time.perf_counter()
   for w in range(args.warmup):
     tr.reset()
