@@ -217,7 +217,7 @@ def run_trace_config(args, cfg_name, cfg, rank, local_rank, world, dist, torch):
     # hit rows of one step are the step's output; the buffer is recycled
     tr.reset() if s < 0 else tr.resetHits()
     first = parallel.shardFirst(s if s >= 0 else -s - 1, rank, world, n_per, warm=s < 0)
-    tr.trace(first, n_per, SEED, record_hits=record_hits, histogram=True)
+    tr.trace(first, n_per, SEED, record_hits=record_hits, histogram=not args.no_histogram)
 
   def barrier():
     tr.sync()
@@ -254,7 +254,7 @@ def run_trace_config(args, cfg_name, cfg, rank, local_rank, world, dist, torch):
     assert cnt['traced_rays'] == total_rays, (cnt, total_rays)
     assert cnt['hits_dropped'] == 0, cnt
     hist_total = int(tr.histogram().sum())
-    assert hist_total + cnt['hist_overflow'] == cnt['recorded_hits'], (hist_total, cnt)
+    assert args.no_histogram or hist_total + cnt['hist_overflow'] == cnt['recorded_hits'], (hist_total, cnt)
     kbar = cnt['segments'] / cnt['traced_rays']
     hbar = cnt['recorded_hits'] / cnt['traced_rays']
     bytes_per_ray = kbar * 2 * RAY_STATE_BYTES + hbar * HIT_BYTES
@@ -420,6 +420,7 @@ def main():
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-end-to-end', action='store_true')
   ap.add_argument('--no-hits', action='store_true', help='histogram only (diagnostic, not the metric)')
+  ap.add_argument('--no-histogram', action='store_true', help='hit rows only (diagnostic, not the metric)')
   ap.add_argument('--no-extra', action='store_true',
                   help='c3 only: leave out the c4 (3 steps) and c5 (1 sweep) lines nested under "extra_configs"')
   args = ap.parse_args()

@@ -1173,11 +1173,18 @@ __device__ __noinline__ void next_hit_block(odw_hit* hits, uint64_t capacity, un
 #define ODW_HIST_WIN 88
 #endif
 // the block's first recorded hit opens the window around its bin (once per block and launch: out of line)
+// (around the MEAN bin of the hits that arrive with the first one -- the lanes of the wave that record together, and
+//  whatever other waves add before the opener reads: win[2] = sum of x | count << 20, win[3] the same for y, each
+//  word consistent in itself.  A window around one hit is off by the beam's own width)
 __device__ __forceinline__ void hist_window_open(uint32_t* win, int ix, int iy, int nx, int ny) {
+  atomicAdd(win + 2, (uint32_t)min(ix, 4095) | (1u << 20));     // (256 lanes x 4095 < 2^20)
+  atomicAdd(win + 3, (uint32_t)min(iy, 4095) | (1u << 20));
   if (atomicCAS(win, 0u, ~0u) == 0u) {
     volatile uint32_t* vw = win;
-    vw[1] = (uint32_t)max(0, min(iy - ODW_HIST_WIN / 2, ny - ODW_HIST_WIN));
-    vw[0] = (uint32_t)max(0, min(ix - ODW_HIST_WIN / 2, nx - ODW_HIST_WIN)) + 1u;
+    const uint32_t sx = vw[2], sy = vw[3];
+    const int mx = (sx >> 20) ? (int)((sx & 0xfffffu) / (sx >> 20)) : ix, my = (sy >> 20) ? (int)((sy & 0xfffffu) / (sy >> 20)) : iy;
+    vw[1] = (uint32_t)max(0, min(my - ODW_HIST_WIN / 2, ny - ODW_HIST_WIN));
+    vw[0] = (uint32_t)max(0, min(mx - ODW_HIST_WIN / 2, nx - ODW_HIST_WIN)) + 1u;
   }
 }
 // true: the hit was counted in the window
