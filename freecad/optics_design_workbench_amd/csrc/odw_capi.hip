@@ -1201,6 +1201,13 @@ void odw_destroy(odw_ctx* ctx) {
     if (total)
       for (int k = 0; k < 6; ++k)
         fprintf(stderr, "[odw mesh time] %-16s %14llu ticks  %5.1f %%\n", phases[k], (unsigned long long)v[16 + k], 100.0 * (double)v[16 + k] / (double)total);
+    // (grid kernel, ODW_GRID_STATS: the same for its phases)
+    uint64_t gtotal = 0;
+    for (int k = 24; k < 28; ++k) gtotal += v[k];
+    const char* gphases[4] = {"A refill", "B setup", "C cell steps", "D resolve+interact"};
+    if (gtotal)
+      for (int k = 0; k < 4; ++k)
+        fprintf(stderr, "[odw grid time] %-18s %14llu ticks  %5.1f %%\n", gphases[k], (unsigned long long)v[24 + k], 100.0 * (double)v[24 + k] / (double)gtotal);
     release(ctx->dbg);
   }
   for (auto& ev : ctx->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }

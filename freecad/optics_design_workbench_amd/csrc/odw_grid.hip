@@ -44,7 +44,7 @@ namespace odw {
 #define ODW_GRID_WAVES (ODW_GRID_THREADS / 64)
 #define ODW_GRID_WAVE_WORDS 32   // per wave: event counters (0..7), diagnostics (8..27), hit-block state (28..31)
 #define ODW_GRID_RING 64         // rays per wave in the ring (one per lane and fill)
-#define ODW_GRID_RING_DOUBLES (ODW_GRID_RING * 6)
+#define ODW_GRID_RING_DOUBLES (ODW_GRID_RING * 7)   // per ray: origin, direction, first cell (found when the ring is filled)
 
 // diagnostic build (-DODW_GRID_STATS): per phase, how often it ran and with how many lanes
 #ifdef ODW_GRID_STATS
@@ -53,8 +53,11 @@ namespace odw {
     const unsigned long long m_ = (mask_);                                                            \
     if (m_ && (int)__lane_id() == __ffsll(m_) - 1) { wave_cnt[8 + 2 * (k)] += 1u; wave_cnt[9 + 2 * (k)] += (uint32_t)__popcll(m_); } \
   } while (0)
+// time per phase: s_memtime ticks between marks, kept per wave, added up at the end (odw_destroy prints)
+#define ODW_GTIME(k) do { const uint64_t t_ = __builtin_readcyclecounter(); phase_t[(k)] += t_ - t_mark; t_mark = t_; } while (0)
 #else
 #define ODW_GSTAT(k, mask_) do {} while (0)
+#define ODW_GTIME(k) do {} while (0)
 #endif
 
 // index i with b[i] <= v < b[i+1], clamped to [0, n-1]   (b: n+1 planes in LDS)
@@ -175,6 +178,10 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
     }                                                                                        \
   } while (0)
 
+#ifdef ODW_GRID_STATS
+  uint64_t phase_t[6] = {0, 0, 0, 0, 0, 0};
+  uint64_t t_mark = __builtin_readcyclecounter();
+#endif
   for (;;) {
     // ---- A: new rays for idle lanes, from the wave's ring ------------------------------------------
     const uint64_t idle = __ballot(!alive);
@@ -206,8 +213,34 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
             const RayInit g = generate_ray(P.source, P.first_ray + r, P.seed);
             o = g.point; d = g.dir;
           }
-          double* slot = ring + 6 * lane;
+          // the cell the ray starts in (clipped to the grid), found here, where all 64 lanes generate together,
+          // and not at the set-up of the first segment, which shares its run with lanes that go on from a hit
+          uint32_t first_cell = 0xffffffffu;
+          {
+            const double jx = frcp(d.x), jy = frcp(d.y), jz = frcp(d.z);
+            bool in = true;
+            double t0 = 0.0, t1 = q.tmax;
+#define ODW_CLIP(O, D, INV, LO, HI)                                          \
+            if ((D) != 0) {                                                  \
+              const double a_ = ((LO) - (O)) * (INV), b_ = ((HI) - (O)) * (INV); \
+              t0 = fmax(t0, fmin(a_, b_));                                   \
+              t1 = fmin(t1, fmax(a_, b_));                                   \
+            } else if ((O) < (LO) || (O) > (HI)) {                           \
+              in = false;                                                    \
+            }
+            ODW_CLIP(o.x, d.x, jx, bx[0], bx[nx])
+            ODW_CLIP(o.y, d.y, jy, bx[by_off], bx[by_off + ny])
+            ODW_CLIP(o.z, d.z, jz, bx[bz_off], bx[bz_off + nz])
+#undef ODW_CLIP
+            if (in && t0 <= t1) {
+              const d3 p0 = o + d * t0;
+              first_cell = (uint32_t)grid_slab(bx, nx, p0.x) | ((uint32_t)grid_slab(bx + by_off, ny, p0.y) << 8) |
+                           ((uint32_t)grid_slab(bx + bz_off, nz, p0.z) << 16);
+            }
+          }
+          double* slot = ring + 7 * lane;
           slot[0] = o.x; slot[1] = o.y; slot[2] = o.z; slot[3] = d.x; slot[4] = d.y; slot[5] = d.z;
+          reinterpret_cast<uint32_t*>(slot + 6)[0] = first_cell;
         }
         // (one wave: its LDS operations complete in program order; this only keeps the compiler from
         //  moving the reads below above the writes)
@@ -222,9 +255,10 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
       const uint32_t take = want < ring_n ? want : ring_n;
       if (!alive && rank < take) {
         const uint32_t s = ring_n - 1 - rank;
-        const double* slot = ring + 6 * s;
+        const double* slot = ring + 7 * s;
         point = mk(slot[0], slot[1], slot[2]);
         dir = mk(slot[3], slot[4], slot[5]);
+        cell = (int)reinterpret_cast<const uint32_t*>(slot + 6)[0];       // (-1: the ray misses the grid)
         i = ring_base + s;
         power = P.ray_origins ? (P.ray_powers ? P.ray_powers[i] : 1.0) : as_const(P.source)->power;
         seq = 0; nint = 0; medium = -1; skip = -1;
@@ -232,6 +266,7 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
       }
       ring_n -= take;
     }
+    ODW_GTIME(0);
     // ---- B: set up the next segment of fresh lanes ---------------------------------------------
     ODW_GSTAT(1, __ballot(alive && fresh));
     if (alive && fresh) {
@@ -251,36 +286,14 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
         walking = false;
         if (mask != 0ull) {
           ivx = frcp(dir.x); ivy = frcp(dir.y); ivz = frcp(dir.z);
-          int ix, iy, iz;
-          bool in = true;
-          if (nint > 1) {
-            // A ray that goes on from a hit starts in the cell its walk stopped in: the walk ends in the
-            // cell whose exit lies beyond the hit (+ 2 distTol), so the hit point is in it or within the
-            // tolerance of it.  If it is a hair outside, the plane distance of that axis comes out
-            // negative (or the cell is entered at once) and the first advance corrects the index: at
-            // worst one cell is looked at in vain.
-            ix = cell & 0xff; iy = (cell >> 8) & 0xff; iz = cell >> 16;
-          } else {
-            // a new ray: clip it to the grid, find the first cell
-            double t0 = 0.0, t1 = q.tmax;
-#define ODW_CLIP(O, D, INV, LO, HI)                                          \
-            if ((D) != 0) {                                                  \
-              const double a_ = ((LO) - (O)) * (INV), b_ = ((HI) - (O)) * (INV); \
-              t0 = fmax(t0, fmin(a_, b_));                                   \
-              t1 = fmin(t1, fmax(a_, b_));                                   \
-            } else if ((O) < (LO) || (O) > (HI)) {                           \
-              in = false;                                                    \
-            }
-            ODW_CLIP(point.x, dir.x, ivx, bx[0], bx[nx])
-            ODW_CLIP(point.y, dir.y, ivy, bx[by_off], bx[by_off + ny])
-            ODW_CLIP(point.z, dir.z, ivz, bx[bz_off], bx[bz_off + nz])
-#undef ODW_CLIP
-            in = in && t0 <= t1;
-            const d3 p0 = point + dir * t0;
-            ix = grid_slab(bx, nx, p0.x); iy = grid_slab(bx + by_off, ny, p0.y); iz = grid_slab(bx + bz_off, nz, p0.z);
-          }
+          // A ray that goes on from a hit starts in the cell its walk stopped in: the walk ends in the cell whose
+          // exit lies beyond the hit (+ 2 distTol), so the hit point is in it or within the tolerance of it.  If it
+          // is a hair outside, the plane distance of that axis comes out negative (or the cell is entered at once)
+          // and the first advance corrects the index: at worst one cell is looked at in vain.  A new ray brings
+          // its first cell from the ring.
+          const bool in = cell != -1;
+          const int ix = cell & 0xff, iy = (cell >> 8) & 0xff, iz = (cell >> 16) & 0xff;
           if (in) {
-            cell = ix | (iy << 8) | (iz << 16);
             tx = dir.x > 0 ? (bx[ix + 1] - point.x) * ivx : (dir.x < 0 ? (bx[ix] - point.x) * ivx : INFINITY);
             ty = dir.y > 0 ? (bx[by_off + iy + 1] - point.y) * ivy : (dir.y < 0 ? (bx[by_off + iy] - point.y) * ivy : INFINITY);
             tz = dir.z > 0 ? (bx[bz_off + iz + 1] - point.z) * ivz : (dir.z < 0 ? (bx[bz_off + iz] - point.z) * ivz : INFINITY);
@@ -289,6 +302,7 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
         }
       }
     }
+    ODW_GTIME(1);
     // ---- C: cell steps, all walking lanes together -----------------------------------------------
     for (int it = 0;; ++it) {
       const uint64_t wb = __ballot(walking);
@@ -342,6 +356,7 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
         }
       }
     }
+    ODW_GTIME(2);
     // ---- D: resolution and interaction of the lanes whose walk has stopped -----------------------------
     ODW_GSTAT(3, __ballot(alive && !walking && !fresh));
     if (alive && !walking && !fresh) {
@@ -475,6 +490,7 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
         }
       }
     }
+    ODW_GTIME(3);
   }
 #undef ODW_WALK_ADVANCE
   // slots of the last block this wave never filled (as in odw_trace_kernel)
@@ -490,6 +506,8 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
   }
 #ifdef ODW_GRID_STATS
   if (lane < 12 && P.dbg) atomicAdd(P.dbg + lane, (unsigned long long)wave_cnt[8 + lane]);
+  if (lane == 0 && P.dbg)
+    for (int k = 0; k < 4; ++k) atomicAdd(P.dbg + 24 + k, (unsigned long long)phase_t[k]);
 #endif
   if (lane < ODW_CNT_LDS) {
     const uint32_t s = wave_cnt[lane];
