@@ -1047,8 +1047,7 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
   const bool use_grid = !use_spec && P.grid.nx > 0 && ctx->n_samplers == 0 && !(flags & ODW_TRACE_RECORD_SEGMENTS);
   const uint64_t grid_blocks = std::max<uint64_t>(1, std::min<uint64_t>((n_chunks + ODW_GRID_WAVES - 1) / ODW_GRID_WAVES, (uint64_t)ctx->n_cu));
   // scenes with facets: the mesh kernel (same exclusions)
-  const bool use_mesh = !use_spec && !use_grid && P.scene.n_nodes && P.scene.bvh_leaf && ctx->n_samplers == 0 &&
-                        !(flags & ODW_TRACE_RECORD_SEGMENTS);
+  const bool use_mesh = !use_spec && !use_grid && P.scene.n_nodes && P.scene.bvh_leaf && !(flags & ODW_TRACE_RECORD_SEGMENTS);
   const uint64_t n_waves = use_grid ? grid_blocks * ODW_GRID_WAVES : (uint64_t)grid * 4;
   if ((!P.scene.n_nodes || use_grid || use_spec || use_mesh) && !ctx->swapping &&
       ctx->hit_slots >= ctx->hit_capacity + ctx->hit_capacity / 8 + 64 + n_waves * kHitBlock)
@@ -1092,7 +1091,8 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
   } else if (use_mesh) {
     const size_t mlds = (size_t)ODW_MESH_STACK * ODW_MESH_THREADS * 2 * sizeof(int) +
                         (size_t)ODW_MESH_BLOCK_WAVES * (ODW_MESH_WAVE_WORDS * sizeof(uint32_t) + ODW_MESH_RING_DOUBLES * sizeof(double));
-    hipLaunchKernelGGL(odw_mesh_kernel, dim3(grid), dim3(ODW_MESH_THREADS), mlds, ctx->stream, P);
+    if (stoch) hipLaunchKernelGGL(odw_mesh_kernel<true>, dim3(grid), dim3(ODW_MESH_THREADS), mlds, ctx->stream, P);
+    else hipLaunchKernelGGL(odw_mesh_kernel<false>, dim3(grid), dim3(ODW_MESH_THREADS), mlds, ctx->stream, P);
   } else if (flags & ODW_TRACE_RECORD_SEGMENTS) {
     if (P.scene.n_nodes) {
       if (stoch) hipLaunchKernelGGL((odw_trace_kernel<true, true, true>), dim3(grid), dim3(256), lds, ctx->stream, P);

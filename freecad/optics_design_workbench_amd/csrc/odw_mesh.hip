@@ -21,7 +21,7 @@
 //             a leaf (a screen behind the mesh) skip the filter.
 //   interact  lanes whose stack is empty: nearest-hit selection, normal (interpolated for facets), Snell / mirror
 //             / grating, hit row, next segment -- or a new ray from the wave's ring (filled 64 rays at a time).
-// No stochastic surfaces and no segment rows here: those launches keep odw_trace_kernel<true, ...>.
+// No segment rows here (RecordRays launches of a handful of rays): those keep odw_trace_kernel<true, ...>.
 // Same rules as nearest<>() (ray.py:290-452): every candidate goes through consider(), subtrees are culled
 // against nearest + 2 distTol.
 #include "odw_device.h"
@@ -62,6 +62,8 @@ namespace odw {
 #endif
 #define ODW_MCOUNT(k) atomicAdd(&wave_cnt[(k)], 1u)
 
+// STOCH: the scene has stochastic surfaces (scatter() after the ideal mirror / Snell direction, as in interact<>)
+template <bool STOCH>
 __global__ __launch_bounds__(ODW_MESH_THREADS, ODW_MESH_WAVES) void odw_mesh_kernel(const TraceParams P) {
   extern __shared__ double mesh_lds[];
   const DeviceScene& sc = P.scene;
@@ -438,7 +440,10 @@ __global__ __launch_bounds__(ODW_MESH_THREADS, ODW_MESH_WAVES) void odw_mesh_ker
           record_hit<true, 1, true>(P, P.first_ray + i, g, point, dir, power, entering, wave_cnt, hit_state);
         }
         if (gtype == ODW_OPT_MIRROR) {
-          dir = mirror(dir, n);
+          const d3 ideal = mirror(dir, n);
+          if (STOCH) dir = scatter(P.samplers, P.group_sampler[2 * g], P.group_sampler[2 * g + 1], P.first_ray + i, P.seed,
+                                   (uint32_t)nint, dir, ideal, n, 1.0);
+          else dir = ideal;
           power *= group_f64[4 * g + 1];
           ++seq;
         } else if (gtype == ODW_OPT_LENS) {
@@ -446,7 +451,10 @@ __global__ __launch_bounds__(ODW_MESH_THREADS, ODW_MESH_WAVES) void odw_mesh_ker
           double n2 = 1.0;
           if (entering) { medium = g; n2 = group_f64[4 * g]; }
           bool tir;
-          dir = snells_law(dir, n1, n2, n, tir);
+          const d3 ideal = snells_law(dir, n1, n2, n, tir);
+          if (STOCH) dir = scatter(P.samplers, P.group_sampler[2 * g], P.group_sampler[2 * g + 1], P.first_ray + i, P.seed,
+                                   (uint32_t)nint, dir, ideal, n, tir ? -1.0 : n1 / n2);
+          else dir = ideal;
           if (!entering && !tir && medium == g) { medium = -1; ++seq; }
         } else if (gtype == ODW_OPT_ABSORBER) {
           power = 0;

@@ -172,6 +172,17 @@ def test_mesh_kernel_equals_bvh_kernel(native_lib, monkeypatch):
   lim2 = copy.copy(lim2)
   lim2.dist_tol = 1e-2
   cases.append(((sc2, lim2, src2), 100000))
+  # stochastic surfaces (odw_mesh_kernel<true>): a tessellated ball with a scattering refraction in front of a
+  # tessellated diffuse mirror
+  doc3 = Document()
+  ball = make.makeTessellated(doc3, make.makeSphere(doc3, 'S', 5, base=(0, 0, 30)), 48)
+  make.makeLens(doc3, [ball], RefractiveIndex=1.5, RefractedProbabilityDensity='exp(-(theta-theta_refl)**2/0.005)')
+  dish = make.makeTessellated(doc3, make.makeSphere(doc3, 'M', 40, base=(0, 0, 100)), 64)
+  make.makeMirror(doc3, [dish], ReflectedProbabilityDensity='cos(theta-theta_refl)**8', RecordHits=True)
+  make.makeAbsorber(doc3, [make.makeBox(doc3, 'A', 200, 200, 1, base=(-100, -100, -20))])
+  make.makeSimulationSettings(doc3, MaxIntersections=12.0)
+  src3 = make.makePointSource(doc3, PowerDensity='exp(-theta**2/0.1**2)')
+  cases.append(((bake.bakeScene(doc3, src3), bake.bakeLimits(doc3, src3), point_source.bakeSource(doc3, src3)), 50000))
   for (sc, lim, src), n in cases:
     rows = {}
     for mode in ('1', '0'):
