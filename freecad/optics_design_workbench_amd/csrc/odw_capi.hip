@@ -708,7 +708,7 @@ int build_grid(odw_ctx* ctx, const std::vector<Box>& boxes, const std::vector<ch
   std::vector<double> recs;
   if (spheres) {
     // 48-byte records: centre (global; prim_f64 12..15 = R, cx, cy, cz as the flat kernel reads them),
-    // radius, {primitive, group | solid << 8}
+    // radius, {primitive, group | solid << 8}, the primitive's flag word
     recs.resize(std::max<size_t>(total, 1) * 6, 0.0);
     for (size_t k = 0; k < total; ++k) {
       const uint32_t p = item_prim[k];
@@ -718,6 +718,8 @@ int build_grid(odw_ctx* ctx, const std::vector<Box>& boxes, const std::vector<ch
       o[0] = par[1]; o[1] = par[2]; o[2] = par[3]; o[3] = par[0];
       const uint64_t bits = (uint64_t)p | ((uint64_t)(uint32_t)((pi[1] & 0xff) | ((pi[2] >> ODW_SOLID_SHIFT) << 8)) << 32);
       std::memcpy(&o[4], &bits, sizeof bits);
+      const uint64_t flag_word = (uint64_t)(uint32_t)pi[2];          // (flags | facemask << 8 | solid << 16, for the interaction)
+      std::memcpy(&o[5], &flag_word, sizeof flag_word);
     }
     item_bytes = recs.size() * sizeof(double);
     if ((rc = upload(ctx, ctx->grid_items, recs.data(), item_bytes))) return rc;
@@ -1080,7 +1082,7 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
       const uint64_t dev_bit = 1ull << (ctx->device & 63);                                                     \
       if (!(attr_set & dev_bit)) {                                                                             \
         HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&odw_grid_kernel<S, L>),                 \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));              \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));   /* + 4.5 KB static */ \
         attr_set |= dev_bit;                                                                                   \
       }                                                                                                        \
       hipLaunchKernelGGL((odw_grid_kernel<S, L>), gb, dim3(ODW_GRID_THREADS), glds, ctx->stream, P);           \

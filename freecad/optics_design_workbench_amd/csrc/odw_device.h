@@ -93,7 +93,7 @@ struct DeviceScene {
 struct DeviceGrid {
   const double* bounds;         // [nx+1 | ny+1 | nz+1]
   const uint32_t* cells;        // [nx*ny*nz] first item | count << 24, x fastest
-  const void* items;            // spheres: 48-byte records (cx, cy, cz, R, {prim, group | solid << 8}, -)
+  const void* items;            // spheres: 48-byte records (cx, cy, cz, R, {prim, group | solid << 8}, flag word)
                                 // else   : u32 primitive indices
   int32_t nx, ny, nz, n_items;
   int32_t spheres;              // every listed primitive is an untrimmed sphere

@@ -113,9 +113,20 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
   sv.prim_hdr = as_const(sc.prim_hdr);
   sv.prim_i32 = as_const(sc.prim_i32);
   sv.cond_i32 = as_const(sc.cond_i32);
-  cf64 group_f64 = as_const(sc.group_f64);
-  ci32 group_i32 = as_const(sc.group_i32);
-  cf64 group_gdir = as_const(sc.group_gdir);
+  // the groups' tables (64 x {ior, reflectivity, absorption length, lines per mm | optical type, record, grating type,
+  // order | grating direction}: 4.5 KB) are read at every interaction with a per-lane index: from LDS, not through the
+  // vector cache (a chain of two to three dependent global loads per interaction otherwise)
+  __shared__ double group_f64[64 * 4];
+  __shared__ int32_t group_i32[64 * 4];
+  __shared__ double group_gdir[64 * 3];
+  {
+    cf64 gf = as_const(sc.group_f64);
+    ci32 gi = as_const(sc.group_i32);
+    cf64 gd = as_const(sc.group_gdir);
+    for (int k = threadIdx.x; k < 64 * 4; k += ODW_GRID_THREADS) { group_f64[k] = gf[k]; group_i32[k] = gi[k]; }
+    for (int k = threadIdx.x; k < 64 * 3; k += ODW_GRID_THREADS) group_gdir[k] = gd[k];
+  }
+  __syncthreads();
   cu64 seq_mask = as_const(sc.seq_mask);
 
   const uint32_t lane = __lane_id();
@@ -388,7 +399,9 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
               double ta, tb;
               if (quad_roots_unit(dot(oc, dir), dot(oc, oc) - r1.y * r1.y, ta, tb) == 2) {
                 const double bt = ta > q.tol ? ta : (tb > q.tol ? tb : INFINITY);
-                consider(sv, q, bt, prim, 0, g, 0, 0);
+                // (a sphere has one face: the candidate's face word carries the record's index instead, so that the
+                //  interaction finds centre, flags and group where the cheap test found them -- hit rows hold no face)
+                consider(sv, q, bt, prim, (int)(first + k), g, 0, 0);
               }
             }
           } else {
@@ -411,8 +424,6 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
           const double t_hit = use_oth ? q.oth.t : q.any.t;
           const int face = use_oth ? q.oth.face : q.any.face;
           const int prim = use_oth ? q.oth.prim : q.any.prim;
-          cf64 pf = sv.prim_f64 + (size_t)prim * 16;
-          ci32 pi = sv.prim_i32 + 4 * prim;
           point = point + dir * t_hit;
           if (medium >= 0) {                                  // ray.py:120-125 (assignment)
             const double L = group_f64[4 * medium + 2];
@@ -420,20 +431,34 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
             else if (L < INFINITY) power = exp(-t_hit / L);
           }
           d3 n;
+          int g, pflags;
           if (SPHERES) {
-            // a sphere's outward normal needs no frame either: (point - centre) / |.|, centre in global
-            // coordinates (prim_f64 row: 12 = R, 13..15 = centre, as in intersect_prim)
-            const d3 v = point - mk(pf[13], pf[14], pf[15]);
+            // a sphere's outward normal needs no frame either: (point - centre) / |.|; centre, group and flag word
+            // from the record of the cheap test (`face` = its index): no read of the primitive tables
+            double2 r0, r1, r2;
+            if (IN_LDS) {
+              const double2* rec = reinterpret_cast<const double2*>(grid_lds + item_off) + 3 * (size_t)face;
+              r0 = rec[0]; r1 = rec[1]; r2 = rec[2];
+            } else {
+              const double2* rec = reinterpret_cast<const double2*>(GD.items) + 3 * (size_t)face;
+              r0 = rec[0]; r1 = rec[1]; r2 = rec[2];
+            }
+            const d3 v = point - mk(r0.x, r0.y, r1.x);
             n = v * frsqrt(dot(v, v));
-            if (pi[2] & ODW_FLAG_FLIP_NORMAL) n = n * -1.0;
+            g = (int)(((uint64_t)__double_as_longlong(r2.x) >> 32) & 0xff);
+            pflags = (int)(uint32_t)(uint64_t)__double_as_longlong(r2.y);
+            if (pflags & ODW_FLAG_FLIP_NORMAL) n = n * -1.0;
           } else {
+            cf64 pf = sv.prim_f64 + (size_t)prim * 16;
+            ci32 pi = sv.prim_i32 + 4 * prim;
             n = face_normal(pi[0], pf + 12, face, xf_point(pf, point));
-            if (pi[2] & ODW_FLAG_FLIP_NORMAL) n = n * -1.0;
+            g = pi[1];
+            pflags = pi[2];
+            if (pflags & ODW_FLAG_FLIP_NORMAL) n = n * -1.0;
             n = xf_vec_t(pf, n);
           }
           const bool entering = dot(dir, n) < 0;
           if (entering) n = n * -1.0;
-          const int g = pi[1];
           const int gtype = group_i32[4 * g];
           if (group_i32[4 * g + 1]) {
             ODW_GCOUNT(ODW_CNT_RECORDED_HITS);
@@ -480,7 +505,7 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
               if (!tir) { medium = -1; ++seq; }
             }
           }
-          skip = ((pi[2] & ODW_FLAG_CONVEX) && (entering ? -dot(dir, n) : dot(dir, n)) > 0) ? (pi[2] >> ODW_SOLID_SHIFT) : -1;
+          skip = ((pflags & ODW_FLAG_CONVEX) && (entering ? -dot(dir, n) : dot(dir, n)) > 0) ? (pflags >> ODW_SOLID_SHIFT) : -1;
           if (alive && power < lim.power_tol) { ODW_GCOUNT(ODW_CNT_DIED); alive = false; }
           fresh = alive;
         }
