@@ -86,9 +86,18 @@ __global__ __launch_bounds__(ODW_MESH_THREADS, ODW_MESH_WAVES) void odw_mesh_ker
   sv.prim_hdr = as_const(sc.prim_hdr);
   sv.prim_i32 = as_const(sc.prim_i32);
   sv.cond_i32 = as_const(sc.cond_i32);
-  cf64 group_f64 = as_const(sc.group_f64);
-  ci32 group_i32 = as_const(sc.group_i32);
-  cf64 group_gdir = as_const(sc.group_gdir);
+  // the groups' tables, read at every interaction with a per-lane index: from LDS (as in the grid kernel)
+  __shared__ double group_f64[64 * 4];
+  __shared__ int32_t group_i32[64 * 4];
+  __shared__ double group_gdir[64 * 3];
+  {
+    cf64 gf = as_const(sc.group_f64);
+    ci32 gi = as_const(sc.group_i32);
+    cf64 gd = as_const(sc.group_gdir);
+    for (int k = threadIdx.x; k < 64 * 4; k += ODW_MESH_THREADS) { group_f64[k] = gf[k]; group_i32[k] = gi[k]; }
+    for (int k = threadIdx.x; k < 64 * 3; k += ODW_MESH_THREADS) group_gdir[k] = gd[k];
+  }
+  __syncthreads();
   cu64 seq_mask = as_const(sc.seq_mask);
   typedef const float ODW_CONST* cf32;
   typedef const uint32_t ODW_CONST* cu32;
