@@ -21,8 +21,10 @@ constexpr int kPhLdsEdges = 2048;
 // key = ray index of a selected row, `sentinel` (above every ray index of the list) for everything else;
 // counts[0] += selected rows, counts[1] += those that leave.  Grid-stride, one pair of atomics per block: one
 // pair per wave serialised 3e5 memory-side atomics of a 1e7-row list on two addresses (1.9 ms; now 0.1).
+// K: uint32_t when ray indices and the sentinel fit 32 bits (the sort then moves half the bytes), else uint64_t
+template <class K>
 __global__ __launch_bounds__(256) void ph_keys_kernel(const odw_hit* __restrict__ hits, uint64_t n, int group, uint64_t sentinel,
-                                                      uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                      K* __restrict__ keys, uint32_t* __restrict__ vals,
                                                       unsigned long long* __restrict__ counts) {
   uint32_t n_sel = 0, n_leave = 0;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -31,7 +33,7 @@ __global__ __launch_bounds__(256) void ph_keys_kernel(const odw_hit* __restrict_
     const bool sel = tag != ODW_TAG_UNUSED && (group < 0 || (int)ODW_HIT_GROUP(tag) == group);
     n_sel += sel ? 1u : 0u;
     n_leave += (sel && !ODW_HIT_ENTERING(tag)) ? 1u : 0u;
-    keys[i] = sel ? ODW_HIT_RAY(tag) : sentinel;         // everything else sorts behind every ray
+    keys[i] = (K)(sel ? ODW_HIT_RAY(tag) : sentinel);    // everything else sorts behind every ray
     vals[i] = (uint32_t)i;
   }
 #pragma unroll
@@ -489,15 +491,29 @@ int odw_hits_select(odw_ctx* ctx, int32_t group, uint64_t* n_rows, uint64_t* n_l
     if (ctx->hit_ray_end && ctx->hit_ray_end < (1ull << 48)) { bits = 1; while ((1ull << bits) < ctx->hit_ray_end) ++bits; }
     const uint64_t sentinel = 1ull << bits;
     const unsigned kgrid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((used + 255) / 256, (uint64_t)ctx->n_cu * 8));
-    hipLaunchKernelGGL(ph_keys_kernel, dim3(kgrid), dim3(256), 0, ctx->stream, (const odw_hit*)ctx->hits.p, used, (int)group,
-                       sentinel, k_in, v_in, (unsigned long long*)ctx->ph_small.p);
-    HIPCHK(ctx, hipGetLastError());
     size_t tmp_bytes = 0;
-    HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k_in, k_out, v_in, v_out, (int)used, 0, bits + 1,
-                                                   ctx->stream));
-    if ((rc = ensure(ctx, ctx->sort_tmp, tmp_bytes))) return rc;
-    HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(ctx->sort_tmp.p, tmp_bytes, k_in, k_out, v_in, v_out, (int)used, 0,
-                                                   bits + 1, ctx->stream));
+    static const bool keys64 = getenv("ODW_SELECT_KEYS64") != nullptr;        // (A/B runs)
+    if (bits + 1 <= 32 && !keys64) {
+      uint32_t* k32_in = (uint32_t*)k_in;
+      uint32_t* k32_out = (uint32_t*)k_out;
+      hipLaunchKernelGGL(ph_keys_kernel<uint32_t>, dim3(kgrid), dim3(256), 0, ctx->stream, (const odw_hit*)ctx->hits.p, used,
+                         (int)group, sentinel, k32_in, v_in, (unsigned long long*)ctx->ph_small.p);
+      HIPCHK(ctx, hipGetLastError());
+      HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k32_in, k32_out, v_in, v_out, (int)used, 0, bits + 1,
+                                                     ctx->stream));
+      if ((rc = ensure(ctx, ctx->sort_tmp, tmp_bytes))) return rc;
+      HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(ctx->sort_tmp.p, tmp_bytes, k32_in, k32_out, v_in, v_out, (int)used, 0,
+                                                     bits + 1, ctx->stream));
+    } else {
+      hipLaunchKernelGGL(ph_keys_kernel<uint64_t>, dim3(kgrid), dim3(256), 0, ctx->stream, (const odw_hit*)ctx->hits.p, used,
+                         (int)group, sentinel, k_in, v_in, (unsigned long long*)ctx->ph_small.p);
+      HIPCHK(ctx, hipGetLastError());
+      HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k_in, k_out, v_in, v_out, (int)used, 0, bits + 1,
+                                                     ctx->stream));
+      if ((rc = ensure(ctx, ctx->sort_tmp, tmp_bytes))) return rc;
+      HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(ctx->sort_tmp.p, tmp_bytes, k_in, k_out, v_in, v_out, (int)used, 0,
+                                                     bits + 1, ctx->stream));
+    }
     uint64_t c[2] = {0, 0};
     HIPCHK(ctx, hipMemcpyAsync(c, ctx->ph_small.p, sizeof c, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
