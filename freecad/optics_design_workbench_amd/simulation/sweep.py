@@ -107,7 +107,8 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
                          on a thinned sample, projection, medians and binning on the device); False:
                          copy every row to the host first (what the reference does)
   pipeline               with deviceHits on a device tracer: a second context on the same GPU, so that
-                         value k + 1 is baked and traced while value k is measured (same results)
+                         value k + 1 is baked and traced while value k is measured (same results); an integer
+                         n: n extra contexts (n measuring threads)
   """
   # (collectives run on the GPU the tracer works on: one process per GPU, each with its own device)
   ranks = parallel.Ranks.detect(dist, getattr(tracer, 'device', device) if tracer is not None else device)
@@ -129,12 +130,14 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
   # the compiled kernel is shared through the process cache.  Only for device tracers measured in HBM.
   lanes = [tr]
   if pipeline and deviceHits and isinstance(tr, Tracer) and len(mine) > 1:
-    second = Tracer(tr.device, referenceStrict=tr.referenceStrict)
-    try:
-      second.compileScene({0: 'off', 1: 'structure', 2: 'auto'}[tr.compileMode()])
-    except Exception:
-      pass
-    lanes.append(second)
+    # (pipeline = 3: two measuring threads -- the measure is partly host work under the GIL, partly waits for the GPU)
+    for _ in range(min(int(pipeline) if pipeline is not True else 1, len(mine) - 1, 3)):
+      extra = Tracer(tr.device, referenceStrict=tr.referenceStrict)
+      try:
+        extra.compileScene({0: 'off', 1: 'structure', 2: 'auto'}[tr.compileMode()])
+      except Exception:
+        pass
+      lanes.append(extra)
   uploaded = [dict() for _ in lanes]
   table = np.zeros((len(values), len(names), 2))        # (result or 0, 1 = a number / 2 = nan)
   totals = np.zeros(3, dtype=np.int64)
