@@ -202,6 +202,57 @@ def test_mesh_kernel_equals_bvh_kernel(native_lib, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_mesh_kernel_on_a_lopsided_tree(native_lib, oracle, monkeypatch):
+  """facets whose sizes and spacings grow geometrically along an axis (a horn of 1200 quadrilateral rings between
+  1e-3 and 1e3 mm): the surface-area heuristic peels them off one side, the binary tree comes out as high as the
+  builder lets it, and the eight-wide tree of the mesh kernel has to open the tallest subtrees first to stay inside
+  its 12 levels -- or the library falls back to the binary kernels.  Either way: the rows of the oracle."""
+  from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
+  rings, sides = 1200, 6
+  z = 1e-3 * (1e6 ** (np.arange(rings + 1) / rings))
+  r = 0.3 * z**0.9                      # (a ray from the apex at angle t meets the wall where 0.3 z^-0.1 = tan t)
+  ang = 2 * np.pi * np.arange(sides) / sides
+  v = np.concatenate([np.column_stack([rk * np.cos(ang), rk * np.sin(ang), np.full(sides, zk)]) for rk, zk in zip(r, z)])
+  tri = []
+  for k in range(rings):
+    for j in range(sides):
+      a, b = k * sides + j, k * sides + (j + 1) % sides
+      c, d = a + sides, b + sides
+      tri += [[a, b, d], [a, d, c]]
+  doc = Document()
+  make.makeMirror(doc, [make.makeMesh(doc, v, np.array(tri), placement=None)], RecordHits=True)
+  make.makeAbsorber(doc, [make.makeBox(doc, 'A', 4000, 4000, 1, base=(-2000, -2000, 1500))])
+  make.makeSimulationSettings(doc, MaxIntersections=40.0)
+  src = make.makePointSource(doc, PowerDensity='1', ThetaDomain='0.1, 0.62')
+  sc, lim, bs = bake.bakeScene(doc, src), bake.bakeLimits(doc, src), point_source.bakeSource(doc, src)
+  assert (sc.prim_type == geometry.TRIANGLE).sum() == 2 * rings * sides
+  n = 20000
+  ref = oracle.trace(sc, bs, lim, 0, n, 5, flags=1, nthreads=0, hit_capacity=n * 41)
+  rows = {}
+  for mode in ('1', '0'):
+    monkeypatch.setenv('ODW_MESH_KERNEL', mode)
+    with Tracer(0) as tr:
+      tr.setScene(sc); tr.setSource(bs); tr.setLimits(lim); tr.setDetector(None)
+      tr.reserveHits(n * 41)
+      tr.reset()
+      tr.trace(0, n, 5, histogram=False)
+      tr.sync()
+      rows[mode] = (tr.counters(), tr.hits())
+  assert rows['1'][0] == rows['0'][0]
+  assert np.array_equal(rows['1'][1]['tag'], rows['0'][1]['tag']) and np.array_equal(rows['1'][1]['point'], rows['0'][1]['point'])
+  # against the oracle: the source sits at the horn's apex, rays meet the wall between 1e-3 and 1e3 mm and bounce on
+  c, h = rows['1']
+  assert c['recorded_hits'] > 2 * n
+  m48 = np.uint64(0xFFFFFFFFFFFF)
+  gr, rr = (h['tag'] & m48).astype(np.int64), (ref['hits']['tag'] & m48).astype(np.int64)
+  cg, cr = np.bincount(gr, minlength=n), np.bincount(rr, minlength=n)
+  ok = (cg == cr) & (cg <= 10)
+  assert (cg == cr).mean() > 0.995 and ok.mean() > 0.4
+  assert np.array_equal(h['tag'][ok[gr]], ref['hits']['tag'][ok[rr]])
+  assert np.abs(h['point'][ok[gr]] - ref['hits']['point'][ok[rr]]).max() < 1e-6
+
+
+@pytest.mark.gpu
 def test_large_mesh_matches_analytic_statistics(tracer):
   """2e5 facets (BVH with binned SAH): the ball-lens spot of the tessellated
   lens equals the analytic one within the facet error, all rays accounted for"""
