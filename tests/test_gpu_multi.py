@@ -155,6 +155,25 @@ def test_bench_config_lines_c4_and_c5(native_lib):
   assert all(v > 0 for v in spot['rms_spot_mm']) and 9 <= spot['best_radius_by_rms_mm'] <= 11
 
 
+def test_default_bench_line_carries_the_three_gpu_configs(native_lib):
+  """the driver's command (`python bench.py`, here with fewer steps): the c3 headline with a roofline that is a
+  bound -- calibrated VALU issue, no fraction above 1 -- and c4 / c5 nested under `extra_configs`, each with its
+  own roofline block (profiles/pmc_current.json holds counters for exactly these workloads)"""
+  out = _line(_bench('--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-end-to-end'))
+  assert out['config']['name'] == 'c3' and out['n_gpus'] == 1 and out['value'] > 5e9
+  lines = dict(c3=out, **out['extra_configs'])
+  assert set(lines) == {'c3', 'c4', 'c5'}
+  for name, line in lines.items():
+    r = line['roofline']
+    assert r['bound'] == 'valu_issue' and 0.3 < r['frac'] <= 1.0, (name, r)
+    for key in ('wavefront_equivalent_frac', 'hbm_counter_frac', 'fp64_flops_frac'):
+      assert r.get(key) is None or 0 <= r[key] < 1.5, (name, key, r[key])
+    assert r.get('hbm_counter_frac') is None or r['hbm_counter_frac'] < 1
+    assert r.get('fp64_flops_frac') is None or r['fp64_flops_frac'] < 1
+  assert lines['c4']['value'] > 3e9 and lines['c4']['roofline']['valu']['active_lanes_per_inst'] > 25
+  assert lines['c5']['value'] > 5e8 and lines['c5']['steps'] == 2
+
+
 @two_ranks
 def test_bench_on_two_gpus_reports_two_gpus(native_lib):
   """`bench.py --gpus 2` (starts its two ranks itself): n_gpus 2, twice the rays, counters and histogram of the whole
