@@ -106,9 +106,9 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
   deviceHits             measure on the hit rows where they are, in HBM (`DeviceHits`: plane search
                          on a thinned sample, projection, medians and binning on the device); False:
                          copy every row to the host first (what the reference does)
-  pipeline               with deviceHits on a device tracer: a second context on the same GPU, so that
-                         value k + 1 is baked and traced while value k is measured (same results); an integer
-                         n: n extra contexts (n measuring threads)
+  pipeline               with deviceHits on a device tracer: further contexts on the same GPU (True: two), so
+                         that value k + 1 is baked and traced while values k and k - 1 are measured (same
+                         results); an integer n: n extra contexts (n measuring threads)
   """
   # (collectives run on the GPU the tracer works on: one process per GPU, each with its own device)
   ranks = parallel.Ranks.detect(dist, getattr(tracer, 'device', device) if tracer is not None else device)
@@ -124,14 +124,15 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
   from .simulation_loop import bakeLightSource
   own = tracer is None
   tr = tracer or Tracer(device)
-  # Two contexts on the same GPU take turns: while a worker thread measures the rows of value k on one of them
+  # Contexts on the same GPU take turns: while worker threads measure the rows of earlier values on theirs
   # (selection, the plane search on the host, projection, binning -- GPU work and host work in alternation),
-  # the main thread bakes and traces value k + 1 on the other.  Each context has its own stream and hit list;
+  # the main thread bakes and traces the next value on a free one.  Each context has its own stream and hit list;
   # the compiled kernel is shared through the process cache.  Only for device tracers measured in HBM.
   lanes = [tr]
   if pipeline and deviceHits and isinstance(tr, Tracer) and len(mine) > 1:
-    # (pipeline = 3: two measuring threads -- the measure is partly host work under the GIL, partly waits for the GPU)
-    for _ in range(min(int(pipeline) if pipeline is not True else 1, len(mine) - 1, 3)):
+    # (two measuring threads by default: the measure is partly host work under the GIL, partly waits for the GPU --
+    #  one thread read 243 - 338 ms per 64 x 1e7 sweep from run to run, two 248 - 273, three 247 - 264)
+    for _ in range(min(int(pipeline) if pipeline is not True else 2, len(mine) - 1, 3)):
       extra = Tracer(tr.device, referenceStrict=tr.referenceStrict)
       try:
         extra.compileScene({0: 'off', 1: 'structure', 2: 'auto'}[tr.compileMode()])

@@ -17,8 +17,9 @@ from freecad.optics_design_workbench_amd.scene import open_fcstd
 from freecad.optics_design_workbench_amd.simulation import sweep
 from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
 
-n_radii = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-rays = int(float(sys.argv[2])) if len(sys.argv) > 2 else 10_000_000
+argv = [a for a in sys.argv[1:] if not a.startswith('--')]
+n_radii = int(argv[0]) if len(argv) > 0 else 64
+rays = int(float(argv[1])) if len(argv) > 1 else 10_000_000
 radii = np.linspace(9, 11, n_radii)
 doc = open_fcstd(os.path.join(ROOT, 'tests', 'golden', 'scenes', 'GettingStarted.FCStd'))
 
@@ -41,13 +42,14 @@ def run(pipeline):
 
 
 run(True)
-for p in (True, 2, 3, False, True, 2, 3):
+for p in (True, 2, True, 2, True, 2, True, 2, True, 2, 3, 3, 3):
   t = time.perf_counter()
   run(p)
   print('pipeline', p, '%.1f ms per sweep' % (1e3 * (time.perf_counter() - t)), flush=True)
-pr = cProfile.Profile()
-pr.enable()
-run(False)
-pr.disable()
-st = pstats.Stats(pr)
-st.sort_stats('cumulative').print_stats(45)
+if '--profile' in sys.argv:
+  pr = cProfile.Profile()
+  pr.enable()
+  run(False)
+  pr.disable()
+  st = pstats.Stats(pr)
+  st.sort_stats('cumulative').print_stats(45)
