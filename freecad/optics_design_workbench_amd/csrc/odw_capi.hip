@@ -1963,8 +1963,11 @@ int odw_fetch_hits(odw_ctx* ctx, odw_hit* out, uint64_t capacity, uint64_t* n) {
     // (only the bits ray indices of this list can have, + 1 for the sentinel: see odw_hits_select)
     int bits = 48;
     if (ctx->hit_ray_end && ctx->hit_ray_end < (1ull << 48)) { bits = 1; while ((1ull << bits) < ctx->hit_ray_end) ++bits; }
+    const bool spare = ctx->hit_ray_end && ctx->hit_ray_end < (1ull << bits);
+    const uint64_t sentinel = spare ? (1ull << bits) - 1 : 1ull << bits;
+    if (spare) --bits;
     hipLaunchKernelGGL(hit_keys_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const odw_hit*)ctx->hits.p,
-                       used, 1ull << bits, k_in, v_in);
+                       used, sentinel, k_in, v_in);
     HIPCHK(ctx, hipGetLastError());
     size_t tmp_bytes = 0;
     HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k_in, k_out, v_in, v_out, (int)used, 0, bits + 1,

@@ -485,11 +485,15 @@ int odw_hits_select(odw_ctx* ctx, int32_t group, uint64_t* n_rows, uint64_t* n_l
     uint64_t* k_out = (uint64_t*)ctx->sort_keys[1].p;
     uint32_t* v_in = (uint32_t*)ctx->sort_vals[0].p;
     uint32_t* v_out = (uint32_t*)ctx->sort_vals[1].p;
-    // ray indices of the list lie below hit_ray_end (launch_trace keeps it): the sort needs their bits only, plus
-    // one for the sentinel of the rows that are not selected (1e7 rays: 25 bits = 4 passes instead of 7)
+    // ray indices of the list lie below hit_ray_end (launch_trace keeps it): the sort needs their bits only; the
+    // sentinel of the rows that are not selected is the largest number of that many bits when no ray has it
+    // (1e7 rays: 24 bits = 3 passes of 8 instead of 7; a 25th bit for the sentinel alone made a fourth pass in which
+    // every key had the same digit -- the slowest of all, 0.29 ms of 0.86)
     int bits = 48;
     if (ctx->hit_ray_end && ctx->hit_ray_end < (1ull << 48)) { bits = 1; while ((1ull << bits) < ctx->hit_ray_end) ++bits; }
-    const uint64_t sentinel = 1ull << bits;
+    const bool spare = ctx->hit_ray_end && ctx->hit_ray_end < (1ull << bits);      // ray indices stay below 2^bits - 1
+    const uint64_t sentinel = spare ? (1ull << bits) - 1 : 1ull << bits;
+    if (spare) --bits;                                                             // (the sorts below take bits + 1)
     const unsigned kgrid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((used + 255) / 256, (uint64_t)ctx->n_cu * 8));
     size_t tmp_bytes = 0;
     static const bool keys64 = getenv("ODW_SELECT_KEYS64") != nullptr;        // (A/B runs)

@@ -16,6 +16,8 @@ into every rank with ONE collective at the end (each rank contributes its own
 entries, zeros elsewhere).  Rays are addressed by the global Philox index, so a
 value's result does not depend on which GPU ran it.
 """
+import sys
+
 import numpy as np
 
 from ..jupyter_utils.hits import Hits
@@ -149,6 +151,14 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
   pending = [None] * len(lanes)
 
   def measureInto(t, scene, k):
+    t_m = time.perf_counter() if clock is not None else 0.0
+    try:
+      _measure(t, scene, k)
+    finally:
+      if clock is not None:
+        clock['measure'] += time.perf_counter() - t_m      # (summed over the measuring threads)
+
+  def _measure(t, scene, k):
     if deviceHits and hasattr(t, 'deviceHits'):
       hits = t.deviceHits()
     else:
@@ -161,17 +171,23 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
       m = float(measures[name](hits)) if len(hits) else np.nan
       table[k, j] = (0.0, 2.0) if np.isnan(m) else (m, 1.0)
 
+  import os
+  import time
+  clock = dict(wait=0.0, bake=0.0, trace=0.0, measure=0.0) if os.environ.get('ODW_SWEEP_TIMING') else None
   try:
     for turn, k in enumerate(mine):
       lane = turn % len(lanes)
       t, up = lanes[lane], uploaded[lane]
+      t0 = time.perf_counter()
       if pending[lane] is not None:
         pending[lane].result()          # the rows of this context are free again (and its errors surface here)
         pending[lane] = None
+      t1 = time.perf_counter()
       setValue(doc, values[k])
       scene = _bake.bakeScene(doc, src)
       bsrc = bakeLightSource(doc, src, seed)
       lim = _bake.bakeLimits(doc, src, **traceKwargs)
+      t2 = time.perf_counter()
       # (tables travel to the device only when they change: a sweep of one shape parameter uploads
       #  the source's 1.6 MB of sampler tables once)
       t.setScene(scene)
@@ -195,6 +211,9 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
           break
         capacity = int(cnt['recorded_hits'] * 1.05) + 1024      # deterministic: trace again with room
       totals += (cnt['traced_rays'], cnt['recorded_hits'], cnt['segments'])
+      if clock is not None:
+        t3 = time.perf_counter()
+        clock['wait'] += t1 - t0; clock['bake'] += t2 - t1; clock['trace'] += t3 - t2
       if pool is not None:
         pending[lane] = pool.submit(measureInto, t, scene, k)
       else:
@@ -209,6 +228,9 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
       extra.close()
     if own:
       tr.close()
+  if clock is not None:
+    print('[odw sweep timing] ms per value: ' + ', '.join(f'{k} {1e3 * v / max(len(mine), 1):.2f}' for k, v in clock.items()),
+          file=sys.stderr, flush=True)
   flat = ranks.sumFloats(np.concatenate([table.ravel(), totals.astype(np.float64)]))
   table = np.asarray(flat[:table.size]).reshape(table.shape)
   if not np.all((table[..., 1] == 1) | (table[..., 1] == 2)):
