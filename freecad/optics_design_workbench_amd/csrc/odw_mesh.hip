@@ -35,6 +35,11 @@ namespace odw {
 #ifndef ODW_MESH_WAVES
 #define ODW_MESH_WAVES 3         // waves per SIMD the register allocation aims at (LDS per block: stacks 24 KB + rings 12 KB)
 #endif
+#ifndef ODW_MESH_CAND_TRIPS
+#define ODW_MESH_CAND_TRIPS 3    // trips of four records per lane and leaf round (0: all of the visit's candidates at once:
+                                 // 13.1 / 18.3 / 25.1 ms per 1e7 rays at 4e3 / 6.5e4 / 1e6 facets; 2: 12.6 / 17.3 / 26.1;
+                                 // 3: 12.9 / 16.9 / 24.4; 4: 13.2 / 17.1 / 23.9)
+#endif
 #define ODW_MESH_THREADS 256
 #define ODW_MESH_BLOCK_WAVES (ODW_MESH_THREADS / 64)
 #define ODW_MESH_WAVE_WORDS 32   // per wave: event counters (0..7), diagnostics (8..27), hit-block state (28..31)
@@ -130,7 +135,8 @@ __global__ __launch_bounds__(ODW_MESH_THREADS, ODW_MESH_WAVES) void odw_mesh_ker
   float ofx = 0, ofy = 0, ofz = 0, ivx = 0, ivy = 0, ivz = 0, cutf = 0, tsh = 0;
   uint32_t oct = 0;
   int cur = -1, sp = 0;
-  uint32_t lbase = 0, lcounts = 0, lhits = 0;
+  uint32_t lbase = 0, lcounts = 0, lhits = 0;      // (or, between the rounds of one visit: the candidates left, low | high word)
+  bool have_cand = false;
   const float tolf = (float)lim.dist_tol * 1.000001f;
 
   // which of the hit children comes first: the set bit whose slot XOR octant is largest
@@ -340,12 +346,16 @@ __global__ __launch_bounds__(ODW_MESH_THREADS, ODW_MESH_WAVES) void odw_mesh_ker
       // the records of the leaf children that were hit, as bits relative to the node's first record (<= 64 per node):
       // a leaf's records follow those of the leaf slots below it (sum of their 4-bit counts)
       uint64_t cand = 0;
-      for (uint32_t todo = lhits; todo; todo &= todo - 1u) {
-        const uint32_t sl = (uint32_t)__ffs((int)todo) - 1u;
-        const uint32_t cnt = (lcounts >> (4u * sl)) & 15u;
-        const uint32_t below = lcounts & ((1u << (4u * sl)) - 1u);
-        const uint32_t pairs = (below & 0x0f0f0f0fu) + ((below >> 4) & 0x0f0f0f0fu);
-        cand |= ((1ull << cnt) - 1ull) << ((pairs * 0x01010101u) >> 24);
+      if (have_cand) {
+        cand = ((uint64_t)lhits << 32) | lcounts;            // (what an earlier round left over)
+      } else {
+        for (uint32_t todo = lhits; todo; todo &= todo - 1u) {
+          const uint32_t sl = (uint32_t)__ffs((int)todo) - 1u;
+          const uint32_t cnt = (lcounts >> (4u * sl)) & 15u;
+          const uint32_t below = lcounts & ((1u << (4u * sl)) - 1u);
+          const uint32_t pairs = (below & 0x0f0f0f0fu) + ((below >> 4) & 0x0f0f0f0fu);
+          cand |= ((1ull << cnt) - 1ull) << ((pairs * 0x01010101u) >> 24);
+        }
       }
       cf32 rec0 = leaves + (size_t)lbase * ODW_LEAF_WORDS;
       const auto filter = [&](vf4 w0, vf4 w1, vf4 w2) -> bool {
@@ -370,7 +380,13 @@ __global__ __launch_bounds__(ODW_MESH_THREADS, ODW_MESH_WAVES) void odw_mesh_ker
         return U >= -ea && V >= -ea && U + V <= ad + 2.0f * ea;
       };
       uint64_t pass = 0;
+#if ODW_MESH_CAND_TRIPS > 0
+      // at most ODW_MESH_CAND_TRIPS trips per round: a lane with many candidates goes on in the next round and does
+      // not hold the lanes with few (they walk or interact meanwhile)
+      for (int trip = 0; cand && trip < ODW_MESH_CAND_TRIPS; ++trip) {
+#else
       while (cand) {
+#endif
         // four records per trip: twelve loads in flight before the first is used (the trip is a round trip to the
         // cache: fewer, fuller trips)
         int kk[4];
@@ -409,7 +425,13 @@ __global__ __launch_bounds__(ODW_MESH_THREADS, ODW_MESH_WAVES) void odw_mesh_ker
         }
       }
       cutf = (float)(fmin(q.tmax, q.any.t + 2.0 * q.tol) - (double)tsh) * 1.00001f + 1e-3f;
-      ODW_MESH_POP();
+      if (cand) {
+        lcounts = (uint32_t)cand; lhits = (uint32_t)(cand >> 32);
+        have_cand = true;                                      // (still pending)
+      } else {
+        have_cand = false;
+        ODW_MESH_POP();
+      }
     }
     ODW_MTIME(3);
     ODW_MSTAT(5, __ballot(alive && !walking && !pending && !fresh));
