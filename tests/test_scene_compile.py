@@ -103,6 +103,6 @@ def test_random_structures_compile(native_lib):
     assert code_bytes > 10000
     assert f'static constexpr int N = {len(sc.prim_type)};' in header
     done += 1
-    if done == 12:
+    if done == 6:                                # (2 - 3 s per structure on one core)
       break
-  assert done >= 8
+  assert done >= 6
