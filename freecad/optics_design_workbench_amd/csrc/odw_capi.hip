@@ -434,6 +434,8 @@ struct BvhBuilder {
 //   4    first inner child         5  first leaf record
 //   6    inner slots | leaf slots << 8          7  facets per leaf slot (4 bits each)
 //   8..13 near corner offsets: x of slots 0-3, x of 4-7, y, y, z, z     14..19 far corner offsets, the same way
+//   20..23 the solid every primitive below a slot belongs to (16 bits per slot, 0xffff: several or none): a ray that
+//          has just left a convex solid drops the slots of that solid before it looks at their boxes' order
 constexpr int kWideWords = 32;
 constexpr int kWideMaxDepth = 11;
 
@@ -441,14 +443,36 @@ struct WideBvh {
   struct Ref { int32_t child, count; float lo[3], hi[3]; };     // count > 0: leaf of `count` primitives from order[child]
   const std::vector<BvhNode>& bn;
   const std::vector<int>& order;
+  const std::vector<int>& solid_of;           // solid id of every primitive
   std::vector<int> height;
+  std::vector<int> solid_below;               // per binary node: the one solid of its primitives, -1 several, -2 not asked yet
   std::vector<uint32_t> nodes;
   std::vector<int> leaf_prim;                 // primitive of every leaf record
   std::vector<float> leaf_center;             // 3 per record: the centre its group is expressed around
   int depth = 0;
   bool ok = true;
 
-  WideBvh(const std::vector<BvhNode>& n, const std::vector<int>& o) : bn(n), order(o), height(n.size(), -1) {}
+  WideBvh(const std::vector<BvhNode>& n, const std::vector<int>& o, const std::vector<int>& so)
+      : bn(n), order(o), solid_of(so), height(n.size(), -1), solid_below(n.size(), -2) {}
+
+  int ref_solid(const Ref& r) {
+    if (r.count == 0) return node_solid(r.child);
+    int s = solid_of[order[(size_t)r.child]];
+    for (int k = 1; k < r.count; ++k)
+      if (solid_of[order[(size_t)r.child + k]] != s) return -1;
+    return s;
+  }
+  int node_solid(int n) {
+    if (solid_below[n] != -2) return solid_below[n];
+    const BvhNode& nd = bn[n];
+    int s = -3;                                 // nothing seen yet
+    for (const Ref& r : {ref0(nd), ref1(nd)}) {
+      if (far_box(r.lo)) continue;
+      const int c = ref_solid(r);
+      s = s == -3 ? c : (s == c ? s : -1);
+    }
+    return solid_below[n] = s == -3 ? -1 : s;
+  }
 
   static bool far_box(const float* lo) { return lo[0] >= 3.0e38f; }        // the child a wrapper root does not have
   static Ref ref0(const BvhNode& nd) { Ref r{nd.child0, nd.count0, {nd.lo0[0], nd.lo0[1], nd.lo0[2]}, {nd.hi0[0], nd.hi0[1], nd.hi0[2]}}; return r; }
@@ -551,6 +575,10 @@ struct WideBvh {
         lmask |= 1u << sl;
         counts |= (uint32_t)r.count << (4 * sl);
         for (int a = 0; a < 3; ++a) { glo[a] = std::min(glo[a], r.lo[a]); ghi[a] = std::max(ghi[a], r.hi[a]); }
+      }
+      {
+        const int so = ref_solid(r);
+        w[20 + (sl >> 1)] |= (uint32_t)((so >= 0 && so < 0xffff) ? so : 0xffff) << (16 * (sl & 1));
       }
       for (int a = 0; a < 3; ++a) {
         const double ql = std::floor(((double)r.lo[a] - (double)lo[a]) / scale[a]);
@@ -891,7 +919,9 @@ int build_bvh(odw_ctx* ctx) {
   std::vector<float> recs;
   // (read at every build: A/B runs and the test that holds the two kernels against each other)
   const bool mesh_kernel = !(getenv("ODW_MESH_KERNEL") && getenv("ODW_MESH_KERNEL")[0] == '0');
-  WideBvh wide(b.nodes, b.order);
+  std::vector<int> prim_solid((size_t)n);
+  for (int p = 0; p < n; ++p) prim_solid[p] = ctx->h_prim_i32[4 * (size_t)p + 2] >> ODW_SOLID_SHIFT;
+  WideBvh wide(b.nodes, b.order, prim_solid);
   if (has_triangles && mesh_kernel) {
     wide.build();
     if (wide.ok) {

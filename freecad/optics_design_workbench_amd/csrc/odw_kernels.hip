@@ -1594,8 +1594,14 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
       const int g = pi[1];
       interact<BVH, STOCH, LEAN>(P, group_f64, group_i32, group_gdir, g, group_i32[4 * g], group_i32[4 * g + 1] != 0, n,
                                  entering, P.first_ray + i, nint, cnt, hit_state, hist_win, point, dir, power, medium, seq, alive);
-      // outward normal of the solid = n against the travel direction when entering
-      const double out = entering ? -dot(dir, n) : dot(dir, n);
+      // outward normal of the solid = n against the travel direction when entering; for a facet of a convex
+      // tessellated solid the FACET's own normal decides (the interpolated one of smooth shading can point out of
+      // the solid where the ray still runs into it)
+      double out = entering ? -dot(dir, n) : dot(dir, n);
+      if (BVH && pi[0] == ODW_PRIM_TRIANGLE) {
+        out = dot(dir, mk(pf[9], pf[10], pf[11]));
+        if (pi[2] & ODW_FLAG_FLIP_NORMAL) out = -out;
+      }
       skip = ((pi[2] & ODW_FLAG_CONVEX) && out > 0) ? (pi[2] >> ODW_SOLID_SHIFT) : -1;
       only = (!BVH && (pi[2] & ODW_FLAG_ISOLATED) && out < 0) ? (pi[2] >> ODW_SOLID_SHIFT) : -1;
       }

@@ -312,6 +312,14 @@ __global__ __launch_bounds__(ODW_MESH_THREADS, ODW_MESH_WAVES) void odw_mesh_ker
         ODW_MESH_SLOT(6, nx1, ny1, nz1, fx1, fy1, fz1, 16)
         ODW_MESH_SLOT(7, nx1, ny1, nz1, fx1, fy1, fz1, 24)
 #undef ODW_MESH_SLOT
+        if (skip >= 0) {
+          // the convex solid the ray has just left: children whose primitives all belong to it are not looked at
+          const vu4 so = *reinterpret_cast<const vu4 ODW_CONST*>(nd + 20);
+          const uint32_t sk = (uint32_t)skip;
+          hits &= ~(((so.x & 0xffffu) == sk ? 1u : 0u) | ((so.x >> 16) == sk ? 2u : 0u) | ((so.y & 0xffffu) == sk ? 4u : 0u) |
+                    ((so.y >> 16) == sk ? 8u : 0u) | ((so.z & 0xffffu) == sk ? 16u : 0u) | ((so.z >> 16) == sk ? 32u : 0u) |
+                    ((so.w & 0xffffu) == sk ? 64u : 0u) | ((so.w >> 16) == sk ? 128u : 0u));
+        }
         const uint32_t imask = h1.z & 0xffu, lmask = (h1.z >> 8) & 0xffu;
         const uint32_t ih = hits & imask, lh = hits & lmask;
         if (lh) {
@@ -517,7 +525,15 @@ __global__ __launch_bounds__(ODW_MESH_THREADS, ODW_MESH_WAVES) void odw_mesh_ker
             if (!tir) { medium = -1; ++seq; }
           }
         }
-        skip = ((pi[2] & ODW_FLAG_CONVEX) && (entering ? -dot(dir, n) : dot(dir, n)) > 0) ? (pi[2] >> ODW_SOLID_SHIFT) : -1;
+        {
+          // (a facet of a convex tessellated solid: the facet's own normal decides, as in odw_trace_kernel)
+          double out = entering ? -dot(dir, n) : dot(dir, n);
+          if (pi[0] == ODW_PRIM_TRIANGLE) {
+            out = dot(dir, mk(pf[9], pf[10], pf[11]));
+            if (pi[2] & ODW_FLAG_FLIP_NORMAL) out = -out;
+          }
+          skip = ((pi[2] & ODW_FLAG_CONVEX) && out > 0) ? (pi[2] >> ODW_SOLID_SHIFT) : -1;
+        }
         if (alive && power < lim.power_tol) { ODW_MCOUNT(ODW_CNT_DIED); alive = false; }
         fresh = alive;
       }

@@ -293,7 +293,7 @@ def bakeScene(doc, source=None, surfaceFamily=None):
         for tree in geometry.solids_of(child):
           if tree.op == 'mesh':
             node = geometry.Node('mesh', gp * tree.placement, tree.mesh, source=tree.source)
-            meshes.append((gi, solid_id) + geometry.meshWorld(node) + (tree.source,))
+            meshes.append((gi, solid_id) + geometry.meshWorld(node) + (tree.source, geometry.meshConvex(tree.mesh)))
             solid_id += 1
             continue
           flat = geometry.flatten(tree, gp)
@@ -347,14 +347,17 @@ def bakeScene(doc, source=None, surfaceFamily=None):
   n_tri = sum(len(m[3]) for m in meshes)
   tri_xform = np.zeros((n_tri, 12))
   tri_group, tri_solid = np.zeros(n_tri, dtype=np.int32), np.zeros(n_tri, dtype=np.int32)
+  tri_flags = np.full(n_tri, 1 << 8, dtype=np.int32)
   tri_normals = np.zeros((n + n_tri, 9)) if any(m[4] is not None for m in meshes) else None
   tri_edges = np.full(n + n_tri, 7, dtype=np.int32) if n_tri else None
   at = 0
-  for gi, sid, v, tri, vn, _ in meshes:
+  for gi, sid, v, tri, vn, _, convex in meshes:
     k = len(tri)
     tri_edges[n + at:n + at + k] = faceEdgeBits(tri, v)
     tri_xform[at:at + k, 0:9] = v[tri].reshape(k, 9)
     tri_group[at:at + k], tri_solid[at:at + k] = gi, sid
+    if convex:                                     # (ODW_FLAG_CONVEX: as for convex analytic solids)
+      tri_flags[at:at + k] |= 2
     if tri_normals is not None:
       if vn is not None:
         tri_normals[n + at:n + at + k] = vn[tri].reshape(k, 9)
@@ -373,7 +376,7 @@ def bakeScene(doc, source=None, surfaceFamily=None):
       prim_solid=np.concatenate([np.array(prim_solid, dtype=np.int32), tri_solid]),
       prim_flags=np.concatenate([np.array([(1 if p.flip else 0) | (2 if getattr(p, 'convex', False) else 0) | (p.facemask << 8)
                                            for p in prims], dtype=np.int32),
-                                 np.full(n_tri, 1 << 8, dtype=np.int32)]),
+                                 tri_flags]),
       prim_xform=np.concatenate([_snapFrames(np.array([p.to_world.inverse().rows12() for p in prims],
                                                       dtype=np.float64).reshape(n, 12)), tri_xform]),
       prim_params=np.concatenate([np.array([p.params for p in prims], dtype=np.float64).reshape(n, 4),

@@ -322,6 +322,75 @@ def is_convex(node):
   return False
 
 
+def mesh_is_convex(vertices, triangles):
+  """is the tessellated shape the boundary of a convex solid, facets counter-clockwise seen from outside?  A closed
+  surface (every edge in exactly two facets, once in each direction, after welding coincident vertices -- seams,
+  poles) whose edges are all convex (the vertex opposite the edge in one facet is not above the plane of the other)
+  bounds a convex body; the enclosed volume is positive for outward facets.  Facets without area (pole fans) are left
+  out.  The tracer's "a ray that has left a convex solid cannot meet it again" rule then holds for it exactly
+  (decided with the FACET's normal, not the interpolated one)."""
+  v = np.asarray(vertices, dtype=np.float64).reshape(-1, 3)
+  tri = np.asarray(triangles, dtype=np.int64).reshape(-1, 3)
+  if len(tri) < 4:
+    return False
+  size = float(np.ptp(v, axis=0).max())
+  if not size > 0:
+    return False
+  q = np.round(v / (1e-9 * size)).astype(np.int64)
+  o = np.lexsort((q[:, 2], q[:, 1], q[:, 0]))
+  first = np.ones(len(q), dtype=bool)
+  first[1:] = np.any(q[o][1:] != q[o][:-1], axis=1)
+  weld = np.empty(len(q), dtype=np.int64)
+  weld[o] = np.cumsum(first) - 1
+  t = weld.reshape(-1)[tri]
+  a, b, c = v[tri[:, 0]], v[tri[:, 1]], v[tri[:, 2]]
+  nrm = np.cross(b - a, c - a)
+  area2 = np.linalg.norm(nrm, axis=1)
+  keep = (area2 > 1e-14 * size * size) & (t[:, 0] != t[:, 1]) & (t[:, 1] != t[:, 2]) & (t[:, 2] != t[:, 0])
+  t, a, nrm, area2 = t[keep], a[keep], nrm[keep], area2[keep]
+  if len(t) < 4:
+    return False
+  # directed edges (from, to) with their facet and the vertex opposite
+  e_from = np.concatenate([t[:, 0], t[:, 1], t[:, 2]])
+  e_to = np.concatenate([t[:, 1], t[:, 2], t[:, 0]])
+  e_opp = np.concatenate([t[:, 2], t[:, 0], t[:, 1]])
+  e_face = np.tile(np.arange(len(t)), 3)
+  n_v = int(weld.max()) + 1
+  key = e_from * n_v + e_to
+  rev = e_to * n_v + e_from
+  order = np.argsort(key)
+  ks = key[order]
+  if len(np.unique(ks)) != len(ks):
+    return False                                   # an edge used twice in the same direction
+  pos = np.searchsorted(ks, rev)
+  if np.any(pos >= len(ks)) or np.any(ks[np.minimum(pos, len(ks) - 1)] != rev):
+    return False                                   # open: an edge without its opposite
+  mate = order[pos]                                # the same edge in the neighbouring facet
+  wpos = np.zeros((n_v, 3))
+  wpos[weld.reshape(-1)] = v                       # (one representative per welded vertex)
+  above = np.einsum('ij,ij->i', nrm[e_face] / area2[e_face][:, None], wpos[e_opp[mate]] - a[e_face])
+  if np.any(above > 1e-9 * size):
+    return False
+  volume = np.einsum('ij,ij->i', a, nrm).sum() / 6.0
+  return bool(volume > 0)
+
+
+_CONVEX_MEMO = []          # [(vertices, triangles, answer)]: the arrays of stored shapes are cached objects, bakes repeat
+
+
+def meshConvex(mesh):
+  """mesh_is_convex of a 'mesh' node's arrays (local coordinates: a placement does not change the answer), remembered
+  for the array objects seen last (a parameter sweep bakes the same stored shape again and again)"""
+  v, tri = mesh[0], mesh[1]
+  for mv, mt, ans in _CONVEX_MEMO:
+    if mv is v and mt is tri:
+      return ans
+  ans = mesh_is_convex(v, tri)
+  _CONVEX_MEMO.append((v, tri, ans))
+  del _CONVEX_MEMO[:-8]
+  return ans
+
+
 def flatten(tree, acc=None):
   """CSG tree -> [FlatPrim] (every leaf once; conditions reference leaves)"""
   out = []

@@ -1256,8 +1256,19 @@ static void trace_one(const odw_scene_desc* sc, const odw_limits* lim,
      * primitives are not candidates of the next segment */
     skip_solid = -1;
     if ((sc->prim_flags[h.prim] & ODW_FLAG_CONVEX) && sc->prim_solid) {
-      double along = dot(dir, n);              /* n points along the incoming travel direction */
-      if ((entering ? -along : along) > 0) skip_solid = sc->prim_solid[h.prim];
+      if (sc->prim_type[h.prim] == ODW_PRIM_TRIANGLE) {
+        /* a convex tessellated solid (scene/geometry.py: mesh_is_convex): the FACET's outward normal decides -- the
+         * interpolated one of smooth shading can point out of the solid where the ray still runs into it */
+        const double* M = sc->prim_xform + 12 * (size_t)h.prim;
+        v3 v0 = V(M[0], M[1], M[2]);
+        v3 ng = cross(sub(V(M[3], M[4], M[5]), v0), sub(V(M[6], M[7], M[8]), v0));
+        double out = dot(dir, ng);
+        if (sc->prim_flags[h.prim] & ODW_FLAG_FLIP_NORMAL) out = -out;
+        if (out > 0) skip_solid = sc->prim_solid[h.prim];
+      } else {
+        double along = dot(dir, n);            /* n points along the incoming travel direction */
+        if ((entering ? -along : along) > 0) skip_solid = sc->prim_solid[h.prim];
+      }
     }
     if (power < lim->power_tol) { sk->cnt[ODW_CNT_DIED]++; break; }
   }

@@ -68,6 +68,33 @@ def _lens_scene(segments=None, smooth=True, n_src='exp(-theta**2/0.05**2)'):
   return doc, bake.bakeScene(doc, src), bake.bakeLimits(doc, src), point_source.bakeSource(doc, src)
 
 
+def test_convex_tessellated_solids_are_recognised(oracle):
+  """`geometry.mesh_is_convex`: closed, outward, every edge convex -- a tessellated ball, box, cylinder and cone are
+  convex polyhedra, a torus is not, an open patch is not, an inside-out ball is not.  The bake flags their facets
+  ODW_FLAG_CONVEX, and with the flag the tracer drops the solid's facets for the segment after a ray has left it
+  (decided with the facet's own normal): the same rows as without the rule (reference-strict mode of the oracle)."""
+  for kind, params, convex in ((geometry.SPHERE, (5.0, 0, 0, 0), True), (geometry.BOX, (1.0, 2.0, 3.0, 0), True),
+                               (geometry.CYLINDER, (2.0, 5.0, 0, 0), True), (geometry.CONE, (2.0, 1.0, 5.0, 0), True),
+                               (geometry.TORUS, (5.0, 1.0, 0, 0), False)):
+    v, tri, _ = geometry.tessellate(kind, params, 24)
+    assert geometry.mesh_is_convex(v, tri) is convex
+  v, tri, _ = geometry.tessellate(geometry.SPHERE, (5.0, 0, 0, 0), 24)
+  assert not geometry.mesh_is_convex(v, tri[:-3]) and not geometry.mesh_is_convex(v, tri[:, ::-1])
+  dented = v.copy()
+  k = int(np.argmax(v[:, 0]))
+  dented[np.linalg.norm(v - v[k], axis=1) < 1e-9] *= 0.8          # one vertex (and its seam twins) pushed inwards
+  assert not geometry.mesh_is_convex(dented, tri)
+  _, sc, lim, src = _lens_scene(48)
+  tri_rows = sc.prim_type == geometry.TRIANGLE
+  assert np.all(sc.prim_flags[tri_rows] & 2) and sc.prim_flags[~tri_rows].tolist() == [2 | (63 << 8)]
+  n = 200000
+  a = oracle.trace(sc, src, lim, 0, n, 3, nthreads=0)
+  with oracle.strict():
+    b = oracle.trace(sc, src, lim, 0, n, 3, nthreads=0)
+  assert a['counters'] == b['counters'] and a['counters']['recorded_hits'] > 0.9 * n
+  assert np.array_equal(a['hits']['tag'], b['hits']['tag']) and np.array_equal(a['hits']['point'], b['hits']['point'])
+
+
 def test_bake_of_meshes():
   _, sc, _, _ = _lens_scene(32)
   tri = sc.prim_type == geometry.TRIANGLE
