@@ -77,7 +77,11 @@ enum {
                                  /* such.  A ray that leaves a convex solid      */
                                  /* (direction . outward normal > 0) cannot meet */
                                  /* it again: its primitives are not tested for  */
-                                 /* the next segment.                            */
+                                 /* the next segment.  On ODW_PRIM_TRIANGLE rows:*/
+                                 /* the tessellated solid is a convex polyhedron */
+                                 /* (closed, facets counter-clockwise from       */
+                                 /* outside); the FACET's normal decides the     */
+                                 /* exit, not the interpolated one.              */
 #define ODW_FACEMASK_SHIFT 8
 
 /* ---- optical types: OpticalGroupProxy.OpticalType enumeration order ----- */
