@@ -360,7 +360,7 @@ def mesh_is_convex(vertices, triangles):
   rev = e_to * n_v + e_from
   order = np.argsort(key)
   ks = key[order]
-  if len(np.unique(ks)) != len(ks):
+  if np.any(ks[1:] == ks[:-1]):
     return False                                   # an edge used twice in the same direction
   pos = np.searchsorted(ks, rev)
   if np.any(pos >= len(ks)) or np.any(ks[np.minimum(pos, len(ks) - 1)] != rev):
@@ -368,9 +368,12 @@ def mesh_is_convex(vertices, triangles):
   mate = order[pos]                                # the same edge in the neighbouring facet
   wpos = np.zeros((n_v, 3))
   wpos[weld.reshape(-1)] = v                       # (one representative per welded vertex)
-  above = np.einsum('ij,ij->i', nrm[e_face] / area2[e_face][:, None], wpos[e_opp[mate]] - a[e_face])
-  if np.any(above > 1e-9 * size):
-    return False
+  unit = nrm / area2[:, None]
+  for k in range(3):                               # (edge k of every facet: a third of the gathers at a time)
+    sl = slice(k * len(t), (k + 1) * len(t))
+    above = np.einsum('ij,ij->i', unit, wpos[e_opp[mate[sl]]] - a)
+    if np.any(above > 1e-9 * size):
+      return False
   volume = np.einsum('ij,ij->i', a, nrm).sum() / 6.0
   return bool(volume > 0)
 
