@@ -134,14 +134,21 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
   if pipeline and deviceHits and isinstance(tr, Tracer) and len(mine) > 1:
     # (two measuring threads by default: the measure is partly host work under the GIL, partly waits for the GPU --
     #  one thread read 243 - 338 ms per 64 x 1e7 sweep from run to run, two 248 - 273, three 247 - 264)
-    for _ in range(min(int(pipeline) if pipeline is not True else 2, len(mine) - 1, 3)):
+    # (the extra contexts stay with the tracer between sweeps: creating them costs ~12 ms, a rank's share of a sweep
+    #  dealt out over eight GPUs takes 30)
+    want = min(int(pipeline) if pipeline is not True else 2, len(mine) - 1, 3)
+    kept = [e for e in (getattr(tr, '_sweepLanes', None) or [])
+            if e.referenceStrict == tr.referenceStrict and e.compileMode() == tr.compileMode()]
+    while len(kept) < want:
       extra = Tracer(tr.device, referenceStrict=tr.referenceStrict)
       try:
         extra.compileScene({0: 'off', 1: 'structure', 2: 'auto'}[tr.compileMode()])
       except Exception:
         pass
-      lanes.append(extra)
-  uploaded = [dict() for _ in lanes]
+      kept.append(extra)
+    tr._sweepLanes = kept
+    lanes += kept[:want]
+  uploaded = [dict() for _ in lanes]       # (what each context holds is looked at afresh every sweep)
   table = np.zeros((len(values), len(names), 2))        # (result or 0, 1 = a number / 2 = nan)
   totals = np.zeros(3, dtype=np.int64)
   pool = None
@@ -224,10 +231,8 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
   finally:
     if pool is not None:
       pool.shutdown(wait=True)
-    for extra in lanes[1:]:
-      extra.close()
     if own:
-      tr.close()
+      tr.close()                       # (with its extra contexts)
   if clock is not None:
     print('[odw sweep timing] ms per value: ' + ', '.join(f'{k} {1e3 * v / max(len(mine), 1):.2f}' for k, v in clock.items()),
           file=sys.stderr, flush=True)

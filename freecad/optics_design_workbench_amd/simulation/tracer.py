@@ -96,6 +96,9 @@ class Tracer:
 
   # -- lifecycle ------------------------------------------------------------
   def close(self):
+    for extra in getattr(self, '_sweepLanes', None) or []:      # (contexts a parameter sweep keeps beside this one)
+      extra.close()
+    self._sweepLanes = []
     if self._ctx:
       for p in getattr(self, '_pinned', []):
         self._lib.odw_host_free(self._ctx, p)
