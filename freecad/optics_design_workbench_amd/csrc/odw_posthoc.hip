@@ -155,12 +155,16 @@ __global__ __launch_bounds__(512) void ph_sel_hist_kernel(const double* __restri
   uint32_t* out = slices + (size_t)blockIdx.x * 2 * kPhSelBins;
   for (int k = threadIdx.x; k < 2 * kPhSelBins; k += blockDim.x) out[k] = h[k];
 }
+// hist (zeroed by the caller) += the slices: block (x, y) sums 32 slices for 256 bins (one block per 256 bins alone
+// read the 16 MB of slices with 32 of the 256 CUs: 75 us)
+constexpr int kPhSelSumSlices = 32;
 __global__ __launch_bounds__(256) void ph_sel_sum_kernel(const uint32_t* __restrict__ slices, int n_slices, uint32_t* __restrict__ hist) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k < 2 * kPhSelBins) {
+    const int b0 = blockIdx.y * kPhSelSumSlices, b1 = min(n_slices, b0 + kPhSelSumSlices);
     uint32_t s = 0;
-    for (int b = 0; b < n_slices; ++b) s += slices[(size_t)b * 2 * kPhSelBins + k];
-    hist[k] = s;
+    for (int b = b0; b < b1; ++b) s += slices[(size_t)b * 2 * kPhSelBins + k];
+    if (s) atomicAdd(hist + k, s);
   }
 }
 // elements of X / Y whose coarse bin lies in [c_lo, c_hi] and whose fine bin is f0 or f1, appended to out
@@ -291,28 +295,31 @@ __global__ __launch_bounds__(256) void ph_bin_kernel(const double* __restrict__ 
   }
 }
 
-// mean and centred second moments of the selected rows' points (two passes)
+// sums of d and d^2, d = point - the first selected row's point (a provisional centre inside the cloud: the
+// variance is E[d^2] - E[d]^2 without the cancellation of raw second moments), one pass over the rows
 __global__ void ph_moment_kernel(const odw_hit* __restrict__ hits, const uint32_t* __restrict__ sel, uint64_t m,
-                                 double cx, double cy, double cz, int squared, double* __restrict__ part) {
-  double sx = 0, sy = 0, sz = 0;
+                                 double* __restrict__ part) {
+  const double* c = hits[sel[0]].point;
+  const double cx = c[0], cy = c[1], cz = c[2];
+  double s[6] = {0, 0, 0, 0, 0, 0};
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
     const double* p = hits[sel[j]].point;
     const double dx = p[0] - cx, dy = p[1] - cy, dz = p[2] - cz;
-    sx += squared ? dx * dx : dx;
-    sy += squared ? dy * dy : dy;
-    sz += squared ? dz * dz : dz;
+    s[0] += dx; s[1] += dy; s[2] += dz;
+    s[3] += dx * dx; s[4] += dy * dy; s[5] += dz * dz;
   }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    sx += __shfl_xor(sx, off); sy += __shfl_xor(sy, off); sz += __shfl_xor(sz, off);
-  }
-  __shared__ double s[4][3];
+  for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s[k] += __shfl_xor(s[k], off);
+  __shared__ double sh[4][6];
   const int w = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) { s[w][0] = sx; s[w][1] = sy; s[w][2] = sz; }
+  if ((threadIdx.x & 63) == 0)
+    for (int k = 0; k < 6; ++k) sh[w][k] = s[k];
   __syncthreads();
-  if (threadIdx.x == 0)
-    for (int k = 0; k < 3; ++k) part[3 * blockIdx.x + k] = s[0][k] + s[1][k] + s[2][k] + s[3][k];
+  if (threadIdx.x < 6) part[6 * blockIdx.x + threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+  if (blockIdx.x == 0 && threadIdx.x == 6) { part[6 * gridDim.x] = cx; part[6 * gridDim.x + 1] = cy; part[6 * gridDim.x + 2] = cz; }
 }
 
 int ph_need_selection(odw_ctx* ctx, const char* who) {
@@ -383,8 +390,9 @@ int ph_select_stats(odw_ctx* ctx, uint64_t m, const double ext[4], double stats[
   std::vector<uint32_t> hist(2 * (size_t)kPhSelBins);
   auto histogram = [&]() -> int {
     hipLaunchKernelGGL(ph_sel_hist_kernel, dim3(hgrid), dim3(512), 0, ctx->stream, X, Y, m, P, slices);
-    hipLaunchKernelGGL(ph_sel_sum_kernel, dim3((2 * kPhSelBins + 255) / 256), dim3(256), 0, ctx->stream, (const uint32_t*)slices,
-                       (int)hgrid, d_hist);
+    HIPCHK(ctx, hipMemsetAsync(d_hist, 0, hist_bytes, ctx->stream));
+    hipLaunchKernelGGL(ph_sel_sum_kernel, dim3((2 * kPhSelBins + 255) / 256, (hgrid + kPhSelSumSlices - 1) / kPhSelSumSlices),
+                       dim3(256), 0, ctx->stream, (const uint32_t*)slices, (int)hgrid, d_hist);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(hist.data(), d_hist, hist_bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -697,22 +705,20 @@ int odw_hits_moments(odw_ctx* ctx, double* mean, double* var) {
   const uint64_t m = ctx->ph_n;
   if (m == 0) return fail(ctx, ODW_ERR_INVALID, "odw_hits_moments: no rows selected");
   const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((m + 255) / 256, (uint64_t)ctx->n_cu * 8));
-  if ((rc = ensure(ctx, ctx->ph_part, (size_t)grid * 4 * sizeof(double)))) return rc;
-  std::vector<double> part((size_t)grid * 3);
-  double c[3] = {0, 0, 0};
-  for (int pass = 0; pass < 2; ++pass) {
-    hipLaunchKernelGGL(ph_moment_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const odw_hit*)ctx->hits.p,
-                       (const uint32_t*)ctx->sort_vals[1].p, m, c[0], c[1], c[2], pass, (double*)ctx->ph_part.p);
-    HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipMemcpyAsync(part.data(), ctx->ph_part.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    double s[3] = {0, 0, 0};
-    for (unsigned b = 0; b < grid; ++b)
-      for (int k = 0; k < 3; ++k) s[k] += part[3 * b + k];
-    for (int k = 0; k < 3; ++k) {
-      if (pass == 0) { c[k] = s[k] / (double)m; mean[k] = c[k]; }
-      else var[k] = s[k] / (double)m;
-    }
+  if ((rc = ensure(ctx, ctx->ph_part, ((size_t)grid * 6 + 3) * sizeof(double)))) return rc;
+  std::vector<double> part((size_t)grid * 6 + 3);
+  hipLaunchKernelGGL(ph_moment_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const odw_hit*)ctx->hits.p,
+                     (const uint32_t*)ctx->sort_vals[1].p, m, (double*)ctx->ph_part.p);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpyAsync(part.data(), ctx->ph_part.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  double s6[6] = {0, 0, 0, 0, 0, 0};
+  for (unsigned b = 0; b < grid; ++b)
+    for (int k = 0; k < 6; ++k) s6[k] += part[6 * (size_t)b + k];
+  for (int k = 0; k < 3; ++k) {
+    const double d = s6[k] / (double)m;                  // mean - provisional centre
+    mean[k] = part[6 * (size_t)grid + k] + d;
+    var[k] = std::max(0.0, s6[3 + k] / (double)m - d * d);
   }
   return ODW_OK;
 }
