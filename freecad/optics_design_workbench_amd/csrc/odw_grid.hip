@@ -60,6 +60,16 @@ namespace odw {
 #define ODW_GTIME(k) do {} while (0)
 #endif
 
+// fmin as ONE v_min_f64.  The compiler puts a v_max_f64 x, x, x in front of every operand of fmin it cannot prove
+// to be a quiet number (values that came through selects or LDS: the plane distances of the walk) -- five of the
+// ~100 vector instructions of a cell step.  The instruction itself does what fmin does (IEEE mode: the operand that
+// is a number wins).
+__device__ __forceinline__ double fmin_raw(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 // index i with b[i] <= v < b[i+1], clamped to [0, n-1]   (b: n+1 planes in LDS)
 __device__ __forceinline__ int grid_slab(const double* b, int n, double v) {
   int lo = 0, hi = n;
@@ -161,8 +171,8 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
   //  46 fewer v_cndmask in the binary, but three LDS reads in a row under divergent masks: 25.6 against 24.3 ms)
 #define ODW_WALK_ADVANCE()                                                                   \
   do {                                                                                       \
-    const double t_exit_ = fmin(tx, fmin(ty, tz));                                           \
-    const double cut_ = fmin(q.tmax, q.any.t + 2.0 * q.tol);                                 \
+    const double t_exit_ = fmin_raw(tx, fmin_raw(ty, tz));                                   \
+    const double cut_ = fmin_raw(q.tmax, q.any.t + 2.0 * q.tol);                             \
     if (!(t_exit_ <= cut_)) {                                                                \
       walking = false;                                                                       \
     } else {                                                                                 \
