@@ -1233,6 +1233,11 @@ void odw_destroy(odw_ctx* ctx) {
     if (total)
       for (int k = 0; k < 6; ++k)
         fprintf(stderr, "[odw mesh time] %-16s %14llu ticks  %5.1f %%\n", phases[k], (unsigned long long)v[16 + k], 100.0 * (double)v[16 + k] / (double)total);
+    // (flat kernels, ODW_FLAT_STATS: refill + generation / nearest-hit search / interaction and recording)
+    if (v[28] + v[29] + v[30])
+      for (int k = 0; k < 3; ++k)
+        fprintf(stderr, "[odw flat time] %-28s %14llu ticks  %5.1f %%\n", k == 0 ? "refill + generation" : (k == 1 ? "nearest hit" : "interaction + recording"),
+                (unsigned long long)v[28 + k], 100.0 * (double)v[28 + k] / (double)(v[28] + v[29] + v[30]));
     // (grid kernel, ODW_GRID_STATS: the same for its phases)
     uint64_t gtotal = 0;
     for (int k = 24; k < 28; ++k) gtotal += v[k];

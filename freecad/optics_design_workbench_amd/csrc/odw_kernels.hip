@@ -1010,13 +1010,16 @@ __device__ __forceinline__ int nearest(const DeviceScene& sc, const SceneView& s
 __device__ __forceinline__ d3 mirror(d3 r, d3 n) { return r - n * (2.0 * dot(r, n)); }
 
 __device__ __forceinline__ d3 snells_law(d3 r, double n1, double n2, d3 n, bool& tir) {
-  const d3 c = cross(n, r);
+  // ray.py:488-495 writes root = 1 - mu^2 |n x r|^2 and the transmitted direction mu n x ((-n) x r) + n sqrt(root).
+  // For the unit vectors this is called with, |n x r|^2 = 1 - (n.r)^2 and n x ((-n) x r) = r - n (n.r): three cross
+  // products less, the same numbers up to rounding (the oracle keeps the reference's form; 1e-16, inside every
+  // tolerance of the parity tests) -- 25 of the ~75 float64 instructions of a refraction
+  const double d = dot(n, r);
   const double mu = n1 * frcp(n2);
-  const double root = 1.0 - mu * mu * dot(c, c);
-  if (root < 0) { tir = true; return mirror(r, n); }
+  const double root = 1.0 - mu * mu * (1.0 - d * d);
+  if (root < 0) { tir = true; return r - n * (2.0 * d); }
   tir = false;
-  // n x ((-n) x r) = r (n.n) - n (n.r)
-  const d3 perp = cross(n, cross(n * -1.0, r));
+  const d3 perp = r - n * d;
   return perp * mu + n * fsqrt(root);
 }
 
@@ -1495,7 +1498,16 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
     for (int k = threadIdx.x; k < 4 + ODW_HIST_WIN * ODW_HIST_WIN; k += 256) hist_win[k] = 0u;
     __syncthreads();
   }
+#ifdef ODW_FLAT_STATS
+  // diagnostic build: s_memtime ticks per wave in refill + generation / nearest-hit search / the rest (odw_destroy prints)
+  uint64_t flat_t[3] = {0, 0, 0};
+  uint64_t flat_mark = __builtin_readcyclecounter();
+#define ODW_FTIME(k) do { const uint64_t t_ = __builtin_readcyclecounter(); flat_t[(k)] += t_ - flat_mark; flat_mark = t_; } while (0)
+#else
+#define ODW_FTIME(k) do {} while (0)
+#endif
   for (;;) {
+    ODW_FTIME(2);
     const uint64_t idle = __ballot(!alive);
     // refill when the wave is empty or enough lanes are idle to make the
     // (divergent) generation code worth running
@@ -1536,6 +1548,7 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
       next += take;
       if (take == 0 && idle == ~0ull) break;               // nothing live, nothing left
     }
+    ODW_FTIME(0);
     if (alive) {
       if (nint >= lim.max_intersections) {
         ODW_COUNT(ODW_CNT_CAPPED);
@@ -1557,6 +1570,7 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
         --nint;
         continue;
       }
+      ODW_FTIME(1);
       if (SEG)   // (p1, p2), power at p1, medium of the segment (ray.py:104-117)
         record_segment(P.out.segs, P.out.seg_capacity, P.out.seg_count, P.first_ray + i, nint - 1, medium, point,
                        point + dir * (prim < 0 ? lim.max_ray_length : t_hit), power);
@@ -1614,6 +1628,10 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
       }
     }
   }
+#ifdef ODW_FLAT_STATS
+  if (!BVH && lane == 0 && P.dbg)
+    for (int k = 0; k < 3; ++k) atomicAdd(P.dbg + 28 + k, (unsigned long long)flat_t[k]);
+#endif
   // slots of the last block this wave never filled
   const uint32_t hit_used = BVH ? 0u : hit_lds[(threadIdx.x >> 6) * 4 + 2];
   const uint64_t hit_base = BVH ? 0ull : ((uint64_t)hit_lds[(threadIdx.x >> 6) * 4 + 1] << 32) | hit_lds[(threadIdx.x >> 6) * 4];
