@@ -56,6 +56,11 @@ __device__ __forceinline__ double frcp(double x) {
   r = fma(fma(-x, r, 1.0), r, r);
   return r;
 }
+// one Newton step (~2^-50): for the inverse direction of the box tests, whose boxes carry 2 distTol of slack
+__device__ __forceinline__ double frcp1(double x) {
+  const double r = __builtin_amdgcn_rcp(x);
+  return fma(fma(-x, r, 1.0), r, r);
+}
 __device__ __forceinline__ double fsqrt(double x) {
   const double y = __builtin_amdgcn_rsq(x);
   double g = x * y, h = 0.5 * y;
@@ -875,7 +880,7 @@ __device__ __forceinline__ int nearest(const DeviceScene& sc, const SceneView& s
   q.medium = medium;
   q.any.t = INFINITY; q.any.prim = 0x7fffffff; q.any.face = 0x7fffffff;
   q.oth = q.any;
-  const d3 inv = mk(frcp(dn.x), frcp(dn.y), frcp(dn.z));
+  const d3 inv = mk(frcp1(dn.x), frcp1(dn.y), frcp1(dn.z));
   const d3 oi = mk(start.x * inv.x, start.y * inv.y, start.z * inv.z);
   if constexpr (SPEC::enabled) {
     spec_prims<SPEC>(sv, q, oi, inv, skip_solid, only_solid, mask, __make_integer_seq<IndexList, int, SPEC::N>{});
