@@ -96,8 +96,10 @@ struct odw_ctx {
   DevBuf sort_keys[2], sort_vals[2], sort_tmp, sorted_rows;
   // post-hoc binning of the rows in HBM (odw_posthoc.hip): the selection = sort_vals[1][0 .. ph_n)
   DevBuf ph_sel_entering, ph_flags, ph_x, ph_y, ph_sorted, ph_small, ph_part, ph_edges, ph_edges_b, ph_counts, ph_sel_hist;
+  DevBuf ph_bitmap, ph_before, ph_row_of;            // ordered selection without a sort (odw_posthoc.hip: ph_mark_kernel)
   uint64_t alt_hit_ray_end = 0;    // the same for the list odw_swap_hit_lists has put aside
   uint64_t hit_ray_end = 0;        // ray indices of the rows in the hit list lie below this (0: list empty; 1 << 48: unknown)
+  uint64_t hit_ray_begin = 0, alt_hit_ray_begin = 0;   // ... and at or above this (meaningful while hit_ray_end is a real bound)
   uint64_t ph_n = 0, ph_n_entering = 0;
   int ph_group = -1;
   bool ph_valid = false, ph_projected = false, ph_entering_built = false;
@@ -1021,6 +1023,7 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
   if (!explicit_rays && !ctx->have_source) return fail(ctx, ODW_ERR_NO_SCENE, "source not uploaded");
   if (n == 0) return ODW_OK;
   ctx->ph_valid = false;           // the hit list is about to change
+  ctx->hit_ray_begin = ctx->hit_ray_end ? std::min<uint64_t>(ctx->hit_ray_begin, first) : first;
   ctx->hit_ray_end = std::max<uint64_t>(ctx->hit_ray_end, std::min<uint64_t>(first + n, 1ull << 48));
   if (ctx->bvh_dirty) {
     int rc = build_bvh(ctx);
@@ -1263,6 +1266,7 @@ void odw_destroy(odw_ctx* ctx) {
   release(ctx->d_samplers);
   release(ctx->d_group_sampler);
   for (DevBuf* b : {&ctx->grid_bounds, &ctx->grid_cells, &ctx->grid_items}) release(*b);
+  for (DevBuf* b : {&ctx->ph_bitmap, &ctx->ph_before, &ctx->ph_row_of}) release(*b);
   for (DevBuf* b : {&ctx->ph_sel_entering, &ctx->ph_flags, &ctx->ph_x, &ctx->ph_y, &ctx->ph_sorted, &ctx->ph_small,
                     &ctx->ph_part, &ctx->ph_edges, &ctx->ph_edges_b, &ctx->ph_counts, &ctx->ph_sel_hist})
     release(*b);
@@ -2044,6 +2048,7 @@ int odw_swap_hit_lists(odw_ctx* ctx) {
   std::swap(ctx->hit_capacity, ctx->alt_capacity);
   std::swap(ctx->hit_slots, ctx->alt_slots);
   std::swap(ctx->hit_ray_end, ctx->alt_hit_ray_end);
+  std::swap(ctx->hit_ray_begin, ctx->alt_hit_ray_begin);
   ctx->swapping = true;
   return ODW_OK;
 }

@@ -21,6 +21,53 @@ constexpr int kPhLdsEdges = 2048;
 // key = ray index of a selected row, `sentinel` (above every ray index of the list) for everything else;
 // counts[0] += selected rows, counts[1] += those that leave.  Grid-stride, one pair of atomics per block: one
 // pair per wave serialised 3e5 memory-side atomics of a 1e7-row list on two addresses (1.9 ms; now 0.1).
+// The ordered selection without a sort, for lists in which no ray has two selected rows (an absorbing detector:
+// every BASELINE config): a bitmap of the rays that have a row + the row of every such ray; the rank of a ray = the
+// set bits before it (prefix sums of the words' popcounts); rows written out by rank.  Three passes over 4-byte
+// tables instead of three radix passes over key / value pairs; the same list, since ray indices are the sort key.
+// dup: set when a ray shows up twice -- the caller then sorts.  counts as in ph_keys_kernel.
+__global__ __launch_bounds__(256) void ph_mark_kernel(const odw_hit* __restrict__ hits, uint64_t n, int group, uint64_t ray0, uint64_t n_rays,
+                                                      uint32_t* __restrict__ bitmap, uint32_t* __restrict__ row_of,
+                                                      unsigned long long* __restrict__ counts, uint32_t* __restrict__ dup) {
+  uint32_t n_sel = 0, n_leave = 0;
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const uint64_t tag = hits[i].tag;
+    const bool sel = tag != ODW_TAG_UNUSED && (group < 0 || (int)ODW_HIT_GROUP(tag) == group);
+    if (sel) {
+      const uint64_t r = ODW_HIT_RAY(tag) - ray0;          // (unsigned: an index below ray0 wraps above n_rays)
+      if (r >= n_rays) { *dup = 1u; continue; }            // (cannot happen: hit_ray_begin / end bound the indices)
+      const uint32_t bit = 1u << (r & 31u);
+      if (atomicOr(bitmap + (r >> 5), bit) & bit) *dup = 1u;
+      row_of[r] = (uint32_t)i;
+      n_sel += 1u;
+      n_leave += ODW_HIT_ENTERING(tag) ? 0u : 1u;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { n_sel += __shfl_xor(n_sel, off); n_leave += __shfl_xor(n_leave, off); }
+  __shared__ uint32_t s[4][2];
+  if ((threadIdx.x & 63) == 0) { s[threadIdx.x >> 6][0] = n_sel; s[threadIdx.x >> 6][1] = n_leave; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t a = s[0][0] + s[1][0] + s[2][0] + s[3][0], b = s[0][1] + s[1][1] + s[2][1] + s[3][1];
+    if (a) atomicAdd(counts, (unsigned long long)a);
+    if (b) atomicAdd(counts + 1, (unsigned long long)b);
+  }
+}
+__global__ void ph_popc_kernel(const uint32_t* __restrict__ bitmap, uint64_t n_words, uint32_t* __restrict__ pop) {
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w < n_words) pop[w] = (uint32_t)__popc(bitmap[w]);
+}
+__global__ void ph_rank_kernel(const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ before, const uint32_t* __restrict__ row_of,
+                               uint64_t n_rays, uint32_t* __restrict__ out) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n_rays) {
+    const uint32_t word = bitmap[r >> 5], bit = 1u << (r & 31u);
+    if (word & bit) out[before[r >> 5] + (uint32_t)__popc(word & (bit - 1u))] = row_of[r];
+  }
+}
+
 // K: uint32_t when ray indices and the sentinel fit 32 bits (the sort then moves half the bytes), else uint64_t
 template <class K>
 __global__ __launch_bounds__(256) void ph_keys_kernel(const odw_hit* __restrict__ hits, uint64_t n, int group, uint64_t sentinel,
@@ -504,6 +551,47 @@ int odw_hits_select(odw_ctx* ctx, int32_t group, uint64_t* n_rows, uint64_t* n_l
     if (spare) --bits;                                                             // (the sorts below take bits + 1)
     const unsigned kgrid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((used + 255) / 256, (uint64_t)ctx->n_cu * 8));
     size_t tmp_bytes = 0;
+    // first the route without a sort (ph_mark_kernel): it gives up when a ray has two selected rows
+    static const bool sort_only = getenv("ODW_SELECT_SORT") != nullptr;        // (A/B runs)
+    const bool bounded = ctx->hit_ray_end && ctx->hit_ray_end < (1ull << 48) && ctx->hit_ray_begin < ctx->hit_ray_end;
+    const uint64_t ray0 = bounded ? ctx->hit_ray_begin : 0, n_rays = bounded ? ctx->hit_ray_end - ray0 : 0;
+    if (!sort_only && n_rays && n_rays <= (1ull << 28)) {
+      const uint64_t n_words = (n_rays + 31) / 32;
+      if ((rc = ensure(ctx, ctx->ph_bitmap, (n_words + 1) * sizeof(uint32_t)))) return rc;     // (+ the dup flag)
+      if ((rc = ensure(ctx, ctx->ph_before, n_words * 2 * sizeof(uint32_t)))) return rc;       // popcounts | prefix sums
+      if ((rc = ensure(ctx, ctx->ph_row_of, n_rays * sizeof(uint32_t)))) return rc;
+      uint32_t* bitmap = (uint32_t*)ctx->ph_bitmap.p;
+      uint32_t* dup = bitmap + n_words;
+      uint32_t* pop = (uint32_t*)ctx->ph_before.p;
+      uint32_t* before = pop + n_words;
+      HIPCHK(ctx, hipMemsetAsync(bitmap, 0, (n_words + 1) * sizeof(uint32_t), ctx->stream));
+      hipLaunchKernelGGL(ph_mark_kernel, dim3(kgrid), dim3(256), 0, ctx->stream, (const odw_hit*)ctx->hits.p, used, (int)group,
+                         ray0, n_rays, bitmap, (uint32_t*)ctx->ph_row_of.p, (unsigned long long*)ctx->ph_small.p, dup);
+      hipLaunchKernelGGL(ph_popc_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, ctx->stream, bitmap, n_words, pop);
+      HIPCHK(ctx, hipGetLastError());
+      HIPCHK(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, pop, before, (int)n_words, ctx->stream));
+      if ((rc = ensure(ctx, ctx->sort_tmp, tmp_bytes))) return rc;
+      HIPCHK(ctx, hipcub::DeviceScan::ExclusiveSum(ctx->sort_tmp.p, tmp_bytes, pop, before, (int)n_words, ctx->stream));
+      hipLaunchKernelGGL(ph_rank_kernel, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, ctx->stream, bitmap, before,
+                         (const uint32_t*)ctx->ph_row_of.p, n_rays, v_out);
+      HIPCHK(ctx, hipGetLastError());
+      uint64_t c[2] = {0, 0};
+      uint32_t h_dup = 0;
+      HIPCHK(ctx, hipMemcpyAsync(c, ctx->ph_small.p, sizeof c, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(ctx, hipMemcpyAsync(&h_dup, dup, sizeof h_dup, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      if (!h_dup) {
+        ctx->ph_n = c[0];
+        ctx->ph_n_entering = c[0] - c[1];
+        ctx->ph_entering_built = false;
+        *n_rows = c[0];
+        if (n_leaving) *n_leaving = c[1];
+        ctx->ph_group = group;
+        ctx->ph_valid = true;
+        return ODW_OK;
+      }
+      HIPCHK(ctx, hipMemsetAsync(ctx->ph_small.p, 0, 2 * sizeof(uint64_t), ctx->stream));      // the counts again, with the sort
+    }
     static const bool keys64 = getenv("ODW_SELECT_KEYS64") != nullptr;        // (A/B runs)
     if (bits + 1 <= 32 && !keys64) {
       uint32_t* k32_in = (uint32_t*)k_in;
