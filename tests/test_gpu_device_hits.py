@@ -160,3 +160,48 @@ def test_hit_columns_equal_the_split_rows(native_lib):
       assert np.array_equal(cols['isEntering'], (sel['tag'] >> np.uint64(63)).astype(np.int64))
       assert np.array_equal(cols['rayIndex'], (sel['tag'] & np.uint64(0xFFFFFFFFFFFF)).astype(np.int64))
     assert seen == 3
+
+
+def test_selection_without_a_sort_is_the_sorted_selection(native_lib):
+  """`odw_hits_select` orders a group's rows by ray index: by rank in a bitmap of rays where no ray has two selected
+  rows (an absorbing detector: GettingStarted), by radix sort otherwise (every group recording: several rows per
+  ray) -- ODW_SELECT_SORT=1 forces the sort (read once per process: a child process per route).  Both routes: the same
+  columns, row for row."""
+  import subprocess
+  import sys
+  import tempfile
+  here = os.path.dirname(os.path.abspath(__file__))
+  n = 300000
+  code = f"""
+import sys, copy, numpy as np
+sys.path.insert(0, {os.path.dirname(here)!r}); sys.path.insert(0, {here!r})
+from conftest import project
+from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
+pr = project('GettingStarted')
+every, group = sys.argv[2] == '1', sys.argv[3]
+sc = copy.copy(pr.scene)
+if every:
+  sc.group_record = np.ones_like(pr.scene.group_record)
+with Tracer(0) as tr:
+  tr.setScene(sc); tr.setSource(pr.source); tr.setLimits(pr.limits); tr.setDetector(None)
+  tr.reserveHits({n} * 8); tr.reset(); tr.trace(1000, {n}, 5, histogram=False); tr.sync()
+  c = tr.hitColumns(-1 if group == 'all' else sc.group_index(group), pinned=False)
+  np.savez(sys.argv[1], **{{k: np.asarray(v) for k, v in c.items()}})
+"""
+  for every, group, unique in (('0', 'OpticalAbsorberGroup', True), ('1', 'all', False), ('1', 'OpticalLensGroup', False)):
+    cols = {}
+    for forced in (False, True):
+      env = {k: v for k, v in os.environ.items() if k != 'ODW_SELECT_SORT'}
+      if forced:
+        env['ODW_SELECT_SORT'] = '1'
+      with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, 'cols.npz')
+        res = subprocess.run([sys.executable, '-c', code, out, every, group], capture_output=True, text=True, timeout=600, env=env)
+        assert res.returncode == 0, res.stderr[-2000:]
+        cols[forced] = dict(np.load(out))
+    a, b = cols[False], cols[True]
+    assert set(a) == set(b) and len(a['rayIndex']) > 0.5 * n
+    for k in a:
+      assert np.array_equal(a[k], b[k]), (group, k)
+    steps = np.diff(a['rayIndex'])
+    assert np.all(steps >= 0) and bool(np.all(steps > 0)) == unique
