@@ -1072,14 +1072,27 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
   // per CU at 4 waves/SIMD, x2 so that a CU never waits for a block launch);
   // chunks of ODW_CHUNK rays are handed out dynamically inside the kernel
   static const int grid_mult = [] { const char* e = getenv("ODW_GRID_MULT"); int v = e ? atoi(e) : 0; return v > 0 ? v : 8; }();
-  const uint64_t n_chunks = (n + ODW_CHUNK - 1) / ODW_CHUNK;
-  const uint64_t cap = (uint64_t)ctx->n_cu * grid_mult;
-  const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_chunks + 3) / 4, cap));
   // big analytic scenes: grid kernel (no stochastic surfaces, no segment rows: those stay with the BVH kernels)
   // a scene compiled against its structure (odw_spec.hip): its own kernel, whatever else was built for it
   const bool use_spec = ctx->spec_fn && ctx->spec_lean == ctx->lean && ctx->spec_stoch == (ctx->n_samplers > 0) &&
                         !(flags & ODW_TRACE_RECORD_SEGMENTS);
   const bool use_grid = !use_spec && P.grid.nx > 0 && ctx->n_samplers == 0 && !(flags & ODW_TRACE_RECORD_SEGMENTS);
+  // Rays per hand-out unit.  A launch should hold many chunks per resident wave: with about one each -- 1e7 rays in
+  // chunks of 2048 on 4096 resident waves -- the waves that get a second one set the launch's length.  Measured
+  // (kernel ms at 1e7 / 1e8 rays): flat kernels 2048: 1.46 / 11.07, 1024: 1.44 / 10.93, 512: 1.39 / 10.97, 256: 1.43;
+  // the ring kernels (grid, mesh: a ring fill is 64 rays whatever the chunk) 2048: 2.24 / 21.34, 512: 2.05 / 20.95,
+  // 256: 1.96 / 20.86, and the mesh kernel at 1e7 rays and 6.5e4 facets 2048: 14.6, 256: 12.5, 64: 12.3.
+  {
+    static const uint64_t forced = [] { const char* e = getenv("ODW_CHUNK_RAYS"); return e ? (uint64_t)atoll(e) : 0ull; }();   // (A/B runs)
+    const bool ring = use_grid || (!use_spec && P.scene.n_nodes && P.scene.bvh_leaf && !(flags & ODW_TRACE_RECORD_SEGMENTS));
+    const uint64_t waves = (uint64_t)ctx->n_cu * 16;
+    const uint64_t want = ring ? std::max<uint64_t>(64, std::min<uint64_t>(256, n / (waves * 32)))
+                               : std::max<uint64_t>(512, std::min<uint64_t>(1024, n / (waves * 4)));
+    P.chunk = (uint32_t)((forced ? std::max<uint64_t>(64, std::min<uint64_t>(ODW_CHUNK, forced)) : want) & ~(uint64_t)63);
+  }
+  const uint64_t n_chunks = (n + P.chunk - 1) / P.chunk;
+  const uint64_t cap = (uint64_t)ctx->n_cu * grid_mult;
+  const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_chunks + 3) / 4, cap));
   const uint64_t grid_blocks = std::max<uint64_t>(1, std::min<uint64_t>((n_chunks + ODW_GRID_WAVES - 1) / ODW_GRID_WAVES, (uint64_t)ctx->n_cu));
   // scenes with facets: the mesh kernel (same exclusions)
   const bool use_mesh = !use_spec && !use_grid && P.scene.n_nodes && P.scene.bvh_leaf && !(flags & ODW_TRACE_RECORD_SEGMENTS);

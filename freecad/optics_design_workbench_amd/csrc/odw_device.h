@@ -188,6 +188,7 @@ struct TraceParams {
   uint64_t ray_stride;          // rays of the launch
   uint64_t first_ray, n_rays, seed;
   uint32_t flags;
+  uint32_t chunk;               // rays per hand-out unit of this launch (a multiple of 64, <= ODW_CHUNK)
   unsigned long long* dbg;      // diagnostic builds only (ODW_GRID_STATS): 16 words, or null
 };
 

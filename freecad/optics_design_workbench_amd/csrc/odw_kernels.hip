@@ -1444,7 +1444,7 @@ template <> struct HitBlockState<false> {
 
 // ------------------------------------------------------------ the kernel
 #ifndef ODW_CHUNK
-#define ODW_CHUNK 2048ull      // rays per hand-out unit (32 per lane)
+#define ODW_CHUNK 2048ull      // rays per hand-out unit of long launches (32 per lane); TraceParams.chunk is what a launch uses
 #endif
 #ifndef ODW_REFILL_MIN
 #define ODW_REFILL_MIN 16      // idle lanes that trigger a refill of a partly busy wave
@@ -1524,9 +1524,9 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
         if (lane == (uint32_t)(__ffsll((unsigned long long)__ballot(1)) - 1)) c = atomicAdd(P.out.chunk_counter, 1ull);
         const uint64_t chunk = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(c >> 32)) << 32) |
                                (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)c);
-        next = chunk * ODW_CHUNK;
+        next = chunk * (uint64_t)P.chunk;
         if (next > P.n_rays) next = P.n_rays;
-        chunk_end = next + ODW_CHUNK < P.n_rays ? next + ODW_CHUNK : P.n_rays;
+        chunk_end = next + P.chunk < P.n_rays ? next + P.chunk : P.n_rays;
       }
       const uint64_t avail = next < chunk_end ? chunk_end - next : 0;
       const uint32_t rank = __popcll(idle & ((1ull << lane) - 1ull));

@@ -183,9 +183,9 @@ __global__ __launch_bounds__(ODW_MESH_THREADS, ODW_MESH_WAVES) void odw_mesh_ker
           if (lane == 0) c = atomicAdd(P.out.chunk_counter, 1ull);
           const uint64_t chunk = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(c >> 32)) << 32) |
                                  (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)c);
-          next = chunk * ODW_CHUNK;
+          next = chunk * (uint64_t)P.chunk;
           if (next >= P.n_rays) { next = P.n_rays; drained = true; }
-          chunk_end = next + ODW_CHUNK < P.n_rays ? next + ODW_CHUNK : P.n_rays;
+          chunk_end = next + P.chunk < P.n_rays ? next + P.chunk : P.n_rays;
         }
         const uint64_t avail = chunk_end - next;
         const uint32_t fill = avail < ODW_MESH_RING ? (uint32_t)avail : (uint32_t)ODW_MESH_RING;
