@@ -27,8 +27,17 @@ using namespace odw;
 namespace {
 
 constexpr int kGuide = 1 << 16;
-constexpr uint32_t kHitBlock = 512;            // hit-list slots a wave reserves per atomic (big hit lists only)
-constexpr uint64_t kHitBlockMinRows = 1ull << 22;
+// Hit-list slots a wave reserves per atomic, and the smallest list that gets the room for it (A/B: ODW_HIT_BLOCK,
+// ODW_HIT_BLOCK_MIN_ROWS).  Atomics on one address complete at about one per 3.6 ns on this chip whatever the number
+// of waves, so a launch's length is bounded below by its atomic count: GettingStarted with a reservation per wave and
+// recording step takes 0.23 / 0.66 ms for 1e6 / 3e6 rays, with blocks of 512 slots 0.16 / 0.34 (128: 0.19 / 0.45,
+// 256: 0.17 / 0.36, 1024: 0.17 / 0.35, 4096: 0.33 / 0.68 -- the unused slots a wave tags at its end); at 1e8 rays
+// 128: 10.7 ms, 256: 6.41, 512: 6.10, 1024: 6.06, 2048: 6.04, 4096: 6.13 (profiles/r03/r03q_hit_blocks.log).
+static const uint32_t kHitBlock = [] { const char* e = getenv("ODW_HIT_BLOCK"); const int v = e ? atoi(e) : 0; return (uint32_t)(v >= 64 ? (v & ~63) : 512); }();
+static const uint64_t kHitBlockMinRows = [] { const char* e = getenv("ODW_HIT_BLOCK_MIN_ROWS"); return e ? (uint64_t)atoll(e) : (1ull << 16); }();
+// room a list of `capacity` rows needs for reservations of `block` slots by `waves` waves: < 64 unused slots per
+// block change, and the last block of every wave
+static inline uint64_t hit_block_room(uint64_t capacity, uint64_t waves, uint64_t block) { return capacity * 64 / block + 64 + waves * block; }
 constexpr int kPhiGuide = 1 << 8;        // azimuth table of a source (~1e2 knots)
 constexpr int kSurfaceGuide = 1 << 10;  // per row of a surface sampler (tables of ~1e3 knots)
 // Analytic scenes of up to this many primitives take the flat kernels (brute force over the primitives, scalar
@@ -1097,9 +1106,9 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
   // scenes with facets: the mesh kernel (same exclusions)
   const bool use_mesh = !use_spec && !use_grid && P.scene.n_nodes && P.scene.bvh_leaf && !(flags & ODW_TRACE_RECORD_SEGMENTS);
   const uint64_t n_waves = use_grid ? grid_blocks * ODW_GRID_WAVES : (uint64_t)grid * 4;
-  if ((!P.scene.n_nodes || use_grid || use_spec || use_mesh) && !ctx->swapping &&
-      ctx->hit_slots >= ctx->hit_capacity + ctx->hit_capacity / 8 + 64 + n_waves * kHitBlock)
-    P.out.hit_block = kHitBlock;     // flat, grid and mesh kernels only (see record_hit)
+  if ((!P.scene.n_nodes || use_grid || use_spec || use_mesh) && !ctx->swapping)   // flat, grid and mesh kernels only (see record_hit)
+    for (uint32_t b = kHitBlock; b >= 128 && b >= kHitBlock / 4 && !P.out.hit_block; b /= 2)   // (a short list: smaller blocks before none)
+      if (ctx->hit_slots >= ctx->hit_capacity + hit_block_room(ctx->hit_capacity, n_waves, b)) P.out.hit_block = b;
   HIPCHK(ctx, hipMemsetAsync(ctx->chunk_counter.p, 0, sizeof(uint64_t), ctx->stream));
   const size_t lds = P.scene.n_nodes ? (size_t)ODW_BVH_STACK * 256 * sizeof(int) : 0;
 
@@ -1846,7 +1855,9 @@ int odw_reserve_hits(odw_ctx* ctx, uint64_t capacity) {
     // big lists get slack for block reservations (launch_trace): an eighth (unused slots at block
     // changes) + one block per wave of the largest grid
     uint64_t slots = capacity;
-    if (capacity >= kHitBlockMinRows) slots += capacity / 8 + 64 + (uint64_t)ctx->n_cu * 8 * 4 * kHitBlock;
+    // (a short list is filled by short launches: a wave per 256 rows, the largest grid at most)
+    if (capacity >= kHitBlockMinRows)
+      slots += hit_block_room(capacity, std::min<uint64_t>((uint64_t)ctx->n_cu * 8 * 4, std::max<uint64_t>(64, capacity / 256)), kHitBlock);
     int rc = ensure(ctx, ctx->hits, slots * sizeof(odw_hit));
     if (rc) return rc;
     ctx->hit_capacity = capacity;

@@ -562,9 +562,12 @@ __global__ __launch_bounds__(ODW_MESH_THREADS, ODW_MESH_WAVES) void odw_mesh_ker
   if (lane == 0 && P.dbg)
     for (int k = 0; k < 6; ++k) atomicAdd(P.dbg + 16 + k, (unsigned long long)phase_t[k]);
 #endif
-  if (lane < ODW_CNT_LDS) {
-    const uint32_t s = wave_cnt[lane];
-    if (s) atomicAdd(P.out.counters + lane, (unsigned long long)s);
+  // (one atomic per block and counter: the waves' words are next to each other in LDS)
+  __syncthreads();
+  if (threadIdx.x < ODW_CNT_LDS) {
+    uint32_t s = 0;
+    for (int w = 0; w < ODW_MESH_BLOCK_WAVES; ++w) s += lds32[word_off + w * ODW_MESH_WAVE_WORDS + threadIdx.x];
+    if (s) atomicAdd(P.out.counters + threadIdx.x, (unsigned long long)s);
   }
 }
 
