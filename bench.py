@@ -456,9 +456,10 @@ def main():
     out = run_sweep_config(args, cfg, rank, local_rank, world, dist, torch)
   else:
     out = run_trace_config(args, args.config, cfg, rank, local_rank, world, dist, torch)
-  if args.config == 'c3' and not args.no_extra and not args.no_hits and not args.rays_per_step:
+  if args.config == 'c3' and world == 1 and not args.no_extra and not args.no_hits and not args.rays_per_step:
     # the other two GPU configs of BASELINE.json in the same driver-timed record: c4 (hugeArray, 3 steps) and
     # c5 (the radius sweep, 2 sweeps after 1 untimed one: its host side makes single sweeps vary by 20 %), each measured exactly like its own `--config` line
+    # (one GPU only: a scaling run needs the headline per N, and an extra that fails on one rank would take the others' line with it)
     import copy
     extra = {}
     for name, steps, warmup in (('c4', 3, 1), ('c5', 2, 1)):
@@ -472,8 +473,6 @@ def main():
           line = run_trace_config(sub, name, CONFIGS[name], rank, local_rank, world, dist, torch)
       except Exception as e:            # (a failing extra must not take the headline line with it; it is reported)
         line = {'error': f'{type(e).__name__}: {e}'[:500]}
-        if dist is not None:
-          raise
       if rank == 0:
         if name == 'c5' and 'config' in line:          # (the per-radius table belongs to the c5 line of its own)
           line['config'].get('spot_size', {}).pop('radii', None)
