@@ -143,6 +143,83 @@ def pmc_figures(cfg_name, n_per, record_hits, kernel):
   return tj
 
 
+class ClockSampler:
+  """Shader clock and package power of this rank's GPU while the timed steps run, read from the amdgpu hwmon files an
+  ordinary user may read (freq1_input in Hz, power1_input in microwatt) by a thread that wakes every 10 ms -- the
+  timing thread sits in a ctypes call without the GIL meanwhile.  The boxes of this pool share hosts (eight GPUs,
+  one power and cooling budget): the same binary reads 10.9 - 11.5 ms per C3 step from box to box, and this is the
+  one cause that can be seen from inside: `roofline.frac` assumes the 2400 MHz maximum, `frac_at_sampled_clock` the
+  clock the chip actually ran at.  Silent (None) where the files are absent or unreadable."""
+
+  def __init__(self, torch, index):
+    import glob
+    self.files = None
+    self.samples = []
+    self._stop = False
+    self._thread = None
+    cands = []
+    try:
+      pr = torch.cuda.get_device_properties(index)
+      dev = '/sys/bus/pci/devices/%04x:%02x:%02x.0' % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+      cands = glob.glob(dev + '/hwmon/hwmon*')
+    except Exception:
+      cands = []
+    if not cands:      # the one card whose clock table this user may read
+      mine = [os.path.dirname(f) for f in glob.glob('/sys/class/drm/card*/device/pp_dpm_sclk') if os.access(f, os.R_OK)]
+      if len(mine) == 1:
+        cands = glob.glob(mine[0] + '/hwmon/hwmon*')
+    for h in cands:
+      f, w = os.path.join(h, 'freq1_input'), os.path.join(h, 'power1_input')
+      if os.access(f, os.R_OK):
+        self.files = (f, w if os.access(w, os.R_OK) else None)
+        break
+
+  def _read(self):
+    out = []
+    for f in self.files:
+      try:
+        with open(f) as fh:
+          out.append(int(fh.read()))
+      except Exception:
+        out.append(None)
+    return out
+
+  def _run(self):
+    while not self._stop:
+      self.samples.append(self._read())
+      time.sleep(0.01)
+
+  def start(self):
+    if self.files:
+      import threading
+      self._stop, self.samples = False, []
+      self._thread = threading.Thread(target=self._run, daemon=True)
+      self._thread.start()
+
+  def stop(self):
+    if not self._thread:
+      return None
+    self._stop = True
+    self._thread.join()
+    self._thread = None
+    clk = [v[0] / 1e6 for v in self.samples if v[0]]
+    pw = [v[1] / 1e6 for v in self.samples if v[1]]
+    if not clk:
+      return None
+    out = {'sclk_mhz_mean': sum(clk) / len(clk), 'sclk_mhz_min': min(clk), 'sclk_mhz_max': max(clk), 'samples': len(clk),
+           'peak_mhz': CLOCK_GHZ * 1e3, 'source': 'amdgpu hwmon freq1_input / power1_input, every 10 ms during the timed steps'}
+    if pw:
+      out.update(power_w_mean=sum(pw) / len(pw), power_w_max=max(pw))
+    return out
+
+
+def with_sampled_clock(roofline, clock):
+  """the calibrated issue fraction at the clock the chip ran at (the peak of `frac` is quoted at 2400 MHz)"""
+  if roofline and clock and roofline.get('frac') and clock.get('sclk_mhz_mean'):
+    roofline['frac_at_sampled_clock'] = roofline['frac'] * clock['peak_mhz'] / clock['sclk_mhz_mean']
+  return roofline
+
+
 def roofline_block(kernel_name, avg_kernel_s, rays_per_launch, bytes_per_ray, pmc, note=None):
   """The bound of these kernels is VECTOR-INSTRUCTION ISSUE, not HBM: rays live in registers from generation to
   termination, the only HBM traffic is the hit rows.  frac = wave64 VALU instructions per second (SQ_INSTS_VALU of
@@ -232,6 +309,8 @@ def run_trace_config(args, cfg_name, cfg, rank, local_rank, world, dist, torch):
   tr.timingEnable(True)
   tr.timingRead()
   barrier()
+  sampler = ClockSampler(torch, local_rank)
+  sampler.start()
   t0 = time.perf_counter()
   for s in range(args.steps):
     step(s)
@@ -240,6 +319,7 @@ def run_trace_config(args, cfg_name, cfg, rank, local_rank, world, dist, torch):
     parallel.reduceResults(tr, dist, torch)
   barrier()
   dt = time.perf_counter() - t0
+  clock = sampler.stop()
   kernel_ms, launches = tr.timingRead()
 
   if dist is not None:
@@ -275,8 +355,10 @@ def run_trace_config(args, cfg_name, cfg, rank, local_rank, world, dist, torch):
                                       'note': 'hiprtc compile of the ray loop against the scene, before the timed region',
                                       **({'error': compiled['error']} if 'error' in compiled else {})},
                    'parallelism': f'ray-index sharding x{world}, one RCCL reduce'},
-        'roofline': roofline_block(kernel_name, avg_kernel_s, n_per, bytes_per_ray, pmc),
+        'roofline': with_sampled_clock(roofline_block(kernel_name, avg_kernel_s, n_per, bytes_per_ray, pmc), clock),
     }
+    if clock:
+      out['clock'] = clock
     if world == 1 and record_hits and cfg_name == 'c3' and not args.no_end_to_end:
       out['end_to_end'] = end_to_end(tr, n_per, max(2, args.steps))
     if world == 1 and not args.no_cpu_baseline:
@@ -352,11 +434,14 @@ def run_sweep_config(args, cfg, rank, local_rank, world, dist, torch):
   tr.timingEnable(True)
   tr.timingRead()
   barrier()
+  sampler = ClockSampler(torch, local_rank)
+  sampler.start()
   t0 = time.perf_counter()
   for _ in range(args.steps):
     res = run()
   barrier()
   dt = time.perf_counter() - t0
+  clock = sampler.stop()
   kernel_ms, launches = tr.timingRead()
   if dist is not None:
     t = torch.tensor([dt], dtype=torch.float64, device='cuda')
@@ -395,10 +480,12 @@ def run_sweep_config(args, cfg, rank, local_rank, world, dist, torch):
                                               'flat near the focus; the rms spot radius below stays defined',
                                  'rms_spot_mm': [float(v) for v in res.columns['rms']],
                                  'best_radius_by_rms_mm': rms_r, 'best_rms_spot_mm': rms_v}},
-        'roofline': roofline_block(kernel_name, avg_kernel_s, n_per, bytes_per_ray, pmc,
+        'roofline': with_sampled_clock(roofline_block(kernel_name, avg_kernel_s, n_per, bytes_per_ray, pmc,
                                    note='launches of rank 0; a launch = one radius; per step the host also re-bakes the scene and '
-                                        'searches the detector plane per radius'),
+                                        'searches the detector plane per radius'), clock),
     }
+    if clock:
+      out['clock'] = clock
     if world == 1 and not args.no_cpu_baseline:
       proj = scenes.bakeProject(doc)
       out['cpu_baseline'] = cpu_baseline(proj, None, seconds=8.0)
