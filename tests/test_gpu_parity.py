@@ -200,24 +200,26 @@ def test_explicit_rays(tracer, oracle):
 
 
 def test_block_reserved_hit_list_equals_exact_list(tracer, oracle):
-  """hit lists of >= 4M rows are filled through per-wave block reservations
-  (slots a wave cannot use are marked and dropped by the fetch); the rows must
-  be those of the one-reservation-per-append path and of the oracle, for
+  """hit lists of >= 65536 rows are filled through per-wave block reservations (slots a wave cannot use are marked
+  and dropped by the fetch; blocks of 512 slots, or of 256 / 128 where the list's room holds no more for the launch's
+  waves); the rows must be those of the one-reservation-per-append path (shorter lists) and of the oracle, for
   appends of varying width (all groups recording), across launches and resets"""
   import copy
+  from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
   pr = project('GettingStarted')
   sc = copy.copy(pr.scene)
   sc.group_record = np.ones_like(sc.group_record)
-  n = 300000
+  n, n_small = 300000, 15000
   rows = {}
-  for label, cap in (('blocks', 5_000_000), ('exact', 4 * n)):
-    from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
+  for label, cap, rays in (('blocks', 5_000_000, n), ('short list', 4 * n, n), ('blocks, few rays', 5_000_000, n_small),
+                           ('exact', 4 * n_small, n_small)):
+    assert (cap < 65536) == (label == 'exact')
     with Tracer(0) as tr:
       tr.setScene(sc); tr.setSource(pr.source); tr.setLimits(pr.limits); tr.setDetector(None)
       tr.reserveHits(cap)
       tr.reset()
-      tr.trace(0, n // 3, 9)
-      tr.trace(n // 3, n - n // 3, 9)             # second launch appends behind the first one's blocks
+      tr.trace(0, rays // 3, 9)
+      tr.trace(rays // 3, rays - rays // 3, 9)    # second launch appends behind the first one's blocks
       tr.sync()
       c = tr.counters()
       assert tr.hitCount() == c['recorded_hits'] and c['hits_dropped'] == 0
@@ -228,16 +230,22 @@ def test_block_reserved_hit_list_equals_exact_list(tracer, oracle):
       tr.sync()
       assert tr.hitCount() == len(tr.hits()) > 2000
   ref = oracle.trace(sc, pr.source, pr.limits, 0, n, 9, hit_capacity=5 * n, nthreads=8)['hits']
-  assert len(rows['blocks']) == len(rows['exact']) == len(ref) > 3 * n
-  assert rows['blocks'].tobytes() == rows['exact'].tobytes()
+  assert len(rows['blocks']) == len(rows['short list']) == len(ref) > 3 * n
+  assert rows['blocks'].tobytes() == rows['short list'].tobytes()
   assert np.array_equal(rows['blocks']['tag'], ref['tag'])
+  ray = (ref['tag'] & np.uint64(0xFFFFFFFFFFFF)).astype(np.int64)
+  few = ref[ray < n_small]
+  assert len(rows['exact']) == len(rows['blocks, few rays']) == len(few) > 3 * n_small
+  assert rows['exact'].tobytes() == rows['blocks, few rays'].tobytes()
+  assert np.array_equal(rows['exact']['tag'], few['tag'])
 
 
-def test_block_reserved_hit_list_overflow(tracer):
+@pytest.mark.parametrize('cap,n', [(1 << 22, 12_000_000), (1 << 17, 400_000)])
+def test_block_reserved_hit_list_overflow(tracer, cap, n):
   """more hits than the (block-reserved) list holds: every stored row is a real
-  hit, stored + dropped = recorded, at least the requested capacity is stored"""
+  hit, stored + dropped = recorded, at least the requested capacity is stored; a long list (blocks of 512 slots) and
+  a short one (its room holds blocks of 256 for this launch's waves)"""
   pr = project('minimal')                          # one hit per ray
-  cap, n = 1 << 22, 12_000_000
   tracer.setScene(pr.scene); tracer.setSource(pr.source); tracer.setLimits(pr.limits); tracer.setDetector(None)
   tracer.reserveHits(cap)
   tracer.reset()
