@@ -22,13 +22,17 @@ constexpr int kPhLdsEdges = 2048;
 // counts[0] += selected rows, counts[1] += those that leave.  Grid-stride, one pair of atomics per block: one
 // pair per wave serialised 3e5 memory-side atomics of a 1e7-row list on two addresses (1.9 ms; now 0.1).
 // The ordered selection without a sort, for lists in which no ray has two selected rows (an absorbing detector:
-// every BASELINE config): a bitmap of the rays that have a row + the row of every such ray; the rank of a ray = the
-// set bits before it (prefix sums of the words' popcounts); rows written out by rank.  Three passes over 4-byte
-// tables instead of three radix passes over key / value pairs; the same list, since ray indices are the sort key.
-// dup: set when a ray shows up twice -- the caller then sorts.  counts as in ph_keys_kernel.
+// every BASELINE config): the row of every ray that has one (plain stores into a table preset to "none": no atomics --
+// an atomicOr per row into a bitmap cost 1.06 ms for 1e7 rows, the memory side's rate for 1e7 returning atomics), the
+// bitmap of those rays and its words' popcounts by ballot over the table, the rank of a ray = the set bits before it
+// (prefix sums of the popcounts); rows written out by rank.  Three passes over 4-byte tables instead of three radix
+// passes over key / value pairs; the same list, since ray indices are the sort key.  A ray with two selected rows
+// leaves one store of the two standing: fewer rays marked than rows selected -- the caller sees that and sorts.
+// counts as in ph_keys_kernel; oob: a ray index outside the launch's range (cannot happen).
+#define PH_NO_ROW 0xffffffffu
 __global__ __launch_bounds__(256) void ph_mark_kernel(const odw_hit* __restrict__ hits, uint64_t n, int group, uint64_t ray0, uint64_t n_rays,
-                                                      uint32_t* __restrict__ bitmap, uint32_t* __restrict__ row_of,
-                                                      unsigned long long* __restrict__ counts, uint32_t* __restrict__ dup) {
+                                                      uint32_t* __restrict__ row_of, unsigned long long* __restrict__ counts,
+                                                      uint32_t* __restrict__ oob) {
   uint32_t n_sel = 0, n_leave = 0;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -36,9 +40,7 @@ __global__ __launch_bounds__(256) void ph_mark_kernel(const odw_hit* __restrict_
     const bool sel = tag != ODW_TAG_UNUSED && (group < 0 || (int)ODW_HIT_GROUP(tag) == group);
     if (sel) {
       const uint64_t r = ODW_HIT_RAY(tag) - ray0;          // (unsigned: an index below ray0 wraps above n_rays)
-      if (r >= n_rays) { *dup = 1u; continue; }            // (cannot happen: hit_ray_begin / end bound the indices)
-      const uint32_t bit = 1u << (r & 31u);
-      if (atomicOr(bitmap + (r >> 5), bit) & bit) *dup = 1u;
+      if (r >= n_rays) { *oob = 1u; continue; }            // (cannot happen: hit_ray_begin / end bound the indices)
       row_of[r] = (uint32_t)i;
       n_sel += 1u;
       n_leave += ODW_HIT_ENTERING(tag) ? 0u : 1u;
@@ -55,13 +57,27 @@ __global__ __launch_bounds__(256) void ph_mark_kernel(const odw_hit* __restrict_
     if (b) atomicAdd(counts + 1, (unsigned long long)b);
   }
 }
-__global__ void ph_popc_kernel(const uint32_t* __restrict__ bitmap, uint64_t n_words, uint32_t* __restrict__ pop) {
-  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (w < n_words) pop[w] = (uint32_t)__popc(bitmap[w]);
+// bitmap words and their popcounts from the table: a wave looks at 64 consecutive rays, its ballot is two words
+// (blocks of 256 threads: n_rays is padded to whole words by the caller's allocation, rays beyond it read as none)
+__global__ __launch_bounds__(256) void ph_popc_kernel(const uint32_t* __restrict__ row_of, uint64_t n_rays, uint32_t* __restrict__ bitmap,
+                                                      uint32_t* __restrict__ pop) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool has = r < n_rays && row_of[r] != PH_NO_ROW;
+  const uint64_t b = __ballot(has);
+  const uint32_t lane = threadIdx.x & 63u;
+  if ((lane & 31u) == 0 && r < n_rays) {
+    const uint32_t word = (uint32_t)(lane ? b >> 32 : b);
+    bitmap[r >> 5] = word;
+    pop[r >> 5] = (uint32_t)__popc(word);
+  }
 }
 __global__ void ph_rank_kernel(const uint32_t* __restrict__ bitmap, const uint32_t* __restrict__ before, const uint32_t* __restrict__ row_of,
-                               uint64_t n_rays, uint32_t* __restrict__ out) {
+                               uint64_t n_rays, uint32_t* __restrict__ out, unsigned long long* __restrict__ marked) {
   const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r == 0) {                                            // rays that have a row: the caller compares with the rows selected
+    const uint64_t w = (n_rays - 1) >> 5;
+    *marked = (unsigned long long)before[w] + (unsigned long long)__popc(bitmap[w]);
+  }
   if (r < n_rays) {
     const uint32_t word = bitmap[r >> 5], bit = 1u << (r & 31u);
     if (word & bit) out[before[r >> 5] + (uint32_t)__popc(word & (bit - 1u))] = row_of[r];
@@ -557,29 +573,31 @@ int odw_hits_select(odw_ctx* ctx, int32_t group, uint64_t* n_rows, uint64_t* n_l
     const uint64_t ray0 = bounded ? ctx->hit_ray_begin : 0, n_rays = bounded ? ctx->hit_ray_end - ray0 : 0;
     if (!sort_only && n_rays && n_rays <= (1ull << 28)) {
       const uint64_t n_words = (n_rays + 31) / 32;
-      if ((rc = ensure(ctx, ctx->ph_bitmap, (n_words + 1) * sizeof(uint32_t)))) return rc;     // (+ the dup flag)
+      if ((rc = ensure(ctx, ctx->ph_bitmap, n_words * sizeof(uint32_t)))) return rc;
       if ((rc = ensure(ctx, ctx->ph_before, n_words * 2 * sizeof(uint32_t)))) return rc;       // popcounts | prefix sums
       if ((rc = ensure(ctx, ctx->ph_row_of, n_rays * sizeof(uint32_t)))) return rc;
       uint32_t* bitmap = (uint32_t*)ctx->ph_bitmap.p;
-      uint32_t* dup = bitmap + n_words;
       uint32_t* pop = (uint32_t*)ctx->ph_before.p;
       uint32_t* before = pop + n_words;
-      HIPCHK(ctx, hipMemsetAsync(bitmap, 0, (n_words + 1) * sizeof(uint32_t), ctx->stream));
+      uint32_t* row_of = (uint32_t*)ctx->ph_row_of.p;
+      unsigned long long* small = (unsigned long long*)ctx->ph_small.p;             // selected, leaving | rays marked | out-of-range flag
+      HIPCHK(ctx, hipMemsetAsync(small + 2, 0, 2 * sizeof(uint64_t), ctx->stream));
+      HIPCHK(ctx, hipMemsetAsync(row_of, 0xff, n_rays * sizeof(uint32_t), ctx->stream));       // PH_NO_ROW
       hipLaunchKernelGGL(ph_mark_kernel, dim3(kgrid), dim3(256), 0, ctx->stream, (const odw_hit*)ctx->hits.p, used, (int)group,
-                         ray0, n_rays, bitmap, (uint32_t*)ctx->ph_row_of.p, (unsigned long long*)ctx->ph_small.p, dup);
-      hipLaunchKernelGGL(ph_popc_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, ctx->stream, bitmap, n_words, pop);
+                         ray0, n_rays, row_of, small, (uint32_t*)(small + 3));
+      hipLaunchKernelGGL(ph_popc_kernel, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)row_of,
+                         n_rays, bitmap, pop);
       HIPCHK(ctx, hipGetLastError());
       HIPCHK(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, pop, before, (int)n_words, ctx->stream));
       if ((rc = ensure(ctx, ctx->sort_tmp, tmp_bytes))) return rc;
       HIPCHK(ctx, hipcub::DeviceScan::ExclusiveSum(ctx->sort_tmp.p, tmp_bytes, pop, before, (int)n_words, ctx->stream));
       hipLaunchKernelGGL(ph_rank_kernel, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, ctx->stream, bitmap, before,
-                         (const uint32_t*)ctx->ph_row_of.p, n_rays, v_out);
+                         (const uint32_t*)row_of, n_rays, v_out, small + 2);
       HIPCHK(ctx, hipGetLastError());
-      uint64_t c[2] = {0, 0};
-      uint32_t h_dup = 0;
-      HIPCHK(ctx, hipMemcpyAsync(c, ctx->ph_small.p, sizeof c, hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(ctx, hipMemcpyAsync(&h_dup, dup, sizeof h_dup, hipMemcpyDeviceToHost, ctx->stream));
+      uint64_t c[4] = {0, 0, 0, 0};
+      HIPCHK(ctx, hipMemcpyAsync(c, small, sizeof c, hipMemcpyDeviceToHost, ctx->stream));
       HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      const bool h_dup = c[3] != 0 || c[2] != c[0];                               // (two rows of one ray: one store of the two stands)
       if (!h_dup) {
         ctx->ph_n = c[0];
         ctx->ph_n_entering = c[0] - c[1];
@@ -782,6 +800,47 @@ int odw_hits_bin(odw_ctx* ctx, int32_t polar, const double* origin, const double
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipMemcpyAsync(counts, ctx->ph_counts.p, nbins * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return ODW_OK;
+}
+
+// ---- the screen of detectPlaneNormal's plane search, on the host (no device work) ----------------------------------
+// extent[i * n_phi + j] = max - min over the cloud of (point . normal(phis[j], thetas[i])): the candidates of one grid
+// of the search in the reference's order (meshgrid(phis, thetas) row-major).  Only a screen: the caller looks again,
+// with numpy's own sums, at the candidates within rounding of the smallest extent.
+int odw_plane_screen(const double* cloud, uint64_t n, const double* phis, int32_t n_phi, const double* thetas, int32_t n_theta,
+                     double* extent) {
+  if (!cloud || !phis || !thetas || !extent || n == 0 || n_phi < 1 || n_theta < 1 || n_phi > 4096 || n_theta > 4096)
+    return ODW_ERR_INVALID;
+  const size_t nc = (size_t)n_phi * (size_t)n_theta;
+  for (uint64_t k = 0; k < 3 * n; ++k)
+    if (!std::isfinite(cloud[k])) {                        // (the caller's margin test then keeps no candidate)
+      for (size_t c = 0; c < nc; ++c) extent[c] = NAN;
+      return ODW_OK;
+    }
+  // candidates side by side, points outside: every candidate keeps its own running minimum and maximum (no chain of
+  // dependent min / max instructions, and the compiler's vector units take the candidate loop as it stands)
+  std::vector<double> nx(nc), ny(nc), nz(nc), lo(nc, INFINITY), hi(nc, -INFINITY);
+  for (int i = 0; i < n_theta; ++i) {
+    const double ct = std::cos(thetas[i]), st = std::sin(thetas[i]);
+    for (int j = 0; j < n_phi; ++j) {
+      const size_t c = (size_t)i * n_phi + j;
+      nx[c] = std::cos(phis[j]) * st; ny[c] = std::sin(phis[j]) * st; nz[c] = ct;
+    }
+  }
+  double* __restrict__ plo = lo.data();
+  double* __restrict__ phi_ = hi.data();
+  const double* __restrict__ pnx = nx.data();
+  const double* __restrict__ pny = ny.data();
+  const double* __restrict__ pnz = nz.data();
+  for (uint64_t k = 0; k < n; ++k) {
+    const double x = cloud[3 * k], y = cloud[3 * k + 1], z = cloud[3 * k + 2];
+    for (size_t c = 0; c < nc; ++c) {
+      const double a = x * pnx[c] + y * pny[c] + z * pnz[c];
+      plo[c] = a < plo[c] ? a : plo[c];
+      phi_[c] = a > phi_[c] ? a : phi_[c];
+    }
+  }
+  for (size_t c = 0; c < nc; ++c) extent[c] = phi_[c] - plo[c];
   return ODW_OK;
 }
 

@@ -22,6 +22,22 @@ from ..jupyter_utils.histogram import Histogram, _radius_bins
 _THIN = 300
 
 
+_ARANGE10 = np.arange(10.0)
+
+
+def _linspace10(start, stop):
+  """numpy.linspace(start, stop, 10), its arithmetic without its argument handling (numpy/_core/function_base.py:
+  arange(num) * ((stop - start) / (num - 1)) + start, the last element = stop): a quarter of the time, the same bits
+  (tests/test_plane_screen.py)"""
+  step = (stop - start) / 9
+  if not (step != 0 and np.isfinite(step)):
+    return np.linspace(start, stop, 10)
+  y = _ARANGE10 * step
+  y += start
+  y[-1] = stop
+  return y
+
+
 class DeviceHits:
 
   def __init__(self, tracer, group=None):
@@ -66,9 +82,48 @@ class DeviceHits:
   def detectPlaneNormal(self, planeNormal=None, xInPlaneVec=None, maxPointCountConsidered=_THIN, angleTol=1e-9):
     cloud, rays = self._sample(maxPointCountConsidered)
     if planeNormal is None:
-      planeNormal = _hits._flattest_direction(cloud, angleTol)
+      planeNormal = self._flattest_direction(cloud, angleTol)
     planeNormal = _hits._against(planeNormal, rays)
     return planeNormal, _hits._in_plane_x(planeNormal, xInPlaneVec)
+
+  def _flattest_direction(self, cloud, angleTol):
+    """the plane search of the host `Hits` class with the screen of every grid run by the library
+    (`odw_plane_screen`, outside the interpreter lock -- in a parameter sweep the measuring threads and the baking
+    thread share that lock, and the search was half of a thread's time under it); candidates within rounding of the
+    smallest extent are evaluated the reference's way, as there: same winner bit for bit"""
+    cloud = np.ascontiguousarray(cloud, dtype=np.float64)
+    if cloud.ndim != 2 or cloud.shape[1] != 3 or not len(cloud):
+      return _hits._flattest_direction(cloud, angleTol)
+    lib = self._tr._lib
+    pd = C.POINTER(C.c_double)
+    cloud_p, n = cloud.ctypes.data_as(pd), C.c_uint64(len(cloud))
+    margin = 1e-12 * max(float(np.abs(cloud).max()), 1e-300)
+    phis, thetas = np.linspace(0, np.pi, 30), np.linspace(-np.pi / 2, np.pi / 2, 30)
+    while True:
+      cell = (phis[1] - phis[0], thetas[1] - thetas[0])
+      rough = np.empty(len(phis) * len(thetas))
+      if lib.odw_plane_screen(cloud_p, n, phis.ctypes.data_as(pd), C.c_int32(len(phis)), thetas.ctypes.data_as(pd),
+                              C.c_int32(len(thetas)), rough.ctypes.data_as(pd)) != 0:
+        return _hits._flattest_direction(cloud, angleTol)
+      near = np.flatnonzero(rough <= rough.min() + margin)
+      if len(near) == 0:                     # (a cloud with a nan: the host routine's business)
+        return _hits._flattest_direction(cloud, angleTol)
+      k = int(near[0])
+      if len(near) > 1:                      # (one candidate clear of the others: the reference's first minimum is that one)
+        cp, sp, ct, st = np.cos(phis), np.sin(phis), np.cos(thetas), np.sin(thetas)
+        best = None
+        for c in near:
+          i, j = divmod(int(c), len(phis))
+          along = np.dot(cloud, np.array([cp[j] * st[i], sp[j] * st[i], ct[i]]))
+          e = along.max() - along.min()
+          if best is None or e < best:
+            best, k = e, int(c)
+      i, j = divmod(k, len(phis))
+      p, t = phis[j], thetas[i]
+      phis = _linspace10(p - 1.1 * cell[0], p + 1.1 * cell[0])
+      thetas = _linspace10(t - 1.1 * cell[1], t + 1.1 * cell[1])
+      if max(phis[1] - phis[0], thetas[1] - thetas[0]) < angleTol:
+        return np.array([np.cos(p) * np.sin(t), np.sin(p) * np.sin(t), np.cos(t)])
 
   def histogram(self, planeNormal=None, xInPlaneVec=None, key='points', origin=None, radius=None,
                 binCoords='cartesian', **kwargs):

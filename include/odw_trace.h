@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ODW_ABI_VERSION 7
+#define ODW_ABI_VERSION 8
 
 /* ---- return codes ------------------------------------------------------ */
 enum {
@@ -463,6 +463,15 @@ int odw_hits_bin(odw_ctx* ctx, int32_t polar, const double* origin, const double
                  const double* edges_b, int32_t n_b, uint64_t* counts);
 /* mean[3] and variance[3] (about the mean) of the selected rows' points     */
 int odw_hits_moments(odw_ctx* ctx, double* mean, double* var);
+/* The screen of the plane search of `Hits.detectPlaneNormal` (jupyter_utils/hits.py:108-137: the direction along
+ * which the thinned cloud has the smallest extent -- a 30 x 30 grid over half the unit sphere, then 10 x 10 grids
+ * around the best candidate): for cloud[n][3] and one grid, extent[i * n_phi + j] = max - min of point . normal with
+ * normal = (cos phi_j sin theta_i, sin phi_j sin theta_i, cos theta_i), the reference's candidate order.  The
+ * reference takes the first minimum of extents summed in numpy's order; the caller therefore evaluates the
+ * candidates within rounding of the smallest screened extent again with numpy and decides there.  No context, no
+ * device work; thread-safe (the measuring threads of a parameter sweep call it without the interpreter lock).   */
+int odw_plane_screen(const double* cloud, uint64_t n, const double* phis, int32_t n_phi, const double* thetas, int32_t n_theta,
+                     double* extent);
 
 /* scene-compiled kernels -------------------------------------------------------
  * The reference prepares a scene once per run and reuses it for every ray
