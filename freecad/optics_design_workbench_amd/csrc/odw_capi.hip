@@ -112,6 +112,8 @@ struct odw_ctx {
   uint64_t ph_n = 0, ph_n_entering = 0;
   int ph_group = -1;
   bool ph_valid = false, ph_projected = false, ph_entering_built = false;
+  std::vector<double> ph_moment_sums;      // per-block moment sums + centre of the current selection's points (odw_hits_project, odw_hits_moments)
+  unsigned ph_moment_grid = 0;             // 0: none
   // stochastic surfaces: one table set per sampler, descriptor block, (group, kind) -> index
   struct SurfaceBufs { DevBuf phi_tab, t_tab, t_guide, atom_mass; };
   std::vector<SurfaceBufs> surf_bufs;

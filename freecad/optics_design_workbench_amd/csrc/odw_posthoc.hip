@@ -145,12 +145,39 @@ __global__ void ph_columns_kernel(const odw_hit* __restrict__ hits, const uint32
 
 // numpy.dot(points, axis): three products, summed left to right, no contraction; per block the extrema of
 // both coordinates (part[4 b ..]: min X, max X, min Y, max Y)
+// sums of d and d^2, d = point - the first selected row's point (a provisional centre inside the cloud: the
+// variance is E[d^2] - E[d]^2 without the cancellation of raw second moments): one row's share, and a block's sums
+// written out -- shared by ph_moment_kernel and by ph_project_kernel, which reads the same points anyway (same grid,
+// same order of additions: the same bits from either)
+__device__ __forceinline__ void ph_moment_add(double (&s)[6], double px, double py, double pz, double cx, double cy, double cz) {
+  const double dx = px - cx, dy = py - cy, dz = pz - cz;
+  s[0] += dx; s[1] += dy; s[2] += dz;
+  s[3] += dx * dx; s[4] += dy * dy; s[5] += dz * dz;
+}
+__device__ __forceinline__ void ph_moment_write(double (&s)[6], double cx, double cy, double cz, double* __restrict__ part) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) s[k] += __shfl_xor(s[k], off);
+  __shared__ double sh[4][6];
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0)
+    for (int k = 0; k < 6; ++k) sh[w][k] = s[k];
+  __syncthreads();
+  if (threadIdx.x < 6) part[6 * blockIdx.x + threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+  if (blockIdx.x == 0 && threadIdx.x == 6) { part[6 * gridDim.x] = cx; part[6 * gridDim.x + 1] = cy; part[6 * gridDim.x + 2] = cz; }
+}
+
+// part: [gridDim.x][4] extrema of X, Y | (key 0: the points' moment sums) [gridDim.x][6] + the centre [3]
 __global__ __launch_bounds__(256) void ph_project_kernel(const odw_hit* __restrict__ hits, const uint32_t* __restrict__ sel,
                                                          uint64_t m, int key, double ex0, double ex1, double ex2, double ey0,
                                                          double ey1, double ey2, double* __restrict__ X,
                                                          double* __restrict__ Y, double* __restrict__ part) {
 #pragma clang fp contract(off)
   double lo_x = INFINITY, hi_x = -INFINITY, lo_y = INFINITY, hi_y = -INFINITY;
+  const double* c0 = hits[sel[0]].point;
+  const double cx = c0[0], cy = c0[1], cz = c0[2];
+  double mom[6] = {0, 0, 0, 0, 0, 0};
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
     const double* p = key ? hits[sel[j]].direction : hits[sel[j]].point;
@@ -160,7 +187,9 @@ __global__ __launch_bounds__(256) void ph_project_kernel(const odw_hit* __restri
     Y[j] = y;
     lo_x = fmin(lo_x, x); hi_x = fmax(hi_x, x);
     lo_y = fmin(lo_y, y); hi_y = fmax(hi_y, y);
+    if (key == 0) ph_moment_add(mom, a, b, c, cx, cy, cz);
   }
+  if (key == 0) ph_moment_write(mom, cx, cy, cz, part + 4 * (size_t)gridDim.x);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     lo_x = fmin(lo_x, __shfl_xor(lo_x, off)); hi_x = fmax(hi_x, __shfl_xor(hi_x, off));
@@ -358,31 +387,18 @@ __global__ __launch_bounds__(256) void ph_bin_kernel(const double* __restrict__ 
   }
 }
 
-// sums of d and d^2, d = point - the first selected row's point (a provisional centre inside the cloud: the
-// variance is E[d^2] - E[d]^2 without the cancellation of raw second moments), one pass over the rows
-__global__ void ph_moment_kernel(const odw_hit* __restrict__ hits, const uint32_t* __restrict__ sel, uint64_t m,
-                                 double* __restrict__ part) {
+// the moment sums by themselves (ph_moment_add / ph_moment_write above), one pass over the rows
+__global__ __launch_bounds__(256) void ph_moment_kernel(const odw_hit* __restrict__ hits, const uint32_t* __restrict__ sel, uint64_t m,
+                                                        double* __restrict__ part) {
   const double* c = hits[sel[0]].point;
   const double cx = c[0], cy = c[1], cz = c[2];
   double s[6] = {0, 0, 0, 0, 0, 0};
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
     const double* p = hits[sel[j]].point;
-    const double dx = p[0] - cx, dy = p[1] - cy, dz = p[2] - cz;
-    s[0] += dx; s[1] += dy; s[2] += dz;
-    s[3] += dx * dx; s[4] += dy * dy; s[5] += dz * dz;
+    ph_moment_add(s, p[0], p[1], p[2], cx, cy, cz);
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1)
-#pragma unroll
-    for (int k = 0; k < 6; ++k) s[k] += __shfl_xor(s[k], off);
-  __shared__ double sh[4][6];
-  const int w = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0)
-    for (int k = 0; k < 6; ++k) sh[w][k] = s[k];
-  __syncthreads();
-  if (threadIdx.x < 6) part[6 * blockIdx.x + threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
-  if (blockIdx.x == 0 && threadIdx.x == 6) { part[6 * gridDim.x] = cx; part[6 * gridDim.x + 1] = cy; part[6 * gridDim.x + 2] = cz; }
+  ph_moment_write(s, cx, cy, cz, part);
 }
 
 int ph_need_selection(odw_ctx* ctx, const char* who) {
@@ -538,6 +554,7 @@ int odw_load_hits(odw_ctx* ctx, const odw_hit* rows, uint64_t n) {
 int odw_hits_select(odw_ctx* ctx, int32_t group, uint64_t* n_rows, uint64_t* n_leaving) {
   if (!ctx || !n_rows) return fail(ctx, ODW_ERR_INVALID, "odw_hits_select: bad argument");
   ctx->ph_valid = ctx->ph_projected = false;
+  ctx->ph_moment_grid = 0;           // (the moment sums belong to a selection)
   uint64_t used = 0, have = 0;
   int rc = hit_slots_used(ctx, &used, &have);
   if (rc) return rc;
@@ -731,14 +748,20 @@ int odw_hits_project(odw_ctx* ctx, int32_t key, const double* ex, const double* 
   if ((rc = ensure(ctx, ctx->ph_x, m * sizeof(double)))) return rc;
   if ((rc = ensure(ctx, ctx->ph_y, m * sizeof(double)))) return rc;
   const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((m + 255) / 256, (uint64_t)ctx->n_cu * 8));
-  if ((rc = ensure(ctx, ctx->ph_part, (size_t)grid * 4 * sizeof(double)))) return rc;
+  // (the projection of the points reads what the moments need: their sums ride along, odw_hits_moments finds them)
+  const size_t n_part = (size_t)grid * 4 + (key == 0 ? (size_t)grid * 6 + 3 : 0);
+  if ((rc = ensure(ctx, ctx->ph_part, n_part * sizeof(double)))) return rc;
   hipLaunchKernelGGL(ph_project_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const odw_hit*)ctx->hits.p,
                      (const uint32_t*)ctx->sort_vals[1].p, m, (int)key, ex[0], ex[1], ex[2], ey[0], ey[1], ey[2],
                      (double*)ctx->ph_x.p, (double*)ctx->ph_y.p, (double*)ctx->ph_part.p);
   HIPCHK(ctx, hipGetLastError());
-  std::vector<double> part((size_t)grid * 4);
+  std::vector<double> part(n_part);
   HIPCHK(ctx, hipMemcpyAsync(part.data(), ctx->ph_part.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (key == 0) {
+    ctx->ph_moment_sums.assign(part.begin() + (size_t)grid * 4, part.end());
+    ctx->ph_moment_grid = grid;
+  }
   double ext[4] = {INFINITY, -INFINITY, INFINITY, -INFINITY};
   for (unsigned b = 0; b < grid; ++b) {
     ext[0] = std::fmin(ext[0], part[4 * b]); ext[1] = std::fmax(ext[1], part[4 * b + 1]);
@@ -852,13 +875,20 @@ int odw_hits_moments(odw_ctx* ctx, double* mean, double* var) {
   const uint64_t m = ctx->ph_n;
   if (m == 0) return fail(ctx, ODW_ERR_INVALID, "odw_hits_moments: no rows selected");
   const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((m + 255) / 256, (uint64_t)ctx->n_cu * 8));
-  if ((rc = ensure(ctx, ctx->ph_part, ((size_t)grid * 6 + 3) * sizeof(double)))) return rc;
-  std::vector<double> part((size_t)grid * 6 + 3);
-  hipLaunchKernelGGL(ph_moment_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const odw_hit*)ctx->hits.p,
-                     (const uint32_t*)ctx->sort_vals[1].p, m, (double*)ctx->ph_part.p);
-  HIPCHK(ctx, hipGetLastError());
-  HIPCHK(ctx, hipMemcpyAsync(part.data(), ctx->ph_part.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  std::vector<double> part;
+  if (ctx->ph_moment_grid == grid && ctx->ph_moment_sums.size() == (size_t)grid * 6 + 3) {
+    part = ctx->ph_moment_sums;          // a projection of this selection's points has added them up already
+  } else {
+    if ((rc = ensure(ctx, ctx->ph_part, ((size_t)grid * 6 + 3) * sizeof(double)))) return rc;
+    part.resize((size_t)grid * 6 + 3);
+    hipLaunchKernelGGL(ph_moment_kernel, dim3(grid), dim3(256), 0, ctx->stream, (const odw_hit*)ctx->hits.p,
+                       (const uint32_t*)ctx->sort_vals[1].p, m, (double*)ctx->ph_part.p);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(part.data(), ctx->ph_part.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->ph_moment_sums = part;
+    ctx->ph_moment_grid = grid;
+  }
   double s6[6] = {0, 0, 0, 0, 0, 0};
   for (unsigned b = 0; b < grid; ++b)
     for (int k = 0; k < 6; ++k) s6[k] += part[6 * (size_t)b + k];

@@ -16,7 +16,9 @@ into every rank with ONE collective at the end (each rank contributes its own
 entries, zeros elsewhere).  Rays are addressed by the global Philox index, so a
 value's result does not depend on which GPU ran it.
 """
+import os
 import sys
+import time
 
 import numpy as np
 
@@ -131,6 +133,8 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
   # the main thread bakes and traces the next value on a free one.  Each context has its own stream and hit list;
   # the compiled kernel is shared through the process cache.  Only for device tracers measured in HBM.
   lanes = [tr]
+  if os.environ.get('ODW_SWEEP_PIPELINE') == '0':        # (diagnostics: every kernel of a sweep by itself in a trace)
+    pipeline = False
   if pipeline and deviceHits and isinstance(tr, Tracer) and len(mine) > 1:
     # (two measuring threads by default: the measure is partly host work under the GIL, partly waits for the GPU --
     #  one thread read 243 - 338 ms per 64 x 1e7 sweep from run to run, two 248 - 273, three 247 - 264)
@@ -178,8 +182,6 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
       m = float(measures[name](hits)) if len(hits) else np.nan
       table[k, j] = (0.0, 2.0) if np.isnan(m) else (m, 1.0)
 
-  import os
-  import time
   clock = dict(wait=0.0, bake=0.0, trace=0.0, measure=0.0) if os.environ.get('ODW_SWEEP_TIMING') else None
   try:
     for turn, k in enumerate(mine):

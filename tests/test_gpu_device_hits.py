@@ -103,6 +103,12 @@ def test_device_histogram_equals_host_hits_on_traced_rows(tracer):
         assert np.abs(H.hist - G.hist).sum() <= 2             # a hit within an ulp of an edge may change sides
       assert dh.rmsSpot() == pytest.approx(sweep.rmsSpot(host), rel=1e-9)
       assert sweep.calcFwhm(dh) == pytest.approx(sweep.calcFwhm(host), rel=1e-6, nan_ok=True)
+      # (the moment sums above rode along with the projection of the points; a new selection adds them up by
+      #  themselves: the same bits)
+      cached = dh.moments()
+      dh = tracer.deviceHits(group)
+      alone = dh.moments()
+      assert np.array_equal(cached[0], alone[0]) and np.array_equal(cached[1], alone[1])
       tracer.hits()                                          # a fetch ends the selection ...
       with pytest.raises(Exception):
         dh.histogram(bins=10)                                # ... and the object says so
