@@ -72,11 +72,28 @@ def _flattest_direction(cloud, angleTol):
       return np.array([np.cos(P[k]) * np.sin(T[k]), np.sin(P[k]) * np.sin(T[k]), np.cos(T[k])])
 
 
+def _signed_quantile(a, q):
+  """a number with the sign of numpy.quantile(a, q) -- all `_against` looks at: the quantile interpolates between two
+  neighbours of the sorted values, so where the values around that position lie on one side of zero (the usual
+  case) one of them will do (numpy.quantile costs 40 us a call, three calls per plane search); where they straddle
+  zero, numpy.quantile itself"""
+  n = len(a)
+  if n >= 4:
+    s = np.sort(a)
+    v = q * (n - 1)
+    below, above = s[max(int(v) - 1, 0)], s[min(int(v) + 2, n - 1)]
+    if below > 0:
+      return below
+    if above < 0:
+      return above
+  return np.quantile(a, q)
+
+
 def _against(normal, rays):
   """the normal or its opposite, whichever the rays run against: clear if 90 % of them agree,
   else by the median, with a warning"""
   along = rays @ normal
-  lo, mid, hi = np.quantile(along, 0.1), np.quantile(along, 0.5), np.quantile(along, 0.9)
+  lo, mid, hi = _signed_quantile(along, 0.1), _signed_quantile(along, 0.5), _signed_quantile(along, 0.9)
   if lo > 0:
     return -normal
   if hi < 0:

@@ -443,8 +443,11 @@ def face_local_bounds(kind, params, face):
   return lo, hi
 
 
+_CORNER_IS_HI = np.array([[x, y, z] for x in (False, True) for y in (False, True) for z in (False, True)])
+
+
 def world_aabb(to_world, lo, hi):
-  corners = np.array([[x, y, z] for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])])
+  corners = np.where(_CORNER_IS_HI, hi, lo)                # the eight corners, x slowest
   w = corners @ to_world.m[:3, :3].T + to_world.m[:3, 3]
   return w.min(axis=0), w.max(axis=0)
 
@@ -453,17 +456,27 @@ def _prune_faces(prims, slack=1e-3):
   """drop faces that can never satisfy a must-be-inside condition (their
   bounding box misses the other operand's): an optimisation only, the trim
   test would reject every candidate on them anyway"""
+  boxes = {}                                               # world boxes of the operands, each worked out once
+
+  def box_of(p):
+    b = boxes.get(id(p))
+    if b is None:
+      b = boxes[id(p)] = world_aabb(p.to_world, *local_bounds(p.kind, p.params))
+    return b
+
   for fp in prims:
+    must_be_in = [other for other, inside in fp.conds if inside]
+    if not must_be_in:                                     # (nothing to miss: every face it has stays)
+      fp.facemask &= (1 << N_FACES[fp.kind]) - 1
+      continue
     mask = 0
     for f in range(N_FACES[fp.kind]):
       if not (fp.facemask >> f) & 1:
         continue
       flo, fhi = world_aabb(fp.to_world, *face_local_bounds(fp.kind, fp.params, f))
       keep = True
-      for other, inside in fp.conds:
-        if not inside:
-          continue
-        olo, ohi = world_aabb(other.to_world, *local_bounds(other.kind, other.params))
+      for other in must_be_in:
+        olo, ohi = box_of(other)
         if np.any(flo > ohi + slack) or np.any(fhi < olo - slack):
           keep = False
           break
