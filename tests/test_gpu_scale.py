@@ -105,6 +105,26 @@ def test_c2_minimal_ten_million(tracer, oracle):
   assert np.abs(h['point'][:, 2] - 15.0).max() < 1e-12
 
 
+def test_more_rays_than_32_bits_in_one_launch(tracer):
+  """maximum sizes: one launch of 2^32 + 54321 rays (histogram only: the rows of such a launch would be 275 GB) --
+  every ray traced and binned, and the same histogram and counters as the same index range in two launches split
+  at 2^32 (ray indices, chunk arithmetic and counters are 64-bit throughout; a ray depends on its index only)"""
+  n = (1 << 32) + 54321
+  setup(tracer, 'minimal', nx=128)
+  tracer.trace(7, n, SEED, record_hits=False)
+  tracer.sync()
+  c = tracer.counters()
+  assert c['traced_rays'] == n and c['recorded_hits'] == n and c['segments'] == n and c['hits_dropped'] == 0
+  one = tracer.histogram().copy()
+  assert int(one.sum()) + c['hist_overflow'] == n
+  tracer.reset()
+  tracer.trace(7, 1 << 32, SEED, record_hits=False)
+  tracer.trace(7 + (1 << 32), 54321, SEED, record_hits=False)
+  tracer.sync()
+  assert tracer.counters() == c
+  assert np.array_equal(tracer.histogram(), one)
+
+
 def test_c4_huge_array_statistics(tracer, oracle):
   """BASELINE configs[3] scene on one GPU: chaotic, so statistics only:
   hit fraction and mean segment count agree with the oracle within 3 sigma"""
