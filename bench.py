@@ -144,12 +144,14 @@ def pmc_figures(cfg_name, n_per, record_hits, kernel):
 
 
 class ClockSampler:
-  """Shader clock and package power of this rank's GPU while the timed steps run, read from the amdgpu hwmon files an
-  ordinary user may read (freq1_input in Hz, power1_input in microwatt) by a thread that wakes every 10 ms -- the
-  timing thread sits in a ctypes call without the GIL meanwhile.  The boxes of this pool share hosts (eight GPUs,
-  one power and cooling budget): the same binary reads 10.9 - 11.5 ms per C3 step from box to box, and this is the
-  one cause that can be seen from inside: `roofline.frac` assumes the 2400 MHz maximum, `frac_at_sampled_clock` the
-  clock the chip actually ran at.  Silent (None) where the files are absent or unreadable."""
+  """Shader clock and package power of this rank's GPU as the amdgpu hwmon files report them while the timed steps
+  run (freq1_input in Hz, power1_input in microwatt: what an ordinary user may read), sampled by a thread that wakes
+  every 10 ms -- the timing thread sits in a ctypes call without the GIL meanwhile.  Context for the reader, not a
+  measurement of the kernel's clock: the driver's figure is smoothed over a time longer than a 0.2 s timed region
+  (one box read 1888 -> 2120 MHz over six consecutive runs whose steps all took 10.9 ms; another 2370 MHz from the
+  first run on), so nothing is derived from it -- `roofline.frac` stays quoted against the 2400 MHz maximum.  The boxes
+  of this pool share hosts (eight GPUs, one power and cooling budget); the same binary reads 10.9 - 11.5 ms per C3
+  step from box to box.  Silent (None) where the files are absent or unreadable."""
 
   def __init__(self, torch, index):
     import glob
@@ -207,17 +209,11 @@ class ClockSampler:
     if not clk:
       return None
     out = {'sclk_mhz_mean': sum(clk) / len(clk), 'sclk_mhz_min': min(clk), 'sclk_mhz_max': max(clk), 'samples': len(clk),
-           'peak_mhz': CLOCK_GHZ * 1e3, 'source': 'amdgpu hwmon freq1_input / power1_input, every 10 ms during the timed steps'}
+           'peak_mhz': CLOCK_GHZ * 1e3, 'source': 'amdgpu hwmon freq1_input / power1_input, every 10 ms during the timed steps',
+           'note': 'smoothed by the driver over more than the timed region: context only, nothing is derived from it'}
     if pw:
       out.update(power_w_mean=sum(pw) / len(pw), power_w_max=max(pw))
     return out
-
-
-def with_sampled_clock(roofline, clock):
-  """the calibrated issue fraction at the clock the chip ran at (the peak of `frac` is quoted at 2400 MHz)"""
-  if roofline and clock and roofline.get('frac') and clock.get('sclk_mhz_mean'):
-    roofline['frac_at_sampled_clock'] = roofline['frac'] * clock['peak_mhz'] / clock['sclk_mhz_mean']
-  return roofline
 
 
 def roofline_block(kernel_name, avg_kernel_s, rays_per_launch, bytes_per_ray, pmc, note=None):
@@ -355,7 +351,7 @@ def run_trace_config(args, cfg_name, cfg, rank, local_rank, world, dist, torch):
                                       'note': 'hiprtc compile of the ray loop against the scene, before the timed region',
                                       **({'error': compiled['error']} if 'error' in compiled else {})},
                    'parallelism': f'ray-index sharding x{world}, one RCCL reduce'},
-        'roofline': with_sampled_clock(roofline_block(kernel_name, avg_kernel_s, n_per, bytes_per_ray, pmc), clock),
+        'roofline': roofline_block(kernel_name, avg_kernel_s, n_per, bytes_per_ray, pmc),
     }
     if clock:
       out['clock'] = clock
@@ -480,9 +476,9 @@ def run_sweep_config(args, cfg, rank, local_rank, world, dist, torch):
                                               'flat near the focus; the rms spot radius below stays defined',
                                  'rms_spot_mm': [float(v) for v in res.columns['rms']],
                                  'best_radius_by_rms_mm': rms_r, 'best_rms_spot_mm': rms_v}},
-        'roofline': with_sampled_clock(roofline_block(kernel_name, avg_kernel_s, n_per, bytes_per_ray, pmc,
+        'roofline': roofline_block(kernel_name, avg_kernel_s, n_per, bytes_per_ray, pmc,
                                    note='launches of rank 0; a launch = one radius; per step the host also re-bakes the scene and '
-                                        'searches the detector plane per radius'), clock),
+                                        'searches the detector plane per radius'),
     }
     if clock:
       out['clock'] = clock

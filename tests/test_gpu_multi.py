@@ -170,11 +170,10 @@ def test_default_bench_line_carries_the_three_gpu_configs(native_lib):
       assert r.get(key) is None or 0 <= r[key] < 1.5, (name, key, r[key])
     assert r.get('hbm_counter_frac') is None or r['hbm_counter_frac'] < 1
     assert r.get('fp64_flops_frac') is None or r['fp64_flops_frac'] < 1
-    # where the box lets the clock be read: the fraction at the clock the chip ran at is no fraction above 1 either
+    # where the box lets the clock be read: a plausible reading (the driver smooths it: context, nothing derived from it)
     clock = line.get('clock')
     if clock:
-      assert 300 < clock['sclk_mhz_min'] <= clock['sclk_mhz_mean'] <= clock['sclk_mhz_max'] <= 1.02 * clock['peak_mhz'], clock
-      assert r['frac'] <= r['frac_at_sampled_clock'] * 1.02 and r['frac_at_sampled_clock'] <= 1.0, (name, r)
+      assert 50 < clock['sclk_mhz_min'] <= clock['sclk_mhz_mean'] <= clock['sclk_mhz_max'] <= 1.05 * clock['peak_mhz'], clock
   assert lines['c4']['value'] > 3e9 and lines['c4']['roofline']['valu']['active_lanes_per_inst'] > 25
   assert lines['c5']['value'] > 5e8 and lines['c5']['steps'] == 2
 
