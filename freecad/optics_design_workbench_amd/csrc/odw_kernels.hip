@@ -1664,15 +1664,17 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
   }
   // counters: wave reduction, then one atomic per BLOCK and counter (one per wave put 4e4 memory-side atomics on
   // eight addresses at the end of every launch: 0.07 ms of a 1e7-ray launch's 1.2)
-  __shared__ uint32_t cnt_wave[4][ODW_CNT_LDS];
+  // (a wave's sums go into the first column of its own quarter of the counter table: no LDS beyond what the kernel
+  //  has -- the BVH kernels' node stacks + this table fill the CU's 160 KB exactly at four blocks)
 #pragma unroll
   for (int k = 0; k < ODW_CNT_LDS; ++k) {
     const uint32_t s = wave_sum(cnt_lds[k * 256 + threadIdx.x]);
-    if (__lane_id() == 0) cnt_wave[threadIdx.x >> 6][k] = s;
+    if (__lane_id() == 0) cnt_lds[k * 256 + (threadIdx.x & ~63u)] = s;
   }
   __syncthreads();
   if (threadIdx.x < ODW_CNT_LDS) {
-    const uint32_t s = cnt_wave[0][threadIdx.x] + cnt_wave[1][threadIdx.x] + cnt_wave[2][threadIdx.x] + cnt_wave[3][threadIdx.x];
+    const uint32_t* col = cnt_lds + threadIdx.x * 256;
+    const uint32_t s = col[0] + col[64] + col[128] + col[192];
     if (s) atomicAdd(P.out.counters + threadIdx.x, (unsigned long long)s);
   }
 }
