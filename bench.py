@@ -254,6 +254,58 @@ def roofline_block(kernel_name, avg_kernel_s, rays_per_launch, bytes_per_ray, pm
   return r
 
 
+def summary_scalars(name, line):
+  """what one nested config line says, as flat numbers: value, ms per step, the roofline fraction of its kernel,
+  lanes per vector instruction (grid kernel), the sweep's answer"""
+  if 'error' in line or 'value' not in line:
+    return {f'{name}_error': line.get('error', 'no line')}
+  rf = line.get('roofline') or {}
+  out = {f'{name}_value': line['value'], f'{name}_unit': line['unit'], f'{name}_ms_per_step': line['ms_per_step'],
+         f'{name}_steps': line['steps'], f'{name}_roofline_frac': rf.get('frac'), f'{name}_avg_kernel_ms': rf.get('avg_kernel_ms'),
+         f'{name}_kernel': rf.get('kernel')}
+  lanes = (rf.get('valu') or {}).get('active_lanes_per_inst')
+  if lanes is not None:
+    out[f'{name}_active_lanes_per_inst'] = lanes
+  spot = (line.get('config') or {}).get('spot_size') or {}
+  for k in ('best_radius_mm', 'best_fwhm_mm', 'best_radius_by_rms_mm', 'best_radius_by_fwhm_1e3_mm', 'fwhm_1e3_at_best_mm'):
+    if k in spot:
+      out[f'{name}_{k}'] = spot[k]
+  return out
+
+
+def compact(line, nested=False):
+  """the stdout line: every number of the record, without the long explanatory blocks (they are in the detail
+  record): per-class instruction tables, notes, per-radius tables of nested lines"""
+  import copy
+  out = copy.deepcopy(line)
+  rf = out.get('roofline')
+  if isinstance(rf, dict):
+    for k in ('wavefront_equivalent_note', 'traffic_source'):
+      rf.pop(k, None)
+    v = rf.get('valu')
+    if isinstance(v, dict):
+      rf['valu'] = {k: v[k] for k in ('insts_per_launch', 'cyc_per_inst_calibrated', 'active_lanes_per_inst', 'wait_any_frac',
+                                      'lds_bank_conflict_frac', 'kernel_ms_profiled', 'source') if k in v}
+  if isinstance(out.get('clock'), dict):
+    out['clock'] = {k: v for k, v in out['clock'].items() if k not in ('source', 'note')}
+  if isinstance(out.get('end_to_end'), dict):
+    out['end_to_end'].pop('note', None)
+  cfg = out.get('config')
+  if isinstance(cfg, dict):
+    if isinstance(cfg.get('scene_compiled'), dict):
+      cfg['scene_compiled'].pop('note', None)
+    spot = cfg.get('spot_size')
+    if isinstance(spot, dict):
+      for k in ('fwhm_note', 'fwhm_1e3_note'):
+        spot.pop(k, None)
+      if nested:
+        for k in ('radii', 'fwhm_mm', 'rms_spot_mm', 'fwhm_1e3_mm'):
+          spot.pop(k, None)
+  if isinstance(out.get('extra_configs'), dict):
+    out['extra_configs'] = {k: compact(v, nested=True) for k, v in out['extra_configs'].items()}
+  return out
+
+
 def run_trace_config(args, cfg_name, cfg, rank, local_rank, world, dist, torch):
   from freecad.optics_design_workbench_amd import scenes
   from freecad.optics_design_workbench_amd.simulation import parallel
@@ -329,7 +381,12 @@ def run_trace_config(args, cfg_name, cfg, rank, local_rank, world, dist, torch):
     total_rays = n_per * args.steps * world
     assert cnt['traced_rays'] == total_rays, (cnt, total_rays)
     assert cnt['hits_dropped'] == 0, cnt
-    hist_total = int(tr.histogram().sum())
+    hist = tr.histogram()
+    hist_total = int(hist.sum())
+    if args.dump_results:      # (tests: the reduced histogram and counters of the whole job, to compare with the shards' sum)
+      import numpy as np
+      np.savez(args.dump_results, hist=hist, counters=np.array([cnt[k] for k in sorted(cnt)], dtype=np.int64),
+               names=np.array(sorted(cnt)))
     assert args.no_histogram or hist_total + cnt['hist_overflow'] == cnt['recorded_hits'], (hist_total, cnt)
     kbar = cnt['segments'] / cnt['traced_rays']
     hbar = cnt['recorded_hits'] / cnt['traced_rays']
@@ -504,6 +561,7 @@ def main():
   ap.add_argument('--no-end-to-end', action='store_true')
   ap.add_argument('--no-hits', action='store_true', help='histogram only (diagnostic, not the metric)')
   ap.add_argument('--no-histogram', action='store_true', help='hit rows only (diagnostic, not the metric)')
+  ap.add_argument('--dump-results', default=None, help='c3 / c4: rank 0 writes the job\'s histogram and counters (after the reduce) to this .npz')
   ap.add_argument('--no-extra', action='store_true',
                   help='c3 only: leave out the c4 (3 steps) and c5 (2 sweeps) lines nested under "extra_configs"')
   args = ap.parse_args()
@@ -562,8 +620,21 @@ def main():
         extra[name] = line
     if rank == 0:
       out['extra_configs'] = extra
+      # the same figures as plain numbers where a reader that keeps only the scalars of `config` still finds them
+      for name, line in extra.items():
+        out['config'].update(summary_scalars(name, line))
   if rank == 0:
-    print(json.dumps(out), flush=True)
+    detail = json.dumps(out)
+    # the full record (instruction mixes, per-radius tables) goes to stderr and, where the folder exists, to
+    # gpurun_out/bench_detail.json; stdout carries ONE compact line
+    sys.stderr.write('[bench detail] ' + detail + '\n')
+    try:
+      if os.path.isdir(os.path.join(ROOT, 'gpurun_out')):
+        with open(os.path.join(ROOT, 'gpurun_out', 'bench_detail.json'), 'w') as f:
+          f.write(detail + '\n')
+    except OSError:
+      pass
+    print(json.dumps(compact(out)), flush=True)
   if dist is not None:
     dist.barrier()
     dist.destroy_process_group()

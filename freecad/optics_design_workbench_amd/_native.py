@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(CSRC, 'libodw_trace.so')
 _SOURCES = ['odw_capi.hip', 'odw_kernels.hip', 'odw_grid.hip', 'odw_mesh.hip', 'odw_posthoc.hip', 'odw_spec.hip', 'odw_device.h']
 _HEADER = os.path.normpath(os.path.join(_HERE, '..', '..', 'include', 'odw_trace.h'))
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 CNT_NAMES = ['traced_rays', 'recorded_hits', 'segments', 'escaped', 'died', 'capped',
              'hist_overflow', 'hits_dropped', 'grating_in_medium']
 TRACE_RECORD_HITS, TRACE_HISTOGRAM, TRACE_RECORD_SEGMENTS = 1, 2, 4
@@ -34,7 +34,7 @@ SYMBOLS = ['odw_abi_version', 'odw_create', 'odw_destroy', 'odw_last_error', 'od
            'odw_upload_source', 'odw_upload_surface_source', 'odw_generate_rays', 'odw_upload_surface_samplers', 'odw_set_surface_seed', 'odw_set_wavelength', 'odw_set_limits', 'odw_set_detector', 'odw_reserve_hits', 'odw_reserve_segments', 'odw_trace',
            'odw_trace_rays', 'odw_sync', 'odw_reset_results', 'odw_reset_hits', 'odw_fetch_counters', 'odw_hit_count',
            'odw_fetch_hits', 'odw_fetch_histogram', 'odw_segment_count', 'odw_fetch_segments', 'odw_reset_segments', 'odw_sample', 'odw_device_histogram',
-           'odw_device_counters', 'odw_stream', 'odw_timing_enable', 'odw_timing_read',
+           'odw_device_counters', 'odw_device_results', 'odw_stream', 'odw_timing_enable', 'odw_timing_read',
            'odw_swap_hit_lists', 'odw_fetch_swapped_hits', 'odw_release_swapped_hits', 'odw_host_alloc', 'odw_host_free', 'odw_load_hits', 'odw_hits_select', 'odw_hits_gather', 'odw_hits_project', 'odw_hits_range', 'odw_hits_bin', 'odw_hits_moments', 'odw_plane_screen',
            'odw_compile_scene', 'odw_compiled_info', 'odw_compile_check', 'odw_hits_columns']
 

@@ -98,7 +98,10 @@ struct odw_ctx {
   DevBuf phi_tab, t_tab, t_guide, phi_guide, d_source, d_det;
   DeviceSource h_source;
   DeviceDetector h_det;
-  DevBuf hits, hit_count, hist, counters, chunk_counter;
+  DevBuf hits, hit_count, chunk_counter;
+  // ONE block holds what ranks sum: [kResultsHead words: the ODW_CNT_COUNT counters, padded] [n_bins histogram words]
+  // -- a multi-GPU job reduces it with a single collective (odw_device_results); `counters` and `hist` are views into it
+  DevBuf results, hist, counters;
   DevBuf segs, seg_count;                  // RecordRays segment list
   uint64_t seg_capacity = 0;
   DevBuf ray_o, ray_d, ray_p, ray_aos, samp_t, samp_phi;
@@ -126,6 +129,20 @@ struct odw_ctx {
   bool emitter_active = false;   // the most recently uploaded source is a surface source
   uint64_t hit_capacity = 0, n_bins = 0;   // hit_capacity: rows the caller asked for
   uint64_t hit_slots = 0;                  // rows allocated (capacity + slack for block reservations)
+  // batch launches (odw_upload_scene_batch / odw_trace_batch): the value tables of batch_n scenes of one structure side by
+  // side, one segment of the batch's hit list and one pair of counters per scene.  odw_batch_select makes a segment the
+  // context's hit list (ctx->hits / hit_count become views; the context's own list waits in own_*)
+  DevBuf batch_values, batch_hits, batch_hit_count;
+  int batch_n = 0;                         // scenes of the uploaded batch (0: none)
+  bool batch_launch = false;               // launch_trace: this launch is a batch
+  uint64_t batch_stride = 0;               // doubles per scene block
+  uint64_t batch_seg_slots = 0, batch_seg_capacity = 0, batch_rays = 0, batch_first = 0;
+  int batch_traced = 0;                    // scenes of the last odw_trace_batch (segments that hold rows)
+  int batch_selected = -1;
+  std::string batch_spec_text;             // the structure all scenes of the batch share (compiled kernels)
+  hipFunction_t spec_batch_fn = nullptr;   // the scene-compiled kernel's BATCH variant (bound on the first batch launch)
+  DevBuf own_hits, own_hit_count;
+  uint64_t own_capacity = 0, own_slots = 0, own_ray_begin = 0, own_ray_end = 0;
   // second hit list (odw_swap_hit_lists): while one is traced into, the other is copied to the host
   // on a stream of its own
   DevBuf alt_hits, alt_hit_count;
@@ -182,6 +199,12 @@ void release(DevBuf& b) {
   b.p = nullptr;
   b.bytes = 0;
 }
+
+constexpr size_t kResultsHead = 16;      // words in front of the histogram (128 B: the bins keep their alignment)
+static_assert(ODW_CNT_COUNT <= kResultsHead, "counters must fit the head of the results block");
+
+// the results block for a histogram of n_bins bins; the counters survive a reallocation
+int ensure_results(odw_ctx* ctx, uint64_t n_bins);
 
 // ---- primitive bounding boxes in global coordinates -----------------------
 void local_bounds(int type, const double* par, double lo[3], double hi[3]) {
@@ -1200,6 +1223,32 @@ int odw_abi_version(void) { return ODW_ABI_VERSION; }
 
 const char* odw_last_error(const odw_ctx* ctx) { return ctx ? ctx->err.c_str() : g_error.c_str(); }
 
+namespace {
+int ensure_results(odw_ctx* ctx, uint64_t n_bins) {
+  const size_t bins = n_bins > 2 ? (size_t)n_bins : 2;
+  const size_t need = (kResultsHead + bins) * sizeof(uint64_t);
+  if (!ctx->results.p || ctx->results.bytes < need) {
+    DevBuf fresh;
+    HIPCHK(ctx, hipMalloc(&fresh.p, need));
+    fresh.bytes = need;
+    if (ctx->results.p) {            // a launch may still be writing the old block; its counters move over
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      HIPCHK(ctx, hipMemcpyAsync(fresh.p, ctx->results.p, kResultsHead * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      release(ctx->results);
+    } else {
+      HIPCHK(ctx, hipMemsetAsync(fresh.p, 0, kResultsHead * sizeof(uint64_t), ctx->stream));
+    }
+    ctx->results = fresh;
+  }
+  ctx->counters.p = ctx->results.p;
+  ctx->counters.bytes = ODW_CNT_COUNT * sizeof(uint64_t);
+  ctx->hist.p = (uint64_t*)ctx->results.p + kResultsHead;
+  ctx->hist.bytes = ctx->results.bytes - kResultsHead * sizeof(uint64_t);
+  return ODW_OK;
+}
+}  // namespace
+
 int odw_create(int device, odw_ctx** out) {
   if (!out) return fail(nullptr, ODW_ERR_INVALID, "odw_create: null out");
   *out = nullptr;
@@ -1229,13 +1278,12 @@ int odw_create(int device, odw_ctx** out) {
   if (getenv("ODW_GRID_STATS")) {               // diagnostic builds of the grid kernel report here (odw_destroy prints)
     if (ensure(ctx, ctx->dbg, 32 * sizeof(uint64_t)) == ODW_OK) (void)hipMemset(ctx->dbg.p, 0, 32 * sizeof(uint64_t));
   }
-  int rc = ensure(ctx, ctx->counters, ODW_CNT_COUNT * sizeof(uint64_t));
+  int rc = ensure_results(ctx, 0);
   if (!rc) rc = ensure(ctx, ctx->hit_count, 2 * sizeof(uint64_t));
   if (!rc) rc = ensure(ctx, ctx->chunk_counter, sizeof(uint64_t));
   if (!rc) rc = ensure(ctx, ctx->seg_count, sizeof(uint64_t));
-  if (!rc) rc = ensure(ctx, ctx->hist, 16);
   if (rc) { g_error = ctx->err; odw_destroy(ctx); return rc; }
-  (void)hipMemsetAsync(ctx->counters.p, 0, ctx->counters.bytes, ctx->stream);
+  (void)hipMemsetAsync(ctx->results.p, 0, ctx->results.bytes, ctx->stream);
   (void)hipMemsetAsync(ctx->hit_count.p, 0, ctx->hit_count.bytes, ctx->stream);
   (void)hipMemsetAsync(ctx->seg_count.p, 0, ctx->seg_count.bytes, ctx->stream);
   *out = ctx;
@@ -1278,8 +1326,8 @@ void odw_destroy(odw_ctx* ctx) {
   for (auto& ev : ctx->free_events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   DevBuf* all[] = {&ctx->prim_f64, &ctx->prim_hdr, &ctx->prim_i32, &ctx->cond_i32, &ctx->group_f64, &ctx->group_i32,
                    &ctx->group_gdir, &ctx->seq_mask, &ctx->bvh_nodes, &ctx->bvh_prims, &ctx->bvh_leaf, &ctx->bvh_wide,
-                   &ctx->phi_tab, &ctx->t_tab, &ctx->t_guide, &ctx->d_source, &ctx->d_det, &ctx->hits, &ctx->hit_count, &ctx->chunk_counter, &ctx->hist,
-                   &ctx->counters, &ctx->ray_o, &ctx->ray_d, &ctx->ray_p, &ctx->ray_aos, &ctx->samp_t, &ctx->samp_phi,
+                   &ctx->phi_tab, &ctx->t_tab, &ctx->t_guide, &ctx->d_source, &ctx->d_det, &ctx->hits, &ctx->hit_count, &ctx->chunk_counter, &ctx->results,
+                   &ctx->ray_o, &ctx->ray_d, &ctx->ray_p, &ctx->ray_aos, &ctx->samp_t, &ctx->samp_phi,
                    &ctx->sort_keys[0], &ctx->sort_keys[1], &ctx->sort_vals[0], &ctx->sort_vals[1],
                    &ctx->sort_tmp, &ctx->sorted_rows, &ctx->segs, &ctx->seg_count};
   for (DevBuf* b : all) release(*b);
@@ -1836,7 +1884,7 @@ int odw_set_detector(odw_ctx* ctx, const odw_detector_desc* det) {
   d.group = det->group;
   d.enabled = 1;
   ctx->n_bins = (uint64_t)det->nx * (uint64_t)det->ny;
-  int rc = ensure(ctx, ctx->hist, ctx->n_bins * sizeof(uint64_t));
+  int rc = ensure_results(ctx, ctx->n_bins);
   if (rc) return rc;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // a running launch may still read the old block
   if ((rc = upload(ctx, ctx->d_det, &ctx->h_det, sizeof(DeviceDetector)))) return rc;
@@ -2196,6 +2244,14 @@ int odw_sample(odw_ctx* ctx, uint64_t first_ray, uint64_t n_rays, uint64_t seed,
   HIPCHK(ctx, hipMemcpyAsync(theta_out, ctx->samp_t.p, n_rays * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(phi_out, ctx->samp_phi.p, n_rays * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return ODW_OK;
+}
+
+int odw_device_results(odw_ctx* ctx, void** dptr, uint64_t* n_words, uint64_t* hist_offset_words) {
+  if (!ctx || !dptr || !n_words || !hist_offset_words) return fail(ctx, ODW_ERR_INVALID, "odw_device_results: bad argument");
+  *dptr = ctx->results.p;
+  *n_words = kResultsHead + ctx->n_bins;
+  *hist_offset_words = kResultsHead;
   return ODW_OK;
 }
 

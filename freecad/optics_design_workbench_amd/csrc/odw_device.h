@@ -167,6 +167,19 @@ struct DeviceOutputs {
   unsigned long long* seg_count;       // rows wanted so far (may exceed the capacity)
 };
 
+// A batch launch (odw_trace_batch): n_scenes scenes of ONE structure -- the same primitives, trimming lists, groups and
+// optical types, different numbers (a parameter sweep: examples/1-getting-started/optimize-spotsize.ipynb cell 9) --
+// traced by one grid.  The float64 tables of scene s (prim_f64, prim_hdr, group_f64, group_gdir) lie `stride` doubles
+// behind those of scene s - 1; hand-out unit g of the launch belongs to scene g / chunks_per_scene, whose rays are
+// first_ray ... first_ray + rays - 1 exactly as in a launch of that scene alone; its rows go to its own segment of the
+// hit list (hit_capacity slots each, a pair of counters each).  A wave works on one scene at a time.
+struct DeviceBatch {
+  uint64_t rays;                // rays per scene
+  uint64_t stride;              // doubles between the value tables of consecutive scenes
+  uint32_t chunks_per_scene;
+  uint32_t n_scenes;            // 0: not a batch launch
+};
+
 // Kernel argument.  The source and detector blocks live in device memory and
 // are read where they are used (once per ray) through an opaque pointer:
 // passed by value, hipcc hoists every field (and values derived from them)
@@ -190,6 +203,7 @@ struct TraceParams {
   uint32_t flags;
   uint32_t chunk;               // rays per hand-out unit of this launch (a multiple of 64, <= ODW_CHUNK)
   unsigned long long* dbg;      // diagnostic builds only (ODW_GRID_STATS): 16 words, or null
+  DeviceBatch batch;            // flat kernels' BATCH variants only (n_scenes = 0 otherwise)
 };
 
 }  // namespace odw

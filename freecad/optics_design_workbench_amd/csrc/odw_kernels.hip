@@ -1221,6 +1221,14 @@ __device__ __forceinline__ void record_hit(const PT& P, uint64_t ray, int group,
     const uint32_t n_act = __popcll(active);
     const uint32_t rank = __popcll(active & ((1ull << lane) - 1ull));
     uint64_t slot;
+    // a batch launch (flat kernels): the wave's scene (hit_state[3]) has its own segment of the list and its own counters
+    odw_hit* hits = P.out.hits;
+    unsigned long long* hit_count = P.out.hit_count;
+    if (BLOCKS && P.batch.n_scenes) {
+      const uint32_t scene = __builtin_amdgcn_readfirstlane(hit_state[3]);
+      hits += (size_t)scene * P.out.hit_capacity;
+      hit_count += 2 * scene;
+    }
     if (BLOCKS && P.out.hit_block) {
       // One atomic per wave and append serialises 1.5e6 appends of a launch on a single counter at
       // the memory side (1.2 - 3 ms of a 20 ms launch, measured).  A wave therefore takes hit_block
@@ -1230,21 +1238,20 @@ __device__ __forceinline__ void record_hit(const PT& P, uint64_t ray, int group,
       // here, a register copy would go stale in the others
       uint32_t hit_used = hit_state[2];
       if (hit_used + n_act > P.out.hit_block) {
-        next_hit_block(P.out.hits, P.out.hit_capacity, P.out.hit_count, P.out.hit_block, hit_state, hit_used, rank,
-                       lane == leader);
+        next_hit_block(hits, P.out.hit_capacity, hit_count, P.out.hit_block, hit_state, hit_used, rank, lane == leader);
         hit_used = 0;
       }
       slot = (((uint64_t)hit_state[1] << 32) | hit_state[0]) + hit_used + rank;
       if (lane == leader) hit_state[2] = hit_used + n_act;
     } else {
       unsigned long long base = 0;
-      if (lane == leader) base = atomicAdd(P.out.hit_count, (unsigned long long)n_act);
+      if (lane == leader) base = atomicAdd(hit_count, (unsigned long long)n_act);
       const uint32_t blo = __builtin_amdgcn_readfirstlane((uint32_t)base);
       const uint32_t bhi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
       slot = (((uint64_t)bhi << 32) | blo) + rank;
     }
     if (slot < P.out.hit_capacity) {
-      double2* row = reinterpret_cast<double2*>(P.out.hits + slot);
+      double2* row = reinterpret_cast<double2*>(hits + slot);
       const uint64_t tag = (ray & 0xFFFFFFFFFFFFull) | ((uint64_t)group << 48) | ((uint64_t)entering << 63);
       // (streamed once, read back much later if at all: non-temporal stores, +0.6 % on C3)
       typedef double vd2 __attribute__((ext_vector_type(2)));
@@ -1432,6 +1439,35 @@ __device__ __forceinline__ void spec_hits(const TraceParams& P, const SceneView&
 
 // LDS of the hit-list block reservations: exists only where it is used
 // (+ the block's histogram window, see record_hit: header at word 16, counts from word 20)
+// a wave gives up its block of hit-list slots (end of the kernel; BATCH: the wave moves on to another scene): the
+// slots it never filled are tagged unused and counted, the wave's state says "no block"
+__device__ __forceinline__ void close_hit_block(const TraceParams& P, volatile uint32_t* hit_state, uint32_t scene) {
+  if (!P.out.hit_block) {
+    if (P.batch.n_scenes && __lane_id() == 0) hit_state[3] = scene;   // (lists without block reservations: only the scene word matters)
+    return;
+  }
+  odw_hit* hits = P.out.hits;
+  unsigned long long* hit_count = P.out.hit_count;
+  if (P.batch.n_scenes) {
+    const uint32_t cur = __builtin_amdgcn_readfirstlane(hit_state[3]);
+    hits += (size_t)cur * P.out.hit_capacity;
+    hit_count += 2 * cur;
+  }
+  const uint32_t hit_used = hit_state[2];
+  const uint64_t hit_base = ((uint64_t)hit_state[1] << 32) | hit_state[0];
+  if (hit_used < P.out.hit_block) {
+    const uint32_t left = P.out.hit_block - hit_used;
+    for (uint32_t k = __lane_id(); k < left; k += 64)
+      if (hit_base + hit_used + k < P.out.hit_capacity) hits[hit_base + hit_used + k].tag = ODW_TAG_UNUSED;
+    const uint64_t at = hit_base + hit_used;
+    const uint64_t in_buf = at < P.out.hit_capacity ? (P.out.hit_capacity - at < left ? P.out.hit_capacity - at : left) : 0;
+    if (__lane_id() == 0 && in_buf) atomicAdd(hit_count + 1, (unsigned long long)in_buf);
+  }
+  if (__lane_id() == 0) {          // "full": the next append reserves a fresh block (of the new scene's segment)
+    hit_state[0] = 0u; hit_state[1] = 0u; hit_state[2] = P.out.hit_block; hit_state[3] = scene;
+  }
+}
+
 template <bool ON> struct HitBlockState {
   __device__ static __forceinline__ uint32_t* lds() {
     __shared__ uint32_t state[4 * 4 + 4 + ODW_HIST_WIN * ODW_HIST_WIN];
@@ -1457,8 +1493,10 @@ template <> struct HitBlockState<false> {
 #endif
 // LEAN: the scene has no grating group and no finite absorption length (the host checks): their code
 // -- line_grating's chain of IEEE divisions and square roots, exp() -- is left out of the binary
-template <bool BVH, bool STOCH, bool SEG, bool LEAN = false, class SPEC = NoSpec>
+// BATCH (flat kernels): scenes of one structure side by side in one launch (DeviceBatch)
+template <bool BVH, bool STOCH, bool SEG, bool LEAN = false, class SPEC = NoSpec, bool BATCH = false>
 __device__ __forceinline__ void trace_body(const TraceParams& P) {
+  static_assert(!BATCH || (!BVH && !SEG), "batch launches: flat kernels, no segment rows");
   extern __shared__ int bvh_stack[];  // ODW_BVH_STACK x 256 ints (BVH variant only)
   // per-thread event counters live in LDS (one column per thread, ds_add_u32
   // at the event): eight fewer VGPRs across the whole ray loop
@@ -1477,6 +1515,8 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
   ci32 group_i32 = as_const(sc.group_i32);
   cf64 group_gdir = as_const(sc.group_gdir);
   cu64 seq_mask = as_const(sc.seq_mask);
+  // BATCH: the scene the wave's rays belong to, and the scene of the hand-out unit it holds (wave-uniform)
+  uint32_t scene = 0, unit_scene = 0;
   // Persistent waves with ray regeneration.  Rays are handed out in chunks of
   // ODW_CHUNK consecutive indices, taken from a launch-wide atomic counter.  A
   // lane whose ray has terminated takes the next index of its wave's chunk
@@ -1524,11 +1564,39 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
         if (lane == (uint32_t)(__ffsll((unsigned long long)__ballot(1)) - 1)) c = atomicAdd(P.out.chunk_counter, 1ull);
         const uint64_t chunk = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(c >> 32)) << 32) |
                                (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)c);
+        if (BATCH) {
+          // unit g of the launch = unit g % chunks_per_scene of scene g / chunks_per_scene; ray indices are the scene's own
+          const uint32_t g = (uint32_t)chunk, cps = P.batch.chunks_per_scene;
+          if (chunk < (uint64_t)cps * P.batch.n_scenes) {
+            unit_scene = g / cps;
+            next = (uint64_t)(g - unit_scene * cps) * P.chunk;
+            chunk_end = next + P.chunk < P.batch.rays ? next + P.chunk : P.batch.rays;
+          } else {
+            next = chunk_end = 0;                              // the launch has handed out everything
+          }
+        } else {
         next = chunk * (uint64_t)P.chunk;
         if (next > P.n_rays) next = P.n_rays;
         chunk_end = next + P.chunk < P.n_rays ? next + P.chunk : P.n_rays;
+        }
       }
-      const uint64_t avail = next < chunk_end ? chunk_end - next : 0;
+      uint64_t avail = next < chunk_end ? chunk_end - next : 0;
+      if (BATCH && avail && unit_scene != scene) {
+        // the unit belongs to another scene than the rays this wave still traces: they finish first (a wave meets
+        // every scene boundary about once per launch), then the wave closes its block of the old scene's hit-list
+        // segment and moves its table pointers
+        if (idle != ~0ull) {
+          avail = 0;
+        } else {
+          close_hit_block(P, hit_lds + (threadIdx.x >> 6) * 4, scene);
+          scene = unit_scene;
+          const size_t off = (size_t)scene * (size_t)P.batch.stride;
+          sv.prim_f64 = as_const(sc.prim_f64 + off);
+          sv.prim_hdr = as_const(sc.prim_hdr + off);
+          group_f64 = as_const(sc.group_f64 + off);
+          group_gdir = as_const(sc.group_gdir + off);
+        }
+      }
       const uint32_t rank = __popcll(idle & ((1ull << lane) - 1ull));
       const uint32_t want = __popcll(idle);
       const uint32_t take = want < avail ? want : (uint32_t)avail;
@@ -1551,7 +1619,7 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
         alive = true;
       }
       next += take;
-      if (take == 0 && idle == ~0ull) break;               // nothing live, nothing left
+      if (take == 0 && idle == ~0ull) break;               // nothing live, nothing left (BATCH: a waiting unit is taken above once all lanes idle)
     }
     ODW_FTIME(0);
     if (alive) {
@@ -1638,16 +1706,7 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
     for (int k = 0; k < 3; ++k) atomicAdd(P.dbg + 28 + k, (unsigned long long)flat_t[k]);
 #endif
   // slots of the last block this wave never filled
-  const uint32_t hit_used = BVH ? 0u : hit_lds[(threadIdx.x >> 6) * 4 + 2];
-  const uint64_t hit_base = BVH ? 0ull : ((uint64_t)hit_lds[(threadIdx.x >> 6) * 4 + 1] << 32) | hit_lds[(threadIdx.x >> 6) * 4];
-  if (!BVH && P.out.hit_block && hit_used < P.out.hit_block) {
-    const uint32_t left = P.out.hit_block - hit_used;
-    for (uint32_t k = __lane_id(); k < left; k += 64)
-      if (hit_base + hit_used + k < P.out.hit_capacity) P.out.hits[hit_base + hit_used + k].tag = ODW_TAG_UNUSED;
-    const uint64_t at = hit_base + hit_used;
-    const uint64_t in_buf = at < P.out.hit_capacity ? (P.out.hit_capacity - at < left ? P.out.hit_capacity - at : left) : 0;
-    if (__lane_id() == 0 && in_buf) atomicAdd(P.out.hit_count + 1, (unsigned long long)in_buf);
-  }
+  if (!BVH) close_hit_block(P, hit_lds + (threadIdx.x >> 6) * 4, BATCH ? scene : 0u);
   // the block's histogram window joins the histogram (every wave of the block has finished its rays)
   if (!BVH) {
     __syncthreads();
@@ -1679,9 +1738,9 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
   }
 }
 
-template <bool BVH, bool STOCH, bool SEG, bool LEAN = false>
+template <bool BVH, bool STOCH, bool SEG, bool LEAN = false, bool BATCH = false>
 __global__ __launch_bounds__(256, BVH ? ODW_WAVES_PER_SIMD_BVH : ODW_WAVES_PER_SIMD) void odw_trace_kernel(const TraceParams P) {
-  trace_body<BVH, STOCH, SEG, LEAN>(P);
+  trace_body<BVH, STOCH, SEG, LEAN, NoSpec, BATCH>(P);
 }
 
 #ifdef ODW_SPEC_HEADER
@@ -1694,8 +1753,11 @@ __global__ __launch_bounds__(256, BVH ? ODW_WAVES_PER_SIMD_BVH : ODW_WAVES_PER_S
 #ifndef ODW_SPEC_STOCH
 #define ODW_SPEC_STOCH false
 #endif
+#ifndef ODW_SPEC_BATCH
+#define ODW_SPEC_BATCH false
+#endif
 extern "C" __global__ __launch_bounds__(256, ODW_SPEC_WAVES) void odw_spec_kernel(const TraceParams P) {
-  trace_body<false, ODW_SPEC_STOCH, false, ODW_SPEC_LEAN, Spec>(P);
+  trace_body<false, ODW_SPEC_STOCH, false, ODW_SPEC_LEAN, Spec, ODW_SPEC_BATCH>(P);
 }
 #endif
 

@@ -26,21 +26,17 @@ def shardFirst(step, rank, world, n_per, warm=False):
   return (WARM_BASE if warm else 0) + (step * world + rank) * n_per
 
 
-def reduceTensors(dist, tensors, dst=0):
-  for t in tensors:
-    dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM)
-
-
 def reduceResults(tracer, dist, torch, dst=0):
-  """sum histogram + counters of every rank into rank `dst`'s device buffers
-  (zero-copy views of the tracer's HBM buffers, int64)"""
+  """sum counters + histogram of every rank into rank `dst`'s device buffers with ONE reduce: the library keeps
+  both in one block of int64 words (`Tracer.resultsView`, odw_device_results), of which this is a zero-copy view"""
   tracer.sync()
-  views = [tracer.countersView()]
-  if tracer._det is not None:
-    views.append(tracer.histogramView())
-  tensors = [torch.as_tensor(v, device=torch.device('cuda', tracer.device)) for v in views]
-  reduceTensors(dist, tensors, dst=dst)
-  torch.cuda.synchronize()
+  view, _ = tracer.resultsView()
+  if hasattr(view, '__cuda_array_interface__'):
+    t = torch.as_tensor(view, device=torch.device('cuda', tracer.device))
+    dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM)
+    torch.cuda.synchronize()
+  else:                                  # a block in host memory (the CPU stand-in of the tests, gloo)
+    dist.reduce(torch.from_numpy(view), dst=dst, op=dist.ReduceOp.SUM)
 
 
 class Ranks:

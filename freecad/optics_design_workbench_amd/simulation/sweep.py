@@ -19,6 +19,7 @@ value's result does not depend on which GPU ran it.
 import os
 import sys
 import time
+import warnings
 
 import numpy as np
 
@@ -42,7 +43,11 @@ def calcFwhm(hits):
   phis, r, hists = polarHist.byAzimuth()
   for phi, dens in zip(phis, hists):
     if max(dens) > 0:
-      a, b = np.polyfit(np.log(r[dens > 0])[:10], np.log(dens[dens > 0])[:10], deg=1)
+      with warnings.catch_warnings():
+        # (numpy's RankWarning where fewer than two radial bins hold hits: the notebook prints it, a sweep of
+        #  64 values would print it hundreds of times; the fit's numbers are the same either way)
+        warnings.simplefilter('ignore')
+        a, b = np.polyfit(np.log(r[dens > 0])[:10], np.log(dens[dens > 0])[:10], deg=1)
       # (outside the try, as in the notebook: an azimuth bin without a radial bin above 10 -- max() of an
       #  empty selection -- raises ValueError to the caller; with the notebook's own 1e3 rays that happens)
       rFit = np.geomspace(min(r), max(r[dens > 10][:10]), 100)

@@ -429,6 +429,13 @@ class Tracer:
     self._chk(self._lib.odw_device_counters(self._ctx, C.byref(p), C.byref(n)), 'odw_device_counters')
     return _CudaArrayView(p.value, n.value, '<i8', self)
 
+  def resultsView(self):
+    """counters and histogram as ONE int64 vector in HBM (`odw_device_results`): what a multi-GPU job sums with a
+    single reduce.  -> (view, offset of the first histogram bin in words)"""
+    p, n, off = C.c_void_p(), C.c_uint64(0), C.c_uint64(0)
+    self._chk(self._lib.odw_device_results(self._ctx, C.byref(p), C.byref(n), C.byref(off)), 'odw_device_results')
+    return _CudaArrayView(p.value, n.value, '<i8', self), int(off.value)
+
   def stream(self):
     p = C.c_void_p()
     self._chk(self._lib.odw_stream(self._ctx, C.byref(p)), 'odw_stream')

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ODW_ABI_VERSION 8
+#define ODW_ABI_VERSION 9
 
 /* ---- return codes ------------------------------------------------------ */
 enum {
@@ -512,7 +512,15 @@ int odw_compiled_info(odw_ctx* ctx, int32_t* bound, double* compile_seconds, int
 int odw_compile_check(const odw_scene_desc* scene, const odw_limits* limits, int32_t mode, const char* arch,
                       char* header_out, uint64_t header_capacity, uint64_t* code_bytes);
 
-/* device-side handles for collectives (RCCL reduce through torch)          */
+/* device-side handles for collectives (RCCL reduce through torch).  The
+ * counters and the detector histogram live in ONE block of 64-bit words,
+ * [hist_offset_words words: the ODW_CNT_* counters, zero-padded][n_bins bins],
+ * so that a multi-GPU job sums everything its ranks produced with a single
+ * reduce (v9; replaces the file-system merge of the reference's workers,
+ * simulation_loop.py:450-507, freecad_document.py:1491-1504).  The block moves
+ * when odw_set_detector asks for more bins: take the pointer after it.      */
+int odw_device_results(odw_ctx* ctx, void** dptr, uint64_t* n_words, uint64_t* hist_offset_words);
+/* the two parts of that block by themselves                                 */
 int odw_device_histogram(odw_ctx* ctx, void** dptr, uint64_t* n_bins);
 int odw_device_counters(odw_ctx* ctx, void** dptr, uint64_t* n);
 int odw_stream(odw_ctx* ctx, void** hip_stream);

@@ -50,6 +50,7 @@ class OracleTracer:
 
   # -- results ---------------------------------------------------------------
   def reset(self):
+    self._block = None
     self._hits = []
     self._cnt = {k: 0 for k in capi.CNT_NAMES}
     self._hist = None
@@ -62,6 +63,7 @@ class OracleTracer:
     self._segs = []
 
   def _absorb(self, r):
+    self._block = None
     for k, v in r['counters'].items():
       self._cnt[k] += v
     if len(r['hits']):
@@ -108,7 +110,22 @@ class OracleTracer:
   def sync(self):
     pass
 
+  RESULTS_HEAD = 16      # (the library's layout: counters, zero-padded to 16 words, then the histogram bins)
+
+  def resultsView(self):
+    """counters + histogram as one int64 block in host memory, the device library's layout (odw_device_results);
+    what a reduce leaves in it is what counters() / histogram() report afterwards"""
+    nb = self._det['nx'] * self._det['ny'] if self._det is not None else 0
+    block = np.zeros(self.RESULTS_HEAD + nb, dtype=np.int64)
+    block[:len(capi.CNT_NAMES)] = [self._cnt[k] for k in capi.CNT_NAMES]
+    if nb:
+      block[self.RESULTS_HEAD:] = self.histogram().astype(np.int64).ravel()
+    self._block = block
+    return block, self.RESULTS_HEAD
+
   def counters(self):
+    if getattr(self, '_block', None) is not None:
+      return {k: int(v) for k, v in zip(capi.CNT_NAMES, self._block)}
     return dict(self._cnt)
 
   def hitCount(self):
@@ -135,6 +152,8 @@ class OracleTracer:
   def histogram(self):
     if self._det is None:
       raise ValueError('no detector set')
+    if getattr(self, '_block', None) is not None:
+      return self._block[self.RESULTS_HEAD:].astype(np.uint64).reshape(self._det['nx'], self._det['ny'])
     if self._hist is None:
       return np.zeros((self._det['nx'], self._det['ny']), dtype=np.uint64)
     return self._hist

@@ -40,7 +40,11 @@ tr.reserveHits(16)
 tr.reset()
 first, n = parallel.shardRange(1000, 300001, rank, world)
 tr.trace(first, n, 77, record_hits=False)
-parallel.reduceResults(tr, dist, torch)            # nccl = RCCL, on the tracer's own HBM buffers
+calls = []
+reduce_ = dist.reduce
+dist.reduce = lambda *a, **k: (calls.append(1), reduce_(*a, **k))[1]
+parallel.reduceResults(tr, dist, torch)            # nccl = RCCL, on the tracer's own HBM block: ONE collective
+assert len(calls) == 1, calls
 if rank == 0:
   cnt = tr.counters()
   np.savez(sys.argv[2], hist=tr.histogram(), cnt=np.array([cnt[k] for k in sorted(cnt)], dtype=np.int64),
@@ -196,6 +200,60 @@ def test_bench_on_two_gpus_reports_two_gpus(native_lib):
   assert t2['n_gpus'] == 2 and t2['scaling'] == 'strong'
   assert t2['config']['spot_size']['fwhm_mm'] == t1['fwhm_mm']
   assert t2['config']['spot_size']['rms_spot_mm'] == t1['rms_spot_mm']
+
+
+# The driver's 8-GPU node: BASELINE configs[3] and [4] as they are quoted -- 1e9 hugeArray rays over eight ranks with one
+# RCCL reduce, 64 radii dealt out over eight ranks -- against the same jobs computed on ONE device.
+eight_ranks = pytest.mark.skipif(_devices() < 8, reason='needs eight GPUs (the driver\'s node); fewer present')
+
+
+@eight_ranks
+def test_c4_on_eight_gpus_equals_the_sum_of_eight_shards(native_lib, tmp_path):
+  """`bench.py --gpus 8 --config c4 --steps 1`: n_gpus 8, 1e9 traced rays, and rank 0's histogram + counters after the
+  single reduce equal the sums over the eight index ranges traced one after another on one GPU"""
+  from freecad.optics_design_workbench_amd import scenes
+  from freecad.optics_design_workbench_amd.simulation import parallel
+  from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
+  import bench
+  dump = str(tmp_path / 'c4_job.npz')
+  out = _line(_bench('--gpus', '8', '--config', 'c4', '--steps', '1', '--warmup', '1', '--no-cpu-baseline',
+                     '--dump-results', dump, timeout=1500))
+  n_per = int(bench.CONFIGS['c4']['rays'])
+  assert out['n_gpus'] == 8 and out['config']['name'] == 'c4' and out['config']['rays_per_step_per_gpu'] == n_per
+  assert out['value'] * out['ms_per_step'] * 1e-3 == pytest.approx(8 * n_per, rel=1e-6)        # 1e9 rays in the step
+  job = np.load(dump)
+  pr = project('hugeArray')
+  gi = pr.scene.group_index('OpticalAbsorberGroup')
+  det = dict(group=gi, origin=[-0.5, -0.5, 61.0], ex=[1.0, 0.0, 0.0], ey=[0.0, 1.0, 0.0],
+             x_lo=-25.0, x_hi=25.0, y_lo=-25.0, y_hi=25.0, nx=1024, ny=1024)
+  hist, cnt = None, None
+  with Tracer(0) as tr:
+    tr.setScene(pr.scene); tr.setSource(pr.source); tr.setLimits(pr.limits); tr.setDetector(det)
+    tr.reserveHits(n_per // 2)
+    for rank in range(8):
+      tr.reset()
+      tr.trace(parallel.shardFirst(0, rank, 8, n_per), n_per, bench.SEED)
+      tr.sync()
+      c = tr.counters()
+      h = tr.histogram().astype(np.int64)
+      hist = h if hist is None else hist + h
+      cnt = c if cnt is None else {k: cnt[k] + c[k] for k in c}
+  assert cnt['traced_rays'] == 8 * n_per == 10**9
+  assert [int(v) for v in job['counters']] == [cnt[k] for k in sorted(cnt)]
+  assert np.array_equal(job['hist'].astype(np.int64), hist)
+
+
+@eight_ranks
+def test_c5_on_eight_gpus_equals_one_gpu(native_lib):
+  """`bench.py --gpus 8 --config c5` (64 radii x 1e7 rays, eight radii per rank, one all-reduce of the table): the
+  table of spot sizes is the 1-rank table bit for bit"""
+  args = ['--config', 'c5', '--steps', '1', '--warmup', '0', '--no-cpu-baseline']
+  t8 = _line(_bench('--gpus', '8', *args, timeout=1500))
+  t1 = _line(_bench('--gpus', '1', *args, timeout=1500))
+  assert t8['n_gpus'] == 8 and t8['scaling'] == 'strong' and t8['config']['radii'] == 64
+  for col in ('fwhm_mm', 'rms_spot_mm'):
+    assert t8['config']['spot_size'][col] == t1['config']['spot_size'][col], col
+  assert t8['config']['spot_size']['best_radius_by_rms_mm'] == t1['config']['spot_size']['best_radius_by_rms_mm']
 
 
 RUN_WORKER = r'''

@@ -23,13 +23,19 @@ dist.init_process_group('gloo')
 rank, world = dist.get_rank(), dist.get_world_size()
 pr = project('lensesAndMirrors')
 det = scenes.planeDetector(pr.scene, 'OpticalAbsorberGroup', nx=64, ny=64, toward=pr.source.xform[[3, 7, 11]])
+from oracle_tracer import OracleTracer
 first, n = parallel.shardRange(1000, 30001, rank, world)
-r = capi.trace(pr.scene, pr.source, pr.limits, first, n, 77, det=det)
-hist = torch.from_numpy(r['hist'].astype(np.int64).ravel().copy())
-cnt = torch.tensor([r['counters'][k] for k in capi.CNT_NAMES], dtype=torch.int64)
-parallel.reduceTensors(dist, [cnt, hist], dst=0)
+tr = OracleTracer(nthreads=2)
+tr.setScene(pr.scene); tr.setSource(pr.source); tr.setLimits(pr.limits); tr.setDetector(det)
+tr.trace(first, n, 77)
+calls = []
+reduce_ = dist.reduce
+dist.reduce = lambda *a, **k: (calls.append(1), reduce_(*a, **k))[1]
+parallel.reduceResults(tr, dist, torch)            # the product's helper: ONE collective for counters + histogram
+assert len(calls) == 1, calls
 if rank == 0:
-  np.savez(sys.argv[2], hist=hist.numpy(), cnt=cnt.numpy())
+  c = tr.counters()
+  np.savez(sys.argv[2], hist=tr.histogram().astype(np.int64), cnt=np.array([c[k] for k in capi.CNT_NAMES]))
 dist.barrier()
 dist.destroy_process_group()
 '''
