@@ -205,6 +205,8 @@ static_assert(ODW_CNT_COUNT <= kResultsHead, "counters must fit the head of the 
 
 // the results block for a histogram of n_bins bins; the counters survive a reallocation
 int ensure_results(odw_ctx* ctx, uint64_t n_bins);
+// ctx->hits / hit_count are views of a batch segment (odw_batch_select): give the context its own list back
+void batch_unselect(odw_ctx* ctx);
 
 // ---- primitive bounding boxes in global coordinates -----------------------
 void local_bounds(int type, const double* par, double lo[3], double hi[3]) {
@@ -1057,8 +1059,10 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
   if (!explicit_rays && !ctx->have_source) return fail(ctx, ODW_ERR_NO_SCENE, "source not uploaded");
   if (n == 0) return ODW_OK;
   ctx->ph_valid = false;           // the hit list is about to change
-  ctx->hit_ray_begin = ctx->hit_ray_end ? std::min<uint64_t>(ctx->hit_ray_begin, first) : first;
-  ctx->hit_ray_end = std::max<uint64_t>(ctx->hit_ray_end, std::min<uint64_t>(first + n, 1ull << 48));
+  if (!ctx->batch_launch) {
+    ctx->hit_ray_begin = ctx->hit_ray_end ? std::min<uint64_t>(ctx->hit_ray_begin, first) : first;
+    ctx->hit_ray_end = std::max<uint64_t>(ctx->hit_ray_end, std::min<uint64_t>(first + n, 1ull << 48));
+  }
   if (ctx->bvh_dirty) {
     int rc = build_bvh(ctx);
     if (rc) return rc;
@@ -1068,7 +1072,7 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
     // stop tracing: the generic kernels run, odw_compile_scene / odw_last_error tell why
     if (spec_bind(ctx) != ODW_OK) ctx->spec_fn = nullptr;
   }
-  if ((flags & ODW_TRACE_RECORD_HITS) && ctx->hit_capacity == 0)
+  if ((flags & ODW_TRACE_RECORD_HITS) && (ctx->batch_launch ? ctx->batch_seg_capacity : ctx->hit_capacity) == 0)
     return fail(ctx, ODW_ERR_CAPACITY, "ODW_TRACE_RECORD_HITS without odw_reserve_hits");
   if (flags & ODW_TRACE_RECORD_SEGMENTS) {
     if (ctx->seg_capacity == 0)
@@ -1078,6 +1082,15 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
   }
   if ((flags & ODW_TRACE_HISTOGRAM) && !ctx->P.det_enabled) flags &= ~ODW_TRACE_HISTOGRAM;
   TraceParams& P = ctx->P;
+  const bool batch = ctx->batch_launch;
+  std::memset(&P.batch, 0, sizeof P.batch);
+  if (batch) {
+    // scenes of one structure side by side: flat kernels only (the scene the context holds is scene 0 of the batch)
+    if (P.scene.n_nodes || P.grid.nx > 0 || ctx->n_samplers > 0 || explicit_rays || (flags & ODW_TRACE_RECORD_SEGMENTS))
+      return fail(ctx, ODW_ERR_UNSUPPORTED, "odw_trace_batch: batches are traced by the flat kernels (analytic scenes of up to 64 "
+                                            "primitives, no stochastic surfaces, no segment rows)");
+    flags &= ~(uint32_t)ODW_TRACE_HISTOGRAM;          // (one histogram cannot serve several scenes)
+  }
   P.first_ray = first;
   P.n_rays = n;
   P.seed = seed;
@@ -1089,12 +1102,12 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
   P.ray_powers = ray_p;
   P.ray_stride = n;
   P.dbg = (unsigned long long*)ctx->dbg.p;
-  P.out.hits = (odw_hit*)ctx->hits.p;
-  P.out.hit_capacity = ctx->hit_slots;
+  P.out.hits = (odw_hit*)(batch ? ctx->batch_hits.p : ctx->hits.p);
+  P.out.hit_capacity = batch ? ctx->batch_seg_slots : ctx->hit_slots;
   // block reservations need room for the unused slots they can leave behind: < 64 per block and the
   // last block of every wave of the grid
   P.out.hit_block = 0;
-  P.out.hit_count = (unsigned long long*)ctx->hit_count.p;
+  P.out.hit_count = (unsigned long long*)(batch ? ctx->batch_hit_count.p : ctx->hit_count.p);
   P.out.hist = (unsigned long long*)ctx->hist.p;
   P.out.counters = (unsigned long long*)ctx->counters.p;
   P.out.chunk_counter = (unsigned long long*)ctx->chunk_counter.p;
@@ -1108,8 +1121,13 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
   static const int grid_mult = [] { const char* e = getenv("ODW_GRID_MULT"); int v = e ? atoi(e) : 0; return v > 0 ? v : 8; }();
   // big analytic scenes: grid kernel (no stochastic surfaces, no segment rows: those stay with the BVH kernels)
   // a scene compiled against its structure (odw_spec.hip): its own kernel, whatever else was built for it
-  const bool use_spec = ctx->spec_fn && ctx->spec_lean == ctx->lean && ctx->spec_stoch == (ctx->n_samplers > 0) &&
-                        !(flags & ODW_TRACE_RECORD_SEGMENTS);
+  if (batch && ctx->spec_fn && !ctx->spec_batch_fn) {
+    // the compiled kernel's BATCH variant: bound on the first batch launch of the structure (a compilation of its own,
+    // cached like the other; odw_compile_scene's mode decides, as for single launches)
+    if (spec_bind(ctx, true) != ODW_OK) ctx->spec_batch_fn = nullptr;
+  }
+  const bool use_spec = (batch ? ctx->spec_batch_fn != nullptr : ctx->spec_fn != nullptr) && ctx->spec_lean == ctx->lean &&
+                        ctx->spec_stoch == (ctx->n_samplers > 0) && !(flags & ODW_TRACE_RECORD_SEGMENTS);
   const bool use_grid = !use_spec && P.grid.nx > 0 && ctx->n_samplers == 0 && !(flags & ODW_TRACE_RECORD_SEGMENTS);
   // Rays per hand-out unit.  A launch should hold many chunks per resident wave: with about one each -- 1e7 rays in
   // chunks of 2048 on 4096 resident waves -- the waves that get a second one set the launch's length.  Measured
@@ -1124,7 +1142,21 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
                                : std::max<uint64_t>(512, std::min<uint64_t>(1024, n / (waves * 4)));
     P.chunk = (uint32_t)((forced ? std::max<uint64_t>(64, std::min<uint64_t>(ODW_CHUNK, forced)) : want) & ~(uint64_t)63);
   }
-  const uint64_t n_chunks = (n + P.chunk - 1) / P.chunk;
+  uint64_t n_chunks = (n + P.chunk - 1) / P.chunk;
+  if (batch) {
+    // n = the rays of ONE scene; the launch hands out chunks_per_scene units per scene
+    const uint64_t total = n * (uint64_t)ctx->batch_traced, waves = (uint64_t)ctx->n_cu * 16;
+    static const uint64_t forced = [] { const char* e = getenv("ODW_CHUNK_RAYS"); return e ? (uint64_t)atoll(e) : 0ull; }();
+    P.chunk = (uint32_t)((forced ? std::max<uint64_t>(64, std::min<uint64_t>(ODW_CHUNK, forced))
+                                 : std::max<uint64_t>(512, std::min<uint64_t>(1024, total / (waves * 4)))) & ~(uint64_t)63);
+    const uint64_t cps = (n + P.chunk - 1) / P.chunk;
+    if (cps * (uint64_t)ctx->batch_traced >= (1ull << 32)) return fail(ctx, ODW_ERR_INVALID, "odw_trace_batch: too many hand-out units");
+    P.batch.rays = n;
+    P.batch.stride = ctx->batch_stride;
+    P.batch.chunks_per_scene = (uint32_t)cps;
+    P.batch.n_scenes = (uint32_t)ctx->batch_traced;
+    n_chunks = cps * (uint64_t)ctx->batch_traced;
+  }
   const uint64_t cap = (uint64_t)ctx->n_cu * grid_mult;
   const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((n_chunks + 3) / 4, cap));
   const uint64_t grid_blocks = std::max<uint64_t>(1, std::min<uint64_t>((n_chunks + ODW_GRID_WAVES - 1) / ODW_GRID_WAVES, (uint64_t)ctx->n_cu));
@@ -1133,7 +1165,8 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
   const uint64_t n_waves = use_grid ? grid_blocks * ODW_GRID_WAVES : (uint64_t)grid * 4;
   if ((!P.scene.n_nodes || use_grid || use_spec || use_mesh) && !ctx->swapping)   // flat, grid and mesh kernels only (see record_hit)
     for (uint32_t b = kHitBlock; b >= 128 && b >= kHitBlock / 4 && !P.out.hit_block; b /= 2)   // (a short list: smaller blocks before none)
-      if (ctx->hit_slots >= ctx->hit_capacity + hit_block_room(ctx->hit_capacity, n_waves, b)) P.out.hit_block = b;
+      if (batch ? ctx->batch_seg_slots >= ctx->batch_seg_capacity + hit_block_room(ctx->batch_seg_capacity, n_waves, b)
+                : ctx->hit_slots >= ctx->hit_capacity + hit_block_room(ctx->hit_capacity, n_waves, b)) P.out.hit_block = b;
   HIPCHK(ctx, hipMemsetAsync(ctx->chunk_counter.p, 0, sizeof(uint64_t), ctx->stream));
   const size_t lds = P.scene.n_nodes ? (size_t)ODW_BVH_STACK * 256 * sizeof(int) : 0;
 
@@ -1150,8 +1183,11 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
   }
   const bool stoch = ctx->n_samplers > 0;
   if (use_spec) {
-    int rc = spec_launch(ctx, grid);
+    int rc = spec_launch(ctx, grid, batch);
     if (rc) return rc;
+  } else if (batch) {
+    if (ctx->lean) hipLaunchKernelGGL((odw_trace_kernel<false, false, false, true, true>), dim3(grid), dim3(256), 0, ctx->stream, P);
+    else hipLaunchKernelGGL((odw_trace_kernel<false, false, false, false, true>), dim3(grid), dim3(256), 0, ctx->stream, P);
   } else if (use_grid) {
     const dim3 gb((unsigned)grid_blocks);
     const size_t glds = P.grid.lds_bytes;
@@ -1294,6 +1330,7 @@ void odw_destroy(odw_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  batch_unselect(ctx);
   if (ctx->dbg.p) {
     uint64_t v[32] = {0};
     (void)hipMemcpy(v, ctx->dbg.p, sizeof v, hipMemcpyDeviceToHost);
@@ -1342,6 +1379,9 @@ void odw_destroy(odw_ctx* ctx) {
   for (DevBuf* b : {&ctx->ph_sel_entering, &ctx->ph_flags, &ctx->ph_x, &ctx->ph_y, &ctx->ph_sorted, &ctx->ph_small,
                     &ctx->ph_part, &ctx->ph_edges, &ctx->ph_edges_b, &ctx->ph_counts, &ctx->ph_sel_hist})
     release(*b);
+  release(ctx->batch_values);
+  release(ctx->batch_hits);
+  release(ctx->batch_hit_count);
   release(ctx->alt_hits);
   release(ctx->alt_hit_count);
   if (ctx->alt_ready) (void)hipEventDestroy(ctx->alt_ready);
@@ -1897,6 +1937,7 @@ int odw_set_detector(odw_ctx* ctx, const odw_detector_desc* det) {
 int odw_reserve_hits(odw_ctx* ctx, uint64_t capacity) {
   if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_reserve_hits: null ctx");
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  batch_unselect(ctx);
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   if (capacity == 0) { release(ctx->hits); ctx->hit_capacity = ctx->hit_slots = 0; return ODW_OK; }
   if (capacity > ctx->hit_capacity) {
@@ -1938,6 +1979,7 @@ int odw_reserve_segments(odw_ctx* ctx, uint64_t capacity) {
 int odw_trace(odw_ctx* ctx, uint64_t first_ray, uint64_t n_rays, uint64_t seed, uint32_t flags) {
   if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_trace: null ctx");
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  batch_unselect(ctx);
   if (!ctx->emitter_active) return launch_trace(ctx, first_ray, n_rays, seed, flags, nullptr, nullptr, nullptr);
   // surface source: initial conditions are generated into a staging buffer,
   // kEmitChunk rays at a time, and traced as explicit rays (same stream: the
@@ -1953,10 +1995,189 @@ int odw_trace(odw_ctx* ctx, uint64_t first_ray, uint64_t n_rays, uint64_t seed, 
   return ODW_OK;
 }
 
+// ---- batches: scenes of one structure in one launch (v9) ---------------------------------------------------------
+namespace {
+void batch_unselect(odw_ctx* ctx) {
+  if (ctx->batch_selected < 0) return;
+  ctx->hits = ctx->own_hits;
+  ctx->hit_count = ctx->own_hit_count;
+  ctx->hit_capacity = ctx->own_capacity;
+  ctx->hit_slots = ctx->own_slots;
+  ctx->hit_ray_begin = ctx->own_ray_begin;
+  ctx->hit_ray_end = ctx->own_ray_end;
+  ctx->own_hits = DevBuf();
+  ctx->own_hit_count = DevBuf();
+  ctx->batch_selected = -1;
+  ctx->ph_valid = false;
+}
+
+// the part of a scene's host tables that is STRUCTURE (what scenes of a batch must share)
+bool same_structure(const odw_ctx& a, const odw_ctx& b, std::string& why) {
+  if (a.P.scene.n_prims != b.P.scene.n_prims || a.P.scene.n_groups != b.P.scene.n_groups) { why = "primitive or group count"; return false; }
+  for (size_t i = 0; i < a.h_prim_i32.size(); ++i) {
+    const int32_t mask = (i % 4 == 2) ? ~(int32_t)ODW_FLAG_ISOLATED : ~0;       // (a matter of the boxes' values)
+    if ((a.h_prim_i32[i] & mask) != (b.h_prim_i32[i] & mask)) { why = "primitive kinds, groups, flags or trimming lists"; return false; }
+  }
+  if (a.h_cond != b.h_cond) { why = "trimming conditions"; return false; }
+  if (a.h_group_i32 != b.h_group_i32) { why = "optical types / recording switches / grating kinds"; return false; }
+  if (a.h_seq != b.h_seq || a.P.scene.seq_enabled != b.P.scene.seq_enabled || a.P.scene.seq_len != b.P.scene.seq_len ||
+      a.P.scene.ignore_mask != b.P.scene.ignore_mask) { why = "tracing sequence / ignored groups"; return false; }
+  if (a.lean != b.lean) { why = "gratings or absorbing media in some scenes only"; return false; }
+  return true;
+}
+}  // namespace
+
+int odw_upload_scene_batch(odw_ctx* ctx, const odw_scene_desc* scenes, int32_t n_scenes) {
+  if (!ctx || !scenes || n_scenes < 1) return fail(ctx, ODW_ERR_INVALID, "odw_upload_scene_batch: bad argument");
+  if (!ctx->have_limits) return fail(ctx, ODW_ERR_NO_SCENE, "odw_upload_scene_batch before odw_set_limits (the boxes carry the tolerance)");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ctx->batch_n = 0;
+  // scene 0 becomes the context's scene (shared integer tables, kernel choice, the compiled kernel's structure)
+  int rc = odw_upload_scene(ctx, &scenes[0]);
+  if (rc) return rc;
+  if ((rc = build_bvh(ctx))) return rc;
+  if (ctx->P.scene.n_nodes || ctx->P.grid.nx > 0)
+    return fail(ctx, ODW_ERR_UNSUPPORTED, "odw_upload_scene_batch: batches are traced by the flat kernels (analytic scenes of up to 64 primitives)");
+  const bool compiled = ctx->compile_mode != ODW_COMPILE_OFF && spec_ineligible(ctx).empty();
+  const std::string text0 = compiled ? spec_text(ctx) : std::string();
+  const size_t n = (size_t)ctx->P.scene.n_prims;
+  // one block of doubles per scene: prim_f64 (16 n) | prim_hdr (8 n) | group_f64 (4 x 64) | group_gdir (3 x 64)
+  const size_t o_hdr = 16 * n, o_gf = o_hdr + 8 * n, o_gd = o_gf + ODW_MAX_GROUPS * 4, stride = o_gd + ODW_MAX_GROUPS * 3;
+  std::vector<double> blocks(stride * (size_t)n_scenes, 0.0);
+  for (int k = 0; k < n_scenes; ++k) {
+    odw_ctx tmp;                     // host tables only: no device, no stream
+    std::memset(&tmp.P, 0, sizeof tmp.P);
+    if ((rc = scene_host_tables(&tmp, &scenes[k]))) { ctx->err = tmp.err; g_error = tmp.err; return rc; }
+    std::string why;
+    if (!same_structure(*ctx, tmp, why))
+      return fail(ctx, ODW_ERR_UNSUPPORTED, "odw_upload_scene_batch: scene " + std::to_string(k) + " differs from scene 0 in structure (" + why + ")");
+    tmp.P.lim = ctx->P.lim;
+    tmp.have_limits = true;
+    std::vector<Box> boxes;
+    std::vector<char> dead;
+    compute_boxes(&tmp, boxes, dead);
+    if (compiled && spec_text(&tmp) != text0)
+      return fail(ctx, ODW_ERR_UNSUPPORTED, "odw_upload_scene_batch: scene " + std::to_string(k) + " differs from scene 0 in the structure a "
+                                            "compiled kernel is built from (which frame entries are 0 / +1 / -1, shared boxes)");
+    double* b = blocks.data() + stride * (size_t)k;
+    std::memcpy(b, tmp.h_prim_f64.data(), 16 * n * sizeof(double));
+    std::memcpy(b + o_hdr, tmp.h_prim_hdr.data(), 8 * n * sizeof(double));
+    // (the isolated-solid shortcut depends on the boxes' values; it never changes a result: left out of batches)
+    for (size_t p = 0; p < n; ++p) {
+      int32_t w[4];
+      std::memcpy(w, b + o_hdr + 8 * p + 6, sizeof w);
+      w[2] &= ~ODW_FLAG_ISOLATED;
+      std::memcpy(b + o_hdr + 8 * p + 6, w, sizeof w);
+    }
+    std::memcpy(b + o_gf, tmp.h_group_f64.data(), ODW_MAX_GROUPS * 4 * sizeof(double));
+    std::memcpy(b + o_gd, tmp.h_group_gdir.data(), ODW_MAX_GROUPS * 3 * sizeof(double));
+  }
+  if ((rc = upload(ctx, ctx->batch_values, blocks.data(), blocks.size() * sizeof(double)))) return rc;
+  // the shared integer tables without the isolated-solid flag
+  std::vector<int32_t> pi = ctx->h_prim_i32;
+  for (size_t p = 0; p < n; ++p) pi[4 * p + 2] &= ~ODW_FLAG_ISOLATED;
+  if (n && (rc = upload(ctx, ctx->prim_i32, pi.data(), pi.size() * sizeof(int32_t)))) return rc;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->h_prim_i32 = pi;
+  ctx->batch_n = n_scenes;
+  ctx->batch_stride = stride;
+  ctx->batch_spec_text = text0;
+  return ODW_OK;
+}
+
+int odw_trace_batch(odw_ctx* ctx, uint64_t first_ray, uint64_t rays_per_scene, uint64_t seed, uint32_t flags,
+                    uint64_t rows_per_scene) {
+  if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_trace_batch: null ctx");
+  if (ctx->batch_n < 1) return fail(ctx, ODW_ERR_NO_SCENE, "odw_trace_batch before odw_upload_scene_batch");
+  if (ctx->emitter_active) return fail(ctx, ODW_ERR_UNSUPPORTED, "odw_trace_batch: point sources only");
+  if (rays_per_scene == 0) return ODW_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  batch_unselect(ctx);
+  const uint64_t S = (uint64_t)ctx->batch_n;
+  if (flags & ODW_TRACE_RECORD_HITS) {
+    if (rows_per_scene == 0) return fail(ctx, ODW_ERR_CAPACITY, "odw_trace_batch: ODW_TRACE_RECORD_HITS with rows_per_scene = 0");
+    uint64_t slots = rows_per_scene;
+    if (rows_per_scene >= kHitBlockMinRows)
+      slots += hit_block_room(rows_per_scene, std::min<uint64_t>((uint64_t)ctx->n_cu * 8 * 4, std::max<uint64_t>(64, rows_per_scene / 256)), kHitBlock);
+    if (slots > 0x7FFFFFFFull) return fail(ctx, ODW_ERR_CAPACITY, "odw_trace_batch: more than 2^31 rows per scene");
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    int rc = ensure(ctx, ctx->batch_hits, S * slots * sizeof(odw_hit));
+    if (!rc) rc = ensure(ctx, ctx->batch_hit_count, S * 2 * sizeof(uint64_t));
+    if (rc) return rc;
+    ctx->batch_seg_slots = slots;
+    ctx->batch_seg_capacity = rows_per_scene;
+    HIPCHK(ctx, hipMemsetAsync(ctx->batch_hit_count.p, 0, S * 2 * sizeof(uint64_t), ctx->stream));
+  }
+  // the value tables of scene 0 stand where the kernels' pointers point; scene s lies s strides further
+  const size_t n = (size_t)ctx->P.scene.n_prims;
+  const double* base = (const double*)ctx->batch_values.p;
+  DeviceScene saved = ctx->P.scene;
+  ctx->P.scene.prim_f64 = base;
+  ctx->P.scene.prim_hdr = base + 16 * n;
+  ctx->P.scene.group_f64 = base + 24 * n;
+  ctx->P.scene.group_gdir = base + 24 * n + ODW_MAX_GROUPS * 4;
+  ctx->batch_launch = true;
+  ctx->batch_traced = ctx->batch_n;
+  ctx->batch_rays = rays_per_scene;
+  ctx->batch_first = first_ray;
+  const int rc = launch_trace(ctx, first_ray, rays_per_scene, seed, flags, nullptr, nullptr, nullptr);
+  ctx->batch_launch = false;
+  const bool dirty = ctx->bvh_dirty;     // (launch_trace may have rebuilt boxes: keep what it set, restore the pointers only)
+  (void)dirty;
+  ctx->P.scene.prim_f64 = saved.prim_f64;
+  ctx->P.scene.prim_hdr = saved.prim_hdr;
+  ctx->P.scene.group_f64 = saved.group_f64;
+  ctx->P.scene.group_gdir = saved.group_gdir;
+  return rc;
+}
+
+int odw_batch_select(odw_ctx* ctx, int32_t scene) {
+  if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_batch_select: null ctx");
+  if (scene < 0) { batch_unselect(ctx); return ODW_OK; }
+  if (scene >= ctx->batch_traced || !ctx->batch_hits.p || !ctx->batch_seg_slots)
+    return fail(ctx, ODW_ERR_INVALID, "odw_batch_select: no such segment (odw_trace_batch with ODW_TRACE_RECORD_HITS first)");
+  if (ctx->batch_selected < 0) {
+    ctx->own_hits = ctx->hits;
+    ctx->own_hit_count = ctx->hit_count;
+    ctx->own_capacity = ctx->hit_capacity;
+    ctx->own_slots = ctx->hit_slots;
+    ctx->own_ray_begin = ctx->hit_ray_begin;
+    ctx->own_ray_end = ctx->hit_ray_end;
+  }
+  ctx->hits.p = (odw_hit*)ctx->batch_hits.p + (size_t)scene * ctx->batch_seg_slots;
+  ctx->hits.bytes = ctx->batch_seg_slots * sizeof(odw_hit);
+  ctx->hit_count.p = (uint64_t*)ctx->batch_hit_count.p + 2 * (size_t)scene;
+  ctx->hit_count.bytes = 2 * sizeof(uint64_t);
+  ctx->hit_capacity = ctx->batch_seg_capacity;
+  ctx->hit_slots = ctx->batch_seg_slots;
+  ctx->hit_ray_begin = ctx->batch_first;
+  ctx->hit_ray_end = std::min<uint64_t>(ctx->batch_first + ctx->batch_rays, 1ull << 48);
+  ctx->batch_selected = scene;
+  ctx->ph_valid = false;
+  return ODW_OK;
+}
+
+int odw_batch_rows(odw_ctx* ctx, uint64_t* rows, uint64_t* wanted, int32_t n) {
+  if (!ctx || !rows || n < 0) return fail(ctx, ODW_ERR_INVALID, "odw_batch_rows: bad argument");
+  if (n > ctx->batch_traced) return fail(ctx, ODW_ERR_INVALID, "odw_batch_rows: more scenes than the batch traced");
+  if (n == 0) return ODW_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  std::vector<uint64_t> v(2 * (size_t)n, 0);
+  HIPCHK(ctx, hipMemcpyAsync(v.data(), ctx->batch_hit_count.p, v.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  for (int k = 0; k < n; ++k) {
+    const uint64_t used = std::min<uint64_t>(v[2 * k], ctx->batch_seg_slots);
+    rows[k] = used > v[2 * k + 1] ? used - v[2 * k + 1] : 0;
+    if (wanted) wanted[k] = v[2 * k];          // slots asked for (above the segment's room: rows were dropped)
+  }
+  return ODW_OK;
+}
+
 int odw_trace_rays(odw_ctx* ctx, uint64_t first_ray, uint64_t n_rays, const double* origins,
                    const double* directions, const double* powers, uint32_t flags) {
   if (!ctx || !origins || !directions) return fail(ctx, ODW_ERR_INVALID, "odw_trace_rays: null argument");
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  batch_unselect(ctx);
   if (n_rays == 0) return ODW_OK;
   // the previous launch may still read the staging buffers
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1995,6 +2216,7 @@ int odw_sync(odw_ctx* ctx) {
 int odw_reset_results(odw_ctx* ctx) {
   if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_reset_results: null ctx");
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  batch_unselect(ctx);
   ctx->ph_valid = false;
   ctx->hit_ray_end = 0;
   HIPCHK(ctx, hipMemsetAsync(ctx->counters.p, 0, ODW_CNT_COUNT * sizeof(uint64_t), ctx->stream));
@@ -2013,6 +2235,7 @@ int odw_reset_segments(odw_ctx* ctx) {
 
 int odw_reset_hits(odw_ctx* ctx) {
   if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_reset_hits: null ctx");
+  batch_unselect(ctx);
   ctx->ph_valid = false;
   ctx->hit_ray_end = 0;
   HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -2100,6 +2323,7 @@ int odw_fetch_hits(odw_ctx* ctx, odw_hit* out, uint64_t capacity, uint64_t* n) {
 
 int odw_swap_hit_lists(odw_ctx* ctx) {
   if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_swap_hit_lists: null ctx");
+  batch_unselect(ctx);
   if (ctx->hit_capacity == 0) return fail(ctx, ODW_ERR_CAPACITY, "odw_swap_hit_lists without odw_reserve_hits");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   ctx->ph_valid = false;

@@ -1441,9 +1441,9 @@ __device__ __forceinline__ void spec_hits(const TraceParams& P, const SceneView&
 // (+ the block's histogram window, see record_hit: header at word 16, counts from word 20)
 // a wave gives up its block of hit-list slots (end of the kernel; BATCH: the wave moves on to another scene): the
 // slots it never filled are tagged unused and counted, the wave's state says "no block"
-__device__ __forceinline__ void close_hit_block(const TraceParams& P, volatile uint32_t* hit_state, uint32_t scene) {
+__device__ __forceinline__ void close_hit_block(const TraceParams& P, volatile uint32_t* hit_state, uint32_t next_scene) {
   if (!P.out.hit_block) {
-    if (P.batch.n_scenes && __lane_id() == 0) hit_state[3] = scene;   // (lists without block reservations: only the scene word matters)
+    if (P.batch.n_scenes && __lane_id() == 0) hit_state[3] = next_scene;   // (lists without block reservations: only the scene word matters)
     return;
   }
   odw_hit* hits = P.out.hits;
@@ -1464,7 +1464,7 @@ __device__ __forceinline__ void close_hit_block(const TraceParams& P, volatile u
     if (__lane_id() == 0 && in_buf) atomicAdd(hit_count + 1, (unsigned long long)in_buf);
   }
   if (__lane_id() == 0) {          // "full": the next append reserves a fresh block (of the new scene's segment)
-    hit_state[0] = 0u; hit_state[1] = 0u; hit_state[2] = P.out.hit_block; hit_state[3] = scene;
+    hit_state[0] = 0u; hit_state[1] = 0u; hit_state[2] = P.out.hit_block; hit_state[3] = next_scene;
   }
 }
 
@@ -1588,7 +1588,7 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
         if (idle != ~0ull) {
           avail = 0;
         } else {
-          close_hit_block(P, hit_lds + (threadIdx.x >> 6) * 4, scene);
+          close_hit_block(P, hit_lds + (threadIdx.x >> 6) * 4, unit_scene);    // (closes the old scene's block, notes the new scene)
           scene = unit_scene;
           const size_t off = (size_t)scene * (size_t)P.batch.stride;
           sv.prim_f64 = as_const(sc.prim_f64 + off);

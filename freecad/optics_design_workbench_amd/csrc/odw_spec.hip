@@ -346,18 +346,25 @@ void spec_wait_at_exit() {
 // earn its compilation: once ctx->spec_hot_rays rays were traced with its structure on generic kernels (by all
 // contexts of the process together), a thread compiles,
 // and the first launch after it has finished binds the result (the rows are the same either way, bit for bit).
-int spec_bind(odw_ctx* ctx) {
-  ctx->spec_dirty = false;
-  ctx->spec_fn = nullptr;
-  ctx->spec_seconds = 0;
-  ctx->spec_cache_hit = 0;
-  ctx->spec_pending = false;
+// batch: the kernel's BATCH variant (scenes of one structure side by side, odw_trace_batch) -> ctx->spec_batch_fn; it is
+// bound on the first batch launch, while the single-scene kernel of the same structure is bound (its mode decides)
+int spec_bind(odw_ctx* ctx, bool batch = false) {
+  if (batch) {
+    ctx->spec_batch_fn = nullptr;
+  } else {
+    ctx->spec_dirty = false;
+    ctx->spec_fn = nullptr;
+    ctx->spec_batch_fn = nullptr;
+    ctx->spec_seconds = 0;
+    ctx->spec_cache_hit = 0;
+    ctx->spec_pending = false;
+  }
   if (ctx->compile_mode == ODW_COMPILE_OFF || !ctx->have_scene) return ODW_OK;
   if (!spec_ineligible(ctx).empty()) return ODW_OK;
   hipDeviceProp_t prop;
   HIPCHK(ctx, hipGetDeviceProperties(&prop, ctx->device));
   const std::string arch = prop.gcnArchName;
-  const std::string text = spec_text(ctx);
+  const std::string text = spec_text(ctx) + (batch ? "#define ODW_SPEC_BATCH true\n" : "");
   const char* xo = getenv("ODW_SPEC_OPTS");
   const std::string jkey = arch + "|" + (xo ? xo : "") + "|" + text;
   const std::string key = std::to_string(ctx->device) + "|" + jkey;
@@ -436,6 +443,10 @@ int spec_bind(odw_ctx* ctx) {
   } else {
     ctx->spec_cache_hit = 1;
   }
+  if (batch) {
+    ctx->spec_batch_fn = it->second.fn;
+    return ODW_OK;
+  }
   ctx->spec_fn = it->second.fn;
   ctx->spec_lean = ctx->lean;
   ctx->spec_stoch = ctx->n_samplers > 0;
@@ -456,11 +467,11 @@ void spec_note_launch(odw_ctx* ctx, uint64_t n_rays) {
   if (jt == G.jobs.end() || jt->second->done.load()) ctx->spec_dirty = true;
 }
 
-int spec_launch(odw_ctx* ctx, unsigned grid) {
+int spec_launch(odw_ctx* ctx, unsigned grid, bool batch) {
   TraceParams P = ctx->P;
   size_t size = sizeof P;
   void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &P, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-  HIPCHK(ctx, hipModuleLaunchKernel(ctx->spec_fn, grid, 1, 1, 256, 1, 1, 0, ctx->stream, nullptr, config));
+  HIPCHK(ctx, hipModuleLaunchKernel(batch ? ctx->spec_batch_fn : ctx->spec_fn, grid, 1, 1, 256, 1, 1, 0, ctx->stream, nullptr, config));
   return ODW_OK;
 }
 

@@ -245,6 +245,55 @@ class Tracer:
         p.ctypes.data_as(pd) if p is not None else None,
         C.c_uint32(self._flags(record_hits, histogram, record_segments))), 'odw_trace_rays')
 
+  # -- batches: scenes of one structure in one launch -------------------------------
+  def setSceneBatch(self, scenes):
+    """scenes that differ in their numbers only (a parameter sweep: the same primitives, trimming lists, groups and
+    optical types) side by side in HBM (`odw_upload_scene_batch`; limits first).  Scene 0 becomes the tracer's scene.
+    Raises NativeError (unsupported) when the scenes differ in structure or lie outside the flat kernels' domain --
+    the caller then traces them one by one."""
+    if not len(scenes):
+      raise ValueError('empty batch')
+    descs, keeps = [], []
+    for sc in scenes:
+      if self.referenceStrict:
+        import copy
+        stripped = copy.copy(sc)
+        stripped.prim_flags = np.asarray(sc.prim_flags, dtype=np.int32) & ~np.int32(_native.FLAG_CONVEX)
+        sc = stripped
+      if getattr(sc, 'surface_samplers', None):
+        raise _native.NativeError('setSceneBatch: scenes with stochastic surfaces are traced one by one')
+      d, keep = _native.scene_desc(sc)
+      descs.append(d)
+      keeps.append(keep)
+    arr = (_native.SceneDesc * len(descs))(*descs)
+    self._chk(self._lib.odw_upload_scene_batch(self._ctx, arr, C.c_int32(len(descs))), 'odw_upload_scene_batch')
+    arr0, n0, keep0 = _native.surface_sampler_descs(None)
+    self._chk(self._lib.odw_upload_surface_samplers(self._ctx, arr0, C.c_int32(n0)), 'odw_upload_surface_samplers')
+    self.scene = scenes[0]
+    self.batchScenes = list(scenes)
+
+  def traceBatch(self, first, n, seed, rowsPerScene, record_hits=True):
+    """asynchronous: rays first..first+n-1 of Philox stream `seed` in EVERY scene of the batch, one launch; a scene's
+    rows (those of trace() on that scene alone) go to its own segment of the batch's hit list"""
+    self._chk(self._lib.odw_trace_batch(self._ctx, C.c_uint64(int(first)), C.c_uint64(int(n)), C.c_uint64(int(seed)),
+                                        C.c_uint32(self._flags(record_hits, False)), C.c_uint64(int(rowsPerScene))),
+              'odw_trace_batch')
+
+  def batchSelect(self, k):
+    """the rows of scene k of the last traceBatch become the tracer's hit list (hits(), hitCount(), deviceHits(),
+    hitColumns() ...); None: back to the tracer's own list"""
+    self._chk(self._lib.odw_batch_select(self._ctx, C.c_int32(-1 if k is None else int(k))), 'odw_batch_select')
+    if k is not None:
+      self.scene = self.batchScenes[int(k)]
+
+  def batchRows(self):
+    """(rows recorded per scene, slots asked for per scene) of the last traceBatch"""
+    n = len(self.batchScenes)
+    rows, wanted = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)
+    pu = C.POINTER(C.c_uint64)
+    self._chk(self._lib.odw_batch_rows(self._ctx, rows.ctypes.data_as(pu), wanted.ctypes.data_as(pu), C.c_int32(n)), 'odw_batch_rows')
+    return rows, wanted
+
   def sync(self):
     self._chk(self._lib.odw_sync(self._ctx), 'odw_sync')
 

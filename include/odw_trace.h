@@ -512,6 +512,31 @@ int odw_compiled_info(odw_ctx* ctx, int32_t* bound, double* compile_seconds, int
 int odw_compile_check(const odw_scene_desc* scene, const odw_limits* limits, int32_t mode, const char* arch,
                       char* header_out, uint64_t header_capacity, uint64_t* code_bytes);
 
+/* ---- batches: many scenes of ONE structure in one launch (v9) -----------
+ * Replaces the loop of a parameter sweep (examples/1-getting-started/
+ * optimize-spotsize.ipynb cell 9; jupyter_utils/parameter_sweeper.py): one
+ * `runSimulation` per parameter value there, one launch for all values here.
+ * The scenes must agree in everything but their numbers: the same primitives,
+ * trimming lists, groups, optical types, sequence (ODW_ERR_UNSUPPORTED names
+ * the difference).  Scene 0 becomes the context's scene; limits first (the
+ * boxes carry the tolerance), flat kernels only (analytic scenes of up to 64
+ * primitives, no stochastic surfaces).
+ * odw_trace_batch traces rays first_ray ... first_ray + rays_per_scene - 1 in
+ * EVERY scene (the rows of a scene are those of odw_trace on that scene
+ * alone, tags included); a scene's rows go to its own segment of the batch's
+ * hit list (room for rows_per_scene rows each); counters add up over the
+ * scenes; no detector histogram.  odw_batch_select makes a segment the
+ * context's hit list for odw_hit_count / odw_fetch_hits / odw_hits_* (scene
+ * < 0, or any other trace / reserve / reset call: back to the context's own
+ * list).  odw_batch_rows: rows recorded per scene, and (optional) the slots
+ * asked for -- above the segment's room rows were dropped (counter
+ * ODW_CNT_HITS_DROPPED): trace again with more room.                        */
+int odw_upload_scene_batch(odw_ctx* ctx, const odw_scene_desc* scenes, int32_t n_scenes);
+int odw_trace_batch(odw_ctx* ctx, uint64_t first_ray, uint64_t rays_per_scene, uint64_t seed, uint32_t flags,
+                    uint64_t rows_per_scene);
+int odw_batch_select(odw_ctx* ctx, int32_t scene);
+int odw_batch_rows(odw_ctx* ctx, uint64_t* rows, uint64_t* wanted, int32_t n);
+
 /* device-side handles for collectives (RCCL reduce through torch).  The
  * counters and the detector histogram live in ONE block of 64-bit words,
  * [hist_offset_words words: the ODW_CNT_* counters, zero-padded][n_bins bins],

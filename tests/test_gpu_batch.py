@@ -1,0 +1,130 @@
+"""Batch launches (`odw_upload_scene_batch` / `odw_trace_batch`, ABI v9): the scenes of a parameter sweep -- one
+structure, different numbers -- traced by ONE launch.  The contract: a scene's rows are the rows of a launch of that
+scene alone, bit for bit (tags included), whatever the batch's size, the hit list's mode (block reservations or one
+atomic per append) and the kernel (generic or compiled against the structure)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import SCENES
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x0D15EA5E
+
+
+def _projects(radii):
+  from freecad.optics_design_workbench_amd import scenes
+  from freecad.optics_design_workbench_amd.scene import open_fcstd
+  doc = open_fcstd(os.path.join(SCENES, 'GettingStarted.FCStd'))
+  out = []
+  for r in radii:
+    doc.Sphere.Radius = float(r)
+    out.append(scenes.bakeProject(doc))
+  return out
+
+
+@pytest.fixture(scope='module', params=['off', 'structure'])
+def tracer(native_lib, request):
+  from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
+  tr = Tracer(0)
+  tr.compileScene(request.param)
+  tr.wanted = request.param
+  yield tr
+  tr.close()
+
+
+def _single(tr, pr, first, n, cap):
+  tr.setScene(pr.scene)
+  tr.setSource(pr.source)
+  tr.setLimits(pr.limits)
+  tr.setDetector(None)
+  tr.reserveHits(cap)
+  tr.reset()
+  tr.trace(first, n, SEED, histogram=False)
+  tr.sync()
+  assert tr.compiledInfo()['mode'] == (1 if tr.wanted == 'structure' else 0)
+  return tr.counters(), tr.hits()
+
+
+@pytest.mark.parametrize('n,first', [(5000, 0), (200_000, 12345), (1_000_003, 7)])
+def test_batch_rows_equal_single_launches(tracer, n, first):
+  radii = [9.0, 9.4, 9.83, 10.0, 10.6, 11.0]
+  prs = _projects(radii)
+  cap = n + 1024
+  singles = [_single(tracer, pr, first, n, cap) for pr in prs]
+  tracer.setLimits(prs[0].limits)
+  tracer.setSource(prs[0].source)
+  tracer.setSceneBatch([pr.scene for pr in prs])
+  tracer.reset()
+  tracer.traceBatch(first, n, SEED, cap)
+  tracer.sync()
+  cnt = tracer.counters()
+  for key in cnt:
+    assert cnt[key] == sum(c[key] for c, _ in singles), key
+  assert cnt['traced_rays'] == n * len(radii) and cnt['hits_dropped'] == 0
+  rows, wanted = tracer.batchRows()
+  assert [int(r) for r in rows] == [len(h) for _, h in singles]
+  for k, (_, want) in enumerate(singles):
+    tracer.batchSelect(k)
+    assert tracer.hitCount() == len(want)
+    got = tracer.hits()
+    for col in ('tag', 'point', 'direction', 'power'):
+      assert np.array_equal(got[col], want[col]), (k, col)
+  tracer.batchSelect(None)
+  # the tracer's own list is untouched by the batch, and single launches go on as before
+  again = _single(tracer, prs[2], first, n, cap)
+  assert np.array_equal(again[1]['tag'], singles[2][1]['tag']) and np.array_equal(again[1]['point'], singles[2][1]['point'])
+
+
+def test_device_hits_on_a_segment_equal_those_of_a_single_launch(tracer):
+  """the post-hoc path (selection, plane search on the thinned sample, projection, medians, polar binning, moments)
+  on a segment of the batch's hit list"""
+  from freecad.optics_design_workbench_amd.simulation import sweep
+  prs = _projects([9.6, 10.1, 10.4])
+  n, cap = 300_000, 301_024
+  want = []
+  for pr in prs:
+    _single(tracer, pr, 0, n, cap)
+    h = tracer.deviceHits()
+    want.append((len(h), sweep.calcFwhm(h), sweep.rmsSpot(h)))
+  tracer.setLimits(prs[0].limits)
+  tracer.setSource(prs[0].source)
+  tracer.setSceneBatch([pr.scene for pr in prs])
+  tracer.reset()
+  tracer.traceBatch(0, n, SEED, cap)
+  tracer.sync()
+  for k in (2, 0, 1):
+    tracer.batchSelect(k)
+    h = tracer.deviceHits()
+    assert (len(h), sweep.calcFwhm(h), sweep.rmsSpot(h)) == want[k]
+  tracer.batchSelect(None)
+
+
+def test_scenes_of_another_structure_are_refused(tracer):
+  from conftest import project
+  from freecad.optics_design_workbench_amd import _native
+  a, b = _projects([10.0])[0], project('lensesAndMirrors')
+  tracer.setLimits(a.limits)
+  with pytest.raises(_native.NativeError, match='structure'):
+    tracer.setSceneBatch([a.scene, b.scene])
+  # a scene the flat kernels do not take
+  huge = project('hugeArray')
+  tracer.setLimits(huge.limits)
+  with pytest.raises(_native.NativeError, match='flat kernels'):
+    tracer.setSceneBatch([huge.scene, huge.scene])
+
+
+def test_rows_dropped_in_a_segment_are_reported(tracer):
+  prs = _projects([9.5, 10.0])
+  tracer.setLimits(prs[0].limits)
+  tracer.setSource(prs[0].source)
+  tracer.setSceneBatch([pr.scene for pr in prs])
+  tracer.reset()
+  tracer.traceBatch(0, 20000, SEED, 5000)
+  tracer.sync()
+  cnt = tracer.counters()
+  rows, wanted = tracer.batchRows()
+  assert cnt['hits_dropped'] > 0 and all(int(r) == 5000 for r in rows) and all(int(w) > 5000 for w in wanted)
+  assert cnt['hits_dropped'] == sum(int(w) - 5000 for w in wanted)
