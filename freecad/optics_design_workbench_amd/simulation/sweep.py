@@ -24,6 +24,7 @@ import warnings
 import numpy as np
 
 from ..jupyter_utils.hits import Hits
+from .. import _native
 from ..scene import bake as _bake
 from . import parallel
 from .tracer import Tracer, hitsToDict
@@ -103,7 +104,7 @@ class SweepResult:
 
 
 def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAULT_SEED, device=0,
-                   dist=None, tracer=None, source=None, deviceHits=True, pipeline=True, **traceKwargs):
+                   dist=None, tracer=None, source=None, deviceHits=True, pipeline=True, batch=8, **traceKwargs):
   """run `rays` true-random rays for every entry of `values` and return a SweepResult.
 
   setValue(doc, value)   applies one parameter value (e.g. `doc.Sphere.Radius = value`)
@@ -115,6 +116,10 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
   deviceHits             measure on the hit rows where they are, in HBM (`DeviceHits`: plane search
                          on a thinned sample, projection, medians and binning on the device); False:
                          copy every row to the host first (what the reference does)
+  batch                  with deviceHits on a device tracer: so many values at a time are traced by ONE launch (scenes of
+                         one structure side by side in HBM, `Tracer.traceBatch`; the rows of a value are those of a launch of
+                         its own); values whose scenes differ in structure, or that the flat kernels do not take, are traced
+                         one by one; 0 / 1: always one by one
   pipeline               with deviceHits on a device tracer: further contexts on the same GPU (True: two), so
                          that value k + 1 is baked and traced while values k and k - 1 are measured (same
                          results); an integer n: n extra contexts (n measuring threads)
@@ -140,12 +145,14 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
   lanes = [tr]
   if os.environ.get('ODW_SWEEP_PIPELINE') == '0':        # (diagnostics: every kernel of a sweep by itself in a trace)
     pipeline = False
+  elif os.environ.get('ODW_SWEEP_PIPELINE'):
+    pipeline = int(os.environ['ODW_SWEEP_PIPELINE'])
   if pipeline and deviceHits and isinstance(tr, Tracer) and len(mine) > 1:
     # (two measuring threads by default: the measure is partly host work under the GIL, partly waits for the GPU --
     #  one thread read 243 - 338 ms per 64 x 1e7 sweep from run to run, two 248 - 273, three 247 - 264)
     # (the extra contexts stay with the tracer between sweeps: creating them costs ~12 ms, a rank's share of a sweep
     #  dealt out over eight GPUs takes 30)
-    want = min(int(pipeline) if pipeline is not True else 2, len(mine) - 1, 3)
+    want = min(int(pipeline) if pipeline is not True else 2, len(mine) - 1, 5)
     kept = [e for e in (getattr(tr, '_sweepLanes', None) or [])
             if e.referenceStrict == tr.referenceStrict and e.compileMode() == tr.compileMode()]
     while len(kept) < want:
@@ -165,6 +172,7 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
     from concurrent.futures import ThreadPoolExecutor
     pool = ThreadPoolExecutor(max_workers=len(lanes), thread_name_prefix='odw-sweep-measure')
   pending = [None] * len(lanes)
+  batch_ok = [True]
 
   def measureInto(t, scene, k):
     t_m = time.perf_counter() if clock is not None else 0.0
@@ -188,54 +196,149 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
       table[k, j] = (0.0, 2.0) if np.isnan(m) else (m, 1.0)
 
   clock = dict(wait=0.0, bake=0.0, trace=0.0, measure=0.0) if os.environ.get('ODW_SWEEP_TIMING') else None
+  import threading
+  totals_lock = threading.Lock()
+
+  def bakeValue(k):
+    setValue(doc, values[k])
+    return _bake.bakeScene(doc, src), bakeLightSource(doc, src, seed), _bake.bakeLimits(doc, src, **traceKwargs)
+
+  def uploadCommon(t, up, bsrc, lim):
+    # (tables travel to the device only when they change: a sweep of one shape parameter uploads
+    #  the source's 1.6 MB of sampler tables once)
+    key = _sourceKey(bsrc)
+    if up.get('source') != key:
+      t.setSource(bsrc)
+      up['source'] = key
+    if up.get('limits') != lim:
+      t.setLimits(lim)
+      up['limits'] = lim
+
+  def runOne(lane, k, baked=None):
+    """one value, one launch (tracers without batch launches, scenes outside the flat kernels' domain, values whose
+    scenes differ in structure)"""
+    t, up = lanes[lane], uploaded[lane]
+    t0 = time.perf_counter()
+    if pending[lane] is not None:
+      pending[lane].result()          # the rows of this context are free again (and its errors surface here)
+      pending[lane] = None
+    t1 = time.perf_counter()
+    scene, bsrc, lim = baked if baked is not None else bakeValue(k)
+    t2 = time.perf_counter()
+    if hasattr(t, 'batchSelect') and getattr(t, 'batchScenes', None):
+      t.batchSelect(None)
+    uploadCommon(t, up, bsrc, lim)
+    t.setScene(scene)
+    t.setDetector(None)
+    capacity = int(rays * 1.25) + 1024
+    while True:
+      t.reserveHits(capacity)
+      t.reset()
+      t.trace(0, int(rays), seed, histogram=False)
+      t.sync()
+      cnt = t.counters()
+      Tracer.raiseForRayErrors(cnt)
+      if not cnt['hits_dropped']:
+        break
+      capacity = int(cnt['recorded_hits'] * 1.05) + 1024      # deterministic: trace again with room
+    with totals_lock:
+      totals[:] += (cnt['traced_rays'], cnt['recorded_hits'], cnt['segments'])
+    if clock is not None:
+      t3 = time.perf_counter()
+      clock['wait'] += t1 - t0; clock['bake'] += t2 - t1; clock['trace'] += t3 - t2
+    if pool is not None:
+      pending[lane] = pool.submit(measureInto, t, scene, k)
+    else:
+      measureInto(t, scene, k)
+
+  def measureGroup(t, scenes, ks, capacity):
+    """the rows of a batch launch, segment by segment (runs on a measuring thread; the launch is still under way when
+    it starts)"""
+    while True:
+      t.sync()
+      cnt = t.counters()
+      Tracer.raiseForRayErrors(cnt)
+      if not cnt['hits_dropped']:
+        break
+      rows, wanted = t.batchRows()                              # deterministic: trace again with room
+      capacity = int(int(wanted.max()) * 1.05) + 1024
+      t.reset()
+      t.traceBatch(0, int(rays), seed, capacity)
+    with totals_lock:
+      totals[:] += (cnt['traced_rays'], cnt['recorded_hits'], cnt['segments'])
+    try:
+      for j, k in enumerate(ks):
+        t.batchSelect(j)
+        measureInto(t, scenes[j], k)
+    finally:
+      t.batchSelect(None)
+
+  # Batch launches (Tracer.setSceneBatch / traceBatch): the values a context gets at a time are baked together and traced
+  # by ONE launch -- their scenes differ in numbers only --, each into its own segment of the hit list; a measuring thread
+  # then goes through the segments while the main thread bakes and launches the next group on another context.
+  group_size = int(batch) if (batch and deviceHits and isinstance(tr, Tracer) and len(mine) > 1) else 1
+  if os.environ.get('ODW_SWEEP_BATCH'):
+    group_size = max(1, int(os.environ['ODW_SWEEP_BATCH'])) if group_size > 1 else 1
+  switch_interval = sys.getswitchinterval()
+  if pool is not None:
+    # (threads that alternate between short library calls and a few lines of Python hand the interpreter lock to
+    #  each other all the time; with the default 5 ms a thread that comes back from a 20 us call can wait that long)
+    sys.setswitchinterval(float(os.environ.get('ODW_SWITCH_INTERVAL', '2e-4')))
   try:
-    for turn, k in enumerate(mine):
+    pos, turn = 0, 0
+    while pos < len(mine):
+      ks = mine[pos:pos + group_size]
       lane = turn % len(lanes)
+      turn += 1
+      if len(ks) == 1 or not batch_ok[0]:
+        for k in ks:
+          runOne(lane, k)
+          lane = turn % len(lanes)
+          turn += 1
+        pos += len(ks)
+        continue
       t, up = lanes[lane], uploaded[lane]
       t0 = time.perf_counter()
       if pending[lane] is not None:
-        pending[lane].result()          # the rows of this context are free again (and its errors surface here)
+        pending[lane].result()
         pending[lane] = None
       t1 = time.perf_counter()
-      setValue(doc, values[k])
-      scene = _bake.bakeScene(doc, src)
-      bsrc = bakeLightSource(doc, src, seed)
-      lim = _bake.bakeLimits(doc, src, **traceKwargs)
+      baked = [bakeValue(k) for k in ks]
       t2 = time.perf_counter()
-      # (tables travel to the device only when they change: a sweep of one shape parameter uploads
-      #  the source's 1.6 MB of sampler tables once)
-      t.setScene(scene)
-      key = _sourceKey(bsrc)
-      if up.get('source') != key:
-        t.setSource(bsrc)
-        up['source'] = key
-      if up.get('limits') != lim:
-        t.setLimits(lim)
-        up['limits'] = lim
-      t.setDetector(None)
-      capacity = int(rays * 1.25) + 1024
-      while True:
-        t.reserveHits(capacity)
-        t.reset()
-        t.trace(0, int(rays), seed, histogram=False)
-        t.sync()
-        cnt = t.counters()
-        Tracer.raiseForRayErrors(cnt)
-        if not cnt['hits_dropped']:
-          break
-        capacity = int(cnt['recorded_hits'] * 1.05) + 1024      # deterministic: trace again with room
-      totals += (cnt['traced_rays'], cnt['recorded_hits'], cnt['segments'])
-      if clock is not None:
-        t3 = time.perf_counter()
-        clock['wait'] += t1 - t0; clock['bake'] += t2 - t1; clock['trace'] += t3 - t2
-      if pool is not None:
-        pending[lane] = pool.submit(measureInto, t, scene, k)
+      same = all(b[2] == baked[0][2] and _sourceKey(b[1]) == _sourceKey(baked[0][1]) for b in baked[1:])
+      launched = False
+      if same:
+        try:
+          uploadCommon(t, up, baked[0][1], baked[0][2])
+          t.setSceneBatch([b[0] for b in baked])
+          t.setDetector(None)
+          capacity = int(rays * 1.25) + 1024
+          t.reset()
+          t.traceBatch(0, int(rays), seed, capacity)
+          launched = True
+        except _native.NativeError as e:
+          if 'unsupported' not in str(e):
+            raise
+          batch_ok[0] = False           # (another structure per value, or scenes the flat kernels do not take: one by one)
+      if launched:
+        if clock is not None:
+          t3 = time.perf_counter()
+          clock['wait'] += t1 - t0; clock['bake'] += t2 - t1; clock['trace'] += t3 - t2
+        if pool is not None:
+          pending[lane] = pool.submit(measureGroup, t, [b[0] for b in baked], ks, capacity)
+        else:
+          measureGroup(t, [b[0] for b in baked], ks, capacity)
       else:
-        measureInto(t, scene, k)
+        for k, b in zip(ks, baked):
+          runOne(lane, k, baked=b)
+          lane = turn % len(lanes)
+          turn += 1
+      pos += len(ks)
     for f in pending:
       if f is not None:
         f.result()
   finally:
+    sys.setswitchinterval(switch_interval)
     if pool is not None:
       pool.shutdown(wait=True)
     if own:

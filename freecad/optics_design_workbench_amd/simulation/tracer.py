@@ -261,7 +261,7 @@ class Tracer:
         stripped.prim_flags = np.asarray(sc.prim_flags, dtype=np.int32) & ~np.int32(_native.FLAG_CONVEX)
         sc = stripped
       if getattr(sc, 'surface_samplers', None):
-        raise _native.NativeError('setSceneBatch: scenes with stochastic surfaces are traced one by one')
+        raise _native.NativeError('setSceneBatch: unsupported: scenes with stochastic surfaces are traced one by one')
       d, keep = _native.scene_desc(sc)
       descs.append(d)
       keeps.append(keep)

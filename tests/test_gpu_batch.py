@@ -128,3 +128,28 @@ def test_rows_dropped_in_a_segment_are_reported(tracer):
   rows, wanted = tracer.batchRows()
   assert cnt['hits_dropped'] > 0 and all(int(r) == 5000 for r in rows) and all(int(w) > 5000 for w in wanted)
   assert cnt['hits_dropped'] == sum(int(w) - 5000 for w in wanted)
+
+
+def test_sweep_with_batch_launches_equals_the_sweep_value_by_value(native_lib):
+  """parameterSweep: groups of values traced by one launch each (default) against one launch per value -- the same
+  table bit for bit, the same totals; an odd group at the end, more values than one group"""
+  from freecad.optics_design_workbench_amd.scene import open_fcstd
+  from freecad.optics_design_workbench_amd.simulation import sweep
+  from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
+  doc = open_fcstd(os.path.join(SCENES, 'GettingStarted.FCStd'))
+
+  def setRadius(d, r):
+    d.Sphere.Radius = r
+  radii = np.linspace(9, 11, 19)
+  res = {}
+  for batch in (0, 8, 5):
+    with Tracer(0) as tr:
+      tr.compileScene('structure')
+      res[batch] = sweep.parameterSweep(doc, setRadius, radii, rays=200_000, seed=11, tracer=tr, batch=batch,
+                                        measure=dict(fwhm=sweep.calcFwhm, rms=sweep.rmsSpot))
+  for batch in (8, 5):
+    for col in ('fwhm', 'rms'):
+      assert np.array_equal(res[batch].columns[col], res[0].columns[col], equal_nan=True), (batch, col)
+    assert (res[batch].tracedRays, res[batch].recordedHits, res[batch].segments) == \
+           (res[0].tracedRays, res[0].recordedHits, res[0].segments)
+  assert res[0].tracedRays == 19 * 200_000 and np.isfinite(res[0].columns['rms']).all()
