@@ -478,8 +478,10 @@ def run_sweep_config(args, cfg, rank, local_rank, world, dist, torch):
       dist.barrier()
 
   def run():
+    # keepSample: every radius also hands back its rows [::n // 1000] -- the sample size the notebook itself works on
+    # (optimize-spotsize.ipynb cell 9: EndAfterRays = 1e3); gathered inside the timed sweep, evaluated after it
     return sweep.parameterSweep(doc, setRadius, radii, rays=n_per, seed=SEED, tracer=tr, dist=dist,
-                                measure=dict(fwhm=sweep.calcFwhm, rms=sweep.rmsSpot))
+                                measure=dict(fwhm=sweep.calcFwhm, rms=sweep.rmsSpot), keepSample=1000)
 
   for _ in range(args.warmup):
     run()
@@ -500,6 +502,9 @@ def run_sweep_config(args, cfg, rank, local_rank, world, dist, torch):
     t = torch.tensor([dt], dtype=torch.float64, device='cuda')
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+  # the notebook's figure of merit on the notebook's sample size: calcFwhm of the ~1000 thinned rows per radius the
+  # last sweep kept (host arithmetic of 64 small clouds, after the timed region; one more all-reduce of the column)
+  fwhm_1e3 = sweep.fwhmOfSamples(res, dist=dist, device=local_rank)
   out = None
   if rank == 0:
     total_rays = n_per * len(radii) * args.steps
@@ -532,7 +537,13 @@ def run_sweep_config(args, cfg, rank, local_rank, world, dist, torch):
                                               'skips such azimuth bins): with 1e7 hits the innermost radial bins are '
                                               'flat near the focus; the rms spot radius below stays defined',
                                  'rms_spot_mm': [float(v) for v in res.columns['rms']],
-                                 'best_radius_by_rms_mm': rms_r, 'best_rms_spot_mm': rms_v}},
+                                 'best_radius_by_rms_mm': rms_r, 'best_rms_spot_mm': rms_v,
+                                 'fwhm_1e3_mm': [None if np.isnan(v) else float(v) for v in fwhm_1e3],
+                                 'best_radius_by_fwhm_1e3_mm': float(radii[int(np.nanargmin(fwhm_1e3))]) if np.isfinite(fwhm_1e3).any() else None,
+                                 'fwhm_1e3_at_best_mm': float(np.nanmin(fwhm_1e3)) if np.isfinite(fwhm_1e3).any() else None,
+                                 'fwhm_1e3_note': 'calcFwhm on points[::n // 1000] of every radius (the ~1e3 hits per run the notebook '
+                                                  'itself traces, cell 9): the estimator in its own regime; the rows are gathered '
+                                                  'inside the timed sweep, the 64 small fits run after it'}},
         'roofline': roofline_block(kernel_name, avg_kernel_s, n_per, bytes_per_ray, pmc,
                                    note='launches of rank 0; a launch = one radius; per step the host also re-bakes the scene and '
                                         'searches the detector plane per radius'),

@@ -13,7 +13,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <new>
+#include <thread>
 #include <string>
 #include <utility>
 #include <vector>
@@ -138,11 +142,20 @@ struct odw_ctx {
   uint64_t batch_stride = 0;               // doubles per scene block
   uint64_t batch_seg_slots = 0, batch_seg_capacity = 0, batch_rays = 0, batch_first = 0;
   int batch_traced = 0;                    // scenes of the last odw_trace_batch (segments that hold rows)
+  bool batch_marked = false;               // ... whose rows noted their slots in phb_row_of while they were recorded
   int batch_selected = -1;
   std::string batch_spec_text;             // the structure all scenes of the batch share (compiled kernels)
   hipFunction_t spec_batch_fn = nullptr;   // the scene-compiled kernel's BATCH variant (bound on the first batch launch)
   DevBuf own_hits, own_hit_count;
   uint64_t own_capacity = 0, own_slots = 0, own_ray_begin = 0, own_ray_end = 0;
+  // post-hoc binning of all segments at once (odw_batch_hits_*, odw_posthoc.hip): per-scene slices of these
+  DevBuf phb_row_of, phb_words, phb_sel, phb_small, phb_rows, phb_x, phb_y, phb_part, phb_sel_hist, phb_cand, phb_counts;
+  std::vector<uint64_t> phb_used, phb_n, phb_leaving;
+  std::vector<int32_t> phb_ordered;
+  std::vector<char> phb_on;
+  uint64_t phb_xy_stride = 0;
+  int phb_group = -1;
+  bool phb_valid = false, phb_projected = false;
   // second hit list (odw_swap_hit_lists): while one is traced into, the other is copied to the host
   // on a stream of its own
   DevBuf alt_hits, alt_hit_count;
@@ -1114,6 +1127,8 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
   P.out.segs = (odw_segment*)ctx->segs.p;
   P.out.seg_capacity = ctx->seg_capacity;
   P.out.seg_count = (unsigned long long*)ctx->seg_count.p;
+  P.out.row_of = (batch && ctx->batch_marked && (flags & ODW_TRACE_RECORD_HITS)) ? (uint32_t*)ctx->phb_row_of.p : nullptr;
+  P.out.row_stride = batch ? (n + 31) / 32 * 32 : 0;
 
   // persistent waves: one grid that fills the chip (4 blocks of 256 threads
   // per CU at 4 waves/SIMD, x2 so that a CU never waits for a block launch);
@@ -1382,6 +1397,9 @@ void odw_destroy(odw_ctx* ctx) {
   release(ctx->batch_values);
   release(ctx->batch_hits);
   release(ctx->batch_hit_count);
+  for (DevBuf* b : {&ctx->phb_row_of, &ctx->phb_words, &ctx->phb_sel, &ctx->phb_small, &ctx->phb_rows, &ctx->phb_x, &ctx->phb_y,
+                    &ctx->phb_part, &ctx->phb_sel_hist, &ctx->phb_cand, &ctx->phb_counts})
+    release(*b);
   release(ctx->alt_hits);
   release(ctx->alt_hit_count);
   if (ctx->alt_ready) (void)hipEventDestroy(ctx->alt_ready);
@@ -2102,11 +2120,20 @@ int odw_trace_batch(odw_ctx* ctx, uint64_t first_ray, uint64_t rays_per_scene, u
     if (slots > 0x7FFFFFFFull) return fail(ctx, ODW_ERR_CAPACITY, "odw_trace_batch: more than 2^31 rows per scene");
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     int rc = ensure(ctx, ctx->batch_hits, S * slots * sizeof(odw_hit));
-    if (!rc) rc = ensure(ctx, ctx->batch_hit_count, S * 2 * sizeof(uint64_t));
+    if (!rc) rc = ensure(ctx, ctx->batch_hit_count, S * 4 * sizeof(uint64_t));
     if (rc) return rc;
     ctx->batch_seg_slots = slots;
     ctx->batch_seg_capacity = rows_per_scene;
-    HIPCHK(ctx, hipMemsetAsync(ctx->batch_hit_count.p, 0, S * 2 * sizeof(uint64_t), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->batch_hit_count.p, 0, S * 4 * sizeof(uint64_t), ctx->stream));
+    // every recorded row notes its slot at its ray's place (DeviceOutputs.row_of): the table starts out as "no row"
+    ctx->batch_marked = false;
+    if (rays_per_scene <= (1ull << 28)) {
+      const uint64_t rays_pad = (rays_per_scene + 31) / 32 * 32;
+      rc = ensure(ctx, ctx->phb_row_of, S * rays_pad * sizeof(uint32_t));
+      if (rc) return rc;
+      HIPCHK(ctx, hipMemsetAsync(ctx->phb_row_of.p, 0xff, S * rays_pad * sizeof(uint32_t), ctx->stream));
+      ctx->batch_marked = true;
+    }
   }
   // the value tables of scene 0 stand where the kernels' pointers point; scene s lies s strides further
   const size_t n = (size_t)ctx->P.scene.n_prims;
@@ -2117,6 +2144,7 @@ int odw_trace_batch(odw_ctx* ctx, uint64_t first_ray, uint64_t rays_per_scene, u
   ctx->P.scene.group_f64 = base + 24 * n;
   ctx->P.scene.group_gdir = base + 24 * n + ODW_MAX_GROUPS * 4;
   ctx->batch_launch = true;
+  ctx->phb_valid = ctx->phb_projected = false;
   ctx->batch_traced = ctx->batch_n;
   ctx->batch_rays = rays_per_scene;
   ctx->batch_first = first_ray;
@@ -2146,7 +2174,7 @@ int odw_batch_select(odw_ctx* ctx, int32_t scene) {
   }
   ctx->hits.p = (odw_hit*)ctx->batch_hits.p + (size_t)scene * ctx->batch_seg_slots;
   ctx->hits.bytes = ctx->batch_seg_slots * sizeof(odw_hit);
-  ctx->hit_count.p = (uint64_t*)ctx->batch_hit_count.p + 2 * (size_t)scene;
+  ctx->hit_count.p = (uint64_t*)ctx->batch_hit_count.p + 4 * (size_t)scene;
   ctx->hit_count.bytes = 2 * sizeof(uint64_t);
   ctx->hit_capacity = ctx->batch_seg_capacity;
   ctx->hit_slots = ctx->batch_seg_slots;
@@ -2162,13 +2190,13 @@ int odw_batch_rows(odw_ctx* ctx, uint64_t* rows, uint64_t* wanted, int32_t n) {
   if (n > ctx->batch_traced) return fail(ctx, ODW_ERR_INVALID, "odw_batch_rows: more scenes than the batch traced");
   if (n == 0) return ODW_OK;
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  std::vector<uint64_t> v(2 * (size_t)n, 0);
+  std::vector<uint64_t> v(4 * (size_t)n, 0);
   HIPCHK(ctx, hipMemcpyAsync(v.data(), ctx->batch_hit_count.p, v.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   for (int k = 0; k < n; ++k) {
-    const uint64_t used = std::min<uint64_t>(v[2 * k], ctx->batch_seg_slots);
-    rows[k] = used > v[2 * k + 1] ? used - v[2 * k + 1] : 0;
-    if (wanted) wanted[k] = v[2 * k];          // slots asked for (above the segment's room: rows were dropped)
+    const uint64_t used = std::min<uint64_t>(v[4 * k], ctx->batch_seg_slots);
+    rows[k] = used > v[4 * k + 1] ? used - v[4 * k + 1] : 0;
+    if (wanted) wanted[k] = v[4 * k];          // slots asked for (above the segment's room: rows were dropped)
   }
   return ODW_OK;
 }

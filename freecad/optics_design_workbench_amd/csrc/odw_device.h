@@ -165,6 +165,12 @@ struct DeviceOutputs {
   odw_segment* segs;                   // ODW_TRACE_RECORD_SEGMENTS (RecordRays sources)
   uint64_t seg_capacity;
   unsigned long long* seg_count;       // rows wanted so far (may exceed the capacity)
+  // batch launches (DeviceBatch): hit_count holds FOUR words per scene -- slots handed out, unused slots, rows of
+  // leaving rays, spare --, and with row_of every recorded row notes its slot at its ray's place in the scene's table
+  // (row_of[scene * row_stride + ray - first_ray], preset to "none" by the host): the ordered selection of the post-hoc
+  // binning (odw_posthoc.hip: ph_mark_kernel) without its pass over the rows
+  uint32_t* row_of;
+  uint64_t row_stride;
 };
 
 // A batch launch (odw_trace_batch): n_scenes scenes of ONE structure -- the same primitives, trimming lists, groups and

@@ -1224,10 +1224,14 @@ __device__ __forceinline__ void record_hit(const PT& P, uint64_t ray, int group,
     // a batch launch (flat kernels): the wave's scene (hit_state[3]) has its own segment of the list and its own counters
     odw_hit* hits = P.out.hits;
     unsigned long long* hit_count = P.out.hit_count;
+    uint32_t* row_of = nullptr;
     if (BLOCKS && P.batch.n_scenes) {
       const uint32_t scene = __builtin_amdgcn_readfirstlane(hit_state[3]);
       hits += (size_t)scene * P.out.hit_capacity;
-      hit_count += 2 * scene;
+      hit_count += 4 * scene;
+      if (P.out.row_of) row_of = P.out.row_of + (size_t)scene * P.out.row_stride;
+      const uint64_t leaving = __ballot(!entering);
+      if (leaving && lane == leader) atomicAdd(hit_count + 2, (unsigned long long)__popcll(leaving));
     }
     if (BLOCKS && P.out.hit_block) {
       // One atomic per wave and append serialises 1.5e6 appends of a launch on a single counter at
@@ -1260,6 +1264,7 @@ __device__ __forceinline__ void record_hit(const PT& P, uint64_t ray, int group,
       __builtin_nontemporal_store((vd2){p.z, d.x}, rw + 1);
       __builtin_nontemporal_store((vd2){d.y, d.z}, rw + 2);
       __builtin_nontemporal_store((vd2){power, __longlong_as_double((long long)tag)}, rw + 3);
+      if (BLOCKS && row_of) row_of[ray - P.first_ray] = (uint32_t)slot;
     } else if (CA) {
       atomicAdd(&cnt[ODW_CNT_HITS_DROPPED * CS], 1u);
     } else {
@@ -1451,7 +1456,7 @@ __device__ __forceinline__ void close_hit_block(const TraceParams& P, volatile u
   if (P.batch.n_scenes) {
     const uint32_t cur = __builtin_amdgcn_readfirstlane(hit_state[3]);
     hits += (size_t)cur * P.out.hit_capacity;
-    hit_count += 2 * cur;
+    hit_count += 4 * cur;
   }
   const uint32_t hit_used = hit_state[2];
   const uint64_t hit_base = ((uint64_t)hit_state[1] << 32) | hit_state[0];

@@ -38,6 +38,120 @@ def _linspace10(start, stop):
   return y
 
 
+def flattestDirection(lib, cloud, angleTol=1e-9):
+  """the plane search of the host `Hits` class with the screen of every grid run by the library
+  (`odw_plane_screen`, outside the interpreter lock -- in a parameter sweep the measuring threads and the baking
+  thread share that lock, and the search was half of a thread's time under it); candidates within rounding of the
+  smallest extent are evaluated the reference's way, as there: same winner bit for bit"""
+  cloud = np.ascontiguousarray(cloud, dtype=np.float64)
+  if cloud.ndim != 2 or cloud.shape[1] != 3 or not len(cloud):
+    return _hits._flattest_direction(cloud, angleTol)
+  pd = C.POINTER(C.c_double)
+  cloud_p, n = cloud.ctypes.data_as(pd), C.c_uint64(len(cloud))
+  margin = 1e-12 * max(float(np.abs(cloud).max()), 1e-300)
+  phis, thetas = np.linspace(0, np.pi, 30), np.linspace(-np.pi / 2, np.pi / 2, 30)
+  while True:
+    cell = (phis[1] - phis[0], thetas[1] - thetas[0])
+    rough = np.empty(len(phis) * len(thetas))
+    if lib.odw_plane_screen(cloud_p, n, phis.ctypes.data_as(pd), C.c_int32(len(phis)), thetas.ctypes.data_as(pd),
+                            C.c_int32(len(thetas)), rough.ctypes.data_as(pd)) != 0:
+      return _hits._flattest_direction(cloud, angleTol)
+    near = np.flatnonzero(rough <= rough.min() + margin)
+    if len(near) == 0:                     # (a cloud with a nan: the host routine's business)
+      return _hits._flattest_direction(cloud, angleTol)
+    k = int(near[0])
+    if len(near) > 1:                      # (one candidate clear of the others: the reference's first minimum is that one)
+      cp, sp, ct, st = np.cos(phis), np.sin(phis), np.cos(thetas), np.sin(thetas)
+      best = None
+      for c in near:
+        i, j = divmod(int(c), len(phis))
+        along = np.dot(cloud, np.array([cp[j] * st[i], sp[j] * st[i], ct[i]]))
+        e = along.max() - along.min()
+        if best is None or e < best:
+          best, k = e, int(c)
+    i, j = divmod(k, len(phis))
+    p, t = phis[j], thetas[i]
+    phis = _linspace10(p - 1.1 * cell[0], p + 1.1 * cell[0])
+    thetas = _linspace10(t - 1.1 * cell[1], t + 1.1 * cell[1])
+    if max(phis[1] - phis[0], thetas[1] - thetas[0]) < angleTol:
+      return np.array([np.cos(p) * np.sin(t), np.sin(p) * np.sin(t), np.cos(t)])
+
+
+
+def flattestDirections(lib, clouds, angleTol=1e-9):
+  """`flattestDirection` for several clouds at once: the searches advance level by level (their grids have the same sizes
+  and shrink alike), every level's screen of all clouds is ONE call into the library, which spreads the clouds over
+  its threads (`odw_plane_screen_batch`).  Cloud by cloud the same result as `flattestDirection`, bit for bit."""
+  clouds = [np.ascontiguousarray(c, dtype=np.float64) for c in clouds]
+  S = len(clouds)
+  out = [None] * S
+  live = [k for k in range(S) if clouds[k].ndim == 2 and clouds[k].shape[1] == 3 and len(clouds[k])]
+  for k in range(S):
+    if k not in live:
+      out[k] = _hits._flattest_direction(clouds[k], angleTol)
+  if not live:
+    return out
+  pd = C.POINTER(C.c_double)
+  ptrs = (pd * len(live))(*[clouds[k].ctypes.data_as(pd) for k in live])
+  counts = np.array([len(clouds[k]) for k in live], dtype=np.uint64)
+  margin = [1e-12 * max(float(np.abs(clouds[k]).max()), 1e-300) for k in live]
+  phis = np.tile(np.linspace(0, np.pi, 30), (len(live), 1))
+  thetas = np.tile(np.linspace(-np.pi / 2, np.pi / 2, 30), (len(live), 1))
+  while True:
+    n_phi, n_theta = phis.shape[1], thetas.shape[1]
+    rough = np.empty((len(live), n_phi * n_theta))
+    if lib.odw_plane_screen_batch(ptrs, counts.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_int32(len(live)), phis.ctypes.data_as(pd),
+                                  C.c_int32(n_phi), thetas.ctypes.data_as(pd), C.c_int32(n_theta), rough.ctypes.data_as(pd)) != 0:
+      for k in live:
+        out[k] = flattestDirection(lib, clouds[k], angleTol)
+      return out
+    # (the bookkeeping of a level for all clouds in a few array operations; clouds whose screen leaves several candidates
+    #  within rounding of the smallest extent are looked at one by one, the reference's way)
+    marg = np.asarray(margin)
+    mask = rough <= (rough.min(axis=1) + marg)[:, None]
+    n_near = mask.sum(axis=1)
+    c_best = mask.argmax(axis=1)
+    for a in np.flatnonzero(n_near != 1):
+      k = live[a]
+      near = np.flatnonzero(mask[a])
+      if len(near) == 0:                     # (a cloud with a nan: the host routine's business)
+        out[k] = _hits._flattest_direction(clouds[k], angleTol)
+        c_best[a] = 0
+        continue
+      ph, th = phis[a], thetas[a]
+      cp, sp, ct, st = np.cos(ph), np.sin(ph), np.cos(th), np.sin(th)
+      best = None
+      for c in near:
+        i, j = divmod(int(c), n_phi)
+        along = np.dot(clouds[k], np.array([cp[j] * st[i], sp[j] * st[i], ct[i]]))
+        e = along.max() - along.min()
+        if best is None or e < best:
+          best, c_best[a] = e, int(c)
+    rows_ = np.arange(len(live))
+    p, t = phis[rows_, c_best % n_phi], thetas[rows_, c_best // n_phi]
+    best_pt = list(zip(p, t))
+    new = []
+    for centre, grid in ((p, phis), (t, thetas)):
+      cl = grid[:, 1] - grid[:, 0]
+      start, stop = centre - 1.1 * cl, centre + 1.1 * cl
+      step = (stop - start) / 9                                  # (_linspace10, row by row)
+      y = _ARANGE10[None, :] * step[:, None]
+      y += start[:, None]
+      y[:, -1] = stop
+      for a in np.flatnonzero(~((step != 0) & np.isfinite(step))):
+        y[a] = np.linspace(start[a], stop[a], 10)
+      new.append(y)
+    new_phis, new_thetas = new
+    phis, thetas = new_phis, new_thetas
+    # (every cloud's grid has the same steps: the searches end together)
+    if max(phis[0, 1] - phis[0, 0], thetas[0, 1] - thetas[0, 0]) < angleTol:
+      for a, k in enumerate(live):
+        if out[k] is None:
+          p, t = best_pt[a]
+          out[k] = np.array([np.cos(p) * np.sin(t), np.sin(p) * np.sin(t), np.cos(t)])
+      return out
+
+
 class DeviceHits:
 
   def __init__(self, tracer, group=None):
@@ -87,43 +201,7 @@ class DeviceHits:
     return planeNormal, _hits._in_plane_x(planeNormal, xInPlaneVec)
 
   def _flattest_direction(self, cloud, angleTol):
-    """the plane search of the host `Hits` class with the screen of every grid run by the library
-    (`odw_plane_screen`, outside the interpreter lock -- in a parameter sweep the measuring threads and the baking
-    thread share that lock, and the search was half of a thread's time under it); candidates within rounding of the
-    smallest extent are evaluated the reference's way, as there: same winner bit for bit"""
-    cloud = np.ascontiguousarray(cloud, dtype=np.float64)
-    if cloud.ndim != 2 or cloud.shape[1] != 3 or not len(cloud):
-      return _hits._flattest_direction(cloud, angleTol)
-    lib = self._tr._lib
-    pd = C.POINTER(C.c_double)
-    cloud_p, n = cloud.ctypes.data_as(pd), C.c_uint64(len(cloud))
-    margin = 1e-12 * max(float(np.abs(cloud).max()), 1e-300)
-    phis, thetas = np.linspace(0, np.pi, 30), np.linspace(-np.pi / 2, np.pi / 2, 30)
-    while True:
-      cell = (phis[1] - phis[0], thetas[1] - thetas[0])
-      rough = np.empty(len(phis) * len(thetas))
-      if lib.odw_plane_screen(cloud_p, n, phis.ctypes.data_as(pd), C.c_int32(len(phis)), thetas.ctypes.data_as(pd),
-                              C.c_int32(len(thetas)), rough.ctypes.data_as(pd)) != 0:
-        return _hits._flattest_direction(cloud, angleTol)
-      near = np.flatnonzero(rough <= rough.min() + margin)
-      if len(near) == 0:                     # (a cloud with a nan: the host routine's business)
-        return _hits._flattest_direction(cloud, angleTol)
-      k = int(near[0])
-      if len(near) > 1:                      # (one candidate clear of the others: the reference's first minimum is that one)
-        cp, sp, ct, st = np.cos(phis), np.sin(phis), np.cos(thetas), np.sin(thetas)
-        best = None
-        for c in near:
-          i, j = divmod(int(c), len(phis))
-          along = np.dot(cloud, np.array([cp[j] * st[i], sp[j] * st[i], ct[i]]))
-          e = along.max() - along.min()
-          if best is None or e < best:
-            best, k = e, int(c)
-      i, j = divmod(k, len(phis))
-      p, t = phis[j], thetas[i]
-      phis = _linspace10(p - 1.1 * cell[0], p + 1.1 * cell[0])
-      thetas = _linspace10(t - 1.1 * cell[1], t + 1.1 * cell[1])
-      if max(phis[1] - phis[0], thetas[1] - thetas[0]) < angleTol:
-        return np.array([np.cos(p) * np.sin(t), np.sin(p) * np.sin(t), np.cos(t)])
+    return flattestDirection(self._tr._lib, cloud, angleTol)
 
   def histogram(self, planeNormal=None, xInPlaneVec=None, key='points', origin=None, radius=None,
                 binCoords='cartesian', **kwargs):
@@ -228,3 +306,140 @@ class DeviceHits:
 
   def isEntering(self):
     return self.toHits().isEntering()
+
+
+class DeviceHitsBatch:
+  """the segments of a batch launch (`Tracer.traceBatch`), measured together: every step of `DeviceHits.histogram` --
+  ordered selection, the thinned sample, [the plane search, on the host, scene by scene], projection + medians +
+  moments, binning -- runs for all scenes back to back on the device and is waited for once (`odw_batch_hits_*`).
+  Scene by scene the results are those of `DeviceHits` on that scene's segment, bit for bit.  A scene the batch route
+  cannot serve (`ordered[k]` False: a ray with two selected rows, a mixed list of entering and leaving rows) yields
+  None and is measured through `Tracer.batchSelect(k)` + `DeviceHits`."""
+
+  def __init__(self, tracer, n_scenes, group=None):
+    self._tr = tracer
+    self._S = int(n_scenes)
+    if isinstance(group, str):
+      group = tracer.scene.group_index(group)
+    self._group = -1 if group is None else int(group)
+    n, leaving = np.zeros(self._S, dtype=np.uint64), np.zeros(self._S, dtype=np.uint64)
+    ordered = np.zeros(self._S, dtype=np.int32)
+    pu = C.POINTER(C.c_uint64)
+    tracer._chk(tracer._lib.odw_batch_hits_select(tracer._ctx, C.c_int32(self._group), n.ctypes.data_as(pu),
+                                                  leaving.ctypes.data_as(pu), ordered.ctypes.data_as(C.POINTER(C.c_int32))),
+                'odw_batch_hits_select')
+    self.rows = [int(v) for v in n]
+    self.leaving = [int(v) for v in leaving]
+    self.ordered = [bool(v) and r > 0 for v, r in zip(ordered, self.rows)]
+    self._planes = None          # per scene (planeNormal, xInPlaneVec), automatic choice
+    self._projected = None       # (stats [S][8], moments [S][6]) of the automatic planes
+
+  def __len__(self):
+    return self._S
+
+  def _detectPlanes(self):
+    if self._planes is None:
+      tr = self._tr
+      cap = _THIN + 8
+      rows = np.zeros((self._S, cap), dtype=_native.HIT_DTYPE)
+      counts = np.zeros(self._S, dtype=np.uint64)
+      tr._chk(tr._lib.odw_batch_hits_sample(tr._ctx, C.c_uint64(_THIN), None, rows.ctypes.data_as(C.c_void_p), C.c_uint64(cap),
+                                            counts.ctypes.data_as(C.POINTER(C.c_uint64))), 'odw_batch_hits_sample')
+      clouds = [rows[k, :int(counts[k])]['point'] if self.ordered[k] else np.zeros((0, 3)) for k in range(self._S)]
+      normals = flattestDirections(tr._lib, [c for k, c in enumerate(clouds) if self.ordered[k]])
+      planes, it = [], iter(normals)
+      for k in range(self._S):
+        if not self.ordered[k]:
+          planes.append(None)
+          continue
+        normal = _hits._against(next(it), rows[k, :int(counts[k])]['direction'])
+        planes.append((normal, _hits._in_plane_x(normal, None)))
+      self._planes = planes
+    return self._planes
+
+  def _project(self):
+    if self._projected is None:
+      planes = self._detectPlanes()
+      tr = self._tr
+      ex, ey = np.zeros((self._S, 3)), np.zeros((self._S, 3))
+      skip = np.ones(self._S, dtype=np.int32)
+      for k, pl in enumerate(planes):
+        if pl is None:
+          continue
+        normal, xvec = pl
+        x = np.asarray(xvec, dtype=np.float64)
+        y = np.cross(normal, xvec)
+        ex[k], ey[k] = x / np.linalg.norm(x), y / np.linalg.norm(y)
+        skip[k] = 0
+      stats, moments = np.zeros((self._S, 8)), np.zeros((self._S, 6))
+      pd = C.POINTER(C.c_double)
+      tr._chk(tr._lib.odw_batch_hits_project(tr._ctx, ex.ctypes.data_as(pd), ey.ctypes.data_as(pd),
+                                             skip.ctypes.data_as(C.POINTER(C.c_int32)), stats.ctypes.data_as(pd),
+                                             moments.ctypes.data_as(pd)), 'odw_batch_hits_project')
+      self._projected = (stats, moments)
+    return self._projected
+
+  def histograms(self, binCoords='cartesian', bins=10, **kwargs):
+    """per scene `DeviceHits.histogram(binCoords=..., bins=...)` with the automatic plane and the median origin, or None
+    where the scene (or the request: integer bin counts, `radius`, a given plane or origin, directions) takes the
+    per-segment route"""
+    if kwargs:
+      return [None] * self._S
+    mode = binCoords.lower()
+    if mode in 'cartesian':
+      polar = False
+    elif mode in 'polar':
+      polar = True
+    else:
+      raise ValueError(f'found invalid binCoord mode {binCoords!r}, expect one of "cartesian" or "polar"')
+    try:
+      n = len(bins)
+    except TypeError:
+      return [None] * self._S
+    if n != 2 or np.ndim(bins[0]) == 0 or np.ndim(bins[1]) == 0:
+      return [None] * self._S
+    edges = [np.ascontiguousarray(b, dtype=np.float64) for b in bins]
+    for e in edges:
+      if e.ndim != 1 or len(e) < 2 or np.any(e[:-1] > e[1:]):
+        raise ValueError('`bins` must be 1d and increase monotonically, when an array')
+    stats, _ = self._project()
+    planes = self._detectPlanes()
+    origins = np.zeros((self._S, 2))
+    for k in range(self._S):
+      if planes[k] is not None:
+        origins[k] = (np.mean(stats[k, 0:2]), np.mean(stats[k, 4:6]))       # numpy.median: the mean of the two middle ones
+    nb = (len(edges[0]) - 1) * (len(edges[1]) - 1)
+    counts = np.zeros((self._S, nb), dtype=np.uint64)
+    tr = self._tr
+    pd = C.POINTER(C.c_double)
+    tr._chk(tr._lib.odw_batch_hits_bin(tr._ctx, C.c_int32(1 if polar else 0), origins.ctypes.data_as(pd),
+                                       edges[0].ctypes.data_as(pd), C.c_int32(len(edges[0])), edges[1].ctypes.data_as(pd),
+                                       C.c_int32(len(edges[1])), counts.ctypes.data_as(C.POINTER(C.c_uint64))), 'odw_batch_hits_bin')
+    out = []
+    for k in range(self._S):
+      if planes[k] is None:
+        out.append(None)
+        continue
+      hist = counts[k].reshape(len(edges[0]) - 1, len(edges[1]) - 1).astype(np.float64)
+      out.append(Histogram.fromBinned(hist, edges[0], edges[1], planes[k][0], planes[k][1], origins[k].copy(),
+                                      'polar' if polar else 'cartesian'))
+    return out
+
+  def thinned(self, count):
+    """per scene the rows [::max(1, n // count)] of the selection in (ray, bounce) order -- what `points[::k]` picks from
+    the arrays `loadHits()` returns --, as HIT_DTYPE arrays; None where the scene takes the per-segment route"""
+    tr = self._tr
+    strides = np.array([max(1, r // int(count)) for r in self.rows], dtype=np.uint64)
+    cap = max([-(-r // int(st)) for r, st in zip(self.rows, strides)] + [1])
+    rows = np.zeros((self._S, cap), dtype=_native.HIT_DTYPE)
+    counts = np.zeros(self._S, dtype=np.uint64)
+    pu = C.POINTER(C.c_uint64)
+    tr._chk(tr._lib.odw_batch_hits_sample(tr._ctx, C.c_uint64(0), strides.ctypes.data_as(pu), rows.ctypes.data_as(C.c_void_p),
+                                          C.c_uint64(cap), counts.ctypes.data_as(pu)), 'odw_batch_hits_sample')
+    return [rows[k, :int(counts[k])].copy() if self.ordered[k] else None for k in range(self._S)]
+
+  def moments(self):
+    """per scene (mean (3,), variance (3,)) of the points, or None"""
+    _, mom = self._project()
+    planes = self._detectPlanes()
+    return [None if planes[k] is None else (mom[k, :3].copy(), mom[k, 3:].copy()) for k in range(self._S)]

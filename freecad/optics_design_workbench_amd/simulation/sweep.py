@@ -32,15 +32,21 @@ from .tracer import Tracer, hitsToDict
 DEFAULT_SEED = 0x0D15EA5E
 
 
+_FWHM_BINS = dict(binCoords='polar', bins=[np.arange(0, 2 * np.pi, np.pi / 2), np.geomspace(1e-3, 5, 500)])
+
+
 def calcFwhm(hits):
   """spot FWHM of a hit cloud: `calcFwhm` of optimize-spotsize.ipynb cell 8, statement by
   statement -- polar histogram with bins [arange(0, 2 pi, pi/2), geomspace(1e-3, 5, 500)], per
   azimuth bin a straight-line fit of log(density) over log(r) through the first ten non-empty
   radial bins, FWHM = the smallest radius of the fitted line at or below half the peak density;
   mean over the azimuth bins that received hits (nan if none did)"""
+  return _fwhmOfPolarHistogram(hits.histogram(**_FWHM_BINS))
+
+
+def _fwhmOfPolarHistogram(polarHist):
+  """cell 8 from `phis, r, hists = polarHist.byAzimuth()` on"""
   fwhmList = []
-  polarHist = hits.histogram(binCoords='polar',
-                             bins=[np.arange(0, 2 * np.pi, np.pi / 2), np.geomspace(1e-3, 5, 500)])
   phis, r, hists = polarHist.byAzimuth()
   for phi, dens in zip(phis, hists):
     if max(dens) > 0:
@@ -61,6 +67,12 @@ def calcFwhm(hits):
   return np.mean(fwhmList) if len(fwhmList) else np.nan
 
 
+# a measure may carry `batched(DeviceHitsBatch) -> list`: its values for all scenes of a batch launch at once (None
+# where a scene has to be measured by itself) -- parameterSweep then waits for the GPU once per step and batch
+# instead of once per step and value
+calcFwhm.batched = lambda batch: [None if H is None else _fwhmOfPolarHistogram(H) for H in batch.histograms(**_FWHM_BINS)]
+
+
 def rmsSpot(hits):
   """rms distance of the hits from their centroid: a figure of merit that stays defined where the
   notebook's calcFwhm is not (with 1e7 hits the innermost ten radial bins are all filled and flat:
@@ -70,6 +82,40 @@ def rmsSpot(hits):
     return hits.rmsSpot()                 # DeviceHits: second moments on the device
   p = hits.points()
   return float(np.sqrt(((p - p.mean(axis=0))**2).sum(axis=1).mean())) if len(p) else np.nan
+
+
+rmsSpot.batched = lambda batch: [None if m is None else float(np.sqrt(m[1].sum())) for m in batch.moments()]
+
+
+def _rowsToDict(rows):
+  return dict(points=np.ascontiguousarray(rows['point']), directions=np.ascontiguousarray(rows['direction']),
+              powers=np.ascontiguousarray(rows['power']), isEntering=(rows['tag'] >> np.uint64(63)).astype(np.int64))
+
+
+def _thinnedRows(hits, count):
+  """`[::max(1, n // count)]` of a run's hit arrays (in the order `loadHits()` returns them: by ray, then bounce)"""
+  if hasattr(hits, 'thinned'):
+    return _rowsToDict(hits.thinned(count))              # DeviceHits: gathered on the device
+  k = max(1, len(hits) // int(count))
+  return dict(points=hits.points()[::k].copy(), directions=hits.directions()[::k].copy(),
+              powers=np.asarray(hits.hits['powers'])[::k].copy(), isEntering=np.asarray(hits.isEntering())[::k].copy())
+
+
+def fwhmOfSamples(result, dist=None, device=0, measure=None):
+  """`calcFwhm` (or `measure`) of the thinned samples a sweep kept (`keepSample`): the notebook's figure of merit on
+  the notebook's own sample size.  Every rank evaluates the samples of the values it ran; one all-reduce gives every
+  rank the whole column (nan where a value has no sample or the notebook's arithmetic raises)."""
+  measure = measure or calcFwhm
+  ranks = parallel.Ranks.detect(dist, device)
+  col = np.zeros((len(result.values), 2))
+  for k, d in result.samples.items():
+    try:
+      m = float(measure(Hits(d)))
+    except ValueError:                 # (cell 8 raises where an azimuth bin holds no radial bin above 10 counts)
+      m = np.nan
+    col[k] = (0.0, 2.0) if np.isnan(m) else (m, 1.0)
+  col = np.asarray(ranks.sumFloats(col.ravel())).reshape(col.shape)
+  return np.where(col[:, 1] == 1, col[:, 0], np.nan)
 
 
 def shareOfRank(n_values, rank, world):
@@ -90,7 +136,8 @@ class SweepResult:
   """values, one column of results per figure of merit (nan where a run produced none), and what
   the runs traced.  `results` is the first (or only) column."""
 
-  def __init__(self, values, columns, tracedRays, recordedHits, segments):
+  def __init__(self, values, columns, tracedRays, recordedHits, segments, samples=None):
+    self.samples = samples or {}      # value index -> thinned hit rows of this rank's own values (keepSample)
     self.values = np.asarray(values, dtype=np.float64)
     self.columns = {k: np.asarray(v, dtype=np.float64) for k, v in columns.items()}
     self.results = next(iter(self.columns.values()))
@@ -104,7 +151,8 @@ class SweepResult:
 
 
 def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAULT_SEED, device=0,
-                   dist=None, tracer=None, source=None, deviceHits=True, pipeline=True, batch=8, **traceKwargs):
+                   dist=None, tracer=None, source=None, deviceHits=True, pipeline=True, batch=12, keepSample=None,
+                   **traceKwargs):
   """run `rays` true-random rays for every entry of `values` and return a SweepResult.
 
   setValue(doc, value)   applies one parameter value (e.g. `doc.Sphere.Radius = value`)
@@ -120,6 +168,9 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
                          one structure side by side in HBM, `Tracer.traceBatch`; the rows of a value are those of a launch of
                          its own); values whose scenes differ in structure, or that the flat kernels do not take, are traced
                          one by one; 0 / 1: always one by one
+  keepSample             an integer N: the rows `[::max(1, n // N)]` of every value's hit list (the sample a notebook that
+                         traces N rays per value works on) are kept in `SweepResult.samples` on the rank that ran the value
+                         (`fwhmOfSamples` turns them into a column)
   pipeline               with deviceHits on a device tracer: further contexts on the same GPU (True: two), so
                          that value k + 1 is baked and traced while values k and k - 1 are measured (same
                          results); an integer n: n extra contexts (n measuring threads)
@@ -152,7 +203,7 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
     #  one thread read 243 - 338 ms per 64 x 1e7 sweep from run to run, two 248 - 273, three 247 - 264)
     # (the extra contexts stay with the tracer between sweeps: creating them costs ~12 ms, a rank's share of a sweep
     #  dealt out over eight GPUs takes 30)
-    want = min(int(pipeline) if pipeline is not True else 2, len(mine) - 1, 5)
+    want = min(int(pipeline) if pipeline is not True else 3, len(mine) - 1, 5)
     kept = [e for e in (getattr(tr, '_sweepLanes', None) or [])
             if e.referenceStrict == tr.referenceStrict and e.compileMode() == tr.compileMode()]
     while len(kept) < want:
@@ -173,6 +224,8 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
     pool = ThreadPoolExecutor(max_workers=len(lanes), thread_name_prefix='odw-sweep-measure')
   pending = [None] * len(lanes)
   batch_ok = [True]
+  samples = {}
+  tail_size = [None]
 
   def measureInto(t, scene, k):
     t_m = time.perf_counter() if clock is not None else 0.0
@@ -194,9 +247,17 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
     for j, name in enumerate(names):
       m = float(measures[name](hits)) if len(hits) else np.nan
       table[k, j] = (0.0, 2.0) if np.isnan(m) else (m, 1.0)
+    if keepSample and len(hits):
+      samples[k] = _thinnedRows(hits, int(keepSample))
 
   clock = dict(wait=0.0, bake=0.0, trace=0.0, measure=0.0) if os.environ.get('ODW_SWEEP_TIMING') else None
   import threading
+  timeline = [] if os.environ.get('ODW_SWEEP_TRACE') else None
+  t_sweep = time.perf_counter()
+
+  def mark(what, t0):
+    if timeline is not None:
+      timeline.append((threading.current_thread().name[-12:], what, 1e3 * (t0 - t_sweep), 1e3 * (time.perf_counter() - t_sweep)))
   totals_lock = threading.Lock()
 
   def bakeValue(k):
@@ -255,7 +316,9 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
     """the rows of a batch launch, segment by segment (runs on a measuring thread; the launch is still under way when
     it starts)"""
     while True:
+      t_w = time.perf_counter()
       t.sync()
+      mark(f'wait-trace {ks[0]}', t_w)
       cnt = t.counters()
       Tracer.raiseForRayErrors(cnt)
       if not cnt['hits_dropped']:
@@ -266,12 +329,50 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
       t.traceBatch(0, int(rays), seed, capacity)
     with totals_lock:
       totals[:] += (cnt['traced_rays'], cnt['recorded_hits'], cnt['segments'])
+    t_m = time.perf_counter() if clock is not None else 0.0
     try:
+      from .device_hits import DeviceHitsBatch
+      together = {}
+      batch_hits = None
+      if any(hasattr(measures[name], 'batched') for name in names):
+        t_s = time.perf_counter()
+        batch_hits = DeviceHitsBatch(t, len(ks))
+        mark(f'select {ks[0]}', t_s)
+        if timeline is not None:
+          t_s = time.perf_counter(); batch_hits._detectPlanes(); mark(f'planes {ks[0]}', t_s)
+          t_s = time.perf_counter(); batch_hits._project(); mark(f'project {ks[0]}', t_s)
+        for name in names:
+          if hasattr(measures[name], 'batched'):
+            t_s = time.perf_counter()
+            together[name] = measures[name].batched(batch_hits)
+            mark(f'{name} {ks[0]}', t_s)
+      kept = batch_hits.thinned(int(keepSample)) if (keepSample and batch_hits is not None) else None
       for j, k in enumerate(ks):
-        t.batchSelect(j)
-        measureInto(t, scenes[j], k)
+        own_hits = None
+        if keepSample:
+          if kept is not None and kept[j] is not None:
+            if len(kept[j]):
+              samples[k] = _rowsToDict(kept[j])
+          else:
+            t.batchSelect(j)
+            own_hits = t.deviceHits()
+            if len(own_hits):
+              samples[k] = _thinnedRows(own_hits, int(keepSample))
+        for i, name in enumerate(names):
+          m = together[name][j] if name in together else None
+          if batch_hits is not None and batch_hits.rows[j] == 0:
+            m = np.nan
+          elif m is None:                     # this measure, or this scene, goes segment by segment
+            if own_hits is None:
+              t.batchSelect(j)
+              own_hits = t.deviceHits()
+            m = float(measures[name](own_hits)) if len(own_hits) else np.nan
+          m = float(m)
+          table[k, i] = (0.0, 2.0) if np.isnan(m) else (m, 1.0)
     finally:
       t.batchSelect(None)
+      if clock is not None:
+        clock['measure'] += time.perf_counter() - t_m
 
   # Batch launches (Tracer.setSceneBatch / traceBatch): the values a context gets at a time are baked together and traced
   # by ONE launch -- their scenes differ in numbers only --, each into its own segment of the hit list; a measuring thread
@@ -287,7 +388,13 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
   try:
     pos, turn = 0, 0
     while pos < len(mine):
-      ks = mine[pos:pos + group_size]
+      # (the first groups are small, so that the measuring threads have rows early; the last ones shrink, so that the
+      #  contexts end together instead of one of them measuring a full group alone)
+      left = len(mine) - pos
+      if group_size > 2 and tail_size[0] is None and left < group_size * len(lanes):
+        tail_size[0] = max(2, -(-left // len(lanes)))
+      size = group_size if group_size <= 2 else min(group_size, 2 << turn if turn < 3 else group_size, tail_size[0] or group_size)
+      ks = mine[pos:pos + size]
       lane = turn % len(lanes)
       turn += 1
       if len(ks) == 1 or not batch_ok[0]:
@@ -305,6 +412,7 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
       t1 = time.perf_counter()
       baked = [bakeValue(k) for k in ks]
       t2 = time.perf_counter()
+      mark(f'bake {ks[0]}', t1)
       same = all(b[2] == baked[0][2] and _sourceKey(b[1]) == _sourceKey(baked[0][1]) for b in baked[1:])
       launched = False
       if same:
@@ -316,6 +424,7 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
           t.reset()
           t.traceBatch(0, int(rays), seed, capacity)
           launched = True
+          mark(f'upload+launch {ks[0]}', t2)
         except _native.NativeError as e:
           if 'unsupported' not in str(e):
             raise
@@ -343,6 +452,10 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
       pool.shutdown(wait=True)
     if own:
       tr.close()                       # (with its extra contexts)
+  if timeline is not None:
+    for row in sorted(timeline, key=lambda r: r[2]):
+      print('[odw sweep trace] %-12s %-22s %8.2f -> %8.2f  (%6.2f)' % (row[0], row[1], row[2], row[3], row[3] - row[2]), file=sys.stderr)
+    print('[odw sweep trace] total %.2f ms' % (1e3 * (time.perf_counter() - t_sweep)), file=sys.stderr, flush=True)
   if clock is not None:
     print('[odw sweep timing] ms per value: ' + ', '.join(f'{k} {1e3 * v / max(len(mine), 1):.2f}' for k, v in clock.items()),
           file=sys.stderr, flush=True)
@@ -352,4 +465,4 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
     raise RuntimeError('parameter sweep: some values were run by no rank or by several')
   results = np.where(table[..., 1] == 1, table[..., 0], np.nan)
   t = [int(round(v)) for v in flat[table.size:]]
-  return SweepResult(values, {name: results[:, j] for j, name in enumerate(names)}, *t)
+  return SweepResult(values, {name: results[:, j] for j, name in enumerate(names)}, *t, samples=samples)

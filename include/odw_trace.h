@@ -472,6 +472,11 @@ int odw_hits_moments(odw_ctx* ctx, double* mean, double* var);
  * device work; thread-safe (the measuring threads of a parameter sweep call it without the interpreter lock).   */
 int odw_plane_screen(const double* cloud, uint64_t n, const double* phis, int32_t n_phi, const double* thetas, int32_t n_theta,
                      double* extent);
+/* the same for n_clouds clouds at once, each with its own grid of the same size (phis [n_clouds][n_phi], thetas
+ * [n_clouds][n_theta], extent [n_clouds][n_theta * n_phi]), on a few threads of the library: the plane searches of the
+ * scenes of a batch launch advance level by level, one call per level (v9)                                        */
+int odw_plane_screen_batch(const double* const* clouds, const uint64_t* n, int32_t n_clouds, const double* phis, int32_t n_phi,
+                           const double* thetas, int32_t n_theta, double* extent);
 
 /* scene-compiled kernels -------------------------------------------------------
  * The reference prepares a scene once per run and reuses it for every ray
@@ -536,6 +541,24 @@ int odw_trace_batch(odw_ctx* ctx, uint64_t first_ray, uint64_t rays_per_scene, u
                     uint64_t rows_per_scene);
 int odw_batch_select(odw_ctx* ctx, int32_t scene);
 int odw_batch_rows(odw_ctx* ctx, uint64_t* rows, uint64_t* wanted, int32_t n);
+/* The post-hoc steps (odw_hits_select / gather / project / bin / moments:
+ * Hits.histogram, jupyter_utils/hits.py:96-193, histogram.py:24-57) for ALL
+ * segments of the last odw_trace_batch at once: the same kernels per segment,
+ * ONE synchronisation per step for the whole batch; arrays are indexed by
+ * scene.  ordered[s] = 0: scene s needs the per-segment calls (a ray with two
+ * selected rows, or a sample that needs the entering rows of a mixed list).
+ * sample: rows [::strides[s]] if strides are given, else
+ * points[::1 + n / limit] (their directions are the sample's
+ * directions: every row enters, or leaving rows are the majority), [S][cap].
+ * project: key = points; stats [S][8] as odw_hits_project, moments [S][6] =
+ * mean (3), variance (3) as odw_hits_moments; skip[s] != 0 leaves a scene out.
+ * bin: the same edges for all scenes, each about its own origin [S][2];
+ * counts [S][(n_a - 1) (n_b - 1)].                                           */
+int odw_batch_hits_select(odw_ctx* ctx, int32_t group, uint64_t* n_rows, uint64_t* n_leaving, int32_t* ordered);
+int odw_batch_hits_sample(odw_ctx* ctx, uint64_t limit, const uint64_t* strides, odw_hit* rows, uint64_t cap, uint64_t* n_out);
+int odw_batch_hits_project(odw_ctx* ctx, const double* ex, const double* ey, const int32_t* skip, double* stats, double* moments);
+int odw_batch_hits_bin(odw_ctx* ctx, int32_t polar, const double* origins, const double* edges_a, int32_t n_a,
+                       const double* edges_b, int32_t n_b, uint64_t* counts);
 
 /* device-side handles for collectives (RCCL reduce through torch).  The
  * counters and the detector histogram live in ONE block of 64-bit words,

@@ -153,3 +153,40 @@ def test_sweep_with_batch_launches_equals_the_sweep_value_by_value(native_lib):
     assert (res[batch].tracedRays, res[batch].recordedHits, res[batch].segments) == \
            (res[0].tracedRays, res[0].recordedHits, res[0].segments)
   assert res[0].tracedRays == 19 * 200_000 and np.isfinite(res[0].columns['rms']).all()
+
+
+def test_batched_measure_equals_the_measure_segment_by_segment(tracer):
+  """DeviceHitsBatch: selection, thinned sample, plane search, projection + medians + moments and binning of all
+  segments step by step -- the Histogram of every scene (plane, origin, edges, counts), its moments and the notebook's
+  FWHM are those of DeviceHits on that scene's segment alone"""
+  from freecad.optics_design_workbench_amd.simulation import sweep
+  from freecad.optics_design_workbench_amd.simulation.device_hits import DeviceHitsBatch
+  prs = _projects([9.2, 9.8, 10.0, 10.3, 10.9])
+  n, cap = 400_000, 401_024
+  tracer.setLimits(prs[0].limits)
+  tracer.setSource(prs[0].source)
+  tracer.setSceneBatch([pr.scene for pr in prs])
+  tracer.reset()
+  tracer.traceBatch(0, n, SEED, cap)
+  tracer.sync()
+  b = DeviceHitsBatch(tracer, len(prs))
+  assert all(b.ordered) and len(b) == 5
+  kw = dict(binCoords='polar', bins=[np.arange(0, 2 * np.pi, np.pi / 2), np.geomspace(1e-3, 5, 500)])
+  cart = dict(binCoords='cartesian', bins=[np.linspace(-.05, .05, 100), np.linspace(-.05, .05, 100)])
+  polar, boxes, moments = b.histograms(**kw), b.histograms(**cart), b.moments()
+  fw, rms = sweep.calcFwhm.batched(b), sweep.rmsSpot.batched(b)
+  assert b.histograms(bins=30) == [None] * 5                    # (integer bin counts: the per-segment route)
+  for k in range(len(prs)):
+    tracer.batchSelect(k)
+    h = tracer.deviceHits()
+    assert len(h) == b.rows[k]
+    for got, args in ((polar[k], kw), (boxes[k], cart)):
+      want = h.histogram(**args)
+      assert np.array_equal(got.hist, want.hist) and np.array_equal(got._origin, want._origin)
+      assert np.array_equal(got._planeNormal, want._planeNormal) and np.array_equal(got._xInPlaneVec, want._xInPlaneVec)
+      assert np.array_equal(got.binX, want.binX) and np.array_equal(got.binY, want.binY)
+    mean, var = h.moments()
+    assert np.array_equal(moments[k][0], mean) and np.array_equal(moments[k][1], var)
+    assert fw[k] == sweep.calcFwhm(h) or (np.isnan(fw[k]) and np.isnan(sweep.calcFwhm(h)))
+    assert rms[k] == sweep.rmsSpot(h)
+  tracer.batchSelect(None)

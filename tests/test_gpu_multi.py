@@ -157,6 +157,9 @@ def test_bench_config_lines_c4_and_c5(native_lib):
   assert out['config']['name'] == 'c5' and out['scaling'] == 'strong' and len(spot['fwhm_mm']) == 6
   assert all(v is None or v > 0 for v in spot['fwhm_mm']) and any(v is not None for v in spot['fwhm_mm'])
   assert all(v > 0 for v in spot['rms_spot_mm']) and 9 <= spot['best_radius_by_rms_mm'] <= 11
+  # the notebook's estimator on the notebook's sample size (rows [::n // 1000] of every radius)
+  assert len(spot['fwhm_1e3_mm']) == 6 and all(v is None or v > 0 for v in spot['fwhm_1e3_mm'])
+  assert 9 <= spot['best_radius_by_fwhm_1e3_mm'] <= 11
 
 
 def test_default_bench_line_carries_the_three_gpu_configs(native_lib):
@@ -180,6 +183,14 @@ def test_default_bench_line_carries_the_three_gpu_configs(native_lib):
       assert 50 < clock['sclk_mhz_min'] <= clock['sclk_mhz_mean'] <= clock['sclk_mhz_max'] <= 1.05 * clock['peak_mhz'], clock
   assert lines['c4']['value'] > 3e9 and lines['c4']['roofline']['valu']['active_lanes_per_inst'] > 25
   assert lines['c5']['value'] > 5e8 and lines['c5']['steps'] == 2
+  # the same figures as plain numbers in `config` (what a reader that keeps only scalars still finds), a short line
+  for name in ('c4', 'c5'):
+    assert out['config'][f'{name}_value'] == lines[name]['value'] and out['config'][f'{name}_ms_per_step'] == lines[name]['ms_per_step']
+    assert out['config'][f'{name}_roofline_frac'] == lines[name]['roofline']['frac']
+  assert out['config']['c4_active_lanes_per_inst'] > 25
+  # c5 at full size: the notebook's FWHM on its own sample size finds the valley the reference's stored curve has
+  # (optimize-spotsize.ipynb cell 10: below 3e-3 mm from R = 9.76 to 10.24; the shipped file holds 9.83)
+  assert 9.7 <= out['config']['c5_best_radius_by_fwhm_1e3_mm'] <= 10.3
 
 
 @two_ranks
@@ -200,6 +211,7 @@ def test_bench_on_two_gpus_reports_two_gpus(native_lib):
   assert t2['n_gpus'] == 2 and t2['scaling'] == 'strong'
   assert t2['config']['spot_size']['fwhm_mm'] == t1['fwhm_mm']
   assert t2['config']['spot_size']['rms_spot_mm'] == t1['rms_spot_mm']
+  assert t2['config']['spot_size']['fwhm_1e3_mm'] == t1['fwhm_1e3_mm']
 
 
 # The driver's 8-GPU node: BASELINE configs[3] and [4] as they are quoted -- 1e9 hugeArray rays over eight ranks with one
@@ -251,7 +263,7 @@ def test_c5_on_eight_gpus_equals_one_gpu(native_lib):
   t8 = _line(_bench('--gpus', '8', *args, timeout=1500))
   t1 = _line(_bench('--gpus', '1', *args, timeout=1500))
   assert t8['n_gpus'] == 8 and t8['scaling'] == 'strong' and t8['config']['radii'] == 64
-  for col in ('fwhm_mm', 'rms_spot_mm'):
+  for col in ('fwhm_mm', 'rms_spot_mm', 'fwhm_1e3_mm'):
     assert t8['config']['spot_size'][col] == t1['config']['spot_size'][col], col
   assert t8['config']['spot_size']['best_radius_by_rms_mm'] == t1['config']['spot_size']['best_radius_by_rms_mm']
 

@@ -76,6 +76,30 @@ def _sweep(tracer, radii, rays, dist=None):
   return sweep.parameterSweep(doc, setRadius, radii, rays=rays, seed=7, tracer=tracer, dist=dist, deviceHits=False)
 
 
+def test_sweep_keeps_the_notebook_sized_sample(oracle):
+  """keepSample = N: the rows [::n // N] of every value, and calcFwhm of them (fwhmOfSamples) = the notebook's
+  figure of merit on the sample size the notebook traces (optimize-spotsize.ipynb cell 9: EndAfterRays = 1e3)"""
+  from oracle_tracer import OracleTracer
+  from freecad.optics_design_workbench_amd.scene import open_fcstd
+  doc = open_fcstd(os.path.join(SCENES, 'GettingStarted.FCStd'))
+
+  def setRadius(d, r):
+    d.Sphere.Radius = r
+  radii = np.linspace(9.2, 10.8, 5)
+  tr = OracleTracer(nthreads=4)
+  res = sweep.parameterSweep(doc, setRadius, radii, rays=30000, seed=7, tracer=tr, deviceHits=False, keepSample=1000)
+  assert sorted(res.samples) == [0, 1, 2, 3, 4]
+  col = sweep.fwhmOfSamples(res)
+  assert np.isfinite(col).all() and col[2] < col[0] and col[2] < col[4]         # smallest near R = 10
+  # by hand for one value: the hits of that value, thinned as a notebook would (points[::k])
+  setRadius(doc, radii[1])
+  one = sweep.parameterSweep(doc, lambda d, v: None, [0.0], rays=30000, seed=7, tracer=tr, deviceHits=False,
+                             measure=lambda h: float(len(h)))
+  n = int(one.results[0])
+  k = max(1, n // 1000)
+  assert len(res.samples[1]['points']) == -(-n // k) and 1000 <= len(res.samples[1]['points']) <= 1100
+
+
 def test_radius_sweep_single_process(oracle):
   from oracle_tracer import OracleTracer
   radii = np.linspace(9, 11, 5)
