@@ -486,8 +486,12 @@ def run_sweep_config(args, cfg, rank, local_rank, world, dist, torch):
   for _ in range(args.warmup):
     run()
   barrier()
-  tr.timingEnable(True)
-  tr.timingRead()
+
+  def contexts():       # the tracer and the contexts the sweep keeps beside it (groups of radii take turns on them)
+    return [tr] + list(getattr(tr, '_sweepLanes', None) or [])
+  for t in contexts():
+    t.timingEnable(True)
+    t.timingRead()
   barrier()
   sampler = ClockSampler(torch, local_rank)
   sampler.start()
@@ -497,7 +501,13 @@ def run_sweep_config(args, cfg, rank, local_rank, world, dist, torch):
   barrier()
   dt = time.perf_counter() - t0
   clock = sampler.stop()
-  kernel_ms, launches = tr.timingRead()
+  # trace kernels of this rank, all contexts: a launch traces a GROUP of radii (batch launches); per radius = per 1e7 rays
+  kernel_ms, launches = 0.0, 0
+  for t in contexts():
+    ms, n = t.timingRead()
+    kernel_ms += ms
+    launches += n
+  radii_of_rank = len(sweep.shareOfRank(len(radii), rank, world)) * args.steps
   if dist is not None:
     t = torch.tensor([dt], dtype=torch.float64, device='cuda')
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -512,7 +522,7 @@ def run_sweep_config(args, cfg, rank, local_rank, world, dist, torch):
     kbar = res.segments / res.tracedRays
     hbar = res.recordedHits / res.tracedRays
     bytes_per_ray = kbar * 2 * RAY_STATE_BYTES + hbar * HIT_BYTES
-    avg_kernel_s = kernel_ms / 1e3 / max(1, launches)
+    avg_kernel_s = kernel_ms / 1e3 / max(1, radii_of_rank)        # per radius (a launch holds several)
     info = tr.compiledInfo()             # the kernel the last radius ran
     kernel_name = 'odw_spec_kernel' if info['mode'] == 1 else cfg['kernel']
     pmc = pmc_figures('c5', n_per, True, kernel_name)
@@ -545,8 +555,9 @@ def run_sweep_config(args, cfg, rank, local_rank, world, dist, torch):
                                                   'itself traces, cell 9): the estimator in its own regime; the rows are gathered '
                                                   'inside the timed sweep, the 64 small fits run after it'}},
         'roofline': roofline_block(kernel_name, avg_kernel_s, n_per, bytes_per_ray, pmc,
-                                   note='launches of rank 0; a launch = one radius; per step the host also re-bakes the scene and '
-                                        'searches the detector plane per radius'),
+                                   note=f'trace kernels of rank 0: {launches} batch launches for {radii_of_rank} radii, kernel time per radius '
+                                        '(1e7 rays), measured while the post-hoc kernels of other groups share the GPU; per step the host '
+                                        'also re-bakes the scenes and searches the detector plane per radius'),
     }
     if clock:
       out['clock'] = clock

@@ -40,6 +40,15 @@ namespace odw {
                                  // 8: 39.8, 16: 41.5 per 1.25e8 hugeArray rays -- a pop costs ~30 instructions, a lane
                                  // that waits for seven others idles through whole cell steps)
 #endif
+#ifndef ODW_GRID_CUT_REG
+#define ODW_GRID_CUT_REG 1       // where the walk ends (nearest + 2 distTol, the length limit) kept in a register pair, renewed when the nearest changes
+#endif
+#ifndef ODW_GRID_EXACT_WALK
+#define ODW_GRID_EXACT_WALK 0    // A/B (round 4): exact sphere roots and consider() inside the cell step, no resolve queue
+#endif
+#ifndef ODW_GRID_LEAN_TEST
+#define ODW_GRID_LEAN_TEST 1     // the walk's sphere test reads centre and radius only (A/B: 0 = the record's group / solid word too)
+#endif
 #define ODW_GRID_THREADS 1024
 #define ODW_GRID_WAVES (ODW_GRID_THREADS / 64)
 #define ODW_GRID_WAVE_WORDS 32   // per wave: event counters (0..7), diagnostics (8..27), hit-block state (28..31)
@@ -159,10 +168,12 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
   int& medium = q.medium;
   double power = 0;
   int seq = 0, nint = 0, skip = -1;
+  int skip_rec = -1;      // SPHERES: the record of the sphere the ray has just left (skip is its solid), or -1
   uint64_t mask = 0;
   // the walk: ray parameter at which it leaves the cell through each axis, 1 / direction, the cell
   // (ix | iy << 8 | iz << 16)
   double tx = INFINITY, ty = INFINITY, tz = INFINITY, ivx = 0, ivy = 0, ivz = 0;
+  double cut = 0;        // min(length limit, nearest + 2 distTol): cells that begin beyond it are not visited (ray.py:432, 440)
   int cell = 0;
 
   // leave the cell through the nearest plane (the axis by selects, the next plane by ONE read of the
@@ -172,7 +183,7 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
 #define ODW_WALK_ADVANCE()                                                                   \
   do {                                                                                       \
     const double t_exit_ = fmin_raw(tx, fmin_raw(ty, tz));                                   \
-    const double cut_ = fmin_raw(q.tmax, q.any.t + 2.0 * q.tol);                             \
+    const double cut_ = ODW_GRID_CUT_REG ? cut : fmin_raw(q.tmax, q.any.t + 2.0 * q.tol);   \
     if (!(t_exit_ <= cut_)) {                                                                \
       walking = false;                                                                       \
     } else {                                                                                 \
@@ -282,7 +293,7 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
         cell = (int)reinterpret_cast<const uint32_t*>(slot + 6)[0];       // (-1: the ray misses the grid)
         i = ring_base + s;
         power = P.ray_origins ? (P.ray_powers ? P.ray_powers[i] : 1.0) : as_const(P.source)->power;
-        seq = 0; nint = 0; medium = -1; skip = -1;
+        seq = 0; nint = 0; medium = -1; skip = -1; skip_rec = -1;
         alive = true; fresh = true; walking = false; pending = false;
       }
       ring_n -= take;
@@ -304,6 +315,7 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
         mask &= ~sc.ignore_mask;
         q.any.t = INFINITY; q.any.prim = 0x7fffffff; q.any.face = 0x7fffffff;
         q.oth = q.any;
+        cut = q.tmax;
         walking = false;
         if (mask != 0ull) {
           ivx = frcp(dir.x); ivy = frcp(dir.y); ivz = frcp(dir.z);
@@ -345,6 +357,46 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
         for (uint32_t k = 0; k < count; ++k) {
           if (SPHERES) {
             // cheap test: does the line meet the sphere (discriminant), not behind the ray
+#if ODW_GRID_EXACT_WALK
+            // A/B (round 4): the exact roots and consider() inside the cell step, no resolve queue -- the lanes whose
+            // line meets the sphere run them under a divergent branch while the others wait
+            double2 r0, r1, r2;
+            if (IN_LDS) {
+              const double2* rec = reinterpret_cast<const double2*>(grid_lds + item_off) + 3 * (size_t)(first + k);
+              r0 = rec[0]; r1 = rec[1]; r2 = rec[2];
+            } else {
+              const double2* rec = reinterpret_cast<const double2*>(GD.items) + 3 * (size_t)(first + k);
+              r0 = rec[0]; r1 = rec[1]; r2 = rec[2];
+            }
+            const uint64_t bits = (uint64_t)__double_as_longlong(r2.x);
+            const int prim = (int)(uint32_t)bits, gs = (int)(uint32_t)(bits >> 32);
+            const d3 oc = point - mk(r0.x, r0.y, r1.x);
+            const double bh = dot(oc, dir), cc = dot(oc, oc) - r1.y * r1.y;
+            if (((mask >> (gs & 0xff)) & 1) && (gs >> 8) != skip && bh * bh - cc >= 0 && (bh < 0 || cc < 0)) {
+              double ta, tb;
+              if (quad_roots_unit(bh, cc, ta, tb) == 2) {
+                const double bt = ta > q.tol ? ta : (tb > q.tol ? tb : INFINITY);
+                consider(sv, q, bt, prim, (int)(first + k), gs & 0xff, 0, 0);
+                cut = fmin_raw(q.tmax, q.any.t + 2.0 * q.tol);
+              }
+            }
+#elif ODW_GRID_LEAN_TEST
+            // geometry only, from the first 32 bytes of the record (centre, radius); the sphere the ray has just left
+            // is known by its record (skip_rec: the interaction keeps the record's index).  Whether the group is
+            // relevant, and the solid rule for a sphere listed in a second cell, are asked when the cell is resolved
+            // (phase D asks them anyway): a third less LDS traffic per step, no 64-bit shift
+            double2 r0, r1;
+            if (IN_LDS) {
+              const double2* rec = reinterpret_cast<const double2*>(grid_lds + item_off) + 3 * (size_t)(first + k);
+              r0 = rec[0]; r1 = rec[1];
+            } else {
+              const double2* rec = reinterpret_cast<const double2*>(GD.items) + 3 * (size_t)(first + k);
+              r0 = rec[0]; r1 = rec[1];
+            }
+            const d3 oc = point - mk(r0.x, r0.y, r1.x);
+            const double bh = dot(oc, dir), cc = dot(oc, oc) - r1.y * r1.y;
+            maybe |= (int)(first + k) != skip_rec && bh * bh - cc >= 0 && (bh < 0 || cc < 0);
+#else
             double2 r0, r1, r2;
             if (IN_LDS) {
               const double2* rec = reinterpret_cast<const double2*>(grid_lds + item_off) + 3 * (size_t)(first + k);
@@ -358,6 +410,7 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
             const double bh = dot(oc, dir), cc = dot(oc, oc) - r1.y * r1.y;
             // (outside the sphere and moving away from its centre: both roots negative)
             maybe |= ((mask >> (gs & 0xff)) & 1) && (int)(gs >> 8) != skip && bh * bh - cc >= 0 && (bh < 0 || cc < 0);
+#endif
           } else {
             int p;
             if (IN_LDS) p = (int)lds32[2 * item_off + first + k]; else p = (int)reinterpret_cast<const uint32_t*>(GD.items)[first + k];
@@ -422,6 +475,7 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
             if (((mask >> g) & 1) && (pi[2] >> ODW_SOLID_SHIFT) != skip) intersect_prim(sv, q, p, pi[0], g, pi[2], pi[3]);
           }
         }
+        cut = fmin_raw(q.tmax, q.any.t + 2.0 * q.tol);
         ODW_WALK_ADVANCE();
       }
       if (!walking) {
@@ -516,6 +570,7 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
             }
           }
           skip = ((pflags & ODW_FLAG_CONVEX) && (entering ? -dot(dir, n) : dot(dir, n)) > 0) ? (pflags >> ODW_SOLID_SHIFT) : -1;
+          skip_rec = (SPHERES && skip >= 0) ? face : -1;
           if (alive && power < lim.power_tol) { ODW_GCOUNT(ODW_CNT_DIED); alive = false; }
           fresh = alive;
         }

@@ -330,6 +330,10 @@ __device__ __forceinline__ double prim_sdist(int type, PP par, d3 p) {
   }
 }
 
+// (s >= 0 ? m : -m) for m >= 0 without a compare and two selects: the sign bit of s + 0.0 (which turns -0 into +0, so
+// that s = -0 counts as s >= 0, as in the comparison) copied onto m -- one add, one bit-field insert
+__device__ __forceinline__ double signed_like(double m, double s) { return __builtin_copysign(m, s + 0.0); }
+
 // a t^2 + 2 bh t + c = 0, cancellation-free; returns number of roots, t0 <= t1
 __device__ __forceinline__ int quad_roots(double a, double bh, double c, double& t0, double& t1) {
   if (a == 0) {
@@ -340,11 +344,10 @@ __device__ __forceinline__ int quad_roots(double a, double bh, double c, double&
   const double disc = bh * bh - a * c;
   if (!(disc >= 0)) return 0;
   const double sq = fsqrt(disc);
-  const double q = -(bh + (bh >= 0 ? sq : -sq));
-  double r0 = q * frcp(a);
-  double r1 = (q != 0) ? c * frcp(q) : r0;
-  if (r0 > r1) { const double tmp = r0; r0 = r1; r1 = tmp; }
-  t0 = r0; t1 = r1;
+  const double q = -(bh + signed_like(sq, bh));
+  const double r0 = q * frcp(a);
+  const double r1 = (q != 0) ? c * frcp(q) : r0;
+  t0 = fmin(r0, r1); t1 = fmax(r0, r1);
   return 2;
 }
 // the same for a == 1 (unit direction in a rigid frame)
@@ -352,11 +355,9 @@ __device__ __forceinline__ int quad_roots_unit(double bh, double c, double& t0, 
   const double disc = bh * bh - c;
   if (!(disc >= 0)) return 0;
   const double sq = fsqrt(disc);
-  const double q = -(bh + (bh >= 0 ? sq : -sq));
-  double r0 = q;
-  double r1 = (q != 0) ? c * frcp(q) : r0;
-  if (r0 > r1) { const double tmp = r0; r0 = r1; r1 = tmp; }
-  t0 = r0; t1 = r1;
+  const double q = -(bh + signed_like(sq, bh));
+  const double r1 = (q != 0) ? c * frcp(q) : q;
+  t0 = fmin(q, r1); t1 = fmax(q, r1);
   return 2;
 }
 
@@ -514,6 +515,10 @@ __device__ __forceinline__ void intersect_prim(const SceneView& sv, Query& q, in
     const double ax = -o.x * ix, ay = -o.y * iy, az = -o.z * iz;            // plane at 0
     const double bx = fma(par[0], ix, ax), by = fma(par[1], iy, ay), bz = fma(par[2], iz, az);
     const bool px = d.x > 0, py = d.y > 0, pz = d.z > 0;
+    // per axis the plane met first / last (the low face first when moving in + direction): the smaller / larger of
+    // the two distances -- one v_min / v_max each instead of a select (two v_cndmask behind the compare) each
+    const double nx_ = fmin(ax, bx), ny_ = fmin(ay, by), nz_ = fmin(az, bz);
+    const double fx_ = fmax(ax, bx), fy_ = fmax(ay, by), fz_ = fmax(az, bz);
     if (cond_cnt) {
       // Trimmed box (operand of a boolean): any face can be rejected by its trim, so every valid
       // face has to reach consider() -- within the tolerance of an edge the ray meets the widened
@@ -532,12 +537,12 @@ __device__ __forceinline__ void intersect_prim(const SceneView& sv, Query& q, in
         TA = a_ ? t_ : TA;                                                                      \
         FA = a_ ? (FACE) : FA;                                                                  \
       }
-      ODW_BOX_FACE2(px ? ax : bx, px ? 0 : 1, o.y, d.y, par[1], o.z, d.z, par[2], c.t0, c.f0, c.t2, c.f2);
-      ODW_BOX_FACE2(py ? ay : by, py ? 2 : 3, o.z, d.z, par[2], o.x, d.x, par[0], c.t0, c.f0, c.t2, c.f2);
-      ODW_BOX_FACE2(pz ? az : bz, pz ? 4 : 5, o.x, d.x, par[0], o.y, d.y, par[1], c.t0, c.f0, c.t2, c.f2);
-      ODW_BOX_FACE2(px ? bx : ax, px ? 1 : 0, o.y, d.y, par[1], o.z, d.z, par[2], c.t1, c.f1, c.t3, c.f3);
-      ODW_BOX_FACE2(py ? by : ay, py ? 3 : 2, o.z, d.z, par[2], o.x, d.x, par[0], c.t1, c.f1, c.t3, c.f3);
-      ODW_BOX_FACE2(pz ? bz : az, pz ? 5 : 4, o.x, d.x, par[0], o.y, d.y, par[1], c.t1, c.f1, c.t3, c.f3);
+      ODW_BOX_FACE2(nx_, px ? 0 : 1, o.y, d.y, par[1], o.z, d.z, par[2], c.t0, c.f0, c.t2, c.f2);
+      ODW_BOX_FACE2(ny_, py ? 2 : 3, o.z, d.z, par[2], o.x, d.x, par[0], c.t0, c.f0, c.t2, c.f2);
+      ODW_BOX_FACE2(nz_, pz ? 4 : 5, o.x, d.x, par[0], o.y, d.y, par[1], c.t0, c.f0, c.t2, c.f2);
+      ODW_BOX_FACE2(fx_, px ? 1 : 0, o.y, d.y, par[1], o.z, d.z, par[2], c.t1, c.f1, c.t3, c.f3);
+      ODW_BOX_FACE2(fy_, py ? 3 : 2, o.z, d.z, par[2], o.x, d.x, par[0], c.t1, c.f1, c.t3, c.f3);
+      ODW_BOX_FACE2(fz_, pz ? 5 : 4, o.x, d.x, par[0], o.y, d.y, par[1], c.t1, c.f1, c.t3, c.f3);
 #undef ODW_BOX_FACE2
     } else {
     double bt = INFINITY;
@@ -551,19 +556,19 @@ __device__ __forceinline__ void intersect_prim(const SceneView& sv, Query& q, in
       if (ok_ && (t_ < bt || (t_ == bt && (FACE) < bf))) { bt = t_; bf = (FACE); }            \
     }
     // entry faces: low face when moving in +axis direction
-    ODW_BOX_FACE(px ? ax : bx, px ? 0 : 1, o.y, d.y, par[1], o.z, d.z, par[2]);
-    ODW_BOX_FACE(py ? ay : by, py ? 2 : 3, o.z, d.z, par[2], o.x, d.x, par[0]);
-    ODW_BOX_FACE(pz ? az : bz, pz ? 4 : 5, o.x, d.x, par[0], o.y, d.y, par[1]);
+    ODW_BOX_FACE(nx_, px ? 0 : 1, o.y, d.y, par[1], o.z, d.z, par[2]);
+    ODW_BOX_FACE(ny_, py ? 2 : 3, o.z, d.z, par[2], o.x, d.x, par[0]);
+    ODW_BOX_FACE(nz_, pz ? 4 : 5, o.x, d.x, par[0], o.y, d.y, par[1]);
     c.t0 = bt;
     c.f0 = bf;
-    const double t_in = fmax(fmax(px ? ax : bx, py ? ay : by), pz ? az : bz);
-    const double t_out = fmin(fmin(px ? bx : ax, py ? by : ay), pz ? bz : az);
+    const double t_in = fmax(fmax(nx_, ny_), nz_);
+    const double t_out = fmin(fmin(fx_, fy_), fz_);
     if (!(bt < INFINITY) || !(t_in < t_out)) {
       bt = INFINITY;
       bf = 0;
-      ODW_BOX_FACE(px ? bx : ax, px ? 1 : 0, o.y, d.y, par[1], o.z, d.z, par[2]);
-      ODW_BOX_FACE(py ? by : ay, py ? 3 : 2, o.z, d.z, par[2], o.x, d.x, par[0]);
-      ODW_BOX_FACE(pz ? bz : az, pz ? 5 : 4, o.x, d.x, par[0], o.y, d.y, par[1]);
+      ODW_BOX_FACE(fx_, px ? 1 : 0, o.y, d.y, par[1], o.z, d.z, par[2]);
+      ODW_BOX_FACE(fy_, py ? 3 : 2, o.z, d.z, par[2], o.x, d.x, par[0]);
+      ODW_BOX_FACE(fz_, pz ? 5 : 4, o.x, d.x, par[0], o.y, d.y, par[1]);
       c.t1 = bt;
       c.f1 = bf;
     }
