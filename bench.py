@@ -556,7 +556,8 @@ def run_sweep_config(args, cfg, rank, local_rank, world, dist, torch):
                                                   'inside the timed sweep, the 64 small fits run after it'}},
         'roofline': roofline_block(kernel_name, avg_kernel_s, n_per, bytes_per_ray, pmc,
                                    note=f'trace kernels of rank 0: {launches} batch launches for {radii_of_rank} radii, kernel time per radius '
-                                        '(1e7 rays), measured while the post-hoc kernels of other groups share the GPU; per step the host '
+                                        '(1e7 rays), measured while the post-hoc kernels of other groups share the GPU (the batch kernel by itself: 0.67 ms '
+                                        'per radius, profiles/r04/r04_batch_launch_kernel.log); per step the host '
                                         'also re-bakes the scenes and searches the detector plane per radius'),
     }
     if clock:

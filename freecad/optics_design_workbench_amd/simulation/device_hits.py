@@ -278,6 +278,11 @@ class DeviceHits:
         out.append(e)
     return out
 
+  def thinned(self, count):
+    """the rows [::max(1, n // count)] of the selection in (ray, bounce) order (HIT_DTYPE): what `points[::k]` picks
+    from the arrays `loadHits()` returns"""
+    return self._gather(False, max(1, self._n // int(count)))
+
   def moments(self):
     """(mean (3,), variance about it (3,)) of the points"""
     tr = self._tr

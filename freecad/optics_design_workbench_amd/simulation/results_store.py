@@ -179,13 +179,18 @@ class SimulationResults:
 
   # -- output ----------------------------------------------------------------
   # -- writing in the background ---------------------------------------------------------------
-  # Pickling 4e6 hits (290 MB) takes ~85 ms, a launch that produces them 1 ms: the run loop hands the files of
-  # a flush to a writer thread (at most two flushes in flight) and goes on tracing; everything that reads the
-  # folder, and the end of the run, waits for it (`drain`).  Protocol 5: numpy arrays go into the file without
-  # the intermediate bytes copy of the default protocol; `pickle.load` of the reference reads them all the same.
+  # Pickling 4e6 hits (290 MB) takes 30 - 85 ms, a launch that produces them 1 ms and their copy out of HBM 7: the run
+  # loop hands the files of a flush to WRITER THREADS (a few of them: one thread moves 7 - 10 GB/s into the page cache,
+  # the copy engine delivers 45; at most two files per thread in flight) and goes on tracing; everything that reads the
+  # folder, and the end of the run, waits for them (`drain`).  Protocol 5: numpy arrays go into the file without the
+  # intermediate bytes copy of the default protocol -- the file write is one system call per array, outside the
+  # interpreter lock --; `pickle.load` of the reference reads them all the same.
+  WRITER_THREADS = max(1, min(6, (os.cpu_count() or 2) // 2))
+
   def _writer_put(self, path, obj):
-    if getattr(self, '_writer', None) is None:
-      self._writeQueue = queue.Queue(maxsize=2)
+    if getattr(self, '_writers', None) is None:
+      n = int(os.environ.get('ODW_WRITER_THREADS', self.WRITER_THREADS))
+      self._writeQueue = queue.Queue(maxsize=2 * n)
       self._writeError = None
 
       def work():
@@ -205,8 +210,9 @@ class SimulationResults:
             self._writeError = e
           finally:
             self._writeQueue.task_done()
-      self._writer = threading.Thread(target=work, name='odw-hit-writer', daemon=True)
-      self._writer.start()
+      self._writers = [threading.Thread(target=work, name=f'odw-hit-writer-{k}', daemon=True) for k in range(n)]
+      for t in self._writers:
+        t.start()
     self._raiseWriteError()
     self._writeQueue.put((path, obj))
 
@@ -220,12 +226,14 @@ class SimulationResults:
   def drain(self, stop=False):
     """wait until every file handed to the writer thread is on disk; raises what the writer met.
     stop: the thread ends as well (the end of a run; a later flush starts a new one)"""
-    if getattr(self, '_writer', None) is not None:
+    if getattr(self, '_writers', None) is not None:
       self._writeQueue.join()
       if stop:
-        self._writeQueue.put(None)
-        self._writer.join()
-        self._writer = None
+        for _ in self._writers:
+          self._writeQueue.put(None)
+        for t in self._writers:
+          t.join()
+        self._writers = None
       self._raiseWriteError()
 
   def flush(self, wait=True):

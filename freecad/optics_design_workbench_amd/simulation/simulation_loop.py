@@ -36,7 +36,7 @@ def _limit(settings, key, default):
 
 def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPath=None, store=None,
                   raysPerLaunch=1 << 22, endIf=None, tracer=None, pseudoIterationsPerLaunch=64,
-                  dist=None, compileScene='auto', **traceKwargs):
+                  dist=None, compileScene='auto', overlapFetch=True, **traceKwargs):
   """trace `doc` until its simulation settings' end criteria are met.
 
   action       'true' (continuous Monte-Carlo) | 'singletrue' (one iteration)
@@ -59,6 +59,11 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
                (Tracer.compileScene('auto'): nothing waits, the results are those of the generic kernels
                bit for bit); 'structure': compile before the first launch; 'off': never.  Applies to
                the tracer this call creates; a tracer passed in keeps its own setting.
+  overlapFetch a continuous true-random run of ONE point or surface source whose end criteria do not look at the hits
+               (EndAfterHits inf, no endIf), in one process: launches alternate between two contexts of the GPU, and
+               while one traces, the hit columns of the other's previous launch cross PCIe into page-locked arrays and
+               go to the writer threads (a thread of this call does that) -- the same files, the order of rays in
+               them included; False: one launch at a time, fetched before the next starts
   traceKwargs  maxRayLength, maxIntersections, powerTol, distTol (ray.py:36-38)
   -> SimulationResults
   """
@@ -114,7 +119,12 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
     first = {src.Name: 0 for src in sources}
     ended = False
     uploaded, hits_per_ray = {}, {}
-    while True:
+    if (overlapFetch and own and continuous and not pseudo and len(baked) == 1 and ranks.world == 1 and endIf is None
+        and not np.isfinite(store.endAfterHits) and hasattr(tr, 'hitColumns')
+        and not isinstance(baked[0][2], replay_source.BakedReplay) and not baked[0][0]._props.get('RecordRays', False)):
+      _run_overlapped(store, tr, baked[0], rpi, raysPerLaunch, seed, enabled, compileScene)
+      baked = []                        # (the loop below has nothing left to do)
+    while baked:
       for src, scene, bsrc, lim in baked:
         per_iter = max(1, int(round(rpi * bsrc.rays_per_iteration_scale)))
         base = first[src.Name]
@@ -275,6 +285,85 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
     if own:
       tr.close()
   return store
+
+
+def _run_overlapped(store, tr, baked, rpi, raysPerLaunch, seed, enabled, compileScene):
+  """the continuous loop for one device-generated source with the fetch of launch k overlapping the trace of launch
+  k + 1 (runSimulation: overlapFetch).  Launch k runs on context k % 2; a fetch thread waits for it, reads its counters,
+  has its rows selected and split into columns on the device, copies them into page-locked arrays and hands them to
+  the store's writer threads; the main thread meanwhile launches k + 1 on the other context.  End criteria on rays and
+  iterations are known at launch time, so the run traces exactly what the one-launch-at-a-time loop traces."""
+  from concurrent.futures import ThreadPoolExecutor
+  src, scene, bsrc, lim = baked
+  other = Tracer(tr.device, referenceStrict=tr.referenceStrict)
+  lanes = [tr, other]
+  try:
+    if compileScene in ('auto', 'structure'):
+      other.compileScene(compileScene)
+    for t in lanes:
+      t.setScene(scene)
+      t.setLimits(lim)
+      t.setSource(bsrc)
+      t.setDetector(None)
+    per_iter = max(1, int(round(rpi * bsrc.rays_per_iteration_scale)))
+    worst_per_ray = lim.max_intersections + 1
+    state = dict(hits_per_ray=4.0)
+
+    def fetch(t, base, n, iters, capacity):
+      while True:
+        t.sync()
+        cnt = t.counters()
+        Tracer.raiseForRayErrors(cnt)
+        if not cnt['hits_dropped']:
+          break
+        worst = max(16, n * worst_per_ray)
+        if capacity >= worst:
+          raise RuntimeError(f'{cnt["hits_dropped"]} hit rows did not fit the device buffer of {capacity} rows')
+        capacity = min(worst, max(2 * capacity, int(cnt['recorded_hits'] * 1.05) + 1024))
+        t.reserveHits(capacity)                        # (deterministic: the same rays again, with room)
+        t.reset()
+        t.trace(base, n, seed)
+      state['hits_per_ray'] = max(cnt['recorded_hits'] / n, 0.25)
+      per_ray = _DeviceInitialConditions(t, bsrc, base, n, seed)
+      _store_hit_columns(store, t, scene, src, per_ray, base, enabled)
+      store.flush(wait=False)                          # (only this thread adds hits and flushes)
+
+    pending = [None, None]
+    base, k = 0, 0
+    with ThreadPoolExecutor(max_workers=1, thread_name_prefix='odw-hit-fetch') as pool:
+      try:
+        while True:
+          lane = k % 2
+          if pending[lane] is not None:
+            pending[lane].result()                     # this context's rows are out (errors of its fetch surface here)
+            pending[lane] = None
+          t = lanes[lane]
+          iters = _iterations_for_launch(store, per_iter, raysPerLaunch)
+          n = iters * per_iter
+          capacity = min(max(16, n * worst_per_ray), int(n * state['hits_per_ray'] * 1.25) + 1024)
+          t.reserveHits(capacity)
+          t.reset()
+          t.trace(base, n, seed)
+          pending[lane] = pool.submit(fetch, t, base, n, iters, capacity)
+          base += n
+          k += 1
+          store.incrementRayCount(n)
+          store.incrementIterationCount(iters)
+          store.dumpProgress()
+          if store.reachedEnd():
+            break
+      finally:
+        errors = []
+        for f in pending:
+          if f is not None:
+            try:
+              f.result()
+            except BaseException as e:              # (the first one is raised below, after both contexts are idle)
+              errors.append(e)
+        if errors:
+          raise errors[0]
+  finally:
+    other.close()
 
 
 def bakeLightSource(doc, src, seed=0):

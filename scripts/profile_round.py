@@ -39,6 +39,10 @@ KERNEL_LIKE = '%' + KERNEL_NAME + '%'
 out = os.path.join(ROOT, 'gpurun_out')
 os.makedirs(out, exist_ok=True)
 env = dict(os.environ, TMPDIR='/tmp')
+if args.config == 'c5':
+  # counters are averaged per dispatch: the sweep traces one radius per launch here (its batch launches hold 2 - 12
+  # radii each); bench.py compares per radius (1e7 rays) either way
+  env['ODW_SWEEP_BATCH'] = '0'
 BENCH = ['python3', os.path.join(ROOT, 'bench.py'), '--config', args.config, '--steps', '1' if args.config == 'c5' else '3', '--warmup', '1',
          '--no-cpu-baseline', '--no-end-to-end', '--no-extra']
 if args.script:
@@ -144,7 +148,7 @@ summary = dict(command='rocprofv3 --pmc <COUNTERS> --kernel-trace -- ' + ' '.joi
                write_bytes=write, hbm_bytes_per_launch=2 * fetch_raw + write, kernel_ms_rocprof=kernel_ms)
 json.dump(summary, open(os.path.join(out, f'{tag}_pmc.json'), 'w'), indent=1)
 ms = kernel_ms or line.get('roofline', {}).get('avg_kernel_ms')
-ROUND = os.environ.get('ODW_PROFILE_ROUND', 'r03')
+ROUND = os.environ.get('ODW_PROFILE_ROUND', 'r04')
 valu = None
 if 'SQ_INSTS_VALU' in avg and ms:
   valu = dict(insts_per_launch=avg['SQ_INSTS_VALU'], salu_insts_per_launch=avg.get('SQ_INSTS_SALU'),

@@ -146,12 +146,18 @@ def test_sweep_with_batch_launches_equals_the_sweep_value_by_value(native_lib):
     with Tracer(0) as tr:
       tr.compileScene('structure')
       res[batch] = sweep.parameterSweep(doc, setRadius, radii, rays=200_000, seed=11, tracer=tr, batch=batch,
-                                        measure=dict(fwhm=sweep.calcFwhm, rms=sweep.rmsSpot))
+                                        measure=dict(fwhm=sweep.calcFwhm, rms=sweep.rmsSpot), keepSample=500)
   for batch in (8, 5):
     for col in ('fwhm', 'rms'):
       assert np.array_equal(res[batch].columns[col], res[0].columns[col], equal_nan=True), (batch, col)
     assert (res[batch].tracedRays, res[batch].recordedHits, res[batch].segments) == \
            (res[0].tracedRays, res[0].recordedHits, res[0].segments)
+    # the thinned rows every value keeps (keepSample): the same rows either way
+    assert sorted(res[batch].samples) == sorted(res[0].samples) == list(range(19))
+    for k in range(19):
+      for col in ('points', 'directions', 'powers', 'isEntering'):
+        assert np.array_equal(res[batch].samples[k][col], res[0].samples[k][col]), (batch, k, col)
+  assert np.array_equal(sweep.fwhmOfSamples(res[8]), sweep.fwhmOfSamples(res[0]), equal_nan=True)
   assert res[0].tracedRays == 19 * 200_000 and np.isfinite(res[0].columns['rms']).all()
 
 
