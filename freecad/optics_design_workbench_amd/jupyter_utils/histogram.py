@@ -2,7 +2,7 @@
 
 Same constructor arguments, attributes (`hist`, `binX`, `binY`, `X`, `Y`,
 `binAreas`) and `byAzimuth()` as the reference's `Histogram`
-(jupyter_utils/histogram.py:19-89, 150-161); plotting is left out.
+(jupyter_utils/histogram.py:19-89, 150-161), with its `plot` / `plotByAzimuth` on explicit matplotlib axes (:91-148, 163-166).
 """
 import numpy as np
 
