@@ -1152,20 +1152,13 @@ __device__ __noinline__ d3 scatter(const DeviceSurfaceSampler* samplers, int s_p
 // Active lanes append one 64-B row each: lanes take consecutive slots by
 // popcount prefix of the ballot, the slots come from the wave's reserved block
 // (big lists) or from one atomic per append (small lists, exact fill).
-// block change of a wave's hit-list reservation (rare: out of line): the slots the old block has
-// left (< number of recording lanes) are marked unused, a new block is taken
-__device__ __noinline__ void next_hit_block(odw_hit* hits, uint64_t capacity, unsigned long long* hit_count,
-                                            uint32_t block, volatile uint32_t* hit_state, uint32_t hit_used,
-                                            uint32_t rank, bool leader) {
-  const uint64_t old_base = ((uint64_t)hit_state[1] << 32) | hit_state[0];
-  const uint32_t left = block - hit_used;
-  if (rank < left && old_base + hit_used + rank < capacity) hits[old_base + hit_used + rank].tag = ODW_TAG_UNUSED;
+// block change of a wave's hit-list reservation (rare: out of line): the leader takes a new block.  The lanes that
+// still fit fill the rest of the old block, the others start the new one (round 4; before, the < 64 slots the old
+// block had left were tagged unused: 6 % of a big list's slots, written as tags and read again by every pass over
+// the list)
+__device__ __noinline__ void next_hit_block(unsigned long long* hit_count, uint32_t block, volatile uint32_t* hit_state, bool leader) {
   if (leader) {
     const unsigned long long base = atomicAdd(hit_count, (unsigned long long)block);
-    // unused slots are counted where they exist (beyond the buffer nothing is stored or counted)
-    const uint64_t at = old_base + hit_used;
-    const uint64_t in_buf = at < capacity ? (capacity - at < left ? capacity - at : left) : 0;
-    if (in_buf) atomicAdd(hit_count + 1, (unsigned long long)in_buf);
     hit_state[0] = (uint32_t)base;
     hit_state[1] = (uint32_t)(base >> 32);
   }
@@ -1245,13 +1238,16 @@ __device__ __forceinline__ void record_hit(const PT& P, uint64_t ray, int group,
       // rest of its last block at the end) are marked ODW_TAG_UNUSED and dropped by odw_fetch_hits.
       // the wave's block lives in LDS (base lo, base hi, used): only the recording lanes are active
       // here, a register copy would go stale in the others
-      uint32_t hit_used = hit_state[2];
-      if (hit_used + n_act > P.out.hit_block) {
-        next_hit_block(hits, P.out.hit_capacity, hit_count, P.out.hit_block, hit_state, hit_used, rank, lane == leader);
-        hit_used = 0;
-      }
+      const uint32_t hit_used = hit_state[2];
+      const uint32_t left = P.out.hit_block - hit_used;          // (0: no block reserved yet, or the block is full)
       slot = (((uint64_t)hit_state[1] << 32) | hit_state[0]) + hit_used + rank;
-      if (lane == leader) hit_state[2] = hit_used + n_act;
+      if (n_act > left) {
+        next_hit_block(hit_count, P.out.hit_block, hit_state, lane == leader);
+        if (rank >= left) slot = (((uint64_t)hit_state[1] << 32) | hit_state[0]) + (rank - left);
+        if (lane == leader) hit_state[2] = n_act - left;
+      } else if (lane == leader) {
+        hit_state[2] = hit_used + n_act;
+      }
     } else {
       unsigned long long base = 0;
       if (lane == leader) base = atomicAdd(hit_count, (unsigned long long)n_act);

@@ -29,22 +29,26 @@
 namespace odw {
 
 #ifndef ODW_MESH_STEP_MIN
-#define ODW_MESH_STEP_MIN 8      // keep walking while at least this many lanes of the wave walk and others wait
-                                 // (1e6 facets: 8: 26.1 ms, 16: 27.0, 28: 29.8 per 1e7 rays)
+#define ODW_MESH_STEP_MIN 16     // keep walking while at least this many lanes of the wave walk and others wait
+                                 // (round 3, rays in index order, 1e6 facets: 8: 26.1 ms, 16: 27.0, 28: 29.8 per 1e7 rays;
+                                 //  round 4, rays handed out in sorted order -- the lanes of a wave take the same turns --:
+                                 //  8: 13.0, 12: 11.8, 16: 11.55, 24: 11.6 at 1e6 facets, 7.9 / 7.65 / 7.45 at 6.5e4)
 #endif
 #ifndef ODW_MESH_WAVES
-#define ODW_MESH_WAVES 3         // waves per SIMD the register allocation aims at (LDS per block: stacks 24 KB + rings 12 KB)
+#define ODW_MESH_WAVES 3         // waves per SIMD the register allocation aims at (LDS per block: stacks 24 KB + rings 14 KB;
+                                 // 4: the hot loops spill -- 16.5 against 11.55 ms)
 #endif
 #ifndef ODW_MESH_CAND_TRIPS
-#define ODW_MESH_CAND_TRIPS 3    // trips of four records per lane and leaf round (0: all of the visit's candidates at once:
-                                 // 13.1 / 18.3 / 25.1 ms per 1e7 rays at 4e3 / 6.5e4 / 1e6 facets; 2: 12.6 / 17.3 / 26.1;
-                                 // 3: 12.9 / 16.9 / 24.4; 4: 13.2 / 17.1 / 23.9)
+#define ODW_MESH_CAND_TRIPS 0    // trips of four records per lane and leaf round; 0: all of the visit's candidates at once.
+                                 // (round 3: 0: 13.1 / 18.3 / 25.1 ms per 1e7 rays at 4e3 / 6.5e4 / 1e6 facets, 3: 12.9 / 16.9 /
+                                 //  24.4 -- a lane with 40 candidates held the lanes with 8; with sorted rays the lanes of a wave
+                                 //  hold about the same number: 0: 7.65 / 11.55, 3: 7.95 / 12.4, 4: 7.93 / 12.0, 6: 8.36 / 12.4)
 #endif
 #define ODW_MESH_THREADS 256
 #define ODW_MESH_BLOCK_WAVES (ODW_MESH_THREADS / 64)
 #define ODW_MESH_WAVE_WORDS 32   // per wave: event counters (0..7), diagnostics (8..27), hit-block state (28..31)
 #define ODW_MESH_RING 64
-#define ODW_MESH_RING_DOUBLES (ODW_MESH_RING * 6)
+#define ODW_MESH_RING_DOUBLES (ODW_MESH_RING * 7)   // per ray: origin, direction, its number within the launch
 #define ODW_MESH_STACK 12        // entries (two words each) per lane: one per level of the wide tree (kWideMaxDepth + 1)
 #define ODW_WIDE_WORDS 32        // words per node (odw_capi.hip: kWideWords)
 
@@ -191,7 +195,8 @@ __global__ __launch_bounds__(ODW_MESH_THREADS, ODW_MESH_WAVES) void odw_mesh_ker
         const uint32_t fill = avail < ODW_MESH_RING ? (uint32_t)avail : (uint32_t)ODW_MESH_RING;
         ODW_MSTAT(0, __ballot(lane < fill));
         if (lane < fill) {
-          const uint64_t r = next + lane;
+          // (position next + lane of the hand-out order is ray number r: the order groups rays that start alike)
+          const uint64_t r = P.ray_order ? (uint64_t)P.ray_order[next + lane] : next + lane;
           d3 o, d;
           if (P.ray_origins) {
             o = mk(P.ray_origins[r], P.ray_origins[P.ray_stride + r], P.ray_origins[2 * P.ray_stride + r]);
@@ -201,8 +206,9 @@ __global__ __launch_bounds__(ODW_MESH_THREADS, ODW_MESH_WAVES) void odw_mesh_ker
             const RayInit g = generate_ray(P.source, P.first_ray + r, P.seed);
             o = g.point; d = g.dir;
           }
-          double* slot = ring + 6 * lane;
+          double* slot = ring + 7 * lane;
           slot[0] = o.x; slot[1] = o.y; slot[2] = o.z; slot[3] = d.x; slot[4] = d.y; slot[5] = d.z;
+          slot[6] = __longlong_as_double((long long)r);
         }
         __builtin_amdgcn_wave_barrier();
         ring_base = next;
@@ -214,10 +220,10 @@ __global__ __launch_bounds__(ODW_MESH_THREADS, ODW_MESH_WAVES) void odw_mesh_ker
       const uint32_t take = want < ring_n ? want : ring_n;
       if (!alive && rank < take) {
         const uint32_t s = ring_n - 1 - rank;
-        const double* slot = ring + 6 * s;
+        const double* slot = ring + 7 * s;
         point = mk(slot[0], slot[1], slot[2]);
         dir = mk(slot[3], slot[4], slot[5]);
-        i = ring_base + s;
+        i = (uint64_t)__double_as_longlong(slot[6]);
         power = P.ray_origins ? (P.ray_powers ? P.ray_powers[i] : 1.0) : as_const(P.source)->power;
         seq = 0; nint = 0; medium = -1; skip = -1;
         alive = true; fresh = true; walking = false; pending = false;
@@ -569,6 +575,58 @@ __global__ __launch_bounds__(ODW_MESH_THREADS, ODW_MESH_WAVES) void odw_mesh_ker
     for (int w = 0; w < ODW_MESH_BLOCK_WAVES; ++w) s += lds32[word_off + w * ODW_MESH_WAVE_WORDS + threadIdx.x];
     if (s) atomicAdd(P.out.counters + threadIdx.x, (unsigned long long)s);
   }
+}
+
+
+// ---- the order rays are handed out in (TraceParams.ray_order) ---------------------------------------------------------
+// key of ray r: where it starts (10 bits per axis of the tree's root box, clamped; Morton order) above where it points
+// (octahedral map of the unit direction, 16 bits per axis, Morton order).  Sorted by it, the 64 rays of a wave are
+// neighbours among ALL rays of the launch: their node and leaf fetches fall into the same cache lines and their
+// traversals take the same turns.
+__device__ __forceinline__ uint32_t spread16(uint32_t v) {        // abcd -> 0a0b0c0d
+  v &= 0xffffu;
+  v = (v | (v << 8)) & 0x00ff00ffu;
+  v = (v | (v << 4)) & 0x0f0f0f0fu;
+  v = (v | (v << 2)) & 0x33333333u;
+  v = (v | (v << 1)) & 0x55555555u;
+  return v;
+}
+__device__ __forceinline__ uint32_t spread10(uint32_t v) {        // 10 bits -> every third bit
+  v &= 0x3ffu;
+  v = (v | (v << 16)) & 0x030000ffu;
+  v = (v | (v << 8)) & 0x0300f00fu;
+  v = (v | (v << 4)) & 0x030c30c3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+// K = uint32_t: the direction bits alone (a point source at its focus: every ray starts at one point)
+template <class K>
+__global__ __launch_bounds__(256) void odw_ray_key_kernel(const DeviceSource* sp, uint64_t first, uint64_t n, uint64_t seed,
+                                                          double lx, double ly, double lz, double sx, double sy, double sz,
+                                                          K* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const RayInit g = generate_ray(sp, first + r, seed);
+  const d3 d = g.dir;
+  const double a = frcp(fabs(d.x) + fabs(d.y) + fabs(d.z));
+  double u = d.x * a, v = d.y * a;
+  if (d.z < 0) {
+    const double fu = (1.0 - fabs(v)) * (u < 0 ? -1.0 : 1.0), fv = (1.0 - fabs(u)) * (v < 0 ? -1.0 : 1.0);
+    u = fu; v = fv;
+  }
+  const uint32_t qu = (uint32_t)fmin(fmax((u * 0.5 + 0.5) * 65535.0, 0.0), 65535.0);
+  const uint32_t qv = (uint32_t)fmin(fmax((v * 0.5 + 0.5) * 65535.0, 0.0), 65535.0);
+  const uint32_t kd = spread16(qu) | (spread16(qv) << 1);
+  if constexpr (sizeof(K) == 4) {
+    keys[r] = kd;
+  } else {
+    const uint32_t qx = (uint32_t)fmin(fmax((g.point.x - lx) * sx, 0.0), 1023.0);
+    const uint32_t qy = (uint32_t)fmin(fmax((g.point.y - ly) * sy, 0.0), 1023.0);
+    const uint32_t qz = (uint32_t)fmin(fmax((g.point.z - lz) * sz, 0.0), 1023.0);
+    const uint32_t ko = spread10(qx) | (spread10(qy) << 1) | (spread10(qz) << 2);
+    keys[r] = ((uint64_t)ko << 32) | kd;
+  }
+  vals[r] = (uint32_t)r;
 }
 
 }  // namespace odw

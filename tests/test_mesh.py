@@ -229,6 +229,34 @@ def test_mesh_kernel_equals_bvh_kernel(native_lib, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_presorted_hand_out_order_changes_no_row(native_lib, monkeypatch):
+  """mesh launches hand their rays out sorted by where they start and point (TraceParams.ray_order: the rays of a wave
+  are neighbours, their fetches share cache lines); a ray's rows depend on its number only -- the same rows with the
+  order (forced for short launches: ODW_MESH_PRESORT_MIN=1) and without it (ODW_MESH_PRESORT=0), for a point source
+  at its focus (direction bits only), a diverging one and a parallel beam (origin bits), first ray not 0"""
+  from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
+  import copy
+  _, sc, lim, src = _lens_scene(96)
+  far, par = copy.copy(src), copy.copy(src)
+  far.focal_length, par.focal_length = -40.0, np.inf
+  for source, n, first in ((src, 70001, 12345), (far, 30000, 0), (par, 30000, 7)):
+    rows = {}
+    for mode in ('on', 'off'):
+      monkeypatch.setenv('ODW_MESH_PRESORT', '1' if mode == 'on' else '0')
+      monkeypatch.setenv('ODW_MESH_PRESORT_MIN', '1')
+      with Tracer(0) as tr:
+        tr.setScene(sc); tr.setSource(source); tr.setLimits(lim); tr.setDetector(None)
+        tr.reserveHits(n * 8)
+        tr.reset()
+        tr.trace(first, n, 5, histogram=False)
+        tr.sync()
+        rows[mode] = (tr.counters(), tr.hits())
+    assert rows['on'][0] == rows['off'][0] and rows['on'][0]['traced_rays'] == n
+    for col in ('tag', 'point', 'direction', 'power'):
+      assert np.array_equal(rows['on'][1][col], rows['off'][1][col]), col
+
+
+@pytest.mark.gpu
 def test_mesh_kernel_on_a_lopsided_tree(native_lib, oracle, monkeypatch):
   """facets whose sizes and spacings grow geometrically along an axis (a horn of 1200 quadrilateral rings between
   1e-3 and 1e3 mm): the surface-area heuristic peels them off one side, the binary tree comes out as high as the
