@@ -171,8 +171,8 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
   keepSample             an integer N: the rows `[::max(1, n // N)]` of every value's hit list (the sample a notebook that
                          traces N rays per value works on) are kept in `SweepResult.samples` on the rank that ran the value
                          (`fwhmOfSamples` turns them into a column)
-  pipeline               with deviceHits on a device tracer: further contexts on the same GPU (True: two), so
-                         that value k + 1 is baked and traced while values k and k - 1 are measured (same
+  pipeline               with deviceHits on a device tracer: further contexts on the same GPU (True: four), so
+                         that the next group of values is baked and traced while earlier ones are measured (same
                          results); an integer n: n extra contexts (n measuring threads)
   """
   # (collectives run on the GPU the tracer works on: one process per GPU, each with its own device)
@@ -199,11 +199,11 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
   elif os.environ.get('ODW_SWEEP_PIPELINE'):
     pipeline = int(os.environ['ODW_SWEEP_PIPELINE'])
   if pipeline and deviceHits and isinstance(tr, Tracer) and len(mine) > 1:
-    # (two measuring threads by default: the measure is partly host work under the GIL, partly waits for the GPU --
-    #  one thread read 243 - 338 ms per 64 x 1e7 sweep from run to run, two 248 - 273, three 247 - 264)
-    # (the extra contexts stay with the tracer between sweeps: creating them costs ~12 ms, a rank's share of a sweep
-    #  dealt out over eight GPUs takes 30)
-    want = min(int(pipeline) if pipeline is not True else 3, len(mine) - 1, 5)
+    # (four extra contexts by default: groups of values take turns on five contexts -- while the measuring threads of
+    #  some wait for the GPU or search planes, others' launches and post-hoc steps keep it busy.  64 x 1e7 rays, batch 12:
+    #  2 / 3 / 4 extra contexts = 105 / 95 / 89 ms per sweep.  Each context holds a group's hit list: ~13 GB at 12 values
+    #  x 1.25e7 rows.  The extra contexts stay with the tracer between sweeps: creating them costs ~12 ms each)
+    want = min(int(pipeline) if pipeline is not True else 4, len(mine) - 1, 5)
     kept = [e for e in (getattr(tr, '_sweepLanes', None) or [])
             if e.referenceStrict == tr.referenceStrict and e.compileMode() == tr.compileMode()]
     while len(kept) < want:
