@@ -378,6 +378,12 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
   # by ONE launch -- their scenes differ in numbers only --, each into its own segment of the hit list; a measuring thread
   # then goes through the segments while the main thread bakes and launches the next group on another context.
   group_size = int(batch) if (batch and deviceHits and isinstance(tr, Tracer) and len(mine) > 1) else 1
+  if group_size > 1:
+    # room in HBM: every context holds the hit list of a group (64-byte rows, with the slack of block reservations) and
+    # the post-hoc state of its segments (row-of-ray table, selection, projected coordinates: ~30 bytes per ray)
+    per_value = (int(rays * 1.25) + 1024 + 4_300_000) * 64 + int(rays) * 30
+    budget = float(os.environ.get('ODW_SWEEP_HBM_GB', '96')) * 1e9 / len(lanes)
+    group_size = max(1, min(group_size, int(budget // per_value)))
   if os.environ.get('ODW_SWEEP_BATCH'):
     group_size = max(1, int(os.environ['ODW_SWEEP_BATCH'])) if group_size > 1 else 1
   switch_interval = sys.getswitchinterval()
