@@ -148,6 +148,10 @@ struct odw_ctx {
   hipFunction_t spec_batch_fn = nullptr;   // the scene-compiled kernel's BATCH variant (bound on the first batch launch)
   DevBuf own_hits, own_hit_count;
   uint64_t own_capacity = 0, own_slots = 0, own_ray_begin = 0, own_ray_end = 0;
+  // a run's rows kept in HBM beyond the launches that recorded them (odw_archive_append / odw_archive_select)
+  DevBuf archive, archive_count;
+  uint64_t archive_slots = 0, archive_unused = 0, archive_ray_begin = 0, archive_ray_end = 0;
+  bool archive_selected = false;
   // post-hoc binning of all segments at once (odw_batch_hits_*, odw_posthoc.hip): per-scene slices of these
   DevBuf phb_row_of, phb_words, phb_sel, phb_small, phb_rows, phb_x, phb_y, phb_part, phb_sel_hist, phb_cand, phb_counts;
   std::vector<uint64_t> phb_used, phb_n, phb_leaving;
@@ -1453,6 +1457,8 @@ void odw_destroy(odw_ctx* ctx) {
   for (DevBuf* b : {&ctx->ph_sel_entering, &ctx->ph_flags, &ctx->ph_x, &ctx->ph_y, &ctx->ph_sorted, &ctx->ph_small,
                     &ctx->ph_part, &ctx->ph_edges, &ctx->ph_edges_b, &ctx->ph_counts, &ctx->ph_sel_hist})
     release(*b);
+  release(ctx->archive);
+  release(ctx->archive_count);
   release(ctx->batch_values);
   release(ctx->batch_hits);
   release(ctx->batch_hit_count);
@@ -2075,7 +2081,8 @@ int odw_trace(odw_ctx* ctx, uint64_t first_ray, uint64_t n_rays, uint64_t seed, 
 // ---- batches: scenes of one structure in one launch (v9) ---------------------------------------------------------
 namespace {
 void batch_unselect(odw_ctx* ctx) {
-  if (ctx->batch_selected < 0) return;
+  if (ctx->batch_selected < 0 && !ctx->archive_selected) return;
+  ctx->archive_selected = false;
   ctx->hits = ctx->own_hits;
   ctx->hit_count = ctx->own_hit_count;
   ctx->hit_capacity = ctx->own_capacity;
@@ -2220,7 +2227,8 @@ int odw_trace_batch(odw_ctx* ctx, uint64_t first_ray, uint64_t rays_per_scene, u
 
 int odw_batch_select(odw_ctx* ctx, int32_t scene) {
   if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_batch_select: null ctx");
-  if (scene < 0) { batch_unselect(ctx); return ODW_OK; }
+  if (scene < 0 || ctx->archive_selected) batch_unselect(ctx);
+  if (scene < 0) return ODW_OK;
   if (scene >= ctx->batch_traced || !ctx->batch_hits.p || !ctx->batch_seg_slots)
     return fail(ctx, ODW_ERR_INVALID, "odw_batch_select: no such segment (odw_trace_batch with ODW_TRACE_RECORD_HITS first)");
   if (ctx->batch_selected < 0) {
@@ -2257,6 +2265,86 @@ int odw_batch_rows(odw_ctx* ctx, uint64_t* rows, uint64_t* wanted, int32_t n) {
     rows[k] = used > v[4 * k + 1] ? used - v[4 * k + 1] : 0;
     if (wanted) wanted[k] = v[4 * k];          // slots asked for (above the segment's room: rows were dropped)
   }
+  return ODW_OK;
+}
+
+static int hit_slots_used(odw_ctx* ctx, uint64_t* used, uint64_t* rows);
+
+// ---- a run's rows kept in HBM (v9) ---------------------------------------------------------------------------------
+int odw_archive_append(odw_ctx* ctx, odw_ctx* src, uint64_t* total_rows) {
+  if (!ctx || !src) return fail(ctx, ODW_ERR_INVALID, "odw_archive_append: null context");
+  if (ctx->device != src->device) return fail(ctx, ODW_ERR_INVALID, "odw_archive_append: the contexts live on different devices");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  batch_unselect(ctx);
+  if (src != ctx) batch_unselect(src);
+  uint64_t used = 0, rows = 0;
+  int rc = hit_slots_used(src, &used, &rows);          // (waits for src's stream: its launch has finished)
+  if (rc) { ctx->err = src->err; return rc; }
+  if (used) {
+    const uint64_t need = ctx->archive_slots + used;
+    if (need > 0x7FFFFFFFull) return fail(ctx, ODW_ERR_CAPACITY, "odw_archive_append: more than 2^31 rows");
+    if (ctx->archive.bytes < need * sizeof(odw_hit)) {
+      // grow by doubling: the rows kept so far move once per doubling
+      DevBuf bigger;
+      const uint64_t cap = std::max<uint64_t>(need, std::max<uint64_t>(1ull << 22, 2 * ctx->archive.bytes / sizeof(odw_hit)));
+      HIPCHK(ctx, hipMalloc(&bigger.p, cap * sizeof(odw_hit)));
+      bigger.bytes = cap * sizeof(odw_hit);
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      if (ctx->archive_slots)
+        HIPCHK(ctx, hipMemcpyAsync(bigger.p, ctx->archive.p, ctx->archive_slots * sizeof(odw_hit), hipMemcpyDeviceToDevice, ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      release(ctx->archive);
+      ctx->archive = bigger;
+    }
+    // (slots tagged unused travel along: every pass over a hit list skips them)
+    HIPCHK(ctx, hipMemcpyAsync((odw_hit*)ctx->archive.p + ctx->archive_slots, src->hits.p, used * sizeof(odw_hit),
+                               hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));    // (src's list may be recycled as soon as this returns)
+    ctx->archive_ray_begin = ctx->archive_slots ? std::min(ctx->archive_ray_begin, src->hit_ray_begin) : src->hit_ray_begin;
+    ctx->archive_ray_end = ctx->archive_slots ? std::max(ctx->archive_ray_end, src->hit_ray_end) : src->hit_ray_end;
+    ctx->archive_slots = need;
+    ctx->archive_unused += used - rows;
+  }
+  if (total_rows) *total_rows = ctx->archive_slots - ctx->archive_unused;
+  return ODW_OK;
+}
+
+int odw_archive_select(odw_ctx* ctx, int32_t on) {
+  if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_archive_select: null ctx");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  batch_unselect(ctx);
+  if (!on) return ODW_OK;
+  if (!ctx->archive_slots) return fail(ctx, ODW_ERR_INVALID, "odw_archive_select: nothing was archived");
+  int rc = ensure(ctx, ctx->archive_count, 2 * sizeof(uint64_t));
+  if (rc) return rc;
+  const uint64_t count[2] = {ctx->archive_slots, ctx->archive_unused};
+  HIPCHK(ctx, hipMemcpyAsync(ctx->archive_count.p, count, sizeof count, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->own_hits = ctx->hits;
+  ctx->own_hit_count = ctx->hit_count;
+  ctx->own_capacity = ctx->hit_capacity;
+  ctx->own_slots = ctx->hit_slots;
+  ctx->own_ray_begin = ctx->hit_ray_begin;
+  ctx->own_ray_end = ctx->hit_ray_end;
+  ctx->hits.p = ctx->archive.p;
+  ctx->hits.bytes = ctx->archive_slots * sizeof(odw_hit);
+  ctx->hit_count.p = ctx->archive_count.p;
+  ctx->hit_count.bytes = 2 * sizeof(uint64_t);
+  ctx->hit_capacity = ctx->hit_slots = ctx->archive_slots;
+  ctx->hit_ray_begin = ctx->archive_ray_begin;
+  ctx->hit_ray_end = ctx->archive_ray_end;
+  ctx->archive_selected = true;
+  ctx->ph_valid = false;
+  return ODW_OK;
+}
+
+int odw_archive_reset(odw_ctx* ctx) {
+  if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_archive_reset: null ctx");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  batch_unselect(ctx);
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  release(ctx->archive);
+  ctx->archive_slots = ctx->archive_unused = 0;
   return ODW_OK;
 }
 

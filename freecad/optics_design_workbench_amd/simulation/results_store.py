@@ -295,6 +295,12 @@ class SimulationResults:
             out.extend(pickle.load(f))
     return out
 
+  def deviceHits(self, group=None):
+    """the run's rows where they are, in HBM (`runSimulation(keepOnDevice=True)`): a `DeviceHits`, or None if the run
+    did not keep them (not asked for, over the budget, several sources or ranks)"""
+    key = getattr(self, '_deviceRunKey', None)
+    return None if key is None else deviceHitsOfRun(key, group)
+
   def hits(self, pattern='*'):
     """everything THIS process recorded so far as one `Hits` (in-memory `loadHits`)"""
     self.flush()
@@ -314,6 +320,40 @@ class SimulationResults:
         for k, v in d.items():
           updateResultEntry(result, k, v)
     return Hits(result)
+
+
+# ---- runs whose rows are still in HBM (runSimulation(keepOnDevice=True)) --------------------------------------------
+_DEVICE_RUNS = {}          # real path of the run folder (or id of the store) -> (store, tracer, owned)
+
+
+def registerDeviceRun(store, tracer, owned):
+  key = os.path.realpath(store.runFolderPath()) if store.basePath is not None else id(store)
+  _DEVICE_RUNS[key] = (store, tracer, owned)
+  store._deviceRunKey = key
+
+
+def releaseDeviceRuns():
+  """drop the rows earlier runs kept on the device (their tracers are closed if the runs created them)"""
+  for key, (store, tracer, owned) in list(_DEVICE_RUNS.items()):
+    try:
+      tracer.archiveReset()
+      if owned:
+        tracer.close()
+    except Exception:
+      pass
+    _DEVICE_RUNS.pop(key, None)
+
+
+def deviceHitsOfRun(key, group=None):
+  """`DeviceHits` on the rows a run kept in HBM, or None"""
+  entry = _DEVICE_RUNS.get(key)
+  if entry is None:
+    return None
+  store, tracer, _ = entry
+  store.drain()
+  tracer.archiveSelect(True)
+  from .device_hits import DeviceHits
+  return DeviceHits(tracer, group)
 
 
 class RawFolder:
@@ -379,7 +419,15 @@ class RawFolder:
     with open(files[-1], 'rb') as f:
       return pickle.load(f)
 
-  def loadHits(self, pattern='*'):
+  def loadHits(self, pattern='*', device=False):
+    """every hit of the run as `Hits` (freecad_document.py:1485-1504).  device=True: if this process made the run with
+    `runSimulation(keepOnDevice=True)` and its rows are still in HBM, a `DeviceHits` on them (histogram(),
+    detectPlaneNormal(), moments() ... where the rows are; `toHits()` for the arrays) -- every recording group's rows
+    (`pattern` must be '*'); otherwise the files are read as usual"""
+    if device and pattern in ('*', '**'):
+      hits = deviceHitsOfRun(os.path.realpath(self._path))
+      if hits is not None:
+        return hits
     if pattern == '*':
       pattern = '**'
     result = {}

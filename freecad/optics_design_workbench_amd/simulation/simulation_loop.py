@@ -36,7 +36,7 @@ def _limit(settings, key, default):
 
 def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPath=None, store=None,
                   raysPerLaunch=1 << 22, endIf=None, tracer=None, pseudoIterationsPerLaunch=64,
-                  dist=None, compileScene='auto', overlapFetch=True, **traceKwargs):
+                  dist=None, compileScene='auto', overlapFetch=True, keepOnDevice=False, **traceKwargs):
   """trace `doc` until its simulation settings' end criteria are met.
 
   action       'true' (continuous Monte-Carlo) | 'singletrue' (one iteration)
@@ -64,6 +64,10 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
                while one traces, the hit columns of the other's previous launch cross PCIe into page-locked arrays and
                go to the writer threads (a thread of this call does that) -- the same files, the order of rays in
                them included; False: one launch at a time, fetched before the next starts
+  keepOnDevice the run's hit rows also stay in HBM (True: up to 64 GB of rows; a number: that many GB), appended launch
+               by launch to an archive on the device: `store.deviceHits()` -- and `RawFolder.loadHits(device=True)` of the
+               same process -- then bin them where they are (`DeviceHits`) instead of reading the run folder back into
+               host arrays (freecad_document.py:1485-1504); the files are written all the same.  One process, one source.
   traceKwargs  maxRayLength, maxIntersections, powerTol, distTol (ray.py:36-38)
   -> SimulationResults
   """
@@ -103,6 +107,11 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
   tr = tracer or Tracer(device)
   if own and compileScene in ('auto', 'structure') and (continuous or compileScene == 'structure'):
     tr.compileScene(compileScene)
+  keep_rows = None
+  if keepOnDevice and hasattr(tr, 'archiveHits') and ranks.world == 1 and len(sources) == 1:
+    results_store.releaseDeviceRuns()                    # (one run at a time keeps its rows on the device)
+    keep_rows = dict(tracer=tr, budget=int((64.0 if keepOnDevice is True else float(keepOnDevice)) * 1e9 // 64), rows=0, complete=True)
+    tr.archiveReset()
   master = ranks.rank == 0
   if master:
     store.setStatus('simulation-is-done', False)
@@ -122,7 +131,7 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
     if (overlapFetch and own and continuous and not pseudo and len(baked) == 1 and ranks.world == 1 and endIf is None
         and not np.isfinite(store.endAfterHits) and hasattr(tr, 'hitColumns')
         and not isinstance(baked[0][2], replay_source.BakedReplay) and not baked[0][0]._props.get('RecordRays', False)):
-      _run_overlapped(store, tr, baked[0], rpi, raysPerLaunch, seed, enabled, compileScene)
+      _run_overlapped(store, tr, baked[0], rpi, raysPerLaunch, seed, enabled, compileScene, keep_rows)
       baked = []                        # (the loop below has nothing left to do)
     while baked:
       for src, scene, bsrc, lim in baked:
@@ -246,6 +255,7 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
         before = store.totalRecordedHits
         if hasattr(tr, 'hitColumns'):
           _store_hit_columns(store, tr, scene, src, per_ray, index_base, enabled)
+          _keep_rows(keep_rows, tr, cnt['recorded_hits'])
         else:                                   # (test doubles without the columnar fetch)
           _store_hits(store, tr.hits(), scene, src, per_ray, index_base, enabled)
         mine = store.totalRecordedHits - before
@@ -282,12 +292,25 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
       store.setStatus('simulation-is-canceled', failed)
       store.setStatus('simulation-is-done', not failed)
       store.setStatus('simulation-is-running', False)
-    if own:
+    if keep_rows is not None and not failed and keep_rows['complete'] and keep_rows['rows']:
+      results_store.registerDeviceRun(store, tr, own)     # (the tracer lives on with the rows: the store closes it)
+    elif own:
       tr.close()
   return store
 
 
-def _run_overlapped(store, tr, baked, rpi, raysPerLaunch, seed, enabled, compileScene):
+def _keep_rows(keep_rows, t, recorded):
+  """runSimulation(keepOnDevice=...): the launch's rows join the run's archive in HBM (device to device)"""
+  if keep_rows is None or not keep_rows['complete'] or not recorded:
+    return
+  if keep_rows['rows'] + recorded > keep_rows['budget']:
+    keep_rows['complete'] = False                       # (over the budget: the run folder is the only copy)
+    keep_rows['tracer'].archiveReset()
+    return
+  keep_rows['rows'] = keep_rows['tracer'].archiveHits(source=t)
+
+
+def _run_overlapped(store, tr, baked, rpi, raysPerLaunch, seed, enabled, compileScene, keep_rows=None):
   """the continuous loop for one device-generated source with the fetch of launch k overlapping the trace of launch
   k + 1 (runSimulation: overlapFetch).  Launch k runs on context k % 2; a fetch thread waits for it, reads its counters,
   has its rows selected and split into columns on the device, copies them into page-locked arrays and hands them to
@@ -326,6 +349,7 @@ def _run_overlapped(store, tr, baked, rpi, raysPerLaunch, seed, enabled, compile
       state['hits_per_ray'] = max(cnt['recorded_hits'] / n, 0.25)
       per_ray = _DeviceInitialConditions(t, bsrc, base, n, seed)
       _store_hit_columns(store, t, scene, src, per_ray, base, enabled)
+      _keep_rows(keep_rows, t, cnt['recorded_hits'])
       store.flush(wait=False)                          # (only this thread adds hits and flushes)
 
     pending = [None, None]

@@ -286,6 +286,24 @@ class Tracer:
     if k is not None:
       self.scene = self.batchScenes[int(k)]
 
+  # -- a run's rows kept in HBM ----------------------------------------------------
+  def archiveHits(self, source=None):
+    """append the rows of `source`'s hit list (default: this tracer's own) to this tracer's archive in HBM
+    (device to device; the source's launch is waited for) -> rows archived so far"""
+    src = self if source is None else source
+    n = C.c_uint64(0)
+    f = self._lib.odw_archive_append
+    f.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64)]
+    self._chk(f(self._ctx, src._ctx, C.byref(n)), 'odw_archive_append')
+    return int(n.value)
+
+  def archiveSelect(self, on=True):
+    """the archive becomes the tracer's hit list (hits(), hitCount(), deviceHits() ...); False: back to its own list"""
+    self._chk(self._lib.odw_archive_select(self._ctx, C.c_int32(1 if on else 0)), 'odw_archive_select')
+
+  def archiveReset(self):
+    self._chk(self._lib.odw_archive_reset(self._ctx), 'odw_archive_reset')
+
   def batchRows(self):
     """(rows recorded per scene, slots asked for per scene) of the last traceBatch"""
     n = len(self.batchScenes)

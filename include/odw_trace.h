@@ -560,6 +560,19 @@ int odw_batch_hits_project(odw_ctx* ctx, const double* ex, const double* ey, con
 int odw_batch_hits_bin(odw_ctx* ctx, int32_t polar, const double* origins, const double* edges_a, int32_t n_a,
                        const double* edges_b, int32_t n_b, uint64_t* counts);
 
+/* ---- a run's rows kept in HBM (v9) ---------------------------------------
+ * The reference keeps a run's hits in its run folder and loads them all into
+ * host arrays to analyse them (freecad_document.py:1485-1504 -> Hits); here a
+ * run can keep its rows on the device: odw_archive_append adds the rows of
+ * src's hit list (src may be ctx itself, or another context of the same device
+ * whose launch has just finished) to ctx's archive, device to device;
+ * odw_archive_select(ctx, 1) makes the archive ctx's hit list for
+ * odw_hit_count / odw_fetch_hits / odw_hits_* (0, or any trace / reserve /
+ * reset call: back to the context's own list); odw_archive_reset drops it.   */
+int odw_archive_append(odw_ctx* ctx, odw_ctx* src, uint64_t* total_rows);
+int odw_archive_select(odw_ctx* ctx, int32_t on);
+int odw_archive_reset(odw_ctx* ctx);
+
 /* device-side handles for collectives (RCCL reduce through torch).  The
  * counters and the detector histogram live in ONE block of 64-bit words,
  * [hist_offset_words words: the ODW_CNT_* counters, zero-padded][n_bins bins],

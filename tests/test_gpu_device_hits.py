@@ -211,3 +211,36 @@ with Tracer(0) as tr:
       assert np.array_equal(a[k], b[k]), (group, k)
     steps = np.diff(a['rayIndex'])
     assert np.all(steps >= 0) and bool(np.all(steps > 0)) == unique
+
+
+def test_a_run_keeps_its_rows_on_the_device(native_lib, tmp_path):
+  """runSimulation(keepOnDevice=True): the rows of every launch join an archive in HBM (odw_archive_append: device to
+  device, also from the second context of the overlapped loop); RawFolder.loadHits(device=True) of the same process
+  bins them where they are -- the Histogram of the files read back (plane, origin, counts), the same moments, the same
+  rows; a later run releases them; without the switch loadHits(device=True) reads the files"""
+  import shutil
+  from conftest import SCENES
+  from freecad.optics_design_workbench_amd.jupyter_utils import FreecadDocument
+  from freecad.optics_design_workbench_amd.simulation import results_store
+  from freecad.optics_design_workbench_amd.simulation.device_hits import DeviceHits
+  path = str(tmp_path / 'GettingStarted.FCStd')
+  shutil.copy(os.path.join(SCENES, 'GettingStarted.FCStd'), path)
+  with FreecadDocument(path) as f:
+    f.OpticalSimulationSettings.EndAfterRays = '3e5'
+    for overlap in (True, False):
+      raw = f.runSimulation('true', raysPerLaunch=70000, keepOnDevice=True, overlapFetch=overlap)
+      host = raw.loadHits()
+      dev = raw.loadHits(device=True)
+      assert isinstance(dev, DeviceHits) and len(dev) == len(host) > 2.9e5
+      kw = dict(binCoords='polar', bins=[np.arange(0, 2 * np.pi, np.pi / 2), np.geomspace(1e-3, 5, 200)])
+      a, b = dev.histogram(**kw), host.histogram(**kw)
+      assert np.array_equal(a.hist, b.hist) and np.allclose(a._origin, b._origin, atol=1e-12)
+      assert np.array_equal(a._planeNormal, b._planeNormal)
+      rows = dev.toHits()
+      order = np.lexsort(host.points().T[::-1])
+      assert np.array_equal(rows.points()[np.lexsort(rows.points().T[::-1])], host.points()[order])
+    assert len(results_store._DEVICE_RUNS) == 1                # (the second run released the first one's rows)
+    plain = f.runSimulation('true', raysPerLaunch=70000)
+    assert not isinstance(plain.loadHits(device=True), DeviceHits)
+  results_store.releaseDeviceRuns()
+  assert not results_store._DEVICE_RUNS
