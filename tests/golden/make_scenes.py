@@ -38,6 +38,9 @@ SCENES = {
   'imported-stepfile-as-surface-source': 'test/80-surface-source-slow/imported-stepfile-as-surface-source.FCStd',
   'external-file': 'test/22-global-placement/external-file.FCStd',
   'external-file2': 'test/22-global-placement/external-file2.FCStd',
+  'lambert-source': 'test/50-old-tests/lambert-source.FCStd',
+  'nesting': 'test/50-old-tests/nesting.FCStd',
+  'replay': 'test/50-old-tests/replay.FCStd',
 }
 
 BREP = {

@@ -1,0 +1,163 @@
+"""Per-ray pins: the polylines the reference drew into its own test documents.
+
+Nine of the reference's documents were saved with the rays of a drawn simulation
+still in them (`RaySegment…` children of the light source, generic_source.py:96-138):
+what OpenCASCADE's intersections, Ray.traceRay's refraction / reflection / grating
+rules and the placement resolution made of 456 rays, edge by edge, with 17 digits.
+tests/golden/make_ray_segment_pins.py reduced them to numbers; here the tracing
+path has to reproduce them -- the oracle in the CPU suite, the HIP path (segment
+recording of `odw_trace_rays`) in the GPU suite, through the same test bodies.
+
+Two readings of every document:
+  * edge by edge -- a ray started where a stored edge starts, along its direction,
+    ends its first segment where the stored edge ends (a nearest-intersection query
+    per stored edge, 1242 in all; also valid behind a random interaction);
+  * ray by ray -- started at the stored first vertex the whole polyline follows
+    (refraction through two imported STEP lenses, overlapping lenses, nested
+    placements, a grating at 480 nm ...); left out where a diffuse mirror redraws
+    the direction.
+The stored coordinates are in the source's local frame (generic_source.py:107-108);
+the source's global placement, resolved by the document reader, maps them back, so
+the placement resolution is pinned along with the rest.
+
+A ray that leaves ends after MaxRayLength (ray.py:107); documents whose limit was
+100 mm when the rays were drawn and is 1000 mm now keep the shorter last edge --
+there the flight has to be free for the stored length and along the stored
+direction.  Tolerance: 1e-9 mm on every vertex (the stored numbers carry 15
+decimals; the largest difference seen is 4e-12)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import BACKENDS, SCENES, _Backend
+from freecad.optics_design_workbench_amd.scene import bake as _bake
+from freecad.optics_design_workbench_amd.scene.fcstd import Document
+
+PINS = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ray_segments.npz')
+TOL = 1e-9
+DOCS = ['grating', 'playground', 'gaussian', 'lambert-source', 'nesting', 'replay', 'edmund-optics-lens',
+        'lens-overlap', 'mirror-diffuse']
+RANDOM_INTERACTION = {'mirror-diffuse'}      # diffuse reflection: a new random direction per hit
+TIES = {'lens-overlap': 1}                   # edges that end in a tie between two lens groups (see the edge test)
+
+
+@pytest.fixture(scope='module', params=BACKENDS)
+def segment_backend(request):
+  b = _Backend(request.param)
+  yield b
+  for t in b._tracers:
+    t.close()
+
+
+_LOADED = {}
+
+
+def stored(doc):
+  """(scene, limits, wavelength, rays) with rays = [[(p1, p2, dir), ...] per stored polyline] in global coordinates"""
+  if doc not in _LOADED:
+    z = np.load(PINS)
+    d = Document(os.path.join(SCENES, doc + '.FCStd'))
+    source = d.getObject(str(z[doc + '__source']))
+    assert source is not None
+    gp = _bake.globalPlacements(d, source, ignoreLinks=True)
+    assert len(gp) == 1
+    m = gp[0].m
+    R, T = m[:3, :3], m[:3, 3]
+    rays = {}
+    for row in z[doc + '__edges']:
+      rays.setdefault(int(row[0]), []).append((R @ row[1:4] + T, R @ row[4:7] + T, R @ row[7:10]))
+    wavelength = float(source.Wavelength) if source.hasProperty('Wavelength') else 500.0
+    _LOADED[doc] = (_bake.bakeScene(d, source), _bake.bakeLimits(d, source), wavelength, [rays[k] for k in sorted(rays)])
+  return _LOADED[doc]
+
+
+def polylines(backend, scene, lim, wavelength, origins, dirs):
+  """per explicit ray the vertices its segments run through: [(k+1, 3) arrays]"""
+  tr = backend._tracers[0] if backend._tracers else backend.tracer()
+  tr.setScene(scene)
+  tr.setLimits(lim)
+  tr.setDetector(None)
+  tr.setWavelength(wavelength)
+  tr.setSurfaceSeed(1234)
+  tr.reserveSegments(len(origins) * lim.max_intersections)
+  tr.reset()
+  tr.resetSegments()
+  tr.traceRays(np.array(origins), np.array(dirs), record_hits=False, histogram=False, record_segments=True)
+  tr.sync()
+  g = tr.segments()
+  assert tr.segmentCount()[1] == 0
+  ray = (g['tag'] & np.uint64(0xFFFFFFFFFF)).astype(np.int64)
+  out = []
+  for i in range(len(origins)):
+    rows = g[ray == i]
+    assert len(rows)
+    out.append(np.vstack([rows['p1'][:1], rows['p2']]))
+  return out
+
+
+def free_flight(edge, last):
+  """a last edge of a whole number of 100 mm is a ray that left: MaxRayLength was 100 or 1000 when it was drawn"""
+  length = np.linalg.norm(edge[1] - edge[0])
+  return last and abs(length - round(length)) < 1e-9 and round(length) in (100, 1000)
+
+
+@pytest.mark.parametrize('doc', DOCS)
+def test_every_stored_edge_ends_where_the_reference_ended_it(segment_backend, doc):
+  scene, lim, wavelength, rays = stored(doc)
+  edges = [(e, i == len(ray) - 1) for ray in rays for i, e in enumerate(ray)]
+  mine = polylines(segment_backend, scene, lim, wavelength, [e[0] for e, _ in edges], [e[2] for e, _ in edges])
+  hits = flights = ties = 0
+  for (e, last), v in zip(edges, mine):
+    assert np.array_equal(v[0], e[0])
+    if free_flight(e, last):
+      # nothing in the way for the stored length, and the same straight line
+      length = np.linalg.norm(e[1] - e[0])
+      assert np.linalg.norm(v[1] - v[0]) >= min(length, lim.max_ray_length) - TOL
+      assert np.abs(v[0] + (v[1] - v[0]) / np.linalg.norm(v[1] - v[0]) * length - e[1]).max() < 1e-9 * max(1.0, length)
+      flights += 1
+    elif np.abs(v[1] - e[1]).max() < TOL:
+      hits += 1
+    else:
+      # intersections closer together than 2 distTol count as one place, and the one that does not belong to
+      # the medium the ray is in wins (ray.py:438-449): a restarted edge has forgotten its medium.  The stored
+      # end then lies on the same line, inside that window behind ours (the whole-ray test below, which
+      # carries the medium, has to hit it exactly)
+      ahead = np.dot(e[1] - v[1], e[2])
+      assert 0 < ahead < 2 * lim.dist_tol and np.abs(v[1] + ahead * e[2] - e[1]).max() < TOL, (doc, e, v[:2])
+      ties += 1
+  assert hits + flights + ties == len(edges) and hits > 0
+  assert ties <= TIES.get(doc, 0)
+
+
+@pytest.mark.parametrize('doc', [d for d in DOCS if d not in RANDOM_INTERACTION])
+def test_whole_rays_follow_the_stored_polylines(segment_backend, doc):
+  scene, lim, wavelength, rays = stored(doc)
+  mine = polylines(segment_backend, scene, lim, wavelength, [r[0][0] for r in rays], [r[0][2] for r in rays])
+  complete = 0
+  for ray, v in zip(rays, mine):
+    ref = np.vstack([ray[0][0][None]] + [e[1][None] for e in ray])
+    # a polyline whose drawing was cut short is a prefix of the ray (one in `playground`, one in `nesting`)
+    assert len(v) >= len(ref), (doc, ref, v)
+    inner = len(ref) - 1 if free_flight(ray[-1], True) else len(ref)
+    assert np.abs(v[:inner] - ref[:inner]).max() < TOL, (doc, ref, v)
+    if inner < len(ref):
+      # the last edge leaves: same direction after the last interaction, and nothing met on the stored stretch
+      length = np.linalg.norm(ref[-1] - ref[-2])
+      step = v[inner] - v[inner - 1]
+      assert np.linalg.norm(step) >= min(length, lim.max_ray_length) - TOL
+      assert np.abs(v[inner - 1] + step / np.linalg.norm(step) * length - ref[-1]).max() < 1e-9 * max(1.0, length)
+    complete += len(v) == len(ref)
+  assert complete >= len(rays) - 1
+
+
+def test_the_pins_cover_what_they_claim():
+  z = np.load(PINS)
+  n_rays = sum(len(np.unique(z[d + '__edges'][:, 0])) for d in DOCS)
+  n_edges = sum(len(z[d + '__edges']) for d in DOCS)
+  assert (n_rays, n_edges) == (456, 1242)
+  # every optical type the flat kernels know meets a stored ray: mirror, lens, grating, absorber, vacuum
+  types = set()
+  for d in DOCS:
+    types |= set(int(t) for t in stored(d)[0].group_type)
+  assert types == {0, 1, 2, 3, 4}
