@@ -151,6 +151,37 @@ def test_whole_rays_follow_the_stored_polylines(segment_backend, doc):
   assert complete >= len(rays) - 1
 
 
+@pytest.mark.parametrize('compiled', ['off', pytest.param('structure', marks=pytest.mark.gpu)])
+@pytest.mark.parametrize('doc', DOCS)
+def test_hit_lists_hold_the_stored_vertices(segment_backend, doc, compiled):
+  """the same rays through the kernels that trace for a living (hit recording on every group; the generic kernel
+  and the one compiled against the scene): a ray's hit rows are the inner vertices of its stored polyline"""
+  if segment_backend.name == 'oracle' and compiled != 'off':
+    pytest.skip('compile modes are a device matter')
+  scene, lim, wavelength, rays = stored(doc)
+  if segment_backend.name == 'device':
+    tr = segment_backend._tracers[0] if segment_backend._tracers else segment_backend.tracer()
+    tr.compileScene(compiled)
+  try:
+    rows = segment_backend.traceRays(scene, lim, np.array([r[0][0] for r in rays]), np.array([r[0][2] for r in rays]),
+                                     wavelength=wavelength)
+    if segment_backend.name == 'device':
+      assert tr.compiledInfo()['mode'] == (1 if compiled == 'structure' else 0)
+  finally:
+    if segment_backend.name == 'device':
+      tr.compileScene('off')
+  owner = (rows['tag'] & np.uint64(0xFFFFFFFFFFFF)).astype(np.int64)
+  for i, ray in enumerate(rays):
+    pts = rows['point'][owner == i]
+    inner = [e[1] for k, e in enumerate(ray) if not free_flight(e, k == len(ray) - 1)]
+    if doc in RANDOM_INTERACTION:
+      inner = inner[:1]
+    else:
+      assert len(pts) >= len(inner)
+    for v in inner:
+      assert len(pts) and np.abs(pts - v).max(axis=1).min() < TOL, (doc, i, v, pts)
+
+
 def test_the_pins_cover_what_they_claim():
   z = np.load(PINS)
   n_rays = sum(len(np.unique(z[d + '__edges'][:, 0])) for d in DOCS)
