@@ -21,3 +21,4 @@ for label, rh, hg in (('full', True, True), ('no hit rows', False, True), ('no h
     tr.sync()
     best = min(best, tr.timingRead()[0])
   print(json.dumps(dict(case=label, ms=round(best, 3))), flush=True)
+tr.close()      # (diagnostic builds print their phase statistics from odw_destroy)

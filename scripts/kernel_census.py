@@ -114,6 +114,9 @@ def main():
            '-I' + d, '-S', '--cuda-device-only', '-o', os.path.join(d, 'k.s'), os.path.join(d, 'odw_kernels.hip')]
     subprocess.run(cmd, check=True, capture_output=True)
     asm = open(os.path.join(d, 'k.s')).read()
+    if os.environ.get('ODW_KEEP_ASM'):      # the assembly itself, to read
+      shutil.copy(os.path.join(d, 'k.s'), os.environ['ODW_KEEP_ASM'])
+      shutil.copy(os.path.join(d, 'odw_spec.h'), os.environ['ODW_KEEP_ASM'] + '.spec.h')
   finally:
     shutil.rmtree(d, ignore_errors=True)
   counts, other, n = census(asm)
