@@ -361,15 +361,25 @@ __device__ __forceinline__ int quad_roots_unit(double bh, double c, double& t0, 
   return 2;
 }
 
+// A/B (round 4): conditions without short-circuit evaluation (compares and scalar ands in a row instead of nests of
+// exec-mask branches with their copies) -- bit 0 box faces, 1 the pick among a primitive's candidates, 2 cylinder side
+// and caps, 3 better()
+#ifndef ODW_FLAT_NOBRANCH
+#define ODW_FLAT_NOBRANCH 15
+#endif
 // ------------------------------------------------------------------------
 struct Best {
   double t;
   int prim, face;
 };
 __device__ __forceinline__ bool better(double t, int p, int f, const Best& b) {
+#if ODW_FLAT_NOBRANCH & 8
+  return (bool)((int)(t < b.t) | ((int)(t == b.t) & ((int)(p < b.prim) | ((int)(p == b.prim) & (int)(f < b.face)))));
+#else
   if (t != b.t) return t < b.t;
   if (p != b.prim) return p < b.prim;
   return f < b.face;
+#endif
 }
 
 struct Query {
@@ -547,12 +557,19 @@ __device__ __forceinline__ void intersect_prim(const SceneView& sv, Query& q, in
     } else {
     double bt = INFINITY;
     int bf = 0;
+    // (ODW_FLAT_NOBRANCH: the six conditions of a face as one expression without short-circuit evaluation -- six
+    //  compares and five scalar ands in a row instead of a nest of exec-mask branches with their copies)
+#if ODW_FLAT_NOBRANCH & 1
+#define ODW_BOX_OK(A, B, C, D, E, F) (bool)((int)(A) & (int)(B) & (int)(C) & (int)(D) & (int)(E) & (int)(F))
+#else
+#define ODW_BOX_OK(A, B, C, D, E, F) ((A) && (B) && (C) && (D) && (E) && (F))
+#endif
 #define ODW_BOX_FACE(T, FACE, P1, D1, S1, P2, D2, S2)                                         \
     {                                                                                         \
       const double t_ = (T);                                                                  \
       const double u_ = fma(t_, D1, P1), v_ = fma(t_, D2, P2);                                \
-      const bool ok_ = ((fmask >> (FACE)) & 1) && t_ > tol && u_ >= -tol && u_ <= (S1) + tol && \
-                       v_ >= -tol && v_ <= (S2) + tol;                                        \
+      const bool ok_ = ODW_BOX_OK(((fmask >> (FACE)) & 1) != 0, t_ > tol, u_ >= -tol, u_ <= (S1) + tol, \
+                                  v_ >= -tol, v_ <= (S2) + tol);                              \
       if (ok_ && (t_ < bt || (t_ == bt && (FACE) < bf))) { bt = t_; bf = (FACE); }            \
     }
     // entry faces: low face when moving in +axis direction
@@ -573,6 +590,7 @@ __device__ __forceinline__ void intersect_prim(const SceneView& sv, Query& q, in
       c.f1 = bf;
     }
 #undef ODW_BOX_FACE
+#undef ODW_BOX_OK
     }
   } else if (type == ODW_PRIM_CYLINDER || type == ODW_PRIM_CONE || (PARAB && type == ODW_PRIM_PARABOLOID)) {
     // one quadric template: cylinder / cone x^2 + y^2 = (R1 + k z)^2, paraboloid x^2 + y^2 = 4 f z
@@ -590,16 +608,26 @@ __device__ __forceinline__ void intersect_prim(const SceneView& sv, Query& q, in
                                 o.x * d.x + o.y * d.y - k * rz * d.z - f2 * d.z,
                                 o.x * o.x + o.y * o.y - rz * rz - 2.0 * f2 * o.z, t0, t1);
       const double z0 = o.z + t0 * d.z, z1 = o.z + t1 * d.z;
+#if ODW_FLAT_NOBRANCH & 4
+      c.t0 = (bool)((int)(nr >= 1) & (int)(z0 >= -tol) & (int)(z0 <= H + tol) & (int)((R1 + k * z0) >= -tol)) ? t0 : c.t0;
+      c.t1 = (bool)((int)(nr == 2) & (int)(z1 >= -tol) & (int)(z1 <= H + tol) & (int)((R1 + k * z1) >= -tol)) ? t1 : c.t1;
+#else
       if (nr >= 1 && z0 >= -tol && z0 <= H + tol && (R1 + k * z0) >= -tol) c.t0 = t0;
       if (nr == 2 && z1 >= -tol && z1 <= H + tol && (R1 + k * z1) >= -tol) c.t1 = t1;
+#endif
     }
     if (fmask & 6) {
       const double invz = frcp(d.z);
       const double ta = (0.0 - o.z) * invz, tb = (H - o.z) * invz;
       const double xa = o.x + ta * d.x, ya = o.y + ta * d.y;
       const double xb = o.x + tb * d.x, yb = o.y + tb * d.y;
+#if ODW_FLAT_NOBRANCH & 4
+      { const bool w_ = (bool)((int)((fmask & 2) != 0) & (int)(R1 > 0) & (int)(xa * xa + ya * ya <= (R1 + tol) * (R1 + tol))); c.t2 = w_ ? ta : c.t2; c.f2 = w_ ? 1 : c.f2; }
+      { const bool w_ = (bool)((int)((fmask & 4) != 0) & (int)(R2 > 0) & (int)(xb * xb + yb * yb <= (R2 + tol) * (R2 + tol))); c.t3 = w_ ? tb : c.t3; c.f3 = w_ ? 2 : c.f3; }
+#else
       if ((fmask & 2) && R1 > 0 && xa * xa + ya * ya <= (R1 + tol) * (R1 + tol)) { c.t2 = ta; c.f2 = 1; }
       if ((fmask & 4) && R2 > 0 && xb * xb + yb * yb <= (R2 + tol) * (R2 + tol)) { c.t3 = tb; c.f3 = 2; }
+#endif
     }
   } else {  // torus
     if (!(fmask & 1)) return;
@@ -705,7 +733,11 @@ __device__ __forceinline__ void intersect_prim(const SceneView& sv, Query& q, in
     // untrimmed: only the nearest admissible candidate can win
     double bt = INFINITY;
     int bf = 0;
+#if ODW_FLAT_NOBRANCH & 2
+#define ODW_PICK(T, F) { const bool w_ = (bool)((int)((T) > tol) & ((int)((T) < bt) | ((int)((T) == bt) & (int)((F) < bf)))); bt = w_ ? (T) : bt; bf = w_ ? (F) : bf; }
+#else
 #define ODW_PICK(T, F) if ((T) > tol && ((T) < bt || ((T) == bt && (F) < bf))) { bt = (T); bf = (F); }
+#endif
     ODW_PICK(c.t0, c.f0)
     ODW_PICK(c.t1, c.f1)
     ODW_PICK(c.t2, c.f2)

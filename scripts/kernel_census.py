@@ -111,6 +111,7 @@ def main():
     text = open(os.path.join(CSRC, 'odw_device.h')).read().replace('"../../../include/odw_trace.h"', '"odw_trace.h"')
     open(os.path.join(d, 'odw_device.h'), 'w').write(text)
     cmd = [_native.hipcc(), '--offload-arch=gfx950', '-std=c++17', '-O3', '-ffp-contract=on', '-DODW_SPEC_HEADER="odw_spec.h"',
+           *os.environ.get('ODW_SPEC_OPTS', '').split(),      # (the experiment switches odw_spec.hip hands hiprtc)
            '-I' + d, '-S', '--cuda-device-only', '-o', os.path.join(d, 'k.s'), os.path.join(d, 'odw_kernels.hip')]
     subprocess.run(cmd, check=True, capture_output=True)
     asm = open(os.path.join(d, 'k.s')).read()
