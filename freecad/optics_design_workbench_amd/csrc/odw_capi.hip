@@ -141,7 +141,8 @@ struct odw_ctx {
   bool batch_launch = false;               // launch_trace: this launch is a batch
   uint64_t batch_stride = 0;               // doubles per scene block
   uint64_t batch_seg_slots = 0, batch_seg_capacity = 0, batch_rays = 0, batch_first = 0;
-  int batch_traced = 0;                    // scenes of the last odw_trace_batch (segments that hold rows)
+  int batch_traced = 0;                    // scenes of the last odw_trace_batch
+  bool batch_rows_ok = false;              // its segments hold rows: the launch recorded hits and was issued without error
   bool batch_marked = false;               // ... whose rows noted their slots in phb_row_of while they were recorded
   int batch_selected = -1;
   std::string batch_spec_text;             // the structure all scenes of the batch share (compiled kernels)
@@ -2116,6 +2117,8 @@ int odw_upload_scene_batch(odw_ctx* ctx, const odw_scene_desc* scenes, int32_t n
   if (!ctx->have_limits) return fail(ctx, ODW_ERR_NO_SCENE, "odw_upload_scene_batch before odw_set_limits (the boxes carry the tolerance)");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   ctx->batch_n = 0;
+  ctx->batch_traced = 0;
+  ctx->batch_rows_ok = false;
   // scene 0 becomes the context's scene (shared integer tables, kernel choice, the compiled kernel's structure)
   int rc = odw_upload_scene(ctx, &scenes[0]);
   if (rc) return rc;
@@ -2177,6 +2180,7 @@ int odw_trace_batch(odw_ctx* ctx, uint64_t first_ray, uint64_t rays_per_scene, u
   if (rays_per_scene == 0) return ODW_OK;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   batch_unselect(ctx);
+  ctx->batch_rows_ok = false;            // (until this launch has been issued: a failed one leaves nothing to select)
   const uint64_t S = (uint64_t)ctx->batch_n;
   if (flags & ODW_TRACE_RECORD_HITS) {
     if (rows_per_scene == 0) return fail(ctx, ODW_ERR_CAPACITY, "odw_trace_batch: ODW_TRACE_RECORD_HITS with rows_per_scene = 0");
@@ -2216,6 +2220,8 @@ int odw_trace_batch(odw_ctx* ctx, uint64_t first_ray, uint64_t rays_per_scene, u
   ctx->batch_first = first_ray;
   const int rc = launch_trace(ctx, first_ray, rays_per_scene, seed, flags, nullptr, nullptr, nullptr);
   ctx->batch_launch = false;
+  ctx->batch_rows_ok = rc == ODW_OK && (flags & ODW_TRACE_RECORD_HITS) != 0;
+  if (rc) ctx->batch_traced = 0;
   const bool dirty = ctx->bvh_dirty;     // (launch_trace may have rebuilt boxes: keep what it set, restore the pointers only)
   (void)dirty;
   ctx->P.scene.prim_f64 = saved.prim_f64;
@@ -2229,7 +2235,7 @@ int odw_batch_select(odw_ctx* ctx, int32_t scene) {
   if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_batch_select: null ctx");
   if (scene < 0 || ctx->archive_selected) batch_unselect(ctx);
   if (scene < 0) return ODW_OK;
-  if (scene >= ctx->batch_traced || !ctx->batch_hits.p || !ctx->batch_seg_slots)
+  if (!ctx->batch_rows_ok || scene >= ctx->batch_traced || !ctx->batch_hits.p || !ctx->batch_seg_slots)
     return fail(ctx, ODW_ERR_INVALID, "odw_batch_select: no such segment (odw_trace_batch with ODW_TRACE_RECORD_HITS first)");
   if (ctx->batch_selected < 0) {
     ctx->own_hits = ctx->hits;
@@ -2254,6 +2260,7 @@ int odw_batch_select(odw_ctx* ctx, int32_t scene) {
 
 int odw_batch_rows(odw_ctx* ctx, uint64_t* rows, uint64_t* wanted, int32_t n) {
   if (!ctx || !rows || n < 0) return fail(ctx, ODW_ERR_INVALID, "odw_batch_rows: bad argument");
+  if (n > 0 && !ctx->batch_rows_ok) return fail(ctx, ODW_ERR_INVALID, "odw_batch_rows: no batch was traced with hit rows");
   if (n > ctx->batch_traced) return fail(ctx, ODW_ERR_INVALID, "odw_batch_rows: more scenes than the batch traced");
   if (n == 0) return ODW_OK;
   HIPCHK(ctx, hipSetDevice(ctx->device));

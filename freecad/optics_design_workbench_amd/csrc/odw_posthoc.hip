@@ -1002,7 +1002,7 @@ extern "C" {
 int odw_batch_hits_select(odw_ctx* ctx, int32_t group, uint64_t* n_rows, uint64_t* n_leaving, int32_t* ordered) {
   if (!ctx || !n_rows || !n_leaving || !ordered) return fail(ctx, ODW_ERR_INVALID, "odw_batch_hits_select: bad argument");
   const int S = ctx->batch_traced;
-  if (S < 1 || !ctx->batch_hits.p || !ctx->batch_seg_slots) return fail(ctx, ODW_ERR_INVALID, "odw_batch_hits_select: no batch was traced with hit rows");
+  if (S < 1 || !ctx->batch_rows_ok || !ctx->batch_hits.p || !ctx->batch_seg_slots) return fail(ctx, ODW_ERR_INVALID, "odw_batch_hits_select: no batch was traced with hit rows");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   ctx->phb_valid = ctx->phb_projected = false;
   const uint64_t n_rays = ctx->batch_rays, ray0 = ctx->batch_first;

@@ -535,7 +535,10 @@ int odw_compile_check(const odw_scene_desc* scene, const odw_limits* limits, int
  * < 0, or any other trace / reserve / reset call: back to the context's own
  * list).  odw_batch_rows: rows recorded per scene, and (optional) the slots
  * asked for -- above the segment's room rows were dropped (counter
- * ODW_CNT_HITS_DROPPED): trace again with more room.                        */
+ * ODW_CNT_HITS_DROPPED): trace again with more room.  The segments belong to
+ * the LAST odw_trace_batch: after one that failed, or one without
+ * ODW_TRACE_RECORD_HITS, odw_batch_select / odw_batch_rows / odw_batch_hits_*
+ * answer ODW_ERR_INVALID instead of handing out an older launch's rows.      */
 int odw_upload_scene_batch(odw_ctx* ctx, const odw_scene_desc* scenes, int32_t n_scenes);
 int odw_trace_batch(odw_ctx* ctx, uint64_t first_ray, uint64_t rays_per_scene, uint64_t seed, uint32_t flags,
                     uint64_t rows_per_scene);

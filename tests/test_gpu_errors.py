@@ -158,3 +158,108 @@ def test_two_contexts_do_not_share_state(native_lib, oracle):
   rb = oracle.trace(b.scene, b.source, b.limits, 0, 20000, 6, nthreads=8)
   assert ca == ra['counters'] and np.array_equal(ha, ra['hist']) and np.array_equal(rows_a['tag'], ra['hits']['tag'])
   assert cb['traced_rays'] == 20000 and abs(cb['recorded_hits'] - rb['counters']['recorded_hits']) <= 0.01 * 20000
+
+
+def _radius_variants(radii):
+  from conftest import SCENES
+  from freecad.optics_design_workbench_amd import scenes
+  from freecad.optics_design_workbench_amd.scene import open_fcstd
+  import os
+  out = []
+  for r in radii:
+    doc = open_fcstd(os.path.join(SCENES, 'GettingStarted.FCStd'))
+    doc.Sphere.Radius = r
+    out.append(scenes.bakeProject(doc))
+  return out
+
+
+def test_batch_entry_points_fail_loudly(tr, native_lib):
+  """ABI v9 batch launches: what a sweep may not do, said as return codes + messages"""
+  a, b = _radius_variants([9.8, 10.1])
+  with pytest.raises(_native.NativeError, match='odw_set_limits'):
+    tr.setSceneBatch([a.scene, b.scene])                       # the boxes carry the tolerance
+  tr.setLimits(a.limits)
+  with pytest.raises(_native.NativeError, match='odw_upload_scene_batch'):
+    tr.traceBatch(0, 100, 1, 200)                              # no batch yet
+  with pytest.raises(ValueError):
+    tr.setSceneBatch([])
+  # scenes of another structure, and scenes the flat kernels do not trace
+  other = project('lensesAndMirrors')
+  with pytest.raises(_native.NativeError, match='differs from scene 0 in structure'):
+    tr.setSceneBatch([a.scene, other.scene])
+  huge = project('hugeArray')
+  tr.setLimits(huge.limits)
+  with pytest.raises(_native.NativeError, match='flat kernels'):
+    tr.setSceneBatch([huge.scene, huge.scene])
+  with pytest.raises(_native.NativeError, match='odw_upload_scene_batch'):
+    tr.traceBatch(0, 100, 1, 200)                              # the failed upload left no batch behind
+  diffuse = project('mirror-diffuse')
+  with pytest.raises(_native.NativeError, match='stochastic'):
+    tr.setSceneBatch([diffuse.scene, diffuse.scene])
+  assert native_lib.odw_upload_scene_batch(tr._ctx, None, 2) == 1
+  assert native_lib.odw_upload_scene_batch(None, None, 2) == 1
+  # a proper batch: rows need room, segments and counts have bounds
+  tr.setLimits(a.limits)
+  tr.setSceneBatch([a.scene, b.scene])
+  with pytest.raises(_native.NativeError, match='source'):
+    tr.traceBatch(0, 100, 1, 200)
+  tr.setSource(a.source)
+  with pytest.raises(_native.NativeError, match='rows_per_scene'):
+    tr.traceBatch(0, 100, 1, 0)
+  with pytest.raises(_native.NativeError, match='no such segment'):
+    tr.batchSelect(0)                                          # nothing traced yet
+  tr.traceBatch(0, 0, 1, 200)                                  # an empty launch is no launch
+  tr.traceBatch(0, 1000, 1, 2000)
+  tr.sync()
+  rows, wanted = tr.batchRows()
+  assert np.array_equal(rows, wanted) and np.all(rows > 900)
+  with pytest.raises(_native.NativeError, match='no such segment'):
+    tr.batchSelect(2)
+  n3 = (C.c_uint64 * 3)()
+  assert native_lib.odw_batch_rows(tr._ctx, n3, None, 3) == 1 and b'more scenes' in native_lib.odw_last_error(tr._ctx)
+  assert native_lib.odw_batch_rows(tr._ctx, None, None, 1) == 1
+  # a segment that is too small keeps what fits and says how much was asked for
+  tr.traceBatch(0, 1000, 1, 100)
+  tr.sync()
+  rows, wanted = tr.batchRows()
+  assert np.all(rows <= 100 + 64) and np.all(wanted > 900) and np.all(rows < wanted)
+  tr.batchSelect(1)
+  assert tr.hitCount() == rows[1]
+  tr.batchSelect(None)
+  # the segments belong to the last batch launch: one without rows leaves nothing to select
+  tr.traceBatch(0, 1000, 1, 2000, record_hits=False)
+  tr.sync()
+  with pytest.raises(_native.NativeError, match='no such segment'):
+    tr.batchSelect(0)
+  with pytest.raises(_native.NativeError, match='no batch was traced with hit rows'):
+    tr.batchRows()
+
+
+def test_archive_entry_points_fail_loudly(tr, native_lib):
+  """ABI v9 rows kept in HBM"""
+  with pytest.raises(_native.NativeError, match='nothing was archived'):
+    tr.archiveSelect()
+  tr.archiveSelect(False)                                      # back to the own list: always fine
+  tr.archiveReset()
+  assert native_lib.odw_archive_append(tr._ctx, None, None) == 1
+  assert native_lib.odw_archive_select(None, 1) == 1 and native_lib.odw_archive_reset(None) == 1
+  pr = project('minimal')
+  tr.setScene(pr.scene); tr.setLimits(pr.limits); tr.setSource(pr.source)
+  assert tr.archiveHits() == 0                                 # an empty list appends nothing
+  with pytest.raises(_native.NativeError, match='nothing was archived'):
+    tr.archiveSelect()
+  tr.reserveHits(4000)
+  tr.trace(0, 1000, 3)
+  n = tr.archiveHits()
+  tr.resetHits()
+  tr.trace(1000, 1000, 3)
+  assert tr.archiveHits() > n > 0
+  tr.archiveSelect()
+  both = tr.hits()
+  tr.archiveSelect(False)
+  own = tr.hits()
+  ray = lambda h: (h['tag'] & np.uint64(0xFFFFFFFFFFFF)).astype(np.int64)
+  assert ray(own).min() >= 1000 and ray(both).min() < 1000 and len(both) > len(own)
+  tr.archiveReset()
+  with pytest.raises(_native.NativeError, match='nothing was archived'):
+    tr.archiveSelect()
