@@ -2119,6 +2119,7 @@ int odw_upload_scene_batch(odw_ctx* ctx, const odw_scene_desc* scenes, int32_t n
   ctx->batch_n = 0;
   ctx->batch_traced = 0;
   ctx->batch_rows_ok = false;
+  ctx->phb_valid = ctx->phb_projected = false;
   // scene 0 becomes the context's scene (shared integer tables, kernel choice, the compiled kernel's structure)
   int rc = odw_upload_scene(ctx, &scenes[0]);
   if (rc) return rc;

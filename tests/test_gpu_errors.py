@@ -263,3 +263,45 @@ def test_archive_entry_points_fail_loudly(tr, native_lib):
   tr.archiveReset()
   with pytest.raises(_native.NativeError, match='nothing was archived'):
     tr.archiveSelect()
+
+
+def test_batched_post_hoc_steps_keep_their_order(tr, native_lib):
+  """odw_batch_hits_*: select, then project, then bin -- of the last batch launch"""
+  a, b = _radius_variants([9.9, 10.0])
+  tr.setLimits(a.limits)
+  tr.setSceneBatch([a.scene, b.scene])
+  tr.setSource(a.source)
+  pd, pu = C.POINTER(C.c_double), C.POINTER(C.c_uint64)
+  n, lv, od = (C.c_uint64 * 2)(), (C.c_uint64 * 2)(), (C.c_int32 * 2)()
+  ex = np.tile([0.0, 1.0, 0.0], 2)
+  ey = np.tile([0.0, 0.0, 1.0], 2)
+  stats, mom = np.zeros(16), np.zeros(12)
+  org, ea, eb = np.zeros(4), np.linspace(-1, 1, 5), np.linspace(-1, 1, 5)
+  counts = np.zeros(2 * 16, dtype=np.uint64)
+  lib = native_lib
+  lib.odw_batch_hits_select.argtypes = [C.c_void_p, C.c_int32, pu, pu, C.POINTER(C.c_int32)]
+  lib.odw_batch_hits_project.argtypes = [C.c_void_p, pd, pd, C.POINTER(C.c_int32), pd, pd]
+  lib.odw_batch_hits_bin.argtypes = [C.c_void_p, C.c_int32, pd, pd, C.c_int32, pd, C.c_int32, pu]
+  as_pd = lambda v: v.ctypes.data_as(pd)
+  select = lambda: lib.odw_batch_hits_select(tr._ctx, -1, n, lv, od)
+  project_ = lambda: lib.odw_batch_hits_project(tr._ctx, as_pd(ex), as_pd(ey), None, as_pd(stats), as_pd(mom))
+  bin_ = lambda e=ea: lib.odw_batch_hits_bin(tr._ctx, 0, as_pd(org), as_pd(e), len(e), as_pd(eb), len(eb), counts.ctypes.data_as(pu))
+  err = lambda: native_lib.odw_last_error(tr._ctx)
+  assert select() == 1 and b'no batch was traced with hit rows' in err()
+  assert project_() == 1 and b'odw_batch_hits_select first' in err()
+  tr.traceBatch(0, 2000, 3, 4000)
+  assert project_() == 1 and b'odw_batch_hits_select first' in err()
+  assert select() == 0 and n[0] > 1900 and n[1] > 1900 and od[0] == 1
+  assert bin_() == 1 and b'odw_batch_hits_project first' in err()
+  assert project_() == 0
+  for k in range(2):                      # the window around each scene's median spot
+    org[2 * k], org[2 * k + 1] = stats[8 * k:8 * k + 2].mean(), stats[8 * k + 4:8 * k + 6].mean()
+  assert bin_(np.array([0.0, 1.0, 0.5])) == 1 and b'monotonically' in err()
+  assert lib.odw_batch_hits_bin(tr._ctx, 0, as_pd(org), as_pd(ea), 1, as_pd(eb), len(eb), counts.ctypes.data_as(pu)) == 1
+  assert bin_() == 0 and counts.sum() > 0
+  # a new launch, or a new batch, starts over
+  tr.traceBatch(0, 2000, 4, 4000)
+  assert bin_() == 1 and project_() == 1
+  assert select() == 0
+  tr.setSceneBatch([a.scene, b.scene])
+  assert project_() == 1 and select() == 1
