@@ -196,3 +196,28 @@ def test_batched_measure_equals_the_measure_segment_by_segment(tracer):
     assert fw[k] == sweep.calcFwhm(h) or (np.isnan(fw[k]) and np.isnan(sweep.calcFwhm(h)))
     assert rms[k] == sweep.rmsSpot(h)
   tracer.batchSelect(None)
+
+
+def test_sweep_traces_again_when_a_value_needs_more_rows(native_lib):
+  """a recording lens gives three rows per ray, more than the room a sweep reserves at first (1.25 per ray): the
+  launch reports the rows it dropped and the sweep traces again with room -- one by one and in batches the same table"""
+  from freecad.optics_design_workbench_amd.scene import open_fcstd
+  from freecad.optics_design_workbench_amd.simulation import sweep
+  from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
+  doc = open_fcstd(os.path.join(SCENES, 'GettingStarted.FCStd'))
+  doc.OpticalLensGroup.RecordHits = True
+
+  def setRadius(d, r):
+    d.Sphere.Radius = r
+  radii = np.linspace(9.5, 10.5, 7)
+  res = {}
+  for batch in (0, 4):
+    with Tracer(0) as tr:
+      res[batch] = sweep.parameterSweep(doc, setRadius, radii, rays=100_000, seed=5, tracer=tr, batch=batch,
+                                        measure=dict(rms=sweep.rmsSpot, rows=len))
+  for batch in (0, 4):
+    assert res[batch].tracedRays == 7 * 100_000
+    assert res[batch].recordedHits > 2.9 * res[batch].tracedRays          # (counted once: by the launch that had room)
+    assert np.array_equal(res[batch].columns['rows'], res[0].columns['rows']) and np.all(res[batch].columns['rows'] > 290_000)
+  assert np.array_equal(res[4].columns['rms'], res[0].columns['rms'])
+  assert res[4].recordedHits == res[0].recordedHits == int(res[0].columns['rows'].sum())
