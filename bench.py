@@ -109,6 +109,12 @@ def cpu_baseline(proj, det, seconds=12.0):
               sample=f'{done} rays of the same workload (oracle/odw_oracle.c, OpenMP, {dt:.1f} s)')
 
 
+# ODW_BENCH_REHEARSE=1: the N ranks of `--gpus N` all work on GPU 0 and talk through gloo -- the launcher, the shards,
+# the reduce, the max-over-ranks clock and rank 0's checks run as on a node, on a box with one GPU.  The line says so
+# ("rehearsal"); its value is not a measurement.
+REHEARSE = os.environ.get('ODW_BENCH_REHEARSE') == '1'
+
+
 def spawn_ranks(args, argv):
   """--gpus N > 1 without a launcher: start the N ranks as a CHILD process.  Counting the devices may
   initialise the HIP runtime in this process (torch.cuda.device_count() calls hipGetDeviceCount); that is
@@ -117,7 +123,7 @@ def spawn_ranks(args, argv):
   pick (--standalone on 127.0.0.1: no bind-then-close race)."""
   import torch
   have = torch.cuda.device_count()
-  if have < args.gpus:
+  if have < args.gpus and not REHEARSE:
     sys.stderr.write(f'bench.py: --gpus {args.gpus} asked for, {have} device(s) present\n')
     return 2
   cmd = [sys.executable, '-m', 'torch.distributed.run', '--standalone', '--local-addr', '127.0.0.1', '--nnodes=1',
@@ -371,7 +377,7 @@ def run_trace_config(args, cfg_name, cfg, rank, local_rank, world, dist, torch):
   kernel_ms, launches = tr.timingRead()
 
   if dist is not None:
-    t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+    t = torch.tensor([dt], dtype=torch.float64, device='cpu' if REHEARSE else 'cuda')
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
@@ -509,7 +515,7 @@ def run_sweep_config(args, cfg, rank, local_rank, world, dist, torch):
     launches += n
   radii_of_rank = len(sweep.shareOfRank(len(radii), rank, world)) * args.steps
   if dist is not None:
-    t = torch.tensor([dt], dtype=torch.float64, device='cuda')
+    t = torch.tensor([dt], dtype=torch.float64, device='cpu' if REHEARSE else 'cuda')
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
   # the notebook's figure of merit on the notebook's sample size: calcFwhm of the ~1000 thinned rows per radius the
@@ -607,14 +613,19 @@ def main():
     sys.exit(2)
 
   import torch
-  if torch.cuda.device_count() < world:
+  if torch.cuda.device_count() < world and not REHEARSE:
     sys.stderr.write(f'bench.py: {world} rank(s) but {torch.cuda.device_count()} device(s) present\n')
     sys.exit(2)
   dist = None
+  if REHEARSE:
+    local_rank = 0                       # (from here on: the device a rank works on)
   if launched:   # launched by torch.distributed.run (also with one rank)
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)
-    dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    if REHEARSE:
+      dist.init_process_group('gloo')
+    else:
+      dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
   if args.config == 'c5':
     out = run_sweep_config(args, cfg, rank, local_rank, world, dist, torch)
@@ -646,6 +657,8 @@ def main():
       # the same figures as plain numbers where a reader that keeps only the scalars of `config` still finds them
       for name, line in extra.items():
         out['config'].update(summary_scalars(name, line))
+  if rank == 0 and REHEARSE:
+    out['rehearsal'] = f'{world} rank(s) on GPU 0 over gloo (ODW_BENCH_REHEARSE=1): the flow of a node, not a measurement'
   if rank == 0:
     detail = json.dumps(out)
     # the full record (instruction mixes, per-radius tables) goes to stderr and, where the folder exists, to

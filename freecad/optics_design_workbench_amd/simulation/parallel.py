@@ -33,7 +33,15 @@ def reduceResults(tracer, dist, torch, dst=0):
   view, _ = tracer.resultsView()
   if hasattr(view, '__cuda_array_interface__'):
     t = torch.as_tensor(view, device=torch.device('cuda', tracer.device))
-    dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM)
+    if dist.get_backend() == 'nccl':
+      dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM)
+    else:
+      # a group without a device backend (gloo: ranks that share one GPU, a rehearsal of a node on one): the block
+      # travels through host memory, still as one reduce
+      h = t.cpu()
+      dist.reduce(h, dst=dst, op=dist.ReduceOp.SUM)
+      if dist.get_rank() == dst:
+        t.copy_(h)
     torch.cuda.synchronize()
   else:                                  # a block in host memory (the CPU stand-in of the tests, gloo)
     dist.reduce(torch.from_numpy(view), dst=dst, op=dist.ReduceOp.SUM)

@@ -324,3 +324,47 @@ def test_two_rank_run_simulation_on_two_gpus(native_lib, tmp_path):
 
   assert len(merged['points']) == len(single['points']) > 150000
   assert np.array_equal(rows(merged), rows(single))
+
+
+# A node rehearsed on one GPU (ODW_BENCH_REHEARSE=1): bench.py's ranks all work on GPU 0 and talk through gloo.  What
+# it executes: the launcher bench.py starts itself, the shards, the single reduce (through host memory here), the
+# max-over-ranks clock, rank 0's checks on the job's totals.  What it cannot: RCCL between devices (the tests above).
+def test_rehearsal_four_ranks_on_one_gpu_equal_the_sum_of_their_shards(native_lib, tmp_path):
+  from freecad.optics_design_workbench_amd import scenes
+  from freecad.optics_design_workbench_amd.simulation import parallel
+  from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
+  import bench
+  env = dict(ODW_BENCH_REHEARSE='1')
+  n_per, steps, world = 1_000_000, 2, 4
+  dump = str(tmp_path / 'c3_job.npz')
+  out = _line(_bench('--gpus', str(world), '--steps', str(steps), '--warmup', '1', '--rays-per-step', str(n_per),
+                     '--no-cpu-baseline', '--no-end-to-end', '--dump-results', dump, env=env))
+  assert out['n_gpus'] == world and 'rehearsal' in out and out['config']['parallelism'].startswith('ray-index sharding x4')
+  assert out['value'] * out['ms_per_step'] * 1e-3 == pytest.approx(world * n_per, rel=1e-6)
+  job = np.load(dump)
+  pr = project('lensesAndMirrors')
+  det = scenes.planeDetector(pr.scene, 'OpticalAbsorberGroup', nx=1024, ny=1024, toward=pr.source.xform[[3, 7, 11]])
+  hist, cnt = None, None
+  with Tracer(0) as tr:
+    tr.setScene(pr.scene); tr.setSource(pr.source); tr.setLimits(pr.limits); tr.setDetector(det)
+    tr.reserveHits(2 * n_per)
+    for rank in range(world):
+      tr.reset()
+      for s in range(steps):
+        tr.resetHits()
+        tr.trace(parallel.shardFirst(s, rank, world, n_per), n_per, bench.SEED)
+      tr.sync()
+      c = tr.counters()
+      h = tr.histogram().astype(np.int64)
+      hist = h if hist is None else hist + h
+      cnt = c if cnt is None else {k: cnt[k] + c[k] for k in c}
+  assert cnt['traced_rays'] == world * steps * n_per
+  assert [int(v) for v in job['counters']] == [cnt[k] for k in sorted(cnt)]
+  assert np.array_equal(job['hist'].astype(np.int64), hist)
+  # the sweep dealt out over three ranks: the 1-rank table bit for bit
+  args = ['--config', 'c5', '--radii', '7', '--rays-per-step', '2e5', '--no-cpu-baseline']
+  t1 = _line(_bench('--gpus', '1', *args))['config']['spot_size']
+  t3 = _line(_bench('--gpus', '3', *args, env=env))
+  assert t3['n_gpus'] == 3 and t3['scaling'] == 'strong' and 'rehearsal' in t3
+  for col in ('fwhm_mm', 'rms_spot_mm', 'fwhm_1e3_mm'):
+    assert t3['config']['spot_size'][col] == t1[col], col
