@@ -274,10 +274,11 @@ sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], 't
 import numpy as np, torch, torch.distributed as dist
 from freecad.optics_design_workbench_amd.scene import open_fcstd
 from freecad.optics_design_workbench_amd.simulation import runSimulation, resultsFolderPath
-local = int(os.environ['LOCAL_RANK'])
+backend = os.environ.get('ODW_TEST_BACKEND', 'nccl')      # (gloo: both ranks on GPU 0, a node rehearsed on one GPU)
+local = int(os.environ['LOCAL_RANK']) if backend == 'nccl' else 0
 # (deliberately no torch.cuda.set_device: runSimulation(device=LOCAL_RANK) alone must put every collective on
 #  the tracer's device -- parallel.Ranks settles that before any GPU work, on every rank alike)
-dist.init_process_group('nccl')
+dist.init_process_group(backend)
 doc = open_fcstd(sys.argv[2])
 st = doc.OpticalSimulationSettings
 st.EndAfterRays, st.EndAfterHits = 'inf', '150000'
@@ -285,18 +286,19 @@ st.StoreHitInitPhi = True
 store = runSimulation(doc, 'true', seed=42, resultsPath=resultsFolderPath(sys.argv[2]), raysPerLaunch=70000, device=local)
 assert store.totalRecordedHits > 150000, store.totalRecordedHits     # the job's total, on every rank
 loc = len(store.hits())
-total = torch.tensor([loc], device=torch.device('cuda', local)); dist.all_reduce(total)
+total = torch.tensor([loc], device=torch.device('cuda', local) if backend == 'nccl' else 'cpu'); dist.all_reduce(total)
 assert int(total) == store.totalRecordedHits and 0 < loc < store.totalRecordedHits
 dist.barrier()
 dist.destroy_process_group()
 '''
 
 
-@two_ranks
-def test_two_rank_run_simulation_on_two_gpus(native_lib, tmp_path):
-  """runSimulation under a 2-rank launcher on two GPUs (simulation_loop.py:386-396, 450-507: the workers of the
-  reference): launches sharded by ray index, both ranks write into ONE run folder, three int64 totals per launch
-  all-reduced over RCCL; the merged folder holds the single-process rows, row for row"""
+@pytest.mark.parametrize('backend', [pytest.param('nccl', marks=two_ranks), 'gloo'])
+def test_two_rank_run_simulation(native_lib, tmp_path, backend):
+  """runSimulation under a 2-rank launcher (simulation_loop.py:386-396, 450-507: the workers of the reference):
+  launches sharded by ray index, both ranks write into ONE run folder, three int64 totals per launch all-reduced; the
+  merged folder holds the single-process rows, row for row.  nccl: on two GPUs over RCCL; gloo: both ranks on GPU 0
+  (the rehearsal every GPU box can run)"""
   import shutil
   from conftest import SCENES
   from freecad.optics_design_workbench_amd.scene import open_fcstd
@@ -307,7 +309,8 @@ def test_two_rank_run_simulation_on_two_gpus(native_lib, tmp_path):
   script.write_text(RUN_WORKER)
   cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2',
          '--master-addr', '127.0.0.1', '--master-port', str(_port()), str(script), ROOT, path]
-  res = subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'), capture_output=True, text=True, timeout=900)
+  res = subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', ODW_TEST_BACKEND=backend), capture_output=True,
+                       text=True, timeout=900)
   assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-3000:]
   folders = rawFolders(resultsFolderPath(path))
   assert len(folders) == 1
