@@ -158,3 +158,27 @@ def test_crowded_scenes_on_the_flat_and_on_the_grid_kernels(native_lib, oracle, 
       d1 = np.abs(g['point'][first] - r['point'][first]).max(axis=1)
       assert d1.max() < 1e-9, (s, float(d1.max()))
   assert scenes >= 12 and big >= 8 and differing_rays <= 2, (scenes, big, differing_rays)
+
+
+@pytest.mark.parametrize('compile', ['off', 'structure'])
+@pytest.mark.parametrize('rich', [False, True])
+def test_random_scenes_in_batches_equal_their_own_launches(native_lib, rich, compile):
+  """batch launches (ABI v9) on random structures: K variants of a random scene that differ in their numbers only, one
+  launch for all against a launch each -- every row and the counters bit for bit (tests/fuzz_batch.py is the long form).
+  rich: gratings, absorbing media, partly reflecting mirrors, sequential mode (stochastic surfaces and facets are
+  traced one by one by design)"""
+  from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
+  import fuzz_batch
+  done = rows = 0
+  with Tracer(0) as tr:
+    tr.compileScene(compile)
+    for s in range(30 if compile == 'off' else 10):
+      r = fuzz_batch.one_trial(tr, 31 * 100003 + s, 2 + s % 4, 4000, rich=rich)
+      if r is None or 'skipped' in r:
+        continue
+      assert r['differing'] == 0, (s, r)
+      assert r['distinct_segments'] > 1 or r['rows'] == 0, (s, r)      # (the variants are different scenes)
+      done += 1
+      rows += r['rows']
+  # (rich: most seeds bring facets or a stochastic surface and are left out)
+  assert done >= ((12 if compile == 'off' else 4) if not rich else (4 if compile == 'off' else 1)) and rows > 3000, (done, rows)
