@@ -81,3 +81,30 @@ def test_linspace_of_ten_is_numpy_linspace():
     w = np.float64(abs(rng.normal()) * 10.0 ** rng.integers(-14, 1))
     assert _linspace10(a - w, a + w).tobytes() == np.linspace(a - w, a + w, 10).tobytes()
   assert _linspace10(np.float64(1.5), np.float64(1.5)).tobytes() == np.linspace(1.5, 1.5, 10).tobytes()
+
+
+def test_searches_in_lockstep_are_the_single_searches(native_lib):
+  """`flattestDirections` (the plane searches of a batch of segments, level by level, one library call per level:
+  odw_plane_screen_batch) against `flattestDirection` cloud by cloud: the same normals bit for bit -- tilted planes,
+  thin slabs, axis-aligned planes (ties between candidates), blobs; groups of one to nine clouds, clouds of one point"""
+  from freecad.optics_design_workbench_amd.simulation.device_hits import flattestDirection, flattestDirections
+  rng = np.random.default_rng(424242)
+  pool = [c for _, c in _clouds(rng, 120)]
+  pool.append(np.array([[1.0, 2.0, 3.0]]))                     # one point: every direction is flat
+  pool.append(np.zeros((5, 3)))
+  pos = 0
+  while pos < len(pool):
+    size = int(rng.integers(1, 10))
+    group = pool[pos:pos + size]
+    pos += size
+    got = flattestDirections(native_lib, group, 1e-9)
+    assert len(got) == len(group)
+    for cloud, g in zip(group, got):
+      want = flattestDirection(native_lib, cloud, 1e-9)
+      assert g.tobytes() == want.tobytes(), (len(cloud), g, want)
+  # a cloud with a nan fails the batch like it fails its own search
+  bad = np.ones((10, 3))
+  bad[3, 1] = np.nan
+  with pytest.raises(ValueError):
+    flattestDirections(native_lib, [pool[0], bad, pool[1]], 1e-9)
+  assert flattestDirections(native_lib, [], 1e-9) == []
