@@ -472,6 +472,9 @@ __device__ __forceinline__ void cand_min2(Cands& c, double t, int f) {
   c.f0 = lt0 ? f : c.f0;
 }
 
+#ifndef ODW_CYL_SIDE_SKIP
+#define ODW_CYL_SIDE_SKIP 1      // (A/B: 0 = every cylinder side by its quadratic)
+#endif
 #ifndef ODW_TORUS_PLAIN
 #define ODW_TORUS_PLAIN 96     // plain distance steps before the curvature bound joins in
 #endif
@@ -601,7 +604,23 @@ __device__ __forceinline__ void intersect_prim(const SceneView& sv, Query& q, in
     const double H = (type == ODW_PRIM_CONE) ? par[2] : par[1];
     const double k = (type == ODW_PRIM_CONE) ? (R2 - R1) / H : 0.0;
     const double f2 = parab ? 2.0 * par[0] : 0.0;
-    if (fmask & 1) {
+    // A cylinder's side without its quadratic (flat kernels): the squared distance from the axis is convex along the
+    // ray, so a ray that is inside the radius where it crosses the planes z = -tol and z = H + tol is inside in between
+    // -- no root of the side can pass the z test below.  A beam through the inside of a lens is that case for every
+    // lane of a wave: two plane distances and two squared radii (14 instructions) instead of discriminant, square root,
+    // reciprocal and roots (~55).  The margin (1e-9 of R^2: the roots then lie >= 5e-10 R beyond the planes) is far above
+    // the roots' rounding; anything closer, a ray parallel to the caps (NaN), cones and paraboloids take the quadratic.
+    constexpr bool side_skip = ODW_CYL_SIDE_SKIP && (SPEC::enabled || !PARAB);
+    bool side = (fmask & 1) != 0;
+    double invz = 0.0;
+    if ((fmask & 6) || (side_skip && type == ODW_PRIM_CYLINDER && side)) invz = frcp(d.z);
+    if (side_skip && type == ODW_PRIM_CYLINDER && side) {
+      const double tl = (-tol - o.z) * invz, th = (H + tol - o.z) * invz;
+      const double xl = fma(tl, d.x, o.x), yl = fma(tl, d.y, o.y), xh = fma(th, d.x, o.x), yh = fma(th, d.y, o.y);
+      const double lim = R1 * R1 * (1.0 - 1e-9);
+      side = !(fma(xl, xl, yl * yl) < lim && fma(xh, xh, yh * yh) < lim);
+    }
+    if (side) {
       const double rz = R1 + k * o.z;
       double t0 = INFINITY, t1 = INFINITY;
       const int nr = quad_roots(d.x * d.x + d.y * d.y - k * k * d.z * d.z,
@@ -617,7 +636,6 @@ __device__ __forceinline__ void intersect_prim(const SceneView& sv, Query& q, in
 #endif
     }
     if (fmask & 6) {
-      const double invz = frcp(d.z);
       const double ta = (0.0 - o.z) * invz, tb = (H - o.z) * invz;
       const double xa = o.x + ta * d.x, ya = o.y + ta * d.y;
       const double xb = o.x + tb * d.x, yb = o.y + tb * d.y;
