@@ -361,6 +361,17 @@ __device__ __forceinline__ int quad_roots_unit(double bh, double c, double& t0, 
   return 2;
 }
 
+// Diagnostic builds (-DODW_DOUBLE=k, through ODW_SPEC_OPTS for the compiled kernels): piece k of the ray loop is
+// computed TWICE, the second time behind an operand the compiler cannot see through, and the two outcomes are merged so
+// that the results stay what they are -- the launch's extra time is what that piece costs as it runs (all lanes, all
+// waves, cache and scheduling effects included).  1 box tests, 2 sphere roots, 3 cylinder / cone side and caps, 4 box
+// faces, 5 trimming tests, 6 normal at the hit, 7 mirror / Snell, 8 ray generation, 9 inverse direction of a segment.
+// scripts/gpu_double_profile.sh runs them all.
+#ifndef ODW_DOUBLE
+#define ODW_DOUBLE 0
+#endif
+__device__ __forceinline__ double opq(double x) { asm volatile("" : "+v"(x)); return x; }
+
 // A/B (round 4): conditions without short-circuit evaluation (compares and scalar ands in a row instead of nests of
 // exec-mask branches with their copies) -- bit 0 box faces, 1 the pick among a primitive's candidates, 2 cylinder side
 // and caps, 3 better()
@@ -444,6 +455,9 @@ __device__ __forceinline__ void consider_spec(const SceneView& sv, Query& q, dou
   if (!cand_any && !cand_oth) return;
   if constexpr (SPEC::cond_cnt(PI) > 0) {
     if (!trim_ok<PARAB, SPEC, SPEC::cond_off(PI), SPEC::cond_off(PI) + SPEC::cond_cnt(PI)>(sv, q, q.start + q.dn * t)) return;
+#if ODW_DOUBLE == 5
+    if (!trim_ok<PARAB, SPEC, SPEC::cond_off(PI), SPEC::cond_off(PI) + SPEC::cond_cnt(PI)>(sv, q, q.start + q.dn * opq(t))) return;
+#endif
   }
   if (cand_any) { q.any.t = t; q.any.prim = PI; q.any.face = face; }
   if (cand_oth) { q.oth.t = t; q.oth.prim = PI; q.oth.face = face; }
@@ -504,6 +518,13 @@ __device__ __forceinline__ void intersect_prim(const SceneView& sv, Query& q, in
         c.t0 = t0;
         c.t1 = t1;
       }
+#if ODW_DOUBLE == 2
+      {
+        const d3 oc2 = mk(opq(oc.x), oc.y, oc.z);
+        double u0 = INFINITY, u1 = INFINITY;
+        if (quad_roots_unit(dot(oc2, q.dn), dot(oc2, oc2) - par[0] * par[0], u0, u1) == 2) { c.t0 = u0 == c.t0 ? c.t0 : u0; c.t1 = u1 == c.t1 ? c.t1 : u1; }
+      }
+#endif
     }
   } else {
   d3 o, d;
@@ -906,10 +927,22 @@ __device__ __forceinline__ void spec_prim(const SceneView& sv, Query& q, d3 oi, 
       } else {
         const double cut = fmin(q.tmax, q.any.t + 2.0 * q.tol);
         in_box = ray_box(sv.prim_hdr + 8 * PI, oi, inv, cut);
+#if ODW_DOUBLE == 1
+        in_box = in_box & ray_box(sv.prim_hdr + 8 * PI, mk(opq(oi.x), oi.y, oi.z), inv, cut);
+#endif
       }
       boxhit[PI] = in_box;
       if (in_box)
         intersect_prim<SPEC::parab(), SPEC, PI>(sv, q, PI, SPEC::type(PI), SPEC::group(PI), flags, SPEC::cond_word(PI));
+#if ODW_DOUBLE == 3 || ODW_DOUBLE == 4 || ODW_DOUBLE == 12
+      // (the second pass finds the candidates already known: consider_spec leaves early, before the trimming tests)
+      if (in_box && SPEC::type(PI) == (ODW_DOUBLE == 3 ? ODW_PRIM_CYLINDER : (ODW_DOUBLE == 4 ? ODW_PRIM_BOX : ODW_PRIM_SPHERE))) {
+        Query q2 = q;
+        q2.start.x = opq(q.start.x);
+        intersect_prim<SPEC::parab(), SPEC, PI>(sv, q2, PI, SPEC::type(PI), SPEC::group(PI), flags, SPEC::cond_word(PI));
+        q.any = q2.any; q.oth = q2.oth;
+      }
+#endif
     } else if constexpr (SPEC::box_of(PI) == PI) {
       // (skipped for this lane -- not relevant, or the convex solid just left --, but a later primitive may
       //  ask for this box: its own test then)
@@ -935,8 +968,20 @@ __device__ __forceinline__ int nearest(const DeviceScene& sc, const SceneView& s
   q.medium = medium;
   q.any.t = INFINITY; q.any.prim = 0x7fffffff; q.any.face = 0x7fffffff;
   q.oth = q.any;
+#if ODW_DOUBLE == 9
+  d3 inv = mk(frcp1(dn.x), frcp1(dn.y), frcp1(dn.z));
+  d3 oi = mk(start.x * inv.x, start.y * inv.y, start.z * inv.z);
+  {
+    const d3 dn2 = mk(opq(dn.x), opq(dn.y), opq(dn.z));
+    const d3 inv2 = mk(frcp1(dn2.x), frcp1(dn2.y), frcp1(dn2.z));
+    const d3 oi2 = mk(start.x * inv2.x, start.y * inv2.y, start.z * inv2.z);
+    inv = inv2.x == inv.x ? inv : inv2;
+    oi = oi2.y == oi.y ? oi : oi2;
+  }
+#else
   const d3 inv = mk(frcp1(dn.x), frcp1(dn.y), frcp1(dn.z));
   const d3 oi = mk(start.x * inv.x, start.y * inv.y, start.z * inv.z);
+#endif
   if constexpr (SPEC::enabled) {
     spec_prims<SPEC>(sv, q, oi, inv, skip_solid, only_solid, mask, __make_integer_seq<IndexList, int, SPEC::N>{});
   } else if (!BVH) {
@@ -1411,7 +1456,12 @@ __device__ __forceinline__ void interact(const TraceParams& P, cf64 group_f64, c
                          hit_state, win);   // (interact is inlined into the kernel: the pointer is the kernel's)
   }
   if (gtype == ODW_OPT_MIRROR) {
+#if ODW_DOUBLE == 7
+    d3 ideal = mirror(dir, n);
+    { const d3 again = mirror(mk(opq(dir.x), dir.y, dir.z), n); ideal = again.x == ideal.x ? ideal : again; }
+#else
     const d3 ideal = mirror(dir, n);
+#endif
     if (STOCH) dir = scatter(P.samplers, P.group_sampler[2 * g], P.group_sampler[2 * g + 1], ray, P.seed, (uint32_t)nint,
                              dir, ideal, n, 1.0);
     else dir = ideal;
@@ -1422,7 +1472,12 @@ __device__ __forceinline__ void interact(const TraceParams& P, cf64 group_f64, c
     double n2 = 1.0;
     if (entering) { medium = g; n2 = group_f64[4 * g]; }
     bool tir;
+#if ODW_DOUBLE == 7
+    d3 ideal = snells_law(dir, n1, n2, n, tir);
+    { bool tir2; const d3 again = snells_law(mk(opq(dir.x), dir.y, dir.z), n1, n2, n, tir2); ideal = again.x == ideal.x ? ideal : again; tir = tir & tir2; }
+#else
     const d3 ideal = snells_law(dir, n1, n2, n, tir);
+#endif
     if (STOCH) dir = scatter(P.samplers, P.group_sampler[2 * g], P.group_sampler[2 * g + 1], ray, P.seed, (uint32_t)nint,
                              dir, ideal, n, tir ? -1.0 : n1 / n2);
     else dir = ideal;
@@ -1472,6 +1527,14 @@ __device__ __forceinline__ void spec_hit(const TraceParams& P, const SceneView& 
   d3 n = face_normal<SPEC::parab()>(SPEC::type(PI), pf + 12, face, xf_point_nz<SPEC::xf(PI)>(pf, point));
   if constexpr ((flags & ODW_FLAG_FLIP_NORMAL) != 0) n = n * -1.0;
   n = xf_vec_t_nz<SPEC::xf(PI)>(pf, n);
+#if ODW_DOUBLE == 6
+  {
+    d3 n2 = face_normal<SPEC::parab()>(SPEC::type(PI), pf + 12, face, xf_point_nz<SPEC::xf(PI)>(pf, mk(opq(point.x), point.y, point.z)));
+    if constexpr ((flags & ODW_FLAG_FLIP_NORMAL) != 0) n2 = n2 * -1.0;
+    n2 = xf_vec_t_nz<SPEC::xf(PI)>(pf, n2);
+    n = n2.x == n.x ? n : n2;
+  }
+#endif
   const bool entering = dot(dir, n) < 0;
   if (entering) n = n * -1.0;
   interact<false, STOCH, LEAN>(P, group_f64, group_i32, group_gdir, g, SPEC::gtype(g), SPEC::record(g), n, entering, ray,
@@ -1667,6 +1730,14 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
         } else {
           const RayInit r = generate_ray(P.source, P.first_ray + i, P.seed);
           point = r.point; dir = r.dir; power = r.power;
+#if ODW_DOUBLE == 8
+          {
+            uint32_t lo = (uint32_t)(P.first_ray + i);
+            asm volatile("" : "+v"(lo));
+            const RayInit r2 = generate_ray(P.source, ((P.first_ray + i) & ~0xFFFFFFFFull) | lo, P.seed);
+            dir = r2.dir.x == dir.x ? dir : r2.dir;
+          }
+#endif
         }
         // `dir` stays a unit vector: mirror() preserves length, snells_law() and
         // line_grating() return unit vectors for unit input; the reference
