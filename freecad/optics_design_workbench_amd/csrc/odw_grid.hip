@@ -396,6 +396,13 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
             const d3 oc = point - mk(r0.x, r0.y, r1.x);
             const double bh = dot(oc, dir), cc = dot(oc, oc) - r1.y * r1.y;
             maybe |= (int)(first + k) != skip_rec && bh * bh - cc >= 0 && (bh < 0 || cc < 0);
+#if ODW_DOUBLE == 21
+            {
+              const d3 oc2 = point - mk(opq(r0.x), r0.y, r1.x);
+              const double bh2 = dot(oc2, dir), cc2 = dot(oc2, oc2) - r1.y * r1.y;
+              maybe |= (int)(first + k) != skip_rec && bh2 * bh2 - cc2 >= 0 && (bh2 < 0 || cc2 < 0);
+            }
+#endif
 #else
             double2 r0, r1, r2;
             if (IN_LDS) {
@@ -460,6 +467,10 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
               // a sphere needs no frame (as in intersect_prim): centre in global coordinates
               const d3 oc = point - mk(r0.x, r0.y, r1.x);
               double ta, tb;
+#if ODW_DOUBLE == 23
+              { const d3 oc2 = mk(opq(oc.x), oc.y, oc.z); double ua, ub;
+                if (quad_roots_unit(dot(oc2, dir), dot(oc2, oc2) - r1.y * r1.y, ua, ub) == 2 && ua != ua) consider(sv, q, ua, prim, (int)(first + k), g, 0, 0); }
+#endif
               if (quad_roots_unit(dot(oc, dir), dot(oc, oc) - r1.y * r1.y, ta, tb) == 2) {
                 const double bt = ta > q.tol ? ta : (tb > q.tol ? tb : INFINITY);
                 // (a sphere has one face: the candidate's face word carries the record's index instead, so that the

@@ -365,8 +365,9 @@ __device__ __forceinline__ int quad_roots_unit(double bh, double c, double& t0, 
 // computed TWICE, the second time behind an operand the compiler cannot see through, and the two outcomes are merged so
 // that the results stay what they are -- the launch's extra time is what that piece costs as it runs (all lanes, all
 // waves, cache and scheduling effects included).  1 box tests, 2 sphere roots, 3 cylinder / cone side and caps, 4 box
-// faces, 5 trimming tests, 6 normal at the hit, 7 mirror / Snell, 8 ray generation, 9 inverse direction of a segment.
-// scripts/gpu_double_profile.sh runs them all.
+// faces, 5 trimming tests, 6 normal at the hit, 7 mirror / Snell, 8 ray generation, 9 inverse direction of a segment,
+// 12 sphere (whole candidate pass); grid kernel (library builds, scripts/build_variant.py): 21 the walk's sphere test,
+// 23 the exact roots of a resolved cell.  scripts/gpu_double_profile.sh runs the compiled kernel's.
 #ifndef ODW_DOUBLE
 #define ODW_DOUBLE 0
 #endif
