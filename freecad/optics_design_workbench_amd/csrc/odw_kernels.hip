@@ -376,6 +376,15 @@ __device__ __forceinline__ double opq(double x) { asm volatile("" : "+v"(x)); re
 // A/B (round 4): conditions without short-circuit evaluation (compares and scalar ands in a row instead of nests of
 // exec-mask branches with their copies) -- bit 0 box faces, 1 the pick among a primitive's candidates, 2 cylinder side
 // and caps, 3 better()
+#ifndef ODW_SPEC_KEY
+#define ODW_SPEC_KEY 1           // (A/B: 0 = primitive and face as two members of a running minimum)
+#endif
+#ifndef ODW_SPEC_LEANCONS
+#define ODW_SPEC_LEANCONS 1       // (A/B: 0 = every candidate slot of a trimmed primitive goes through consider_spec)
+#endif
+#ifndef ODW_OTH_LAZY
+#define ODW_OTH_LAZY 1           // (A/B: 0 = the second running minimum kept for every candidate)
+#endif
 #ifndef ODW_FLAT_NOBRANCH
 #define ODW_FLAT_NOBRANCH 15
 #endif
@@ -398,6 +407,7 @@ struct Query {
   d3 start, dn;       // global ray (unit direction)
   double tol, tmax;   // distTol, maxRayLength + distTol
   int medium;
+  bool in_medium;     // (compiled kernels) some lane of the wave is inside a medium: the second running minimum is kept
   Best any, oth;
 };
 
@@ -451,8 +461,23 @@ __device__ __forceinline__ bool trim_ok(const SceneView& sv, const Query& q, d3 
 template <bool PARAB, class SPEC, int PI>
 __device__ __forceinline__ void consider_spec(const SceneView& sv, Query& q, double t, int face) {
   if (!(t > q.tol && t < q.tmax)) return;
-  const bool cand_any = better(t, PI, face, q.any);
-  const bool cand_oth = (SPEC::group(PI) != q.medium) && better(t, PI, face, q.oth);
+#if ODW_SPEC_KEY
+  // (compiled kernels keep (primitive, face) as ONE word, primitive << 8 | face, in the `face` member: the order of the
+  //  pairs is the order of the words -- one integer comparison per running minimum instead of three, one select less
+  //  per update; nearest() takes the word apart once per segment)
+  const int key = (PI << 8) | face;
+#define ODW_BETTER(B) ((bool)((int)(t < (B).t) | ((int)(t == (B).t) & (int)(key < (B).face))))
+#else
+  const int key = face;
+#define ODW_BETTER(B) better(t, PI, face, B)
+#endif
+  const bool cand_any = ODW_BETTER(q.any);
+  // (a ray in vacuum: every candidate's group differs from its medium, `oth` would be `any` all along and the rule at
+  //  the end of nearest() returns `any` either way -- a wave whose lanes are all in vacuum leaves the second minimum
+  //  alone: a uniform branch around its comparison and its selects)
+  bool cand_oth = false;
+  if (!ODW_OTH_LAZY || q.in_medium) cand_oth = (SPEC::group(PI) != q.medium) && (!ODW_OTH_LAZY || q.medium >= 0) && ODW_BETTER(q.oth);
+#undef ODW_BETTER
   if (!cand_any && !cand_oth) return;
   if constexpr (SPEC::cond_cnt(PI) > 0) {
     if (!trim_ok<PARAB, SPEC, SPEC::cond_off(PI), SPEC::cond_off(PI) + SPEC::cond_cnt(PI)>(sv, q, q.start + q.dn * t)) return;
@@ -460,8 +485,13 @@ __device__ __forceinline__ void consider_spec(const SceneView& sv, Query& q, dou
     if (!trim_ok<PARAB, SPEC, SPEC::cond_off(PI), SPEC::cond_off(PI) + SPEC::cond_cnt(PI)>(sv, q, q.start + q.dn * opq(t))) return;
 #endif
   }
+#if ODW_SPEC_KEY
+  if (cand_any) { q.any.t = t; q.any.face = key; }
+  if (cand_oth) { q.oth.t = t; q.oth.face = key; }
+#else
   if (cand_any) { q.any.t = t; q.any.prim = PI; q.any.face = face; }
   if (cand_oth) { q.oth.t = t; q.oth.prim = PI; q.oth.face = face; }
+#endif
 }
 
 // up to four candidate (t, face) pairs of one primitive, kept in registers
@@ -787,11 +817,16 @@ __device__ __forceinline__ void intersect_prim(const SceneView& sv, Query& q, in
     else consider<PARAB>(sv, q, bt, p, bf, group, 0, 0);
   } else if constexpr (SPEC::enabled) {
     // (a sphere has two candidates; the trimming code exists once per candidate slot)
-    consider_spec<PARAB, SPEC, PI>(sv, q, c.t0, c.f0);
-    consider_spec<PARAB, SPEC, PI>(sv, q, c.t1, c.f1);
+    // (faces that the boolean left nothing of produce no candidate: their slots are not looked at)
+    constexpr int fm = (SPEC::flags(PI) >> ODW_FACEMASK_SHIFT) & 0xff;
+    constexpr bool quadric = SPEC::type(PI) == ODW_PRIM_CYLINDER || SPEC::type(PI) == ODW_PRIM_CONE || SPEC::type(PI) == ODW_PRIM_PARABOLOID;
+    if constexpr (!ODW_SPEC_LEANCONS || !quadric || (fm & 1) != 0) {
+      consider_spec<PARAB, SPEC, PI>(sv, q, c.t0, c.f0);
+      consider_spec<PARAB, SPEC, PI>(sv, q, c.t1, c.f1);
+    }
     if constexpr (SPEC::type(PI) != ODW_PRIM_SPHERE) {
-      consider_spec<PARAB, SPEC, PI>(sv, q, c.t2, c.f2);
-      consider_spec<PARAB, SPEC, PI>(sv, q, c.t3, c.f3);
+      if constexpr (!ODW_SPEC_LEANCONS || !quadric || (fm & 2) != 0) consider_spec<PARAB, SPEC, PI>(sv, q, c.t2, c.f2);
+      if constexpr (!ODW_SPEC_LEANCONS || !quadric || (fm & 4) != 0) consider_spec<PARAB, SPEC, PI>(sv, q, c.t3, c.f3);
     }
   } else {
 #pragma unroll 1
@@ -967,6 +1002,7 @@ __device__ __forceinline__ int nearest(const DeviceScene& sc, const SceneView& s
   Query q;
   q.start = start; q.dn = dn; q.tol = lim.dist_tol; q.tmax = lim.max_ray_length + lim.dist_tol;
   q.medium = medium;
+  q.in_medium = __ballot(medium >= 0) != 0ull;
   q.any.t = INFINITY; q.any.prim = 0x7fffffff; q.any.face = 0x7fffffff;
   q.oth = q.any;
 #if ODW_DOUBLE == 9
@@ -1100,6 +1136,15 @@ __device__ __forceinline__ int nearest(const DeviceScene& sc, const SceneView& s
         }
       }
     }
+  }
+  if constexpr (SPEC::enabled && ODW_SPEC_KEY) {
+    // (consider_spec keeps primitive << 8 | face in the `face` member)
+    if (q.any.face == 0x7fffffff) return -1;
+    const bool use_oth_ = q.oth.face != 0x7fffffff && q.oth.t < q.any.t + 2.0 * q.tol;
+    t_hit = use_oth_ ? q.oth.t : q.any.t;
+    const int key = use_oth_ ? q.oth.face : q.any.face;
+    face = key & 0xff;
+    return key >> 8;
   }
   if (q.any.prim == 0x7fffffff) return -1;
   // hits within 2*distTol of the nearest: prefer one whose group differs
