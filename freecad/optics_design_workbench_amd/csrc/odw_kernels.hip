@@ -382,6 +382,9 @@ __device__ __forceinline__ double opq(double x) { asm volatile("" : "+v"(x)); re
 #ifndef ODW_SPEC_LEANCONS
 #define ODW_SPEC_LEANCONS 1       // (A/B: 0 = every candidate slot of a trimmed primitive goes through consider_spec)
 #endif
+#ifndef ODW_SPEC_CUT
+#define ODW_SPEC_CUT 1            // (A/B: 0 = the end of the search computed anew before every box test)
+#endif
 #ifndef ODW_OTH_LAZY
 #define ODW_OTH_LAZY 1           // (A/B: 0 = the second running minimum kept for every candidate)
 #endif
@@ -408,6 +411,7 @@ struct Query {
   double tol, tmax;   // distTol, maxRayLength + distTol
   int medium;
   bool in_medium;     // (compiled kernels) some lane of the wave is inside a medium: the second running minimum is kept
+  double cut;         // (compiled kernels, ODW_SPEC_CUT) min(tmax, nearest + 2 tol): where the search ends, renewed when the nearest changes
   Best any, oth;
 };
 
@@ -425,7 +429,8 @@ __device__ __forceinline__ void consider(const SceneView& sv, Query& q, double t
                                          int group, int cond_off, int cond_cnt) {
   if (!(t > q.tol && t < q.tmax)) return;
   const bool cand_any = better(t, p, face, q.any);
-  const bool cand_oth = (group != q.medium) && better(t, p, face, q.oth);
+  // (in vacuum the second running minimum would be the first all along: see consider_spec)
+  const bool cand_oth = (!ODW_OTH_LAZY || q.medium >= 0) && (group != q.medium) && better(t, p, face, q.oth);
   if (!cand_any && !cand_oth) return;
   if (cond_cnt) {
     const d3 gp = q.start + q.dn * t;
@@ -486,7 +491,7 @@ __device__ __forceinline__ void consider_spec(const SceneView& sv, Query& q, dou
 #endif
   }
 #if ODW_SPEC_KEY
-  if (cand_any) { q.any.t = t; q.any.face = key; }
+  if (cand_any) { q.any.t = t; q.any.face = key; if (ODW_SPEC_CUT) q.cut = fmin(q.tmax, t + 2.0 * q.tol); }
   if (cand_oth) { q.oth.t = t; q.oth.face = key; }
 #else
   if (cand_any) { q.any.t = t; q.any.prim = PI; q.any.face = face; }
@@ -961,7 +966,7 @@ __device__ __forceinline__ void spec_prim(const SceneView& sv, Query& q, d3 oi, 
       if constexpr (SPEC::box_of(PI) != PI) {
         in_box = boxhit[SPEC::box_of(PI)];
       } else {
-        const double cut = fmin(q.tmax, q.any.t + 2.0 * q.tol);
+        const double cut = (ODW_SPEC_CUT && ODW_SPEC_KEY) ? q.cut : fmin(q.tmax, q.any.t + 2.0 * q.tol);
         in_box = ray_box(sv.prim_hdr + 8 * PI, oi, inv, cut);
 #if ODW_DOUBLE == 1
         in_box = in_box & ray_box(sv.prim_hdr + 8 * PI, mk(opq(oi.x), oi.y, oi.z), inv, cut);
@@ -982,7 +987,7 @@ __device__ __forceinline__ void spec_prim(const SceneView& sv, Query& q, d3 oi, 
     } else if constexpr (SPEC::box_of(PI) == PI) {
       // (skipped for this lane -- not relevant, or the convex solid just left --, but a later primitive may
       //  ask for this box: its own test then)
-      boxhit[PI] = SPEC::box_shared(PI) ? ray_box(sv.prim_hdr + 8 * PI, oi, inv, fmin(q.tmax, q.any.t + 2.0 * q.tol)) : false;
+      boxhit[PI] = SPEC::box_shared(PI) ? ray_box(sv.prim_hdr + 8 * PI, oi, inv, (ODW_SPEC_CUT && ODW_SPEC_KEY) ? q.cut : fmin(q.tmax, q.any.t + 2.0 * q.tol)) : false;
     }
   }
 }
@@ -1003,6 +1008,7 @@ __device__ __forceinline__ int nearest(const DeviceScene& sc, const SceneView& s
   q.start = start; q.dn = dn; q.tol = lim.dist_tol; q.tmax = lim.max_ray_length + lim.dist_tol;
   q.medium = medium;
   q.in_medium = __ballot(medium >= 0) != 0ull;
+  q.cut = q.tmax;
   q.any.t = INFINITY; q.any.prim = 0x7fffffff; q.any.face = 0x7fffffff;
   q.oth = q.any;
 #if ODW_DOUBLE == 9
