@@ -49,6 +49,9 @@ namespace odw {
 #ifndef ODW_GRID_LEAN_TEST
 #define ODW_GRID_LEAN_TEST 1     // the walk's sphere test reads centre and radius only (A/B: 0 = the record's group / solid word too)
 #endif
+#ifndef ODW_GRID_RCP
+#define ODW_GRID_RCP frcp1          // (A/B: frcp = two Newton steps)
+#endif
 #define ODW_GRID_THREADS 1024
 #define ODW_GRID_WAVES (ODW_GRID_THREADS / 64)
 #define ODW_GRID_WAVE_WORDS 32   // per wave: event counters (0..7), diagnostics (8..27), hit-block state (28..31)
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
           // and not at the set-up of the first segment, which shares its run with lanes that go on from a hit
           uint32_t first_cell = 0xffffffffu;
           {
-            const double jx = frcp(d.x), jy = frcp(d.y), jz = frcp(d.z);
+            const double jx = ODW_GRID_RCP(d.x), jy = ODW_GRID_RCP(d.y), jz = ODW_GRID_RCP(d.z);
             bool in = true;
             double t0 = 0.0, t1 = q.tmax;
 #define ODW_CLIP(O, D, INV, LO, HI)                                          \
@@ -318,7 +321,9 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
         cut = q.tmax;
         walking = false;
         if (mask != 0ull) {
-          ivx = frcp(dir.x); ivy = frcp(dir.y); ivz = frcp(dir.z);
+          // (one Newton step, 2^-50: the plane distances of the walk decide the order of the cells and where it ends,
+          //  against boxes that carry 2 distTol of slack -- as the inverse direction of the flat kernels' box tests)
+          ivx = ODW_GRID_RCP(dir.x); ivy = ODW_GRID_RCP(dir.y); ivz = ODW_GRID_RCP(dir.z);
           // A ray that goes on from a hit starts in the cell its walk stopped in: the walk ends in the cell whose
           // exit lies beyond the hit (+ 2 distTol), so the hit point is in it or within the tolerance of it.  If it
           // is a hair outside, the plane distance of that axis comes out negative (or the cell is entered at once)
