@@ -14,10 +14,10 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(CSRC, 'libodw_trace.so')
-_SOURCES = ['odw_capi.hip', 'odw_kernels.hip', 'odw_grid.hip', 'odw_mesh.hip', 'odw_posthoc.hip', 'odw_spec.hip', 'odw_device.h']
+_SOURCES = ['odw_capi.hip', 'odw_kernels.hip', 'odw_grid.hip', 'odw_mesh.hip', 'odw_posthoc.hip', 'odw_posthoc_batch.hip', 'odw_spec.hip', 'odw_device.h']
 _HEADER = os.path.normpath(os.path.join(_HERE, '..', '..', 'include', 'odw_trace.h'))
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 CNT_NAMES = ['traced_rays', 'recorded_hits', 'segments', 'escaped', 'died', 'capped',
              'hist_overflow', 'hits_dropped', 'grating_in_medium']
 TRACE_RECORD_HITS, TRACE_HISTOGRAM, TRACE_RECORD_SEGMENTS = 1, 2, 4
@@ -25,6 +25,7 @@ FLAG_FLIP_NORMAL, FLAG_CONVEX = 1, 2      # ODW_FLAG_* of prim_flags (include/od
 COMPILE_OFF, COMPILE_STRUCTURE, COMPILE_AUTO = 0, 1, 2
 COMPILE_MODES = {None: 0, False: 0, 'off': 0, 0: 0, 'structure': 1, 1: 1, True: 1, 'auto': 2, 2: 2}
 ERRORS = {1: 'invalid argument', 2: 'device error', 3: 'no scene', 4: 'capacity', 5: 'unsupported'}
+BUSY = 6             # ODW_BUSY: not an error (polling calls)
 
 HIT_DTYPE = np.dtype([('point', '<f8', 3), ('direction', '<f8', 3), ('power', '<f8'), ('tag', '<u8')])
 SEGMENT_DTYPE = np.dtype([('p1', '<f8', 3), ('p2', '<f8', 3), ('power', '<f8'), ('tag', '<u8')])
@@ -38,7 +39,8 @@ SYMBOLS = ['odw_abi_version', 'odw_create', 'odw_destroy', 'odw_last_error', 'od
            'odw_swap_hit_lists', 'odw_fetch_swapped_hits', 'odw_release_swapped_hits', 'odw_host_alloc', 'odw_host_free', 'odw_load_hits', 'odw_hits_select', 'odw_hits_gather', 'odw_hits_project', 'odw_hits_range', 'odw_hits_bin', 'odw_hits_moments', 'odw_plane_screen',
            'odw_compile_scene', 'odw_compiled_info', 'odw_compile_check', 'odw_hits_columns',
            'odw_upload_scene_batch', 'odw_trace_batch', 'odw_batch_select', 'odw_batch_rows',
-           'odw_plane_screen_batch', 'odw_archive_append', 'odw_archive_select', 'odw_archive_reset', 'odw_batch_hits_select', 'odw_batch_hits_sample', 'odw_batch_hits_project', 'odw_batch_hits_bin']
+           'odw_plane_screen_batch', 'odw_archive_append', 'odw_archive_select', 'odw_archive_reset', 'odw_batch_hits_select', 'odw_batch_hits_sample', 'odw_batch_hits_project', 'odw_batch_hits_bin',
+           'odw_batch_hits_begin', 'odw_batch_hits_sampled', 'odw_batch_hits_measure', 'odw_batch_hits_measured']
 
 _pd = C.POINTER(C.c_double)
 _pi = C.POINTER(C.c_int32)

@@ -138,6 +138,7 @@ struct odw_ctx {
   // context's hit list (ctx->hits / hit_count become views; the context's own list waits in own_*)
   DevBuf batch_values, batch_hits, batch_hit_count;
   int batch_n = 0;                         // scenes of the uploaded batch (0: none)
+  size_t batch_prims = 0;                  // primitives per scene of that batch
   bool batch_launch = false;               // launch_trace: this launch is a batch
   uint64_t batch_stride = 0;               // doubles per scene block
   uint64_t batch_seg_slots = 0, batch_seg_capacity = 0, batch_rays = 0, batch_first = 0;
@@ -155,6 +156,15 @@ struct odw_ctx {
   bool archive_selected = false;
   // post-hoc binning of all segments at once (odw_batch_hits_*, odw_posthoc.hip): per-scene slices of these
   DevBuf phb_row_of, phb_words, phb_sel, phb_small, phb_rows, phb_x, phb_y, phb_part, phb_sel_hist, phb_cand, phb_counts;
+  DevBuf phb_scenes, phb_hist, phb_planes, phb_strides, phb_origins;   // device-resident state of the chain (odw_posthoc_batch.hip)
+  void* phb_pin_p = nullptr;               // page-locked block the chain's results arrive in
+  size_t phb_pin_bytes = 0;
+  hipEvent_t phb_ev = nullptr;             // end of the piece enqueued last (odw_batch_hits_begin / _measure)
+  int phb_stage = 0, phb_S = 0;            // 1 begin enqueued, 2 sampled, 3 measure enqueued, 4 measured
+  uint64_t phb_cap = 0, phb_nbins = 0;
+  size_t phb_part_stride = 0;
+  std::vector<double> phb_edges_host;      // the edges on the device (uploaded when they change)
+  int phb_edges_na = 0, phb_edges_nb = 0;
   std::vector<uint64_t> phb_used, phb_n, phb_leaving;
   std::vector<int32_t> phb_ordered;
   std::vector<char> phb_on;
@@ -1124,6 +1134,35 @@ int presort_rays(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed) {
   return ODW_OK;
 }
 
+#if ODW_GRID_SORTED
+// Grid launches of device-generated rays (diagnostic builds, -DODW_GRID_SORTED=1): hand-out order = sorted by the top `bits`
+// bits of the Morton key of the two uniform numbers a ray's direction is drawn from (odw_grid.hip: odw_ray_ukey_kernel;
+// Philox only).  ODW_GRID_PRESORT = bits; the rows of a ray depend on its number only.  See profiles/r05/README.md.
+int presort_rays_grid(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, int bits) {
+  if (bits <= 0 || n < (1ull << 16) || n > 0x7FFFFFFFull) return ODW_OK;
+  bits = std::min(bits, 32);
+  int rc;
+  for (int k = 0; k < 2; ++k) {
+    if ((rc = ensure(ctx, ctx->sort_keys[k], n * sizeof(uint32_t)))) return rc;
+    if ((rc = ensure(ctx, ctx->sort_vals[k], n * sizeof(uint32_t)))) return rc;
+  }
+  uint32_t* k_in = (uint32_t*)ctx->sort_keys[0].p;
+  uint32_t* k_out = (uint32_t*)ctx->sort_keys[1].p;
+  uint32_t* v_in = (uint32_t*)ctx->sort_vals[0].p;
+  uint32_t* v_out = (uint32_t*)ctx->sort_vals[1].p;
+  const unsigned kgrid = (unsigned)((n + 255) / 256);
+  size_t tmp_bytes = 0;
+  hipLaunchKernelGGL(odw_ray_ukey_kernel, dim3(kgrid), dim3(256), 0, ctx->stream, first, n, seed, k_in, v_in);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, k_in, k_out, v_in, v_out, (int)n, 32 - bits, 32, ctx->stream));
+  if ((rc = ensure(ctx, ctx->sort_tmp, tmp_bytes))) return rc;
+  HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(ctx->sort_tmp.p, tmp_bytes, k_in, k_out, v_in, v_out, (int)n, 32 - bits, 32, ctx->stream));
+  ctx->P.ray_order = v_out;
+  ctx->ph_valid = false;           // (the sort buffers are shared with odw_hits_select)
+  return ODW_OK;
+}
+#endif
+
 int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32_t flags,
                  const double* ray_o, const double* ray_d, const double* ray_p) {
   const bool explicit_rays = ray_o != nullptr;
@@ -1257,10 +1296,26 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
   }
   const bool stoch = ctx->n_samplers > 0;
   P.ray_order = nullptr;
+  P.interact_min = 1;
+  P.refill_min = 0;
   if (use_mesh && !explicit_rays) {
     int rc = presort_rays(ctx, first, n, seed);       // (inside the timed window: part of the launch's cost)
     if (rc) return rc;
   }
+#if ODW_GRID_SORTED
+  if (use_grid) {
+    // (diagnostic builds only; read at every launch: A/B runs)
+    const char* e_bits = getenv("ODW_GRID_PRESORT");
+    const char* e_gate = getenv("ODW_GRID_GATE");
+    const char* e_refill = getenv("ODW_GRID_REFILL");
+    P.refill_min = e_refill ? (uint32_t)std::max(1, std::min(64, atoi(e_refill))) : 1u;
+    if (!explicit_rays && e_bits) {
+      int rc = presort_rays_grid(ctx, first, n, seed, atoi(e_bits));
+      if (rc) return rc;
+      if (P.ray_order && e_gate) P.interact_min = (uint32_t)std::max(1, std::min(64, atoi(e_gate)));
+    }
+  }
+#endif
   if (use_spec) {
     int rc = spec_launch(ctx, grid, batch);
     if (rc) return rc;
@@ -1270,20 +1325,28 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
   } else if (use_grid) {
     const dim3 gb((unsigned)grid_blocks);
     const size_t glds = P.grid.lds_bytes;
-#define ODW_GRID_LAUNCH(S, L)                                                                                  \
+#define ODW_GRID_LAUNCH(S, L, O)                                                                                 \
     do {                                                                                                       \
       /* (once per device and instantiation: a second context on another GPU of the process needs its own) */  \
       static uint64_t attr_set = 0;                                                                            \
       const uint64_t dev_bit = 1ull << (ctx->device & 63);                                                     \
       if (!(attr_set & dev_bit)) {                                                                             \
-        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&odw_grid_kernel<S, L>),                 \
+        HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&odw_grid_kernel<S, L, O>),              \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));   /* + 4.5 KB static */ \
         attr_set |= dev_bit;                                                                                   \
       }                                                                                                        \
-      hipLaunchKernelGGL((odw_grid_kernel<S, L>), gb, dim3(ODW_GRID_THREADS), glds, ctx->stream, P);           \
+      hipLaunchKernelGGL((odw_grid_kernel<S, L, O>), gb, dim3(ODW_GRID_THREADS), glds, ctx->stream, P);        \
     } while (0)
-    if (P.grid.spheres) { if (P.grid.in_lds) ODW_GRID_LAUNCH(true, true); else ODW_GRID_LAUNCH(true, false); }
-    else { if (P.grid.in_lds) ODW_GRID_LAUNCH(false, true); else ODW_GRID_LAUNCH(false, false); }
+#if ODW_GRID_SORTED
+    if (P.ray_order) {
+      if (P.grid.spheres) { if (P.grid.in_lds) ODW_GRID_LAUNCH(true, true, true); else ODW_GRID_LAUNCH(true, false, true); }
+      else { if (P.grid.in_lds) ODW_GRID_LAUNCH(false, true, true); else ODW_GRID_LAUNCH(false, false, true); }
+    } else
+#endif
+    {
+      if (P.grid.spheres) { if (P.grid.in_lds) ODW_GRID_LAUNCH(true, true, false); else ODW_GRID_LAUNCH(true, false, false); }
+      else { if (P.grid.in_lds) ODW_GRID_LAUNCH(false, true, false); else ODW_GRID_LAUNCH(false, false, false); }
+    }
 #undef ODW_GRID_LAUNCH
   } else if (use_mesh) {
     const size_t mlds = (size_t)ODW_MESH_STACK * ODW_MESH_THREADS * 2 * sizeof(int) +
@@ -1463,8 +1526,11 @@ void odw_destroy(odw_ctx* ctx) {
   release(ctx->batch_values);
   release(ctx->batch_hits);
   release(ctx->batch_hit_count);
+  if (ctx->phb_pin_p) (void)hipHostFree(ctx->phb_pin_p);
+  if (ctx->phb_ev) (void)hipEventDestroy(ctx->phb_ev);
   for (DevBuf* b : {&ctx->phb_row_of, &ctx->phb_words, &ctx->phb_sel, &ctx->phb_small, &ctx->phb_rows, &ctx->phb_x, &ctx->phb_y,
-                    &ctx->phb_part, &ctx->phb_sel_hist, &ctx->phb_cand, &ctx->phb_counts})
+                    &ctx->phb_part, &ctx->phb_sel_hist, &ctx->phb_cand, &ctx->phb_counts, &ctx->phb_scenes, &ctx->phb_hist, &ctx->phb_planes,
+                    &ctx->phb_strides, &ctx->phb_origins})
     release(*b);
   release(ctx->alt_hits);
   release(ctx->alt_hit_count);
@@ -1621,6 +1687,7 @@ int odw_upload_scene(odw_ctx* ctx, const odw_scene_desc* s) {
   ctx->spec_dirty = true;
   ctx->spec_fn = nullptr;
   ctx->n_samplers = 0;   // surface samplers belong to the previous scene's groups
+  ctx->batch_n = 0;      // an uploaded batch belonged to the previous scene (odw_upload_scene_batch sets it again after this call)
   return ODW_OK;
 }
 
@@ -1979,7 +2046,10 @@ int odw_set_limits(odw_ctx* ctx, const odw_limits* l) {
   if (!ctx || !l) return fail(ctx, ODW_ERR_INVALID, "odw_set_limits: null argument");
   if (!(l->dist_tol > 0) || l->max_intersections < 0 || !(l->max_ray_length > 0))
     return fail(ctx, ODW_ERR_INVALID, "odw_set_limits: values out of range");
-  if (!ctx->have_limits || ctx->P.lim.dist_tol != l->dist_tol) ctx->bvh_dirty = true;   // (the boxes carry the tolerance; a compiled scene is bound again after the rebuild)
+  if (!ctx->have_limits || ctx->P.lim.dist_tol != l->dist_tol) {
+    ctx->bvh_dirty = true;   // (the boxes carry the tolerance; a compiled scene is bound again after the rebuild)
+    ctx->batch_n = 0;        // (and so do the boxes of an uploaded batch: it has to be uploaded again)
+  }
   ctx->P.lim.max_ray_length = l->max_ray_length;
   ctx->P.lim.max_intersections = l->max_intersections;
   ctx->P.lim.dist_tol = l->dist_tol;
@@ -2168,6 +2238,7 @@ int odw_upload_scene_batch(odw_ctx* ctx, const odw_scene_desc* scenes, int32_t n
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->h_prim_i32 = pi;
   ctx->batch_n = n_scenes;
+  ctx->batch_prims = n;
   ctx->batch_stride = stride;
   ctx->batch_spec_text = text0;
   return ODW_OK;
@@ -2176,7 +2247,12 @@ int odw_upload_scene_batch(odw_ctx* ctx, const odw_scene_desc* scenes, int32_t n
 int odw_trace_batch(odw_ctx* ctx, uint64_t first_ray, uint64_t rays_per_scene, uint64_t seed, uint32_t flags,
                     uint64_t rows_per_scene) {
   if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_trace_batch: null ctx");
-  if (ctx->batch_n < 1) return fail(ctx, ODW_ERR_NO_SCENE, "odw_trace_batch before odw_upload_scene_batch");
+  if (ctx->batch_n < 1)
+    return fail(ctx, ODW_ERR_NO_SCENE, "odw_trace_batch before odw_upload_scene_batch (odw_upload_scene and a new dist_tol discard an uploaded batch)");
+  // the batch's tables stand beside the single-scene tables build_bvh() writes: a rebuild now would hand the BATCH kernel
+  // a one-scene box table (odw_upload_scene_batch leaves everything built)
+  if (ctx->bvh_dirty || (size_t)ctx->P.scene.n_prims != ctx->batch_prims)
+    return fail(ctx, ODW_ERR_NO_SCENE, "odw_trace_batch: the scene changed after odw_upload_scene_batch");
   if (ctx->emitter_active) return fail(ctx, ODW_ERR_UNSUPPORTED, "odw_trace_batch: point sources only");
   if (rays_per_scene == 0) return ODW_OK;
   HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -2710,3 +2786,4 @@ int odw_timing_read(odw_ctx* ctx, double* total_ms, uint64_t* launches) {
 }  // extern "C"
 
 #include "odw_posthoc.hip"
+#include "odw_posthoc_batch.hip"

@@ -210,10 +210,12 @@ struct TraceParams {
   uint32_t chunk;               // rays per hand-out unit of this launch (a multiple of 64, <= ODW_CHUNK)
   unsigned long long* dbg;      // diagnostic builds only (ODW_GRID_STATS): 16 words, or null
   DeviceBatch batch;            // flat kernels' BATCH variants only (n_scenes = 0 otherwise)
-  const uint32_t* ray_order;    // mesh kernel: the launch's rays in the order they are handed out (position -> number of
-                                // the ray within the launch), or null: by number.  Which wave traces a ray never shows in
-                                // its rows (a ray depends on its number only); rays that start alike, traced side by side,
-                                // visit the same nodes and facets (odw_capi.hip: presort_rays)
+  const uint32_t* ray_order;    // mesh and grid kernels: the launch's rays in the order they are handed out (position ->
+                                // number of the ray within the launch), or null: by number.  Which wave traces a ray never
+                                // shows in its rows (a ray depends on its number only); rays that start alike, traced side
+                                // by side, visit the same nodes, facets and cells (odw_capi.hip: presort_rays)
+  uint32_t interact_min;        // grid kernel with ray_order: lanes whose walk is over before the wave interacts (<= 1: at once)
+  uint32_t refill_min;          // grid kernel: idle lanes that make the wave pop new rays from its ring (0: ODW_GRID_REFILL_MIN)
 };
 
 }  // namespace odw

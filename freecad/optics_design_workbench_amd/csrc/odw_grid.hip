@@ -49,6 +49,10 @@ namespace odw {
 #ifndef ODW_GRID_LEAN_TEST
 #define ODW_GRID_LEAN_TEST 1     // the walk's sphere test reads centre and radius only (A/B: 0 = the record's group / solid word too)
 #endif
+#ifndef ODW_GRID_SORTED
+#define ODW_GRID_SORTED 0        // A/B (round 5, profiles/r05/README.md): 1 = also build the kernels that hand the launch's rays out sorted by
+#endif                           // where they point (ODW_GRID_PRESORT = key bits) and let a wave's lanes interact together (ODW_GRID_GATE):
+                                 // hugeArray 20.3 ms -> kernel 17.6 - 18.6 + key pass and radix sort 2.2 - 3.9 = 20.8 - 21.5 ms; not kept
 #ifndef ODW_GRID_RCP
 #define ODW_GRID_RCP frcp1          // (A/B: frcp = two Newton steps)
 #endif
@@ -96,7 +100,7 @@ __device__ __forceinline__ int grid_slab(const double* b, int n, double v) {
 // lanes add with ds_add_u32 (a handful of events per ray)
 #define ODW_GCOUNT(k) atomicAdd(&wave_cnt[(k)], 1u)
 
-template <bool SPHERES, bool IN_LDS>
+template <bool SPHERES, bool IN_LDS, bool SORTED>
 __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceParams P) {
   extern __shared__ double grid_lds[];
   const DeviceScene& sc = P.scene;
@@ -178,6 +182,9 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
   double tx = INFINITY, ty = INFINITY, tz = INFINITY, ivx = 0, ivy = 0, ivz = 0;
   double cut = 0;        // min(length limit, nearest + 2 distTol): cells that begin beyond it are not visited (ray.py:432, 440)
   int cell = 0;
+  // (index order: the constants; a sorted launch reads its thresholds from the arguments -- A/B runs)
+#define refill_min (SORTED ? P.refill_min : (uint32_t)ODW_GRID_REFILL_MIN)
+#define interact_min (SORTED ? P.interact_min : 1u)
 
   // leave the cell through the nearest plane (the axis by selects, the next plane by ONE read of the
   // contiguous plane tables), or end the walk: beyond nearest + 2 distTol (ray.py:432, 440), or out of the grid
@@ -221,7 +228,7 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
     // ---- A: new rays for idle lanes, from the wave's ring ------------------------------------------
     const uint64_t idle = __ballot(!alive);
     if (idle == ~0ull && drained && ring_n == 0) break;    // nothing live, nothing left
-    if (idle && !(drained && ring_n == 0) && (idle == ~0ull || __popcll(idle) >= ODW_GRID_REFILL_MIN)) {
+    if (idle && !(drained && ring_n == 0) && (idle == ~0ull || (uint32_t)__popcll(idle) >= refill_min)) {
       if (ring_n == 0) {
         // fill: the whole wave generates the next (up to) 64 rays of its chunk, one per lane
         if (next >= chunk_end) {
@@ -238,7 +245,8 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
         const uint32_t fill = avail < ODW_GRID_RING ? (uint32_t)avail : (uint32_t)ODW_GRID_RING;
         ODW_GSTAT(0, __ballot(lane < fill));
         if (lane < fill) {
-          const uint64_t r = next + lane;
+          // (position next + lane of the hand-out order is ray number r: odw_capi.hip, presort_rays)
+          const uint64_t r = SORTED ? (uint64_t)P.ray_order[next + lane] : next + lane;
           d3 o, d;
           if (P.ray_origins) {
             o = mk(P.ray_origins[r], P.ray_origins[P.ray_stride + r], P.ray_origins[2 * P.ray_stride + r]);
@@ -276,6 +284,7 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
           double* slot = ring + 7 * lane;
           slot[0] = o.x; slot[1] = o.y; slot[2] = o.z; slot[3] = d.x; slot[4] = d.y; slot[5] = d.z;
           reinterpret_cast<uint32_t*>(slot + 6)[0] = first_cell;
+          if (SORTED) reinterpret_cast<uint32_t*>(slot + 6)[1] = (uint32_t)r;  // (a sorted launch holds < 2^31 rays)
         }
         // (one wave: its LDS operations complete in program order; this only keeps the compiler from
         //  moving the reads below above the writes)
@@ -294,7 +303,7 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
         point = mk(slot[0], slot[1], slot[2]);
         dir = mk(slot[3], slot[4], slot[5]);
         cell = (int)reinterpret_cast<const uint32_t*>(slot + 6)[0];       // (-1: the ray misses the grid)
-        i = ring_base + s;
+        i = SORTED ? (uint64_t)reinterpret_cast<const uint32_t*>(slot + 6)[1] : ring_base + s;
         power = P.ray_origins ? (P.ray_powers ? P.ray_powers[i] : 1.0) : as_const(P.source)->power;
         seq = 0; nint = 0; medium = -1; skip = -1; skip_rec = -1;
         alive = true; fresh = true; walking = false; pending = false;
@@ -347,9 +356,11 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
       if (wb == 0ull) break;
       // stop stepping once few lanes walk if lanes wait: for resolution / interaction, or -- enough of
       // them -- for a new ray
+      // (a sorted launch whose lanes interact together: lanes that wait for the others are no reason to stop stepping,
+      //  lanes that wait for their cell to be resolved are)
       if (it > 0 && __popcll(wb) < ODW_GRID_STEP_MIN &&
-          (__ballot(alive && !walking) != 0ull ||
-           (!(drained && ring_n == 0) && __popcll(__ballot(!alive)) >= ODW_GRID_REFILL_MIN)))
+          (__ballot(alive && !walking && (interact_min <= 1u || pending || fresh)) != 0ull ||
+           (!(drained && ring_n == 0) && (uint32_t)__popcll(__ballot(!alive)) >= refill_min)))
         break;
       ODW_GSTAT(2, wb);
       if (walking) {
@@ -445,7 +456,16 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
     ODW_GTIME(2);
     // ---- D: resolution and interaction of the lanes whose walk has stopped -----------------------------
     ODW_GSTAT(3, __ballot(alive && !walking && !fresh));
-    if (alive && !walking && !fresh) {
+    // Rays handed out in sorted order (ray_order): the lanes of a wave hold neighbouring rays; the interaction may wait
+    // until interact_min lanes are through with their walk (or nobody walks or waits for a resolve any more), so that the
+    // wave sets out on the next segment together (as odw_mesh_kernel does).  Index order: every lane goes on at once.
+    bool go = true;
+    if (SORTED && interact_min > 1u) {
+      const uint64_t busy = __ballot(walking || (alive && pending));
+      const uint64_t done = __ballot(alive && !walking && !fresh && !pending);
+      go = busy == 0ull || (uint32_t)__popcll(done) >= interact_min;
+    }
+    if (alive && !walking && !fresh && (pending || go)) {
       if (pending) {
         // the exact tests of the cell the walk stands in (every primitive listed there), then on or stop
         pending = false;
@@ -494,7 +514,7 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
         cut = fmin_raw(q.tmax, q.any.t + 2.0 * q.tol);
         ODW_WALK_ADVANCE();
       }
-      if (!walking) {
+      if (!walking && go) {
         ODW_GSTAT(5, __ballot(1));
         if (q.any.prim == 0x7fffffff) {
           ODW_GCOUNT(ODW_CNT_ESCAPED);
@@ -599,6 +619,8 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
     ODW_GTIME(3);
   }
 #undef ODW_WALK_ADVANCE
+#undef refill_min
+#undef interact_min
   // slots of the last block this wave never filled (as in odw_trace_kernel)
   const uint32_t hit_used = hit_state[2];
   const uint64_t hit_base = ((uint64_t)hit_state[1] << 32) | hit_state[0];
@@ -623,5 +645,30 @@ __global__ __launch_bounds__(ODW_GRID_THREADS) void odw_grid_kernel(const TraceP
     if (s) atomicAdd(P.out.counters + threadIdx.x, (unsigned long long)s);
   }
 }
+
+#if ODW_GRID_SORTED
+// ---- the order rays are handed out in (TraceParams.ray_order), grid launches ------------------------------------------
+// key of ray r = the two uniform numbers its direction is drawn from (azimuth and polar inverse CDFs are monotone in
+// them), 16 bits each, Morton order: Philox alone, no table inversion, no sin / cos.  Sorted by its top bits, the rays of
+// a wave leave the source side by side (equal-probability patches of the beam).
+__device__ __forceinline__ uint32_t grid_spread16(uint32_t v) {        // abcd -> 0a0b0c0d
+  v &= 0xffffu;
+  v = (v | (v << 8)) & 0x00ff00ffu;
+  v = (v | (v << 4)) & 0x0f0f0f0fu;
+  v = (v | (v << 2)) & 0x33333333u;
+  v = (v | (v << 1)) & 0x55555555u;
+  return v;
+}
+__global__ __launch_bounds__(256) void odw_ray_ukey_kernel(uint64_t first, uint64_t n, uint64_t seed,
+                                                           uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const uint64_t ray = first + r;
+  uint32_t c0 = (uint32_t)ray, c1 = (uint32_t)(ray >> 32), c2 = 0u, c3 = 0u;
+  philox4x32_10(c0, c1, c2, c3, (uint32_t)seed, (uint32_t)(seed >> 32));      // (ray_uniforms: u_phi from c0, u_t from c2)
+  keys[r] = grid_spread16(c0 >> 16) | (grid_spread16(c2 >> 16) << 1);
+  vals[r] = (uint32_t)r;
+}
+#endif
 
 }  // namespace odw

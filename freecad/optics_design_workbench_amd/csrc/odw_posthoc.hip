@@ -154,7 +154,9 @@ __device__ __forceinline__ void ph_moment_add(double (&s)[6], double px, double 
   s[0] += dx; s[1] += dy; s[2] += dz;
   s[3] += dx * dx; s[4] += dy * dy; s[5] += dz * dz;
 }
-__device__ __forceinline__ void ph_moment_write(double (&s)[6], double cx, double cy, double cz, double* __restrict__ part) {
+__device__ __forceinline__ void ph_moment_write(double (&s)[6], double cx, double cy, double cz, double* __restrict__ part,
+                                                unsigned n_blocks = 0) {       // (0: the launch's grid)
+  if (n_blocks == 0) n_blocks = gridDim.x;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1)
 #pragma unroll
@@ -165,7 +167,7 @@ __device__ __forceinline__ void ph_moment_write(double (&s)[6], double cx, doubl
     for (int k = 0; k < 6; ++k) sh[w][k] = s[k];
   __syncthreads();
   if (threadIdx.x < 6) part[6 * blockIdx.x + threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
-  if (blockIdx.x == 0 && threadIdx.x == 6) { part[6 * gridDim.x] = cx; part[6 * gridDim.x + 1] = cy; part[6 * gridDim.x + 2] = cz; }
+  if (blockIdx.x == 0 && threadIdx.x == 6) { part[6 * n_blocks] = cx; part[6 * n_blocks + 1] = cy; part[6 * n_blocks + 2] = cz; }
 }
 
 // part: [gridDim.x][4] extrema of X, Y | (key 0: the points' moment sums) [gridDim.x][6] + the centre [3]
@@ -990,332 +992,3 @@ int odw_hits_moments(odw_ctx* ctx, double* mean, double* var) {
 
 }  // extern "C"
 
-// ---- the same steps for ALL segments of a batch launch at once (odw_trace_batch) -----------------------------------------
-// One scene's chain -- select, sample, [plane search on the host], project + medians, [origin], bin -- costs eight
-// synchronisations with the host; a sweep of 64 values paid them 64 times, on threads that took turns on the GPU.  Here
-// every step runs for all S segments back to back (the kernels above, per-scene slices of the state buffers) and is
-// waited for ONCE.  Scenes the ordered selection without a sort cannot serve (a ray with two selected rows; a sample
-// that needs the entering rows of a mixed list) are reported and left to the per-segment calls.
-
-extern "C" {
-
-int odw_batch_hits_select(odw_ctx* ctx, int32_t group, uint64_t* n_rows, uint64_t* n_leaving, int32_t* ordered) {
-  if (!ctx || !n_rows || !n_leaving || !ordered) return fail(ctx, ODW_ERR_INVALID, "odw_batch_hits_select: bad argument");
-  const int S = ctx->batch_traced;
-  if (S < 1 || !ctx->batch_rows_ok || !ctx->batch_hits.p || !ctx->batch_seg_slots) return fail(ctx, ODW_ERR_INVALID, "odw_batch_hits_select: no batch was traced with hit rows");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
-  ctx->phb_valid = ctx->phb_projected = false;
-  const uint64_t n_rays = ctx->batch_rays, ray0 = ctx->batch_first;
-  if (n_rays == 0 || n_rays > (1ull << 28)) return fail(ctx, ODW_ERR_UNSUPPORTED, "odw_batch_hits_select: more than 2^28 rays per scene");
-  int rc;
-  std::vector<uint64_t> cnt(4 * (size_t)S);      // per scene: slots handed out, unused slots, rows of leaving rays, spare
-  HIPCHK(ctx, hipMemcpyAsync(cnt.data(), ctx->batch_hit_count.p, cnt.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  // every group's rows are wanted and the launch noted each row's slot at its ray's place while it recorded it
-  // (DeviceOutputs.row_of): the pass over the rows that would fill the table is not needed
-  const bool marked = ctx->batch_marked && group < 0;
-  const uint64_t n_words = (n_rays + 31) / 32, rays_pad = n_words * 32;
-  if (!marked && (rc = ensure(ctx, ctx->phb_row_of, (size_t)S * rays_pad * sizeof(uint32_t)))) return rc;
-  if ((rc = ensure(ctx, ctx->phb_words, (size_t)S * 3 * n_words * sizeof(uint32_t)))) return rc;
-  if ((rc = ensure(ctx, ctx->phb_sel, (size_t)S * ctx->batch_seg_slots * sizeof(uint32_t)))) return rc;
-  if ((rc = ensure(ctx, ctx->phb_small, (size_t)S * 4 * sizeof(uint64_t)))) return rc;
-  HIPCHK(ctx, hipMemsetAsync(ctx->phb_small.p, 0, (size_t)S * 4 * sizeof(uint64_t), ctx->stream));
-  if (!marked) HIPCHK(ctx, hipMemsetAsync(ctx->phb_row_of.p, 0xff, (size_t)S * rays_pad * sizeof(uint32_t), ctx->stream));       // PH_NO_ROW
-  ctx->batch_marked = marked;          // (a table filled for one group is not the launch's any more)
-  size_t tmp_bytes = 0;
-  HIPCHK(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n_words, ctx->stream));
-  if ((rc = ensure(ctx, ctx->sort_tmp, tmp_bytes))) return rc;
-  ctx->phb_used.assign((size_t)S, 0);
-  for (int s = 0; s < S; ++s) {
-    const uint64_t used = std::min<uint64_t>(cnt[4 * s], ctx->batch_seg_slots);
-    ctx->phb_used[s] = used;
-    if (!used) continue;
-    const odw_hit* hits = (const odw_hit*)ctx->batch_hits.p + (size_t)s * ctx->batch_seg_slots;
-    uint32_t* row_of = (uint32_t*)ctx->phb_row_of.p + (size_t)s * rays_pad;
-    uint32_t* bitmap = (uint32_t*)ctx->phb_words.p + (size_t)s * 3 * n_words;
-    uint32_t* pop = bitmap + n_words;
-    uint32_t* before = pop + n_words;
-    unsigned long long* small = (unsigned long long*)ctx->phb_small.p + 4 * (size_t)s;
-    const unsigned kgrid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((used + 255) / 256, (uint64_t)ctx->n_cu * 8));
-    if (!marked)
-      hipLaunchKernelGGL(ph_mark_kernel, dim3(kgrid), dim3(256), 0, ctx->stream, hits, used, (int)group, ray0, n_rays, row_of, small,
-                         (uint32_t*)(small + 3));
-    hipLaunchKernelGGL(ph_popc_kernel, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)row_of,
-                       n_rays, bitmap, pop);
-    HIPCHK(ctx, hipcub::DeviceScan::ExclusiveSum(ctx->sort_tmp.p, tmp_bytes, pop, before, (int)n_words, ctx->stream));
-    hipLaunchKernelGGL(ph_rank_kernel, dim3((unsigned)((n_rays + 255) / 256)), dim3(256), 0, ctx->stream, bitmap, before,
-                       (const uint32_t*)row_of, n_rays, (uint32_t*)ctx->phb_sel.p + (size_t)s * ctx->batch_seg_slots, small + 2);
-  }
-  HIPCHK(ctx, hipGetLastError());
-  std::vector<uint64_t> c(4 * (size_t)S, 0);
-  HIPCHK(ctx, hipMemcpyAsync(c.data(), ctx->phb_small.p, c.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  ctx->phb_n.assign((size_t)S, 0);
-  ctx->phb_leaving.assign((size_t)S, 0);
-  ctx->phb_ordered.assign((size_t)S, 0);
-  for (int s = 0; s < S; ++s) {
-    // (marked by the launch: rows and leaving rows by its own counters, dropped rows never reached the table)
-    const uint64_t rows_s = ctx->phb_used[s] > cnt[4 * s + 1] ? ctx->phb_used[s] - cnt[4 * s + 1] : 0;
-    const bool dropped = cnt[4 * s] > ctx->batch_seg_slots;
-    const uint64_t sel = marked ? rows_s : c[4 * s], leave = marked ? (dropped ? 0 : cnt[4 * s + 2]) : c[4 * s + 1];
-    const uint64_t marked_rays = c[4 * s + 2], oob = c[4 * s + 3];
-    n_rows[s] = ctx->phb_n[s] = sel;
-    n_leaving[s] = ctx->phb_leaving[s] = leave;
-    // (two rows of one ray: one store of the two stands, fewer rays marked than rows selected; a sample of the entering
-    //  rows of a list that also holds leaving ones needs a compaction of its own: both take the per-segment calls)
-    const bool mixed = leave > 0 && (double)leave < .51 * (double)sel;
-    ordered[s] = ctx->phb_ordered[s] = (oob == 0 && marked_rays == sel && !mixed && !(marked && dropped)) ? 1 : 0;
-  }
-  ctx->phb_group = group;
-  ctx->phb_valid = true;
-  return ODW_OK;
-}
-
-// the rows detectPlaneNormal looks at (hits.py:108-113) of every ordered scene: points[::1 + int(n / limit)] and the
-// directions of the same rows (all rows enter, or leaving ones are the majority: DeviceHits._sample).  rows: [S][cap].
-// strides (optional, per scene): rows [::strides[s]] instead.
-int odw_batch_hits_sample(odw_ctx* ctx, uint64_t limit, const uint64_t* strides, odw_hit* rows, uint64_t cap, uint64_t* n_out) {
-  if (!ctx || !rows || !n_out || (limit == 0 && !strides)) return fail(ctx, ODW_ERR_INVALID, "odw_batch_hits_sample: bad argument");
-  if (!ctx->phb_valid) return fail(ctx, ODW_ERR_INVALID, "odw_batch_hits_sample: odw_batch_hits_select first");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
-  const int S = ctx->batch_traced;
-  int rc;
-  if ((rc = ensure(ctx, ctx->phb_rows, (size_t)S * cap * sizeof(odw_hit)))) return rc;
-  for (int s = 0; s < S; ++s) {
-    n_out[s] = 0;
-    const uint64_t m = ctx->phb_n[s];
-    if (!ctx->phb_ordered[s] || m == 0) continue;
-    const uint64_t stride = strides ? std::max<uint64_t>(1, strides[s]) : 1 + m / limit, count = (m + stride - 1) / stride;
-    if (count > cap) return fail(ctx, ODW_ERR_CAPACITY, "odw_batch_hits_sample: output buffer too small");
-    n_out[s] = count;
-    hipLaunchKernelGGL(ph_gather_strided_kernel, dim3((unsigned)((count * 4 + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (const odw_hit*)ctx->batch_hits.p + (size_t)s * ctx->batch_seg_slots,
-                       (const uint32_t*)ctx->phb_sel.p + (size_t)s * ctx->batch_seg_slots, stride, count,
-                       (odw_hit*)ctx->phb_rows.p + (size_t)s * cap);
-  }
-  HIPCHK(ctx, hipGetLastError());
-  HIPCHK(ctx, hipMemcpyAsync(rows, ctx->phb_rows.p, (size_t)S * cap * sizeof(odw_hit), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  return ODW_OK;
-}
-
-// X = p . ex, Y = p . ey of every ordered scene's selected points, their two middle elements and extrema
-// (stats: [S][8] as odw_hits_project), mean and variance of the points (moments: [S][6]).  skip[s] != 0: leave scene s out.
-int odw_batch_hits_project(odw_ctx* ctx, const double* ex, const double* ey, const int32_t* skip, double* stats, double* moments) {
-  if (!ctx || !ex || !ey || !stats || !moments) return fail(ctx, ODW_ERR_INVALID, "odw_batch_hits_project: bad argument");
-  if (!ctx->phb_valid) return fail(ctx, ODW_ERR_INVALID, "odw_batch_hits_project: odw_batch_hits_select first");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
-  const int S = ctx->batch_traced;
-  ctx->phb_projected = false;
-  int rc;
-  uint64_t max_m = 0;
-  std::vector<char> on((size_t)S, 0);
-  for (int s = 0; s < S; ++s) {
-    on[s] = ctx->phb_ordered[s] && ctx->phb_n[s] > 0 && !(skip && skip[s]);
-    if (on[s]) max_m = std::max(max_m, ctx->phb_n[s]);
-  }
-  ctx->phb_on = on;
-  if (max_m == 0) { ctx->phb_projected = true; return ODW_OK; }
-  ctx->phb_xy_stride = max_m;
-  if ((rc = ensure(ctx, ctx->phb_x, (size_t)S * max_m * sizeof(double)))) return rc;
-  if ((rc = ensure(ctx, ctx->phb_y, (size_t)S * max_m * sizeof(double)))) return rc;
-  const unsigned gmax = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((max_m + 255) / 256, (uint64_t)ctx->n_cu * 8));
-  const size_t part_stride = (size_t)gmax * 10 + 3;
-  if ((rc = ensure(ctx, ctx->phb_part, (size_t)S * part_stride * sizeof(double)))) return rc;
-  std::vector<unsigned> grid((size_t)S, 0);
-  for (int s = 0; s < S; ++s) {
-    if (!on[s]) continue;
-    const uint64_t m = ctx->phb_n[s];
-    grid[s] = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((m + 255) / 256, (uint64_t)ctx->n_cu * 8));
-    hipLaunchKernelGGL(ph_project_kernel, dim3(grid[s]), dim3(256), 0, ctx->stream,
-                       (const odw_hit*)ctx->batch_hits.p + (size_t)s * ctx->batch_seg_slots,
-                       (const uint32_t*)ctx->phb_sel.p + (size_t)s * ctx->batch_seg_slots, m, 0, ex[3 * s], ex[3 * s + 1], ex[3 * s + 2],
-                       ey[3 * s], ey[3 * s + 1], ey[3 * s + 2], (double*)ctx->phb_x.p + (size_t)s * max_m,
-                       (double*)ctx->phb_y.p + (size_t)s * max_m, (double*)ctx->phb_part.p + (size_t)s * part_stride);
-  }
-  HIPCHK(ctx, hipGetLastError());
-  std::vector<double> part((size_t)S * part_stride);
-  HIPCHK(ctx, hipMemcpyAsync(part.data(), ctx->phb_part.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  // --- extrema, moments (the sums of odw_hits_moments, in its order of additions) -----------------------------------------
-  std::vector<double> ext((size_t)S * 4);
-  for (int s = 0; s < S; ++s) {
-    if (!on[s]) continue;
-    const double* p = part.data() + (size_t)s * part_stride;
-    double* e = ext.data() + 4 * (size_t)s;
-    e[0] = e[2] = INFINITY; e[1] = e[3] = -INFINITY;
-    for (unsigned b = 0; b < grid[s]; ++b) {
-      e[0] = std::fmin(e[0], p[4 * b]); e[1] = std::fmax(e[1], p[4 * b + 1]);
-      e[2] = std::fmin(e[2], p[4 * b + 2]); e[3] = std::fmax(e[3], p[4 * b + 3]);
-    }
-    const double* q = p + (size_t)grid[s] * 4;
-    double s6[6] = {0, 0, 0, 0, 0, 0};
-    for (unsigned b = 0; b < grid[s]; ++b)
-      for (int k = 0; k < 6; ++k) s6[k] += q[6 * (size_t)b + k];
-    const double m = (double)ctx->phb_n[s];
-    for (int k = 0; k < 3; ++k) {
-      const double d = s6[k] / m;
-      moments[6 * s + k] = q[6 * (size_t)grid[s] + k] + d;
-      moments[6 * s + 3 + k] = std::max(0.0, s6[3 + k] / m - d * d);
-    }
-  }
-  // --- medians: ph_select_stats, its three waits shared by the scenes -------------------------------------------------------
-  const size_t slice_bytes = (size_t)kPhSelBlocks * 2 * kPhSelBins * sizeof(uint32_t);
-  const size_t hist_bytes = 2 * (size_t)kPhSelBins * sizeof(uint32_t);
-  const size_t sel_stride = slice_bytes + hist_bytes + 64;
-  if ((rc = ensure(ctx, ctx->phb_sel_hist, (size_t)S * sel_stride))) return rc;
-  struct Job { PhSel P; double width[2]; uint32_t cbin[2][2], fbin[2][2]; uint64_t cbelow[2][2], fbelow[2][2], take[2]; bool by_sort[2]; uint64_t k_lo, k_hi, off_y, n_out, cand_off; };
-  std::vector<Job> jobs((size_t)S);
-  std::vector<uint32_t> hist((size_t)S * 2 * kPhSelBins);
-  auto histogram_all = [&]() -> int {
-    for (int s = 0; s < S; ++s) {
-      if (!on[s]) continue;
-      const uint64_t m = ctx->phb_n[s];
-      char* base = (char*)ctx->phb_sel_hist.p + (size_t)s * sel_stride;
-      uint32_t* slices = (uint32_t*)base;
-      uint32_t* d_hist = (uint32_t*)(base + slice_bytes);
-      const unsigned hgrid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((m + 511) / 512, (uint64_t)kPhSelBlocks));
-      hipLaunchKernelGGL(ph_sel_hist_kernel, dim3(hgrid), dim3(512), 0, ctx->stream, (const double*)ctx->phb_x.p + (size_t)s * max_m,
-                         (const double*)ctx->phb_y.p + (size_t)s * max_m, m, jobs[s].P, slices);
-      HIPCHK(ctx, hipMemsetAsync(d_hist, 0, hist_bytes, ctx->stream));
-      hipLaunchKernelGGL(ph_sel_sum_kernel, dim3((2 * kPhSelBins + 255) / 256, (hgrid + kPhSelSumSlices - 1) / kPhSelSumSlices),
-                         dim3(256), 0, ctx->stream, (const uint32_t*)slices, (int)hgrid, d_hist);
-      HIPCHK(ctx, hipMemcpyAsync(hist.data() + (size_t)s * 2 * kPhSelBins, d_hist, hist_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    }
-    HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return ODW_OK;
-  };
-  for (int s = 0; s < S; ++s) {
-    if (!on[s]) continue;
-    Job& J = jobs[s];
-    std::memset(&J.P, 0, sizeof J.P);
-    const double* e = ext.data() + 4 * (size_t)s;
-    const uint64_t m = ctx->phb_n[s];
-    J.k_lo = (m - 1) / 2; J.k_hi = m / 2;
-    for (int a = 0; a < 2; ++a) {
-      J.P.lo[a] = e[2 * a];
-      J.width[a] = e[2 * a + 1] - e[2 * a];
-      J.P.sc[a] = (J.width[a] > 0 && J.width[a] < INFINITY) ? (double)kPhSelBins / J.width[a] : 0.0;
-    }
-    double* st = stats + 8 * (size_t)s;
-    st[2] = e[0]; st[3] = e[1]; st[6] = e[2]; st[7] = e[3];
-  }
-  if ((rc = histogram_all())) return rc;
-  for (int s = 0; s < S; ++s) {
-    if (!on[s]) continue;
-    Job& J = jobs[s];
-    for (int a = 0; a < 2; ++a) {
-      if (!ph_rank_bins(hist.data() + (size_t)s * 2 * kPhSelBins + (size_t)a * kPhSelBins, J.k_lo, J.k_hi, J.cbin[a], J.cbelow[a]))
-        return fail(ctx, ODW_ERR_DEVICE, "odw_batch_hits_project: histogram of the projection does not add up");
-      J.P.c_lo[a] = J.cbin[a][0]; J.P.c_hi[a] = J.cbin[a][1];
-      const double w = J.width[a] / (double)kPhSelBins;
-      J.P.flo[a] = J.P.lo[a] + (double)J.P.c_lo[a] * w;
-      const double fw = (double)(J.P.c_hi[a] - J.P.c_lo[a] + 1) * w;
-      J.P.fsc[a] = (fw > 0 && fw < INFINITY) ? (double)kPhSelBins / fw : 0.0;
-    }
-    J.P.fine = 1;
-  }
-  if ((rc = histogram_all())) return rc;
-  uint64_t cand_total = 0;
-  for (int s = 0; s < S; ++s) {
-    if (!on[s]) continue;
-    Job& J = jobs[s];
-    const uint32_t* hs = hist.data() + (size_t)s * 2 * kPhSelBins;
-    for (int a = 0; a < 2; ++a) {
-      if (!ph_rank_bins(hs + (size_t)a * kPhSelBins, J.k_lo - J.cbelow[a][0], J.k_hi - J.cbelow[a][0], J.fbin[a], J.fbelow[a]))
-        return fail(ctx, ODW_ERR_DEVICE, "odw_batch_hits_project: second histogram of the projection does not add up");
-      J.P.f0[a] = J.fbin[a][0]; J.P.f1[a] = J.fbin[a][1];
-      const uint32_t* h = hs + (size_t)a * kPhSelBins;
-      J.take[a] = h[J.fbin[a][0]] + (J.fbin[a][1] != J.fbin[a][0] ? h[J.fbin[a][1]] : 0u);
-      J.by_sort[a] = J.take[a] > kPhSelMax;
-      if (J.by_sort[a]) { J.P.c_lo[a] = 1; J.P.c_hi[a] = 0; }       // (collects nothing)
-    }
-    J.off_y = J.by_sort[0] ? 0 : J.take[0];
-    J.n_out = (J.by_sort[0] ? 0 : J.take[0]) + (J.by_sort[1] ? 0 : J.take[1]);
-    J.cand_off = cand_total;
-    cand_total += J.n_out;
-  }
-  std::vector<double> cand(cand_total);
-  if (cand_total) {
-    // (the candidates' number changes from batch to batch: room to spare, so that the buffer is not released and
-    //  allocated again -- which waits for every stream of the device -- in the middle of a sweep)
-    if (ctx->phb_cand.bytes < cand_total * sizeof(double) && (rc = ensure(ctx, ctx->phb_cand, 2 * cand_total * sizeof(double)))) return rc;
-    for (int s = 0; s < S; ++s) {
-      if (!on[s] || !jobs[s].n_out) continue;
-      Job& J = jobs[s];
-      const uint64_t m = ctx->phb_n[s];
-      unsigned long long* d_count = (unsigned long long*)((char*)ctx->phb_sel_hist.p + (size_t)s * sel_stride + slice_bytes + hist_bytes);
-      HIPCHK(ctx, hipMemsetAsync(d_count, 0, 2 * sizeof(unsigned long long), ctx->stream));
-      const unsigned g = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((m + 255) / 256, (uint64_t)ctx->n_cu * 8));
-      hipLaunchKernelGGL(ph_sel_collect_kernel, dim3(g), dim3(256), 0, ctx->stream, (const double*)ctx->phb_x.p + (size_t)s * max_m,
-                         (const double*)ctx->phb_y.p + (size_t)s * max_m, m, J.P, (double*)ctx->phb_cand.p + J.cand_off, J.off_y, d_count);
-    }
-    HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipMemcpyAsync(cand.data(), ctx->phb_cand.p, cand_total * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  }
-  for (int s = 0; s < S; ++s) {
-    if (!on[s]) continue;
-    Job& J = jobs[s];
-    double* st = stats + 8 * (size_t)s;
-    const uint32_t* hs = hist.data() + (size_t)s * 2 * kPhSelBins;
-    for (int a = 0; a < 2; ++a) {
-      if (J.by_sort[a]) {            // (a cloud piled up on one value: the sort, for this scene and coordinate alone)
-        double four[4];
-        const double* v = (const double*)(a ? ctx->phb_y.p : ctx->phb_x.p) + (size_t)s * max_m;
-        if ((rc = ph_sorted_stats(ctx, v, ctx->phb_n[s], four))) return rc;
-        st[4 * a] = four[0]; st[4 * a + 1] = four[1];
-        continue;
-      }
-      double* c = cand.data() + J.cand_off + (a ? J.off_y : 0);
-      std::sort(c, c + J.take[a]);
-      const uint64_t r_lo = J.k_lo - J.cbelow[a][0], r_hi = J.k_hi - J.cbelow[a][0];
-      const uint64_t n0 = hs[(size_t)a * kPhSelBins + J.fbin[a][0]];
-      st[4 * a] = c[r_lo - J.fbelow[a][0]];
-      st[4 * a + 1] = J.fbin[a][1] == J.fbin[a][0] ? c[r_hi - J.fbelow[a][0]] : c[n0 + (r_hi - J.fbelow[a][1])];
-    }
-  }
-  ctx->phb_projected = true;
-  return ODW_OK;
-}
-
-// numpy.histogram2d of every projected scene about its own origin, the same edges for all (counts: [S][(n_a - 1) (n_b - 1)])
-int odw_batch_hits_bin(odw_ctx* ctx, int32_t polar, const double* origins, const double* edges_a, int32_t n_a,
-                       const double* edges_b, int32_t n_b, uint64_t* counts) {
-  if (!ctx || !origins || !edges_a || !edges_b || !counts || n_a < 2 || n_b < 2)
-    return fail(ctx, ODW_ERR_INVALID, "odw_batch_hits_bin: bad argument");
-  for (int k = 1; k < n_a; ++k) if (!(edges_a[k] >= edges_a[k - 1])) return fail(ctx, ODW_ERR_INVALID, "odw_batch_hits_bin: edges must increase monotonically");
-  for (int k = 1; k < n_b; ++k) if (!(edges_b[k] >= edges_b[k - 1])) return fail(ctx, ODW_ERR_INVALID, "odw_batch_hits_bin: edges must increase monotonically");
-  if (!ctx->phb_valid || !ctx->phb_projected) return fail(ctx, ODW_ERR_INVALID, "odw_batch_hits_bin: odw_batch_hits_project first");
-  HIPCHK(ctx, hipSetDevice(ctx->device));
-  const int S = ctx->batch_traced;
-  const uint64_t nbins = (uint64_t)(n_a - 1) * (uint64_t)(n_b - 1);
-  int rc;
-  if ((rc = upload(ctx, ctx->ph_edges, edges_a, (size_t)n_a * sizeof(double)))) return rc;
-  if ((rc = ensure(ctx, ctx->ph_edges_b, (size_t)n_b * sizeof(double)))) return rc;
-  HIPCHK(ctx, hipMemcpyAsync(ctx->ph_edges_b.p, edges_b, (size_t)n_b * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  if ((rc = ensure(ctx, ctx->phb_counts, (size_t)S * nbins * sizeof(uint64_t)))) return rc;
-  HIPCHK(ctx, hipMemsetAsync(ctx->phb_counts.p, 0, (size_t)S * nbins * sizeof(uint64_t), ctx->stream));
-  const uint64_t max_m = ctx->phb_xy_stride;
-  for (int s = 0; s < S; ++s) {
-    if (!ctx->phb_on[s]) continue;
-    const uint64_t m = ctx->phb_n[s];
-    const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((m + 255) / 256, (uint64_t)ctx->n_cu * 8));
-    const double* X = (const double*)ctx->phb_x.p + (size_t)s * max_m;
-    const double* Y = (const double*)ctx->phb_y.p + (size_t)s * max_m;
-    unsigned long long* out = (unsigned long long*)ctx->phb_counts.p + (size_t)s * nbins;
-    if (nbins <= (uint64_t)kPhLdsBins)
-      hipLaunchKernelGGL((ph_bin_kernel<true>), dim3(grid), dim3(256), 0, ctx->stream, X, Y, m, origins[2 * s], origins[2 * s + 1], (int)polar,
-                         (const double*)ctx->ph_edges.p, (int)n_a, (const double*)ctx->ph_edges_b.p, (int)n_b, out);
-    else
-      hipLaunchKernelGGL((ph_bin_kernel<false>), dim3(grid), dim3(256), 0, ctx->stream, X, Y, m, origins[2 * s], origins[2 * s + 1], (int)polar,
-                         (const double*)ctx->ph_edges.p, (int)n_a, (const double*)ctx->ph_edges_b.p, (int)n_b, out);
-  }
-  HIPCHK(ctx, hipGetLastError());
-  HIPCHK(ctx, hipMemcpyAsync(counts, ctx->phb_counts.p, (size_t)S * nbins * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  return ODW_OK;
-}
-
-}  // extern "C"

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ODW_ABI_VERSION 9
+#define ODW_ABI_VERSION 10
 
 /* ---- return codes ------------------------------------------------------ */
 enum {
@@ -34,7 +34,8 @@ enum {
   ODW_ERR_DEVICE = 2,       /* HIP runtime error (see odw_last_error)      */
   ODW_ERR_NO_SCENE = 3,     /* trace before scene/source upload            */
   ODW_ERR_CAPACITY = 4,     /* hit buffer too small for requested fetch    */
-  ODW_ERR_UNSUPPORTED = 5   /* scene feature outside the supported set     */
+  ODW_ERR_UNSUPPORTED = 5,  /* scene feature outside the supported set     */
+  ODW_BUSY = 6              /* not an error: the enqueued work has not finished yet (polling calls, v10) */
 };
 
 /* ---- primitive kinds (solid primitives; faces are implicit) ------------ */
@@ -562,6 +563,33 @@ int odw_batch_hits_sample(odw_ctx* ctx, uint64_t limit, const uint64_t* strides,
 int odw_batch_hits_project(odw_ctx* ctx, const double* ex, const double* ey, const int32_t* skip, double* stats, double* moments);
 int odw_batch_hits_bin(odw_ctx* ctx, int32_t polar, const double* origins, const double* edges_a, int32_t n_a,
                        const double* edges_b, int32_t n_b, uint64_t* counts);
+/* v10: the same chain as TWO stream-ordered pieces that are enqueued and
+ * polled instead of waited for step by step -- every decision between two
+ * kernels (row counts, the histogram bins that hold the middle ranks, the
+ * ranks among the median candidates, the origin) is taken on the device, the
+ * only hand-over to the host is the plane search of Hits.detectPlaneNormal
+ * (jupyter_utils/hits.py:96-174) on the thinned sample.  A parameter sweep
+ * (optimize-spotsize.ipynb cells 8 - 11) keeps several contexts' chains in
+ * flight from one host thread.
+ *   begin     select + the sample points[::1 + n / limit] of every ordered
+ *             scene (limit <= 4096), enqueued behind the batch launch
+ *   sampled   wait != 0: waits; else ODW_BUSY while the piece is under way.
+ *             n_rows / n_leaving / ordered / n_sample: [S]; rows: [S][cap],
+ *             cap >= limit + 8
+ *   measure   planes (ex, ey: [S][3]; skip[s] != 0 leaves a scene out) ->
+ *             projection, medians, moments, histogram of (polar ? (arctan2(X,
+ *             Y), hypot) : (X, Y)) about the median origin, enqueued
+ *   measured  stats [S][8], moments [S][6], origins [S][2], counts
+ *             [S][(n_a - 1) (n_b - 1)], flags [S] (non-zero: this scene needs
+ *             the per-segment calls -- more median candidates than the device
+ *             ranks, i.e. a cloud piled up on one value)                    */
+int odw_batch_hits_begin(odw_ctx* ctx, int32_t group, uint64_t limit);
+int odw_batch_hits_sampled(odw_ctx* ctx, int32_t wait, uint64_t* n_rows, uint64_t* n_leaving, int32_t* ordered, odw_hit* rows,
+                           uint64_t cap, uint64_t* n_sample);
+int odw_batch_hits_measure(odw_ctx* ctx, const double* ex, const double* ey, const int32_t* skip, int32_t polar,
+                           const double* edges_a, int32_t n_a, const double* edges_b, int32_t n_b);
+int odw_batch_hits_measured(odw_ctx* ctx, int32_t wait, double* stats, double* moments, double* origins, uint64_t* counts,
+                            uint32_t* flags);
 
 /* ---- a run's rows kept in HBM (v9) ---------------------------------------
  * The reference keeps a run's hits in its run folder and loads them all into

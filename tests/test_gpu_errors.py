@@ -5,6 +5,7 @@ the binding like the reference raises ValueError / RuntimeError
 Edge cases: empty launches, overflowing hit lists, limits of the tables."""
 import copy
 import ctypes as C
+import dataclasses
 
 import numpy as np
 import pytest
@@ -233,6 +234,26 @@ def test_batch_entry_points_fail_loudly(tr, native_lib):
     tr.batchSelect(0)
   with pytest.raises(_native.NativeError, match='no batch was traced with hit rows'):
     tr.batchRows()
+  # a batch does not outlive the scene it was uploaded beside: a single-scene upload, or a tolerance that moves the
+  # boxes, discards it (a rebuild of the one-scene tables under a batch launch would be read past its end)
+  tr.setScene(a.scene)
+  with pytest.raises(_native.NativeError, match='odw_upload_scene_batch'):
+    tr.traceBatch(0, 1000, 1, 2000)
+  tr.setSceneBatch([a.scene, b.scene])
+  tr.traceBatch(0, 1000, 1, 2000)
+  tr.sync()
+  tr.setLimits(a.limits)                                        # the same tolerance: the batch stays
+  tr.traceBatch(0, 1000, 1, 2000)
+  tr.sync()
+  looser = dataclasses.replace(a.limits, dist_tol=a.limits.dist_tol * 10)
+  tr.setLimits(looser)
+  with pytest.raises(_native.NativeError, match='odw_upload_scene_batch'):
+    tr.traceBatch(0, 1000, 1, 2000)
+  tr.setSceneBatch([a.scene, b.scene])
+  tr.traceBatch(0, 1000, 1, 2000)
+  tr.sync()
+  rows, wanted = tr.batchRows()
+  assert np.array_equal(rows, wanted) and np.all(rows > 900)
 
 
 def test_archive_entry_points_fail_loudly(tr, native_lib):
