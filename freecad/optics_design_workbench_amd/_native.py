@@ -40,7 +40,7 @@ SYMBOLS = ['odw_abi_version', 'odw_create', 'odw_destroy', 'odw_last_error', 'od
            'odw_compile_scene', 'odw_compiled_info', 'odw_compile_check', 'odw_hits_columns',
            'odw_upload_scene_batch', 'odw_trace_batch', 'odw_batch_select', 'odw_batch_rows',
            'odw_plane_screen_batch', 'odw_archive_append', 'odw_archive_select', 'odw_archive_reset', 'odw_batch_hits_select', 'odw_batch_hits_sample', 'odw_batch_hits_project', 'odw_batch_hits_bin',
-           'odw_batch_hits_begin', 'odw_batch_hits_sampled', 'odw_batch_hits_measure', 'odw_batch_hits_measured']
+           'odw_batch_reserve', 'odw_batch_hits_begin', 'odw_batch_hits_sampled', 'odw_batch_hits_measure', 'odw_batch_hits_measured']
 
 _pd = C.POINTER(C.c_double)
 _pi = C.POINTER(C.c_int32)

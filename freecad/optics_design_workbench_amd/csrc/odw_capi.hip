@@ -112,6 +112,7 @@ struct odw_ctx {
   DevBuf sort_keys[2], sort_vals[2], sort_tmp, sorted_rows;
   // post-hoc binning of the rows in HBM (odw_posthoc.hip): the selection = sort_vals[1][0 .. ph_n)
   DevBuf ph_sel_entering, ph_flags, ph_x, ph_y, ph_sorted, ph_small, ph_part, ph_edges, ph_edges_b, ph_counts, ph_sel_hist;
+  DevBuf ph_accel;                                   // tables of the polar binning (odw_posthoc.hip: PhbBinAccel)
   DevBuf ph_bitmap, ph_before, ph_row_of;            // ordered selection without a sort (odw_posthoc.hip: ph_mark_kernel)
   uint64_t alt_hit_ray_end = 0;    // the same for the list odw_swap_hit_lists has put aside
   uint64_t hit_ray_end = 0;        // ray indices of the rows in the hit list lie below this (0: list empty; 1 << 48: unknown)
@@ -156,7 +157,7 @@ struct odw_ctx {
   bool archive_selected = false;
   // post-hoc binning of all segments at once (odw_batch_hits_*, odw_posthoc.hip): per-scene slices of these
   DevBuf phb_row_of, phb_words, phb_sel, phb_small, phb_rows, phb_x, phb_y, phb_part, phb_sel_hist, phb_cand, phb_counts;
-  DevBuf phb_scenes, phb_hist, phb_planes, phb_strides, phb_origins;   // device-resident state of the chain (odw_posthoc_batch.hip)
+  DevBuf phb_scenes, phb_hist, phb_planes, phb_strides, phb_origins, phb_accel;   // device-resident state of the chain (odw_posthoc_batch.hip)
   void* phb_pin_p = nullptr;               // page-locked block the chain's results arrive in
   size_t phb_pin_bytes = 0;
   hipEvent_t phb_ev = nullptr;             // end of the piece enqueued last (odw_batch_hits_begin / _measure)
@@ -164,7 +165,7 @@ struct odw_ctx {
   uint64_t phb_cap = 0, phb_nbins = 0;
   size_t phb_part_stride = 0;
   std::vector<double> phb_edges_host;      // the edges on the device (uploaded when they change)
-  int phb_edges_na = 0, phb_edges_nb = 0;
+  int phb_edges_na = 0, phb_edges_nb = 0, phb_edges_polar = -1;
   std::vector<uint64_t> phb_used, phb_n, phb_leaving;
   std::vector<int32_t> phb_ordered;
   std::vector<char> phb_on;
@@ -235,6 +236,8 @@ static_assert(ODW_CNT_COUNT <= kResultsHead, "counters must fit the head of the 
 int ensure_results(odw_ctx* ctx, uint64_t n_bins);
 // ctx->hits / hit_count are views of a batch segment (odw_batch_select): give the context its own list back
 void batch_unselect(odw_ctx* ctx);
+// room for the post-hoc chain of a batch (odw_posthoc_batch.hip)
+int phb_reserve(odw_ctx* ctx, int S, uint64_t rays_per_scene, uint64_t slots);
 
 // ---- primitive bounding boxes in global coordinates -----------------------
 void local_bounds(int type, const double* par, double lo[3], double hi[3]) {
@@ -1519,7 +1522,7 @@ void odw_destroy(odw_ctx* ctx) {
   for (DevBuf* b : {&ctx->grid_bounds, &ctx->grid_cells, &ctx->grid_items}) release(*b);
   for (DevBuf* b : {&ctx->ph_bitmap, &ctx->ph_before, &ctx->ph_row_of}) release(*b);
   for (DevBuf* b : {&ctx->ph_sel_entering, &ctx->ph_flags, &ctx->ph_x, &ctx->ph_y, &ctx->ph_sorted, &ctx->ph_small,
-                    &ctx->ph_part, &ctx->ph_edges, &ctx->ph_edges_b, &ctx->ph_counts, &ctx->ph_sel_hist})
+                    &ctx->ph_part, &ctx->ph_edges, &ctx->ph_edges_b, &ctx->ph_counts, &ctx->ph_sel_hist, &ctx->ph_accel})
     release(*b);
   release(ctx->archive);
   release(ctx->archive_count);
@@ -1530,7 +1533,7 @@ void odw_destroy(odw_ctx* ctx) {
   if (ctx->phb_ev) (void)hipEventDestroy(ctx->phb_ev);
   for (DevBuf* b : {&ctx->phb_row_of, &ctx->phb_words, &ctx->phb_sel, &ctx->phb_small, &ctx->phb_rows, &ctx->phb_x, &ctx->phb_y,
                     &ctx->phb_part, &ctx->phb_sel_hist, &ctx->phb_cand, &ctx->phb_counts, &ctx->phb_scenes, &ctx->phb_hist, &ctx->phb_planes,
-                    &ctx->phb_strides, &ctx->phb_origins})
+                    &ctx->phb_strides, &ctx->phb_origins, &ctx->phb_accel})
     release(*b);
   release(ctx->alt_hits);
   release(ctx->alt_hit_count);
@@ -2244,6 +2247,34 @@ int odw_upload_scene_batch(odw_ctx* ctx, const odw_scene_desc* scenes, int32_t n
   return ODW_OK;
 }
 
+namespace {
+// slots of a scene's segment: the rows asked for + the slack of block reservations
+uint64_t batch_slots(odw_ctx* ctx, uint64_t rows_per_scene) {
+  uint64_t slots = rows_per_scene;
+  if (rows_per_scene >= kHitBlockMinRows)
+    slots += hit_block_room(rows_per_scene, std::min<uint64_t>((uint64_t)ctx->n_cu * 8 * 4, std::max<uint64_t>(64, rows_per_scene / 256)), kHitBlock);
+  return slots;
+}
+}  // namespace
+
+// Room for batch launches of up to n_scenes scenes x rays_per_scene rays x rows_per_scene rows and for their post-hoc
+// chain, allocated NOW: a buffer that has to grow in the middle of a sweep is released and allocated again, which waits for
+// every stream of the device (and a hit list of 13 GB takes half a second to allocate).
+int odw_batch_reserve(odw_ctx* ctx, int32_t n_scenes, uint64_t rays_per_scene, uint64_t rows_per_scene) {
+  if (!ctx || n_scenes < 1 || rays_per_scene == 0) return fail(ctx, ODW_ERR_INVALID, "odw_batch_reserve: bad argument");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const uint64_t S = (uint64_t)n_scenes, slots = batch_slots(ctx, rows_per_scene);
+  if (slots > 0x7FFFFFFFull) return fail(ctx, ODW_ERR_CAPACITY, "odw_batch_reserve: more than 2^31 rows per scene");
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  int rc = ODW_OK;
+  if (rows_per_scene) {
+    rc = ensure(ctx, ctx->batch_hits, S * slots * sizeof(odw_hit));
+    if (!rc) rc = ensure(ctx, ctx->batch_hit_count, S * 4 * sizeof(uint64_t));
+  }
+  if (!rc) rc = phb_reserve(ctx, (int)S, rays_per_scene, slots);
+  return rc;
+}
+
 int odw_trace_batch(odw_ctx* ctx, uint64_t first_ray, uint64_t rays_per_scene, uint64_t seed, uint32_t flags,
                     uint64_t rows_per_scene) {
   if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_trace_batch: null ctx");
@@ -2261,9 +2292,7 @@ int odw_trace_batch(odw_ctx* ctx, uint64_t first_ray, uint64_t rays_per_scene, u
   const uint64_t S = (uint64_t)ctx->batch_n;
   if (flags & ODW_TRACE_RECORD_HITS) {
     if (rows_per_scene == 0) return fail(ctx, ODW_ERR_CAPACITY, "odw_trace_batch: ODW_TRACE_RECORD_HITS with rows_per_scene = 0");
-    uint64_t slots = rows_per_scene;
-    if (rows_per_scene >= kHitBlockMinRows)
-      slots += hit_block_room(rows_per_scene, std::min<uint64_t>((uint64_t)ctx->n_cu * 8 * 4, std::max<uint64_t>(64, rows_per_scene / 256)), kHitBlock);
+    const uint64_t slots = batch_slots(ctx, rows_per_scene);
     if (slots > 0x7FFFFFFFull) return fail(ctx, ODW_ERR_CAPACITY, "odw_trace_batch: more than 2^31 rows per scene");
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     int rc = ensure(ctx, ctx->batch_hits, S * slots * sizeof(odw_hit));

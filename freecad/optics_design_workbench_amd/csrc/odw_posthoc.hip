@@ -351,31 +351,176 @@ __device__ __forceinline__ int ph_bin(const double* __restrict__ edges, int n, d
   return v == edges[n - 1] ? n - 2 : lo - 1;
 }
 
+// ---- binning without arctan2 and without a search over all edges ------------------------------------------------------------
+// The polar histogram of a sweep costs more than the projection: per row an arctan2 (~100 instructions) and a binary search
+// over 500 radial edges (9 dependent LDS reads).  Both answers can be had exactly without them:
+//  * azimuth (<= kPhbAzEdges edges): whether arctan2(x, y) >= e is the sign of the cross product with the edge's direction
+//    (sin e, cos e), once the half (x >= 0: angle >= 0) is known.  Rows within 2e-15 rad of an edge or of the half's border
+//    -- where the rounding of arctan2 itself decides -- take arctan2 and the search, as before (none in 1e7 rows, typically);
+//  * radius (positive, finite edges): the bit pattern of a positive double grows with its value, so a table over equal
+//    steps of the pattern between the first and the last edge (kPhbGuide entries, made by the host) gives the bin of a
+//    bucket's first value; the row's bin lies between that and the next entry's -- usually the same.
+// The counts are those of ph_bin_kernel (integers; the per-segment entry points keep the plain kernel: the tests hold the
+// two against each other).
+constexpr int kPhbAzEdges = 8;
+constexpr int kPhbGuide = 4096;
+struct PhbBinAccel {
+  int32_t az_on, n_az;
+  double az_s[kPhbAzEdges], az_c[kPhbAzEdges];
+  int32_t az_kind[kPhbAzEdges];        // 0: below every angle (e < -pi), 1: an angle, 2: above every angle (e > pi)
+  int32_t r_on, r_shift;
+  uint64_t r_bits0;
+  uint16_t guide[kPhbGuide + 2];
+};
+
+// bin of v among the edges [lo, hi] known to bracket it (edges[lo] <= v, bin <= hi): numpy.searchsorted(..., 'right') - 1
+__device__ __forceinline__ int phb_bin_between(const double* __restrict__ edges, int lo, int hi, double v) {
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (edges[mid] <= v) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+__device__ __forceinline__ double ph_minus(double a, double b) { return a - b; }
+// one row's pair of bins (ia, ib; -1: outside): numpy.histogram2d's rule, polar rows through the tables above where they apply
+__device__ __forceinline__ void ph_bin_pair(const PhbBinAccel* __restrict__ accel, bool az_fast, bool r_fast, const uint16_t* __restrict__ s_guide,
+                                            int polar, double x, double y, const double* __restrict__ ea, int na,
+                                            const double* __restrict__ eb, int nb, int& ia, int& ib) {
+#pragma clang fp contract(off)
+  if (polar) {
+    const double b = sqrt(x * x + y * y);
+    if (r_fast) {
+      const double e_b0 = eb[0], e_b1 = eb[nb - 1];
+      if (!(b >= e_b0) || !(b <= e_b1)) {
+        ib = -1;
+      } else if (b == e_b1) {
+        ib = nb - 2;
+      } else {
+        const uint32_t k = (uint32_t)(((uint64_t)__double_as_longlong(b) - accel->r_bits0) >> accel->r_shift);
+        ib = phb_bin_between(eb, (int)s_guide[k], (int)s_guide[k + 1], b);
+      }
+    } else {
+      ib = ph_bin(eb, nb, b);
+    }
+    bool slow = !az_fast;
+    ia = -1;
+    if (az_fast) {
+      const int n_az = accel->n_az;
+      const double zone = 2e-15 * (fabs(x) + fabs(y));
+      slow = !(fabs(x) > zone);                          // (the border between the halves, NaN, the origin itself)
+      const bool upper = x > 0;                          // arctan2(x, y) > 0
+      int cnt = 0;
+      for (int k = 0; k < n_az; ++k) {
+        const int kind = accel->az_kind[k];
+        const double s = accel->az_s[k], c = accel->az_c[k];
+        const double cross = x * c - y * s;
+        slow = slow || (kind == 1 && !(fabs(cross) > zone));
+        // e >= 0: the angle reaches it only in the upper half, and there iff the cross product says so;
+        // e < 0: every angle of the upper half is above it, in the lower half the cross product decides
+        const bool e_nonneg = s > 0 || (s == 0 && c > 0);
+        const bool ge = kind == 0 || (kind == 1 && (e_nonneg ? (upper && cross >= 0) : (upper || cross >= 0)));
+        cnt += ge ? 1 : 0;
+      }
+      ia = (cnt == 0 || cnt == n_az) ? -1 : cnt - 1;
+    }
+    if (slow) ia = ph_bin(ea, na, atan2(x, y));          // (rare: under the wave's divergence)
+  } else {
+    ia = ph_bin(ea, na, x);
+    ib = ph_bin(eb, nb, y);
+  }
+}
+
+// the tables of PhbBinAccel for a pair of edge arrays (host)
+void ph_make_accel(PhbBinAccel& A, int polar, const double* ea, int na, const double* eb, int nb) {
+  std::memset(&A, 0, sizeof A);
+  if (!polar) return;
+  if (na <= kPhbAzEdges && !getenv("ODW_BIN_PLAIN")) {
+    bool ok = true;
+    const double pi = 3.14159265358979323846;
+    for (int k = 0; k < na; ++k) {
+      const double e = ea[k];
+      if (!std::isfinite(e)) { ok = false; break; }
+      // (edges within rounding of +-pi: whether an angle reaches them is a matter of arctan2's last bit everywhere on
+      //  the negative y axis -- the cross product's zone test sends those rows to arctan2, so they may stay "angles")
+      A.az_kind[k] = e < -pi - 1e-12 ? 0 : (e > pi + 1e-12 ? 2 : 1);
+      A.az_s[k] = std::sin(e);
+      A.az_c[k] = std::cos(e);
+    }
+    // (the last edge is closed: an angle equal to it counts -- equality lies inside the zone, arctan2 decides)
+    A.az_on = ok ? 1 : 0;
+    A.n_az = na;
+  }
+  if (nb >= 2 && nb <= 60000 && !getenv("ODW_BIN_PLAIN")) {
+    bool ok = true;
+    for (int k = 0; k < nb; ++k) ok = ok && std::isfinite(eb[k]) && eb[k] > 0;
+    if (ok && eb[nb - 1] > eb[0]) {
+      uint64_t b0, b1;
+      std::memcpy(&b0, &eb[0], 8);
+      std::memcpy(&b1, &eb[nb - 1], 8);
+      int shift = 0;
+      while (((b1 - b0) >> shift) >= (uint64_t)kPhbGuide) ++shift;
+      A.r_bits0 = b0;
+      A.r_shift = shift;
+      // guide[k] = bin of the first value of bucket k (searchsorted(edges, v, 'right') - 1); the last entries = the last bin
+      int at = 0;
+      for (int k = 0; k <= kPhbGuide + 1; ++k) {
+        const uint64_t bits = b0 + ((uint64_t)k << shift);
+        double v;
+        std::memcpy(&v, &bits, 8);
+        if (bits > b1) v = eb[nb - 1];
+        while (at + 1 < nb && eb[at + 1] <= v) ++at;
+        A.guide[k] = (uint16_t)std::min(at, nb - 2);
+      }
+      A.r_on = 1;
+    }
+  }
+}
+
+// dynamic LDS of the bin kernels: edges (if they fit), counts (if kept in LDS), the radius guide (polar)
+size_t ph_bin_lds_bytes(int na, int nb, uint64_t lds_bins, bool polar) {
+  size_t bytes = (na + nb <= kPhLdsEdges) ? (size_t)(na + nb) * sizeof(double) : 0;
+  bytes += (size_t)lds_bins * sizeof(uint32_t);
+  if (polar) bytes += (size_t)(kPhbGuide + 2) * sizeof(uint16_t);
+  return bytes + 16;
+}
+
 template <bool LDS_COUNTS>
 __global__ __launch_bounds__(256) void ph_bin_kernel(const double* __restrict__ X, const double* __restrict__ Y,
                                                      uint64_t m, double ox, double oy, int polar,
                                                      const double* __restrict__ edges_a, int na,
                                                      const double* __restrict__ edges_b, int nb,
-                                                     unsigned long long* __restrict__ counts) {
-  __shared__ double s_edges[kPhLdsEdges];
-  __shared__ uint32_t s_counts[LDS_COUNTS ? kPhLdsBins : 1];
+                                                     const PhbBinAccel* __restrict__ accel, unsigned long long* __restrict__ counts) {
+  extern __shared__ double ph_bin_lds[];          // [edges | counts | guide], sized by the caller (ph_bin_lds_bytes)
   const bool edges_in_lds = na + nb <= kPhLdsEdges;
+  const int nbins = (na - 1) * (nb - 1);
+  double* s_edges = ph_bin_lds;
+  uint32_t* s_counts = reinterpret_cast<uint32_t*>(ph_bin_lds + (edges_in_lds ? na + nb : 0));
+  uint16_t* s_guide = reinterpret_cast<uint16_t*>(s_counts + (LDS_COUNTS ? nbins : 0));
+  const bool az_fast = polar && accel && accel->az_on && edges_in_lds;
+  const bool r_fast = polar && accel && accel->r_on && edges_in_lds;
   if (edges_in_lds) {
     for (int k = threadIdx.x; k < na; k += blockDim.x) s_edges[k] = edges_a[k];
     for (int k = threadIdx.x; k < nb; k += blockDim.x) s_edges[na + k] = edges_b[k];
   }
-  const int nbins = (na - 1) * (nb - 1);
   if (LDS_COUNTS)
     for (int k = threadIdx.x; k < nbins; k += blockDim.x) s_counts[k] = 0;
+  if (r_fast)
+    for (int k = threadIdx.x; k < kPhbGuide + 2; k += blockDim.x) s_guide[k] = accel->guide[k];
   __syncthreads();
   const double* ea = edges_in_lds ? s_edges : edges_a;
   const double* eb = edges_in_lds ? s_edges + na : edges_b;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
-    double a, b;
-    ph_coords(X[j], Y[j], ox, oy, polar, a, b);
-    const int ia = ph_bin(ea, na, a);
-    const int ib = ph_bin(eb, nb, b);
+    int ia, ib;
+    if (accel) {
+      ph_bin_pair(accel, az_fast, r_fast, s_guide, polar, ph_minus(X[j], ox), ph_minus(Y[j], oy), ea, na, eb, nb, ia, ib);
+    } else {
+      double a, b;
+      ph_coords(X[j], Y[j], ox, oy, polar, a, b);
+      ia = ph_bin(ea, na, a);
+      ib = ph_bin(eb, nb, b);
+    }
     if (ia >= 0 && ib >= 0) {
       const int k = ia * (nb - 1) + ib;
       if (LDS_COUNTS) atomicAdd(&s_counts[k], 1u);
@@ -814,14 +959,27 @@ int odw_hits_bin(odw_ctx* ctx, int32_t polar, const double* origin, const double
   if ((rc = ensure(ctx, ctx->ph_counts, nbins * sizeof(uint64_t)))) return rc;
   HIPCHK(ctx, hipMemsetAsync(ctx->ph_counts.p, 0, nbins * sizeof(uint64_t), ctx->stream));
   const unsigned grid = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>((m + 255) / 256, (uint64_t)ctx->n_cu * 8));
+  // polar bins without arctan2 / the search over all edges where the tables apply (ODW_BIN_PLAIN=1: the plain kernel; tests
+  // hold the two against each other and against numpy)
+  const PhbBinAccel* accel = nullptr;
+  PhbBinAccel A;
+  if (polar && !getenv("ODW_BIN_PLAIN")) {
+    ph_make_accel(A, polar, edges_a, n_a, edges_b, n_b);
+    if (A.az_on || A.r_on) {
+      if ((rc = ensure(ctx, ctx->ph_accel, sizeof A))) return rc;
+      HIPCHK(ctx, hipMemcpyAsync(ctx->ph_accel.p, &A, sizeof A, hipMemcpyHostToDevice, ctx->stream));
+      accel = (const PhbBinAccel*)ctx->ph_accel.p;
+    }
+  }
+  const size_t lds = ph_bin_lds_bytes(n_a, n_b, nbins <= (uint64_t)kPhLdsBins ? nbins : 0, polar != 0);
   if (nbins <= (uint64_t)kPhLdsBins)
-    hipLaunchKernelGGL((ph_bin_kernel<true>), dim3(grid), dim3(256), 0, ctx->stream, (const double*)ctx->ph_x.p,
+    hipLaunchKernelGGL((ph_bin_kernel<true>), dim3(grid), dim3(256), lds, ctx->stream, (const double*)ctx->ph_x.p,
                        (const double*)ctx->ph_y.p, m, origin[0], origin[1], (int)polar, (const double*)ctx->ph_edges.p,
-                       (int)n_a, (const double*)ctx->ph_edges_b.p, (int)n_b, (unsigned long long*)ctx->ph_counts.p);
+                       (int)n_a, (const double*)ctx->ph_edges_b.p, (int)n_b, accel, (unsigned long long*)ctx->ph_counts.p);
   else
-    hipLaunchKernelGGL((ph_bin_kernel<false>), dim3(grid), dim3(256), 0, ctx->stream, (const double*)ctx->ph_x.p,
+    hipLaunchKernelGGL((ph_bin_kernel<false>), dim3(grid), dim3(256), lds, ctx->stream, (const double*)ctx->ph_x.p,
                        (const double*)ctx->ph_y.p, m, origin[0], origin[1], (int)polar, (const double*)ctx->ph_edges.p,
-                       (int)n_a, (const double*)ctx->ph_edges_b.p, (int)n_b, (unsigned long long*)ctx->ph_counts.p);
+                       (int)n_a, (const double*)ctx->ph_edges_b.p, (int)n_b, accel, (unsigned long long*)ctx->ph_counts.p);
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipMemcpyAsync(counts, ctx->ph_counts.p, nbins * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

@@ -20,6 +20,7 @@
 
 namespace {
 
+constexpr uint64_t kPhbRowsRoom = 4104, kPhbBinsRoom = 4096;   // sample rows / histogram bins per scene the buffers hold from the start
 constexpr uint32_t kPhbCand = 2048;        // median candidates per coordinate the pick kernel ranks; more (a cloud piled up on
                                            // one value): that coordinate is sorted (sync entry points) / the scene reported
 enum : uint32_t { PHB_SLOW_X = 1u, PHB_SLOW_Y = 2u, PHB_BAD_HIST = 4u, PHB_SAMPLE_CUT = 8u };
@@ -497,12 +498,12 @@ __global__ __launch_bounds__(256) void phb_pick_kernel(PhbScene* __restrict__ sc
   }
 }
 
-// ph_bin_kernel for every scene that is on, each about its own origin (counts: [S][nbins])
 template <bool LDS_COUNTS>
 __global__ __launch_bounds__(256) void phb_bin_kernel(const PhbScene* __restrict__ scenes, const double* __restrict__ X_all,
                                                       const double* __restrict__ Y_all, uint64_t xy_stride, int polar,
                                                       const double* __restrict__ edges_a, int na, const double* __restrict__ edges_b, int nb,
-                                                      unsigned long long* __restrict__ counts_all) {
+                                                      const PhbBinAccel* __restrict__ accel, unsigned long long* __restrict__ counts_all) {
+#pragma clang fp contract(off)
   const PhbScene& P = scenes[blockIdx.y];
   if (!P.on || (P.flags & (PHB_SLOW_X | PHB_SLOW_Y | PHB_BAD_HIST))) return;
   const uint64_t m = P.m;
@@ -511,24 +512,30 @@ __global__ __launch_bounds__(256) void phb_bin_kernel(const PhbScene* __restrict
   const double* Y = Y_all + (size_t)blockIdx.y * xy_stride;
   const int nbins = (na - 1) * (nb - 1);
   unsigned long long* counts = counts_all + (size_t)blockIdx.y * nbins;
-  __shared__ double s_edges[kPhLdsEdges];
-  __shared__ uint32_t s_counts[LDS_COUNTS ? kPhLdsBins : 1];
+  // dynamic LDS, sized by the caller to what this histogram needs ([edges | counts | guide]: ph_bin_lds_bytes) -- fixed arrays
+  // for the largest case (56 KB) left room for two blocks per CU, and the kernel waits on dependent LDS reads
+  extern __shared__ double ph_bin_lds[];
   const bool edges_in_lds = na + nb <= kPhLdsEdges;
+  double* s_edges = ph_bin_lds;
+  uint32_t* s_counts = reinterpret_cast<uint32_t*>(ph_bin_lds + (edges_in_lds ? na + nb : 0));
+  const bool az_fast = polar && accel->az_on && edges_in_lds;
+  const bool r_fast = polar && accel->r_on && edges_in_lds;
+  uint16_t* s_guide = reinterpret_cast<uint16_t*>(s_counts + (LDS_COUNTS ? nbins : 0));
   if (edges_in_lds) {
     for (int k = threadIdx.x; k < na; k += blockDim.x) s_edges[k] = edges_a[k];
     for (int k = threadIdx.x; k < nb; k += blockDim.x) s_edges[na + k] = edges_b[k];
   }
   if (LDS_COUNTS)
     for (int k = threadIdx.x; k < nbins; k += blockDim.x) s_counts[k] = 0;
+  if (r_fast)
+    for (int k = threadIdx.x; k < kPhbGuide + 2; k += blockDim.x) s_guide[k] = accel->guide[k];
   __syncthreads();
   const double* ea = edges_in_lds ? s_edges : edges_a;
   const double* eb = edges_in_lds ? s_edges + na : edges_b;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
-    double a, b;
-    ph_coords(X[j], Y[j], ox, oy, polar, a, b);
-    const int ia = ph_bin(ea, na, a);
-    const int ib = ph_bin(eb, nb, b);
+    int ia, ib;
+    ph_bin_pair(accel, az_fast, r_fast, s_guide, polar, X[j] - ox, Y[j] - oy, ea, na, eb, nb, ia, ib);
     if (ia >= 0 && ib >= 0) {
       const int k = ia * (nb - 1) + ib;
       if (LDS_COUNTS) atomicAdd(&s_counts[k], 1u);
@@ -570,19 +577,52 @@ int phb_wait(odw_ctx* ctx, bool wait) {
   return -1;
 }
 
-// layout of the page-locked block: [scenes S][sample rows S x cap | moment parts S x part_stride + counts S x nbins][planes S x 7]
+// layout of the page-locked block: [scenes S][moment parts S x part_stride][counts S x nbins][planes S x 7][origins S x 2,
+// strides S][sample rows S x cap] -- the rows last: their size changes from call to call (the plane search's sample, a
+// caller's thinned rows) and must not move what an enqueued piece still writes to
 struct PhbPinLayout { size_t scenes, rows, part, counts, planes, extra, total; };
 PhbPinLayout phb_layout(int S, uint64_t cap, size_t part_stride, uint64_t nbins) {
   PhbPinLayout L;
   auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
   L.scenes = 0;
-  L.rows = up((size_t)S * sizeof(PhbScene));
-  L.part = L.rows + up((size_t)S * cap * sizeof(odw_hit));
+  L.part = up((size_t)S * sizeof(PhbScene));
   L.counts = L.part + up((size_t)S * part_stride * sizeof(double));
   L.planes = L.counts + up((size_t)S * nbins * sizeof(uint64_t));
   L.extra = L.planes + up((size_t)S * 7 * sizeof(double));
-  L.total = L.extra + up((size_t)S * 2 * sizeof(double) + (size_t)S * sizeof(uint64_t));
+  L.rows = L.extra + up((size_t)S * 2 * sizeof(double) + (size_t)S * sizeof(uint64_t));
+  L.total = L.rows + up((size_t)S * cap * sizeof(odw_hit));
   return L;
+}
+
+}  // namespace
+namespace {
+// every buffer of the chain for S scenes of rays_per_scene rays and `slots` slots each (odw_batch_reserve)
+int phb_reserve(odw_ctx* ctx, int S, uint64_t rays_per_scene, uint64_t slots) {
+  if (rays_per_scene > (1ull << 28)) return ODW_OK;            // (the chain does not serve such launches)
+  const uint64_t n_words = (rays_per_scene + 31) / 32, rays_pad = n_words * 32;
+  const uint64_t xy_stride = std::min<uint64_t>(slots, rays_pad);
+  const size_t part_stride = (size_t)ctx->n_cu * 8 * 10 + 3;
+  int rc;
+  if ((rc = ensure(ctx, ctx->phb_row_of, (size_t)S * rays_pad * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(ctx, ctx->phb_words, (size_t)S * 3 * n_words * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(ctx, ctx->phb_sel, (size_t)S * slots * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(ctx, ctx->phb_small, (size_t)S * 4 * sizeof(uint64_t)))) return rc;
+  if ((rc = ensure(ctx, ctx->phb_scenes, (size_t)S * sizeof(PhbScene)))) return rc;
+  if ((rc = ensure(ctx, ctx->phb_rows, (size_t)S * kPhbRowsRoom * sizeof(odw_hit)))) return rc;
+  if ((rc = ensure(ctx, ctx->phb_x, (size_t)S * xy_stride * sizeof(double)))) return rc;
+  if ((rc = ensure(ctx, ctx->phb_y, (size_t)S * xy_stride * sizeof(double)))) return rc;
+  if ((rc = ensure(ctx, ctx->phb_part, (size_t)S * part_stride * sizeof(double)))) return rc;
+  if ((rc = ensure(ctx, ctx->phb_sel_hist, (size_t)S * kPhSelBlocks * 2 * kPhSelBins * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(ctx, ctx->phb_hist, (size_t)S * 2 * kPhSelBins * sizeof(uint32_t)))) return rc;
+  if ((rc = ensure(ctx, ctx->phb_cand, (size_t)S * 2 * kPhbCand * sizeof(double)))) return rc;
+  if ((rc = ensure(ctx, ctx->phb_planes, (size_t)S * 7 * sizeof(double)))) return rc;
+  if ((rc = ensure(ctx, ctx->phb_origins, (size_t)S * 2 * sizeof(double)))) return rc;
+  if ((rc = ensure(ctx, ctx->phb_strides, (size_t)S * sizeof(uint64_t)))) return rc;
+  if ((rc = ensure(ctx, ctx->phb_counts, (size_t)S * kPhbBinsRoom * sizeof(uint64_t)))) return rc;
+  size_t tmp_bytes = 0;
+  HIPCHK(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n_words, ctx->stream));
+  if ((rc = ensure(ctx, ctx->sort_tmp, tmp_bytes))) return rc;
+  return phb_pin(ctx, phb_layout(S, kPhbRowsRoom, part_stride, kPhbBinsRoom).total);
 }
 
 // select for all segments, enqueued (no wait): popcounts, prefix sums, state, rows by rank
@@ -640,9 +680,11 @@ int phb_enqueue_select(odw_ctx* ctx, int32_t group, uint64_t limit, uint64_t cap
 int phb_enqueue_sample(odw_ctx* ctx, const uint64_t* strides, uint64_t cap) {
   const int S = ctx->phb_S;
   int rc;
-  if ((rc = ensure(ctx, ctx->phb_rows, (size_t)S * cap * sizeof(odw_hit)))) return rc;
+  // (room for the largest sample a chain asks for from the start: growing a device buffer or the page-locked block in the
+  //  middle of a sweep waits for every stream of the device)
+  if ((rc = ensure(ctx, ctx->phb_rows, (size_t)S * std::max<uint64_t>(cap, kPhbRowsRoom) * sizeof(odw_hit)))) return rc;
   const PhbPinLayout L = phb_layout(S, cap, ctx->phb_part_stride, ctx->phb_nbins);
-  if ((rc = phb_pin(ctx, L.total))) return rc;
+  if ((rc = phb_pin(ctx, phb_layout(S, std::max<uint64_t>(cap, kPhbRowsRoom), ctx->phb_part_stride, std::max<uint64_t>(ctx->phb_nbins, kPhbBinsRoom)).total))) return rc;
   const uint64_t* d_strides = nullptr;
   if (strides) {
     uint64_t* h = (uint64_t*)((char*)ctx->phb_pin_p + L.extra + (size_t)S * 2 * sizeof(double));
@@ -695,7 +737,7 @@ int phb_enqueue_project(odw_ctx* ctx, const double* ex, const double* ey, const 
   if ((rc = ensure(ctx, ctx->phb_cand, (size_t)S * 2 * kPhbCand * sizeof(double)))) return rc;
   if ((rc = ensure(ctx, ctx->phb_planes, (size_t)S * 7 * sizeof(double)))) return rc;
   const PhbPinLayout L = phb_layout(S, ctx->phb_cap, part_stride, ctx->phb_nbins);
-  if ((rc = phb_pin(ctx, L.total))) return rc;
+  if ((rc = phb_pin(ctx, phb_layout(S, std::max<uint64_t>(ctx->phb_cap, kPhbRowsRoom), part_stride, std::max<uint64_t>(ctx->phb_nbins, kPhbBinsRoom)).total))) return rc;
   double* h = (double*)((char*)ctx->phb_pin_p + L.planes);
   for (int s = 0; s < S; ++s) {
     for (int k = 0; k < 3; ++k) { h[7 * s + k] = ex[3 * s + k]; h[7 * s + 3 + k] = ey[3 * s + k]; }
@@ -786,12 +828,12 @@ int phb_enqueue_bin(odw_ctx* ctx, int32_t polar, const double* origins, const do
   int rc;
   if ((rc = ensure(ctx, ctx->ph_edges, (size_t)n_a * sizeof(double)))) return rc;
   if ((rc = ensure(ctx, ctx->ph_edges_b, (size_t)n_b * sizeof(double)))) return rc;
-  if ((rc = ensure(ctx, ctx->phb_counts, (size_t)S * nbins * sizeof(uint64_t)))) return rc;
+  if ((rc = ensure(ctx, ctx->phb_counts, (size_t)S * std::max<uint64_t>(nbins, kPhbBinsRoom) * sizeof(uint64_t)))) return rc;
   ctx->phb_nbins = nbins;
   const PhbPinLayout L = phb_layout(S, ctx->phb_cap, ctx->phb_part_stride, nbins);
-  if ((rc = phb_pin(ctx, L.total))) return rc;
+  if ((rc = phb_pin(ctx, phb_layout(S, std::max<uint64_t>(ctx->phb_cap, kPhbRowsRoom), ctx->phb_part_stride, std::max<uint64_t>(nbins, kPhbBinsRoom)).total))) return rc;
   // (the edges through the page-locked block too: the caller's arrays may go away before the copy runs)
-  bool same = ctx->phb_edges_na == n_a && ctx->phb_edges_nb == n_b && ctx->phb_edges_host.size() == (size_t)(n_a + n_b);
+  bool same = ctx->phb_edges_na == n_a && ctx->phb_edges_nb == n_b && ctx->phb_edges_polar == polar && ctx->phb_edges_host.size() == (size_t)(n_a + n_b);
   if (!same) ctx->phb_edges_host.assign((size_t)(n_a + n_b), 0.0);
   for (int k = 0; same && k < n_a; ++k) same = ctx->phb_edges_host[k] == edges_a[k];
   for (int k = 0; same && k < n_b; ++k) same = ctx->phb_edges_host[n_a + k] == edges_b[k];
@@ -801,8 +843,12 @@ int phb_enqueue_bin(odw_ctx* ctx, int32_t polar, const double* origins, const do
     for (int k = 0; k < n_b; ++k) ctx->phb_edges_host[n_a + k] = edges_b[k];
     HIPCHK(ctx, hipMemcpyAsync(ctx->ph_edges.p, ctx->phb_edges_host.data(), (size_t)n_a * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(ctx->ph_edges_b.p, ctx->phb_edges_host.data() + n_a, (size_t)n_b * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    PhbBinAccel A;
+    ph_make_accel(A, polar, edges_a, n_a, edges_b, n_b);
+    if ((rc = ensure(ctx, ctx->phb_accel, sizeof A))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->phb_accel.p, &A, sizeof A, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->phb_edges_na = n_a; ctx->phb_edges_nb = n_b;
+    ctx->phb_edges_na = n_a; ctx->phb_edges_nb = n_b; ctx->phb_edges_polar = polar;
   }
   PhbScene* scenes = (PhbScene*)ctx->phb_scenes.p;
   if (origins) {
@@ -814,14 +860,16 @@ int phb_enqueue_bin(odw_ctx* ctx, int32_t polar, const double* origins, const do
   }
   HIPCHK(ctx, hipMemsetAsync(ctx->phb_counts.p, 0, (size_t)S * nbins * sizeof(uint64_t), ctx->stream));
   const unsigned gmax = (unsigned)ctx->n_cu * 8;
-  if (nbins <= (uint64_t)kPhLdsBins)
-    hipLaunchKernelGGL((phb_bin_kernel<true>), dim3(gmax, S), dim3(256), 0, ctx->stream, (const PhbScene*)scenes, (const double*)ctx->phb_x.p,
+  const bool lds_counts = nbins <= (uint64_t)kPhLdsBins;
+  const size_t lds = ph_bin_lds_bytes(n_a, n_b, lds_counts ? nbins : 0, polar != 0);
+  if (lds_counts)
+    hipLaunchKernelGGL((phb_bin_kernel<true>), dim3(gmax, S), dim3(256), lds, ctx->stream, (const PhbScene*)scenes, (const double*)ctx->phb_x.p,
                        (const double*)ctx->phb_y.p, ctx->phb_xy_stride, (int)polar, (const double*)ctx->ph_edges.p, (int)n_a,
-                       (const double*)ctx->ph_edges_b.p, (int)n_b, (unsigned long long*)ctx->phb_counts.p);
+                       (const double*)ctx->ph_edges_b.p, (int)n_b, (const PhbBinAccel*)ctx->phb_accel.p, (unsigned long long*)ctx->phb_counts.p);
   else
-    hipLaunchKernelGGL((phb_bin_kernel<false>), dim3(gmax, S), dim3(256), 0, ctx->stream, (const PhbScene*)scenes, (const double*)ctx->phb_x.p,
+    hipLaunchKernelGGL((phb_bin_kernel<false>), dim3(gmax, S), dim3(256), lds, ctx->stream, (const PhbScene*)scenes, (const double*)ctx->phb_x.p,
                        (const double*)ctx->phb_y.p, ctx->phb_xy_stride, (int)polar, (const double*)ctx->ph_edges.p, (int)n_a,
-                       (const double*)ctx->ph_edges_b.p, (int)n_b, (unsigned long long*)ctx->phb_counts.p);
+                       (const double*)ctx->ph_edges_b.p, (int)n_b, (const PhbBinAccel*)ctx->phb_accel.p, (unsigned long long*)ctx->phb_counts.p);
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipMemcpyAsync((char*)ctx->phb_pin_p + L.counts, ctx->phb_counts.p, (size_t)S * nbins * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
   return ODW_OK;
@@ -845,7 +893,7 @@ int odw_batch_hits_select(odw_ctx* ctx, int32_t group, uint64_t* n_rows, uint64_
   if (rc) return rc;
   const int S = ctx->phb_S;
   const PhbPinLayout L = phb_layout(S, ctx->phb_cap, ctx->phb_part_stride, ctx->phb_nbins);
-  if ((rc = phb_pin(ctx, L.total))) return rc;
+  if ((rc = phb_pin(ctx, phb_layout(S, std::max<uint64_t>(ctx->phb_cap, kPhbRowsRoom), ctx->phb_part_stride, std::max<uint64_t>(ctx->phb_nbins, kPhbBinsRoom)).total))) return rc;
   HIPCHK(ctx, hipMemcpyAsync((char*)ctx->phb_pin_p + L.scenes, ctx->phb_scenes.p, (size_t)S * sizeof(PhbScene), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   phb_note_state(ctx);

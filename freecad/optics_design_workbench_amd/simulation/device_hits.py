@@ -152,6 +152,30 @@ def flattestDirections(lib, clouds, angleTol=1e-9):
       return out
 
 
+def _polar_flag(binCoords):
+  mode = binCoords.lower()
+  if mode in 'cartesian':
+    return False
+  if mode in 'polar':
+    return True
+  raise ValueError(f'found invalid binCoord mode {binCoords!r}, expect one of "cartesian" or "polar"')
+
+
+def _two_edge_arrays(bins):
+  """`bins` as two arrays of edges, or None (integer bin counts, one array for both: the per-segment route)"""
+  try:
+    n = len(bins)
+  except TypeError:
+    return None
+  if n != 2 or np.ndim(bins[0]) == 0 or np.ndim(bins[1]) == 0:
+    return None
+  edges = [np.ascontiguousarray(b, dtype=np.float64) for b in bins]
+  for e in edges:
+    if e.ndim != 1 or len(e) < 2 or np.any(e[:-1] > e[1:]):
+      raise ValueError('`bins` must be 1d and increase monotonically, when an array')
+  return edges
+
+
 class DeviceHits:
 
   def __init__(self, tracer, group=None):
@@ -316,66 +340,179 @@ class DeviceHits:
 class DeviceHitsBatch:
   """the segments of a batch launch (`Tracer.traceBatch`), measured together: every step of `DeviceHits.histogram` --
   ordered selection, the thinned sample, [the plane search, on the host, scene by scene], projection + medians +
-  moments, binning -- runs for all scenes back to back on the device and is waited for once (`odw_batch_hits_*`).
-  Scene by scene the results are those of `DeviceHits` on that scene's segment, bit for bit.  A scene the batch route
-  cannot serve (`ordered[k]` False: a ray with two selected rows, a mixed list of entering and leaving rows) yields
-  None and is measured through `Tracer.batchSelect(k)` + `DeviceHits`."""
+  moments, binning -- runs for all scenes at once on the device (`odw_batch_hits_*`; every decision between two kernels
+  is taken there).  Scene by scene the results are those of `DeviceHits` on that scene's segment, bit for bit.  A scene
+  the batch route cannot serve (`ordered[k]` False: a ray with two selected rows, a mixed list of entering and leaving
+  rows) yields None and is measured through `Tracer.batchSelect(k)` + `DeviceHits`.
 
-  def __init__(self, tracer, n_scenes, group=None):
+  Two ways to drive it: step by step (the constructor selects and waits; `histograms` / `moments` / `thinned` wait once
+  each), or as a chain that is enqueued and polled -- `DeviceHitsBatch.begin(...)`, `sampled()`, `searchPlanes()`,
+  `enqueueMeasure(...)`, `measured()` -- so that one host thread keeps several tracers' chains in flight (a parameter sweep)."""
+
+  def __init__(self, tracer, n_scenes, group=None, _begin=None):
     self._tr = tracer
     self._S = int(n_scenes)
     if isinstance(group, str):
       group = tracer.scene.group_index(group)
     self._group = -1 if group is None else int(group)
+    self._planes = None          # per scene (planeNormal, xInPlaneVec), automatic choice
+    self._projected = None       # (stats [S][8], moments [S][6]) of the automatic planes
+    self._sample = None          # (rows [S][cap], counts [S]) of the plane search's sample
+    self._request = None         # the histogram the enqueued chain bins: (polar, edges_a, edges_b)
+    self._binned = None          # its counts [S][nbins], origins [S][2], flags [S]
+    self._stage = None           # 'begun' | 'sampled' | 'measuring' | 'measured' (chains only)
+    pu = C.POINTER(C.c_uint64)
+    if _begin is not None:
+      tracer._chk(tracer._lib.odw_batch_hits_begin(tracer._ctx, C.c_int32(self._group), C.c_uint64(int(_begin))), 'odw_batch_hits_begin')
+      self._limit = int(_begin)
+      self._stage = 'begun'
+      self.rows = self.leaving = self.ordered = None
+      return
     n, leaving = np.zeros(self._S, dtype=np.uint64), np.zeros(self._S, dtype=np.uint64)
     ordered = np.zeros(self._S, dtype=np.int32)
-    pu = C.POINTER(C.c_uint64)
     tracer._chk(tracer._lib.odw_batch_hits_select(tracer._ctx, C.c_int32(self._group), n.ctypes.data_as(pu),
                                                   leaving.ctypes.data_as(pu), ordered.ctypes.data_as(C.POINTER(C.c_int32))),
                 'odw_batch_hits_select')
+    self._note(n, leaving, ordered)
+
+  def _note(self, n, leaving, ordered):
     self.rows = [int(v) for v in n]
     self.leaving = [int(v) for v in leaving]
     self.ordered = [bool(v) and r > 0 for v, r in zip(ordered, self.rows)]
-    self._planes = None          # per scene (planeNormal, xInPlaneVec), automatic choice
-    self._projected = None       # (stats [S][8], moments [S][6]) of the automatic planes
 
   def __len__(self):
     return self._S
 
-  def _detectPlanes(self):
-    if self._planes is None:
+  # -- the chain: enqueue and poll ------------------------------------------------------------------------------------
+  @classmethod
+  def begin(cls, tracer, n_scenes, group=None, limit=_THIN):
+    """enqueue selection + sample behind the tracer's batch launch; nothing is waited for"""
+    return cls(tracer, n_scenes, group, _begin=limit)
+
+  def sampled(self, wait=False):
+    """True once the sample and the row counts have arrived (wait: block until then)"""
+    if self._stage != 'begun':
+      return self._stage is not None
+    tr = self._tr
+    cap = self._limit + 8
+    rows = np.zeros((self._S, cap), dtype=_native.HIT_DTYPE)
+    n, leaving, counts = (np.zeros(self._S, dtype=np.uint64) for _ in range(3))
+    ordered = np.zeros(self._S, dtype=np.int32)
+    pu = C.POINTER(C.c_uint64)
+    rc = tr._lib.odw_batch_hits_sampled(tr._ctx, C.c_int32(1 if wait else 0), n.ctypes.data_as(pu), leaving.ctypes.data_as(pu),
+                                        ordered.ctypes.data_as(C.POINTER(C.c_int32)), rows.ctypes.data_as(C.c_void_p), C.c_uint64(cap),
+                                        counts.ctypes.data_as(pu))
+    if rc == _native.BUSY:
+      return False
+    tr._chk(rc, 'odw_batch_hits_sampled')
+    self._note(n, leaving, ordered)
+    self._sample = (rows, counts)
+    self._stage = 'sampled'
+    return True
+
+  def enqueueMeasure(self, binCoords='cartesian', bins=None):
+    """enqueue projection, medians, moments and the histogram `bins` (two edge arrays) about the median origin for the
+    automatic planes; nothing is waited for.  bins None: a one-bin histogram (moments only)"""
+    polar = _polar_flag(binCoords)
+    edges = _two_edge_arrays(bins) if bins is not None else [np.array([-np.inf, np.inf]), np.array([-np.inf, np.inf])]
+    if edges is None:
+      raise ValueError('DeviceHitsBatch.enqueueMeasure bins two arrays of edges')
+    ex, ey, skip = self._axes()
+    tr = self._tr
+    pd = C.POINTER(C.c_double)
+    tr._chk(tr._lib.odw_batch_hits_measure(tr._ctx, ex.ctypes.data_as(pd), ey.ctypes.data_as(pd), skip.ctypes.data_as(C.POINTER(C.c_int32)),
+                                           C.c_int32(1 if polar else 0), edges[0].ctypes.data_as(pd), C.c_int32(len(edges[0])),
+                                           edges[1].ctypes.data_as(pd), C.c_int32(len(edges[1]))), 'odw_batch_hits_measure')
+    self._request = (polar, edges[0], edges[1])
+    self._stage = 'measuring'
+
+  def measured(self, wait=False):
+    """True once the enqueued measure has arrived"""
+    if self._stage != 'measuring':
+      return self._stage == 'measured'
+    tr = self._tr
+    polar, ea, eb = self._request
+    nb = (len(ea) - 1) * (len(eb) - 1)
+    stats, moments, origins = np.zeros((self._S, 8)), np.zeros((self._S, 6)), np.zeros((self._S, 2))
+    counts, flags = np.zeros((self._S, nb), dtype=np.uint64), np.zeros(self._S, dtype=np.uint32)
+    pd = C.POINTER(C.c_double)
+    rc = tr._lib.odw_batch_hits_measured(tr._ctx, C.c_int32(1 if wait else 0), stats.ctypes.data_as(pd), moments.ctypes.data_as(pd),
+                                         origins.ctypes.data_as(pd), counts.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                         flags.ctypes.data_as(C.POINTER(C.c_uint32)))
+    if rc == _native.BUSY:
+      return False
+    tr._chk(rc, 'odw_batch_hits_measured')
+    # (a scene the device could not finish -- more median candidates than it ranks -- is the caller's, per segment)
+    for k in np.flatnonzero(flags):
+      self._planes[k] = None
+    self._projected = (stats, moments)
+    self._binned = (counts, origins, flags)
+    self._stage = 'measured'
+    return True
+
+  # -- steps ----------------------------------------------------------------------------------------------------------
+  def _sampleRows(self):
+    if self._sample is None:
       tr = self._tr
       cap = _THIN + 8
       rows = np.zeros((self._S, cap), dtype=_native.HIT_DTYPE)
       counts = np.zeros(self._S, dtype=np.uint64)
       tr._chk(tr._lib.odw_batch_hits_sample(tr._ctx, C.c_uint64(_THIN), None, rows.ctypes.data_as(C.c_void_p), C.c_uint64(cap),
                                             counts.ctypes.data_as(C.POINTER(C.c_uint64))), 'odw_batch_hits_sample')
-      clouds = [rows[k, :int(counts[k])]['point'] if self.ordered[k] else np.zeros((0, 3)) for k in range(self._S)]
-      normals = flattestDirections(tr._lib, [c for k, c in enumerate(clouds) if self.ordered[k]])
-      planes, it = [], iter(normals)
-      for k in range(self._S):
-        if not self.ordered[k]:
-          planes.append(None)
-          continue
-        normal = _hits._against(next(it), rows[k, :int(counts[k])]['direction'])
-        planes.append((normal, _hits._in_plane_x(normal, None)))
-      self._planes = planes
+      self._sample = (rows, counts)
+    return self._sample
+
+  def _clouds(self):
+    rows, counts = self._sampleRows()
+    return [rows[k, :int(counts[k])]['point'] for k in range(self._S) if self.ordered[k]]
+
+  def _setNormals(self, normals):
+    rows, counts = self._sampleRows()
+    planes, it = [], iter(normals)
+    for k in range(self._S):
+      if not self.ordered[k]:
+        planes.append(None)
+        continue
+      normal = _hits._against(next(it), rows[k, :int(counts[k])]['direction'])
+      planes.append((normal, _hits._in_plane_x(normal, None)))
+    self._planes = planes
+
+  def _detectPlanes(self):
+    if self._planes is None:
+      self._setNormals(flattestDirections(self._tr._lib, self._clouds()))
     return self._planes
+
+  searchPlanes = _detectPlanes
+
+  @staticmethod
+  def searchPlanesTogether(batches):
+    """the plane searches of several batches in lockstep (one screen call per level for all their scenes)"""
+    batches = [b for b in batches if b._planes is None]
+    if not batches:
+      return
+    clouds = [b._clouds() for b in batches]
+    normals = iter(flattestDirections(batches[0]._tr._lib, [c for cs in clouds for c in cs]))
+    for b, cs in zip(batches, clouds):
+      b._setNormals([next(normals) for _ in cs])
+
+  def _axes(self):
+    planes = self._detectPlanes()
+    ex, ey = np.zeros((self._S, 3)), np.zeros((self._S, 3))
+    skip = np.ones(self._S, dtype=np.int32)
+    for k, pl in enumerate(planes):
+      if pl is None:
+        continue
+      normal, xvec = pl
+      x = np.asarray(xvec, dtype=np.float64)
+      y = np.cross(normal, xvec)
+      ex[k], ey[k] = x / np.linalg.norm(x), y / np.linalg.norm(y)
+      skip[k] = 0
+    return ex, ey, skip
 
   def _project(self):
     if self._projected is None:
-      planes = self._detectPlanes()
       tr = self._tr
-      ex, ey = np.zeros((self._S, 3)), np.zeros((self._S, 3))
-      skip = np.ones(self._S, dtype=np.int32)
-      for k, pl in enumerate(planes):
-        if pl is None:
-          continue
-        normal, xvec = pl
-        x = np.asarray(xvec, dtype=np.float64)
-        y = np.cross(normal, xvec)
-        ex[k], ey[k] = x / np.linalg.norm(x), y / np.linalg.norm(y)
-        skip[k] = 0
+      ex, ey, skip = self._axes()
       stats, moments = np.zeros((self._S, 8)), np.zeros((self._S, 6))
       pd = C.POINTER(C.c_double)
       tr._chk(tr._lib.odw_batch_hits_project(tr._ctx, ex.ctypes.data_as(pd), ey.ctypes.data_as(pd),
@@ -390,36 +527,27 @@ class DeviceHitsBatch:
     per-segment route"""
     if kwargs:
       return [None] * self._S
-    mode = binCoords.lower()
-    if mode in 'cartesian':
-      polar = False
-    elif mode in 'polar':
-      polar = True
-    else:
-      raise ValueError(f'found invalid binCoord mode {binCoords!r}, expect one of "cartesian" or "polar"')
-    try:
-      n = len(bins)
-    except TypeError:
+    polar = _polar_flag(binCoords)
+    edges = _two_edge_arrays(bins)
+    if edges is None:
       return [None] * self._S
-    if n != 2 or np.ndim(bins[0]) == 0 or np.ndim(bins[1]) == 0:
-      return [None] * self._S
-    edges = [np.ascontiguousarray(b, dtype=np.float64) for b in bins]
-    for e in edges:
-      if e.ndim != 1 or len(e) < 2 or np.any(e[:-1] > e[1:]):
-        raise ValueError('`bins` must be 1d and increase monotonically, when an array')
-    stats, _ = self._project()
     planes = self._detectPlanes()
-    origins = np.zeros((self._S, 2))
-    for k in range(self._S):
-      if planes[k] is not None:
-        origins[k] = (np.mean(stats[k, 0:2]), np.mean(stats[k, 4:6]))       # numpy.median: the mean of the two middle ones
-    nb = (len(edges[0]) - 1) * (len(edges[1]) - 1)
-    counts = np.zeros((self._S, nb), dtype=np.uint64)
-    tr = self._tr
-    pd = C.POINTER(C.c_double)
-    tr._chk(tr._lib.odw_batch_hits_bin(tr._ctx, C.c_int32(1 if polar else 0), origins.ctypes.data_as(pd),
-                                       edges[0].ctypes.data_as(pd), C.c_int32(len(edges[0])), edges[1].ctypes.data_as(pd),
-                                       C.c_int32(len(edges[1])), counts.ctypes.data_as(C.POINTER(C.c_uint64))), 'odw_batch_hits_bin')
+    req = self._request
+    if (self._binned is not None and req[0] == polar and np.array_equal(req[1], edges[0]) and np.array_equal(req[2], edges[1])):
+      counts, origins, _ = self._binned          # (the chain binned exactly this)
+    else:
+      stats, _ = self._project()
+      origins = np.zeros((self._S, 2))
+      for k in range(self._S):
+        if planes[k] is not None:
+          origins[k] = (np.mean(stats[k, 0:2]), np.mean(stats[k, 4:6]))       # numpy.median: the mean of the two middle ones
+      nb = (len(edges[0]) - 1) * (len(edges[1]) - 1)
+      counts = np.zeros((self._S, nb), dtype=np.uint64)
+      tr = self._tr
+      pd = C.POINTER(C.c_double)
+      tr._chk(tr._lib.odw_batch_hits_bin(tr._ctx, C.c_int32(1 if polar else 0), origins.ctypes.data_as(pd),
+                                         edges[0].ctypes.data_as(pd), C.c_int32(len(edges[0])), edges[1].ctypes.data_as(pd),
+                                         C.c_int32(len(edges[1])), counts.ctypes.data_as(C.POINTER(C.c_uint64))), 'odw_batch_hits_bin')
     out = []
     for k in range(self._S):
       if planes[k] is None:

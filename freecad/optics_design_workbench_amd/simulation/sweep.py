@@ -71,6 +71,7 @@ def _fwhmOfPolarHistogram(polarHist):
 # where a scene has to be measured by itself) -- parameterSweep then waits for the GPU once per step and batch
 # instead of once per step and value
 calcFwhm.batched = lambda batch: [None if H is None else _fwhmOfPolarHistogram(H) for H in batch.histograms(**_FWHM_BINS)]
+calcFwhm.batchedBins = _FWHM_BINS        # (the histogram `batched` asks for: a chain bins it on its way)
 
 
 def rmsSpot(hits):
@@ -219,9 +220,6 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
   table = np.zeros((len(values), len(names), 2))        # (result or 0, 1 = a number / 2 = nan)
   totals = np.zeros(3, dtype=np.int64)
   pool = None
-  if len(lanes) > 1:
-    from concurrent.futures import ThreadPoolExecutor
-    pool = ThreadPoolExecutor(max_workers=len(lanes), thread_name_prefix='odw-sweep-measure')
   pending = [None] * len(lanes)
   batch_ok = [True]
   samples = {}
@@ -312,41 +310,23 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
     else:
       measureInto(t, scene, k)
 
-  def measureGroup(t, scenes, ks, capacity):
-    """the rows of a batch launch, segment by segment (runs on a measuring thread; the launch is still under way when
-    it starts)"""
-    while True:
-      t_w = time.perf_counter()
-      t.sync()
-      mark(f'wait-trace {ks[0]}', t_w)
-      cnt = t.counters()
-      Tracer.raiseForRayErrors(cnt)
-      if not cnt['hits_dropped']:
-        break
-      rows, wanted = t.batchRows()                              # deterministic: trace again with room
-      capacity = int(int(wanted.max()) * 1.05) + 1024
-      t.reset()
-      t.traceBatch(0, int(rays), seed, capacity)
-    with totals_lock:
-      totals[:] += (cnt['traced_rays'], cnt['recorded_hits'], cnt['segments'])
-    t_m = time.perf_counter() if clock is not None else 0.0
+  def histogramRequest():
+    """the histogram the measures' batched forms will ask a DeviceHitsBatch for (the chain bins it on the way), or None"""
+    for name in names:
+      req = getattr(measures[name], 'batchedBins', None)
+      if req is not None and hasattr(measures[name], 'batched'):
+        return req
+    return None
+
+  def finishGroup(t, ks, batch_hits):
+    """the measures of a group whose chain has arrived (DeviceHitsBatch in state 'measured'), scene by scene"""
+    t_m = time.perf_counter()
     try:
-      from .device_hits import DeviceHitsBatch
       together = {}
-      batch_hits = None
-      if any(hasattr(measures[name], 'batched') for name in names):
-        t_s = time.perf_counter()
-        batch_hits = DeviceHitsBatch(t, len(ks))
-        mark(f'select {ks[0]}', t_s)
-        if timeline is not None:
-          t_s = time.perf_counter(); batch_hits._detectPlanes(); mark(f'planes {ks[0]}', t_s)
-          t_s = time.perf_counter(); batch_hits._project(); mark(f'project {ks[0]}', t_s)
-        for name in names:
-          if hasattr(measures[name], 'batched'):
-            t_s = time.perf_counter()
-            together[name] = measures[name].batched(batch_hits)
-            mark(f'{name} {ks[0]}', t_s)
-      kept = batch_hits.thinned(int(keepSample)) if (keepSample and batch_hits is not None) else None
+      for name in names:
+        if hasattr(measures[name], 'batched'):
+          together[name] = measures[name].batched(batch_hits)
+      kept = batch_hits.thinned(int(keepSample)) if keepSample else None
       for j, k in enumerate(ks):
         own_hits = None
         if keepSample:
@@ -360,7 +340,7 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
               samples[k] = _thinnedRows(own_hits, int(keepSample))
         for i, name in enumerate(names):
           m = together[name][j] if name in together else None
-          if batch_hits is not None and batch_hits.rows[j] == 0:
+          if batch_hits.rows[j] == 0:
             m = np.nan
           elif m is None:                     # this measure, or this scene, goes segment by segment
             if own_hits is None:
@@ -371,8 +351,125 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
           table[k, i] = (0.0, 2.0) if np.isnan(m) else (m, 1.0)
     finally:
       t.batchSelect(None)
+      mark(f'finish {ks[0]}', t_m)
       if clock is not None:
         clock['measure'] += time.perf_counter() - t_m
+
+  def sweepBatched(group_size):
+    """Batch launches driven as chains from THIS thread: a group of values is baked, traced by one launch and its
+    measure enqueued behind it on a context of its own (`DeviceHitsBatch.begin`); the thread then turns to whatever is
+    ready -- samples that have arrived (their plane searches, in lockstep for all groups that are ready, then the rest of
+    the chain is enqueued), chains that have finished (fits, table) -- and launches the next group when a context is free.
+    No worker threads: nothing here waits for the GPU while there is host work to do, and the host work (bake, plane
+    search, fits) never competes for the interpreter lock."""
+    from .device_hits import DeviceHitsBatch
+    request = histogramRequest()
+    for t in lanes:
+      # (every context sized for the largest group before the first launch: a hit list that has to grow later is released
+      #  and allocated again, which waits for every stream of the device -- 13 GB take half a second)
+      key = (group_size, int(rays))
+      if getattr(t, '_sweepReserved', None) != key:
+        t.reserveBatch(group_size, int(rays), int(rays * 1.25) + 1024)
+        t._sweepReserved = key
+    busy = [None] * len(lanes)           # per context: dict(ks, batch, capacity, t0) of the group in flight
+    order = []                           # contexts in the order their groups were launched
+    pos, turn = 0, 0
+
+    def launch(lane, ks, baked):
+      t, up = lanes[lane], uploaded[lane]
+      uploadCommon(t, up, baked[0][1], baked[0][2])
+      t.setSceneBatch([b[0] for b in baked])
+      t.setDetector(None)
+      capacity = int(rays * 1.25) + 1024
+      t.reset()
+      t.traceBatch(0, int(rays), seed, capacity)
+      busy[lane] = dict(ks=ks, batch=DeviceHitsBatch.begin(t, len(ks)), capacity=capacity)
+      order.append(lane)
+
+    def sampledGroups(wait_lane=None):
+      """contexts whose sample has arrived: counters checked (a segment without room: traced again), planes searched
+      together, the rest of the chain enqueued"""
+      ready = []
+      for lane in list(order):
+        g = busy[lane]
+        if g['batch']._stage == 'begun' and g['batch'].sampled(wait=(lane == wait_lane)):
+          t = lanes[lane]
+          cnt = t.counters()
+          Tracer.raiseForRayErrors(cnt)
+          if cnt['hits_dropped']:
+            rows, wanted = t.batchRows()                              # deterministic: trace again with room
+            g['capacity'] = int(int(wanted.max()) * 1.05) + 1024
+            t.reset()
+            t.traceBatch(0, int(rays), seed, g['capacity'])
+            g['batch'] = DeviceHitsBatch.begin(t, len(g['ks']))
+            continue
+          totals[:] += (cnt['traced_rays'], cnt['recorded_hits'], cnt['segments'])
+          ready.append(lane)
+      if ready:
+        t_s = time.perf_counter()
+        DeviceHitsBatch.searchPlanesTogether([busy[lane]['batch'] for lane in ready])
+        mark(f'planes {[busy[lane]["ks"][0] for lane in ready]}', t_s)
+        for lane in ready:
+          busy[lane]['batch'].enqueueMeasure(**(request or {}))
+      return bool(ready)
+
+    def measuredGroups(wait_lane=None):
+      done = False
+      for lane in list(order):
+        g = busy[lane]
+        if g['batch']._stage == 'measuring' and g['batch'].measured(wait=(lane == wait_lane)):
+          finishGroup(lanes[lane], g['ks'], g['batch'])
+          busy[lane] = None
+          order.remove(lane)
+          done = True
+      return done
+
+    while pos < len(mine) or order:
+      did = measuredGroups()
+      did = sampledGroups() or did
+      free = [lane for lane in range(len(lanes)) if busy[lane] is None]
+      if pos < len(mine) and free and batch_ok[0]:
+        # (the first groups are small, so that chains start early; the last ones shrink, so that the contexts end together)
+        left = len(mine) - pos
+        if group_size > 2 and tail_size[0] is None and left < group_size * len(lanes):
+          tail_size[0] = max(2, -(-left // len(lanes)))
+        size = group_size if group_size <= 2 else min(group_size, 2 << turn if turn < 3 else group_size, tail_size[0] or group_size)
+        ks = mine[pos:pos + size]
+        turn += 1
+        t1 = time.perf_counter()
+        baked = [bakeValue(k) for k in ks]
+        mark(f'bake {ks[0]}', t1)
+        same = all(b[2] == baked[0][2] and _sourceKey(b[1]) == _sourceKey(baked[0][1]) for b in baked[1:])
+        launched = False
+        if same and len(ks) > 1:
+          t2 = time.perf_counter()
+          try:
+            launch(free[0], ks, baked)
+            launched = True
+            mark(f'upload+launch {ks[0]}', t2)
+          except _native.NativeError as e:
+            if 'unsupported' not in str(e):
+              raise
+            batch_ok[0] = False           # (another structure per value, or scenes the flat kernels do not take: one by one)
+        if not launched:
+          for k, b in zip(ks, baked):
+            runOne(free[0], k, baked=b)
+        pos += len(ks)
+        continue
+      if pos < len(mine) and not batch_ok[0] and not order:
+        for k in mine[pos:]:
+          runOne(0, k)
+        pos = len(mine)
+        continue
+      if not did and order:
+        # nothing ready and nothing to launch: wait for the oldest chain's next piece
+        lane = order[0]
+        t_w = time.perf_counter()
+        if busy[lane]['batch']._stage == 'begun':
+          sampledGroups(wait_lane=lane)
+        else:
+          measuredGroups(wait_lane=lane)
+        mark(f'wait {busy[lane]["ks"][0] if busy[lane] else ""}', t_w)
 
   # Batch launches (Tracer.setSceneBatch / traceBatch): the values a context gets at a time are baked together and traced
   # by ONE launch -- their scenes differ in numbers only --, each into its own segment of the hit list; a measuring thread
@@ -387,68 +484,20 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
   if os.environ.get('ODW_SWEEP_BATCH'):
     group_size = max(1, int(os.environ['ODW_SWEEP_BATCH'])) if group_size > 1 else 1
   switch_interval = sys.getswitchinterval()
+  if group_size <= 1 and len(lanes) > 1:
+    # values one by one: measuring threads, one per context (batch launches are driven as chains from this thread alone)
+    from concurrent.futures import ThreadPoolExecutor
+    pool = ThreadPoolExecutor(max_workers=len(lanes), thread_name_prefix='odw-sweep-measure')
   if pool is not None:
     # (threads that alternate between short library calls and a few lines of Python hand the interpreter lock to
     #  each other all the time; with the default 5 ms a thread that comes back from a 20 us call can wait that long)
     sys.setswitchinterval(float(os.environ.get('ODW_SWITCH_INTERVAL', '2e-4')))
   try:
-    pos, turn = 0, 0
-    while pos < len(mine):
-      # (the first groups are small, so that the measuring threads have rows early; the last ones shrink, so that the
-      #  contexts end together instead of one of them measuring a full group alone)
-      left = len(mine) - pos
-      if group_size > 2 and tail_size[0] is None and left < group_size * len(lanes):
-        tail_size[0] = max(2, -(-left // len(lanes)))
-      size = group_size if group_size <= 2 else min(group_size, 2 << turn if turn < 3 else group_size, tail_size[0] or group_size)
-      ks = mine[pos:pos + size]
-      lane = turn % len(lanes)
-      turn += 1
-      if len(ks) == 1 or not batch_ok[0]:
-        for k in ks:
-          runOne(lane, k)
-          lane = turn % len(lanes)
-          turn += 1
-        pos += len(ks)
-        continue
-      t, up = lanes[lane], uploaded[lane]
-      t0 = time.perf_counter()
-      if pending[lane] is not None:
-        pending[lane].result()
-        pending[lane] = None
-      t1 = time.perf_counter()
-      baked = [bakeValue(k) for k in ks]
-      t2 = time.perf_counter()
-      mark(f'bake {ks[0]}', t1)
-      same = all(b[2] == baked[0][2] and _sourceKey(b[1]) == _sourceKey(baked[0][1]) for b in baked[1:])
-      launched = False
-      if same:
-        try:
-          uploadCommon(t, up, baked[0][1], baked[0][2])
-          t.setSceneBatch([b[0] for b in baked])
-          t.setDetector(None)
-          capacity = int(rays * 1.25) + 1024
-          t.reset()
-          t.traceBatch(0, int(rays), seed, capacity)
-          launched = True
-          mark(f'upload+launch {ks[0]}', t2)
-        except _native.NativeError as e:
-          if 'unsupported' not in str(e):
-            raise
-          batch_ok[0] = False           # (another structure per value, or scenes the flat kernels do not take: one by one)
-      if launched:
-        if clock is not None:
-          t3 = time.perf_counter()
-          clock['wait'] += t1 - t0; clock['bake'] += t2 - t1; clock['trace'] += t3 - t2
-        if pool is not None:
-          pending[lane] = pool.submit(measureGroup, t, [b[0] for b in baked], ks, capacity)
-        else:
-          measureGroup(t, [b[0] for b in baked], ks, capacity)
-      else:
-        for k, b in zip(ks, baked):
-          runOne(lane, k, baked=b)
-          lane = turn % len(lanes)
-          turn += 1
-      pos += len(ks)
+    if group_size > 1:
+      sweepBatched(group_size)
+    else:
+      for turn, k in enumerate(mine):
+        runOne(turn % len(lanes), k)
     for f in pending:
       if f is not None:
         f.result()

@@ -272,6 +272,11 @@ class Tracer:
     self.scene = scenes[0]
     self.batchScenes = list(scenes)
 
+  def reserveBatch(self, nScenes, rays, rowsPerScene):
+    """room for batches of up to nScenes scenes (and for measuring them in HBM) now, not when the first large batch arrives"""
+    self._chk(self._lib.odw_batch_reserve(self._ctx, C.c_int32(int(nScenes)), C.c_uint64(int(rays)), C.c_uint64(int(rowsPerScene))),
+              'odw_batch_reserve')
+
   def traceBatch(self, first, n, seed, rowsPerScene, record_hits=True):
     """asynchronous: rays first..first+n-1 of Philox stream `seed` in EVERY scene of the batch, one launch; a scene's
     rows (those of trace() on that scene alone) go to its own segment of the batch's hit list"""

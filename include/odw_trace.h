@@ -543,6 +543,11 @@ int odw_compile_check(const odw_scene_desc* scene, const odw_limits* limits, int
 int odw_upload_scene_batch(odw_ctx* ctx, const odw_scene_desc* scenes, int32_t n_scenes);
 int odw_trace_batch(odw_ctx* ctx, uint64_t first_ray, uint64_t rays_per_scene, uint64_t seed, uint32_t flags,
                     uint64_t rows_per_scene);
+/* v10: room for batches of up to n_scenes x rays_per_scene rays x rows_per_scene
+ * rows (and for the post-hoc chain below) allocated now instead of when a
+ * larger batch first arrives: growing a buffer in the middle of a sweep waits
+ * for every stream of the device.                                           */
+int odw_batch_reserve(odw_ctx* ctx, int32_t n_scenes, uint64_t rays_per_scene, uint64_t rows_per_scene);
 int odw_batch_select(odw_ctx* ctx, int32_t scene);
 int odw_batch_rows(odw_ctx* ctx, uint64_t* rows, uint64_t* wanted, int32_t n);
 /* The post-hoc steps (odw_hits_select / gather / project / bin / moments:

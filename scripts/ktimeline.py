@@ -28,8 +28,10 @@ print(f'span {span:.2f} ms, busy {busy / 1e6:.2f} ms ({100 * busy / 1e6 / span:.
 print('time at concurrency k (ms):', {k: round(v / 1e6, 2) for k, v in sorted(conc_time.items())})
 tot = {}
 for n, s, e, q, st in rows:
-  k = n.split('(')[0][-48:]
+  import re
+  mm = re.search(r'([A-Za-z_][A-Za-z_0-9]*)\s*(<[^()]*>)?\s*\(', n.replace('(anonymous namespace)::', ''))
+  k = (mm.group(1) if mm else n)[-48:]
   a = tot.setdefault(k, [0, 0.0]); a[0] += 1; a[1] += (e - s) / 1e6
-for k, (c, ms) in sorted(tot.items(), key=lambda kv: -kv[1][1])[:14]:
-  print(f'  {k:48s} {c:5d} calls {ms:9.2f} ms')
+for k, (c, ms) in sorted(tot.items(), key=lambda kv: -kv[1][1])[:18]:
+  print(f'  {k:48s} {c:5d} calls {ms:9.2f} ms  avg {1e3 * ms / c:9.1f} us')
 print('idle gaps > 50 us:', len(gaps), 'total', round(sum(g[1] for g in gaps), 2), 'ms; largest', sorted(gaps, key=lambda g: -g[1])[:8])

@@ -255,7 +255,10 @@ def test_polar_binning_decides_every_row_like_numpy(tracer):
   rng = np.random.default_rng(11)
   xs, ys = [], []
   for edge in (0.0, np.pi / 2, np.pi, -np.pi / 2, -np.pi, 1.0, -2.5):
-    for delta in (0.0, 1e-13, -1e-13, 1e-10, -1e-10, 1e-8, -1e-8, 9e-6, -9e-6, 1.1e-5, -1.1e-5, 1e-4, -1e-4):
+    # (not +-4e-16: at pi - 3.2e-16 ocml's arctan2 and libm's round to different neighbours -- one ulp, the plain kernel
+    #  and the tables alike; "a hit within an ulp of an edge may change sides")
+    for delta in (0.0, 1e-16, -1e-16, 1.5e-15, -1.5e-15, 2.5e-15, -2.5e-15, 1e-14, -1e-14, 1e-13, -1e-13, 1e-10, -1e-10,
+                  1e-8, -1e-8, 9e-6, -9e-6, 1.1e-5, -1.1e-5, 1e-4, -1e-4):
       for r in (1.5e-3, 0.1, 3.0, 700.0):
         a = edge + delta
         xs.append(r * np.sin(a))
@@ -266,6 +269,13 @@ def test_polar_binning_decides_every_row_like_numpy(tracer):
   xs += [s[0] for s in special]
   ys += [s[1] for s in special]
   bulk = rng.normal(size=(200_000, 2)) * np.array([0.3, 0.3])
+  radial = np.geomspace(1e-3, 2000.0, 300)
+  # rows whose radius is a radial edge, or the double next to one (the table over the bit patterns of the radius,
+  # round 5: PhbBinAccel), along directions whose squares add up without rounding
+  for e in np.r_[radial[:5], radial[148:152], radial[-3:], np.linspace(0.5, 40.0, 12)]:
+    for v in (e, np.nextafter(e, 0.0), np.nextafter(e, np.inf)):
+      xs += [v, 0.0, 0.6 * v]
+      ys += [0.0, v, 0.8 * v]
   X = np.r_[xs, bulk[:, 0]]
   Y = np.r_[ys, bulk[:, 1]]
   # the plane z = 0 seen against +z: x in the plane = (1, 0, 0), y = n x x = (0, -1, 0); with these axes the
@@ -273,13 +283,22 @@ def test_polar_binning_decides_every_row_like_numpy(tracer):
   P = np.c_[X, -Y, np.zeros(len(X))]
   D = np.tile([0.0, 0.0, 1.0], (len(X), 1))
   dh = tracer.loadHits(dict(points=P, directions=D, powers=np.ones(len(P)), isEntering=np.ones(len(P), dtype=int)))
-  radial = np.geomspace(1e-3, 2000.0, 300)
-  for azimuth in (np.arange(0, 2 * np.pi, np.pi / 2), np.linspace(-np.pi, np.pi, 9), np.array([-3.0, -2.5, 1.0, 3.0]),
-                  np.array([0.5, 1.0, 2.0])):
-    H = dh.histogram(planeNormal=np.array([0.0, 0.0, -1.0]), xInPlaneVec=np.array([1.0, 0.0, 0.0]), origin=np.zeros(2),
-                     binCoords='polar', bins=[azimuth, radial])
-    assert np.array_equal(H._planeNormal, [0.0, 0.0, -1.0])
-    x, y = X + 0.0 - 0.0, Y + 0.0 - 0.0      # (a projection sums three products: -0.0 + 0.0 = +0.0)
-    want, _, _ = np.histogram2d(np.arctan2(x, y), np.sqrt(x * x + y * y), bins=[azimuth, radial])
-    assert np.array_equal(H.hist, want), np.argwhere(H.hist != want)
-    assert H.hist.sum() > 1000
+  import os
+  x, y = X + 0.0 - 0.0, Y + 0.0 - 0.0      # (a projection sums three products: -0.0 + 0.0 = +0.0)
+  for azimuth in (np.arange(0, 2 * np.pi, np.pi / 2), np.linspace(-np.pi, np.pi, 9), np.linspace(-np.pi, np.pi, 8), np.array([-3.0, -2.5, 1.0, 3.0]),
+                  np.array([0.5, 1.0, 2.0]), np.array([-4.0, -np.pi, 0.0, np.pi, 4.0])):
+    for rad in (radial, np.linspace(0.5, 40.0, 12), np.array([1e-3, 1e-3, 0.2, 0.2, 7.0])):
+      want, _, _ = np.histogram2d(np.arctan2(x, y), np.sqrt(x * x + y * y), bins=[azimuth, rad])
+      # (with the tables of round 5 -- cross products for the azimuth, a guide over the radius' bit pattern --, and plain)
+      for plain in (False, True):
+        os.environ.pop('ODW_BIN_PLAIN', None)
+        if plain:
+          os.environ['ODW_BIN_PLAIN'] = '1'
+        try:
+          H = dh.histogram(planeNormal=np.array([0.0, 0.0, -1.0]), xInPlaneVec=np.array([1.0, 0.0, 0.0]), origin=np.zeros(2),
+                           binCoords='polar', bins=[azimuth, rad])
+        finally:
+          os.environ.pop('ODW_BIN_PLAIN', None)
+        assert np.array_equal(H._planeNormal, [0.0, 0.0, -1.0])
+        assert np.array_equal(H.hist, want), (plain, len(azimuth), len(rad), np.argwhere(H.hist != want)[:5])
+    assert want.sum() > 1000
