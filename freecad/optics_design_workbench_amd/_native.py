@@ -11,6 +11,11 @@ import subprocess
 
 import numpy as np
 
+# HIP spreads a process' streams over this many hardware queues (default 4); kernels of streams that share one wait for each
+# other.  A parameter sweep keeps five contexts' chains in flight beside each other: small kernels of one must not queue
+# behind the 7 ms launch of another.  Read by the HIP runtime when it initialises, so: set before the first HIP call.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.path.join(CSRC, 'libodw_trace.so')

@@ -151,11 +151,16 @@ __global__ void phb_rank_kernel(const uint32_t* __restrict__ words_all, uint64_t
 // rows sel[j * stride], j < count, of every ordered scene: four lanes per 64-byte row.  strides: per scene (the caller's),
 // or null: the scene's own (points[::1 + n / limit])
 __global__ void phb_sample_kernel(const PhbScene* __restrict__ scenes, const uint64_t* __restrict__ strides, const odw_hit* __restrict__ hits_all,
-                                  uint64_t slots, const uint32_t* __restrict__ sel_all, odw_hit* __restrict__ out_all, uint64_t cap) {
+                                  uint64_t slots, const uint32_t* __restrict__ sel_all, odw_hit* __restrict__ out_all, uint64_t cap,
+                                  uint64_t keep) {
   const PhbScene& P = scenes[blockIdx.y];
   if (!P.ordered || P.m == 0) return;
   uint64_t stride = P.sample_stride, count = P.sample_n;
-  if (strides) {
+  if (keep) {                     // rows [::max(1, m // keep)]
+    stride = P.m / keep ? P.m / keep : 1;
+    count = (P.m + stride - 1) / stride;
+    if (count > cap) count = cap;
+  } else if (strides) {
     stride = strides[blockIdx.y] ? strides[blockIdx.y] : 1;
     count = (P.m + stride - 1) / stride;
     if (count > cap) count = cap;
@@ -694,7 +699,8 @@ int phb_enqueue_sample(odw_ctx* ctx, const uint64_t* strides, uint64_t cap) {
     d_strides = (const uint64_t*)ctx->phb_strides.p;
   }
   hipLaunchKernelGGL(phb_sample_kernel, dim3((unsigned)((cap * 4 + 255) / 256), S), dim3(256), 0, ctx->stream, (const PhbScene*)ctx->phb_scenes.p,
-                     d_strides, (const odw_hit*)ctx->batch_hits.p, ctx->batch_seg_slots, (const uint32_t*)ctx->phb_sel.p, (odw_hit*)ctx->phb_rows.p, cap);
+                     d_strides, (const odw_hit*)ctx->batch_hits.p, ctx->batch_seg_slots, (const uint32_t*)ctx->phb_sel.p, (odw_hit*)ctx->phb_rows.p, cap,
+                     (uint64_t)0);
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipMemcpyAsync((char*)ctx->phb_pin_p + L.rows, ctx->phb_rows.p, (size_t)S * cap * sizeof(odw_hit), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync((char*)ctx->phb_pin_p + L.scenes, ctx->phb_scenes.p, (size_t)S * sizeof(PhbScene), hipMemcpyDeviceToHost, ctx->stream));
@@ -994,7 +1000,7 @@ int odw_batch_hits_sampled(odw_ctx* ctx, int32_t wait, uint64_t* n_rows, uint64_
 }
 
 int odw_batch_hits_measure(odw_ctx* ctx, const double* ex, const double* ey, const int32_t* skip, int32_t polar, const double* edges_a,
-                           int32_t n_a, const double* edges_b, int32_t n_b) {
+                           int32_t n_a, const double* edges_b, int32_t n_b, uint64_t keep) {
   if (!ctx || !ex || !ey) return fail(ctx, ODW_ERR_INVALID, "odw_batch_hits_measure: bad argument");
   int rc = phb_check_edges(ctx, "odw_batch_hits_measure", edges_a, n_a, edges_b, n_b);
   if (rc) return rc;
@@ -1005,14 +1011,35 @@ int odw_batch_hits_measure(odw_ctx* ctx, const double* ex, const double* ey, con
   rc = phb_enqueue_project(ctx, ex, ey, skip);
   if (!rc) rc = phb_enqueue_bin(ctx, polar, nullptr, edges_a, n_a, edges_b, n_b);
   if (!rc) rc = phb_enqueue_fetch_project(ctx);
+  ctx->phb_keep = 0;
+  if (!rc && keep) {
+    // the rows [::max(1, n // keep)] of every ordered scene ride along (what a notebook that traces `keep` rays per value
+    // works on): at most 2 keep - 1 rows per scene
+    if (keep > (1ull << 20)) return fail(ctx, ODW_ERR_INVALID, "odw_batch_hits_measure: keep beyond 2^20 rows");
+    const uint64_t cap = 2 * keep + 8;
+    const int S = ctx->phb_S;
+    if ((rc = ensure(ctx, ctx->phb_rows, (size_t)S * std::max<uint64_t>(cap, kPhbRowsRoom) * sizeof(odw_hit)))) return rc;
+    if ((rc = phb_pin(ctx, phb_layout(S, std::max<uint64_t>(cap, kPhbRowsRoom), ctx->phb_part_stride, std::max<uint64_t>(ctx->phb_nbins, kPhbBinsRoom)).total))) return rc;
+    const PhbPinLayout L = phb_layout(S, cap, ctx->phb_part_stride, ctx->phb_nbins);
+    hipLaunchKernelGGL(phb_sample_kernel, dim3((unsigned)((cap * 4 + 255) / 256), S), dim3(256), 0, ctx->stream, (const PhbScene*)ctx->phb_scenes.p,
+                       (const uint64_t*)nullptr, (const odw_hit*)ctx->batch_hits.p, ctx->batch_seg_slots, (const uint32_t*)ctx->phb_sel.p,
+                       (odw_hit*)ctx->phb_rows.p, cap, keep);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync((char*)ctx->phb_pin_p + L.rows, ctx->phb_rows.p, (size_t)S * cap * sizeof(odw_hit), hipMemcpyDeviceToHost, ctx->stream));
+    ctx->phb_keep = keep;
+    ctx->phb_cap = cap;
+  }
   if (!rc) rc = phb_event(ctx);
   if (rc) return rc;
   ctx->phb_stage = 3;
   return ODW_OK;
 }
 
-int odw_batch_hits_measured(odw_ctx* ctx, int32_t wait, double* stats, double* moments, double* origins, uint64_t* counts, uint32_t* flags) {
+int odw_batch_hits_measured(odw_ctx* ctx, int32_t wait, double* stats, double* moments, double* origins, uint64_t* counts, uint32_t* flags,
+                            odw_hit* keep_rows, uint64_t keep_cap, uint64_t* n_keep) {
   if (!ctx || !stats || !moments || !origins || !counts || !flags) return fail(ctx, ODW_ERR_INVALID, "odw_batch_hits_measured: bad argument");
+  if (ctx->phb_keep && (!keep_rows || !n_keep || keep_cap < ctx->phb_cap))
+    return fail(ctx, ODW_ERR_CAPACITY, "odw_batch_hits_measured: room for 2 keep + 8 rows per scene is needed");
   if (ctx->phb_stage != 3) return fail(ctx, ODW_ERR_INVALID, "odw_batch_hits_measured: odw_batch_hits_measure first");
   const int w = phb_wait(ctx, wait != 0);
   if (w < 0) return fail(ctx, ODW_ERR_DEVICE, "odw_batch_hits_measured: the device reported an error");
@@ -1024,6 +1051,17 @@ int odw_batch_hits_measured(odw_ctx* ctx, int32_t wait, double* stats, double* m
   const PhbScene* sc = (const PhbScene*)((char*)ctx->phb_pin_p + L.scenes);
   for (int s = 0; s < S; ++s) { origins[2 * s] = sc[s].origin[0]; origins[2 * s + 1] = sc[s].origin[1]; }
   std::memcpy(counts, (char*)ctx->phb_pin_p + L.counts, (size_t)S * ctx->phb_nbins * sizeof(uint64_t));
+  if (ctx->phb_keep) {
+    const odw_hit* src = (const odw_hit*)((char*)ctx->phb_pin_p + L.rows);
+    for (int s = 0; s < S; ++s) {
+      n_keep[s] = 0;
+      if (!sc[s].ordered || sc[s].m == 0) continue;
+      const uint64_t stride = sc[s].m / ctx->phb_keep ? sc[s].m / ctx->phb_keep : 1;
+      const uint64_t count = std::min<uint64_t>((sc[s].m + stride - 1) / stride, ctx->phb_cap);
+      n_keep[s] = count;
+      std::memcpy(keep_rows + (size_t)s * keep_cap, src + (size_t)s * ctx->phb_cap, (size_t)count * sizeof(odw_hit));
+    }
+  }
   ctx->phb_stage = 4;
   return ODW_OK;
 }

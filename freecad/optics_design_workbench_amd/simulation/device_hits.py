@@ -361,6 +361,7 @@ class DeviceHitsBatch:
     self._request = None         # the histogram the enqueued chain bins: (polar, edges_a, edges_b)
     self._binned = None          # its counts [S][nbins], origins [S][2], flags [S]
     self._stage = None           # 'begun' | 'sampled' | 'measuring' | 'measured' (chains only)
+    self._keep, self._kept = 0, None
     pu = C.POINTER(C.c_uint64)
     if _begin is not None:
       tracer._chk(tracer._lib.odw_batch_hits_begin(tracer._ctx, C.c_int32(self._group), C.c_uint64(int(_begin))), 'odw_batch_hits_begin')
@@ -410,7 +411,7 @@ class DeviceHitsBatch:
     self._stage = 'sampled'
     return True
 
-  def enqueueMeasure(self, binCoords='cartesian', bins=None):
+  def enqueueMeasure(self, binCoords='cartesian', bins=None, keep=0):
     """enqueue projection, medians, moments and the histogram `bins` (two edge arrays) about the median origin for the
     automatic planes; nothing is waited for.  bins None: a one-bin histogram (moments only)"""
     polar = _polar_flag(binCoords)
@@ -422,7 +423,8 @@ class DeviceHitsBatch:
     pd = C.POINTER(C.c_double)
     tr._chk(tr._lib.odw_batch_hits_measure(tr._ctx, ex.ctypes.data_as(pd), ey.ctypes.data_as(pd), skip.ctypes.data_as(C.POINTER(C.c_int32)),
                                            C.c_int32(1 if polar else 0), edges[0].ctypes.data_as(pd), C.c_int32(len(edges[0])),
-                                           edges[1].ctypes.data_as(pd), C.c_int32(len(edges[1]))), 'odw_batch_hits_measure')
+                                           edges[1].ctypes.data_as(pd), C.c_int32(len(edges[1])), C.c_uint64(int(keep or 0))), 'odw_batch_hits_measure')
+    self._keep = int(keep or 0)
     self._request = (polar, edges[0], edges[1])
     self._stage = 'measuring'
 
@@ -436,9 +438,13 @@ class DeviceHitsBatch:
     stats, moments, origins = np.zeros((self._S, 8)), np.zeros((self._S, 6)), np.zeros((self._S, 2))
     counts, flags = np.zeros((self._S, nb), dtype=np.uint64), np.zeros(self._S, dtype=np.uint32)
     pd = C.POINTER(C.c_double)
+    keep_cap = 2 * self._keep + 8 if self._keep else 1
+    keep_rows = np.zeros((self._S, keep_cap), dtype=_native.HIT_DTYPE)
+    n_keep = np.zeros(self._S, dtype=np.uint64)
     rc = tr._lib.odw_batch_hits_measured(tr._ctx, C.c_int32(1 if wait else 0), stats.ctypes.data_as(pd), moments.ctypes.data_as(pd),
                                          origins.ctypes.data_as(pd), counts.ctypes.data_as(C.POINTER(C.c_uint64)),
-                                         flags.ctypes.data_as(C.POINTER(C.c_uint32)))
+                                         flags.ctypes.data_as(C.POINTER(C.c_uint32)), keep_rows.ctypes.data_as(C.c_void_p),
+                                         C.c_uint64(keep_cap), n_keep.ctypes.data_as(C.POINTER(C.c_uint64)))
     if rc == _native.BUSY:
       return False
     tr._chk(rc, 'odw_batch_hits_measured')
@@ -447,6 +453,8 @@ class DeviceHitsBatch:
       self._planes[k] = None
     self._projected = (stats, moments)
     self._binned = (counts, origins, flags)
+    if self._keep:
+      self._kept = (self._keep, [keep_rows[k, :int(n_keep[k])].copy() if self.ordered[k] else None for k in range(self._S)])
     self._stage = 'measured'
     return True
 
@@ -561,6 +569,9 @@ class DeviceHitsBatch:
   def thinned(self, count):
     """per scene the rows [::max(1, n // count)] of the selection in (ray, bounce) order -- what `points[::k]` picks from
     the arrays `loadHits()` returns --, as HIT_DTYPE arrays; None where the scene takes the per-segment route"""
+    kept = getattr(self, '_kept', None)
+    if kept is not None and kept[0] == int(count):
+      return kept[1]                 # (the chain brought them along)
     tr = self._tr
     strides = np.array([max(1, r // int(count)) for r in self.rows], dtype=np.uint64)
     cap = max([-(-r // int(st)) for r, st in zip(self.rows, strides)] + [1])

@@ -410,7 +410,7 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
         DeviceHitsBatch.searchPlanesTogether([busy[lane]['batch'] for lane in ready])
         mark(f'planes {[busy[lane]["ks"][0] for lane in ready]}', t_s)
         for lane in ready:
-          busy[lane]['batch'].enqueueMeasure(**(request or {}))
+          busy[lane]['batch'].enqueueMeasure(keep=int(keepSample or 0), **(request or {}))
       return bool(ready)
 
     def measuredGroups(wait_lane=None):

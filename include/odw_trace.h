@@ -587,14 +587,17 @@ int odw_batch_hits_bin(odw_ctx* ctx, int32_t polar, const double* origins, const
  *   measured  stats [S][8], moments [S][6], origins [S][2], counts
  *             [S][(n_a - 1) (n_b - 1)], flags [S] (non-zero: this scene needs
  *             the per-segment calls -- more median candidates than the device
- *             ranks, i.e. a cloud piled up on one value)                    */
+ *             ranks, i.e. a cloud piled up on one value); keep != 0: the rows
+ *             [::max(1, n / keep)] of every ordered scene ride along
+ *             (keep_rows [S][keep_cap], keep_cap >= 2 keep + 8; n_keep [S]):
+ *             the sample a notebook that traces `keep` rays per value sees  */
 int odw_batch_hits_begin(odw_ctx* ctx, int32_t group, uint64_t limit);
 int odw_batch_hits_sampled(odw_ctx* ctx, int32_t wait, uint64_t* n_rows, uint64_t* n_leaving, int32_t* ordered, odw_hit* rows,
                            uint64_t cap, uint64_t* n_sample);
 int odw_batch_hits_measure(odw_ctx* ctx, const double* ex, const double* ey, const int32_t* skip, int32_t polar,
-                           const double* edges_a, int32_t n_a, const double* edges_b, int32_t n_b);
+                           const double* edges_a, int32_t n_a, const double* edges_b, int32_t n_b, uint64_t keep);
 int odw_batch_hits_measured(odw_ctx* ctx, int32_t wait, double* stats, double* moments, double* origins, uint64_t* counts,
-                            uint32_t* flags);
+                            uint32_t* flags, odw_hit* keep_rows, uint64_t keep_cap, uint64_t* n_keep);
 
 /* ---- a run's rows kept in HBM (v9) ---------------------------------------
  * The reference keeps a run's hits in its run folder and loads them all into
