@@ -146,6 +146,7 @@ struct odw_ctx {
   int batch_traced = 0;                    // scenes of the last odw_trace_batch
   bool batch_rows_ok = false;              // its segments hold rows: the launch recorded hits and was issued without error
   bool batch_marked = false;               // ... whose rows noted their slots in phb_row_of while they were recorded
+  bool batch_pts = false;                  // ... and their points in phb_pts (the chain's projection reads those)
   int batch_selected = -1;
   std::string batch_spec_text;             // the structure all scenes of the batch share (compiled kernels)
   hipFunction_t spec_batch_fn = nullptr;   // the scene-compiled kernel's BATCH variant (bound on the first batch launch)
@@ -157,7 +158,7 @@ struct odw_ctx {
   bool archive_selected = false;
   // post-hoc binning of all segments at once (odw_batch_hits_*, odw_posthoc.hip): per-scene slices of these
   DevBuf phb_row_of, phb_words, phb_sel, phb_small, phb_rows, phb_x, phb_y, phb_part, phb_sel_hist, phb_cand, phb_counts;
-  DevBuf phb_scenes, phb_hist, phb_planes, phb_strides, phb_origins, phb_accel;   // device-resident state of the chain (odw_posthoc_batch.hip)
+  DevBuf phb_scenes, phb_hist, phb_planes, phb_strides, phb_origins, phb_accel, phb_pts;   // device-resident state of the chain (odw_posthoc_batch.hip)
   void* phb_pin_p = nullptr;               // page-locked block the chain's results arrive in
   size_t phb_pin_bytes = 0;
   hipEvent_t phb_ev = nullptr;             // end of the piece enqueued last (odw_batch_hits_begin / _measure)
@@ -1230,6 +1231,7 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
   P.out.seg_count = (unsigned long long*)ctx->seg_count.p;
   P.out.row_of = (batch && ctx->batch_marked && (flags & ODW_TRACE_RECORD_HITS)) ? (uint32_t*)ctx->phb_row_of.p : nullptr;
   P.out.row_stride = batch ? (n + 31) / 32 * 32 : 0;
+  P.out.pts = (P.out.row_of && ctx->batch_pts) ? (double*)ctx->phb_pts.p : nullptr;
 
   // persistent waves: one grid that fills the chip (4 blocks of 256 threads
   // per CU at 4 waves/SIMD, x2 so that a CU never waits for a block launch);
@@ -1538,7 +1540,7 @@ void odw_destroy(odw_ctx* ctx) {
   if (ctx->phb_ev) (void)hipEventDestroy(ctx->phb_ev);
   for (DevBuf* b : {&ctx->phb_row_of, &ctx->phb_words, &ctx->phb_sel, &ctx->phb_small, &ctx->phb_rows, &ctx->phb_x, &ctx->phb_y,
                     &ctx->phb_part, &ctx->phb_sel_hist, &ctx->phb_cand, &ctx->phb_counts, &ctx->phb_scenes, &ctx->phb_hist, &ctx->phb_planes,
-                    &ctx->phb_strides, &ctx->phb_origins, &ctx->phb_accel})
+                    &ctx->phb_strides, &ctx->phb_origins, &ctx->phb_accel, &ctx->phb_pts})
     release(*b);
   release(ctx->alt_hits);
   release(ctx->alt_hit_count);
@@ -2277,6 +2279,8 @@ int odw_batch_reserve(odw_ctx* ctx, int32_t n_scenes, uint64_t rays_per_scene, u
     if (!rc) rc = ensure(ctx, ctx->batch_hit_count, S * 4 * sizeof(uint64_t));
   }
   if (!rc) rc = phb_reserve(ctx, (int)S, rays_per_scene, slots);
+  if (!rc && rows_per_scene && rays_per_scene <= (1ull << 28) && !(getenv("ODW_BATCH_PTS") && getenv("ODW_BATCH_PTS")[0] == '0'))
+    rc = ensure(ctx, ctx->phb_pts, S * slots * 3 * sizeof(double));
   return rc;
 }
 
@@ -2308,12 +2312,16 @@ int odw_trace_batch(odw_ctx* ctx, uint64_t first_ray, uint64_t rays_per_scene, u
     HIPCHK(ctx, hipMemsetAsync(ctx->batch_hit_count.p, 0, S * 4 * sizeof(uint64_t), ctx->stream));
     // every recorded row notes its slot at its ray's place (DeviceOutputs.row_of): the table starts out as "no row"
     ctx->batch_marked = false;
+    ctx->batch_pts = false;
     if (rays_per_scene <= (1ull << 28)) {
       const uint64_t rays_pad = (rays_per_scene + 31) / 32 * 32;
       rc = ensure(ctx, ctx->phb_row_of, S * rays_pad * sizeof(uint32_t));
       if (rc) return rc;
       HIPCHK(ctx, hipMemsetAsync(ctx->phb_row_of.p, 0xff, S * rays_pad * sizeof(uint32_t), ctx->stream));
       ctx->batch_marked = true;
+      // (the points alone, by slot: 24 bytes more per row; ODW_BATCH_PTS=0: the projection reads the rows)
+      static const bool pts_off = [] { const char* e = getenv("ODW_BATCH_PTS"); return e && e[0] == '0'; }();
+      ctx->batch_pts = !pts_off && ensure(ctx, ctx->phb_pts, S * slots * 3 * sizeof(double)) == ODW_OK;
     }
   }
   // the value tables of scene 0 stand where the kernels' pointers point; scene s lies s strides further

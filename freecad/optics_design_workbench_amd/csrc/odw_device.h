@@ -171,6 +171,9 @@ struct DeviceOutputs {
   // binning (odw_posthoc.hip: ph_mark_kernel) without its pass over the rows
   uint32_t* row_of;
   uint64_t row_stride;
+  // ... and, with pts, writes its point once more into a table of points alone (component c at pts[(scene * 3 + c) * hit_capacity + slot]):
+  // the projection of the post-hoc chain then reads 24 bytes per row instead of the 64-byte row (odw_posthoc_batch.hip)
+  double* pts;
 };
 
 // A batch launch (odw_trace_batch): n_scenes scenes of ONE structure -- the same primitives, trimming lists, groups and

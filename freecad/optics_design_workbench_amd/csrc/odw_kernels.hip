@@ -1370,11 +1370,13 @@ __device__ __forceinline__ void record_hit(const PT& P, uint64_t ray, int group,
     odw_hit* hits = P.out.hits;
     unsigned long long* hit_count = P.out.hit_count;
     uint32_t* row_of = nullptr;
+    double* pts = nullptr;
     if (BLOCKS && P.batch.n_scenes) {
       const uint32_t scene = __builtin_amdgcn_readfirstlane(hit_state[3]);
       hits += (size_t)scene * P.out.hit_capacity;
       hit_count += 4 * scene;
       if (P.out.row_of) row_of = P.out.row_of + (size_t)scene * P.out.row_stride;
+      if (P.out.pts) pts = P.out.pts + (size_t)scene * P.out.hit_capacity * 3;
       const uint64_t leaving = __ballot(!entering);
       if (leaving && lane == leader) atomicAdd(hit_count + 2, (unsigned long long)__popcll(leaving));
     }
@@ -1413,6 +1415,13 @@ __device__ __forceinline__ void record_hit(const PT& P, uint64_t ray, int group,
       __builtin_nontemporal_store((vd2){d.y, d.z}, rw + 2);
       __builtin_nontemporal_store((vd2){power, __longlong_as_double((long long)tag)}, rw + 3);
       if (BLOCKS && row_of) row_of[ray - P.first_ray] = (uint32_t)slot;
+      if (BLOCKS && pts) {
+        // (component-major: a wave's 64 rows write 512 contiguous bytes per component)
+        double* q = pts + slot;
+        __builtin_nontemporal_store(p.x, q);
+        __builtin_nontemporal_store(p.y, q + P.out.hit_capacity);
+        __builtin_nontemporal_store(p.z, q + 2 * P.out.hit_capacity);
+      }
     } else if (CA) {
       atomicAdd(&cnt[ODW_CNT_HITS_DROPPED * CS], 1u);
     } else {

@@ -194,7 +194,7 @@ __global__ void phb_origins_kernel(PhbScene* __restrict__ scenes, int S, const d
 // ph_project_kernel (key = points) for every scene that is on; a scene of m rows uses the blocks the per-segment launch
 // would (min(ceil(m / 256), gridDim.x)): the same strides, the same order of additions in the moment sums
 __global__ __launch_bounds__(256) void phb_project_kernel(const PhbScene* __restrict__ scenes, const odw_hit* __restrict__ hits_all, uint64_t slots,
-                                                          const uint32_t* __restrict__ sel_all, double* __restrict__ X_all,
+                                                          const double* __restrict__ pts_all, const uint32_t* __restrict__ sel_all, double* __restrict__ X_all,
                                                           double* __restrict__ Y_all, uint64_t xy_stride, double* __restrict__ part_all,
                                                           uint64_t part_stride) {
 #pragma clang fp contract(off)
@@ -211,13 +211,16 @@ __global__ __launch_bounds__(256) void phb_project_kernel(const PhbScene* __rest
   double* part = part_all + (size_t)blockIdx.y * part_stride;
   const double ex0 = P.ex[0], ex1 = P.ex[1], ex2 = P.ex[2], ey0 = P.ey[0], ey1 = P.ey[1], ey2 = P.ey[2];
   double lo_x = INFINITY, hi_x = -INFINITY, lo_y = INFINITY, hi_y = -INFINITY;
-  const double* c0 = hits[sel[0]].point;
-  const double cx = c0[0], cy = c0[1], cz = c0[2];
+  // (the points by themselves where the launch wrote them too: 24 bytes per row instead of the row's 64)
+  const double* pts = pts_all ? pts_all + (size_t)blockIdx.y * slots * 3 : nullptr;
+  const double cx = pts ? pts[sel[0]] : hits[sel[0]].point[0], cy = pts ? pts[slots + sel[0]] : hits[sel[0]].point[1],
+               cz = pts ? pts[2 * slots + sel[0]] : hits[sel[0]].point[2];
   double mom[6] = {0, 0, 0, 0, 0, 0};
   const uint64_t stride = (uint64_t)g * blockDim.x;
   for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
-    const double* p = hits[sel[j]].point;
-    const double a = p[0], b = p[1], c = p[2];
+    const uint32_t at = sel[j];
+    const double a = pts ? pts[at] : hits[at].point[0], b = pts ? pts[slots + at] : hits[at].point[1],
+                 c = pts ? pts[2 * slots + at] : hits[at].point[2];
     const double x = a * ex0 + b * ex1 + c * ex2, y = a * ey0 + b * ey1 + c * ey2;
     X[j] = x;
     Y[j] = y;
@@ -758,7 +761,7 @@ int phb_enqueue_project(odw_ctx* ctx, const double* ex, const double* ey, const 
   HIPCHK(ctx, hipMemcpyAsync(ctx->phb_planes.p, h, (size_t)S * 7 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(phb_planes_kernel, dim3((S + 63) / 64), dim3(64), 0, ctx->stream, scenes, S, (const double*)ctx->phb_planes.p);
   hipLaunchKernelGGL(phb_project_kernel, dim3(gmax, S), dim3(256), 0, ctx->stream, (const PhbScene*)scenes, (const odw_hit*)ctx->batch_hits.p, slots,
-                     (const uint32_t*)ctx->phb_sel.p, (double*)ctx->phb_x.p, (double*)ctx->phb_y.p, xy_stride, (double*)ctx->phb_part.p, (uint64_t)part_stride);
+                     ctx->batch_pts ? (const double*)ctx->phb_pts.p : (const double*)nullptr, (const uint32_t*)ctx->phb_sel.p, (double*)ctx->phb_x.p, (double*)ctx->phb_y.p, xy_stride, (double*)ctx->phb_part.p, (uint64_t)part_stride);
   hipLaunchKernelGGL(phb_ext_kernel, dim3(S), dim3(256), 0, ctx->stream, scenes, (const double*)ctx->phb_part.p, (uint64_t)part_stride, gmax);
   for (int level = 0; level < 2; ++level) {
     hipLaunchKernelGGL(phb_sel_hist_kernel, dim3(kPhSelBlocks, S), dim3(512), 0, ctx->stream, (const PhbScene*)scenes, X, Y, xy_stride, slices);
