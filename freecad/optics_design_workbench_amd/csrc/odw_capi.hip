@@ -66,6 +66,9 @@ struct DevBuf {
 struct odw_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  void* up_pin = nullptr;                  // page-locked arena small uploads are staged in (upload())
+  size_t up_off = 0;
+  bool up_unstaged = false;                // an upload since the last wait was copied from the caller's memory
   int n_cu = 256;
   std::string err;
 
@@ -217,10 +220,44 @@ int ensure(odw_ctx* ctx, DevBuf& b, size_t bytes) {
   return ODW_OK;
 }
 
+// Host to device on the context's stream.  Small tables (a scene's, a batch's: a few KB) travel through a page-locked
+// arena of the context and are NOT waited for: a copy from pageable memory blocks the caller until it has run, and in a
+// sweep it runs behind whatever other contexts have queued on the copy path -- up to a launch's length (10 ms stalls in
+// the launch of a group, measured).  The caller's array may go away at once either way; upload_done() is the wait for
+// copies that did not fit the arena.
+constexpr size_t kUploadArena = 4u << 20, kUploadStaged = 512u << 10;
 int upload(odw_ctx* ctx, DevBuf& b, const void* src, size_t bytes) {
   int rc = ensure(ctx, b, bytes);
   if (rc) return rc;
-  if (bytes) HIPCHK(ctx, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  if (!bytes) return ODW_OK;
+  if (bytes <= kUploadStaged) {
+    if (!ctx->up_pin) {
+      if (hipHostMalloc(&ctx->up_pin, kUploadArena, hipHostMallocDefault) != hipSuccess) { ctx->up_pin = nullptr; (void)hipGetLastError(); }
+      ctx->up_off = 0;
+    }
+    if (ctx->up_pin) {
+      const size_t need = (bytes + 63) & ~(size_t)63;
+      if (ctx->up_off + need > kUploadArena) {             // the arena comes round: what lies in it must have been copied
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->up_off = 0;
+      }
+      char* at = (char*)ctx->up_pin + ctx->up_off;
+      std::memcpy(at, src, bytes);
+      ctx->up_off += need;
+      HIPCHK(ctx, hipMemcpyAsync(b.p, at, bytes, hipMemcpyHostToDevice, ctx->stream));
+      return ODW_OK;
+    }
+  }
+  HIPCHK(ctx, hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  ctx->up_unstaged = true;
+  return ODW_OK;
+}
+// after a series of uploads from arrays that are about to go away: waits only if one of them was copied in place
+int upload_done(odw_ctx* ctx) {
+  if (ctx->up_unstaged) {
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->up_unstaged = false;
+  }
   return ODW_OK;
 }
 
@@ -826,7 +863,7 @@ int build_grid(odw_ctx* ctx, const std::vector<Box>& boxes, const std::vector<ch
     item_bytes = item_prim.size() * sizeof(uint32_t);
     if ((rc = upload(ctx, ctx->grid_items, item_prim.data(), item_bytes))) return rc;
   }
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));                   // host vectors die with this scope
+  if ((rc = upload_done(ctx))) return rc;                           // host vectors die with this scope
   // the kernel's LDS image (odw_grid_kernel, same arithmetic): planes | per-wave words | ray rings | cells | items
   const size_t nbp = bounds.size();
   const size_t word_off = 2 * nbp;
@@ -930,7 +967,7 @@ int build_bvh(odw_ctx* ctx) {
     // (compute_boxes has set ODW_FLAG_ISOLATED in the flag words)
     if (!rc && n > 0) rc = upload(ctx, ctx->prim_i32, ctx->h_prim_i32.data(), ctx->h_prim_i32.size() * sizeof(int32_t));
     if (rc) return rc;
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = upload_done(ctx))) return rc;
     ctx->P.scene.prim_hdr = (const double*)ctx->prim_hdr.p;
   }
   const int bvh_threshold = ctx->flat_limit;
@@ -1038,7 +1075,7 @@ int build_bvh(odw_ctx* ctx) {
       }
     }
   }
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host vectors die with this scope
+  { int rc_ = upload_done(ctx); if (rc_) return rc_; }  // host vectors die with this scope
   ctx->P.scene.bvh_nodes = (const float*)ctx->bvh_nodes.p;
   ctx->P.scene.bvh_prims = (const int32_t*)ctx->bvh_prims.p;
   ctx->P.scene.bvh_leaf = recs.empty() ? nullptr : (const float*)ctx->bvh_leaf.p;
@@ -1537,6 +1574,7 @@ void odw_destroy(odw_ctx* ctx) {
   release(ctx->batch_hits);
   release(ctx->batch_hit_count);
   if (ctx->phb_pin_p) (void)hipHostFree(ctx->phb_pin_p);
+  if (ctx->up_pin) (void)hipHostFree(ctx->up_pin);
   if (ctx->phb_ev) (void)hipEventDestroy(ctx->phb_ev);
   for (DevBuf* b : {&ctx->phb_row_of, &ctx->phb_words, &ctx->phb_sel, &ctx->phb_small, &ctx->phb_rows, &ctx->phb_x, &ctx->phb_y,
                     &ctx->phb_part, &ctx->phb_sel_hist, &ctx->phb_cand, &ctx->phb_counts, &ctx->phb_scenes, &ctx->phb_hist, &ctx->phb_planes,
@@ -1682,7 +1720,7 @@ int odw_upload_scene(odw_ctx* ctx, const odw_scene_desc* s) {
   if (s->tri_normals && n > 0) {
     if ((rc = upload(ctx, ctx->tri_nrm, s->tri_normals, (size_t)n * 9 * sizeof(double)))) return rc;
   }
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if ((rc = upload_done(ctx))) return rc;
   DeviceScene& d = ctx->P.scene;
   d.tri_nrm = (s->tri_normals && n > 0) ? (const double*)ctx->tri_nrm.p : nullptr;
   d.prim_f64 = (const double*)ctx->prim_f64.p;
@@ -1756,6 +1794,7 @@ int odw_upload_surface_samplers(odw_ctx* ctx, const odw_surface_sampler_desc* sa
   if (!ctx || n < 0 || (n && !samplers)) return fail(ctx, ODW_ERR_INVALID, "odw_upload_surface_samplers: bad argument");
   if (!ctx->have_scene) return fail(ctx, ODW_ERR_NO_SCENE, "odw_upload_surface_samplers before odw_upload_scene");
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (n == 0 && ctx->n_samplers == 0) return ODW_OK;   // (none before, none now: nothing to wait for, nothing to bind again)
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // a running launch may still read the old tables
   ctx->n_samplers = 0;
   ctx->spec_dirty = true;                           // (a compiled scene: the kernel variant with / without scatter())
@@ -2245,7 +2284,7 @@ int odw_upload_scene_batch(odw_ctx* ctx, const odw_scene_desc* scenes, int32_t n
   std::vector<int32_t> pi = ctx->h_prim_i32;
   for (size_t p = 0; p < n; ++p) pi[4 * p + 2] &= ~ODW_FLAG_ISOLATED;
   if (n && (rc = upload(ctx, ctx->prim_i32, pi.data(), pi.size() * sizeof(int32_t)))) return rc;
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if ((rc = upload_done(ctx))) return rc;
   ctx->h_prim_i32 = pi;
   ctx->batch_n = n_scenes;
   ctx->batch_prims = n;
@@ -2303,7 +2342,8 @@ int odw_trace_batch(odw_ctx* ctx, uint64_t first_ray, uint64_t rays_per_scene, u
     if (rows_per_scene == 0) return fail(ctx, ODW_ERR_CAPACITY, "odw_trace_batch: ODW_TRACE_RECORD_HITS with rows_per_scene = 0");
     const uint64_t slots = batch_slots(ctx, rows_per_scene);
     if (slots > 0x7FFFFFFFull) return fail(ctx, ODW_ERR_CAPACITY, "odw_trace_batch: more than 2^31 rows per scene");
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // (a list that has to grow is released first, which waits for the device; one that is large enough is written by
+    //  this stream's next launch, behind whatever this stream still does with it)
     int rc = ensure(ctx, ctx->batch_hits, S * slots * sizeof(odw_hit));
     if (!rc) rc = ensure(ctx, ctx->batch_hit_count, S * 4 * sizeof(uint64_t));
     if (rc) return rc;
