@@ -172,7 +172,7 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
   keepSample             an integer N: the rows `[::max(1, n // N)]` of every value's hit list (the sample a notebook that
                          traces N rays per value works on) are kept in `SweepResult.samples` on the rank that ran the value
                          (`fwhmOfSamples` turns them into a column)
-  pipeline               with deviceHits on a device tracer: further contexts on the same GPU (True: four), so
+  pipeline               with deviceHits on a device tracer: further contexts on the same GPU (True: three), so
                          that the next group of values is baked and traced while earlier ones are measured (same
                          results); an integer n: n extra contexts (n measuring threads)
   """
@@ -200,11 +200,11 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
   elif os.environ.get('ODW_SWEEP_PIPELINE'):
     pipeline = int(os.environ['ODW_SWEEP_PIPELINE'])
   if pipeline and deviceHits and isinstance(tr, Tracer) and len(mine) > 1:
-    # (four extra contexts by default: groups of values take turns on five contexts -- while the measuring threads of
-    #  some wait for the GPU or search planes, others' launches and post-hoc steps keep it busy.  64 x 1e7 rays, batch 12:
-    #  2 / 3 / 4 extra contexts = 105 / 95 / 89 ms per sweep.  Each context holds a group's hit list: ~13 GB at 12 values
-    #  x 1.25e7 rows.  The extra contexts stay with the tracer between sweeps: creating them costs ~12 ms each)
-    want = min(int(pipeline) if pipeline is not True else 4, len(mine) - 1, 5)
+    # (three extra contexts by default: groups of values take turns on four contexts -- while the chain of one waits for its
+    #  plane search or its fits, the launches and chains of the others keep the GPU busy.  64 x 1e7 rays, batch 12, round 5:
+    #  1 / 2 / 3 / 4 extra contexts = 90 / 83 / 74 / 79 ms per sweep.  Each context holds a group's hit list and the chain's
+    #  buffers: ~17 GB at 12 values x 1.25e7 rows.  The extra contexts stay with the tracer between sweeps)
+    want = min(int(pipeline) if pipeline is not True else 3, len(mine) - 1, 5)
     kept = [e for e in (getattr(tr, '_sweepLanes', None) or [])
             if e.referenceStrict == tr.referenceStrict and e.compileMode() == tr.compileMode()]
     while len(kept) < want:
