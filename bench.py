@@ -131,12 +131,15 @@ def spawn_ranks(args, argv):
   return subprocess.call(cmd, env=dict(os.environ, MASTER_ADDR='127.0.0.1'))
 
 
-def pmc_figures(cfg_name, n_per, record_hits, kernel):
+def pmc_figures(cfg_name, n_per, record_hits, kernel, sources_sha256=None, path=None):
   """HBM traffic and VALU figures of the dominant kernel from the committed rocprofv3 PMC passes of
   this same command (profiles/pmc_current.json: FETCH_SIZE / WRITE_SIZE / SQ_* in separate --pmc
   runs, gfx950 correction applied).  PMC cannot be collected from inside the process, so the
-  figures are attached only when the workload matches the profiled one."""
-  path = os.path.join(ROOT, 'profiles', 'pmc_current.json')
+  figures are attached only when the workload matches the profiled one -- and only when they were taken on THIS code:
+  every entry carries the sha256 of the library's sources at the time of its pass (scripts/profile_round.py,
+  _native.sources_hash); on a mismatch the entry comes back as {'pmc_stale': True, ...} and roofline_block() reports
+  `pmc_stale` instead of a fraction computed from another kernel's instruction counts."""
+  path = path or os.path.join(ROOT, 'profiles', 'pmc_current.json')
   if not os.path.exists(path):
     return None
   with open(path) as f:
@@ -146,80 +149,13 @@ def pmc_figures(cfg_name, n_per, record_hits, kernel):
     return None
   if tj.get('kernel') and not kernel.startswith(tj['kernel']):     # profiled on another kernel (e.g. --compile off)
     return None
+  if sources_sha256 is None:
+    from freecad.optics_design_workbench_amd import _native
+    sources_sha256 = _native.sources_hash()
+  if tj.get('sources_sha256') != sources_sha256:
+    return dict(pmc_stale=True, source=tj.get('source'), profiled_sources_sha256=tj.get('sources_sha256'),
+                sources_sha256=sources_sha256)
   return tj
-
-
-class ClockSampler:
-  """Shader clock and package power of this rank's GPU as the amdgpu hwmon files report them while the timed steps
-  run (freq1_input in Hz, power1_input in microwatt: what an ordinary user may read), sampled by a thread that wakes
-  every 10 ms -- the timing thread sits in a ctypes call without the GIL meanwhile.  Context for the reader, not a
-  measurement of the kernel's clock: the driver's figure is smoothed over a time longer than a 0.2 s timed region
-  (one box read 1888 -> 2120 MHz over six consecutive runs whose steps all took 10.9 ms; another 2370 MHz from the
-  first run on), so nothing is derived from it -- `roofline.frac` stays quoted against the 2400 MHz maximum.  The boxes
-  of this pool share hosts (eight GPUs, one power and cooling budget); the same binary reads 10.9 - 11.5 ms per C3
-  step from box to box.  Silent (None) where the files are absent or unreadable."""
-
-  def __init__(self, torch, index):
-    import glob
-    self.files = None
-    self.samples = []
-    self._stop = False
-    self._thread = None
-    cands = []
-    try:
-      pr = torch.cuda.get_device_properties(index)
-      dev = '/sys/bus/pci/devices/%04x:%02x:%02x.0' % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
-      cands = glob.glob(dev + '/hwmon/hwmon*')
-    except Exception:
-      cands = []
-    if not cands:      # the one card whose clock table this user may read
-      mine = [os.path.dirname(f) for f in glob.glob('/sys/class/drm/card*/device/pp_dpm_sclk') if os.access(f, os.R_OK)]
-      if len(mine) == 1:
-        cands = glob.glob(mine[0] + '/hwmon/hwmon*')
-    for h in cands:
-      f, w = os.path.join(h, 'freq1_input'), os.path.join(h, 'power1_input')
-      if os.access(f, os.R_OK):
-        self.files = (f, w if os.access(w, os.R_OK) else None)
-        break
-
-  def _read(self):
-    out = []
-    for f in self.files:
-      try:
-        with open(f) as fh:
-          out.append(int(fh.read()))
-      except Exception:
-        out.append(None)
-    return out
-
-  def _run(self):
-    while not self._stop:
-      self.samples.append(self._read())
-      time.sleep(0.01)
-
-  def start(self):
-    if self.files:
-      import threading
-      self._stop, self.samples = False, []
-      self._thread = threading.Thread(target=self._run, daemon=True)
-      self._thread.start()
-
-  def stop(self):
-    if not self._thread:
-      return None
-    self._stop = True
-    self._thread.join()
-    self._thread = None
-    clk = [v[0] / 1e6 for v in self.samples if v[0]]
-    pw = [v[1] / 1e6 for v in self.samples if v[1]]
-    if not clk:
-      return None
-    out = {'sclk_mhz_mean': sum(clk) / len(clk), 'sclk_mhz_min': min(clk), 'sclk_mhz_max': max(clk), 'samples': len(clk),
-           'peak_mhz': CLOCK_GHZ * 1e3, 'source': 'amdgpu hwmon freq1_input / power1_input, every 10 ms during the timed steps',
-           'note': 'smoothed by the driver over more than the timed region: context only, nothing is derived from it'}
-    if pw:
-      out.update(power_w_mean=sum(pw) / len(pw), power_w_max=max(pw))
-    return out
 
 
 def roofline_block(kernel_name, avg_kernel_s, rays_per_launch, bytes_per_ray, pmc, note=None):
@@ -239,6 +175,13 @@ def roofline_block(kernel_name, avg_kernel_s, rays_per_launch, bytes_per_ray, pm
        'algorithmic_bytes_per_ray': bytes_per_ray, 'algorithmic_bytes_per_launch': alg}
   if note:
     r['note'] = note
+  if pmc and pmc.get('pmc_stale'):
+    # the committed counter pass was taken on other sources than the library that ran: no fraction from it
+    r['pmc_stale'] = True
+    r['note'] = ((note + '; ') if note else '') + ('profiles/pmc_current.json was taken on other sources (sha256 %s...) than this build (%s...): '
+                                                   'run scripts/profile_round.py again; frac not computed'
+                                                   % (str(pmc.get('profiled_sources_sha256'))[:12], str(pmc.get('sources_sha256'))[:12]))
+    return r
   v = pmc.get('valu') if pmc else None
   if pmc:
     r['traffic'] = pmc['hbm_bytes_per_launch'] / avg_kernel_s / 1e9            # GB/s, PMC bytes per launch / live kernel time
@@ -292,8 +235,6 @@ def compact(line, nested=False):
     if isinstance(v, dict):
       rf['valu'] = {k: v[k] for k in ('insts_per_launch', 'cyc_per_inst_calibrated', 'active_lanes_per_inst', 'wait_any_frac',
                                       'lds_bank_conflict_frac', 'kernel_ms_profiled', 'source') if k in v}
-  if isinstance(out.get('clock'), dict):
-    out['clock'] = {k: v for k, v in out['clock'].items() if k not in ('source', 'note')}
   if isinstance(out.get('end_to_end'), dict):
     out['end_to_end'].pop('note', None)
   cfg = out.get('config')
@@ -363,8 +304,6 @@ def run_trace_config(args, cfg_name, cfg, rank, local_rank, world, dist, torch):
   tr.timingEnable(True)
   tr.timingRead()
   barrier()
-  sampler = ClockSampler(torch, local_rank)
-  sampler.start()
   t0 = time.perf_counter()
   for s in range(args.steps):
     step(s)
@@ -373,7 +312,6 @@ def run_trace_config(args, cfg_name, cfg, rank, local_rank, world, dist, torch):
     parallel.reduceResults(tr, dist, torch)
   barrier()
   dt = time.perf_counter() - t0
-  clock = sampler.stop()
   kernel_ms, launches = tr.timingRead()
 
   if dist is not None:
@@ -416,8 +354,6 @@ def run_trace_config(args, cfg_name, cfg, rank, local_rank, world, dist, torch):
                    'parallelism': f'ray-index sharding x{world}, one RCCL reduce'},
         'roofline': roofline_block(kernel_name, avg_kernel_s, n_per, bytes_per_ray, pmc),
     }
-    if clock:
-      out['clock'] = clock
     if world == 1 and record_hits and cfg_name == 'c3' and not args.no_end_to_end:
       out['end_to_end'] = end_to_end(tr, n_per, max(2, args.steps))
     if world == 1 and not args.no_cpu_baseline:
@@ -499,14 +435,11 @@ def run_sweep_config(args, cfg, rank, local_rank, world, dist, torch):
     t.timingEnable(True)
     t.timingRead()
   barrier()
-  sampler = ClockSampler(torch, local_rank)
-  sampler.start()
   t0 = time.perf_counter()
   for _ in range(args.steps):
     res = run()
   barrier()
   dt = time.perf_counter() - t0
-  clock = sampler.stop()
   # trace kernels of this rank, all contexts: a launch traces a GROUP of radii (batch launches); per radius = per 1e7 rays
   kernel_ms, launches = 0.0, 0
   for t in contexts():
@@ -566,8 +499,6 @@ def run_sweep_config(args, cfg, rank, local_rank, world, dist, torch):
                                         'per radius, profiles/r04/r04_batch_launch_kernel.log); per step the host '
                                         'also re-bakes the scenes and searches the detector plane per radius'),
     }
-    if clock:
-      out['clock'] = clock
     if world == 1 and not args.no_cpu_baseline:
       proj = scenes.bakeProject(doc)
       out['cpu_baseline'] = cpu_baseline(proj, None, seconds=8.0)

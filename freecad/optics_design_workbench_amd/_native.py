@@ -42,7 +42,7 @@ SYMBOLS = ['odw_abi_version', 'odw_create', 'odw_destroy', 'odw_last_error', 'od
            'odw_fetch_hits', 'odw_fetch_histogram', 'odw_segment_count', 'odw_fetch_segments', 'odw_reset_segments', 'odw_sample', 'odw_device_histogram',
            'odw_device_counters', 'odw_device_results', 'odw_stream', 'odw_timing_enable', 'odw_timing_read',
            'odw_swap_hit_lists', 'odw_fetch_swapped_hits', 'odw_release_swapped_hits', 'odw_host_alloc', 'odw_host_free', 'odw_load_hits', 'odw_hits_select', 'odw_hits_gather', 'odw_hits_project', 'odw_hits_range', 'odw_hits_bin', 'odw_hits_moments', 'odw_plane_screen',
-           'odw_compile_scene', 'odw_compiled_info', 'odw_compile_check', 'odw_hits_columns',
+           'odw_compile_scene', 'odw_compiled_info', 'odw_compile_check', 'odw_build_check', 'odw_hits_columns',
            'odw_upload_scene_batch', 'odw_trace_batch', 'odw_batch_select', 'odw_batch_rows',
            'odw_plane_screen_batch', 'odw_archive_append', 'odw_archive_select', 'odw_archive_reset', 'odw_batch_hits_select', 'odw_batch_hits_sample', 'odw_batch_hits_project', 'odw_batch_hits_bin',
            'odw_batch_reserve', 'odw_batch_hits_begin', 'odw_batch_hits_sampled', 'odw_batch_hits_measure', 'odw_batch_hits_measured']
@@ -107,6 +107,25 @@ def hipcc():
   raise NativeError('hipcc not found; the HIP library cannot be built')
 
 
+def sources_hash(csrc=None, header=None):
+  """sha256 over the sources a build of the library is made of (csrc/*.hip, csrc/*.h, include/odw_trace.h; names and
+  contents, in name order): what ties a committed counter pass (profiles/pmc_current.json) to the code it was taken on"""
+  import hashlib
+  csrc = CSRC if csrc is None else csrc
+  header = _HEADER if header is None else header
+  h = hashlib.sha256()
+  for name in sorted(_SOURCES):
+    path = os.path.join(csrc, name)
+    h.update(name.encode() + b'\0')
+    with open(path, 'rb') as f:
+      h.update(f.read())
+    h.update(b'\0')
+  h.update(b'odw_trace.h\0')
+  with open(header, 'rb') as f:
+    h.update(f.read())
+  return h.hexdigest()
+
+
 def needs_build():
   if not os.path.exists(LIB_PATH):
     return True
@@ -132,6 +151,29 @@ def build(force=False, verbose=False):
   if verbose:
     print(res.stderr)
   return LIB_PATH
+
+
+ASAN_LIB_PATH = os.path.join(CSRC, 'libodw_trace_asan.so')
+
+
+def build_sanitized(force=False):
+  """The library with AddressSanitizer + UndefinedBehaviorSanitizer on its HOST code (the device code is compiled as
+  usual: GPU sanitizers are not available on this pool), for the entry points that never touch a GPU -- scene validation,
+  boxes, the grid / tree builders (odw_build_check), the plane screens, the header of a compiled scene -- in a child
+  process with the sanitizer runtime preloaded (tests/test_native_sanitized.py).  -> (library path, runtime path)"""
+  runtime = subprocess.run([hipcc(), '--print-file-name=libclang_rt.asan-x86_64.so'], capture_output=True, text=True).stdout.strip()
+  if not os.path.isabs(runtime) or not os.path.exists(runtime):
+    raise NativeError('the sanitizer runtime of hipcc\'s clang was not found')
+  deps = [os.path.join(CSRC, s) for s in _SOURCES] + [_HEADER]
+  if force or not os.path.exists(ASAN_LIB_PATH) or any(os.path.getmtime(d) > os.path.getmtime(ASAN_LIB_PATH) for d in deps):
+    cmd = [hipcc(), '--offload-arch=gfx950', '-O1', '-g', '-std=c++17', '-ffp-contract=on', '-fPIC', '-shared',
+           '-fsanitize=address,undefined', '-fno-gpu-sanitize', '-fno-omit-frame-pointer', '-shared-libasan',
+           '-o', ASAN_LIB_PATH + '.tmp', os.path.join(CSRC, 'odw_capi.hip')]
+    res = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
+    if res.returncode != 0:
+      raise NativeError('hipcc (sanitized build) failed:\n' + res.stdout + res.stderr)
+    os.replace(ASAN_LIB_PATH + '.tmp', ASAN_LIB_PATH)
+  return ASAN_LIB_PATH, runtime
 
 
 _lib = None
@@ -219,6 +261,27 @@ def compile_check(scene, limits, mode='structure', arch=None):
   rc = f(C.byref(d), C.byref(lim), COMPILE_MODES[mode], arch.encode() if arch else None, buf, len(buf), C.byref(size))
   check(None, rc, 'odw_compile_check')
   return buf.value.decode(), int(size.value)
+
+
+STRUCTURES = {0: 'flat', 1: 'grid', 2: 'bvh', 3: 'wide-bvh'}
+
+
+def build_check(scene, limits, library=None):
+  """Host only (no GPU): what the library will trace `scene` with -- 'flat' loop, rectilinear 'grid', binary 'bvh' or the
+  eight-wide tree of the mesh kernel --, after building it in host memory (`odw_build_check`), and the sizes it reports"""
+  d, keep = scene_desc(scene)
+  lim = LimitsDesc(float(limits.max_ray_length), int(limits.max_intersections), float(limits.dist_tol),
+                   float(limits.power_tol))
+  structure = C.c_int32(-1)
+  sizes = (C.c_uint64 * 6)()
+  f = (library or lib()).odw_build_check
+  f.argtypes = [C.POINTER(SceneDesc), C.POINTER(LimitsDesc), C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
+  rc = f(C.byref(d), C.byref(lim), C.byref(structure), sizes)
+  if rc != 0:
+    msg = (library or lib()).odw_last_error(None)
+    raise NativeError(f'odw_build_check: {ERRORS.get(rc, rc)}: {msg.decode() if msg else ""}')
+  names = ('primitives', 'nodes', 'grid_cells', 'grid_items', 'grid_lds_bytes', 'dead_primitives')
+  return dict(structure=STRUCTURES[int(structure.value)], **{k: int(v) for k, v in zip(names, sizes)})
 
 
 def source_desc(src):

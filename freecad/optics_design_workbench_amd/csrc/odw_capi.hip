@@ -59,6 +59,7 @@ std::string g_error;
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
+  bool host = false;       // allocated with malloc (a context without a device: odw_build_check)
 };
 
 }  // namespace
@@ -68,7 +69,8 @@ struct odw_ctx {
   hipStream_t stream = nullptr;
   void* up_pin = nullptr;                  // page-locked arena small uploads are staged in (upload())
   size_t up_off = 0;
-  bool up_unstaged = false;                // an upload since the last wait was copied from the caller's memory
+  bool up_unstaged = false;
+  bool host_only = false;                  // no device behind this context: buffers are host memory (odw_build_check)                // an upload since the last wait was copied from the caller's memory
   int n_cu = 256;
   std::string err;
 
@@ -212,6 +214,15 @@ int fail(odw_ctx* ctx, int code, const std::string& msg) {
 int ensure(odw_ctx* ctx, DevBuf& b, size_t bytes) {
   if (bytes == 0) bytes = 16;
   if (b.bytes >= bytes && b.p) return ODW_OK;
+  if (ctx && ctx->host_only) {
+    // a context without a device (odw_build_check): the tables the builders "upload" live in host memory -- the same code
+    // paths, under a CPU sanitizer
+    if (b.p) free(b.p);
+    b.p = malloc(bytes);
+    b.bytes = b.p ? bytes : 0;
+    b.host = true;
+    return b.p ? ODW_OK : fail(ctx, ODW_ERR_DEVICE, "out of host memory");
+  }
   if (b.p) HIPCHK(ctx, hipFree(b.p));
   b.p = nullptr;
   b.bytes = 0;
@@ -230,6 +241,7 @@ int upload(odw_ctx* ctx, DevBuf& b, const void* src, size_t bytes) {
   int rc = ensure(ctx, b, bytes);
   if (rc) return rc;
   if (!bytes) return ODW_OK;
+  if (ctx->host_only) { std::memcpy(b.p, src, bytes); return ODW_OK; }
   if (bytes <= kUploadStaged) {
     if (!ctx->up_pin) {
       if (hipHostMalloc(&ctx->up_pin, kUploadArena, hipHostMallocDefault) != hipSuccess) { ctx->up_pin = nullptr; (void)hipGetLastError(); }
@@ -262,7 +274,9 @@ int upload_done(odw_ctx* ctx) {
 }
 
 void release(DevBuf& b) {
-  if (b.p) (void)hipFree(b.p);
+  if (b.p && b.host) free(b.p);
+  else if (b.p) (void)hipFree(b.p);
+  b.host = false;
   b.p = nullptr;
   b.bytes = 0;
 }
@@ -1788,6 +1802,52 @@ int odw_compile_check(const odw_scene_desc* scene, const odw_limits* limits, int
     return fail(nullptr, ODW_ERR_DEVICE, err);
   if (code_bytes) *code_bytes = code.size();
   return ODW_OK;
+}
+
+// The host half of odw_upload_scene + the first launch's preparations -- validation, host tables, bounding boxes, the
+// choice among the flat loop, the rectilinear grid, the binary tree and the eight-wide tree with its leaf records, and
+// their construction -- on a context WITHOUT a device: every table the builders would upload goes to host memory instead.
+// For tests of these 1 500 lines under a CPU sanitizer (tests/test_native_sanitized.py) and for callers that want to know
+// what a scene will be traced with before a GPU is there.  structure: 0 flat loop, 1 grid, 2 binary tree, 3 eight-wide
+// tree (facets); sizes: [primitives, tree nodes, grid cells, grid items, bytes of dynamic LDS of a grid block, dead primitives].
+int odw_build_check(const odw_scene_desc* scene, const odw_limits* limits, int32_t* structure, uint64_t* sizes) {
+  if (!scene || !limits) return fail(nullptr, ODW_ERR_INVALID, "odw_build_check: null argument");
+  if (!(limits->dist_tol > 0) || limits->max_intersections < 0 || !(limits->max_ray_length > 0))
+    return fail(nullptr, ODW_ERR_INVALID, "odw_build_check: limits out of range");
+  odw_ctx tmp;
+  std::memset(&tmp.P, 0, sizeof tmp.P);
+  tmp.host_only = true;
+  if (const char* e = getenv("ODW_BVH_THRESHOLD")) tmp.flat_limit = atoi(e);
+  int rc = scene_host_tables(&tmp, scene);
+  if (!rc) {
+    tmp.P.lim.max_ray_length = limits->max_ray_length;
+    tmp.P.lim.max_intersections = limits->max_intersections;
+    tmp.P.lim.dist_tol = limits->dist_tol;
+    tmp.P.lim.power_tol = limits->power_tol;
+    tmp.have_limits = tmp.have_scene = true;
+    if (scene->tri_normals && scene->n_prims > 0)
+      rc = upload(&tmp, tmp.tri_nrm, scene->tri_normals, (size_t)scene->n_prims * 9 * sizeof(double));
+    if (!rc) rc = build_bvh(&tmp);
+  }
+  if (!rc) {
+    if (structure) *structure = tmp.P.grid.nx > 0 ? 1 : (tmp.P.scene.n_nodes ? (tmp.P.scene.bvh_leaf ? 3 : 2) : 0);
+    if (sizes) {
+      uint64_t dead = 0;
+      for (char d : tmp.h_dead) dead += d ? 1 : 0;
+      sizes[0] = (uint64_t)tmp.P.scene.n_prims;
+      sizes[1] = (uint64_t)tmp.P.scene.n_nodes;
+      sizes[2] = (uint64_t)tmp.P.grid.nx * (uint64_t)tmp.P.grid.ny * (uint64_t)tmp.P.grid.nz;
+      sizes[3] = (uint64_t)tmp.P.grid.n_items;
+      sizes[4] = (uint64_t)tmp.P.grid.lds_bytes;
+      sizes[5] = dead;
+    }
+  } else {
+    g_error = tmp.err;
+  }
+  for (DevBuf* b : {&tmp.prim_f64, &tmp.prim_hdr, &tmp.prim_i32, &tmp.cond_i32, &tmp.group_f64, &tmp.group_i32, &tmp.group_gdir, &tmp.seq_mask,
+                    &tmp.bvh_nodes, &tmp.bvh_prims, &tmp.bvh_leaf, &tmp.bvh_wide, &tmp.tri_nrm, &tmp.grid_bounds, &tmp.grid_cells, &tmp.grid_items})
+    release(*b);
+  return rc;
 }
 
 int odw_upload_surface_samplers(odw_ctx* ctx, const odw_surface_sampler_desc* samplers, int32_t n) {

@@ -517,6 +517,15 @@ int odw_compiled_info(odw_ctx* ctx, int32_t* bound, double* compile_seconds, int
  * outside the flat kernel's domain.                                          */
 int odw_compile_check(const odw_scene_desc* scene, const odw_limits* limits, int32_t mode, const char* arch,
                       char* header_out, uint64_t header_capacity, uint64_t* code_bytes);
+/* v10: what odw_upload_scene + the first launch prepare -- validation, host
+ * tables, boxes, the choice among flat loop / grid / binary tree / eight-wide
+ * tree and their construction -- WITHOUT a device (the tables go to host memory).
+ * Replaces nothing of the reference (its acceleration structure is OCC's);
+ * exists so that these builders run under a CPU sanitizer and so that a caller
+ * can ask what a scene will be traced with.  structure: 0 flat, 1 grid, 2
+ * binary tree, 3 eight-wide tree; sizes [6]: primitives, tree nodes, grid
+ * cells, grid items, LDS bytes of a grid block, dead primitives.            */
+int odw_build_check(const odw_scene_desc* scene, const odw_limits* limits, int32_t* structure, uint64_t* sizes);
 
 /* ---- batches: many scenes of ONE structure in one launch (v9) -----------
  * Replaces the loop of a parameter sweep (examples/1-getting-started/

@@ -148,7 +148,14 @@ summary = dict(command='rocprofv3 --pmc <COUNTERS> --kernel-trace -- ' + ' '.joi
                write_bytes=write, hbm_bytes_per_launch=2 * fetch_raw + write, kernel_ms_rocprof=kernel_ms)
 json.dump(summary, open(os.path.join(out, f'{tag}_pmc.json'), 'w'), indent=1)
 ms = kernel_ms or line.get('roofline', {}).get('avg_kernel_ms')
-ROUND = os.environ.get('ODW_PROFILE_ROUND', 'r04')
+ROUND = os.environ.get('ODW_PROFILE_ROUND', 'r05')
+
+
+def _native_sources_hash():
+  sys.path.insert(0, ROOT)
+  from freecad.optics_design_workbench_amd import _native
+  return _native.sources_hash()
+
 valu = None
 if 'SQ_INSTS_VALU' in avg and ms:
   valu = dict(insts_per_launch=avg['SQ_INSTS_VALU'], salu_insts_per_launch=avg.get('SQ_INSTS_SALU'),
@@ -207,6 +214,8 @@ entry = dict(kernel=KERNEL_LIKE.strip('%'), rays_per_launch=n_per, fetch_bytes_c
              hbm_bytes_per_launch=2 * fetch_raw + write,
              correction='FETCH_SIZE x2 (gfx950 under-count of wide reads, MI355X_MICROARCH.md HBM section; upper bound for '
                         'this access mix), WRITE_SIZE as is; separate --pmc passes',
-             source=f'profiles/{ROUND}/{tag}_pmc.json', valu=valu)
+             source=f'profiles/{ROUND}/{tag}_pmc.json', valu=valu,
+             # the code these counters were taken on: bench.py attaches them only to a build of the same sources
+             sources_sha256=_native_sources_hash())
 json.dump({(args.config if not args.script else tag): entry}, open(os.path.join(out, f'{tag}_pmc_current.json'), 'w'), indent=1)
 print(json.dumps(entry)[:600])
