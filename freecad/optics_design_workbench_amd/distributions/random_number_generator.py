@@ -2,12 +2,15 @@
 
 Mirror of the reference's `VectorRandomVariable` / `ScalarRandomVariable`
 interface (distributions/random_number_generator.py:54-769) restricted to what
-the device needs: the *numeric mode* tables.  The reference first tries a
-sympy analytic inverse CDF for 2 s and falls back to numeric mode
-(random_number_generator.py:72-119); every BASELINE source stores
-`RandomNumberGeneratorMode = numeric`.  Here numeric mode is the only mode:
-for the few densities the reference can invert analytically the samples differ
-from its by the table's discretisation error only (resolution 1e5 x 1e2).
+the device needs.  The reference first tries a sympy analytic inverse CDF for
+2 s and falls back to numeric mode (random_number_generator.py:72-119); every
+BASELINE source stores `RandomNumberGeneratorMode = numeric` (sympy does not
+invert their densities).  Both modes are here (round 5): `compile()` makes the
+same attempt (distributions/analytic.py), `mode()` reports its outcome like the
+reference's, host draws use the closed form, and the device's table is then
+built FROM the closed form -- cdf values exact at the numeric mode's edges --
+instead of from mid-point sums.  `compile(disableAnalytical=True)` is numeric
+mode as before, bit for bit.
 
 Table definition (random_number_generator.py:337-369, 372-464), reproduced
 bit for bit (tests/test_distributions.py against tests/golden/sampler_*.npz):
@@ -61,9 +64,21 @@ class SamplerTables:
     return v0, v1
 
 
+def _as_cdf(values):
+  """a closed-form cdf evaluated on the edges, as a table column: finite, from 0 to 1, not decreasing"""
+  c = np.asarray(values, dtype=np.float64)
+  if not np.all(np.isfinite(c)) or abs(c[0]) > 1e-9 or abs(c[-1] - 1.0) > 1e-9:
+    raise ValueError('closed-form cdf does not run from 0 to 1 over the domain')
+  c = np.clip(c, 0.0, 1.0)
+  c[0], c[-1] = 0.0, 1.0
+  if np.any(np.diff(c) < -1e-12):
+    raise ValueError('closed-form cdf decreases')
+  return np.maximum.accumulate(c)
+
+
 class VectorRandomVariable:
   '''
-  Vector valued random variable (two variables), numeric mode.
+  Vector valued random variable (two variables).
   '''
 
   def __init__(self, probabilityDensity, variableDomains={}, numericalResolutions={},
@@ -75,6 +90,8 @@ class VectorRandomVariable:
     self._constantsDict = {}
     self._mode = 'not yet compiled'
     self._tables = None
+    self._inverses = None
+    self._analytic_off = False
 
   def mode(self):
     return self._mode
@@ -116,15 +133,26 @@ class VectorRandomVariable:
       raise ValueError('cannot use numeric mode for expression containing DiracDelta')
     return expr, syms, order, used
 
-  def compile(self, **kwargs):
+  def compile(self, timeout=None, disableAnalytical=False, **kwargs):
+    """timeout: give up on a closed-form inverse after so many seconds and use the numeric tables; disableAnalytical: do
+    not try (random_number_generator.py:72-119).  timeout None: 2 s like the reference (ODW_ANALYTIC_TIMEOUT overrides).  Other keywords: constants of the density expression."""
     expr, syms, order, used = self._prepare(**kwargs)
-    if self._tables is not None and used == self._constantsDict:
+    if self._tables is not None and used == self._constantsDict and bool(disableAnalytical) == self._analytic_off:
       return
+    self._analytic_off = bool(disableAnalytical)
     if len(order) != 2:
       raise ValueError(f'expected two variables, found {order}')
     e0 = np.linspace(*self._variableDomains[order[0]], self._resolution(order[0], 2))
     e1 = np.linspace(*self._variableDomains[order[1]], self._resolution(order[1], 2))
     m0, m1 = (e0[1:] + e0[:-1]) / 2, (e1[1:] + e1[:-1]) / 2
+    self._inverses = None
+    if not disableAnalytical:
+      from . import analytic
+      try:
+        self._inverses = analytic.inverses(expr, syms, {n: self._variableDomains[n] for n in order},
+                                           timeout=analytic.default_timeout() if timeout is None else timeout)
+      except analytic.AnalyticFailure:
+        self._inverses = None
     lam = sy.lambdify(syms, expr, modules=['numpy', 'scipy'])
     depends_on_last = syms[1] in expr.free_symbols
 
@@ -159,10 +187,23 @@ class VectorRandomVariable:
     # weight is compared with (freecad_elements/optical_group.py)
     self._mass = float(cdf1[-1]) * float(e0[1] - e0[0]) * float(e1[1] - e1[0])
     cdf1 = cdf1 / cdf1[-1]
+    self._mode = 'numeric'
+    if self._inverses is not None:
+      # analytic mode: the same knots, their cdf values from the closed form (exact where the mid-point sums are 2nd order)
+      inv0, inv1 = self._inverses
+      try:
+        a1 = _as_cdf(inv1.cdf_at(e1))
+        if depends_on_last:
+          a0 = np.array([_as_cdf(inv0.cdf_at(e0, np.full_like(e0, v))) for v in m1])
+        else:
+          a0 = _as_cdf(inv0.cdf_at(e0, np.full_like(e0, m1[0])))[None, :]
+        cdf0, cdf1 = a0, a1
+        self._mode = 'analytic'
+      except ValueError:
+        self._inverses = None                    # (a closed form that does not evaluate to a cdf on the grid: numeric)
     self._tables = SamplerTables(e0, cdf0, e1, cdf1)
     self._order = order
     self._constantsDict = used
-    self._mode = 'numeric'
 
   def tables(self):
     if self._tables is None:
@@ -186,7 +227,11 @@ class VectorRandomVariable:
     np.random.random_sample(n)
     u_first = np.random.random_sample(n)
     np.random.random_sample(n)
-    v0, v1 = self._tables.draw(u_last, u_first)
+    if self._inverses is not None:
+      v1 = self._inverses[1](u_last)             # (the closed form itself, as the reference's analytic mode draws)
+      v0 = self._inverses[0](u_first, v1)
+    else:
+      v0, v1 = self._tables.draw(u_last, u_first)
     res = {self._order[0]: v0, self._order[1]: v1}
     names = self._variableOrder or self._order
     out = np.array([res[k] for k in names])
@@ -268,8 +313,10 @@ class ScalarRandomVariable:
     self._variable = variable
     self._resolution = numericalResolution
     self._expr = None
+    self._inverse = None
+    self._mode = 'not yet compiled'
 
-  def compile(self, **constants):
+  def compile(self, timeout=None, disableAnalytical=False, **constants):
     expr = sy.sympify(self._probabilityDensity)
     for name, val in constants.items():
       if name in [str(s) for s in expr.free_symbols]:
@@ -283,6 +330,16 @@ class ScalarRandomVariable:
     kw = dict(nonnegative=True) if l1 >= 0 else dict(nonpositive=True) if l2 <= 0 else {}
     self._sym = sy.Symbol(var, real=True, **kw)
     self._expr = expr.subs(sy.Symbol(var), self._sym)
+    self._inverse = None
+    self._mode = 'numeric'
+    if not disableAnalytical and np.isfinite(l1) and np.isfinite(l2):
+      from . import analytic
+      try:
+        self._inverse = analytic.inverses(self._expr, [self._sym], {var: (l1, l2)},
+                                          timeout=analytic.default_timeout() if timeout is None else timeout)[0]
+        self._mode = 'analytic'
+      except analytic.AnalyticFailure:
+        self._inverse = None
 
   def tables(self, **constants):
     """numeric-mode inverse-CDF table of the single variable
@@ -295,6 +352,11 @@ class ScalarRandomVariable:
       raise ValueError(f'numerical solution requires finite limits, but found limits [{l1}, {l2}]')
     res = self._resolution if self._resolution else 5 + int(1e6)
     edges = np.linspace(l1, l2, _odd(res))
+    if self._inverse is not None:
+      try:
+        return edges, _as_cdf(self._inverse.cdf_at(edges))     # analytic mode: the closed-form cdf at the same knots
+      except ValueError:
+        self._inverse, self._mode = None, 'numeric'
     mid = (edges[1:] + edges[:-1]) / 2
     p = sy.lambdify(self._sym, self._expr, modules=['numpy', 'scipy'])(mid)
     if not hasattr(p, 'shape') or np.shape(p) != mid.shape:
@@ -305,13 +367,20 @@ class ScalarRandomVariable:
     return edges, cdf / cdf[-1]
 
   def mode(self):
-    return 'numeric'
+    return self._mode
 
   def draw(self, N=None, **constants):
     """host draw with numpy's global RNG in the reference's order
     (random_number_generator.py:492-528): u, one unused block"""
-    edges, cdf = self.tables(**constants)
+    if self._expr is None or constants:
+      self.compile(**constants)
     n = 1 if N is None else max(1, int(round(N)))
+    if self._inverse is not None:
+      u = np.random.random_sample(n)
+      np.random.random_sample(n)
+      v = self._inverse(u)
+      return v if N is not None else v[0]
+    edges, cdf = self.tables()
     u = np.random.random_sample(n)
     np.random.random_sample(n)
     v = np.interp(u, cdf, edges)
@@ -319,7 +388,9 @@ class ScalarRandomVariable:
 
   def findGrid(self, N, constants=None):
     if self._expr is None or constants:
-      self.compile(**(constants or {}))
+      # (the grid follows the density itself, not its inverse cdf: no analytic attempt -- the reference makes one here
+      #  too, random_number_generator.py:691-692, and waits up to its timeout for every fan without using the outcome)
+      self.compile(disableAnalytical=True, **(constants or {}))
     l1, l2 = self._domain
     if not np.isfinite(l1) or not np.isfinite(l2):
       raise ValueError('variable domains must be finite for grid generation')

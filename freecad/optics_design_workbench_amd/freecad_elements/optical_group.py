@@ -269,7 +269,9 @@ def _bakeOne(obj, group_index, kind, density, theta_dom, phi_dom, optical_type, 
       constants['theta_refl'] = c
     cont_mass = 0.0
     if vrv is not None and valid:
-      vrv.compile(**{n: v for n, v in constants.items() if n in {str(x) for x in cont_expr.free_symbols}})
+      # (families of tables, one member per value of the per-hit constant: numeric mode -- an analytic attempt per member
+      #  would cost up to its timeout hundreds of times; the reference compiles per hit and may go either way)
+      vrv.compile(disableAnalytical=True, **{n: v for n, v in constants.items() if n in {str(x) for x in cont_expr.free_symbols}})
       t = vrv.tables()
       phi_cdf.append(t.phi_cdf.copy())
       t_cdf.append(t.t_cdf.copy())

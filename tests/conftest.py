@@ -11,6 +11,11 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 SCENES = os.path.join(GOLDEN, 'scenes')
 
 
+# the sampler's analytic attempt waits up to 2 s for sympy (like the reference's); the suites compile dozens of densities it
+# never inverts -- the same outcome after 0.4 s (tests of the analytic mode itself pass their own timeouts)
+os.environ.setdefault('ODW_ANALYTIC_TIMEOUT', '0.4')
+
+
 def pytest_configure(config):
   config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 

@@ -1,0 +1,197 @@
+"""Primitive kinds and placement constructs the reference's stored ray polylines (tests/test_reference_ray_segments.py:
+boxes, spheres, cylinders, a STEP doublet, nested Parts) do NOT exercise, held to closed forms directly -- on the oracle
+(`not gpu`) and on the device (`-m gpu`) through one test body (`backend` fixture), every crossing within 1e-9 mm:
+torus, cone (frustum and pointed), a paraboloid, each also displaced and rotated; and the 1 500 sphere centres of
+benchmark/hugeArray (a Draft link array of a linked sphere) against the `PlacementList` payloads of the FCStd file,
+read here independently of the loader."""
+import struct
+import zipfile
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, project
+from freecad.optics_design_workbench_amd.freecad_elements import make
+from freecad.optics_design_workbench_amd.scene import Document, bake
+from freecad.optics_design_workbench_amd.scene.placement import Placement
+
+import os
+
+TOL = 1e-9
+
+
+def _scene(elems):
+  """one Vacuum group (records where a ray enters AND where it leaves, changes nothing) around the solids"""
+  doc = Document()
+  make.makeOpticalGroup(doc, 'Vacuum', elems(doc))
+  make.makeSimulationSettings(doc, DistanceTolerance='1e-6')
+  src = make.makePointSource(doc)
+  return bake.bakeScene(doc, src), bake.bakeLimits(doc, src)
+
+
+def _crossings(backend, sc, lim, origins, dirs):
+  """per ray the recorded points in the order they were met"""
+  origins, dirs = np.asarray(origins, float), np.asarray(dirs, float)
+  dirs = dirs / np.linalg.norm(dirs, axis=1)[:, None]
+  rows = backend.traceRays(sc, lim, origins, dirs)
+  ray = (rows['tag'] & np.uint64(0xFFFFFFFFFFFF)).astype(np.int64)
+  out = []
+  for k in range(len(origins)):
+    p = rows['point'][ray == k]
+    t = (p - origins[k]) @ dirs[k]
+    out.append(p[np.argsort(t)])
+  return out
+
+
+def _quat(axis, deg):
+  a = np.asarray(axis, float)
+  a = a / np.linalg.norm(a)
+  h = np.radians(deg) / 2
+  return tuple(np.r_[a * np.sin(h), np.cos(h)])
+
+
+PLACEMENTS = [dict(), dict(base=(3.0, -7.0, 11.0), quat=_quat((1, 2, -1), 37.0))]
+
+
+@pytest.mark.parametrize('pl', PLACEMENTS, ids=['at-origin', 'moved'])
+def test_torus_crossings(backend, pl):
+  """torus R = 10, r = 2 about z: a line in the plane z = h at distance b from the axis crosses where
+  rho = R +- sqrt(r^2 - h^2); a line parallel to the axis at rho crosses at z = +- sqrt(r^2 - (rho - R)^2)"""
+  R, r = 10.0, 2.0
+  sc, lim = _scene(lambda d: [make.makeTorus(d, 'T', R, r, **pl)])
+  P = Placement(**pl) if pl else Placement()
+  O, D, want = [], [], []
+  for h, b in ((0.0, 0.0), (1.2, 3.0), (-0.7, 7.5), (1.9, 9.0)):
+    w = np.sqrt(r * r - h * h)
+    xs = []
+    for rho in (R + w, R - w):
+      if rho > abs(b):
+        xs += [-np.sqrt(rho * rho - b * b), np.sqrt(rho * rho - b * b)]
+    O.append([-40.0, b, h]); D.append([1.0, 0.0, 0.0])
+    want.append(np.array([[x, b, h] for x in sorted(xs)]))
+  for rho, phi in ((10.0, 0.3), (11.5, 2.0), (8.4, -1.1)):
+    z = np.sqrt(r * r - (rho - R)**2)
+    c, s = np.cos(phi), np.sin(phi)
+    O.append([rho * c, rho * s, 30.0]); D.append([0.0, 0.0, -1.0])
+    want.append(np.array([[rho * c, rho * s, z], [rho * c, rho * s, -z]]))
+  # through the hole along the axis: nothing
+  O.append([0.5, 0.5, -30.0]); D.append([0.0, 0.0, 1.0]); want.append(np.zeros((0, 3)))
+  got = _crossings(backend, sc, lim, [P * np.array(o) for o in O], [P.Rotation @ np.array(d) for d in D])
+  for k, (g, w) in enumerate(zip(got, want)):
+    assert len(g) == len(w), (k, g, w)
+    if len(w):
+      assert np.abs(g - np.array([P * p for p in w])).max() < TOL, (k, g, w)
+
+
+@pytest.mark.parametrize('pl', PLACEMENTS, ids=['at-origin', 'moved'])
+@pytest.mark.parametrize('radii', [(1.0, 4.0), (3.0, 0.0)], ids=['frustum', 'pointed'])
+def test_cone_crossings(backend, pl, radii):
+  """cone about z, radius R1 at z = 0 and R2 at z = H: a line across the axis at height z meets the side at
+  rho(z) = R1 + (R2 - R1) z / H; a line parallel to the axis at rho meets a cap where the cap is wider than rho and
+  the side at z(rho) = H (rho - R1) / (R2 - R1) otherwise; a slanted line through the axis: its closed-form roots"""
+  R1, R2 = radii
+  H = 6.0
+  sc, lim = _scene(lambda d: [make.makeCone(d, 'C', R1, R2, H, **pl)])
+  P = Placement(**pl) if pl else Placement()
+  rho_at = lambda z: R1 + (R2 - R1) * z / H
+  O, D, want = [], [], []
+  for z in (0.5, 3.0, 5.5):
+    a = rho_at(z)
+    O.append([-30.0, 0.0, z]); D.append([1.0, 0.0, 0.0])
+    want.append(np.array([[-a, 0.0, z], [a, 0.0, z]]))
+  for rho in (0.4, 2.0, 3.5):
+    if not 0 <= rho < max(R1, R2):
+      continue
+    lo = 0.0 if rho < R1 else H * (rho - R1) / (R2 - R1)       # bottom cap, or the side below
+    hi = H if rho < R2 else H * (rho - R1) / (R2 - R1)         # top cap, or the side above
+    if rho >= R1 and rho >= R2:
+      continue
+    O.append([rho, 0.0, -20.0]); D.append([0.0, 0.0, 1.0])
+    want.append(np.array([[rho, 0.0, min(lo, hi)], [rho, 0.0, max(lo, hi)]]))
+  # a slanted line in the plane y = 0 through (x0, 0, 0) with slope dz/dx = m: |x| = rho(z), z = m (x - x0)
+  x0, m = -9.0, 0.35
+  k = (R2 - R1) / H
+  roots = []
+  for sgn in (-1.0, 1.0):                     # sgn x = R1 + k m (x - x0)
+    den = sgn - k * m
+    if abs(den) > 1e-12:
+      x = (R1 - k * m * x0) / den
+      z = m * (x - x0)
+      if sgn * x >= 0 and 0 <= z <= H:
+        roots.append([x, 0.0, z])
+  if len(roots) == 2:
+    O.append([x0, 0.0, 0.0]); D.append([1.0, 0.0, m]); want.append(np.array(sorted(roots)))
+  got = _crossings(backend, sc, lim, [P * np.array(o) for o in O], [P.Rotation @ np.array(d) for d in D])
+  for k_, (g, w) in enumerate(zip(got, want)):
+    assert len(g) == len(w), (k_, g, w)
+    assert np.abs(g - np.array([P * p for p in w])).max() < TOL, (k_, g, w)
+
+
+@pytest.mark.parametrize('pl', PLACEMENTS, ids=['at-origin', 'moved'])
+def test_paraboloid_crossings(backend, pl):
+  """solid paraboloid z = rho^2 / (4 f) up to z = H: a line along the axis direction at rho enters at z = rho^2 / (4 f)
+  and leaves through the cap; a line across at height z crosses at rho = 2 sqrt(f z)"""
+  f, H = 1.5, 6.0
+  sc, lim = _scene(lambda d: [make.makeParaboloid(d, 'P', f, H, **pl)])
+  P = Placement(**pl) if pl else Placement()
+  O, D, want = [], [], []
+  for rho in (0.0, 1.0, 4.0, 5.5):
+    O.append([rho, 0.0, -25.0]); D.append([0.0, 0.0, 1.0])
+    want.append(np.array([[rho, 0.0, rho * rho / (4 * f)], [rho, 0.0, H]]))
+  for z in (0.4, 2.0, 5.0):
+    a = 2 * np.sqrt(f * z)
+    O.append([0.0, -30.0, z]); D.append([0.0, 1.0, 0.0])
+    want.append(np.array([[0.0, -a, z], [0.0, a, z]]))
+  got = _crossings(backend, sc, lim, [P * np.array(o) for o in O], [P.Rotation @ np.array(d) for d in D])
+  for k, (g, w) in enumerate(zip(got, want)):
+    assert len(g) == len(w), (k, g, w)
+    assert np.abs(g - np.array([P * p for p in w])).max() < TOL, (k, g, w)
+
+
+def test_huge_array_lattice_equals_the_stored_placement_lists():
+  """benchmark/hugeArray: three Draft link arrays of a linked unit sphere, 500 elements each.  The file stores every
+  element's placement (`PlacementList*` members of the zip: a count, then base x y z + quaternion x y z w as doubles);
+  the baked scene's 1 500 sphere primitives sit exactly there -- element by element, array by array -- under the
+  optical group's, the array's and the sphere's own placements (pure translations in this file), radius 1"""
+  path = os.path.join(GOLDEN, 'scenes', 'hugeArray.FCStd')
+  import re
+  stored = {}
+  with zipfile.ZipFile(path) as z:
+    xml = z.read('Document.xml').decode()
+    data_part = xml[xml.index('<ObjectData'):]
+    for m in re.finditer(r'<Object name="(Array\d*)"(.*?)</Object>', data_part, re.S):
+      member = re.search(r'<PlacementList file="([^"]+)"', m.group(2)).group(1)
+      data = z.read(member)
+      (count,) = struct.unpack_from('<I', data, 0)
+      vals = np.frombuffer(data, dtype='<f8', count=count * 7, offset=4).reshape(count, 7)
+      assert count == 500 and np.array_equal(vals[:, 3:], np.tile([0.0, 0.0, 0.0, 1.0], (500, 1)))    # pure translations
+      stored[m.group(1)] = vals[:, :3].copy()
+  assert sorted(stored) == ['Array', 'Array001', 'Array002']
+  pr = project('hugeArray')
+  sc = pr.scene
+  assert sc.n_prims == 1500 and np.all(np.asarray(sc.prim_type) == 1) and np.allclose(np.asarray(sc.prim_params)[:, 0], 1.0, rtol=0, atol=0)
+  centres = np.array([list(pl.Base) for pl in sc.prim_to_world])
+  groups = np.asarray(sc.prim_group)
+  # which array belongs to which optical group, and each array's / sphere's own placement: from the document itself
+  from freecad.optics_design_workbench_amd.scene import open_fcstd
+  doc = open_fcstd(path)
+  seen = 0
+  for gname in ('OpticalMirrorGroup', 'OpticalLensGroup', 'OpticalAbsorberGroup'):
+    grp = doc.getObject(gname)
+    arrays = [o for o in grp._props.get('ElementList') or []]
+    assert len(arrays) == 1
+    arr = arrays[0]
+    own = arr.Placement
+    base = arr.Base.Placement if bool(arr._props.get('LinkTransform', False)) else Placement()
+    want = np.array([grp.Placement * (own * (Placement(base=tuple(v)) * (base * np.zeros(3)))) for v in stored[arr.Name]])
+    got = centres[groups == sc.group_index(gname)]
+    assert got.shape == want.shape == (500, 3)
+    assert np.array_equal(got, want), (gname, np.abs(got - want).max())
+    seen += len(got)
+  assert seen == 1500
+  # the lattice itself: 10 x 10 x 5 per array at pitch 5 mm
+  for g in range(3):
+    c = centres[groups == g]
+    for a, n in ((0, 10), (1, 10), (2, 5)):
+      u = np.unique(c[:, a])
+      assert len(u) == n and np.allclose(np.diff(u), 5.0, rtol=0, atol=1e-12)

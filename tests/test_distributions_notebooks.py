@@ -19,10 +19,13 @@ from freecad.optics_design_workbench_amd.distributions import (calcDiffDensity, 
   (lambda x: 0.5 * x + np.cos(x), 'x/2+cos(x)', (0, 4 * np.pi)),
   (lambda x: np.exp(-(x - 3)**2), 'exp(-(x-3)**2)', (1, 5)),
 ])
-def test_scalar_histograms(expect, expr, domain):
+@pytest.mark.parametrize('disableAnalytical', [True, False])
+def test_scalar_histograms(expect, expr, domain, disableAnalytical):
+  # (cell 15 runs every density with and without the analytic mode)
   np.random.seed(1)
   x = distributions.ScalarRandomVariable(expr, variableDomain=domain)
-  assert x.mode() == 'numeric'
+  x.compile(disableAnalytical=disableAnalytical, timeout=20)
+  assert x.mode() == ('numeric' if disableAnalytical or expr == 'x/2+cos(x)' else 'analytic')
   H, bins = np.histogram(x.draw(1e6), bins=50)
   bins = (bins[1:] + bins[:-1]) / 2
   want = expect(bins)
@@ -37,11 +40,13 @@ def test_scalar_histograms(expect, expr, domain):
   (lambda x, y: np.exp(-x**2 / (1 + y / 3)**2), 'exp(-theta**2/(1+phi/3)**2)', ['theta', 'phi'],
    dict(theta=(0, np.pi), phi=(0, 2 * np.pi))),
 ])
-def test_vector_histograms(expect, expr, order, domain):
+@pytest.mark.parametrize('disableAnalytical', [True, False])
+def test_vector_histograms(expect, expr, order, domain, disableAnalytical):
+  # (cell 19 likewise)
   np.random.seed(2)
   x = distributions.VectorRandomVariable(expr, variableDomains=domain, variableOrder=order)
-  x.compile()
-  assert x.mode() == 'numeric'
+  x.compile(disableAnalytical=disableAnalytical)
+  assert x.mode() in (('numeric',) if disableAnalytical else ('numeric', 'analytic'))
   H, bx, by = np.histogram2d(*x.draw(1e6), bins=(50, 55))
   X, Y = (bx[1:] + bx[:-1]) / 2, (by[1:] + by[:-1]) / 2
   want = expect(*np.meshgrid(X, Y))
