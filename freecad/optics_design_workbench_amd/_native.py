@@ -41,7 +41,7 @@ SYMBOLS = ['odw_abi_version', 'odw_create', 'odw_destroy', 'odw_last_error', 'od
            'odw_trace_rays', 'odw_sync', 'odw_reset_results', 'odw_reset_hits', 'odw_fetch_counters', 'odw_hit_count',
            'odw_fetch_hits', 'odw_fetch_histogram', 'odw_segment_count', 'odw_fetch_segments', 'odw_reset_segments', 'odw_sample', 'odw_device_histogram',
            'odw_device_counters', 'odw_device_results', 'odw_stream', 'odw_timing_enable', 'odw_timing_read',
-           'odw_swap_hit_lists', 'odw_fetch_swapped_hits', 'odw_release_swapped_hits', 'odw_host_alloc', 'odw_host_free', 'odw_load_hits', 'odw_hits_select', 'odw_hits_gather', 'odw_hits_project', 'odw_hits_range', 'odw_hits_bin', 'odw_hits_moments', 'odw_plane_screen',
+           'odw_swap_hit_lists', 'odw_fetch_swapped_hits', 'odw_release_swapped_hits', 'odw_mem_info', 'odw_host_alloc', 'odw_host_free', 'odw_load_hits', 'odw_hits_select', 'odw_hits_gather', 'odw_hits_project', 'odw_hits_range', 'odw_hits_bin', 'odw_hits_moments', 'odw_plane_screen',
            'odw_compile_scene', 'odw_compiled_info', 'odw_compile_check', 'odw_build_check', 'odw_hits_columns',
            'odw_upload_scene_batch', 'odw_trace_batch', 'odw_batch_select', 'odw_batch_rows',
            'odw_plane_screen_batch', 'odw_archive_append', 'odw_archive_select', 'odw_archive_reset', 'odw_batch_hits_select', 'odw_batch_hits_sample', 'odw_batch_hits_project', 'odw_batch_hits_bin',

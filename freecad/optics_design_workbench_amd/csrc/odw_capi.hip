@@ -2760,6 +2760,16 @@ int odw_host_alloc(odw_ctx* ctx, uint64_t bytes, void** out) {
   return ODW_OK;
 }
 
+int odw_mem_info(odw_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes) {
+  if (!ctx) return fail(ctx, ODW_ERR_INVALID, "odw_mem_info: null ctx");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  size_t f = 0, t = 0;
+  HIPCHK(ctx, hipMemGetInfo(&f, &t));
+  if (free_bytes) *free_bytes = (uint64_t)f;
+  if (total_bytes) *total_bytes = (uint64_t)t;
+  return ODW_OK;
+}
+
 int odw_host_free(odw_ctx* ctx, void* p) {
   // (ctx may be null: page-locked arrays handed to the caller can outlive the context that allocated them)
   if (p) HIPCHK(ctx, hipHostFree(p));

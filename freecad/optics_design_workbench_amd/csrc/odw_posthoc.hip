@@ -820,6 +820,30 @@ int odw_hits_columns(odw_ctx* ctx, double* points, double* directions, double* p
   *n = m;
   if (m == 0 || !(points || directions || powers || is_entering || ray_index)) return ODW_OK;
   if (m > capacity) return fail(ctx, ODW_ERR_CAPACITY, "odw_hits_columns: output arrays too small");
+  // Page-locked destinations (odw_host_alloc: the run loop's arrays) are written by the kernel itself, across PCIe:
+  // no staging buffer, no copy commands -- five copies of 30 - 100 MB through one copy engine moved 30 GB/s, the kernel's
+  // stores fill the link (ODW_COLUMNS_DIRECT=0: the staged route, also taken for pageable destinations)
+  {
+    static const bool direct_off = [] { const char* e = getenv("ODW_COLUMNS_DIRECT"); return e && e[0] == '0'; }();
+    bool direct = !direct_off;
+    void* dev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    void* host[5] = {points, directions, powers, is_entering, ray_index};
+    for (int k = 0; k < 5 && direct; ++k) {
+      if (!host[k]) continue;
+      hipPointerAttribute_t attr;
+      if (hipPointerGetAttributes(&attr, host[k]) != hipSuccess) { (void)hipGetLastError(); direct = false; break; }
+      if (attr.type != hipMemoryTypeHost || !attr.devicePointer) { direct = false; break; }
+      dev[k] = attr.devicePointer;
+    }
+    if (direct) {
+      hipLaunchKernelGGL(ph_columns_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, ctx->stream,
+                         (const odw_hit*)ctx->hits.p, (const uint32_t*)ctx->sort_vals[1].p, m, (double*)dev[0], (double*)dev[1], (double*)dev[2],
+                         (long long*)dev[3], (long long*)dev[4]);
+      HIPCHK(ctx, hipGetLastError());
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      return ODW_OK;
+    }
+  }
   // staging: 9 doubles per row (3 + 3 + 1 + 1 + 1), one buffer
   if ((rc = ensure(ctx, ctx->sorted_rows, m * 9 * sizeof(double)))) return rc;
   double* base = (double*)ctx->sorted_rows.p;

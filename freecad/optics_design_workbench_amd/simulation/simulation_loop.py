@@ -14,6 +14,10 @@ Worker processes, flag files and the FreeCAD child process of the reference
 are replaced by the device; `devices` > 1 shards the ray index range over
 several GPUs of this process' node through `parallel`.
 """
+import os
+import threading
+import time
+
 import numpy as np
 
 from ..freecad_elements import point_source, replay_source, surface_fans, surface_source
@@ -36,7 +40,7 @@ def _limit(settings, key, default):
 
 def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPath=None, store=None,
                   raysPerLaunch=1 << 22, endIf=None, tracer=None, pseudoIterationsPerLaunch=64,
-                  dist=None, compileScene='auto', overlapFetch=True, keepOnDevice=False, **traceKwargs):
+                  dist=None, compileScene='auto', overlapFetch=True, keepOnDevice='auto', **traceKwargs):
   """trace `doc` until its simulation settings' end criteria are met.
 
   action       'true' (continuous Monte-Carlo) | 'singletrue' (one iteration)
@@ -64,10 +68,13 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
                while one traces, the hit columns of the other's previous launch cross PCIe into page-locked arrays and
                go to the writer threads (a thread of this call does that) -- the same files, the order of rays in
                them included; False: one launch at a time, fetched before the next starts
-  keepOnDevice the run's hit rows also stay in HBM (True: up to 64 GB of rows; a number: that many GB), appended launch
-               by launch to an archive on the device: `store.deviceHits()` -- and `RawFolder.loadHits(device=True)` of the
-               same process -- then bin them where they are (`DeviceHits`) instead of reading the run folder back into
-               host arrays (freecad_document.py:1485-1504); the files are written all the same.  One process, one source.
+  keepOnDevice the run's hit rows also stay in HBM, appended launch by launch to an archive on the device (a context of its
+               own): `store.deviceHits()` -- and `RawFolder.loadHits()` of the same process -- then bin them where they
+               are (`DeviceHits`) instead of reading the run folder back into host arrays (freecad_document.py:1485-1504);
+               the files are written all the same.  'auto' (default) / True: up to 64 GB of rows and at most a third of
+               the device memory that is free when the run starts; a number: that many GB; False: never.  Applies to one
+               process tracing one source; a run that outgrows its budget drops the archive and goes on (the run folder
+               is then the only copy).
   traceKwargs  maxRayLength, maxIntersections, powerTol, distTol (ray.py:36-38)
   -> SimulationResults
   """
@@ -110,8 +117,12 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
   keep_rows = None
   if keepOnDevice and hasattr(tr, 'archiveHits') and ranks.world == 1 and len(sources) == 1:
     results_store.releaseDeviceRuns()                    # (one run at a time keeps its rows on the device)
-    keep_rows = dict(tracer=tr, budget=int((64.0 if keepOnDevice is True else float(keepOnDevice)) * 1e9 // 64), rows=0, complete=True)
-    tr.archiveReset()
+    # the archive lives on a context of its own: launches' fetch threads append to it while the main thread launches on
+    # the tracing contexts (a context is not to be used from two threads at once)
+    budget_gb = _keep_budget_gb(tr, keepOnDevice)
+    if budget_gb > 0:
+      arch = Tracer(tr.device, referenceStrict=getattr(tr, 'referenceStrict', None))
+      keep_rows = dict(tracer=arch, budget=int(budget_gb * 1e9 // 64), rows=0, complete=True, lock=threading.Lock())
   master = ranks.rank == 0
   if master:
     store.setStatus('simulation-is-done', False)
@@ -292,37 +303,63 @@ def runSimulation(doc, action='true', *, seed=DEFAULT_SEED, device=0, resultsPat
       store.setStatus('simulation-is-canceled', failed)
       store.setStatus('simulation-is-done', not failed)
       store.setStatus('simulation-is-running', False)
-    if keep_rows is not None and not failed and keep_rows['complete'] and keep_rows['rows']:
-      results_store.registerDeviceRun(store, tr, own)     # (the tracer lives on with the rows: the store closes it)
-    elif own:
+    if keep_rows is not None:
+      if not failed and keep_rows['complete'] and keep_rows['rows']:
+        keep_rows['tracer'].scene = getattr(tr, 'scene', None)       # (group names of deviceHits('name'))
+        results_store.registerDeviceRun(store, keep_rows['tracer'], True)     # (lives on with the rows: the registry closes it)
+      else:
+        keep_rows['tracer'].close()
+    if own:
       tr.close()
   return store
 
 
+def _keep_budget_gb(tr, keepOnDevice):
+  """GB of hit rows a run may keep in HBM: True / 'auto' = up to 64 GB, and never more than a third of what is free now
+  (other contexts, other ranks of a rehearsal on the same GPU); a number = that many GB"""
+  if keepOnDevice is True or keepOnDevice == 'auto':
+    want = 64.0
+  else:
+    return max(0.0, float(keepOnDevice))
+  try:
+    free, _ = tr.memInfo()
+    return min(want, free / 3e9)
+  except Exception:
+    return want
+
+
 def _keep_rows(keep_rows, t, recorded):
-  """runSimulation(keepOnDevice=...): the launch's rows join the run's archive in HBM (device to device)"""
+  """runSimulation(keepOnDevice=...): the launch's rows join the run's archive in HBM (device to device; on the archive's
+  own context, one append at a time)"""
   if keep_rows is None or not keep_rows['complete'] or not recorded:
     return
-  if keep_rows['rows'] + recorded > keep_rows['budget']:
-    keep_rows['complete'] = False                       # (over the budget: the run folder is the only copy)
-    keep_rows['tracer'].archiveReset()
-    return
-  keep_rows['rows'] = keep_rows['tracer'].archiveHits(source=t)
+  with keep_rows['lock']:
+    if not keep_rows['complete']:
+      return
+    if keep_rows['rows'] + recorded > keep_rows['budget']:
+      keep_rows['complete'] = False                       # (over the budget: the run folder is the only copy)
+      keep_rows['tracer'].archiveReset()
+      return
+    keep_rows['rows'] = keep_rows['tracer'].archiveHits(source=t)
 
 
 def _run_overlapped(store, tr, baked, rpi, raysPerLaunch, seed, enabled, compileScene, keep_rows=None):
-  """the continuous loop for one device-generated source with the fetch of launch k overlapping the trace of launch
-  k + 1 (runSimulation: overlapFetch).  Launch k runs on context k % 2; a fetch thread waits for it, reads its counters,
-  has its rows selected and split into columns on the device, copies them into page-locked arrays and hands them to
-  the store's writer threads; the main thread meanwhile launches k + 1 on the other context.  End criteria on rays and
-  iterations are known at launch time, so the run traces exactly what the one-launch-at-a-time loop traces."""
+  """the continuous loop for one device-generated source with the fetch of launches overlapping the trace of the next
+  ones (runSimulation: overlapFetch).  Launch k runs on context k % 3; one of TWO fetch threads waits for it, reads its
+  counters, has its rows selected and split into columns on the device, copies them into page-locked arrays and hands
+  them to the store's writer threads -- while the selection and the column kernels of one launch run, the copy engine
+  moves the columns of the one before --; the main thread meanwhile launches on the next context.  The store is touched
+  by one thread at a time (a lock around adding a launch's rows and flushing them).  End criteria on rays and iterations
+  are known at launch time, so the run traces exactly what the one-launch-at-a-time loop traces."""
   from concurrent.futures import ThreadPoolExecutor
   src, scene, bsrc, lim = baked
-  other = Tracer(tr.device, referenceStrict=tr.referenceStrict)
-  lanes = [tr, other]
+  n_lanes = max(2, int(os.environ.get('ODW_RUN_LANES', '3')))
+  lanes = [tr] + [Tracer(tr.device, referenceStrict=tr.referenceStrict) for _ in range(n_lanes - 1)]
+  store_lock = threading.Lock()
   try:
-    if compileScene in ('auto', 'structure'):
-      other.compileScene(compileScene)
+    for t in lanes[1:]:
+      if compileScene in ('auto', 'structure'):
+        t.compileScene(compileScene)
     for t in lanes:
       t.setScene(scene)
       t.setLimits(lim)
@@ -332,7 +369,10 @@ def _run_overlapped(store, tr, baked, rpi, raysPerLaunch, seed, enabled, compile
     worst_per_ray = lim.max_intersections + 1
     state = dict(hits_per_ray=4.0)
 
+    clock = dict(wait=0.0, columns=0.0, keep=0.0, launches=0) if os.environ.get('ODW_RUN_TIMING') else None
+
     def fetch(t, base, n, iters, capacity):
+      t0 = time.perf_counter()
       while True:
         t.sync()
         cnt = t.counters()
@@ -348,16 +388,20 @@ def _run_overlapped(store, tr, baked, rpi, raysPerLaunch, seed, enabled, compile
         t.trace(base, n, seed)
       state['hits_per_ray'] = max(cnt['recorded_hits'] / n, 0.25)
       per_ray = _DeviceInitialConditions(t, bsrc, base, n, seed)
-      _store_hit_columns(store, t, scene, src, per_ray, base, enabled)
+      t1 = time.perf_counter()
+      _store_hit_columns(store, t, scene, src, per_ray, base, enabled, lock=store_lock, flush=True)
+      t2 = time.perf_counter()
       _keep_rows(keep_rows, t, cnt['recorded_hits'])
-      store.flush(wait=False)                          # (only this thread adds hits and flushes)
+      if clock is not None:
+        t3 = time.perf_counter()
+        clock['wait'] += t1 - t0; clock['columns'] += t2 - t1; clock['keep'] += t3 - t2; clock['launches'] += 1
 
-    pending = [None, None]
+    pending = [None] * n_lanes
     base, k = 0, 0
-    with ThreadPoolExecutor(max_workers=1, thread_name_prefix='odw-hit-fetch') as pool:
+    with ThreadPoolExecutor(max_workers=min(2, n_lanes - 1), thread_name_prefix='odw-hit-fetch') as pool:
       try:
         while True:
-          lane = k % 2
+          lane = k % n_lanes
           if pending[lane] is not None:
             pending[lane].result()                     # this context's rows are out (errors of its fetch surface here)
             pending[lane] = None
@@ -371,23 +415,32 @@ def _run_overlapped(store, tr, baked, rpi, raysPerLaunch, seed, enabled, compile
           pending[lane] = pool.submit(fetch, t, base, n, iters, capacity)
           base += n
           k += 1
-          store.incrementRayCount(n)
-          store.incrementIterationCount(iters)
-          store.dumpProgress()
-          if store.reachedEnd():
-            break
+          with store_lock:
+            store.incrementRayCount(n)
+            store.incrementIterationCount(iters)
+            store.dumpProgress()
+            if store.reachedEnd():
+              break
       finally:
         errors = []
         for f in pending:
           if f is not None:
             try:
               f.result()
-            except BaseException as e:              # (the first one is raised below, after both contexts are idle)
+            except BaseException as e:              # (the first one is raised below, after all contexts are idle)
               errors.append(e)
         if errors:
           raise errors[0]
   finally:
-    other.close()
+    if clock is not None and clock['launches']:
+      import sys
+      print('[odw run timing] ms per launch in the fetch threads: ' + ', '.join(f'{k} {1e3 * v / clock["launches"]:.2f}' for k, v in clock.items()
+                                                                              if k != 'launches') +
+            ' | of columns: ' + ', '.join(f'{k} {1e3 * v / clock["launches"]:.2f}' for k, v in (_STORE_CLOCK or {}).items()), file=sys.stderr, flush=True)
+      for k in (_STORE_CLOCK or {}):
+        _STORE_CLOCK[k] = 0.0
+    for t in lanes[1:]:
+      t.close()
 
 
 def bakeLightSource(doc, src, seed=0):
@@ -458,24 +511,43 @@ class _DeviceInitialConditions:
     raise KeyError(key)
 
 
-def _store_hit_columns(store, tr, scene, src, per_ray, base, enabled):
+_STORE_CLOCK = {'lock': 0.0, 'add+flush': 0.0} if os.environ.get('ODW_RUN_TIMING') else None
+
+
+def _store_hit_columns(store, tr, scene, src, per_ray, base, enabled, lock=None, flush=False):
   """the launch's rows into the store, one recording group at a time, as the device hands them over: already
-  split into the arrays of the reference's hit dictionary (Tracer.hitColumns) -- the host copies nothing"""
+  split into the arrays of the reference's hit dictionary (Tracer.hitColumns) -- the host copies nothing.
+  lock: held while the store is touched (the overlapped loop's fetch threads); flush: hand the rows to the writer
+  threads at once, under the same lock"""
   keys = [k for k in enabled if k in per_ray]
   columns = {k: per_ray[k] for k in keys}
   # Page-locked destination arrays (the copy engine writes them directly: 45+ GB/s instead of 17) when the rows
   # only pass through the host on their way into the run folder: the writer thread drops them after pickling and
-  # their memory is used again two launches later.  Rows that are KEPT in memory would pin a new slab per launch
+  # their memory is used again a few launches later.  Rows that are KEPT in memory would pin a new slab per launch
   # (page-locking costs more than the staged copy saves: measured 4.0e7 against 1.1e8 rays/s): plain arrays.
   pinned = store.basePath is not None and not getattr(store, 'keepInMemory', False)
+  got = []
   for g in np.nonzero(np.asarray(scene.group_record))[0]:
-    cols = tr.hitColumns(int(g), pinned=pinned)
+    cols = tr.hitColumns(int(g), pinned=pinned, rayIndex=bool(columns))       # (the ray's number: for per-ray metadata only)
     if cols is None:
       continue
-    ray = cols['rayIndex'] - int(base)
-    extra = {k: np.asarray(v)[ray] for k, v in columns.items()}
-    store.addRayHits(src.Name, src._props.get('Label', src.Name), scene.group_names[g], scene.group_labels[g],
-                     cols['points'], cols['directions'], cols['powers'], cols['isEntering'], **extra)
+    extra = {}
+    if columns:
+      ray = cols['rayIndex'] - int(base)
+      extra = {k: np.asarray(v)[ray] for k, v in columns.items()}
+    got.append((g, cols, extra))
+  import contextlib
+  t_a = time.perf_counter()
+  with (lock if lock is not None else contextlib.nullcontext()):
+    t_b = time.perf_counter()
+    for g, cols, extra in got:
+      store.addRayHits(src.Name, src._props.get('Label', src.Name), scene.group_names[g], scene.group_labels[g],
+                       cols['points'], cols['directions'], cols['powers'], cols['isEntering'], **extra)
+    if flush:
+      store.flush(wait=False)
+  if _STORE_CLOCK is not None:
+    _STORE_CLOCK['lock'] += t_b - t_a
+    _STORE_CLOCK['add+flush'] += time.perf_counter() - t_b
 
 
 def _store_hits(store, rows, scene, src, per_ray, base, enabled):

@@ -28,8 +28,14 @@ class _PinnedPool:
   into them directly (48 - 56 GB/s; 17 GB/s through the staging copies of pageable memory).  One pool per
   process: the arrays may outlive the tracer that filled them (a run's results kept in memory).  A slab goes
   back to the pool when the last array carved from it is garbage-collected (the run loop's arrays: once the
-  writer thread has pickled them), so a continuous run cycles through two or three slabs; arrays that are
-  kept keep their slab and the pool allocates another; free slabs beyond KEEP are given back to the system."""
+  writer threads have pickled them), so a continuous run cycles through as many slabs as it has launches in flight
+  between the device and the files (writer threads + their queue + the fetch under way: `reserve` tells the pool; with
+  fewer slabs kept than that, every launch page-locks a new 300 MB slab and gives one back -- 50 - 100 ms each, which is
+  why MORE writer threads made round 4's run loop SLOWER: 4 / 6 / 8 / 12 writers = 2.9 / 2.1 / 1.7 / 1.2e8 rays/s);
+  arrays that are kept keep their slab and the pool allocates another; free slabs beyond KEEP are given back to the
+  system.  Page-locking costs 0.22 ms per MB on the pool's boxes (67 ms for a launch's 300 MB slab, 55 ms to give it
+  back: scripts/bench_pinned_alloc.py) -- fifteen times what the launch itself may take at 5e8 rays/s --, so the slabs stay
+  with the process between runs (a second run starts warm); `releasePinnedMemory()` gives them back."""
   KEEP = 4
 
   def __init__(self):
@@ -48,6 +54,24 @@ class _PinnedPool:
         _native.lib().odw_host_free(None, C.c_void_p(drop[1]))
       except Exception:
         pass
+
+  def reserve(self, slabs):
+    """free slabs the pool holds on to from now on (a run's pipeline depth)"""
+    self.KEEP = max(4, int(slabs))
+
+  def trim(self, keep=2):
+    """after a run: give free slabs beyond `keep` back to the system"""
+    self.KEEP = max(int(keep), 0)
+    while True:
+      with self._lock:
+        if len(self._free) <= self.KEEP:
+          break
+        drop = self._free.pop(0)
+      try:
+        _native.lib().odw_host_free(None, C.c_void_p(drop[1]))
+      except Exception:
+        pass
+    self.KEEP = 4
 
   def take(self, tracer, nbytes):
     """a ctypes buffer of >= nbytes page-locked bytes; numpy arrays made from it (np.frombuffer) keep it alive"""
@@ -69,6 +93,11 @@ class _PinnedPool:
 
 
 _POOL = _PinnedPool()
+
+
+def releasePinnedMemory(keep=0):
+  """give the page-locked slabs the run loops of this process keep for their next run back to the system"""
+  _POOL.trim(keep)
 
 
 class Tracer:
@@ -317,6 +346,12 @@ class Tracer:
     self._chk(self._lib.odw_batch_rows(self._ctx, rows.ctypes.data_as(pu), wanted.ctypes.data_as(pu), C.c_int32(n)), 'odw_batch_rows')
     return rows, wanted
 
+  def memInfo(self):
+    """(free, total) bytes of the tracer's device"""
+    free, total = C.c_uint64(0), C.c_uint64(0)
+    self._chk(self._lib.odw_mem_info(self._ctx, C.byref(free), C.byref(total)), 'odw_mem_info')
+    return int(free.value), int(total.value)
+
   def sync(self):
     self._chk(self._lib.odw_sync(self._ctx), 'odw_sync')
 
@@ -400,31 +435,36 @@ class Tracer:
       # back to one list: later launches reserve hit-list blocks per wave again
       self._chk(self._lib.odw_release_swapped_hits(self._ctx), 'odw_release_swapped_hits')
 
-  def hitColumns(self, group, pinned=True):
+  def hitColumns(self, group, pinned=True, rayIndex=True):
     """the recorded rows of one group as the arrays the reference pickles per (source, object)
     (results_store.py:405-457): dict(points (n, 3), directions (n, 3), powers (n), isEntering (n) int64,
     rayIndex (n) int64), in (ray index, bounce) order -- selected and split into columns on the device
     (odw_hits_select + odw_hits_columns), so the host only receives them; None if the group has no row.
     pinned: the arrays live in page-locked memory of the process' pool (_PinnedPool) until they are dropped
-    (they may outlive the tracer); then their memory returns to the pool"""
+    (they may outlive the tracer); then their memory returns to the pool.  rayIndex=False: without that column (it
+    serves the per-ray metadata only: an eighth less to copy)"""
     n, leaving = C.c_uint64(0), C.c_uint64(0)
     self._chk(self._lib.odw_hits_select(self._ctx, C.c_int32(int(group)), C.byref(n), C.byref(leaving)), 'odw_hits_select')
     m = int(n.value)
     if m == 0:
       return None
+    per_row = 9 if rayIndex else 8                          # doubles per row: 3 + 3 + 1 + 1 (+ 1: the ray's number)
     if pinned:
-      buf = _POOL.take(self, m * 72)                        # 9 doubles per row: 3 + 3 + 1 + 1 + 1
-      f8 = np.frombuffer(buf, dtype=np.float64, count=9 * m)
+      buf = _POOL.take(self, m * 8 * per_row)
+      f8 = np.frombuffer(buf, dtype=np.float64, count=per_row * m)
       out = dict(points=f8[:3 * m].reshape(m, 3), directions=f8[3 * m:6 * m].reshape(m, 3), powers=f8[6 * m:7 * m],
-                 isEntering=f8[7 * m:8 * m].view(np.int64), rayIndex=f8[8 * m:9 * m].view(np.int64))
+                 isEntering=f8[7 * m:8 * m].view(np.int64))
+      if rayIndex:
+        out['rayIndex'] = f8[8 * m:9 * m].view(np.int64)
     else:
-      out = dict(points=np.empty((m, 3)), directions=np.empty((m, 3)), powers=np.empty(m),
-                 isEntering=np.empty(m, dtype=np.int64), rayIndex=np.empty(m, dtype=np.int64))
+      out = dict(points=np.empty((m, 3)), directions=np.empty((m, 3)), powers=np.empty(m), isEntering=np.empty(m, dtype=np.int64))
+      if rayIndex:
+        out['rayIndex'] = np.empty(m, dtype=np.int64)
     f = self._lib.odw_hits_columns
     f.argtypes = [C.c_void_p] + [C.c_void_p] * 5 + [C.c_uint64, C.POINTER(C.c_uint64)]
     got = C.c_uint64(0)
-    self._chk(f(self._ctx, *(out[k].ctypes.data_as(C.c_void_p) for k in ('points', 'directions', 'powers', 'isEntering',
-                                                                          'rayIndex')), C.c_uint64(m), C.byref(got)),
+    self._chk(f(self._ctx, *(out[k].ctypes.data_as(C.c_void_p) if k in out else None
+                             for k in ('points', 'directions', 'powers', 'isEntering', 'rayIndex')), C.c_uint64(m), C.byref(got)),
               'odw_hits_columns')
     assert int(got.value) == m
     return out

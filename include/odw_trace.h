@@ -407,6 +407,11 @@ int odw_fetch_swapped_hits(odw_ctx* ctx, odw_hit* out, uint64_t capacity, uint64
 int odw_release_swapped_hits(odw_ctx* ctx);
 /* page-locked host memory for the destination of row fetches (the copy engine
  * writes it directly: no staging through the runtime's own pinned buffers)  */
+/* v10: free and total memory of the context's device (hipMemGetInfo): what a
+ * sweep sizes its groups by and a run decides by whether its rows may stay in
+ * HBM -- instead of a fixed budget that ignores other contexts and ranks on
+ * the same GPU.                                                             */
+int odw_mem_info(odw_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes);
 int odw_host_alloc(odw_ctx* ctx, uint64_t bytes, void** out);
 /* ctx may be NULL: arrays handed to the caller (hit columns of a run kept in memory) outlive their context */
 int odw_host_free(odw_ctx* ctx, void* p);

@@ -214,8 +214,9 @@ with Tracer(0) as tr:
 
 
 def test_a_run_keeps_its_rows_on_the_device(native_lib, tmp_path):
-  """runSimulation(keepOnDevice=True): the rows of every launch join an archive in HBM (odw_archive_append: device to
-  device, also from the second context of the overlapped loop); RawFolder.loadHits(device=True) of the same process
+  """runSimulation (keepOnDevice 'auto', the default, and True): the rows of every launch join an archive in HBM
+  (odw_archive_append: device to device, from the fetch threads of the overlapped loop onto a context of its own);
+  RawFolder.loadHits() of the same process is lazy about the files and bins in HBM; loadHits(device=True)
   bins them where they are -- the Histogram of the files read back (plane, origin, counts), the same moments, the same
   rows; a later run releases them; without the switch loadHits(device=True) reads the files"""
   import shutil
@@ -228,20 +229,35 @@ def test_a_run_keeps_its_rows_on_the_device(native_lib, tmp_path):
   with FreecadDocument(path) as f:
     f.OpticalSimulationSettings.EndAfterRays = '3e5'
     for overlap in (True, False):
-      raw = f.runSimulation('true', raysPerLaunch=70000, keepOnDevice=True, overlapFetch=overlap)
-      host = raw.loadHits()
+      # (keepOnDevice is the default since round 5: 'auto')
+      raw = f.runSimulation('true', raysPerLaunch=70000, overlapFetch=overlap, **({} if overlap else dict(keepOnDevice=True)))
+      host = raw.loadHits(device=False)
+      assert type(host) is results_store.Hits
       dev = raw.loadHits(device=True)
       assert isinstance(dev, DeviceHits) and len(dev) == len(host) > 2.9e5
       kw = dict(binCoords='polar', bins=[np.arange(0, 2 * np.pi, np.pi / 2), np.geomspace(1e-3, 5, 200)])
       a, b = dev.histogram(**kw), host.histogram(**kw)
       assert np.array_equal(a.hist, b.hist) and np.allclose(a._origin, b._origin, atol=1e-12)
       assert np.array_equal(a._planeNormal, b._planeNormal)
+      # what a notebook gets without asking for anything: the files are not read until an array is wanted, histograms
+      # and the plane come from the rows in HBM
+      lazy = raw.loadHits()
+      assert isinstance(lazy, results_store.RunHits) and lazy._loaded is None
+      c = lazy.histogram(**kw)
+      assert len(lazy) == len(host) and lazy._loaded is None
+      assert np.array_equal(c.hist, b.hist) and np.array_equal(c._planeNormal, b._planeNormal) and np.allclose(c._origin, b._origin, atol=1e-12)
+      n1, x1 = lazy.detectPlaneNormal()
+      n2, x2 = host.detectPlaneNormal()
+      assert np.array_equal(n1, n2) and np.array_equal(x1, x2) and lazy._loaded is None
+      assert np.array_equal(lazy.points(), host.points()) and lazy._loaded is not None      # (now the arrays are there ...)
+      d = lazy.histogram(**kw)                                                               # (... and numpy bins them)
+      assert np.array_equal(d.hist, b.hist) and np.array_equal(d._origin, b._origin)
       rows = dev.toHits()
       order = np.lexsort(host.points().T[::-1])
       assert np.array_equal(rows.points()[np.lexsort(rows.points().T[::-1])], host.points()[order])
     assert len(results_store._DEVICE_RUNS) == 1                # (the second run released the first one's rows)
-    plain = f.runSimulation('true', raysPerLaunch=70000)
-    assert not isinstance(plain.loadHits(device=True), DeviceHits)
+    plain = f.runSimulation('true', raysPerLaunch=70000, keepOnDevice=False)
+    assert not isinstance(plain.loadHits(device=True), DeviceHits) and type(plain.loadHits()) is results_store.Hits
   results_store.releaseDeviceRuns()
   assert not results_store._DEVICE_RUNS
 
