@@ -253,6 +253,18 @@ def compact(line, nested=False):
   return out
 
 
+def detector_of(cfg_name, proj):
+  """the 1024 x 1024 detector window a config's launches bin into"""
+  from freecad.optics_design_workbench_amd import scenes
+  if cfg_name == 'c4':
+    # the absorbers are spheres (no planar face): their hits are binned in projection along the
+    # array's z axis, window = the footprint of the 10 x 10 x 5 array (pitch 5 mm) + margin
+    gi = proj.scene.group_index('OpticalAbsorberGroup')
+    return dict(group=gi, origin=[-0.5, -0.5, 61.0], ex=[1.0, 0.0, 0.0], ey=[0.0, 1.0, 0.0],
+                x_lo=-25.0, x_hi=25.0, y_lo=-25.0, y_hi=25.0, nx=1024, ny=1024)
+  return scenes.planeDetector(proj.scene, 'OpticalAbsorberGroup', nx=1024, ny=1024, toward=proj.source.xform[[3, 7, 11]])
+
+
 def run_trace_config(args, cfg_name, cfg, rank, local_rank, world, dist, torch):
   from freecad.optics_design_workbench_amd import scenes
   from freecad.optics_design_workbench_amd.simulation import parallel
@@ -260,15 +272,7 @@ def run_trace_config(args, cfg_name, cfg, rank, local_rank, world, dist, torch):
 
   n_per = int(args.rays_per_step if args.rays_per_step else cfg['rays'])
   proj = scenes.bakeProject(os.path.join(SCENES, cfg['scene'] + '.FCStd'))
-  if cfg_name == 'c4':
-    # the absorbers are spheres (no planar face): their hits are binned in projection along the
-    # array's z axis, window = the footprint of the 10 x 10 x 5 array (pitch 5 mm) + margin
-    gi = proj.scene.group_index('OpticalAbsorberGroup')
-    det = dict(group=gi, origin=[-0.5, -0.5, 61.0], ex=[1.0, 0.0, 0.0], ey=[0.0, 1.0, 0.0],
-               x_lo=-25.0, x_hi=25.0, y_lo=-25.0, y_hi=25.0, nx=1024, ny=1024)
-  else:
-    det = scenes.planeDetector(proj.scene, 'OpticalAbsorberGroup', nx=1024, ny=1024,
-                               toward=proj.source.xform[[3, 7, 11]])
+  det = detector_of(cfg_name, proj)
   tr = Tracer(local_rank)
   tr.setScene(proj.scene)
   tr.setSource(proj.source)
@@ -550,6 +554,7 @@ def main():
   dist = None
   if REHEARSE:
     local_rank = 0                       # (from here on: the device a rank works on)
+    os.environ.setdefault('ODW_RANKS_PER_DEVICE', str(world))      # (the ranks share GPU 0's memory: simulation/sweep.py)
   if launched:   # launched by torch.distributed.run (also with one rank)
     import torch.distributed as dist
     torch.cuda.set_device(local_rank)

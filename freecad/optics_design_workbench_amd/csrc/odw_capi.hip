@@ -155,6 +155,7 @@ struct odw_ctx {
   int batch_selected = -1;
   std::string batch_spec_text;             // the structure all scenes of the batch share (compiled kernels)
   hipFunction_t spec_batch_fn = nullptr;   // the scene-compiled kernel's BATCH variant (bound on the first batch launch)
+  bool spec_batch_failed = false;          // ... could not be built for the bound structure: generic kernels for its batches
   DevBuf own_hits, own_hit_count;
   uint64_t own_capacity = 0, own_slots = 0, own_ray_begin = 0, own_ray_end = 0;
   // a run's rows kept in HBM beyond the launches that recorded them (odw_archive_append / odw_archive_select)
@@ -1290,10 +1291,17 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
   static const int grid_mult = [] { const char* e = getenv("ODW_GRID_MULT"); int v = e ? atoi(e) : 0; return v > 0 ? v : 8; }();
   // big analytic scenes: grid kernel (no stochastic surfaces, no segment rows: those stay with the BVH kernels)
   // a scene compiled against its structure (odw_spec.hip): its own kernel, whatever else was built for it
-  if (batch && ctx->spec_fn && !ctx->spec_batch_fn) {
+  if (batch && ctx->spec_fn && !ctx->spec_batch_fn && !ctx->spec_batch_failed) {
     // the compiled kernel's BATCH variant: bound on the first batch launch of the structure (a compilation of its own,
-    // cached like the other; odw_compile_scene's mode decides, as for single launches)
-    if (spec_bind(ctx, true) != ODW_OK) ctx->spec_batch_fn = nullptr;
+    // cached like the other; odw_compile_scene's mode decides, as for single launches).  A variant that cannot be built
+    // is not tried again for this binding, and its failure does not become the error of a launch that succeeds on the
+    // generic kernel
+    const std::string keep_err = ctx->err;
+    if (spec_bind(ctx, true) != ODW_OK) {
+      ctx->spec_batch_fn = nullptr;
+      ctx->spec_batch_failed = true;
+      ctx->err = keep_err;
+    }
   }
   const bool use_spec = (batch ? ctx->spec_batch_fn != nullptr : ctx->spec_fn != nullptr) && ctx->spec_lean == ctx->lean &&
                         ctx->spec_stoch == (ctx->n_samplers > 0) && !(flags & ODW_TRACE_RECORD_SEGMENTS);

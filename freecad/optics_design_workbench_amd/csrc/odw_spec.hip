@@ -355,6 +355,7 @@ int spec_bind(odw_ctx* ctx, bool batch = false) {
     ctx->spec_dirty = false;
     ctx->spec_fn = nullptr;
     ctx->spec_batch_fn = nullptr;
+    ctx->spec_batch_failed = false;
     ctx->spec_seconds = 0;
     ctx->spec_cache_hit = 0;
     ctx->spec_pending = false;
@@ -384,8 +385,8 @@ int spec_bind(odw_ctx* ctx, bool batch = false) {
           fclose(f);
         } else {
           // not hot yet, or hot: start the thread
-          ctx->spec_pending = true;
-          ctx->spec_key = jkey;
+          // (the BATCH variant rides on the single-scene kernel's bookkeeping: its own key must not replace that one's)
+          if (!batch) { ctx->spec_pending = true; ctx->spec_key = jkey; }
           if (G.rays[jkey] < ctx->spec_hot_rays) return ODW_OK;
           auto job = std::make_shared<SpecJob>();
           G.jobs[jkey] = job;
@@ -401,8 +402,7 @@ int spec_bind(odw_ctx* ctx, bool batch = false) {
           return ODW_OK;
         }
       } else if (!jt->second->done.load()) {
-        ctx->spec_pending = true;
-        ctx->spec_key = jkey;
+        if (!batch) { ctx->spec_pending = true; ctx->spec_key = jkey; }
         return ODW_OK;                                      // still compiling: generic kernels meanwhile
       } else {
         std::shared_ptr<SpecJob> job = jt->second;

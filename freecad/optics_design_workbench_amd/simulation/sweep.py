@@ -213,6 +213,8 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
         extra.compileScene({0: 'off', 1: 'structure', 2: 'auto'}[tr.compileMode()])
       except Exception:
         pass
+      if getattr(tr, '_timingOn', False):
+        extra.timingEnable(True)         # (a tracer whose launches are being timed: those of its new contexts too)
       kept.append(extra)
     tr._sweepLanes = kept
     lanes += kept[:want]
@@ -364,13 +366,28 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
     search, fits) never competes for the interpreter lock."""
     from .device_hits import DeviceHitsBatch
     request = histogramRequest()
-    for t in lanes:
-      # (every context sized for the largest group before the first launch: a hit list that has to grow later is released
-      #  and allocated again, which waits for every stream of the device -- 13 GB take half a second)
-      key = (group_size, int(rays))
-      if getattr(t, '_sweepReserved', None) != key:
-        t.reserveBatch(group_size, int(rays), int(rays * 1.25) + 1024)
-        t._sweepReserved = key
+    while True:
+      try:
+        for t in lanes:
+          # (every context sized for the largest group before the first launch: a hit list that has to grow later is
+          #  released and allocated again, which waits for every stream of the device -- 13 GB take half a second)
+          key = (group_size, int(rays))
+          if getattr(t, '_sweepReserved', None) != key:
+            t.reserveBatch(group_size, int(rays), int(rays * 1.25) + 1024)
+            t._sweepReserved = key
+            t._sweepHeld = group_size * ((int(rays * 1.25) + 1024 + 4_300_000) * (64 + 24 + 4) + int(rays) * 30)
+        break
+      except _native.NativeError as e:
+        # the device has less room than the estimate said (someone else's buffers): half the group, down to values one by one
+        if 'device error' not in str(e) or group_size <= 1:
+          raise
+        group_size = max(1, group_size // 2)
+        for t in lanes:
+          t._sweepReserved = None
+        if group_size == 1:
+          for turn_, k in enumerate(mine):
+            runOne(turn_ % len(lanes), k)
+          return
     busy = [None] * len(lanes)           # per context: dict(ks, batch, capacity, t0) of the group in flight
     order = []                           # contexts in the order their groups were launched
     pos, turn = 0, 0
@@ -478,9 +495,19 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
   if group_size > 1:
     # room in HBM: every context holds the hit list of a group (64-byte rows, with the slack of block reservations) and
     # the post-hoc state of its segments (row-of-ray table, selection, projected coordinates: ~30 bytes per ray)
-    per_value = (int(rays * 1.25) + 1024 + 4_300_000) * 64 + int(rays) * 30
-    budget = float(os.environ.get('ODW_SWEEP_HBM_GB', '96')) * 1e9 / len(lanes)
-    group_size = max(1, min(group_size, int(budget // per_value)))
+    per_value = (int(rays * 1.25) + 1024 + 4_300_000) * (64 + 24 + 4) + int(rays) * 30
+    # (what the device has free NOW, shared with whatever else lives on it -- other ranks of a rehearsal, the caller's own
+    #  buffers --, never more than ODW_SWEEP_HBM_GB; two thirds of it, over this sweep's contexts)
+    budget = float(os.environ.get('ODW_SWEEP_HBM_GB', '128')) * 1e9
+    try:
+      free, _ = tr.memInfo()
+      held = sum(getattr(t, '_sweepHeld', 0) for t in lanes)        # (what these contexts reserved in earlier sweeps is theirs)
+      budget = min(budget, (free + held) * 2 / 3)
+    except Exception:
+      pass
+    # (ranks that share one device -- a node rehearsed on one GPU -- share its memory too, and ask at the same moment)
+    budget /= max(1, int(os.environ.get('ODW_RANKS_PER_DEVICE', '1')))
+    group_size = max(1, min(group_size, int(budget / len(lanes) // per_value)))
   if os.environ.get('ODW_SWEEP_BATCH'):
     group_size = max(1, int(os.environ['ODW_SWEEP_BATCH'])) if group_size > 1 else 1
   switch_interval = sys.getswitchinterval()

@@ -556,6 +556,7 @@ class Tracer:
   # -- timing -----------------------------------------------------------------
   def timingEnable(self, on=True):
     self._chk(self._lib.odw_timing_enable(self._ctx, C.c_int(1 if on else 0)), 'odw_timing_enable')
+    self._timingOn = bool(on)          # (contexts a sweep creates beside this one follow it: simulation/sweep.py)
 
   def timingRead(self):
     ms, n = C.c_double(0), C.c_uint64(0)

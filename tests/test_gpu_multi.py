@@ -172,22 +172,24 @@ def test_default_bench_line_carries_the_three_gpu_configs(native_lib):
   assert set(lines) == {'c3', 'c4', 'c5'}
   for name, line in lines.items():
     r = line['roofline']
-    assert r['bound'] == 'valu_issue' and 0.3 < r['frac'] <= 1.0, (name, r)
+    assert r['bound'] == 'valu_issue'
+    if r.get('pmc_stale'):
+      # the committed counter pass was taken on other sources than this build: the line says so and computes nothing from it
+      assert r['frac'] is None and r['achieved'] is None and 'other sources' in r['note'], (name, r)
+    else:
+      assert 0.3 < r['frac'] <= 1.0, (name, r)
     for key in ('wavefront_equivalent_frac', 'hbm_counter_frac', 'fp64_flops_frac'):
       assert r.get(key) is None or 0 <= r[key] < 1.5, (name, key, r[key])
     assert r.get('hbm_counter_frac') is None or r['hbm_counter_frac'] < 1
     assert r.get('fp64_flops_frac') is None or r['fp64_flops_frac'] < 1
-    # where the box lets the clock be read: a plausible reading (the driver smooths it: context, nothing derived from it)
-    clock = line.get('clock')
-    if clock:
-      assert 50 < clock['sclk_mhz_min'] <= clock['sclk_mhz_mean'] <= clock['sclk_mhz_max'] <= 1.05 * clock['peak_mhz'], clock
-  assert lines['c4']['value'] > 3e9 and lines['c4']['roofline']['valu']['active_lanes_per_inst'] > 25
+  stale = any(line['roofline'].get('pmc_stale') for line in lines.values())
+  assert lines['c4']['value'] > 3e9 and (stale or lines['c4']['roofline']['valu']['active_lanes_per_inst'] > 25)
   assert lines['c5']['value'] > 5e8 and lines['c5']['steps'] == 2
   # the same figures as plain numbers in `config` (what a reader that keeps only scalars still finds), a short line
   for name in ('c4', 'c5'):
     assert out['config'][f'{name}_value'] == lines[name]['value'] and out['config'][f'{name}_ms_per_step'] == lines[name]['ms_per_step']
     assert out['config'][f'{name}_roofline_frac'] == lines[name]['roofline']['frac']
-  assert out['config']['c4_active_lanes_per_inst'] > 25
+  assert stale or out['config']['c4_active_lanes_per_inst'] > 25
   # c5 at full size: the notebook's FWHM on its own sample size finds the valley the reference's stored curve has
   # (optimize-spotsize.ipynb cell 10: below 3e-3 mm from R = 9.76 to 10.24; the shipped file holds 9.83)
   assert 9.7 <= out['config']['c5_best_radius_by_fwhm_1e3_mm'] <= 10.3
@@ -371,3 +373,53 @@ def test_rehearsal_four_ranks_on_one_gpu_equal_the_sum_of_their_shards(native_li
   assert t3['n_gpus'] == 3 and t3['scaling'] == 'strong' and 'rehearsal' in t3
   for col in ('fwhm_mm', 'rms_spot_mm', 'fwhm_1e3_mm'):
     assert t3['config']['spot_size'][col] == t1[col], col
+
+
+def test_rehearsal_four_ranks_c4_and_the_whole_sweep(native_lib, tmp_path):
+  """BASELINE configs[3] and [4] as a node runs them, rehearsed with as many ranks as one GPU of this pool admits beside
+  the test process and the launcher (six processes may have a card open: four ranks; the eight-rank arithmetic itself runs
+  on CPU, tests/test_parallel_gloo.py::test_eight_rank_reduce_matches_single): hugeArray sharded over four ranks (two
+  steps of 2e6 rays each) = the sum of the eight shards traced one by one; the WHOLE 64-radius sweep dealt out over four
+  ranks = the one-rank table bit for bit"""
+  from freecad.optics_design_workbench_amd import scenes
+  from freecad.optics_design_workbench_amd.simulation import parallel
+  from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
+  import bench
+  env = dict(ODW_BENCH_REHEARSE='1')
+  n_per, steps, world = 2_000_000, 2, 4
+  dump = str(tmp_path / 'c4_job.npz')
+  out = _line(_bench('--gpus', str(world), '--config', 'c4', '--steps', str(steps), '--warmup', '1', '--rays-per-step', str(n_per),
+                     '--no-cpu-baseline', '--no-end-to-end', '--dump-results', dump, env=env))
+  assert out['n_gpus'] == world and 'rehearsal' in out and out['config']['name'] == 'c4'
+  assert out['value'] * out['ms_per_step'] * 1e-3 == pytest.approx(world * n_per, rel=1e-6)
+  job = np.load(dump)
+  pr = project('hugeArray')
+  det = bench.detector_of('c4', pr)
+  hist, cnt = None, None
+  with Tracer(0) as tr:
+    tr.setScene(pr.scene); tr.setSource(pr.source); tr.setLimits(pr.limits)
+    if det is not None:
+      tr.setDetector(det)
+    tr.reserveHits(2 * n_per)
+    for rank in range(world):
+      tr.reset()
+      for s in range(steps):
+        tr.resetHits()
+        tr.trace(parallel.shardFirst(s, rank, world, n_per), n_per, bench.SEED)
+      tr.sync()
+      c = tr.counters()
+      cnt = c if cnt is None else {k: cnt[k] + c[k] for k in c}
+      if det is not None:
+        h = tr.histogram().astype(np.int64)
+        hist = h if hist is None else hist + h
+  assert cnt['traced_rays'] == world * steps * n_per
+  assert [int(v) for v in job['counters']] == [cnt[k] for k in sorted(cnt)]
+  if hist is not None:
+    assert np.array_equal(job['hist'].astype(np.int64), hist)
+  # the whole sweep (64 radii) over four ranks: sixteen values each, one all-reduce of the table
+  args = ['--config', 'c5', '--rays-per-step', '1e5', '--no-cpu-baseline']
+  t1 = _line(_bench('--gpus', '1', *args))
+  t4 = _line(_bench('--gpus', '4', *args, env=env))
+  assert t4['n_gpus'] == 4 and t4['scaling'] == 'strong' and 'rehearsal' in t4 and t4['config']['radii'] == 64
+  for col in ('fwhm_mm', 'rms_spot_mm', 'fwhm_1e3_mm'):
+    assert t4['config']['spot_size'][col] == t1['config']['spot_size'][col], col

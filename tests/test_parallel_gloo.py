@@ -29,16 +29,45 @@ tr = OracleTracer(nthreads=2)
 tr.setScene(pr.scene); tr.setSource(pr.source); tr.setLimits(pr.limits); tr.setDetector(det)
 tr.trace(first, n, 77)
 calls = []
-reduce_ = dist.reduce
-dist.reduce = lambda *a, **k: (calls.append(1), reduce_(*a, **k))[1]
+reduce_, sync_ = dist.reduce, tr.sync
+dist.reduce = lambda *a, **k: (calls.append('reduce'), reduce_(*a, **k))[1]
+tr.sync = lambda *a, **k: (calls.append('sync'), sync_(*a, **k))[1]
 parallel.reduceResults(tr, dist, torch)            # the product's helper: ONE collective for counters + histogram
-assert len(calls) == 1, calls
+# ... and the tracer's own stream is waited for BEFORE the collective reads the block (the launches run on a stream torch
+# knows nothing about: without this wait the reduce could sum a block that is still being written)
+assert calls == ['sync', 'reduce'], calls
 if rank == 0:
   c = tr.counters()
   np.savez(sys.argv[2], hist=tr.histogram().astype(np.int64), cnt=np.array([c[k] for k in capi.CNT_NAMES]))
 dist.barrier()
 dist.destroy_process_group()
 '''
+
+
+def test_eight_rank_reduce_matches_single(tmp_path, oracle):
+  """the rank arithmetic of a whole node (BASELINE configs[3] / [4] run on 8 GPUs), on CPU: eight gloo ranks, each its
+  shard of the index range on the oracle, ONE reduce -- rank 0 holds the single-process histogram and counters"""
+  from freecad.optics_design_workbench_amd import scenes
+  script = tmp_path / 'worker.py'
+  script.write_text(WORKER)
+  out = tmp_path / 'r0.npz'
+  s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+  env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), OMP_NUM_THREADS='1')
+  res = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=8', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), str(script), ROOT, str(out)], env=env, capture_output=True, text=True, timeout=600)
+  assert res.returncode == 0, res.stderr[-3000:]
+  pr = project('lensesAndMirrors')
+  det = scenes.planeDetector(pr.scene, 'OpticalAbsorberGroup', nx=64, ny=64, toward=pr.source.xform[[3, 7, 11]])
+  ref = oracle.trace(pr.scene, pr.source, pr.limits, 1000, 30001, 77, det=det)
+  got = np.load(out)
+  assert np.array_equal(got['hist'], ref['hist'].astype(np.int64))
+  assert [int(v) for v in got['cnt']] == [ref['counters'][k] for k in oracle.CNT_NAMES]
+  # the sweep's deal over eight ranks: every value to exactly one rank, loads within one of each other
+  from freecad.optics_design_workbench_amd.simulation import sweep
+  shares = [sweep.shareOfRank(64, r, 8) for r in range(8)]
+  assert sorted(k for sh in shares for k in sh) == list(range(64)) and all(len(sh) == 8 for sh in shares)
+  shares = [sweep.shareOfRank(30, r, 8) for r in range(8)]
+  assert sorted(k for sh in shares for k in sh) == list(range(30)) and max(map(len, shares)) - min(map(len, shares)) == 1
 
 
 def test_shard_range_partitions_exactly():
