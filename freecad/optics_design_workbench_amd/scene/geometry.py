@@ -44,26 +44,65 @@ def _close(a, b, tol=1e-9):
   return abs(float(a) - float(b)) <= tol
 
 
+def _half_space(theta_deg, size, source):
+  """the points whose azimuth about the local z axis lies in [theta, theta + 180 deg], as a box large enough to stand for
+  the half-space (its face through the axis is the cutting plane; the others lie outside anything of extent `size`)"""
+  L = 4.0 * float(size)
+  pl = Placement(base=(0.0, 0.0, 0.0), quat=tuple(np.r_[np.array([0.0, 0.0, 1.0]) * np.sin(np.radians(theta_deg) / 2),
+                                                        np.cos(np.radians(theta_deg) / 2)]))
+  return Node('prim', placement=pl * Placement(base=(-L, 0.0, -L)), kind=BOX, params=(2 * L, L, 2 * L, 0.0), source=source)
+
+
+def _swept(prim, angle_deg, size, name):
+  """`prim` (a solid of revolution about its local z axis) cut down to the azimuths [0, angle]: what OpenCASCADE builds
+  for a partial revolution (BRepPrim_OneAxis: the meridian swept counter-clockwise from the local x axis, closed by two
+  planar faces through the axis).  Up to half a turn that is the common part with two half-spaces -- a conjunction, which
+  the trimming lists of the flat scene hold; beyond half a turn it is a disjunction (inside one half-space OR inside
+  the other), which they do not: such solids need the shape FreeCAD stored with the document."""
+  a = float(angle_deg)
+  if _close(a, 360):
+    return prim
+  if not 0 < a <= 180 + 1e-9:
+    raise UnsupportedGeometry(f'{name}: a revolution of {a} degrees (more than half a turn) is a disjunction of half-spaces: needs FreeCAD')
+  kids = [prim, _half_space(0.0, size, name)]
+  if not _close(a, 180):
+    kids.append(_half_space(a - 180.0, size, name))
+  return Node('common', children=kids, source=name)
+
+
 def _primitive_of(obj):
   t = obj.TypeId
   if t == 'Part::Box':
     return Node('prim', kind=BOX, params=(obj.Length, obj.Width, obj.Height, 0.0), source=obj.Name)
   if t == 'Part::Sphere':
-    if not (_close(obj.Angle1, -90) and _close(obj.Angle2, 90) and _close(obj.Angle3, 360)):
-      raise UnsupportedGeometry(f'{obj.Name}: partial spheres need FreeCAD')
-    return Node('prim', kind=SPHERE, params=(obj.Radius, 0.0, 0.0, 0.0), source=obj.Name)
+    R = float(obj.Radius)
+    prim = Node('prim', kind=SPHERE, params=(R, 0.0, 0.0, 0.0), source=obj.Name)
+    a1, a2 = float(obj.Angle1), float(obj.Angle2)
+    if not (_close(a1, -90) and _close(a2, 90)):
+      # a spherical segment: the sphere between the parallels at latitudes Angle1 and Angle2, closed by the planes of
+      # those parallels (BRepPrim_Sphere: a meridian arc revolved, flat top and bottom)
+      if not -90 - 1e-9 <= a1 < a2 <= 90 + 1e-9:
+        raise UnsupportedGeometry(f'{obj.Name}: sphere latitudes {a1}, {a2}')
+      z1, z2 = R * np.sin(np.radians(max(a1, -90.0))), R * np.sin(np.radians(min(a2, 90.0)))
+      slab = Node('prim', placement=Placement(base=(-2 * R, -2 * R, z1)), kind=BOX, params=(4 * R, 4 * R, z2 - z1, 0.0), source=obj.Name)
+      prim = Node('common', children=[prim, slab], source=obj.Name)
+    swept = _swept(prim, obj.Angle3, R, obj.Name)
+    if swept is not prim and prim.op == 'common':        # (one conjunction, not a nest of them)
+      swept = Node('common', children=prim.children + swept.children[1:], source=obj.Name)
+    return swept
   if t == 'Part::Cylinder':
-    if not _close(obj.Angle, 360):
-      raise UnsupportedGeometry(f'{obj.Name}: cylinder segments need FreeCAD')
-    return Node('prim', kind=CYLINDER, params=(obj.Radius, obj.Height, 0.0, 0.0), source=obj.Name)
+    prim = Node('prim', kind=CYLINDER, params=(obj.Radius, obj.Height, 0.0, 0.0), source=obj.Name)
+    return _swept(prim, obj.Angle, max(float(obj.Radius), float(obj.Height)), obj.Name)
   if t == 'Part::Cone':
-    if not _close(obj.Angle, 360):
-      raise UnsupportedGeometry(f'{obj.Name}: cone segments need FreeCAD')
-    return Node('prim', kind=CONE, params=(obj.Radius1, obj.Radius2, obj.Height, 0.0), source=obj.Name)
+    prim = Node('prim', kind=CONE, params=(obj.Radius1, obj.Radius2, obj.Height, 0.0), source=obj.Name)
+    return _swept(prim, obj.Angle, max(float(obj.Radius1), float(obj.Radius2), float(obj.Height)), obj.Name)
   if t == 'Part::Torus':
-    if not (_close(obj.Angle1, -180) and _close(obj.Angle2, 180) and _close(obj.Angle3, 360)):
-      raise UnsupportedGeometry(f'{obj.Name}: partial tori need FreeCAD')
-    return Node('prim', kind=TORUS, params=(obj.Radius1, obj.Radius2, 0.0, 0.0), source=obj.Name)
+    if not (_close(obj.Angle1, -180) and _close(obj.Angle2, 180)):
+      # (a tube that is not closed: what OpenCASCADE closes it with -- planes from the arc's ends to the axis -- makes a
+      #  solid that is not a torus any more; not derived here)
+      raise UnsupportedGeometry(f'{obj.Name}: tori with an open tube section need FreeCAD')
+    prim = Node('prim', kind=TORUS, params=(obj.Radius1, obj.Radius2, 0.0, 0.0), source=obj.Name)
+    return _swept(prim, obj.Angle3, float(obj.Radius1) + float(obj.Radius2), obj.Name)
   if t == 'Part::FeaturePython' and obj.ProxyClass == 'Paraboloid':
     # solid paraboloid of revolution x^2 + y^2 <= 4 f z, z <= Height (freecad_elements.make.makeParaboloid;
     # FreeCAD has no such primitive: there it is the revolution of a parabola about its axis)

@@ -195,3 +195,62 @@ def test_huge_array_lattice_equals_the_stored_placement_lists():
     for a, n in ((0, 10), (1, 10), (2, 5)):
       u = np.unique(c[:, a])
       assert len(u) == n and np.allclose(np.diff(u), 5.0, rtol=0, atol=1e-12)
+
+
+def _partial(doc, kind, name, **props):
+  """a Part primitive with the angles FreeCAD's property editor offers"""
+  base = dict(Sphere=dict(Radius=5.0, Angle1=-90.0, Angle2=90.0, Angle3=360.0), Cylinder=dict(Radius=2.0, Height=10.0, Angle=360.0),
+              Cone=dict(Radius1=2.0, Radius2=4.0, Height=10.0, Angle=360.0), Torus=dict(Radius1=10.0, Radius2=2.0, Angle1=-180.0, Angle2=180.0, Angle3=360.0))[kind]
+  base.update(props)
+  return doc.addObject(f'Part::{kind}', name, Placement=Placement(), **base)
+
+
+def test_partial_revolutions_as_exact_csg(backend):
+  """Part::Sphere Angle1 / 2 / 3, Part::Cylinder / Cone Angle, Part::Torus Angle3 up to half a turn (the reference gets
+  these from OpenCASCADE, raytracing_cache.py:92-111: a meridian revolved counter-clockwise from the local x axis, closed by
+  planes through the axis; a sphere's latitudes closed by the planes of its parallels): crossings at their closed forms"""
+  # spherical segment between latitudes 0 and 60 degrees (flat base at z = 0, flat top at z = R sin 60), swept 90 degrees
+  R = 5.0
+  sc, lim = _scene(lambda d: [_partial(d, 'Sphere', 'S', Radius=R, Angle1=0.0, Angle2=60.0, Angle3=90.0)])
+  zt = R * np.sin(np.radians(60.0))
+  O = [[1.0, 1.0, -10.0], [1.0, 1.0, 10.0], [-10.0, 1.5, 1.0], [1.5, -10.0, 1.0], [3.5, 3.0, -10.0], [-1.0, 1.0, -10.0], [2.0, 2.0, 20.0]]
+  D = [[0, 0, 1.0], [0, 0, -1.0], [1.0, 0, 0], [0, 1.0, 0], [0, 0, 1.0], [0, 0, 1.0], [0, 0, -1.0]]
+  zs = lambda x, y: np.sqrt(R * R - x * x - y * y)
+  want = [np.array([[1, 1, 0.0], [1, 1, zt]]), np.array([[1, 1, zt], [1, 1, 0.0]]),
+          np.array([[0.0, 1.5, 1.0], [np.sqrt(R * R - 1.5**2 - 1.0), 1.5, 1.0]]),          # enters through the plane x = 0 (phi = 90)
+          np.array([[1.5, 0.0, 1.0], [1.5, np.sqrt(R * R - 1.5**2 - 1.0), 1.0]]),          # enters through the plane y = 0 (phi = 0)
+          np.array([[3.5, 3.0, 0.0], [3.5, 3.0, zs(3.5, 3.0)]]),                            # leaves through the sphere below the top plane
+          np.zeros((0, 3)),                                                                  # outside the wedge
+          np.array([[2.0, 2.0, zs(2.0, 2.0)], [2.0, 2.0, 0.0]])]
+  got = _crossings(backend, sc, lim, O, D)
+  for k, (g, w) in enumerate(zip(got, want)):
+    assert len(g) == len(w) and (len(w) == 0 or np.abs(g - w).max() < TOL), (k, g, w)
+  # half a cylinder (Angle 180: y >= 0) and a third of a cone (Angle 120)
+  sc, lim = _scene(lambda d: [_partial(d, 'Cylinder', 'C', Radius=2.0, Height=10.0, Angle=180.0)])
+  got = _crossings(backend, sc, lim, [[0.5, -5.0, 3.0], [0.5, 1.0, -5.0], [0.5, -1.0, -5.0]], [[0, 1.0, 0], [0, 0, 1.0], [0, 0, 1.0]])
+  assert np.abs(got[0] - np.array([[0.5, 0.0, 3.0], [0.5, np.sqrt(4 - 0.25), 3.0]])).max() < TOL
+  assert np.abs(got[1] - np.array([[0.5, 1.0, 0.0], [0.5, 1.0, 10.0]])).max() < TOL and len(got[2]) == 0
+  sc, lim = _scene(lambda d: [_partial(d, 'Cone', 'K', Radius1=2.0, Radius2=4.0, Height=10.0, Angle=120.0)])
+  c, s_ = np.cos(np.radians(120.0)), np.sin(np.radians(120.0))
+  # along +z at azimuth 60 degrees, rho = 1; across at z = 5 from outside: through the side (rho = 3) and out through the
+  # plane at phi = 0 (y = 0)
+  p60 = np.array([np.cos(np.radians(60.0)), np.sin(np.radians(60.0))])
+  got = _crossings(backend, sc, lim, [[p60[0], p60[1], -5.0], [1.0, 10.0, 5.0], [-1.0, -0.5, -5.0]], [[0, 0, 1.0], [0, -1.0, 0], [0, 0, 1.0]])
+  assert np.abs(got[0] - np.array([[p60[0], p60[1], 0.0], [p60[0], p60[1], 10.0]])).max() < TOL
+  assert np.abs(got[1] - np.array([[1.0, np.sqrt(9.0 - 1.0), 5.0], [1.0, 0.0, 5.0]])).max() < TOL and len(got[2]) == 0
+  # a quarter of a torus (Angle3 90): across the tube at azimuth 45 degrees
+  sc, lim = _scene(lambda d: [_partial(d, 'Torus', 'T', Radius1=10.0, Radius2=2.0, Angle3=90.0)])
+  u = np.array([np.sqrt(0.5), np.sqrt(0.5), 0.0])
+  got = _crossings(backend, sc, lim, [20.0 * u, -20.0 * u + [0, 0, 0.0], [10.0, -5.0, 0.5]], [-u, u, [0, 1.0, 0]])
+  assert np.abs(got[0] - np.array([12.0 * u, 8.0 * u])).max() < TOL
+  assert np.abs(got[1] - np.array([8.0 * u, 12.0 * u])).max() < TOL                        # (the far quarter does not exist)
+  w = np.sqrt(4.0 - 0.25)
+  assert np.abs(got[2] - np.array([[10.0, 0.0, 0.5], [10.0, np.sqrt((10 + w)**2 - 100.0), 0.5]])).max() < TOL   # in through the plane y = 0
+
+
+def test_partial_revolutions_beyond_half_a_turn_are_refused():
+  from freecad.optics_design_workbench_amd.scene.geometry import UnsupportedGeometry
+  for kind, props in (('Sphere', dict(Angle3=270.0)), ('Cylinder', dict(Angle=200.0)), ('Torus', dict(Angle1=-90.0, Angle2=90.0)),
+                      ('Sphere', dict(Angle1=10.0, Angle2=5.0))):
+    with pytest.raises(UnsupportedGeometry):
+      _scene(lambda d: [_partial(d, kind, 'X', **props)])
