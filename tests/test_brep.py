@@ -384,14 +384,14 @@ def test_stored_shape_stands_in_where_the_recipe_ends(oracle):
   doc = open_fcstd(os.path.join(SCENES, 'nested-structure.FCStd'))
   sphere = doc.getObject('Sphere')
   assert geometry.solids_of(sphere)[0].op == 'prim'
-  sphere._props['Angle3'] = 180.0                 # as if the file had been saved with a half sphere
+  sphere._props['Angle3'] = 270.0                 # as if the file had been saved with three quarters of a sphere
   node, = geometry.solids_of(sphere)              # the stored shape (here still the full sphere), recognised
   assert node.op == 'prim' and node.kind == geometry.SPHERE and node.source == 'Sphere'
   assert np.allclose((node.placement).Base, sphere.Placement.Base)
   sphere.Placement = sphere.Placement             # placements do not invalidate stored shapes
   assert geometry.solids_of(sphere)[0].kind == geometry.SPHERE
   sphere.Radius = 4.0                             # ... shape-defining properties do
-  with pytest.raises(UnsupportedGeometry, match='partial spheres'):
+  with pytest.raises(UnsupportedGeometry, match='half a turn'):
     geometry.solids_of(sphere)
 
 

@@ -122,9 +122,12 @@ def test_unsupported_geometry_is_loud():
   from freecad.optics_design_workbench_amd.scene import Document, UnsupportedGeometry
   from freecad.optics_design_workbench_amd.scene import geometry
   doc = Document()
-  o = doc.addObject('Part::Sphere', 'S', Radius=1.0, Angle1=-90.0, Angle2=90.0, Angle3=180.0)
-  with pytest.raises(UnsupportedGeometry):
-    geometry.solids_of(o)
+  o = doc.addObject('Part::Sphere', 'S', Radius=1.0, Angle1=-90.0, Angle2=90.0, Angle3=270.0)
+  with pytest.raises(UnsupportedGeometry, match='half a turn'):
+    geometry.solids_of(o)                           # (more than half a turn: a disjunction of half-spaces)
+  h = doc.addObject('Part::Sphere', 'H', Radius=1.0, Angle1=-90.0, Angle2=90.0, Angle3=180.0)
+  node, = geometry.solids_of(h)                     # (half a turn and less: exact CSG since round 5)
+  assert node.op == 'common' and [c.kind for c in node.children] == [geometry.SPHERE, geometry.BOX]
   f = doc.addObject('Part::Feature', 'Imported')
   with pytest.raises(UnsupportedGeometry):
     geometry.solids_of(f)
