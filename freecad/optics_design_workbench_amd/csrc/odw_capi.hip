@@ -51,7 +51,7 @@ constexpr int kSurfaceGuide = 1 << 10;  // per row of a surface sampler (tables 
 // (scripts/bench_lens_train.py, scripts/bench_crowded.py).  ODW_BVH_THRESHOLD (read when a context is created)
 // overrides it: the tests keep the grid kernel's generic variant covered with 16.
 constexpr int kBvhThreshold = 64;
-const int kBvhLeaf = [] { const char* e = getenv("ODW_BVH_LEAF"); const int v = e ? atoi(e) : 0; return v > 0 && v < 200 ? v : 8; }();   // largest leaf the SAH may form (measured: 8 >= 4 > 2 > 1 on meshes)
+const int kBvhLeaf = [] { const char* e = getenv("ODW_BVH_LEAF"); const int v = e ? atoi(e) : 0; return v > 0 && v < 200 ? v : 8; }();   // largest leaf the SAH may form (measured: 8 >= 4 > 2 > 1 on meshes; round 5, mesh kernel at 1e6 facets: 8 / 6 / 4 / 3 / 2 / 1 = 7.70 / 7.73 / 7.84 / 7.95 / 8.16 / 9.04 ms -- candidates per segment 18 -> 8, node visits 11.7 -> 14.7)
 constexpr int kBvhSweepMax = 2048;       // nodes with more primitives use binned SAH
 
 std::string g_error;
@@ -1545,8 +1545,8 @@ void odw_destroy(odw_ctx* ctx) {
   if (ctx->dbg.p) {
     uint64_t v[32] = {0};
     (void)hipMemcpy(v, ctx->dbg.p, sizeof v, hipMemcpyDeviceToHost);
-    const char* names[6] = {"A ring fills", "B segment setup", "C cell steps", "D all", "D resolve", "D interact"};
-    for (int k = 0; k < 6; ++k)
+    const char* names[8] = {"A ring fills", "B segment setup", "C cell steps", "D all", "D resolve", "D interact", "candidates", "passed"};
+    for (int k = 0; k < 8; ++k)
       fprintf(stderr, "[odw grid stats] %-16s runs %12llu  lanes %14llu  (%.1f per run)\n", names[k], (unsigned long long)v[2 * k],
               (unsigned long long)v[2 * k + 1], v[2 * k] ? (double)v[2 * k + 1] / (double)v[2 * k] : 0.0);
     // (mesh kernel, ODW_MESH_STATS: clock ticks of s_memtime every wave spent in each phase, waits included)

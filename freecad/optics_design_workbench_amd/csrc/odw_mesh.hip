@@ -68,11 +68,162 @@ namespace odw {
   } while (0)
 // time per phase: s_memtime ticks between marks, kept per wave (uniform), added up at the end
 #define ODW_MTIME(k) do { const uint64_t t_ = __builtin_readcyclecounter(); phase_t[(k)] += t_ - t_mark; t_mark = t_; } while (0)
+// a per-lane quantity added up (runs: the lanes that report, lanes: the sum)
+#define ODW_MSUM(k, n_) do { atomicAdd(&wave_cnt[8 + 2 * (k)], 1u); atomicAdd(&wave_cnt[9 + 2 * (k)], (uint32_t)(n_)); } while (0)
 #else
 #define ODW_MSTAT(k, mask_) do {} while (0)
 #define ODW_MTIME(k) do {} while (0)
+#define ODW_MSUM(k, n_) do {} while (0)
 #endif
 #define ODW_MCOUNT(k) atomicAdd(&wave_cnt[(k)], 1u)
+
+// what a lane does at the end of a segment (ray.py:120-268): absorption along the segment, normal, hit row, the new
+// direction, the solid a convex facet lets the ray leave.  A function of its own so that it can be kept out of line
+// (ODW_MESH_INTERACT_INLINE=0; kargs: the kernel's argument segment, as record_hit_flat) -- measured in round 5
+// (1e7 rays, 4e3 / 6.5e4 / 1e6 facets, ms): inlined 4.11 / 4.93 / 7.36 with 47 spilled registers, out of line 4.47 / 5.28 /
+// 7.70 with 22 (the call moves ~50 registers per segment and lane, the spills it saves were not in the hot loops); out of
+// line at four waves per SIMD (ODW_MESH_WAVES=4, still 96 spilled) 5.47 / 6.45 / 9.12.
+#ifndef ODW_MESH_INTERACT_INLINE
+#define ODW_MESH_INTERACT_INLINE 1
+#endif
+struct MeshRay { d3 point, dir; double power; int medium, seq, skip; bool alive; };
+template <bool STOCH>
+#if ODW_MESH_INTERACT_INLINE
+__device__ __forceinline__
+#else
+__device__ __noinline__
+#endif
+MeshRay mesh_interact(ckargs kargs, d3 point, d3 dir, double power, int medium, int seq, int nint, uint64_t i, double t_hit, int prim,
+                      int face, uint32_t* wave_cnt, volatile uint32_t* hit_state, const double* group_f64, const int32_t* group_i32,
+                      const double* group_gdir) {
+  const uint64_t a_ = (uint64_t)(uintptr_t)kargs;
+  const uint64_t u_ = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(a_ >> 32)) << 32) |
+                      (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)a_);
+  const TraceParams ODW_CONST& P = *(ckargs)(uintptr_t)u_;
+  const DeviceScene ODW_CONST& sc = P.scene;
+  const DeviceLimits ODW_CONST& lim = P.lim;
+  SceneView sv;
+  sv.prim_f64 = as_const(sc.prim_f64);
+  sv.prim_hdr = as_const(sc.prim_hdr);
+  sv.prim_i32 = as_const(sc.prim_i32);
+  sv.cond_i32 = as_const(sc.cond_i32);
+  bool alive = true;
+  int skip = -1;
+  {
+        cf64 pf = sv.prim_f64 + (size_t)prim * 16;
+        ci32 pi = sv.prim_i32 + 4 * prim;
+        point = point + dir * t_hit;
+        if (medium >= 0) {                                  // ray.py:120-125 (assignment)
+          const double L = group_f64[4 * medium + 2];
+          if (L == 0) power = 0;
+          else if (L < INFINITY) power = exp(-t_hit / L);
+        }
+        d3 n;
+        if (pi[0] == ODW_PRIM_TRIANGLE) {
+          n = tri_normal(pf, sc.tri_nrm ? sc.tri_nrm + (size_t)prim * 9 : nullptr, point);
+          if (pi[2] & ODW_FLAG_FLIP_NORMAL) n = n * -1.0;
+        } else {
+          n = face_normal<true>(pi[0], pf + 12, face, xf_point(pf, point));
+          if (pi[2] & ODW_FLAG_FLIP_NORMAL) n = n * -1.0;
+          n = xf_vec_t(pf, n);
+        }
+        const bool entering = dot(dir, n) < 0;
+        if (entering) n = n * -1.0;
+        const int g = pi[1];
+        const int gtype = group_i32[4 * g];
+        if (group_i32[4 * g + 1]) {
+          ODW_MCOUNT(ODW_CNT_RECORDED_HITS);
+          record_hit<true, 1, true>(P, P.first_ray + i, g, point, dir, power, entering, wave_cnt, hit_state);
+        }
+        if (gtype == ODW_OPT_MIRROR) {
+          const d3 ideal = mirror(dir, n);
+          if (STOCH) dir = scatter(P.samplers, P.group_sampler[2 * g], P.group_sampler[2 * g + 1], P.first_ray + i, P.seed,
+                                   (uint32_t)nint, dir, ideal, n, 1.0);
+          else dir = ideal;
+          power *= group_f64[4 * g + 1];
+          ++seq;
+        } else if (gtype == ODW_OPT_LENS) {
+          const double n1 = (medium >= 0) ? group_f64[4 * medium] : 1.0;
+          double n2 = 1.0;
+          if (entering) { medium = g; n2 = group_f64[4 * g]; }
+          bool tir;
+          const d3 ideal = snells_law(dir, n1, n2, n, tir);
+          if (STOCH) dir = scatter(P.samplers, P.group_sampler[2 * g], P.group_sampler[2 * g + 1], P.first_ray + i, P.seed,
+                                   (uint32_t)nint, dir, ideal, n, tir ? -1.0 : n1 / n2);
+          else dir = ideal;
+          if (!entering && !tir && medium == g) { medium = -1; ++seq; }
+        } else if (gtype == ODW_OPT_ABSORBER) {
+          power = 0;
+          ++seq;
+        } else if (gtype == ODW_OPT_VACUUM) {
+          ++seq;
+        } else {  // grating (ray.py:216-268)
+          const d3 gd = mk(group_gdir[3 * g], group_gdir[3 * g + 1], group_gdir[3 * g + 2]);
+          const double lpm = group_f64[4 * g + 3];
+          const int order = group_i32[4 * g + 3];
+          if (group_i32[4 * g + 2] == 0) {
+            if (entering) {
+              const double nn = (medium >= 0) ? group_f64[4 * medium] : 1.0;
+              dir = line_grating(dir, nn, nn, n, P.wavelength, order, lpm, gd, false);
+              ++seq;
+            }
+          } else if (entering) {
+            if (medium >= 0) {
+              atomicAdd(P.out.counters + ODW_CNT_GRATING_IN_MEDIUM, 1ull);     // a ValueError of the reference
+              ODW_MCOUNT(ODW_CNT_DIED);
+              alive = false;
+            }
+            medium = g;
+            dir = line_grating(dir, 1.0, group_f64[4 * g], n, P.wavelength, order, lpm, gd, true);
+          } else {
+            const double n1 = (medium >= 0) ? group_f64[4 * medium] : 1.0;
+            bool tir;
+            dir = snells_law(dir, n1, 1.0, n, tir);
+            if (!tir) { medium = -1; ++seq; }
+          }
+        }
+        {
+          // (a facet of a convex tessellated solid: the facet's own normal decides, as in odw_trace_kernel)
+          double out = entering ? -dot(dir, n) : dot(dir, n);
+          if (pi[0] == ODW_PRIM_TRIANGLE) {
+            out = dot(dir, mk(pf[9], pf[10], pf[11]));
+            if (pi[2] & ODW_FLAG_FLIP_NORMAL) out = -out;
+          }
+          skip = ((pi[2] & ODW_FLAG_CONVEX) && out > 0) ? (pi[2] >> ODW_SOLID_SHIFT) : -1;
+        }
+        if (alive && power < lim.power_tol) { ODW_MCOUNT(ODW_CNT_DIED); alive = false; }
+  }
+  MeshRay r;
+  r.point = point; r.dir = dir; r.power = power; r.medium = medium; r.seq = seq; r.skip = skip; r.alive = alive;
+  return r;
+}
+
+// an analytic primitive listed in a leaf (a screen behind the mesh), out of line for the same reason: intersect_prim<>
+// holds every kind of primitive, the quartic of the torus included
+struct MeshBest { Best any, oth; };
+#if ODW_MESH_INTERACT_INLINE
+__device__ __forceinline__
+#else
+__device__ __noinline__
+#endif
+MeshBest mesh_intersect_prim(ckargs kargs, d3 start, d3 dn, double tol, double tmax, int medium, Best any, Best oth, int p) {
+  const uint64_t a_ = (uint64_t)(uintptr_t)kargs;
+  const uint64_t u_ = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(a_ >> 32)) << 32) |
+                      (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)a_);
+  const DeviceScene ODW_CONST& sc = ((ckargs)(uintptr_t)u_)->scene;
+  SceneView sv;
+  sv.prim_f64 = as_const(sc.prim_f64);
+  sv.prim_hdr = as_const(sc.prim_hdr);
+  sv.prim_i32 = as_const(sc.prim_i32);
+  sv.cond_i32 = as_const(sc.cond_i32);
+  Query q;
+  q.start = start; q.dn = dn; q.tol = tol; q.tmax = tmax; q.medium = medium; q.any = any; q.oth = oth;
+  ci32 pi = sv.prim_i32 + 4 * p;
+  intersect_prim<true>(sv, q, p, pi[0], pi[1], pi[2], pi[3]);
+  MeshBest r;
+  r.any = q.any; r.oth = q.oth;
+  return r;
+}
 
 // STOCH: the scene has stochastic surfaces (scatter() after the ideal mirror / Snell direction, as in interact<>)
 template <bool STOCH>
@@ -375,6 +526,7 @@ __global__ __launch_bounds__(ODW_MESH_THREADS, ODW_MESH_WAVES) void odw_mesh_ker
           cand |= ((1ull << cnt) - 1ull) << ((pairs * 0x01010101u) >> 24);
         }
       }
+      ODW_MSUM(6, __popcll(cand));
       cf32 rec0 = leaves + (size_t)lbase * ODW_LEAF_WORDS;
       const auto filter = [&](vf4 w0, vf4 w1, vf4 w2) -> bool {
         // w0: v0x v0y v0z e1x, w1: e1y e1z e2x e2y, w2: e2z gs smax err.  Geometry only: whether the facet's group is
@@ -428,6 +580,7 @@ __global__ __launch_bounds__(ODW_MESH_THREADS, ODW_MESH_WAVES) void odw_mesh_ker
           pass |= (on[j] && filter(w[j][0], w[j][1], w[j][2])) ? (1ull << kk[j]) : 0ull;
       }
       ODW_MSTAT(4, __ballot(pass != 0ull));
+      ODW_MSUM(7, __popcll(pass));
       while (pass) {
         const int k = __ffsll((unsigned long long)pass) - 1;
         pass &= pass - 1ull;
@@ -436,8 +589,9 @@ __global__ __launch_bounds__(ODW_MESH_THREADS, ODW_MESH_WAVES) void odw_mesh_ker
         const uint32_t gs = __float_as_uint(rec[9]);
         if (!(((mask >> (gs & 0xff)) & 1) && (int)((gs >> 8) & 0x7fff) != skip)) continue;
         if (gs >> 31) {
-          ci32 pi = sv.prim_i32 + 4 * p;
-          intersect_prim<true>(sv, q, p, pi[0], pi[1], pi[2], pi[3]);
+          const MeshBest b = mesh_intersect_prim((ckargs)__builtin_amdgcn_kernarg_segment_ptr(), q.start, q.dn, q.tol, q.tmax, q.medium,
+                                                 q.any, q.oth, p);
+          q.any = b.any; q.oth = b.oth;
         } else {
           intersect_tri(sv, q, p, (int)(gs & 0xff));
         }
@@ -467,91 +621,10 @@ __global__ __launch_bounds__(ODW_MESH_THREADS, ODW_MESH_WAVES) void odw_mesh_ker
         alive = false;
       } else {
         const bool use_oth = q.oth.prim != 0x7fffffff && q.oth.t < q.any.t + 2.0 * q.tol;
-        const double t_hit = use_oth ? q.oth.t : q.any.t;
-        const int face = use_oth ? q.oth.face : q.any.face;
-        const int prim = use_oth ? q.oth.prim : q.any.prim;
-        cf64 pf = sv.prim_f64 + (size_t)prim * 16;
-        ci32 pi = sv.prim_i32 + 4 * prim;
-        point = point + dir * t_hit;
-        if (medium >= 0) {                                  // ray.py:120-125 (assignment)
-          const double L = group_f64[4 * medium + 2];
-          if (L == 0) power = 0;
-          else if (L < INFINITY) power = exp(-t_hit / L);
-        }
-        d3 n;
-        if (pi[0] == ODW_PRIM_TRIANGLE) {
-          n = tri_normal(pf, sc.tri_nrm ? sc.tri_nrm + (size_t)prim * 9 : nullptr, point);
-          if (pi[2] & ODW_FLAG_FLIP_NORMAL) n = n * -1.0;
-        } else {
-          n = face_normal<true>(pi[0], pf + 12, face, xf_point(pf, point));
-          if (pi[2] & ODW_FLAG_FLIP_NORMAL) n = n * -1.0;
-          n = xf_vec_t(pf, n);
-        }
-        const bool entering = dot(dir, n) < 0;
-        if (entering) n = n * -1.0;
-        const int g = pi[1];
-        const int gtype = group_i32[4 * g];
-        if (group_i32[4 * g + 1]) {
-          ODW_MCOUNT(ODW_CNT_RECORDED_HITS);
-          record_hit<true, 1, true>(P, P.first_ray + i, g, point, dir, power, entering, wave_cnt, hit_state);
-        }
-        if (gtype == ODW_OPT_MIRROR) {
-          const d3 ideal = mirror(dir, n);
-          if (STOCH) dir = scatter(P.samplers, P.group_sampler[2 * g], P.group_sampler[2 * g + 1], P.first_ray + i, P.seed,
-                                   (uint32_t)nint, dir, ideal, n, 1.0);
-          else dir = ideal;
-          power *= group_f64[4 * g + 1];
-          ++seq;
-        } else if (gtype == ODW_OPT_LENS) {
-          const double n1 = (medium >= 0) ? group_f64[4 * medium] : 1.0;
-          double n2 = 1.0;
-          if (entering) { medium = g; n2 = group_f64[4 * g]; }
-          bool tir;
-          const d3 ideal = snells_law(dir, n1, n2, n, tir);
-          if (STOCH) dir = scatter(P.samplers, P.group_sampler[2 * g], P.group_sampler[2 * g + 1], P.first_ray + i, P.seed,
-                                   (uint32_t)nint, dir, ideal, n, tir ? -1.0 : n1 / n2);
-          else dir = ideal;
-          if (!entering && !tir && medium == g) { medium = -1; ++seq; }
-        } else if (gtype == ODW_OPT_ABSORBER) {
-          power = 0;
-          ++seq;
-        } else if (gtype == ODW_OPT_VACUUM) {
-          ++seq;
-        } else {  // grating (ray.py:216-268)
-          const d3 gd = mk(group_gdir[3 * g], group_gdir[3 * g + 1], group_gdir[3 * g + 2]);
-          const double lpm = group_f64[4 * g + 3];
-          const int order = group_i32[4 * g + 3];
-          if (group_i32[4 * g + 2] == 0) {
-            if (entering) {
-              const double nn = (medium >= 0) ? group_f64[4 * medium] : 1.0;
-              dir = line_grating(dir, nn, nn, n, P.wavelength, order, lpm, gd, false);
-              ++seq;
-            }
-          } else if (entering) {
-            if (medium >= 0) {
-              atomicAdd(P.out.counters + ODW_CNT_GRATING_IN_MEDIUM, 1ull);     // a ValueError of the reference
-              ODW_MCOUNT(ODW_CNT_DIED);
-              alive = false;
-            }
-            medium = g;
-            dir = line_grating(dir, 1.0, group_f64[4 * g], n, P.wavelength, order, lpm, gd, true);
-          } else {
-            const double n1 = (medium >= 0) ? group_f64[4 * medium] : 1.0;
-            bool tir;
-            dir = snells_law(dir, n1, 1.0, n, tir);
-            if (!tir) { medium = -1; ++seq; }
-          }
-        }
-        {
-          // (a facet of a convex tessellated solid: the facet's own normal decides, as in odw_trace_kernel)
-          double out = entering ? -dot(dir, n) : dot(dir, n);
-          if (pi[0] == ODW_PRIM_TRIANGLE) {
-            out = dot(dir, mk(pf[9], pf[10], pf[11]));
-            if (pi[2] & ODW_FLAG_FLIP_NORMAL) out = -out;
-          }
-          skip = ((pi[2] & ODW_FLAG_CONVEX) && out > 0) ? (pi[2] >> ODW_SOLID_SHIFT) : -1;
-        }
-        if (alive && power < lim.power_tol) { ODW_MCOUNT(ODW_CNT_DIED); alive = false; }
+        const MeshRay r = mesh_interact<STOCH>((ckargs)__builtin_amdgcn_kernarg_segment_ptr(), point, dir, power, medium, seq, nint, i,
+                                               use_oth ? q.oth.t : q.any.t, use_oth ? q.oth.prim : q.any.prim,
+                                               use_oth ? q.oth.face : q.any.face, wave_cnt, hit_state, group_f64, group_i32, group_gdir);
+        point = r.point; dir = r.dir; power = r.power; medium = r.medium; seq = r.seq; skip = r.skip; alive = r.alive;
         fresh = alive;
       }
       if (!alive) {
@@ -575,7 +648,7 @@ __global__ __launch_bounds__(ODW_MESH_THREADS, ODW_MESH_WAVES) void odw_mesh_ker
     if (__lane_id() == 0 && in_buf) atomicAdd(P.out.hit_count + 1, (unsigned long long)in_buf);
   }
 #ifdef ODW_MESH_STATS
-  if (lane < 12 && P.dbg) atomicAdd(P.dbg + lane, (unsigned long long)wave_cnt[8 + lane]);
+  if (lane < 16 && P.dbg) atomicAdd(P.dbg + lane, (unsigned long long)wave_cnt[8 + lane]);
   if (lane == 0 && P.dbg)
     for (int k = 0; k < 6; ++k) atomicAdd(P.dbg + 16 + k, (unsigned long long)phase_t[k]);
 #endif
