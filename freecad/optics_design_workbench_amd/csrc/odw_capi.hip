@@ -142,7 +142,7 @@ struct odw_ctx {
   // batch launches (odw_upload_scene_batch / odw_trace_batch): the value tables of batch_n scenes of one structure side by
   // side, one segment of the batch's hit list and one pair of counters per scene.  odw_batch_select makes a segment the
   // context's hit list (ctx->hits / hit_count become views; the context's own list waits in own_*)
-  DevBuf batch_values, batch_hits, batch_hit_count;
+  DevBuf batch_values, batch_hits, batch_hit_count, batch_rays_buf;
   int batch_n = 0;                         // scenes of the uploaded batch (0: none)
   size_t batch_prims = 0;                  // primitives per scene of that batch
   bool batch_launch = false;               // launch_trace: this launch is a batch
@@ -1333,6 +1333,26 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
     P.batch.chunks_per_scene = (uint32_t)cps;
     P.batch.n_scenes = (uint32_t)ctx->batch_traced;
     n_chunks = cps * (uint64_t)ctx->batch_traced;
+    // the batch's rays once, for all its scenes (from three scenes on: the pass writes 24 bytes per ray -- 48 where the
+    // origins differ -- and every scene reads them; ODW_BATCH_SHARED_RAYS=0: every scene generates its own, =1: always)
+    P.batch.gen_dirs = P.batch.gen_origins = nullptr;
+    P.batch.gen_stride = 0;
+    static const int shared_mode = [] { const char* e = getenv("ODW_BATCH_SHARED_RAYS"); return e ? atoi(e) : -1; }();
+    if (shared_mode != 0 && (ctx->batch_traced >= 3 || shared_mode == 1)) {
+      const bool one_origin = ctx->h_source.finite_focal && ctx->h_source.focal_length == 0.0;
+      const uint64_t gs = (n + 31) / 32 * 32;
+      const size_t bytes = (size_t)(gs * (one_origin ? 3 : 6) + 4) * sizeof(double);
+      // (sized by odw_batch_reserve before a sweep; here only if nobody did: a launch without the pass is still right)
+      if (ctx->batch_rays_buf.bytes >= bytes || ensure(ctx, ctx->batch_rays_buf, bytes) == ODW_OK) {
+        double* dirs = (double*)ctx->batch_rays_buf.p;
+        double* orgs = one_origin ? nullptr : dirs + 3 * gs + 4;
+        P.batch.gen_dirs = dirs;                    // (the pass itself: below, inside the launch's timed interval)
+        P.batch.gen_origins = orgs;
+        P.batch.gen_stride = gs;
+      } else {
+        ctx->err.clear();
+      }
+    }
   }
   // Batch launches share the GPU with the post-hoc chains of other contexts (a sweep keeps several groups in flight): three
   // blocks per CU instead of all four leave a quarter of every SIMD's registers to their kernels and to the runtime's copy
@@ -1362,6 +1382,11 @@ int launch_trace(odw_ctx* ctx, uint64_t first, uint64_t n, uint64_t seed, uint32
       HIPCHK(ctx, hipEventCreate(&ev.second));
     }
     HIPCHK(ctx, hipEventRecord(ev.first, ctx->stream));
+  }
+  if (batch && P.batch.gen_dirs) {
+    const unsigned gb = (unsigned)std::min<uint64_t>((n + 255) / 256, (uint64_t)ctx->n_cu * 16);
+    hipLaunchKernelGGL(odw_batch_rays_kernel, dim3(gb), dim3(256), 0, ctx->stream, P.source, first, n, seed,
+                       const_cast<double*>(P.batch.gen_dirs), const_cast<double*>(P.batch.gen_origins), P.batch.gen_stride);
   }
   const bool stoch = ctx->n_samplers > 0;
   P.ray_order = nullptr;
@@ -1593,6 +1618,7 @@ void odw_destroy(odw_ctx* ctx) {
   release(ctx->archive);
   release(ctx->archive_count);
   release(ctx->batch_values);
+  release(ctx->batch_rays_buf);
   release(ctx->batch_hits);
   release(ctx->batch_hit_count);
   if (ctx->phb_pin_p) (void)hipHostFree(ctx->phb_pin_p);
@@ -2388,6 +2414,8 @@ int odw_batch_reserve(odw_ctx* ctx, int32_t n_scenes, uint64_t rays_per_scene, u
   if (!rc) rc = phb_reserve(ctx, (int)S, rays_per_scene, slots);
   if (!rc && rows_per_scene && rays_per_scene <= (1ull << 28) && !(getenv("ODW_BATCH_PTS") && getenv("ODW_BATCH_PTS")[0] == '0'))
     rc = ensure(ctx, ctx->phb_pts, S * slots * 3 * sizeof(double));
+  // (the rays generated once per launch, DeviceBatch.gen_dirs: with origins, whatever the source will be)
+  if (!rc && S >= 3) rc = ensure(ctx, ctx->batch_rays_buf, (size_t)((rays_per_scene + 31) / 32 * 32 * 6 + 4) * sizeof(double));
   return rc;
 }
 

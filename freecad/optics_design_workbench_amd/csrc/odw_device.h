@@ -187,6 +187,13 @@ struct DeviceBatch {
   uint64_t stride;              // doubles between the value tables of consecutive scenes
   uint32_t chunks_per_scene;
   uint32_t n_scenes;            // 0: not a batch launch
+  // every scene of a batch traces the SAME rays (one source, one seed, the same ray numbers): their initial conditions
+  // are generated once, by a pass before the launch, and read here -- component-major directions (x of every ray, then
+  // y, z: gen_stride doubles apart), then three doubles of the common origin (a source at its focus); gen_origins: the
+  // origins the same way where they differ from ray to ray.  Null: every scene generates its rays itself.
+  const double* gen_dirs;
+  const double* gen_origins;
+  uint64_t gen_stride;
 };
 
 // Kernel argument.  The source and detector blocks live in device memory and

@@ -1788,6 +1788,14 @@ __device__ __forceinline__ void trace_body(const TraceParams& P) {
           dir = mk(P.ray_dirs[i], P.ray_dirs[P.ray_stride + i], P.ray_dirs[2 * P.ray_stride + i]);
           dir = dir * (1.0 / sqrt(dot(dir, dir)));
           power = P.ray_powers ? P.ray_powers[i] : 1.0;
+        } else if (BATCH && P.batch.gen_dirs) {
+          // (generated once for all scenes of the batch, odw_batch_rays_kernel: the values generate_ray() returns)
+          const double* gd = P.batch.gen_dirs;
+          const uint64_t gs = P.batch.gen_stride;
+          dir = mk(gd[i], gd[gs + i], gd[2 * gs + i]);
+          if (P.batch.gen_origins) point = mk(P.batch.gen_origins[i], P.batch.gen_origins[gs + i], P.batch.gen_origins[2 * gs + i]);
+          else point = mk(gd[3 * gs], gd[3 * gs + 1], gd[3 * gs + 2]);
+          power = as_const(P.source)->power;
         } else {
           const RayInit r = generate_ray(P.source, P.first_ray + i, P.seed);
           point = r.point; dir = r.dir; power = r.power;
@@ -2115,6 +2123,19 @@ __global__ __launch_bounds__(256) void odw_rays_to_components_kernel(const doubl
     const uint64_t ray = i / 3, c = i - 3 * ray;           // (reads are contiguous, writes three interleaved streams)
     o_out[c * n + ray] = o_in[i];
     d_out[c * n + ray] = d_in[i];
+  }
+}
+
+// the rays of a batch launch, generated once for all its scenes (DeviceBatch.gen_dirs): exactly generate_ray()'s values
+__global__ __launch_bounds__(256) void odw_batch_rays_kernel(const DeviceSource* sp, uint64_t first, uint64_t n, uint64_t seed,
+                                                             double* __restrict__ dirs, double* __restrict__ origins,
+                                                             uint64_t stride) {
+  const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += step) {
+    const RayInit r = generate_ray(sp, first + i, seed);
+    dirs[i] = r.dir.x; dirs[stride + i] = r.dir.y; dirs[2 * stride + i] = r.dir.z;
+    if (origins) { origins[i] = r.point.x; origins[stride + i] = r.point.y; origins[2 * stride + i] = r.point.z; }
+    else if (i == 0) { dirs[3 * stride] = r.point.x; dirs[3 * stride + 1] = r.point.y; dirs[3 * stride + 2] = r.point.z; }
   }
 }
 

@@ -226,6 +226,7 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
   batch_ok = [True]
   samples = {}
   tail_size = [None]
+  taper = int(os.environ.get('ODW_SWEEP_TAPER', '0'))
 
   def measureInto(t, scene, k):
     t_m = time.perf_counter() if clock is not None else 0.0
@@ -448,8 +449,13 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
       if pos < len(mine) and free and batch_ok[0]:
         # (the first groups are small, so that chains start early; the last ones shrink, so that the contexts end together)
         left = len(mine) - pos
-        if group_size > 2 and tail_size[0] is None and left < group_size * len(lanes):
-          tail_size[0] = max(2, -(-left // len(lanes)))
+        # (ODW_SWEEP_TAPER = d > 0: every group of the tail takes 1 / d of what is left, so that the last chain -- whose
+        #  plane search and measuring nothing else overlaps with -- belongs to two values; 0: the tail in equal groups)
+        if group_size > 2 and left < group_size * len(lanes):
+          if taper > 0:
+            tail_size[0] = max(2, -(-left // taper))
+          elif tail_size[0] is None:
+            tail_size[0] = max(2, -(-left // len(lanes)))
         size = group_size if group_size <= 2 else min(group_size, 2 << turn if turn < 3 else group_size, tail_size[0] or group_size)
         ks = mine[pos:pos + size]
         turn += 1

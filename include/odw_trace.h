@@ -543,7 +543,9 @@ int odw_build_check(const odw_scene_desc* scene, const odw_limits* limits, int32
  * primitives, no stochastic surfaces).
  * odw_trace_batch traces rays first_ray ... first_ray + rays_per_scene - 1 in
  * EVERY scene (the rows of a scene are those of odw_trace on that scene
- * alone, tags included); a scene's rows go to its own segment of the batch's
+ * alone, tags included -- the scenes share their rays, so from three scenes
+ * on their initial conditions are generated once per launch and read by
+ * every scene, instead of once per scene); a scene's rows go to its own segment of the batch's
  * hit list (room for rows_per_scene rows each); counters add up over the
  * scenes; no detector histogram.  odw_batch_select makes a segment the
  * context's hit list for odw_hit_count / odw_fetch_hits / odw_hits_* (scene
