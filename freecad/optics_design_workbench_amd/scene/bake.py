@@ -358,6 +358,8 @@ def bakeScene(doc, source=None, surfaceFamily=None):
     tri_group[at:at + k], tri_solid[at:at + k] = gi, sid
     if convex:                                     # (ODW_FLAG_CONVEX: as for convex analytic solids)
       tri_flags[at:at + k] |= 2
+    if convex == 2:                                # (ODW_FLAG_STRICTLY_CONVEX: geometry.mesh_convexity)
+      tri_flags[at:at + k] |= 8
     if tri_normals is not None:
       if vn is not None:
         tri_normals[n + at:n + at + k] = vn[tri].reshape(k, 9)

@@ -362,7 +362,17 @@ def is_convex(node):
 
 
 def mesh_is_convex(vertices, triangles):
-  """is the tessellated shape the boundary of a convex solid, facets counter-clockwise seen from outside?  A closed
+  """`mesh_convexity` as a yes / no"""
+  return mesh_convexity(vertices, triangles) > 0
+
+
+def mesh_convexity(vertices, triangles):
+  """0: not (known to be) convex; 1: convex by the test below, whose edges may bend OUTWARD by up to 1e-9 of the mesh's
+  size (what many small bends add up to across a fine mesh is not bounded by it); 2: no edge bends outward by more than
+  rounding (1e-13 of the size) -- the polyhedron is convex as it stands, every point of a facet lies on or below the
+  plane of every other facet up to rounding (ODW_FLAG_STRICTLY_CONVEX: the mesh kernel's normal cones rely on it).
+
+  Is the tessellated shape the boundary of a convex solid, facets counter-clockwise seen from outside?  A closed
   surface (every edge in exactly two facets, once in each direction, after welding coincident vertices -- seams,
   poles) whose edges are all convex (the vertex opposite the edge in one facet is not above the plane of the other)
   bounds a convex body; the enclosed volume is positive for outward facets.  Facets without area (pole fans) are left
@@ -371,10 +381,10 @@ def mesh_is_convex(vertices, triangles):
   v = np.asarray(vertices, dtype=np.float64).reshape(-1, 3)
   tri = np.asarray(triangles, dtype=np.int64).reshape(-1, 3)
   if len(tri) < 4:
-    return False
+    return 0
   size = float(np.ptp(v, axis=0).max())
   if not size > 0:
-    return False
+    return 0
   q = np.round(v / (1e-9 * size)).astype(np.int64)
   o = np.lexsort((q[:, 2], q[:, 1], q[:, 0]))
   first = np.ones(len(q), dtype=bool)
@@ -388,7 +398,7 @@ def mesh_is_convex(vertices, triangles):
   keep = (area2 > 1e-14 * size * size) & (t[:, 0] != t[:, 1]) & (t[:, 1] != t[:, 2]) & (t[:, 2] != t[:, 0])
   t, a, nrm, area2 = t[keep], a[keep], nrm[keep], area2[keep]
   if len(t) < 4:
-    return False
+    return 0
   # directed edges (from, to) with their facet and the vertex opposite
   e_from = np.concatenate([t[:, 0], t[:, 1], t[:, 2]])
   e_to = np.concatenate([t[:, 1], t[:, 2], t[:, 0]])
@@ -400,21 +410,26 @@ def mesh_is_convex(vertices, triangles):
   order = np.argsort(key)
   ks = key[order]
   if np.any(ks[1:] == ks[:-1]):
-    return False                                   # an edge used twice in the same direction
+    return 0                                       # an edge used twice in the same direction
   pos = np.searchsorted(ks, rev)
   if np.any(pos >= len(ks)) or np.any(ks[np.minimum(pos, len(ks) - 1)] != rev):
-    return False                                   # open: an edge without its opposite
+    return 0                                       # open: an edge without its opposite
   mate = order[pos]                                # the same edge in the neighbouring facet
   wpos = np.zeros((n_v, 3))
   wpos[weld.reshape(-1)] = v                       # (one representative per welded vertex)
   unit = nrm / area2[:, None]
+  worst = -np.inf
   for k in range(3):                               # (edge k of every facet: a third of the gathers at a time)
     sl = slice(k * len(t), (k + 1) * len(t))
     above = np.einsum('ij,ij->i', unit, wpos[e_opp[mate[sl]]] - a)
-    if np.any(above > 1e-9 * size):
-      return False
+    worst = max(worst, float(above.max()))
+    if worst > 1e-9 * size:
+      return 0
   volume = np.einsum('ij,ij->i', a, nrm).sum() / 6.0
-  return bool(volume > 0)
+  if not volume > 0:
+    return 0
+  # (facets without area were left out above: a mesh that has any keeps the plain answer)
+  return 2 if (worst <= 1e-13 * size and bool(keep.all())) else 1
 
 
 _CONVEX_MEMO = []          # [(vertices, triangles, answer)]: the arrays of stored shapes are cached objects, bakes repeat
@@ -427,7 +442,7 @@ def meshConvex(mesh):
   for mv, mt, ans in _CONVEX_MEMO:
     if mv is v and mt is tri:
       return ans
-  ans = mesh_is_convex(v, tri)
+  ans = mesh_convexity(v, tri)                     # (0 / 1 / 2: truth value = mesh_is_convex)
   _CONVEX_MEMO.append((v, tri, ans))
   del _CONVEX_MEMO[:-8]
   return ans

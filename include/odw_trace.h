@@ -83,6 +83,12 @@ enum {
                                  /* (closed, facets counter-clockwise from       */
                                  /* outside); the FACET's normal decides the     */
                                  /* exit, not the interpolated one.              */
+#define ODW_FLAG_STRICTLY_CONVEX 0x8 /* ODW_PRIM_TRIANGLE rows of an ODW_FLAG_CONVEX solid: no    */
+                                 /* edge of the polyhedron bends outward by more than rounding  */
+                                 /* (1e-13 of its size), so every point of a facet is on or     */
+                                 /* below every other facet's plane.  A ray that travels INSIDE */
+                                 /* such a solid is not tested against facets it could only     */
+                                 /* meet from outside (results unchanged; a hint for speed).    */
 #define ODW_FACEMASK_SHIFT 8
 
 /* ---- optical types: OpticalGroupProxy.OpticalType enumeration order ----- */

@@ -78,7 +78,17 @@ def test_convex_tessellated_solids_are_recognised(oracle):
                                (geometry.TORUS, (5.0, 1.0, 0, 0), False)):
     v, tri, _ = geometry.tessellate(kind, params, 24)
     assert geometry.mesh_is_convex(v, tri) is convex
+    # (2: no edge bends outward by more than rounding -- ODW_FLAG_STRICTLY_CONVEX, what the mesh kernel's normal cones need)
+    assert geometry.mesh_convexity(v, tri) == (2 if convex else 0)
   v, tri, _ = geometry.tessellate(geometry.SPHERE, (5.0, 0, 0, 0), 24)
+  # a vertex pulled OUT by 1e-10 of its radius: the diagonal of a (planar) quadrilateral of the tessellation now bends
+  # outward by more than rounding, within the tolerance of the test -- convex for the exit rule, not strictly; by 1e-6: not convex
+  k = int(np.argmax(v[:, 0]))
+  ring = np.linalg.norm(v - v[k], axis=1) < 1e-9
+  for eps, level in ((1e-10, 1), (1e-6, 0)):
+    w = v.copy()
+    w[ring] = v[ring] * (1 + eps)
+    assert geometry.mesh_convexity(w, tri) == level
   assert not geometry.mesh_is_convex(v, tri[:-3]) and not geometry.mesh_is_convex(v, tri[:, ::-1])
   dented = v.copy()
   k = int(np.argmax(v[:, 0]))
@@ -86,7 +96,7 @@ def test_convex_tessellated_solids_are_recognised(oracle):
   assert not geometry.mesh_is_convex(dented, tri)
   _, sc, lim, src = _lens_scene(48)
   tri_rows = sc.prim_type == geometry.TRIANGLE
-  assert np.all(sc.prim_flags[tri_rows] & 2) and sc.prim_flags[~tri_rows].tolist() == [2 | (63 << 8)]
+  assert np.all(sc.prim_flags[tri_rows] & 2) and np.all(sc.prim_flags[tri_rows] & 8) and sc.prim_flags[~tri_rows].tolist() == [2 | (63 << 8)]
   n = 200000
   a = oracle.trace(sc, src, lim, 0, n, 3, nthreads=0)
   with oracle.strict():
@@ -226,6 +236,51 @@ def test_mesh_kernel_equals_bvh_kernel(native_lib, monkeypatch):
     assert np.array_equal(a['tag'], b['tag'])
     assert np.array_equal(a['point'], b['point']) and np.array_equal(a['direction'], b['direction'])
     assert np.array_equal(a['power'], b['power'])
+
+
+@pytest.mark.gpu
+def test_normal_cones_change_no_row(native_lib, monkeypatch):
+  """a ray that travels inside a convex tessellated solid drops the slots of the eight-wide tree whose facets all face
+  it (WideBvh::cone_word: the neighbourhood of the facet it starts on) -- facets it could only meet from outside, at a
+  distance below distTol.  The rows are those without the cones (ODW_MESH_CONES=0) and those of the binary kernel, bit
+  for bit: a coarse ball under a beam that covers it up to grazing incidence (wide cones, long facets), a fine one, a
+  cylinder and a cone as lenses (several faces: rays that enter next to a rim start on a facet with an open edge and get
+  no cones), a ball mirror that rays never enter, total reflection inside a ball of high index."""
+  from freecad.optics_design_workbench_amd.simulation.tracer import Tracer
+  def scene(solid, n_seg, index=1.5, theta='0, 0.25', mirror=False, max_int=30.0, **kw):
+    doc = Document()
+    shape = make.makeTessellated(doc, solid(doc), n_seg, **kw)
+    if mirror:
+      make.makeMirror(doc, [shape], RecordHits=True)
+    else:
+      make.makeLens(doc, [shape], RefractiveIndex=index, RecordHits=True)
+    make.makeAbsorber(doc, [make.makeBox(doc, 'A', 400, 400, 1, base=(-200, -200, 80))])
+    make.makeSimulationSettings(doc, MaxIntersections=max_int)
+    src = make.makePointSource(doc, PowerDensity='1', ThetaDomain=theta)
+    return bake.bakeScene(doc, src), bake.bakeLimits(doc, src), point_source.bakeSource(doc, src)
+  ball = lambda doc: make.makeSphere(doc, 'S', 5, base=(0, 0, 25))
+  cases = [(scene(ball, 12), 400_000), (scene(ball, 160), 400_000), (scene(ball, 48, index=2.6), 300_000),
+           (scene(lambda doc: make.makeCylinder(doc, 'C', 4, 9, base=(0, -1, 22), quat=(np.sin(0.4), 0, 0, np.cos(0.4))), 40, smooth=False), 300_000),
+           (scene(lambda doc: make.makeCone(doc, 'K', 5, 1.5, 7, base=(0.5, 0, 22), quat=(0, np.sin(0.5), 0, np.cos(0.5))), 32, smooth=False), 300_000),
+           (scene(ball, 32, mirror=True), 200_000)]
+  for (sc, lim, src), n in cases:
+    assert (sc.prim_flags[sc.prim_type == geometry.TRIANGLE] & 2).all()          # (convex: the rule is armed)
+    rows = {}
+    for mode, kernel, cones in (('cones', '1', '1'), ('plain', '1', '0'), ('binary', '0', '1')):
+      monkeypatch.setenv('ODW_MESH_KERNEL', kernel)
+      monkeypatch.setenv('ODW_MESH_CONES', cones)
+      with Tracer(0) as tr:
+        tr.setScene(sc); tr.setSource(src); tr.setLimits(lim); tr.setDetector(None)
+        tr.reserveHits(n * 6)
+        tr.reset()
+        tr.trace(3, n, 17, histogram=False)
+        tr.sync()
+        rows[mode] = (tr.counters(), tr.hits())
+    assert rows['cones'][0]['hits_dropped'] == 0 and rows['cones'][0]['recorded_hits'] > n // 4
+    for other in ('plain', 'binary'):
+      assert rows['cones'][0] == rows[other][0], other
+      for col in ('tag', 'point', 'direction', 'power'):
+        assert np.array_equal(rows['cones'][1][col], rows[other][1][col]), (other, col)
 
 
 @pytest.mark.gpu
