@@ -574,15 +574,17 @@ struct BvhBuilder {
 //   8..13 near corner offsets: x of slots 0-3, x of 4-7, y, y, z, z     14..19 far corner offsets, the same way
 //   20..23 the solid every primitive below a slot belongs to (16 bits per slot, 0xffff: several or none): a ray that
 //          has just left a convex solid drops the slots of that solid before it looks at their boxes' order
-//   24..31 per slot, the cone of the outward normals of the facets below it, where they all belong to ONE CONVEX solid:
-//          bytes 0..2 an axis (128 + round(127 u)), byte 3 a threshold T, 255: no cone.  A ray that travels INSIDE that
-//          solid (it entered through one of its facets, odw_mesh.hip `inside`) can only leave through facets it meets from
-//          behind, d . n > 0; with d . (axis - 128) < -(T + 1.5) every facet below the slot has d . n < -cone_margin and
-//          the slot is dropped -- the whole neighbourhood of the facet the ray starts on, for one.  T = ceil(|axis - 128| *
-//          sin(widest angle between the axis and a normal + asin(cone_margin))).  cone_margin (WideBvh::margin) is what
-//          keeps the rule exact: the start point lies on its facet up to the closed-edge slack, so it is above the plane of
-//          a dropped facet by less than out_of_plane, and the plane would be met at t < out_of_plane / margin <= dist_tol,
-//          where consider() rejects it anyway.
+//   24..31 per slot, the cone of the outward normals of the facets below it, where they all belong to ONE STRICTLY
+//          CONVEX solid: bytes 0..2 an axis a = round(127 u) (signed), byte 3 a threshold T + 3 <= 126 (signed); no cone:
+//          0, 0, 0, 127.  A ray that travels INSIDE that solid (it entered through one of its facets, odw_mesh.hip `inside`)
+//          can only leave through facets it meets from behind, d . n > 0; the kernel drops a slot when
+//          v_dot4(word, [round(127 d), 127]) < 0, i.e. round(127 d) . a < -127 (T + 3): then d . a < -(T + 1.5) whatever the
+//          rounding of d did (|round(127 d) - 127 d| <= 0.5 per axis, |a|_1 <= 220: 110 of the 190 to spare), and with
+//          T = ceil(|a| sin(widest angle between a and a normal + asin(cone_margin))) every facet below the slot has
+//          d . n < -cone_margin -- the whole neighbourhood of the facet the ray starts on, for one.  cone_margin
+//          (WideBvh::margin) is what keeps the rule exact: the start point lies on its facet up to the closed-edge slack, so
+//          it is above the plane of a dropped facet by less than `above`, and the plane would be met at
+//          t < above / margin <= dist_tol, where consider() rejects it anyway.
 constexpr int kWideWords = 32;
 constexpr int kWideMaxDepth = 11;
 
@@ -642,22 +644,23 @@ struct WideBvh {
   }
   // the cone word of a slot (see the node layout above)
   uint32_t cone_word(const Ref& r) {
-    if (!out_normal || !(margin < 0.5)) return 0xff000000u;
+    constexpr uint32_t none = 0x7f000000u;
+    if (!out_normal || !(margin < 0.5)) return none;
     int lo, hi;
     if (r.count > 0) { lo = r.child; hi = r.child + r.count; } else node_span(r.child, lo, hi);
     double sum[3] = {0.0, 0.0, 0.0};
     for (int k = lo; k < hi; ++k) {
       const float* nv = out_normal + 3 * (size_t)order[(size_t)k];
-      if (!(nv[0] == nv[0])) return 0xff000000u;
+      if (!(nv[0] == nv[0])) return none;
       for (int a = 0; a < 3; ++a) sum[a] += (double)nv[a];
     }
     const double len = std::sqrt(sum[0] * sum[0] + sum[1] * sum[1] + sum[2] * sum[2]);
-    if (!(len > 1e-6 * (double)(hi - lo)) || hi <= lo) return 0xff000000u;
+    if (!(len > 1e-6 * (double)(hi - lo)) || hi <= lo) return none;
     int ax[3];
     double al = 0.0;
     for (int a = 0; a < 3; ++a) { ax[a] = (int)std::lround(127.0 * sum[a] / len); al += (double)ax[a] * ax[a]; }
     al = std::sqrt(al);
-    if (!(al > 100.0)) return 0xff000000u;
+    if (!(al > 100.0)) return none;
     double cmin = 1.0;
     for (int k = lo; k < hi; ++k) {
       const float* nv = out_normal + 3 * (size_t)order[(size_t)k];
@@ -666,10 +669,10 @@ struct WideBvh {
     }
     // (1e-5: the normals are float32 copies of unit vectors, the ray's direction is rounded to float32 in the kernel)
     const double theta = std::acos(std::max(-1.0, std::min(1.0, cmin))) + std::asin(margin) + 1e-5;
-    if (!(theta < 1.5)) return 0xff000000u;
+    if (!(theta < 1.5)) return none;
     const double t = std::ceil(al * std::sin(theta));
-    if (!(t < 254.0)) return 0xff000000u;
-    return (uint32_t)(ax[0] + 128) | ((uint32_t)(ax[1] + 128) << 8) | ((uint32_t)(ax[2] + 128) << 16) | ((uint32_t)t << 24);
+    if (!(t + 3.0 <= 126.0)) return none;                      // (cones that wide drop next to nothing)
+    return (uint32_t)(ax[0] & 0xff) | ((uint32_t)(ax[1] & 0xff) << 8) | ((uint32_t)(ax[2] & 0xff) << 16) | ((uint32_t)(t + 3.0) << 24);
   }
 
   static bool far_box(const float* lo) { return lo[0] >= 3.0e38f; }        // the child a wrapper root does not have
@@ -765,7 +768,7 @@ struct WideBvh {
     float glo[3] = {INFINITY, INFINITY, INFINITY}, ghi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int sl = 0; sl < 8; ++sl) {
       const int c = cand_in[sl];
-      if (c < 0) { w[24 + sl] = 0xff000000u; continue; }
+      if (c < 0) { w[24 + sl] = 0x7f000000u; continue; }
       const Ref& r = cand[c];
       if (r.count == 0) { imask |= 1u << sl; ++n_inner; }
       else {
@@ -777,7 +780,7 @@ struct WideBvh {
       {
         const int so = ref_solid(r);
         w[20 + (sl >> 1)] |= (uint32_t)((so >= 0 && so < 0xffff) ? so : 0xffff) << (16 * (sl & 1));
-        w[24 + sl] = (so >= 0 && so < 0xffff) ? cone_word(r) : 0xff000000u;
+        w[24 + sl] = (so >= 0 && so < 0xffff) ? cone_word(r) : 0x7f000000u;
       }
       for (int a = 0; a < 3; ++a) {
         const double ql = std::floor(((double)r.lo[a] - (double)lo[a]) / scale[a]);
@@ -1187,7 +1190,7 @@ int build_bvh(odw_ctx* ctx) {
         size_t slots = 0, cones = 0;
         for (size_t k = 0; k + kWideWords <= wide.nodes.size(); k += kWideWords)
           for (int sl = 0; sl < 8; ++sl)
-            if ((wide.nodes[k + 6] | (wide.nodes[k + 6] >> 8)) & (1u << sl)) { ++slots; cones += (wide.nodes[k + 24 + sl] >> 24) != 255u; }
+            if ((wide.nodes[k + 6] | (wide.nodes[k + 6] >> 8)) & (1u << sl)) { ++slots; cones += (wide.nodes[k + 24 + sl] >> 24) != 127u; }
         fprintf(stderr, "[odw mesh cones] margin %.4g, %zu of %zu slots carry a cone\n", wide.margin, cones, slots);
       }
       if ((rc = upload(ctx, ctx->bvh_leaf, recs.data(), recs.size() * sizeof(float)))) return rc;

@@ -303,7 +303,7 @@ __global__ __launch_bounds__(ODW_MESH_THREADS, ODW_MESH_WAVES) void odw_mesh_ker
   // cut-off (relative to the moved origin), node, stack height; the leaf children that wait for their test
   float ofx = 0, ofy = 0, ofz = 0, ivx = 0, ivy = 0, ivz = 0, cutf = 0, tsh = 0, dfx = 0, dfy = 0, dfz = 0;
   uint32_t oct = 0;
-  int cur = -1, sp = 0;
+  int cur = -1, sp = 0, dq = 0;
   uint32_t lbase = 0, lcounts = 0, lhits = 0;      // (or, between the rounds of one visit: the candidates left, low | high word)
   bool have_cand = false;
   const float tolf = (float)lim.dist_tol * 1.000001f;
@@ -433,6 +433,9 @@ __global__ __launch_bounds__(ODW_MESH_THREADS, ODW_MESH_WAVES) void odw_mesh_ker
             ofx = (float)o.x; ofy = (float)o.y; ofz = (float)o.z;
             ivx = (float)inv.x; ivy = (float)inv.y; ivz = (float)inv.z;
             dfx = (float)dir.x; dfy = (float)dir.y; dfz = (float)dir.z;
+            // (the direction in units of 1 / 127, one signed byte per axis, 127 in the fourth: the cone test is one v_dot4)
+            dq = (int)(((uint32_t)(int)rintf(127.0f * dfx) & 0xffu) | (((uint32_t)(int)rintf(127.0f * dfy) & 0xffu) << 8) |
+                       (((uint32_t)(int)rintf(127.0f * dfz) & 0xffu) << 16) | (127u << 24));
             oct = (dir.x > 0 ? 1u : 0u) | (dir.y > 0 ? 2u : 0u) | (dir.z > 0 ? 4u : 0u);
             cutf = (float)(q.tmax - (double)tsh) * 1.00001f + 1e-3f;
             cur = 0; sp = 0;
@@ -501,11 +504,9 @@ __global__ __launch_bounds__(ODW_MESH_THREADS, ODW_MESH_WAVES) void odw_mesh_ker
           const vu4 ca = *reinterpret_cast<const vu4 ODW_CONST*>(nd + 24);
           const vu4 cb = *reinterpret_cast<const vu4 ODW_CONST*>(nd + 28);
           const uint32_t in = (uint32_t)inside;
-          const float bias = 128.0f * (dfx + dfy + dfz) - 1.5f;      // (d . (axis - 128) < -(T + 1.5): 1.5 for the rounding of this sum)
 #define ODW_MESH_CONE(S, W, SOLID)                                                                                      \
           {                                                                                                             \
-            const float dv = fmaf((float)((W) & 0xffu), dfx, fmaf((float)(((W) >> 8) & 0xffu), dfy, (float)(((W) >> 16) & 0xffu) * dfz)); \
-            const bool drop = (SOLID) == in && ((W) >> 24) != 255u && dv - bias < -(float)((W) >> 24);                   \
+            const bool drop = (SOLID) == in && __builtin_amdgcn_sdot4((int)(W), dq, 0, false) < 0;                       \
             hits &= drop ? ~(1u << (S)) : ~0u;                                                                          \
           }
           ODW_MESH_CONE(0, ca.x, so.x & 0xffffu)
