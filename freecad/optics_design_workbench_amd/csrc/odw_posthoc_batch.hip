@@ -80,19 +80,31 @@ __global__ __launch_bounds__(256) void phb_mark_kernel(const odw_hit* __restrict
 }
 
 // (ph_popc_kernel for every scene: words = [bitmap | popcounts | prefix sums] per scene)
+// kPhbPer rays per thread, their loads issued together: with one 4-byte load per thread the pass was bound by the latency of
+// that load (40 MB in 22 us), not by bandwidth
+constexpr int kPhbPer = 8;
 __global__ __launch_bounds__(256) void phb_popc_kernel(const uint32_t* __restrict__ row_of_all, uint64_t n_rays, uint64_t rays_pad,
                                                        uint32_t* __restrict__ words_all, uint64_t n_words) {
   const uint32_t* row_of = row_of_all + (size_t)blockIdx.y * rays_pad;
   uint32_t* bitmap = words_all + (size_t)blockIdx.y * 3 * n_words;
   uint32_t* pop = bitmap + n_words;
-  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool has = r < n_rays && row_of[r] != PH_NO_ROW;
-  const uint64_t b = __ballot(has);
+  const uint64_t base = (uint64_t)blockIdx.x * (blockDim.x * kPhbPer) + threadIdx.x;
+  uint32_t v[kPhbPer];
+#pragma unroll
+  for (int k = 0; k < kPhbPer; ++k) {
+    const uint64_t r = base + (uint64_t)k * blockDim.x;
+    v[k] = r < n_rays ? row_of[r] : PH_NO_ROW;
+  }
   const uint32_t lane = threadIdx.x & 63u;
-  if ((lane & 31u) == 0 && r < n_rays) {
-    const uint32_t word = (uint32_t)(lane ? b >> 32 : b);
-    bitmap[r >> 5] = word;
-    pop[r >> 5] = (uint32_t)__popc(word);
+#pragma unroll
+  for (int k = 0; k < kPhbPer; ++k) {
+    const uint64_t r = base + (uint64_t)k * blockDim.x;
+    const uint64_t b = __ballot(v[k] != PH_NO_ROW);
+    if ((lane & 31u) == 0 && r < n_rays) {
+      const uint32_t word = (uint32_t)(lane ? b >> 32 : b);
+      bitmap[r >> 5] = word;
+      pop[r >> 5] = (uint32_t)__popc(word);
+    }
   }
 }
 
@@ -132,18 +144,29 @@ __global__ void phb_state_kernel(PhbScene* __restrict__ scenes, int S, const uns
   P.sample_n = (uint32_t)count;
 }
 
-__global__ void phb_rank_kernel(const uint32_t* __restrict__ words_all, uint64_t n_words, const uint32_t* __restrict__ row_of_all,
-                                uint64_t n_rays, uint64_t rays_pad, uint32_t* __restrict__ sel_all, uint64_t slots) {
+__global__ __launch_bounds__(256) void phb_rank_kernel(const uint32_t* __restrict__ words_all, uint64_t n_words, const uint32_t* __restrict__ row_of_all,
+                                                       uint64_t n_rays, uint64_t rays_pad, uint32_t* __restrict__ sel_all, uint64_t slots) {
   const uint32_t* bitmap = words_all + (size_t)blockIdx.y * 3 * n_words;
   const uint32_t* before = bitmap + 2 * n_words;
   const uint32_t* row_of = row_of_all + (size_t)blockIdx.y * rays_pad;
   uint32_t* out = sel_all + (size_t)blockIdx.y * slots;
-  const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < n_rays) {
-    const uint32_t word = bitmap[r >> 5], bit = 1u << (r & 31u);
-    if (word & bit) {
-      const uint64_t at = (uint64_t)before[r >> 5] + (uint32_t)__popc(word & (bit - 1u));
-      if (at < slots) out[at] = row_of[r];
+  const uint64_t base = (uint64_t)blockIdx.x * (blockDim.x * kPhbPer) + threadIdx.x;
+  uint32_t word[kPhbPer], bef[kPhbPer], row[kPhbPer];
+#pragma unroll
+  for (int k = 0; k < kPhbPer; ++k) {
+    const uint64_t r = base + (uint64_t)k * blockDim.x;
+    const bool in = r < n_rays;
+    word[k] = in ? bitmap[r >> 5] : 0u;
+    bef[k] = in ? before[r >> 5] : 0u;
+    row[k] = in ? row_of[r] : PH_NO_ROW;
+  }
+#pragma unroll
+  for (int k = 0; k < kPhbPer; ++k) {
+    const uint64_t r = base + (uint64_t)k * blockDim.x;
+    const uint32_t bit = 1u << (r & 31u);
+    if (r < n_rays && (word[k] & bit)) {
+      const uint64_t at = (uint64_t)bef[k] + (uint32_t)__popc(word[k] & (bit - 1u));
+      if (at < slots) out[at] = row[k];
     }
   }
 }
@@ -541,6 +564,7 @@ __global__ __launch_bounds__(256) void phb_bin_kernel(const PhbScene* __restrict
   const double* ea = edges_in_lds ? s_edges : edges_a;
   const double* eb = edges_in_lds ? s_edges + na : edges_b;
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  // (two or four rows per trip, `#pragma unroll`: 556 -> 648 us per 8 x 1e7 rows -- the kernel is bound by its arithmetic)
   for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
     int ia, ib;
     ph_bin_pair(accel, az_fast, r_fast, s_guide, polar, X[j] - ox, Y[j] - oy, ea, na, eb, nb, ia, ib);
@@ -665,7 +689,7 @@ int phb_enqueue_select(odw_ctx* ctx, int32_t group, uint64_t limit, uint64_t cap
   size_t tmp_bytes = 0;
   HIPCHK(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n_words, ctx->stream));
   if ((rc = ensure(ctx, ctx->sort_tmp, tmp_bytes))) return rc;
-  const unsigned rgrid = (unsigned)((n_rays + 255) / 256);
+  const unsigned rgrid = (unsigned)((n_rays + 256 * kPhbPer - 1) / (256 * kPhbPer));
   hipLaunchKernelGGL(phb_popc_kernel, dim3(rgrid, S), dim3(256), 0, ctx->stream, (const uint32_t*)ctx->phb_row_of.p, n_rays, rays_pad,
                      (uint32_t*)ctx->phb_words.p, n_words);
   for (int s = 0; s < S; ++s) {
