@@ -39,10 +39,12 @@ KERNEL_LIKE = '%' + KERNEL_NAME + '%'
 out = os.path.join(ROOT, 'gpurun_out')
 os.makedirs(out, exist_ok=True)
 env = dict(os.environ, TMPDIR='/tmp')
-if args.config == 'c5':
-  # counters are averaged per dispatch: the sweep traces one radius per launch here (its batch launches hold 2 - 12
-  # radii each); bench.py compares per radius (1e7 rays) either way
-  env['ODW_SWEEP_BATCH'] = '0'
+# c5: the sweep as it runs -- batch launches of 2 - 16 radii each, their rays generated once per launch by
+# odw_batch_rays_kernel.  Counters and kernel time are SUMMED over every dispatch of the two kernels in the process
+# and divided by the radii the process traced (64 per sweep x (warmup + steps) sweeps): per radius = per 1e7 rays,
+# what bench.py compares with.
+C5_RADII, C5_SWEEPS = 64, 2
+KERNELS = [KERNEL_NAME] + (['odw_batch_rays_kernel'] if args.config == 'c5' and not args.script else [])
 BENCH = ['python3', os.path.join(ROOT, 'bench.py'), '--config', args.config, '--steps', '1' if args.config == 'c5' else '3', '--warmup', '1',
          '--no-cpu-baseline', '--no-end-to-end', '--no-extra']
 if args.script:
@@ -98,13 +100,21 @@ shutil.rmtree(d, ignore_errors=True)        # the raw databases are large; gpuru
 kernel_ms = None
 if rows and cols:
   ci = {c.lower(): k for k, c in enumerate(cols)}
+  total_us = 0.0
   for r in rows:
     nm = str(r[ci.get('name', 0)])
-    if KERNEL_NAME in nm:
+    if KERNEL_NAME in nm and kernel_ms is None:
       for key in ('average', 'avg', 'averagens', 'average_ns'):
         if key in ci:
           kernel_ms = float(r[ci[key]]) / 1e3          # the view reports microseconds
           break
+    if any(k in nm for k in KERNELS):
+      calls = [ci[k] for k in ('calls', 'count', 'total_calls') if k in ci]
+      avgc = [ci[k] for k in ('average', 'avg', 'averagens', 'average_ns') if k in ci]
+      if calls and avgc:
+        total_us += float(r[calls[0]]) * float(r[avgc[0]])
+  if len(KERNELS) > 1 and total_us:
+    kernel_ms = total_us / 1e3 / (C5_RADII * C5_SWEEPS)        # per radius
 
 # 3. counters, one set per run
 sets = [['FETCH_SIZE'], ['WRITE_SIZE'], ['SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_SMEM', 'SQ_WAVE_CYCLES'],
@@ -130,9 +140,12 @@ for k, cs in enumerate(sets):
   vcol = [c for c in cols if c.lower() in ('value', 'counter_value')]
   if not (kcol and ncol and vcol):
     raise SystemExit(f'unexpected columns in {view[0]}: {cols}')
-  q = (f'select {ncol[0]}, avg({vcol[0]}), count(*) from {view[0]} '
-       f"where {kcol[0]} like '{KERNEL_LIKE}' group by {ncol[0]}")
-  for cname, value, count in con.execute(q):
+  like = ' or '.join(f"{kcol[0]} like '%{k}%'" for k in KERNELS)
+  q = (f'select {ncol[0]}, avg({vcol[0]}), count(*), sum({vcol[0]}) from {view[0]} '
+       f"where {like} group by {ncol[0]}")
+  for cname, value, count, total in con.execute(q):
+    if len(KERNELS) > 1:
+      value = total / (C5_RADII * C5_SWEEPS)            # per radius
     avg[cname] = value
     print(cname, value, f'({count} dispatches)', flush=True)
   con.close()
@@ -144,6 +157,7 @@ n_per = line.get('config', {}).get('rays_per_step_per_gpu') or line.get('config'
 summary = dict(command='rocprofv3 --pmc <COUNTERS> --kernel-trace -- ' + ' '.join(BENCH[:1] + ['bench.py'] + BENCH[2:]) +
                        ' (one counter set per run)',
                kernel=KERNEL_LIKE.strip('%'), rays_per_launch=n_per,
+               counters_unit=('per radius: summed over every dispatch of ' + ' + '.join(KERNELS) + f' and divided by {C5_RADII} radii x {C5_SWEEPS} sweeps') if len(KERNELS) > 1 else 'average per dispatch',
                counters_avg_per_dispatch=avg, fetch_bytes_raw=fetch_raw, fetch_bytes_corrected=2 * fetch_raw,
                write_bytes=write, hbm_bytes_per_launch=2 * fetch_raw + write, kernel_ms_rocprof=kernel_ms)
 json.dump(summary, open(os.path.join(out, f'{tag}_pmc.json'), 'w'), indent=1)
