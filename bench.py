@@ -527,7 +527,7 @@ def main():
   ap.add_argument('--no-histogram', action='store_true', help='hit rows only (diagnostic, not the metric)')
   ap.add_argument('--dump-results', default=None, help='c3 / c4: rank 0 writes the job\'s histogram and counters (after the reduce) to this .npz')
   ap.add_argument('--no-extra', action='store_true',
-                  help='c3 only: leave out the c4 (3 steps) and c5 (2 sweeps) lines nested under "extra_configs"')
+                  help='c3 only: leave out the c4 (3 steps) and c5 (4 sweeps) lines nested under "extra_configs"')
   args = ap.parse_args()
   cfg = CONFIGS[args.config]
   if args.steps is None:
@@ -569,11 +569,12 @@ def main():
     out = run_trace_config(args, args.config, cfg, rank, local_rank, world, dist, torch)
   if args.config == 'c3' and world == 1 and not args.no_extra and not args.no_hits and not args.rays_per_step:
     # the other two GPU configs of BASELINE.json in the same driver-timed record: c4 (hugeArray, 3 steps) and
-    # c5 (the radius sweep, 2 sweeps after 1 untimed one: its host side makes single sweeps vary by 20 %), each measured exactly like its own `--config` line
+    # c5 (the radius sweep, 4 sweeps after 2 untimed ones: the first sweep after the contexts are set up runs ~10 % slower than the
+    # steady state, and single sweeps vary box to box), each measured exactly like its own `--config` line
     # (one GPU only: a scaling run needs the headline per N, and an extra that fails on one rank would take the others' line with it)
     import copy
     extra = {}
-    for name, steps, warmup in (('c4', 3, 1), ('c5', 2, 1)):
+    for name, steps, warmup in (('c4', 3, 1), ('c5', 4, 2)):
       sub = copy.copy(args)
       sub.config, sub.steps, sub.warmup = name, steps, warmup
       sub.no_cpu_baseline = sub.no_end_to_end = True
