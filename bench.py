@@ -212,6 +212,9 @@ def summary_scalars(name, line):
   out = {f'{name}_value': line['value'], f'{name}_unit': line['unit'], f'{name}_ms_per_step': line['ms_per_step'],
          f'{name}_steps': line['steps'], f'{name}_roofline_frac': rf.get('frac'), f'{name}_avg_kernel_ms': rf.get('avg_kernel_ms'),
          f'{name}_kernel': rf.get('kernel')}
+  if rf.get('frac_kernel_alone') is not None:
+    out[f'{name}_roofline_frac_kernel_alone'] = rf['frac_kernel_alone']
+    out[f'{name}_kernel_alone_ms'] = rf.get('kernel_alone_ms')
   lanes = (rf.get('valu') or {}).get('active_lanes_per_inst')
   if lanes is not None:
     out[f'{name}_active_lanes_per_inst'] = lanes
@@ -455,6 +458,29 @@ def run_sweep_config(args, cfg, rank, local_rank, world, dist, torch):
     t = torch.tensor([dt], dtype=torch.float64, device='cpu' if REHEARSE else 'cuda')
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+  # the batch launch by itself (after the timed region, nothing else on the GPU): one launch of up to 16 radii, three times,
+  # the last two timed -- inside a sweep the kernel shares the GPU with the post-hoc chains of other groups, which stretches
+  # its own time; `frac_kernel_alone` is the same instruction count against this time
+  solo_ms = None
+  if rank == 0:
+    try:
+      ks = radii[:min(16, len(radii))]
+      prs = []
+      for r in ks:
+        setRadius(doc, r)
+        prs.append(scenes.bakeProject(doc))
+      tr.setLimits(prs[0].limits); tr.setSource(prs[0].source); tr.setSceneBatch([p.scene for p in prs]); tr.setDetector(None)
+      for rep in range(3):
+        tr.reset()
+        tr.traceBatch(0, n_per, SEED, int(n_per * 1.25) + 1024)
+        tr.sync()
+        if rep == 0:
+          tr.timingRead()
+      ms, n = tr.timingRead()
+      solo_ms = ms / max(n, 1) / len(ks)
+    except Exception as e:
+      solo_ms = None
+      print(f'[bench] the solo batch launch failed: {e}', file=sys.stderr)
   # the notebook's figure of merit on the notebook's sample size: calcFwhm of the ~1000 thinned rows per radius the
   # last sweep kept (host arithmetic of 64 small clouds, after the timed region; one more all-reduce of the column)
   fwhm_1e3 = sweep.fwhmOfSamples(res, dist=dist, device=local_rank)
@@ -499,10 +525,16 @@ def run_sweep_config(args, cfg, rank, local_rank, world, dist, torch):
                                                   'inside the timed sweep, the 64 small fits run after it'}},
         'roofline': roofline_block(kernel_name, avg_kernel_s, n_per, bytes_per_ray, pmc,
                                    note=f'trace kernels of rank 0: {launches} batch launches for {radii_of_rank} radii, kernel time per radius '
-                                        '(1e7 rays), measured while the post-hoc kernels of other groups share the GPU (the batch kernel by itself: 0.67 ms '
-                                        'per radius, profiles/r04/r04_batch_launch_kernel.log); per step the host '
+                                        '(1e7 rays), the ray pass of the launch included, measured while the post-hoc kernels of other groups share the GPU (the batch '
+                                        'kernel by itself: kernel_alone_ms / frac_kernel_alone); per step the host '
                                         'also re-bakes the scenes and searches the detector plane per radius'),
     }
+    if solo_ms:
+      rf = out['roofline']
+      rf['kernel_alone_ms'] = solo_ms
+      rf['kernel_alone_note'] = 'one batch launch of up to 16 radii with nothing else on the GPU, per radius, after the timed region'
+      if rf.get('frac') is not None:
+        rf['frac_kernel_alone'] = rf['frac'] * rf['avg_kernel_ms'] / solo_ms
     if world == 1 and not args.no_cpu_baseline:
       proj = scenes.bakeProject(doc)
       out['cpu_baseline'] = cpu_baseline(proj, None, seconds=8.0)
