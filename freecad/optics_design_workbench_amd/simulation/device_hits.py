@@ -458,6 +458,14 @@ class DeviceHitsBatch:
     self._stage = 'measured'
     return True
 
+  def detached(self):
+    """True when every answer the chain was asked for is on the host and no scene was left to the per-segment calls: the
+    context may trace its next batch while the caller still reads this one (histograms of the chain's request, moments,
+    the kept sample)"""
+    return (self._stage == 'measured' and self._binned is not None and self._projected is not None and
+            not np.any(self._binned[2]) and all(self.ordered) and self._planes is not None and
+            all(p is not None for p in self._planes) and (not self._keep or getattr(self, '_kept', None) is not None))
+
   # -- steps ----------------------------------------------------------------------------------------------------------
   def _sampleRows(self):
     if self._sample is None:

@@ -353,7 +353,8 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
           m = float(m)
           table[k, i] = (0.0, 2.0) if np.isnan(m) else (m, 1.0)
     finally:
-      t.batchSelect(None)
+      if t is not None:
+        t.batchSelect(None)
       mark(f'finish {ks[0]}', t_m)
       if clock is not None:
         clock['measure'] += time.perf_counter() - t_m
@@ -392,6 +393,11 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
     busy = [None] * len(lanes)           # per context: dict(ks, batch, capacity, t0) of the group in flight
     order = []                           # contexts in the order their groups were launched
     pos, turn = 0, 0
+    # host work nobody waits for is done when the GPU has been fed: the fits of a group whose answers are all on the host
+    # (its context is free at once), and the bake of the group that goes next (ODW_SWEEP_DEFER=0: both where they used to be)
+    defer = os.environ.get('ODW_SWEEP_DEFER', '1') != '0' and all(hasattr(measures[name], 'batched') for name in names)
+    deferred = []                        # (ks, batch) whose fits are still to do
+    ahead = [None]                       # (ks, baked) of the next group, baked in an idle moment
 
     def launch(lane, ks, baked):
       t, up = lanes[lane], uploaded[lane]
@@ -436,32 +442,44 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
       for lane in list(order):
         g = busy[lane]
         if g['batch']._stage == 'measuring' and g['batch'].measured(wait=(lane == wait_lane)):
-          finishGroup(lanes[lane], g['ks'], g['batch'])
+          if defer and g['batch'].detached():
+            deferred.append((g['ks'], g['batch']))
+          else:
+            finishGroup(lanes[lane], g['ks'], g['batch'])
           busy[lane] = None
           order.remove(lane)
           done = True
       return done
 
-    while pos < len(mine) or order:
+    def nextGroup():
+      """the values of the next group, baked (the sizes: see below)"""
+      nonlocal turn
+      if ahead[0] is not None:
+        out, ahead[0] = ahead[0], None
+        return out
+      # (the first groups are small, so that chains start early; the last ones shrink, so that the contexts end together.
+      #  ODW_SWEEP_TAPER = d > 0: every group of the tail takes 1 / d of what is left; 0: the tail in equal groups -- measured
+      #  better: small launches are worse launches)
+      left = len(mine) - pos
+      if group_size > 2 and left < group_size * len(lanes):
+        if taper > 0:
+          tail_size[0] = max(2, -(-left // taper))
+        elif tail_size[0] is None:
+          tail_size[0] = max(2, -(-left // len(lanes)))
+      size = group_size if group_size <= 2 else min(group_size, 2 << turn if turn < 3 else group_size, tail_size[0] or group_size)
+      ks = mine[pos:pos + size]
+      turn += 1
+      t1 = time.perf_counter()
+      baked = [bakeValue(k) for k in ks]
+      mark(f'bake {ks[0]}', t1)
+      return ks, baked
+
+    while pos < len(mine) or order or deferred:
       did = measuredGroups()
       did = sampledGroups() or did
       free = [lane for lane in range(len(lanes)) if busy[lane] is None]
       if pos < len(mine) and free and batch_ok[0]:
-        # (the first groups are small, so that chains start early; the last ones shrink, so that the contexts end together)
-        left = len(mine) - pos
-        # (ODW_SWEEP_TAPER = d > 0: every group of the tail takes 1 / d of what is left, so that the last chain -- whose
-        #  plane search and measuring nothing else overlaps with -- belongs to two values; 0: the tail in equal groups)
-        if group_size > 2 and left < group_size * len(lanes):
-          if taper > 0:
-            tail_size[0] = max(2, -(-left // taper))
-          elif tail_size[0] is None:
-            tail_size[0] = max(2, -(-left // len(lanes)))
-        size = group_size if group_size <= 2 else min(group_size, 2 << turn if turn < 3 else group_size, tail_size[0] or group_size)
-        ks = mine[pos:pos + size]
-        turn += 1
-        t1 = time.perf_counter()
-        baked = [bakeValue(k) for k in ks]
-        mark(f'bake {ks[0]}', t1)
+        ks, baked = nextGroup()
         same = all(b[2] == baked[0][2] and _sourceKey(b[1]) == _sourceKey(baked[0][1]) for b in baked[1:])
         launched = False
         if same and len(ks) > 1:
@@ -483,6 +501,13 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
         for k in mine[pos:]:
           runOne(0, k)
         pos = len(mine)
+        continue
+      if not did and defer and batch_ok[0] and pos < len(mine) and ahead[0] is None and order:
+        ahead[0] = nextGroup()             # every context is busy: the next group's bake, so that its launch is an upload away
+        continue
+      if not did and deferred:
+        ks_d, batch_d = deferred.pop(0)    # nothing to feed the GPU with: the fits of a group that has arrived
+        finishGroup(None, ks_d, batch_d)
         continue
       if not did and order:
         # nothing ready and nothing to launch: wait for the oldest chain's next piece
