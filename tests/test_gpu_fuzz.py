@@ -3,6 +3,9 @@ oracle on whole trajectories.  `tests/fuzz_parity.py` is the long form (150 scen
 round 1: 141 scenes identical to 1e-7 mm, 8 with rounding amplified along trapped multi-bounce
 paths -- deviations grow geometrically from 1e-12 --, one ray of 3e6 with a different hit sequence
 after 30 bounces between tori)."""
+import json
+import os
+
 import numpy as np
 import pytest
 
@@ -182,3 +185,17 @@ def test_random_scenes_in_batches_equal_their_own_launches(native_lib, rich, com
       rows += r['rows']
   # (rich: most seeds bring facets or a stochastic surface and are left out)
   assert done >= ((12 if compile == 'off' else 4) if not rich else (4 if compile == 'off' else 1)) and rows > 3000, (done, rows)
+
+
+def test_normal_cones_on_random_convex_hulls(native_lib):
+  """the mesh kernel's normal cones (rays inside a strictly convex tessellated solid drop the tree slots whose facets all
+  face them) on convex hulls of random point clouds -- balls, needles, discs, cut balls, blobs --, as lenses and mirrors,
+  distTol 1e-6 .. 1e-2: the rows with cones == without == the binary-tree kernel's, bit for bit (tests/fuzz_cones.py is the
+  long form: 300 hulls x 2e5 rays, profiles/r05/README.md)"""
+  import subprocess
+  import sys
+  res = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'fuzz_cones.py'), '16', '40000', '5'],
+                       capture_output=True, text=True, timeout=600)
+  line = [l for l in res.stdout.splitlines() if l.startswith('{')][-1]
+  out = json.loads(line)
+  assert res.returncode == 0 and out['differing'] == 0 and out['scenes'] >= 12 and out['strictly_convex'] >= 12, (res.stdout[-2000:], res.stderr[-2000:])
