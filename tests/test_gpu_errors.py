@@ -326,3 +326,64 @@ def test_batched_post_hoc_steps_keep_their_order(tr, native_lib):
   assert select() == 0
   tr.setSceneBatch([a.scene, b.scene])
   assert project_() == 1 and select() == 1
+
+
+def test_enqueued_chain_keeps_its_order(tr, native_lib):
+  """ABI v10, the chain that is enqueued and polled: begin -> sampled -> measure -> measured, each of the last batch
+  launch; a piece asked for out of turn is refused with the name of the call that has to come first, polling a piece that
+  is under way answers ODW_BUSY or the result, never an error, and the synchronous calls start over"""
+  a, b = _radius_variants([9.9, 10.0])
+  tr.setLimits(a.limits)
+  tr.setSceneBatch([a.scene, b.scene])
+  tr.setSource(a.source)
+  lib, ctx = native_lib, tr._ctx
+  pd, pu, pi = C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)
+  lib.odw_batch_hits_begin.argtypes = [C.c_void_p, C.c_int32, C.c_uint64]
+  lib.odw_batch_hits_sampled.argtypes = [C.c_void_p, C.c_int32, pu, pu, pi, C.c_void_p, C.c_uint64, pu]
+  lib.odw_batch_hits_measure.argtypes = [C.c_void_p, pd, pd, pi, C.c_int32, pd, C.c_int32, pd, C.c_int32, C.c_uint64]
+  lib.odw_batch_hits_measured.argtypes = [C.c_void_p, C.c_int32, pd, pd, pd, pu, C.POINTER(C.c_uint32), C.c_void_p, C.c_uint64, pu]
+  n, lv, ns = (np.zeros(2, dtype=np.uint64) for _ in range(3))
+  od = np.zeros(2, dtype=np.int32)
+  cap = 308
+  rows = np.zeros((2, cap), dtype=_native.HIT_DTYPE)
+  ex, ey = np.tile([0.0, 1.0, 0.0], 2), np.tile([0.0, 0.0, 1.0], 2)
+  ea, eb = np.linspace(-30, 30, 7), np.linspace(-30, 30, 7)
+  stats, mom, org = np.zeros(16), np.zeros(12), np.zeros(4)
+  counts, flags, nk = np.zeros(2 * 36, dtype=np.uint64), np.zeros(2, dtype=np.uint32), np.zeros(2, dtype=np.uint64)
+  as_ = lambda v, t: v.ctypes.data_as(t)
+  begin = lambda limit=300: lib.odw_batch_hits_begin(ctx, -1, limit)
+  sampled = lambda wait, c=cap: lib.odw_batch_hits_sampled(ctx, wait, as_(n, pu), as_(lv, pu), as_(od, pi), rows.ctypes.data_as(C.c_void_p), c, as_(ns, pu))
+  measure = lambda e=ea: lib.odw_batch_hits_measure(ctx, as_(ex, pd), as_(ey, pd), None, 0, as_(e, pd), len(e), as_(eb, pd), len(eb), 0)
+  measured = lambda wait: lib.odw_batch_hits_measured(ctx, wait, as_(stats, pd), as_(mom, pd), as_(org, pd), as_(counts, pu),
+                                                      flags.ctypes.data_as(C.POINTER(C.c_uint32)), None, 0, as_(nk, pu))
+  err = lambda: lib.odw_last_error(ctx)
+  assert begin() == 1 and b'no batch was traced with hit rows' in err()
+  assert sampled(1) == 1 and b'odw_batch_hits_begin first' in err()
+  tr.traceBatch(0, 3000, 3, 6000)
+  assert begin(0) == 1 and begin(5000) == 1                     # the sample's size has bounds
+  assert measure() == 1 and b'odw_batch_hits_sampled first' in err()
+  assert measured(1) == 1 and b'odw_batch_hits_measure first' in err()
+  assert begin() == 0
+  assert sampled(1, 10) == 4 and b'too small' in err()          # ODW_ERR_CAPACITY; the piece is still there
+  while True:
+    rc = sampled(0)
+    assert rc in (0, _native.BUSY), err()
+    if rc == 0:
+      break
+  assert n.min() > 2800 and od.tolist() == [1, 1] and 0 < ns.min() <= 300
+  assert sampled(1) == 1                                        # handed over once
+  assert measured(0) == 1 and b'odw_batch_hits_measure first' in err()
+  assert measure(np.array([0.0, 1.0, 0.5])) == 1 and b'monotonically' in err()
+  assert measure() == 0
+  assert measure() == 1                                         # one measure per sample
+  while True:
+    rc = measured(0)
+    assert rc in (0, _native.BUSY), err()
+    if rc == 0:
+      break
+  assert flags.tolist() == [0, 0] and counts.reshape(2, -1).sum(axis=1).min() > 2800
+  assert measured(1) == 1
+  # a new launch starts over; so does a chain begun again
+  tr.traceBatch(0, 3000, 4, 6000)
+  assert sampled(1) == 1 and measure() == 1
+  assert begin() == 0 and begin() == 0 and sampled(1) == 0
