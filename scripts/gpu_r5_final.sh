@@ -16,7 +16,7 @@ fi
 step "python bench.py"
 timeout -k 10 600 python bench.py > $O/${T}_bench_default.json 2> $O/${T}_bench_default.err || { tail -5 $O/${T}_bench_default.err; exit 1; }
 cut -c1-1500 $O/${T}_bench_default.json | tee -a $O/${T}_final.log
-for C in c3 c4 c5; do
+for C in ${PROFILE_CONFIGS-c3 c4 c5}; do
   step "profile $C"
   timeout -k 10 900 python scripts/profile_round.py ${T}_$C --config $C > $O/${T}_${C}_profile.log 2>&1 || { tail -20 $O/${T}_${C}_profile.log; exit 1; }
   tail -3 $O/${T}_${C}_profile.log | cut -c1-300 | tee -a $O/${T}_final.log
