@@ -43,6 +43,22 @@ for k in range(24):
   seen.add(got['structure'])
   assert got['primitives'] == len(sc.prim_type)
 assert {'flat', 'wide-bvh'} <= seen and ('grid' in seen or 'bvh' in seen), seen
+# a strictly convex tessellated lens beside an analytic screen: the eight-wide tree with a normal cone per slot
+# (WideBvh::cone_word / node_span), coarse and fine, at the tolerance that arms the cones and at one that does not
+from freecad.optics_design_workbench_amd.freecad_elements import make
+from freecad.optics_design_workbench_amd.scene import Document, bake
+for segments, tol in ((8, '1e-2'), (48, '1e-6'), (96, '1e-4')):
+  doc = Document()
+  ball = make.makeTessellated(doc, make.makeSphere(doc, 'S', 5, base=(0, 0, 30)), segments)
+  make.makeLens(doc, [ball], RefractiveIndex=1.5)
+  make.makeAbsorber(doc, [make.makeBox(doc, 'A', 100, 100, 1, base=(-50, -50, 60))])
+  make.makeSimulationSettings(doc, DistanceTolerance=tol)
+  src = make.makePointSource(doc, PowerDensity='1')
+  sc, lim = bake.bakeScene(doc, src), bake.bakeLimits(doc, src)
+  from freecad.optics_design_workbench_amd.scene import geometry
+  assert (sc.prim_flags[sc.prim_type == geometry.TRIANGLE] & 8).all() and (sc.prim_type == geometry.TRIANGLE).sum() > 50
+  got = _native.build_check(sc, lim, library=lib)
+  assert got['structure'] == 'wide-bvh' and got['primitives'] == len(sc.prim_type), got
 # the flat loop's limit moved: the same crowded scene on the other analytic structures
 os.environ['ODW_BVH_THRESHOLD'] = '4'
 sc, lim, _ = random_scenes.scene(np.random.RandomState(7), crowded=True)
