@@ -510,14 +510,20 @@ def parameterSweep(doc, setValue, values, *, rays, measure=calcFwhm, seed=DEFAUL
         finishGroup(None, ks_d, batch_d)
         continue
       if not did and order:
-        # nothing ready and nothing to launch: wait for the oldest chain's next piece
-        lane = order[0]
+        # nothing ready and nothing to launch: until ANY chain's next piece has arrived.  (Waiting for the oldest chain's
+        # piece blocks the thread while a younger chain's sample lies ready -- its plane search, its measure and the launch
+        # that needs its context all start late: sweeps of 65 instead of 59 ms, every other one, measured.)
         t_w = time.perf_counter()
-        if busy[lane]['batch']._stage == 'begun':
-          sampledGroups(wait_lane=lane)
+        if os.environ.get('ODW_SWEEP_WAIT_OLDEST') == '1':
+          lane = order[0]
+          if busy[lane]['batch']._stage == 'begun':
+            sampledGroups(wait_lane=lane)
+          else:
+            measuredGroups(wait_lane=lane)
         else:
-          measuredGroups(wait_lane=lane)
-        mark(f'wait {busy[lane]["ks"][0] if busy[lane] else ""}', t_w)
+          while not (measuredGroups() or sampledGroups()):
+            time.sleep(2e-5)
+        mark('wait', t_w)
 
   # Batch launches (Tracer.setSceneBatch / traceBatch): the values a context gets at a time are baked together and traced
   # by ONE launch -- their scenes differ in numbers only --, each into its own segment of the hit list; a measuring thread

@@ -27,6 +27,7 @@ doc.Sphere.Radius = float(radii[0])
 first = scenes.bakeProject(doc)
 tr.setScene(first.scene); tr.setLimits(first.limits)
 tr.compileScene('structure')
+traces = []
 for k in range(int(sys.argv[1]) if len(sys.argv) > 1 else 8):
   buf = io.StringIO()
   tr.sync(); torch.cuda.synchronize()
@@ -43,6 +44,10 @@ for k in range(int(sys.argv[1]) if len(sys.argv) > 1 else 8):
     if m:
       kinds[m.group(1)] += float(m.group(3)) - float(m.group(2))
       last = max(last, float(m.group(3)))
-  if k == 0:
-    print(buf.getvalue()[:1500])
+  traces.append((ms, buf.getvalue()))
   print(f'sweep {k}: {ms:6.1f} ms  last mark {last:6.1f}  ' + '  '.join(f'{a} {b:.1f}' for a, b in sorted(kinds.items())), flush=True)
+
+later = traces[2:]
+for label, (ms, text) in (('fastest', min(later)), ('slowest', max(later))):
+  print(f'---- {label}: {ms:.1f} ms')
+  print(text)
