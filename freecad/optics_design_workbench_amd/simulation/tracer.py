@@ -6,12 +6,29 @@ walks `ray.traceRay(store=store)` for each; here one `Tracer.trace(first, n,
 seed)` call does that for n rays on the GPU through the C-ABI and leaves hit
 rows, counters and the detector histogram in HBM until they are fetched.
 """
+import atexit
 import ctypes as C
+import weakref
 
 import numpy as np
 
 from .. import _native
 from .._native import CNT_NAMES, HIT_DTYPE, SEGMENT_DTYPE, TRACE_HISTOGRAM, TRACE_RECORD_HITS, TRACE_RECORD_SEGMENTS
+
+
+# Contexts that are still open when the interpreter ends are closed in ITS order, at the start of its shutdown (atexit),
+# while the HIP runtime and every module are whole -- not whenever the garbage collector reaches their Tracer during
+# module teardown
+_LIVE = weakref.WeakSet()
+
+
+@atexit.register
+def _close_live_tracers():
+  for t in list(_LIVE):
+    try:
+      t.close()
+    except Exception:
+      pass
 
 
 class _CudaArrayView:
@@ -117,6 +134,7 @@ class Tracer:
     self._ctx = C.c_void_p()
     self.device = int(device)
     _native.check(None, self._lib.odw_create(self.device, C.byref(self._ctx)), 'odw_create')
+    _LIVE.add(self)
     self._det = None
     self._keep = {}
     # ODW_COMPILE=structure: every tracer of the process compiles its scenes (test campaigns)
